@@ -1,0 +1,670 @@
+/*
+ * splat_oracle.c -- CPU restatement of the GPS-SLAM `ges` splat path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (gps_slam_amd/) may
+ * include, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference owns no tests, fixtures or golden vectors for
+ * this path and its implementation is CUDA-only (cannot run here), so this
+ * restatement is pinned only by (i) line-by-line reading of the cited CUDA
+ * sources and (ii) the autograd / finite-difference cross-checks in
+ * tests/test_oracle_splat.py.
+ *
+ * Plain scalar fp32 C, compiled with -ffp-contract=off.  Every function cites
+ * the reference file:line (relative to /root/reference) it restates.
+ * Matrices here are ROW-major float[9] (m[3*r+c]); the reference uses glm
+ * (column-major) -- the summation order of every 3-term product follows glm's
+ * left-to-right order so that results agree to rounding.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---------- small dense helpers ---------- */
+static void m3_mul(const float *A, const float *B, float *C) { /* C = A*B */
+    float T[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            T[3 * r + c] = A[3 * r + 0] * B[0 + c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+    memcpy(C, T, sizeof(T));
+}
+static void m3_T(const float *A, float *C) {
+    float T[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) T[3 * r + c] = A[3 * c + r];
+    memcpy(C, T, sizeof(T));
+}
+static void m3_add(const float *A, const float *B, float *C) {
+    for (int i = 0; i < 9; i++) C[i] = A[i] + B[i];
+}
+
+/* gsplat/rasterizer/utils.cuh:14-36  quat (wxyz, normalised in place) -> R */
+static void quat_to_rotmat(const float *q, float *R) {
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float inv_norm = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+    x *= inv_norm; y *= inv_norm; z *= inv_norm; w *= inv_norm;
+    float x2 = x * x, y2 = y * y, z2 = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.f - 2.f * (y2 + z2); R[1] = 2.f * (xy - wz);       R[2] = 2.f * (xz + wy);
+    R[3] = 2.f * (xy + wz);       R[4] = 1.f - 2.f * (x2 + z2); R[5] = 2.f * (yz - wx);
+    R[6] = 2.f * (xz - wy);       R[7] = 2.f * (yz + wx);       R[8] = 1.f - 2.f * (x2 + y2);
+}
+
+/* utils.cuh:38-62  v_R (row-major dL/dR) -> v_quat (accumulated) */
+static void quat_to_rotmat_vjp(const float *q, const float *vR, float *v_quat) {
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float inv_norm = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+    x *= inv_norm; y *= inv_norm; z *= inv_norm; w *= inv_norm;
+    /* glm v_R[c][r] == vR[3*r+c] */
+#define G(c, r) vR[3 * (r) + (c)]
+    float vqn[4];
+    vqn[0] = 2.f * (x * (G(1, 2) - G(2, 1)) + y * (G(2, 0) - G(0, 2)) + z * (G(0, 1) - G(1, 0)));
+    vqn[1] = 2.f * (-2.f * x * (G(1, 1) + G(2, 2)) + y * (G(0, 1) + G(1, 0)) + z * (G(0, 2) + G(2, 0)) +
+                    w * (G(1, 2) - G(2, 1)));
+    vqn[2] = 2.f * (x * (G(0, 1) + G(1, 0)) - 2.f * y * (G(0, 0) + G(2, 2)) + z * (G(1, 2) + G(2, 1)) +
+                    w * (G(2, 0) - G(0, 2)));
+    vqn[3] = 2.f * (x * (G(0, 2) + G(2, 0)) + y * (G(1, 2) + G(2, 1)) - 2.f * z * (G(0, 0) + G(1, 1)) +
+                    w * (G(0, 1) - G(1, 0)));
+#undef G
+    float qn[4] = {w, x, y, z};
+    float d = vqn[0] * qn[0] + vqn[1] * qn[1] + vqn[2] * qn[2] + vqn[3] * qn[3];
+    for (int i = 0; i < 4; i++) v_quat[i] += (vqn[i] - d * qn[i]) * inv_norm;
+}
+
+/* utils.cuh:64-96  covar = (R S)(R S)^T */
+static void quat_scale_to_covar(const float *q, const float *s, float *covar) {
+    float R[9], M[9], Mt[9];
+    quat_to_rotmat(q, R);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) M[3 * r + c] = R[3 * r + c] * s[c];
+    m3_T(M, Mt);
+    m3_mul(M, Mt, covar);
+}
+
+/* utils.cuh:253-292  pinhole projection of mean + covariance, with fov clamp */
+static void persp_proj(const float *mc, const float *cov3, float fx, float fy, float cx, float cy, uint32_t W,
+                       uint32_t H, float *cov2 /*[4] row-major 2x2*/, float *m2) {
+    float x = mc[0], y = mc[1], z = mc[2];
+    float tan_fovx = 0.5f * W / fx, tan_fovy = 0.5f * H / fy;
+    float lim_x_pos = (W - cx) / fx + 0.3f * tan_fovx;
+    float lim_x_neg = cx / fx + 0.3f * tan_fovx;
+    float lim_y_pos = (H - cy) / fy + 0.3f * tan_fovy;
+    float lim_y_neg = cy / fy + 0.3f * tan_fovy;
+    float rz = 1.f / z, rz2 = rz * rz;
+    float tx = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, x * rz));
+    float ty = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, y * rz));
+    /* J rows: [fx*rz, 0, -fx*tx*rz2], [0, fy*rz, -fy*ty*rz2] */
+    float J[6] = {fx * rz, 0.f, -fx * tx * rz2, 0.f, fy * rz, -fy * ty * rz2};
+    float JC[6]; /* J * cov3 (2x3) */
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 3; c++)
+            JC[3 * r + c] = J[3 * r + 0] * cov3[0 + c] + J[3 * r + 1] * cov3[3 + c] + J[3 * r + 2] * cov3[6 + c];
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++)
+            cov2[2 * r + c] = JC[3 * r + 0] * J[3 * c + 0] + JC[3 * r + 1] * J[3 * c + 1] + JC[3 * r + 2] * J[3 * c + 2];
+    m2[0] = fx * x * rz + cx;
+    m2[1] = fy * y * rz + cy;
+}
+
+/*
+ * gsplat/rasterizer/fully_fused_projection_fwd.cu:20-194 (PINHOLE, quats+scales,
+ * C = 1, no compensations).  Outputs where radii==0 are left untouched (the
+ * reference leaves them uninitialised).
+ */
+ORC_API void orc_proj_fwd(int N, const float *means, const float *quats, const float *scales, const float *viewmat,
+                          const float *K, int W, int H, float eps2d, float near_plane, float far_plane,
+                          float radius_clip, int32_t *radii, float *means2d, float *depths, float *conics) {
+    float R[9] = {viewmat[0], viewmat[1], viewmat[2], viewmat[4], viewmat[5], viewmat[6], viewmat[8], viewmat[9], viewmat[10]};
+    float t[3] = {viewmat[3], viewmat[7], viewmat[11]};
+    float Rt[9];
+    m3_T(R, Rt);
+    for (int i = 0; i < N; i++) {
+        const float *p = means + 3 * i;
+        float mc[3];
+        for (int r = 0; r < 3; r++) mc[r] = R[3 * r] * p[0] + R[3 * r + 1] * p[1] + R[3 * r + 2] * p[2] + t[r];
+        if (mc[2] < near_plane || mc[2] > far_plane) { radii[i] = 0; continue; }
+        float covar[9], tmp[9], covar_c[9];
+        quat_scale_to_covar(quats + 4 * i, scales + 3 * i, covar);
+        m3_mul(R, covar, tmp);
+        m3_mul(tmp, Rt, covar_c);
+        float c2[4], m2[2];
+        persp_proj(mc, covar_c, K[0], K[4], K[2], K[5], (uint32_t)W, (uint32_t)H, c2, m2);
+        /* add_blur utils.cuh:601-608 */
+        c2[0] += eps2d; c2[3] += eps2d;
+        float det = c2[0] * c2[3] - c2[1] * c2[2];
+        if (det <= 0.f) { radii[i] = 0; continue; }
+        float invDet = 1.f / det; /* inverse utils.cuh:580-592 */
+        float i00 = c2[3] * invDet, i01 = -c2[1] * invDet, i11 = c2[0] * invDet;
+        float b = 0.5f * (c2[0] + c2[3]);
+        float v1 = b + sqrtf(fmaxf(0.01f, b * b - det));
+        float radius = ceilf(3.f * sqrtf(v1));
+        if (radius <= radius_clip) { radii[i] = 0; continue; }
+        if (m2[0] + radius <= 0 || m2[0] - radius >= W || m2[1] + radius <= 0 || m2[1] - radius >= H) {
+            radii[i] = 0; continue;
+        }
+        radii[i] = (int32_t)radius;
+        means2d[2 * i] = m2[0]; means2d[2 * i + 1] = m2[1];
+        depths[i] = mc[2];
+        conics[3 * i] = i00; conics[3 * i + 1] = i01; conics[3 * i + 2] = i11;
+    }
+}
+
+/*
+ * gsplat/rasterizer/fully_fused_projection_bwd.cu:21-286 (PINHOLE, quats+scales,
+ * C = 1, no compensations, no viewmat grad).  v_* outputs must be zeroed by the
+ * caller (the reference uses zeros_like + atomicAdd).
+ */
+ORC_API void orc_proj_bwd(int N, const float *means, const float *quats, const float *scales, const float *viewmat,
+                          const float *K, int W, int H, const int32_t *radii, const float *conics,
+                          const float *v_means2d, const float *v_depths, const float *v_conics, float *v_means,
+                          float *v_quats, float *v_scales) {
+    float R[9] = {viewmat[0], viewmat[1], viewmat[2], viewmat[4], viewmat[5], viewmat[6], viewmat[8], viewmat[9], viewmat[10]};
+    float t[3] = {viewmat[3], viewmat[7], viewmat[11]};
+    float Rt[9];
+    m3_T(R, Rt);
+    float fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    for (int i = 0; i < N; i++) {
+        if (radii[i] <= 0) continue;
+        /* inverse_vjp utils.cuh:594-599: v_M = -P * v_P * P with P = conic (sym 2x2) */
+        float P[4] = {conics[3 * i], conics[3 * i + 1], conics[3 * i + 1], conics[3 * i + 2]};
+        float vP[4] = {v_conics[3 * i], v_conics[3 * i + 1] * .5f, v_conics[3 * i + 1] * .5f, v_conics[3 * i + 2]};
+        float nP[4] = {-P[0], -P[1], -P[2], -P[3]};
+        float A[4], vC2[4];
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 2; c++) A[2 * r + c] = nP[2 * r] * vP[c] + nP[2 * r + 1] * vP[2 + c];
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 2; c++) vC2[2 * r + c] = A[2 * r] * P[c] + A[2 * r + 1] * P[2 + c];
+
+        const float *p = means + 3 * i;
+        const float *q = quats + 4 * i;
+        const float *s = scales + 3 * i;
+        float mc[3];
+        for (int r = 0; r < 3; r++) mc[r] = R[3 * r] * p[0] + R[3 * r + 1] * p[1] + R[3 * r + 2] * p[2] + t[r];
+        float covar[9], tmp[9], covar_c[9];
+        quat_scale_to_covar(q, s, covar);
+        m3_mul(R, covar, tmp);
+        m3_mul(tmp, Rt, covar_c);
+
+        /* persp_proj_vjp utils.cuh:295-372 */
+        float x = mc[0], y = mc[1], z = mc[2];
+        float tan_fovx = 0.5f * (uint32_t)W / fx, tan_fovy = 0.5f * (uint32_t)H / fy;
+        float lim_x_pos = ((uint32_t)W - cx) / fx + 0.3f * tan_fovx;
+        float lim_x_neg = cx / fx + 0.3f * tan_fovx;
+        float lim_y_pos = ((uint32_t)H - cy) / fy + 0.3f * tan_fovy;
+        float lim_y_neg = cy / fy + 0.3f * tan_fovy;
+        float rz = 1.f / z, rz2 = rz * rz;
+        float tx = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, x * rz));
+        float ty = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, y * rz));
+        float J[6] = {fx * rz, 0.f, -fx * tx * rz2, 0.f, fy * rz, -fy * ty * rz2};
+        /* v_cov3d = J^T * v_cov2d * J */
+        float JtV[6]; /* 3x2 */
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 2; c++) JtV[2 * r + c] = J[r] * vC2[c] + J[3 + r] * vC2[2 + c];
+        float v_covar_c[9];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) v_covar_c[3 * r + c] = JtV[2 * r] * J[c] + JtV[2 * r + 1] * J[3 + c];
+        float vm2x = v_means2d[2 * i], vm2y = v_means2d[2 * i + 1];
+        float v_mc[3] = {fx * rz * vm2x, fy * rz * vm2y, -(fx * x * vm2x + fy * y * vm2y) * rz2};
+        /* v_J = v_cov2d * J * cov3d^T + v_cov2d^T * J * cov3d   (2x3) */
+        float rz3 = rz2 * rz;
+        float VJ[6], VtJ[6], vJ[6];
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 3; c++) {
+                VJ[3 * r + c] = vC2[2 * r] * J[c] + vC2[2 * r + 1] * J[3 + c];
+                VtJ[3 * r + c] = vC2[r] * J[c] + vC2[2 + r] * J[3 + c];
+            }
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 3; c++) {
+                float a = VJ[3 * r] * covar_c[3 * c] + VJ[3 * r + 1] * covar_c[3 * c + 1] + VJ[3 * r + 2] * covar_c[3 * c + 2];
+                float b = VtJ[3 * r] * covar_c[c] + VtJ[3 * r + 1] * covar_c[3 + c] + VtJ[3 * r + 2] * covar_c[6 + c];
+                vJ[3 * r + c] = a + b;
+            }
+        /* glm v_J[2][0] == vJ[0*3+2], v_J[2][1] == vJ[1*3+2], v_J[0][0]==vJ[0], v_J[1][1]==vJ[4] */
+        if (x * rz <= lim_x_pos && x * rz >= -lim_x_neg) v_mc[0] += -fx * rz2 * vJ[2];
+        else v_mc[2] += -fx * rz3 * vJ[2] * tx;
+        if (y * rz <= lim_y_pos && y * rz >= -lim_y_neg) v_mc[1] += -fy * rz2 * vJ[5];
+        else v_mc[2] += -fy * rz3 * vJ[5] * ty;
+        v_mc[2] += -fx * rz2 * vJ[0] - fy * rz2 * vJ[4] + 2.f * fx * tx * rz3 * vJ[2] + 2.f * fy * ty * rz3 * vJ[5];
+
+        v_mc[2] += v_depths[i]; /* fully_fused_projection_bwd.cu:193 */
+
+        /* pos_world_to_cam_vjp utils.cuh:531-546: v_p = R^T v_mc */
+        for (int r = 0; r < 3; r++)
+            v_means[3 * i + r] += Rt[3 * r] * v_mc[0] + Rt[3 * r + 1] * v_mc[1] + Rt[3 * r + 2] * v_mc[2];
+        /* covar_world_to_cam_vjp utils.cuh:559-578: v_covar = R^T v_covar_c R */
+        float v_covar[9];
+        m3_mul(Rt, v_covar_c, tmp);
+        m3_mul(tmp, R, v_covar);
+
+        /* quat_scale_to_covar_vjp utils.cuh:99-136 */
+        float Rq[9], S[9] = {s[0], 0, 0, 0, s[1], 0, 0, 0, s[2]}, M[9], vct[9], sym[9], v_M[9], v_Rq[9];
+        quat_to_rotmat(q, Rq);
+        m3_mul(Rq, S, M);
+        m3_T(v_covar, vct);
+        m3_add(v_covar, vct, sym);
+        m3_mul(sym, M, v_M);
+        m3_mul(v_M, S, v_Rq);
+        quat_to_rotmat_vjp(q, v_Rq, v_quats + 4 * i);
+        /* glm R[c][r] * v_M[c][r] summed over r: column c */
+        for (int c = 0; c < 3; c++)
+            v_scales[3 * i + c] += Rq[0 + c] * v_M[0 + c] + Rq[3 + c] * v_M[3 + c] + Rq[6 + c] * v_M[6 + c];
+    }
+}
+
+/* ---------- spherical harmonics ---------- */
+/*
+ * gsplat/rasterizer/spherical_harmonics.cuh:17-105 (Sloan 2013 fast SH eval),
+ * driver compute_sh_fwd.cu:12-38.  coeffs [N,K,3], dirs [N,3], masks [N] (may
+ * be NULL), colors [N,3].  Masked-out rows are not written.
+ */
+static void sh_basis(int degree, const float *dir, float *Y /*[25]*/, float *xyz, float *inorm_out) {
+    float inorm = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    float x = dir[0] * inorm, y = dir[1] * inorm, z = dir[2] * inorm;
+    xyz[0] = x; xyz[1] = y; xyz[2] = z; *inorm_out = inorm;
+    Y[0] = 0.2820947917738781f;
+    if (degree < 1) return;
+    Y[1] = -0.48860251190292f * y; Y[2] = 0.48860251190292f * z; Y[3] = -0.48860251190292f * x;
+    if (degree < 2) return;
+    float z2 = z * z;
+    float fTmp0B = -1.092548430592079f * z;
+    float fC1 = x * x - y * y, fS1 = 2.f * x * y;
+    Y[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    Y[7] = fTmp0B * x; Y[5] = fTmp0B * y;
+    Y[8] = 0.5462742152960395f * fC1; Y[4] = 0.5462742152960395f * fS1;
+    if (degree < 3) return;
+    float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float fTmp1B = 1.445305721320277f * z;
+    float fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
+    Y[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    Y[13] = fTmp0C * x; Y[11] = fTmp0C * y;
+    Y[14] = fTmp1B * fC1; Y[10] = fTmp1B * fS1;
+    Y[15] = -0.5900435899266435f * fC2; Y[9] = -0.5900435899266435f * fS2;
+    if (degree < 4) return;
+    float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+    float fTmp2B = -1.770130769779931f * z;
+    float fC3 = x * fC2 - y * fS2, fS3 = x * fS2 + y * fC2;
+    Y[20] = 1.984313483298443f * z * Y[12] - 1.006230589874905f * Y[6];
+    Y[21] = fTmp0D * x; Y[19] = fTmp0D * y;
+    Y[22] = fTmp1C * fC1; Y[18] = fTmp1C * fS1;
+    Y[23] = fTmp2B * fC2; Y[17] = fTmp2B * fS2;
+    Y[24] = 0.6258357354491763f * fC3; Y[16] = 0.6258357354491763f * fS3;
+}
+
+static const int SH_NB[5] = {1, 4, 9, 16, 25};
+
+ORC_API void orc_sh_fwd(int N, int K, int degree, const float *dirs, const float *coeffs, const uint8_t *masks,
+                        float *colors) {
+    for (int i = 0; i < N; i++) {
+        if (masks && !masks[i]) continue;
+        float Y[25], xyz[3], inorm;
+        sh_basis(degree, dirs + 3 * i, Y, xyz, &inorm);
+        const float *cf = coeffs + (size_t)i * K * 3;
+        for (int c = 0; c < 3; c++) {
+            /* summation grouped per band as in spherical_harmonics.cuh:26-100 */
+            float result = Y[0] * cf[c];
+            if (degree >= 1) /* :34-36 keeps the common factor outside the bracket */
+                result += 0.48860251190292f * (-xyz[1] * cf[3 + c] + xyz[2] * cf[6 + c] - xyz[0] * cf[9 + c]);
+            if (degree >= 2) {
+                float band = 0.f;
+                for (int k = 4; k < 9; k++) band = (k == 4) ? Y[k] * cf[3 * k + c] : band + Y[k] * cf[3 * k + c];
+                result += band;
+            }
+            if (degree >= 3) {
+                float band = 0.f;
+                for (int k = 9; k < 16; k++) band = (k == 9) ? Y[k] * cf[3 * k + c] : band + Y[k] * cf[3 * k + c];
+                result += band;
+            }
+            if (degree >= 4) {
+                float band = 0.f;
+                for (int k = 16; k < 25; k++) band = (k == 16) ? Y[k] * cf[3 * k + c] : band + Y[k] * cf[3 * k + c];
+                result += band;
+            }
+            colors[3 * i + c] = result;
+        }
+    }
+}
+
+/*
+ * spherical_harmonics.cuh:108-366 + compute_sh_bwd.cu:14-54.  v_coeffs [N,K,3]
+ * must be zeroed by the caller (reference: zeros + plain write of the used
+ * bands); v_dirs [N,3] (may be NULL) is accumulated over the 3 channels.
+ * Analytic d(basis)/d(x,y,z) of the same polynomials, then projection onto the
+ * tangent space of the unit sphere and division by |dir| (:138-146,...).
+ */
+ORC_API void orc_sh_bwd(int N, int K, int degree, const float *dirs, const float *coeffs, const uint8_t *masks,
+                        const float *v_colors, float *v_coeffs, float *v_dirs) {
+    for (int i = 0; i < N; i++) {
+        if (masks && !masks[i]) continue;
+        float Y[25], xyz[3], inorm;
+        sh_basis(degree, dirs + 3 * i, Y, xyz, &inorm);
+        float x = xyz[0], y = xyz[1], z = xyz[2];
+        int nb = SH_NB[degree];
+        /* basis derivatives wrt normalised (x,y,z) */
+        float dX[25] = {0}, dY[25] = {0}, dZ[25] = {0};
+        if (degree >= 1) { dY[1] = -0.48860251190292f; dZ[2] = 0.48860251190292f; dX[3] = -0.48860251190292f; }
+        float z2 = z * z, fC1 = x * x - y * y, fS1 = 2.f * x * y;
+        float fC1_x = 2.f * x, fC1_y = -2.f * y, fS1_x = 2.f * y, fS1_y = 2.f * x;
+        float fC2 = 0, fS2 = 0, fC2_x = 0, fC2_y = 0, fS2_x = 0, fS2_y = 0, pSH12_z = 0, pSH6_z = 0;
+        if (degree >= 2) {
+            float fTmp0B = -1.092548430592079f * z, fTmp0B_z = -1.092548430592079f;
+            pSH6_z = 2.f * 0.9461746957575601f * z;
+            dZ[6] = pSH6_z;
+            dX[7] = fTmp0B; dZ[7] = fTmp0B_z * x;
+            dY[5] = fTmp0B; dZ[5] = fTmp0B_z * y;
+            dX[8] = 0.5462742152960395f * fC1_x; dY[8] = 0.5462742152960395f * fC1_y;
+            dX[4] = 0.5462742152960395f * fS1_x; dY[4] = 0.5462742152960395f * fS1_y;
+        }
+        if (degree >= 3) {
+            float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+            float fTmp1B = 1.445305721320277f * z;
+            float fTmp0C_z = -2.285228997322329f * 2.f * z, fTmp1B_z = 1.445305721320277f;
+            fC2 = x * fC1 - y * fS1; fS2 = x * fS1 + y * fC1;
+            fC2_x = fC1 + x * fC1_x - y * fS1_x; fC2_y = x * fC1_y - fS1 - y * fS1_y;
+            fS2_x = fS1 + x * fS1_x + y * fC1_x; fS2_y = x * fS1_y + fC1 + y * fC1_y;
+            pSH12_z = 3.f * 1.865881662950577f * z2 - 1.119528997770346f;
+            dZ[12] = pSH12_z;
+            dX[13] = fTmp0C; dZ[13] = fTmp0C_z * x;
+            dY[11] = fTmp0C; dZ[11] = fTmp0C_z * y;
+            dX[14] = fTmp1B * fC1_x; dY[14] = fTmp1B * fC1_y; dZ[14] = fTmp1B_z * fC1;
+            dX[10] = fTmp1B * fS1_x; dY[10] = fTmp1B * fS1_y; dZ[10] = fTmp1B_z * fS1;
+            dX[15] = -0.5900435899266435f * fC2_x; dY[15] = -0.5900435899266435f * fC2_y;
+            dX[9] = -0.5900435899266435f * fS2_x; dY[9] = -0.5900435899266435f * fS2_y;
+        }
+        if (degree >= 4) {
+            float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+            float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+            float fTmp2B = -1.770130769779931f * z;
+            float fTmp0D_z = 3.f * -4.683325804901025f * z2 + 2.007139630671868f;
+            float fTmp1C_z = 2.f * 3.31161143515146f * z, fTmp2B_z = -1.770130769779931f;
+            float fC3_x = fC2 + x * fC2_x - y * fS2_x, fC3_y = x * fC2_y - fS2 - y * fS2_y;
+            float fS3_x = fS2 + y * fC2_x + x * fS2_x, fS3_y = x * fS2_y + fC2 + y * fC2_y;
+            dZ[20] = 1.984313483298443f * (Y[12] + z * pSH12_z) + -1.006230589874905f * pSH6_z;
+            dX[21] = fTmp0D; dZ[21] = fTmp0D_z * x;
+            dY[19] = fTmp0D; dZ[19] = fTmp0D_z * y;
+            dX[22] = fTmp1C * fC1_x; dY[22] = fTmp1C * fC1_y; dZ[22] = fTmp1C_z * fC1;
+            dX[18] = fTmp1C * fS1_x; dY[18] = fTmp1C * fS1_y; dZ[18] = fTmp1C_z * fS1;
+            dX[23] = fTmp2B * fC2_x; dY[23] = fTmp2B * fC2_y; dZ[23] = fTmp2B_z * fC2;
+            dX[17] = fTmp2B * fS2_x; dY[17] = fTmp2B * fS2_y; dZ[17] = fTmp2B_z * fS2;
+            dX[24] = 0.6258357354491763f * fC3_x; dY[24] = 0.6258357354491763f * fC3_y;
+            dX[16] = 0.6258357354491763f * fS3_x; dY[16] = 0.6258357354491763f * fS3_y;
+        }
+        const float *cf = coeffs + (size_t)i * K * 3;
+        float *vcf = v_coeffs + (size_t)i * K * 3;
+        float vdir[3] = {0, 0, 0};
+        for (int c = 0; c < 3; c++) {
+            float vc = v_colors[3 * i + c];
+            for (int k = 0; k < nb; k++) vcf[3 * k + c] = Y[k] * vc;
+            if (v_dirs && degree >= 1) {
+                float vx = 0, vy = 0, vz = 0;
+                for (int k = 1; k < nb; k++) {
+                    vx += dX[k] * cf[3 * k + c];
+                    vy += dY[k] * cf[3 * k + c];
+                    vz += dZ[k] * cf[3 * k + c];
+                }
+                vx *= vc; vy *= vc; vz *= vc;
+                float d = vx * x + vy * y + vz * z;
+                vdir[0] += (vx - d * x) * inorm;
+                vdir[1] += (vy - d * y) * inorm;
+                vdir[2] += (vz - d * z) * inorm;
+            }
+        }
+        if (v_dirs) { v_dirs[3 * i] += vdir[0]; v_dirs[3 * i + 1] += vdir[1]; v_dirs[3 * i + 2] += vdir[2]; }
+    }
+}
+
+/* ---------- tile binning (no depth) ---------- */
+static uint32_t sat_u32(float v) { /* CUDA float->uint32 conversion saturates; C is UB for negatives */
+    if (!(v > 0.f)) return 0u;
+    if (v >= 4294967296.f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+static void tile_bbox(const float *m2, int32_t radius_i, uint32_t tile_size, uint32_t tw, uint32_t th, uint32_t *mn,
+                      uint32_t *mx) {
+    /* isect_tiles_no_depth.cu:68-80 */
+    float radius = (float)radius_i;
+    float tile_radius = radius / (float)tile_size;
+    float tile_x = m2[0] / (float)tile_size, tile_y = m2[1] / (float)tile_size;
+    uint32_t a;
+    a = sat_u32(floorf(tile_x - tile_radius)); mn[0] = a < tw ? a : tw;
+    a = sat_u32(floorf(tile_y - tile_radius)); mn[1] = a < th ? a : th;
+    a = sat_u32(ceilf(tile_x + tile_radius)); mx[0] = a < tw ? a : tw;
+    a = sat_u32(ceilf(tile_y + tile_radius)); mx[1] = a < th ? a : th;
+}
+
+/* pass 1: isect_tiles_no_depth.cu:57-93.  Returns n_isects via *n_isects and n_groups via *n_groups. */
+ORC_API void orc_isect_count(int N, const float *means2d, const int32_t *radii, int tile_size, int tw, int th,
+                             int32_t *tiles_per_gauss, int32_t *groups_per_gauss, int64_t *n_isects,
+                             int64_t *n_groups) {
+    int64_t ni = 0, ng = 0;
+    for (int i = 0; i < N; i++) {
+        if (radii[i] <= 0) { tiles_per_gauss[i] = 0; groups_per_gauss[i] = 0; continue; }
+        uint32_t mn[2], mx[2];
+        tile_bbox(means2d + 2 * i, radii[i], (uint32_t)tile_size, (uint32_t)tw, (uint32_t)th, mn, mx);
+        tiles_per_gauss[i] = (int32_t)((mx[1] - mn[1]) * (mx[0] - mn[0]));
+        float radius = (float)radii[i];
+        groups_per_gauss[i] = (int32_t)((4 * radius * radius + 32 - 1) / 32);
+        ni += tiles_per_gauss[i];
+        ng += groups_per_gauss[i];
+    }
+    *n_isects = ni; *n_groups = ng;
+}
+
+/*
+ * pass 2 + stable sort by tile id + offset encode:
+ * isect_tiles_no_depth.cu:95-129, 313-327 (cub stable LSD radix sort over the
+ * tile bits), 373-425.  isect_ids/flatten_ids are returned SORTED.
+ * offsets [th*tw].
+ */
+ORC_API void orc_isect_fill_sort(int N, const float *means2d, const int32_t *radii, int tile_size, int tw, int th,
+                                 const int32_t *groups_per_gauss, int64_t n_isects, int64_t n_groups,
+                                 int64_t *isect_ids, int32_t *flatten_ids, int32_t *group_gs_ids,
+                                 int32_t *group_starts, int32_t *offsets) {
+    int n_tiles = tw * th;
+    int64_t *ids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_isects > 0 ? n_isects : 1));
+    int32_t *flat = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_isects > 0 ? n_isects : 1));
+    int64_t cur = 0, gcur = 0;
+    for (int i = 0; i < N; i++) {
+        if (radii[i] <= 0) continue;
+        uint32_t mn[2], mx[2];
+        tile_bbox(means2d + 2 * i, radii[i], (uint32_t)tile_size, (uint32_t)tw, (uint32_t)th, mn, mx);
+        for (int32_t ty = (int32_t)mn[1]; ty < (int32_t)mx[1]; ++ty)
+            for (int32_t tx = (int32_t)mn[0]; tx < (int32_t)mx[0]; ++tx) {
+                ids[cur] = (int64_t)ty * tw + tx;
+                flat[cur] = i;
+                ++cur;
+            }
+        for (int g = 0; g < groups_per_gauss[i]; g++) {
+            group_gs_ids[gcur + g] = i;
+            group_starts[gcur + g] = (int32_t)gcur;
+        }
+        gcur += groups_per_gauss[i];
+    }
+    (void)n_groups;
+    /* stable counting sort by tile id */
+    int64_t *cnt = (int64_t *)calloc((size_t)n_tiles + 1, sizeof(int64_t));
+    for (int64_t k = 0; k < n_isects; k++) cnt[ids[k] + 1]++;
+    for (int t = 0; t < n_tiles; t++) cnt[t + 1] += cnt[t];
+    for (int t = 0; t < n_tiles; t++) offsets[t] = (int32_t)cnt[t];
+    for (int64_t k = 0; k < n_isects; k++) {
+        int64_t pos = cnt[ids[k]]++;
+        isect_ids[pos] = ids[k];
+        flatten_ids[pos] = flat[k];
+    }
+    free(cnt); free(ids); free(flat);
+}
+
+/* ---------- ges rasterizer ---------- */
+/*
+ * gsplat/rasterizer/rasterize_to_pixels_fwd_ges.cu:18-221, COLOR_DIM = 4
+ * (rgb + depth; channel 3 is the Gaussian's camera depth, :165-167).
+ * Per pixel, Gaussians of the tile are visited in sorted (ascending index)
+ * order.  Outputs: render_colors [H,W,4], render_alphas(weight_sum) [H,W],
+ * last_ids [H,W].
+ */
+ORC_API void orc_raster_ges_fwd(int W, int H, int tile_size, int tw, int th, int64_t n_isects, float delta_depth,
+                                const float *means2d, const float *conics, const float *colors /*[N,4]*/,
+                                const float *opacities, const float *ref_depth, const int32_t *tile_offsets,
+                                const int32_t *flatten_ids, float *render_colors, float *render_alphas,
+                                int32_t *last_ids) {
+    for (int ty = 0; ty < th; ty++)
+        for (int tx = 0; tx < tw; tx++) {
+            int tile_id = ty * tw + tx;
+            int32_t rs = tile_offsets[tile_id];
+            int32_t re = (tile_id == tw * th - 1) ? (int32_t)n_isects : tile_offsets[tile_id + 1];
+            for (int ly = 0; ly < tile_size; ly++)
+                for (int lx = 0; lx < tile_size; lx++) {
+                    int i = ty * tile_size + ly, j = tx * tile_size + lx;
+                    if (i >= H || j >= W) continue;
+                    float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                    int pix = i * W + j;
+                    float rd = ref_depth[pix];
+                    float out[4] = {0, 0, 0, 0}, wsum = 0.f;
+                    uint32_t cur_idx = 0;
+                    for (int32_t k = rs; k < re; k++) {
+                        int32_t g = flatten_ids[k];
+                        const float *c = colors + 4 * (size_t)g;
+                        if (c[3] > rd + delta_depth) continue;
+                        float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                        float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                        float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                        float alpha = fminf(0.999f, opacities[g] * expf(-sigma));
+                        if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+                        for (int q = 0; q < 4; q++) out[q] += c[q] * alpha;
+                        wsum += alpha;
+                        cur_idx = (uint32_t)k;
+                    }
+                    render_alphas[pix] = wsum;
+                    for (int q = 0; q < 4; q++) render_colors[4 * pix + q] = out[q];
+                    last_ids[pix] = (int32_t)cur_idx;
+                }
+        }
+}
+
+/*
+ * gsplat/rasterizer/rasterize_to_pixels_bwd_ges_new_parallel.cu:18-201
+ * (Gaussian-parallel backward over the 2r x 2r integer box, :83-96).
+ * Each 32-pixel group is reduced in fp32 in lane order, then added to the
+ * Gaussian's gradient (the reference uses a warp tree-reduce + atomicAdd, so
+ * summation order differs at the ulp level by construction).
+ * v_* outputs must be zeroed by the caller.
+ */
+ORC_API void orc_raster_ges_bwd_gs(int W, int H, int64_t n_groups, float delta_depth, const int32_t *group_gs_ids,
+                                   const int32_t *group_starts, const float *means2d, const float *conics,
+                                   const float *colors, const float *opacities, const int32_t *radiis,
+                                   const float *ref_depth, const float *v_render_colors,
+                                   const float *v_render_alphas, float *v_means2d, float *v_conics,
+                                   float *v_colors, float *v_opacities) {
+    for (int64_t gid = 0; gid < n_groups; gid++) {
+        int32_t g = group_gs_ids[gid];
+        int32_t r = radiis[g];
+        float x = means2d[2 * g], y = means2d[2 * g + 1];
+        float opac = opacities[g];
+        float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+        float rgb[4];
+        for (int q = 0; q < 4; q++) rgb[q] = colors[4 * (size_t)g + q];
+        int32_t x_min = (int32_t)x - r, x_max = (int32_t)x + r;
+        int32_t y_min = (int32_t)y - r, y_max = (int32_t)y + r;
+        uint32_t gstart = (uint32_t)group_starts[gid];
+        float a_rgb[4] = {0, 0, 0, 0}, a_conic[3] = {0, 0, 0}, a_xy[2] = {0, 0}, a_op = 0.f;
+        int any = 0;
+        for (uint32_t lane = 0; lane < 32; lane++) {
+            uint32_t pid = ((uint32_t)gid - gstart) * 32u + lane;
+            int32_t j = x_min + 1 + (int32_t)(pid % (uint32_t)(x_max - x_min));
+            int32_t i = y_min + 1 + (int32_t)(pid / (uint32_t)(x_max - x_min));
+            int valid = (i < H && j < W && i >= 0 && j >= 0);
+            if (i > y_max) valid = 0;
+            if (!valid) continue;
+            int pix = i * W + j;
+            float rd = ref_depth[pix];
+            float px = (float)j + 0.5f, py = (float)i + 0.5f;
+            float dx = x - px, dy = y - py;
+            float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+            float vis = expf(-sigma);
+            float alpha = fminf(0.999f, opac * vis);
+            if (sigma < 0.f || alpha < 1.f / 255.f || rgb[3] > rd + delta_depth) continue;
+            any = 1;
+            float v_alpha = 0.f;
+            for (int q = 0; q < 4; q++) {
+                float vc = v_render_colors[4 * pix + q];
+                a_rgb[q] += alpha * vc;
+                v_alpha += rgb[q] * vc;
+            }
+            v_alpha += v_render_alphas[pix];
+            if (opac * vis <= 0.999f) {
+                float v_sigma = -opac * vis * v_alpha;
+                a_conic[0] += 0.5f * v_sigma * dx * dx;
+                a_conic[1] += v_sigma * dx * dy;
+                a_conic[2] += 0.5f * v_sigma * dy * dy;
+                a_xy[0] += v_sigma * (ca * dx + cb * dy);
+                a_xy[1] += v_sigma * (cb * dx + cc * dy);
+                a_op += vis * v_alpha;
+            }
+        }
+        if (!any) continue;
+        for (int q = 0; q < 4; q++) v_colors[4 * (size_t)g + q] += a_rgb[q];
+        for (int q = 0; q < 3; q++) v_conics[3 * g + q] += a_conic[q];
+        v_means2d[2 * g] += a_xy[0]; v_means2d[2 * g + 1] += a_xy[1];
+        v_opacities[g] += a_op;
+    }
+}
+
+/*
+ * Exact tile-parallel adjoint of the ges forward
+ * (gsplat/rasterizer/rasterize_to_pixels_bwd_ges.cu:164-291; unused by the
+ * shipped configs, kept as the mathematical reference for gradient tests).
+ */
+ORC_API void orc_raster_ges_bwd_exact(int W, int H, int tile_size, int tw, int th, int64_t n_isects,
+                                      float delta_depth, const float *means2d, const float *conics,
+                                      const float *colors, const float *opacities, const float *ref_depth,
+                                      const int32_t *tile_offsets, const int32_t *flatten_ids,
+                                      const float *v_render_colors, const float *v_render_alphas,
+                                      float *v_means2d, float *v_conics, float *v_colors, float *v_opacities) {
+    for (int ty = 0; ty < th; ty++)
+        for (int tx = 0; tx < tw; tx++) {
+            int tile_id = ty * tw + tx;
+            int32_t rs = tile_offsets[tile_id];
+            int32_t re = (tile_id == tw * th - 1) ? (int32_t)n_isects : tile_offsets[tile_id + 1];
+            for (int ly = 0; ly < tile_size; ly++)
+                for (int lx = 0; lx < tile_size; lx++) {
+                    int i = ty * tile_size + ly, j = tx * tile_size + lx;
+                    if (i >= H || j >= W) continue;
+                    float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                    int pix = i * W + j;
+                    float rd = ref_depth[pix];
+                    for (int32_t k = rs; k < re; k++) {
+                        int32_t g = flatten_ids[k];
+                        const float *c = colors + 4 * (size_t)g;
+                        if (c[3] > rd + delta_depth) continue;
+                        float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                        float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                        float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                        float vis = expf(-sigma);
+                        float opac = opacities[g];
+                        float alpha = fminf(0.999f, opac * vis);
+                        if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+                        float v_alpha = 0.f;
+                        for (int q = 0; q < 4; q++) {
+                            float vc = v_render_colors[4 * pix + q];
+                            v_colors[4 * (size_t)g + q] += alpha * vc;
+                            v_alpha += c[q] * vc;
+                        }
+                        v_alpha += v_render_alphas[pix];
+                        if (opac * vis <= 0.999f) {
+                            float v_sigma = -opac * vis * v_alpha;
+                            v_conics[3 * g] += 0.5f * v_sigma * dx * dx;
+                            v_conics[3 * g + 1] += v_sigma * dx * dy;
+                            v_conics[3 * g + 2] += 0.5f * v_sigma * dy * dy;
+                            v_means2d[2 * g] += v_sigma * (ca * dx + cb * dy);
+                            v_means2d[2 * g + 1] += v_sigma * (cb * dx + cc * dy);
+                            v_opacities[g] += vis * v_alpha;
+                        }
+                    }
+                }
+        }
+}

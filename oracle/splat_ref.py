@@ -1,0 +1,157 @@
+"""ctypes front-end for oracle/liboracle_splat.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  numpy in, numpy out; every function mirrors one reference
+launcher (see splat_oracle.c for the file:line citations).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle_splat.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _HERE, so])
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle needs contiguous arrays"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def proj_fwd(means, quats, scales, viewmat, K, W, H, eps2d=0.3, near=0.01, far=1e10, radius_clip=0.0):
+    means, quats, scales, viewmat, K = map(_f32, (means, quats, scales, viewmat, K))
+    N = means.shape[0]
+    radii = np.zeros(N, np.int32)
+    means2d = np.zeros((N, 2), np.float32)
+    depths = np.zeros(N, np.float32)
+    conics = np.zeros((N, 3), np.float32)
+    _lib().orc_proj_fwd(C.c_int(N), _p(means), _p(quats), _p(scales), _p(viewmat), _p(K), C.c_int(W), C.c_int(H),
+                        C.c_float(eps2d), C.c_float(near), C.c_float(far), C.c_float(radius_clip), _p(radii),
+                        _p(means2d), _p(depths), _p(conics))
+    return radii, means2d, depths, conics
+
+
+def proj_bwd(means, quats, scales, viewmat, K, W, H, radii, conics, v_means2d, v_depths, v_conics):
+    means, quats, scales, viewmat, K, conics = map(_f32, (means, quats, scales, viewmat, K, conics))
+    v_means2d, v_depths, v_conics = map(_f32, (v_means2d, v_depths, v_conics))
+    radii = _i32(radii)
+    N = means.shape[0]
+    v_means = np.zeros((N, 3), np.float32)
+    v_quats = np.zeros((N, 4), np.float32)
+    v_scales = np.zeros((N, 3), np.float32)
+    _lib().orc_proj_bwd(C.c_int(N), _p(means), _p(quats), _p(scales), _p(viewmat), _p(K), C.c_int(W), C.c_int(H),
+                        _p(radii), _p(conics), _p(v_means2d), _p(v_depths), _p(v_conics), _p(v_means), _p(v_quats),
+                        _p(v_scales))
+    return v_means, v_quats, v_scales
+
+
+def sh_fwd(degree, dirs, coeffs, masks=None):
+    dirs, coeffs = _f32(dirs), _f32(coeffs)
+    N, K = coeffs.shape[0], coeffs.shape[1]
+    m = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint8)
+    colors = np.zeros((N, 3), np.float32)
+    _lib().orc_sh_fwd(C.c_int(N), C.c_int(K), C.c_int(degree), _p(dirs), _p(coeffs), _p(m), _p(colors))
+    return colors
+
+
+def sh_bwd(degree, dirs, coeffs, masks, v_colors, want_v_dirs=True):
+    dirs, coeffs, v_colors = _f32(dirs), _f32(coeffs), _f32(v_colors)
+    N, K = coeffs.shape[0], coeffs.shape[1]
+    m = None if masks is None else np.ascontiguousarray(masks, dtype=np.uint8)
+    v_coeffs = np.zeros((N, K, 3), np.float32)
+    v_dirs = np.zeros((N, 3), np.float32) if want_v_dirs else None
+    _lib().orc_sh_bwd(C.c_int(N), C.c_int(K), C.c_int(degree), _p(dirs), _p(coeffs), _p(m), _p(v_colors),
+                      _p(v_coeffs), _p(v_dirs))
+    return v_coeffs, v_dirs
+
+
+def isect_tiles(means2d, radii, tile_size, tw, th):
+    """-> tiles_per_gauss, isect_ids(sorted), flatten_ids(sorted), group_gs_ids, group_starts, offsets[th,tw]"""
+    means2d, radii = _f32(means2d), _i32(radii)
+    N = radii.shape[0]
+    tpg = np.zeros(N, np.int32)
+    gpg = np.zeros(N, np.int32)
+    ni, ng = C.c_int64(0), C.c_int64(0)
+    _lib().orc_isect_count(C.c_int(N), _p(means2d), _p(radii), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                           _p(tpg), _p(gpg), C.byref(ni), C.byref(ng))
+    ni, ng = ni.value, ng.value
+    isect_ids = np.zeros(max(ni, 1), np.int64)
+    flatten_ids = np.zeros(max(ni, 1), np.int32)
+    ggs = np.zeros(max(ng, 1), np.int32)
+    gst = np.zeros(max(ng, 1), np.int32)
+    offsets = np.zeros((th, tw), np.int32)
+    _lib().orc_isect_fill_sort(C.c_int(N), _p(means2d), _p(radii), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                               _p(gpg), C.c_int64(ni), C.c_int64(ng), _p(isect_ids), _p(flatten_ids), _p(ggs),
+                               _p(gst), _p(offsets))
+    return tpg, isect_ids[:ni], flatten_ids[:ni], ggs[:ng], gst[:ng], offsets
+
+
+def raster_ges_fwd(means2d, conics, colors, opacities, ref_depth, W, H, tile_size, offsets, flatten_ids,
+                   delta_depth):
+    means2d, conics, colors, opacities, ref_depth = map(_f32, (means2d, conics, colors, opacities, ref_depth))
+    offsets, flatten_ids = _i32(offsets), _i32(flatten_ids)
+    th, tw = offsets.shape
+    rc = np.zeros((H, W, 4), np.float32)
+    ra = np.zeros((H, W), np.float32)
+    last = np.zeros((H, W), np.int32)
+    _lib().orc_raster_ges_fwd(C.c_int(W), C.c_int(H), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                              C.c_int64(flatten_ids.shape[0]), C.c_float(delta_depth), _p(means2d), _p(conics),
+                              _p(colors), _p(opacities), _p(ref_depth), _p(offsets), _p(flatten_ids), _p(rc), _p(ra),
+                              _p(last))
+    return rc, ra, last
+
+
+def raster_ges_bwd_gs(means2d, conics, colors, opacities, radiis, ref_depth, W, H, group_gs_ids, group_starts,
+                      delta_depth, v_render_colors, v_render_alphas):
+    means2d, conics, colors, opacities, ref_depth = map(_f32, (means2d, conics, colors, opacities, ref_depth))
+    v_render_colors, v_render_alphas = _f32(v_render_colors), _f32(v_render_alphas)
+    radiis, group_gs_ids, group_starts = map(_i32, (radiis, group_gs_ids, group_starts))
+    N = radiis.shape[0]
+    v_m = np.zeros((N, 2), np.float32)
+    v_c = np.zeros((N, 3), np.float32)
+    v_col = np.zeros((N, 4), np.float32)
+    v_o = np.zeros(N, np.float32)
+    _lib().orc_raster_ges_bwd_gs(C.c_int(W), C.c_int(H), C.c_int64(group_gs_ids.shape[0]), C.c_float(delta_depth),
+                                 _p(group_gs_ids), _p(group_starts), _p(means2d), _p(conics), _p(colors),
+                                 _p(opacities), _p(radiis), _p(ref_depth), _p(v_render_colors), _p(v_render_alphas),
+                                 _p(v_m), _p(v_c), _p(v_col), _p(v_o))
+    return v_m, v_c, v_col, v_o
+
+
+def raster_ges_bwd_exact(means2d, conics, colors, opacities, ref_depth, W, H, tile_size, offsets, flatten_ids,
+                         delta_depth, v_render_colors, v_render_alphas):
+    means2d, conics, colors, opacities, ref_depth = map(_f32, (means2d, conics, colors, opacities, ref_depth))
+    v_render_colors, v_render_alphas = _f32(v_render_colors), _f32(v_render_alphas)
+    offsets, flatten_ids = _i32(offsets), _i32(flatten_ids)
+    th, tw = offsets.shape
+    N = means2d.shape[0]
+    v_m = np.zeros((N, 2), np.float32)
+    v_c = np.zeros((N, 3), np.float32)
+    v_col = np.zeros((N, 4), np.float32)
+    v_o = np.zeros(N, np.float32)
+    _lib().orc_raster_ges_bwd_exact(C.c_int(W), C.c_int(H), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                                    C.c_int64(flatten_ids.shape[0]), C.c_float(delta_depth), _p(means2d), _p(conics),
+                                    _p(colors), _p(opacities), _p(ref_depth), _p(offsets), _p(flatten_ids),
+                                    _p(v_render_colors), _p(v_render_alphas), _p(v_m), _p(v_c), _p(v_col), _p(v_o))
+    return v_m, v_c, v_col, v_o

@@ -1,0 +1,53 @@
+"""Seeded synthetic inputs shared by the oracle tests and the GPU parity tests (data only)."""
+import numpy as np
+
+
+def look_at_c2w(eye, target, up=(0.0, -1.0, 0.0)):
+    """OpenCV-style camera (x right, y down, z forward) -> 4x4 camera-to-world."""
+    eye = np.asarray(eye, np.float64)
+    f = np.asarray(target, np.float64) - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, -np.asarray(up, np.float64))
+    r /= np.linalg.norm(r)
+    d = np.cross(f, r)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = r, d, f, eye
+    return c2w.astype(np.float32)
+
+
+def intrinsics(W, H):
+    fx = fy = 0.5 * W  # 90 deg HFOV as in SURVEY 8(d)
+    return np.array([[fx, 0, (W - 1) / 2.0], [0, fy, (H - 1) / 2.0], [0, 0, 1]], np.float32)
+
+
+def random_gaussians(N, seed=1234, depth_range=(1.0, 4.0), spread=2.5, scale_range=(0.003, 0.05), sh_k=16):
+    """Gaussians scattered in front of a camera at the origin looking down +z."""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(*depth_range, N)
+    x = rng.uniform(-spread, spread, N) * z / depth_range[1]
+    y = rng.uniform(-spread * 0.75, spread * 0.75, N) * z / depth_range[1]
+    means = np.stack([x, y, z], 1).astype(np.float32)
+    quats = rng.normal(size=(N, 4)).astype(np.float32)
+    ls = rng.uniform(np.log(scale_range[0]), np.log(scale_range[1]), (N, 3))
+    ls[:, 2] += np.log(0.3)
+    log_scales = ls.astype(np.float32)
+    opac_logit = rng.normal(0.0, 1.5, (N, 1)).astype(np.float32)
+    sh = np.zeros((N, sh_k, 3), np.float32)
+    sh[:, 0] = (rng.uniform(0.05, 0.95, (N, 3)) - 0.5) / 0.28209479177387814
+    sh[:, 1:] = rng.normal(0, 0.05, (N, sh_k - 1, 3))
+    return dict(means=means, quats=quats, log_scales=log_scales, opac_logit=opac_logit, sh=sh.astype(np.float32))
+
+
+def default_camera(W, H, seed=0):
+    rng = np.random.default_rng(seed)
+    eye = rng.normal(0, 0.05, 3)
+    c2w = look_at_c2w(eye, [0.05, -0.03, 3.0])
+    return c2w, intrinsics(W, H)
+
+
+def pose_inv(c2w):
+    R, t = c2w[:3, :3], c2w[:3, 3]
+    w2c = np.eye(4, dtype=np.float32)
+    w2c[:3, :3] = R.T
+    w2c[:3, 3] = -R.T @ t
+    return w2c
