@@ -1,0 +1,71 @@
+"""ctypes binding of include/gps_slam_hip.h.  Fails loudly if the HIP library is missing:
+there is NO CPU fallback for any operator in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libgpsslam_hip.so")
+_lib = None
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+
+class AdamSegment(C.Structure):
+    _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", f64)]
+
+
+# name -> (restype, argtypes); mirrors include/gps_slam_hip.h one to one
+PROTOTYPES = {
+    "gps_version": (C.c_char_p, []),
+    "gps_proj_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
+    "gps_proj_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_sh_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),
+    "gps_sh_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_isect_workspace_bytes": (i64, [i32, i64]),
+    "gps_isect_tiles_no_depth": (i32, [i32, vp, vp, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "gps_raster_ges_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
+    "gps_raster_ges_bwd_gs": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp,
+                                    vp]),
+    "gps_compose_l1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_adam_step": (i32, [C.POINTER(AdamSegment), i32, f64, f64, f64, i32, vp]),
+}
+
+
+def load_library(path=None):
+    """Load libgpsslam_hip.so (building is done by __graft_entry__.build / _build.py, never implicitly here)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIBPATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "gps_slam_amd: %s not found. Build it with `python -m gps_slam_amd._build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % p)
+    lib_ = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib_, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib_
+    return lib_
+
+
+class _Lazy:
+    def __getattr__(self, name):
+        return getattr(load_library(), name)
+
+
+lib = _Lazy()
+
+
+class GpsError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "GPS_ERR_ARG", -2: "GPS_ERR_LAUNCH", -3: "GPS_ERR_CAPACITY"}
+
+
+def check(status, what):
+    if status != 0:
+        raise GpsError("%s failed: %s (%d)" % (what, _ERR.get(status, "?"), status))

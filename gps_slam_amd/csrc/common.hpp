@@ -1,0 +1,49 @@
+// Shared host/device helpers for the gfx950 kernels (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gps_slam_hip.h"
+
+#define GPS_WAVE 64
+
+// Every C-ABI entry point returns GPS_OK or a negative error; launches are checked
+// with hipGetLastError so a bad configuration is reported, never silently skipped.
+#define GPS_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return GPS_ERR_LAUNCH;        \
+    } while (0)
+
+#define GPS_REQUIRE(cond)                 \
+    do {                                  \
+        if (!(cond)) return GPS_ERR_ARG;  \
+    } while (0)
+
+static inline int gps_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 reductions (DPP-free, shuffle based; all 64 lanes active) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}

@@ -1,0 +1,397 @@
+// Tile binning without a depth key, entirely on the device.
+//
+// gps_isect_tiles_no_depth <- gsplat::isect_tiles_tensor_no_depth +
+//                             isect_offset_encode_tensor_no_depth
+//                             (gsplat/rasterizer/isect_tiles_no_depth.cu:132-461)
+//
+// The reference does: count kernel -> torch cumsum x2 -> two .item() host syncs ->
+// fill kernel -> cub radix sort of (int64 key, int32 value) -> offset kernel.
+// Here n_isects / n_groups never leave the device (counts[]), buffers have a
+// caller-chosen capacity, and the pipeline is
+//   count (+ per-256 block sums) -> single-workgroup scan of block sums ->
+//   expand (balanced, coalesced: one thread per OUTPUT element, binary search
+//   in the block's LDS prefix) -> stable LSD radix sort on the tile id only
+//   (1 or 2 passes of <= 8 bits: 1,200 tiles = 11 bits, 3,600 tiles = 12 bits)
+//   -> tile offsets.
+// Sort keys are u32 tile ids; the int64 isect_ids of the reference API are
+// materialised only if the caller asks for them.  The sort is stable, so inside
+// a tile Gaussians stay in ascending index order exactly like cub's LSD sort.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BIN_BLOCK = 256;          // Gaussians per count/expand workgroup
+constexpr int SORT_THREADS = 256;       // 4 waves
+constexpr int SORT_ITEMS = 8;           // items per thread
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 2048 items per workgroup
+constexpr int SCAN_THREADS = 1024;
+
+struct TileBox { uint32_t x0, y0, x1, y1; };
+
+// isect_tiles_no_depth.cu:68-80: bbox in tile units; float->uint conversion saturates at 0.
+__device__ __forceinline__ TileBox tile_bbox(float mx, float my, int radius_i, int tile_size, int tw, int th) {
+    float radius = (float)radius_i;
+    float ts = (float)tile_size;
+    float tr = radius / ts, tx = mx / ts, ty = my / ts;
+    TileBox b;
+    float fx0 = floorf(tx - tr), fy0 = floorf(ty - tr), fx1 = ceilf(tx + tr), fy1 = ceilf(ty + tr);
+    b.x0 = (uint32_t)fminf(fmaxf(fx0, 0.f), (float)tw);
+    b.y0 = (uint32_t)fminf(fmaxf(fy0, 0.f), (float)th);
+    b.x1 = (uint32_t)fminf(fmaxf(fx1, 0.f), (float)tw);
+    b.y1 = (uint32_t)fminf(fmaxf(fy1, 0.f), (float)th);
+    return b;
+}
+
+// ---- workgroup-wide exclusive scan of one int per thread (blockDim multiple of 64, <= 1024) ----
+__device__ __forceinline__ int block_excl_scan(int v, int* lds_wave_sums /*[17]*/, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    int incl = wave_incl_scan_i(v);
+    if (lane == 63) lds_wave_sums[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int s = lane < nwaves ? lds_wave_sums[lane] : 0;
+        int si = wave_incl_scan_i(s);
+        if (lane < nwaves) lds_wave_sums[lane] = si - s;
+        if (lane == 63) lds_wave_sums[16] = si;
+    }
+    __syncthreads();
+    int r = lds_wave_sums[wave] + incl - v;
+    total = lds_wave_sums[16];
+    __syncthreads();
+    return r;
+}
+
+// ---------------- pass 1: per-Gaussian counts + per-block sums ----------------
+__global__ __launch_bounds__(BIN_BLOCK) void count_kernel(int N, const float* __restrict__ means2d,
+                                                         const int32_t* __restrict__ radii, int tile_size, int tw,
+                                                         int th, int32_t* __restrict__ tiles_per_gauss,
+                                                         int32_t* __restrict__ groups_per_gauss,
+                                                         int32_t* __restrict__ blk_tiles,
+                                                         int32_t* __restrict__ blk_groups,
+                                                         int32_t* __restrict__ blk_vis) {
+    __shared__ int red[3][BIN_BLOCK / 64];
+    int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    int t = 0, g = 0, vis = 0;
+    if (i < N) {
+        int r = radii[i];
+        if (r > 0) {
+            float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
+            TileBox b = tile_bbox(m.x, m.y, r, tile_size, tw, th);
+            t = (int)((b.y1 - b.y0) * (b.x1 - b.x0));
+            float rf = (float)r;
+            g = (int)((4 * rf * rf + 32 - 1) / 32);  // fp32 expression of isect_tiles_no_depth.cu:87
+            vis = 1;
+        }
+        tiles_per_gauss[i] = t;
+        groups_per_gauss[i] = g;
+    }
+    int ts = wave_sum_i(t), gs = wave_sum_i(g), vs = wave_sum_i(vis);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ts; red[1][threadIdx.x >> 6] = gs; red[2][threadIdx.x >> 6] = vs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0, c = 0;
+        for (int w = 0; w < BIN_BLOCK / 64; w++) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+        blk_tiles[blockIdx.x] = a; blk_groups[blockIdx.x] = b; blk_vis[blockIdx.x] = c;
+    }
+}
+
+// ---------------- single workgroup: exclusive scan of the block sums, totals -> counts ----------------
+__global__ __launch_bounds__(SCAN_THREADS) void scan_blocks_kernel(int nblk, int32_t* __restrict__ blk_tiles,
+                                                                  int32_t* __restrict__ blk_groups,
+                                                                  const int32_t* __restrict__ blk_vis,
+                                                                  int64_t isect_cap, int64_t group_cap,
+                                                                  int64_t* __restrict__ counts) {
+    __shared__ int ws[17];
+    const int per = (nblk + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = threadIdx.x * per, hi = min(nblk, lo + per);
+    int totals[2];
+    for (int which = 0; which < 2; which++) {
+        int32_t* a = which == 0 ? blk_tiles : blk_groups;
+        int s = 0;
+        for (int k = lo; k < hi; k++) s += a[k];
+        int total;
+        int base = block_excl_scan(s, ws, total);
+        for (int k = lo; k < hi; k++) { int v = a[k]; a[k] = base; base += v; }
+        totals[which] = total;
+    }
+    int s = 0;
+    for (int k = lo; k < hi; k++) s += blk_vis[k];
+    int vis_total;
+    block_excl_scan(s, ws, vis_total);
+    if (threadIdx.x == 0) {
+        int64_t ni = totals[0], ng = totals[1];
+        int64_t ovf = 0;
+        if (ni > isect_cap) { ni = isect_cap; ovf = 1; }
+        if (ng > group_cap) { ng = group_cap; ovf = 1; }
+        counts[0] = ni; counts[1] = ng; counts[2] = ovf; counts[3] = vis_total;
+    }
+}
+
+// ---------------- pass 2: expand (Gaussian, tile) pairs and the 32-pixel group table ----------------
+__global__ __launch_bounds__(BIN_BLOCK) void expand_kernel(int N, const float* __restrict__ means2d,
+                                                          const int32_t* __restrict__ radii, int tile_size, int tw,
+                                                          int th, const int32_t* __restrict__ tiles_per_gauss,
+                                                          const int32_t* __restrict__ groups_per_gauss,
+                                                          const int32_t* __restrict__ blk_tiles,
+                                                          const int32_t* __restrict__ blk_groups, int64_t isect_cap,
+                                                          int64_t group_cap, uint32_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals,
+                                                          int32_t* __restrict__ group_gs_ids,
+                                                          int32_t* __restrict__ group_starts) {
+    __shared__ int ws[17];
+    __shared__ int pre_t[BIN_BLOCK + 1];
+    __shared__ int pre_g[BIN_BLOCK + 1];
+    __shared__ uint32_t box_x0[BIN_BLOCK], box_y0[BIN_BLOCK], box_w[BIN_BLOCK];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BIN_BLOCK + tid;
+    int t = 0, g = 0;
+    if (i < N) {
+        t = tiles_per_gauss[i];
+        g = groups_per_gauss[i];
+        if (t > 0) {
+            float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
+            TileBox b = tile_bbox(m.x, m.y, radii[i], tile_size, tw, th);
+            box_x0[tid] = b.x0; box_y0[tid] = b.y0; box_w[tid] = b.x1 - b.x0;
+        }
+    }
+    int tot_t, tot_g;
+    int et = block_excl_scan(t, ws, tot_t);
+    int eg = block_excl_scan(g, ws, tot_g);
+    pre_t[tid] = et; pre_g[tid] = eg;
+    if (tid == 0) { pre_t[BIN_BLOCK] = tot_t; pre_g[BIN_BLOCK] = tot_g; }
+    __syncthreads();
+    const int64_t base_t = blk_tiles[blockIdx.x], base_g = blk_groups[blockIdx.x];
+    // one thread per output intersection
+    for (int j = tid; j < tot_t; j += BIN_BLOCK) {
+        int lo = 0, hi = BIN_BLOCK;  // largest src with pre_t[src] <= j
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre_t[mid] <= j) lo = mid; else hi = mid; }
+        int k = j - pre_t[lo];
+        uint32_t w = box_w[lo];
+        uint32_t ty = box_y0[lo] + (uint32_t)k / w, tx = box_x0[lo] + (uint32_t)k % w;
+        int64_t o = base_t + j;
+        if (o < isect_cap) { keys[o] = ty * (uint32_t)tw + tx; vals[o] = (uint32_t)(blockIdx.x * BIN_BLOCK + lo); }
+    }
+    // one thread per output group
+    for (int j = tid; j < tot_g; j += BIN_BLOCK) {
+        int lo = 0, hi = BIN_BLOCK;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pre_g[mid] <= j) lo = mid; else hi = mid; }
+        int64_t o = base_g + j;
+        if (o < group_cap) {
+            group_gs_ids[o] = blockIdx.x * BIN_BLOCK + lo;
+            group_starts[o] = (int32_t)(base_g + pre_g[lo]);
+        }
+    }
+}
+
+// ---------------- stable LSD radix sort pass on `bits` bits starting at `shift` ----------------
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys,
+                                                                 const int64_t* __restrict__ counts, int shift,
+                                                                 int bits, int nblk_cap, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    const int n = (int)counts[0];
+    const int base = blockIdx.x * SORT_TILE;
+    if (base >= n) return;
+    const int bins = 1 << bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    if (threadIdx.x < bins) h[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        int idx = base + k * SORT_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < bins) hist[(size_t)threadIdx.x * nblk_cap + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void radix_scan_kernel(const int64_t* __restrict__ counts, int bits,
+                                                                 int nblk_cap, uint32_t* __restrict__ hist) {
+    __shared__ int ws[17];
+    const int n = (int)counts[0];
+    const int nblk = (n + SORT_TILE - 1) / SORT_TILE;
+    const int total = nblk << bits;  // digit-major order: e = d * nblk + b
+    const int per = (total + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(total, (int)threadIdx.x * per), hi = min(total, lo + per);
+    int s = 0;
+    for (int e = lo; e < hi; e++) { int d = e / nblk, b = e - d * nblk; s += (int)hist[(size_t)d * nblk_cap + b]; }
+    int tot;
+    int run = block_excl_scan(s, ws, tot);
+    for (int e = lo; e < hi; e++) {
+        int d = e / nblk, b = e - d * nblk;
+        size_t a = (size_t)d * nblk_cap + b;
+        int v = (int)hist[a]; hist[a] = (uint32_t)run; run += v;
+    }
+}
+
+// Each wave owns a contiguous 512-item slice; inside it items are visited in index order
+// (iteration-major, lane-minor) so "earlier item, same digit" == stable rank.
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                    const uint32_t* __restrict__ vals_in,
+                                                                    const int64_t* __restrict__ counts, int shift,
+                                                                    int bits, int nblk_cap,
+                                                                    const uint32_t* __restrict__ hist,
+                                                                    uint32_t* __restrict__ keys_out,
+                                                                    uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t wavecnt[SORT_THREADS / 64][256];
+    __shared__ uint32_t digitbase[256];
+    const int n = (int)counts[0];
+    const int base = blockIdx.x * SORT_TILE;
+    if (base >= n) return;
+    const int bins = 1 << bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < (SORT_THREADS / 64) * 256; k += SORT_THREADS) (&wavecnt[0][0])[k] = 0;
+    __syncthreads();
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    const int wbase = base + wave * (64 * SORT_ITEMS);
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        int idx = wbase + k * 64 + lane;
+        bool valid = idx < n;
+        key[k] = valid ? keys_in[idx] : 0u;
+        val[k] = valid ? vals_in[idx] : 0u;
+        uint32_t d = (key[k] >> shift) & mask;
+        unsigned long long same = __ballot(valid);
+        for (int b = 0; b < bits; b++) {
+            unsigned long long bal = __ballot(valid && ((d >> b) & 1u));
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t prev = wavecnt[wave][d];
+        rank[k] = prev + (uint32_t)__popcll(same & lt);
+        // highest lane of each digit group publishes the new running count
+        if (valid && (same >> lane) == 1ull) wavecnt[wave][d] = prev + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < bins) {
+        uint32_t run = hist[(size_t)threadIdx.x * nblk_cap + blockIdx.x];
+        digitbase[threadIdx.x] = run;
+        uint32_t acc = 0;
+        for (int w = 0; w < SORT_THREADS / 64; w++) { uint32_t c = wavecnt[w][threadIdx.x]; wavecnt[w][threadIdx.x] = acc; acc += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        int idx = wbase + k * 64 + lane;
+        if (idx < n) {
+            uint32_t d = (key[k] >> shift) & mask;
+            uint32_t pos = digitbase[d] + wavecnt[wave][d] + rank[k];
+            keys_out[pos] = key[k];
+            vals_out[pos] = val[k];
+        }
+    }
+}
+
+// ---------------- tile offsets (+ optional int64 copy of the sorted keys) ----------------
+// isect_tiles_no_depth.cu:373-425
+__global__ __launch_bounds__(256) void offsets_kernel(const uint32_t* __restrict__ keys,
+                                                     const int64_t* __restrict__ counts, int n_tiles,
+                                                     int32_t* __restrict__ offsets, int64_t* __restrict__ isect_ids) {
+    const int n = (int)counts[0];
+    const int stride = gridDim.x * blockDim.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) {
+        for (int t = gid; t < n_tiles; t += stride) offsets[t] = 0;
+        return;
+    }
+    for (int idx = gid; idx < n; idx += stride) {
+        int cur = (int)keys[idx];
+        if (isect_ids) isect_ids[idx] = (int64_t)cur;
+        int prev = idx > 0 ? (int)keys[idx - 1] : -1;
+        for (int t = prev + 1; t <= cur; t++) offsets[t] = idx;
+        if (idx == n - 1)
+            for (int t = cur + 1; t < n_tiles; t++) offsets[t] = n;
+    }
+}
+
+struct Workspace {
+    int32_t *groups_per_gauss, *blk_tiles, *blk_groups, *blk_vis;
+    uint32_t *keys_a, *vals_a, *keys_b, *vals_b, *hist;
+    int nblkN, nblkI;
+};
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t carve(Workspace* w, char* base, int N, int64_t cap) {
+    size_t off = 0;
+    int nblkN = gps_div_up(N > 0 ? N : 1, BIN_BLOCK);
+    int nblkI = gps_div_up(cap > 0 ? cap : 1, SORT_TILE);
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? base + o : nullptr; };
+    char* p;
+    p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->groups_per_gauss = (int32_t*)p;
+    p = take((size_t)nblkN * 4); if (w) w->blk_tiles = (int32_t*)p;
+    p = take((size_t)nblkN * 4); if (w) w->blk_groups = (int32_t*)p;
+    p = take((size_t)nblkN * 4); if (w) w->blk_vis = (int32_t*)p;
+    p = take((size_t)cap * 4); if (w) w->keys_a = (uint32_t*)p;
+    p = take((size_t)cap * 4); if (w) w->vals_a = (uint32_t*)p;
+    p = take((size_t)cap * 4); if (w) w->keys_b = (uint32_t*)p;
+    p = take((size_t)cap * 4); if (w) w->vals_b = (uint32_t*)p;
+    p = take((size_t)256 * nblkI * 4); if (w) w->hist = (uint32_t*)p;
+    if (w) { w->nblkN = nblkN; w->nblkI = nblkI; }
+    return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity) {
+    if (N < 0 || isect_capacity < 0) return GPS_ERR_ARG;
+    return (int64_t)carve(nullptr, nullptr, N, isect_capacity);
+}
+
+int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
+                             int tile_height, int64_t isect_capacity, int64_t group_capacity,
+                             int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids,
+                             int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets, int64_t* counts,
+                             void* workspace, int64_t workspace_bytes, gps_stream stream) {
+    GPS_REQUIRE(N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
+    GPS_REQUIRE(isect_capacity > 0 && isect_capacity < (1ll << 31) && group_capacity > 0 && group_capacity < (1ll << 31));
+    GPS_REQUIRE(tiles_per_gauss && flatten_ids && group_gs_ids && group_starts && tile_offsets && counts && workspace);
+    GPS_REQUIRE(N == 0 || (means2d && radii));
+    const int n_tiles = tile_width * tile_height;
+    GPS_REQUIRE(n_tiles <= (1 << 16));
+    if (workspace_bytes < gps_isect_workspace_bytes(N, isect_capacity)) return GPS_ERR_CAPACITY;
+    Workspace w;
+    carve(&w, (char*)workspace, N, isect_capacity);
+    hipStream_t s = (hipStream_t)stream;
+
+    if (N > 0)
+        count_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
+                                                   tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
+                                                   w.blk_vis);
+    scan_blocks_kernel<<<1, SCAN_THREADS, 0, s>>>(N > 0 ? w.nblkN : 0, w.blk_tiles, w.blk_groups, w.blk_vis,
+                                                  isect_capacity, group_capacity, counts);
+    if (N > 0)
+        expand_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
+                                                    tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
+                                                    isect_capacity, group_capacity, w.keys_a, w.vals_a, group_gs_ids,
+                                                    group_starts);
+    int bits_total = 1;
+    while ((1 << bits_total) < n_tiles) bits_total++;
+    const uint32_t* sorted_keys;
+    if (bits_total <= 8) {
+        radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, counts, 0, bits_total, w.nblkI, w.hist);
+        radix_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(counts, bits_total, w.nblkI, w.hist);
+        radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, w.vals_a, counts, 0, bits_total, w.nblkI,
+                                                                    w.hist, w.keys_b, (uint32_t*)flatten_ids);
+        sorted_keys = w.keys_b;
+    } else {
+        int b1 = (bits_total + 1) / 2, b2 = bits_total - b1;
+        radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, counts, 0, b1, w.nblkI, w.hist);
+        radix_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(counts, b1, w.nblkI, w.hist);
+        radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, w.vals_a, counts, 0, b1, w.nblkI,
+                                                                     w.hist, w.keys_b, w.vals_b);
+        radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_b, counts, b1, b2, w.nblkI, w.hist);
+        radix_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(counts, b2, w.nblkI, w.hist);
+        radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_b, w.vals_b, counts, b1, b2, w.nblkI,
+                                                                    w.hist, w.keys_a, (uint32_t*)flatten_ids);
+        sorted_keys = w.keys_a;
+    }
+    offsets_kernel<<<512, 256, 0, s>>>(sorted_keys, counts, n_tiles, tile_offsets, isect_ids);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // extern "C"

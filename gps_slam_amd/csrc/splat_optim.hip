@@ -1,0 +1,135 @@
+// Fused replacements for the libtorch glue around the rasterizer:
+//
+// gps_compose_l1 <- raw_gs_model.cpp:318-326 (compose with the TSDF layer) +
+//                   :369-417 computeLoss (L1 only: ssim_weight = depth_weight = 0 in every
+//                   shipped config) + the autograd backward of both  (~35 libtorch launches)
+// gps_adam_step  <- 7 x torch::optim::Adam::step (raw_gs_model.cpp:654-705), one launch
+//
+// Both are pure HBM streams: one pass, float4 where the layout allows it.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void compose_l1_kernel(int P, const float4* __restrict__ render_colors,
+                                                        const float* __restrict__ weight_sum,
+                                                        const float* __restrict__ base_color,
+                                                        const float* __restrict__ ref_depth_raw,
+                                                        const float* __restrict__ gt_rgb, float* __restrict__ rgb,
+                                                        float* __restrict__ depth, float* __restrict__ loss,
+                                                        float4* __restrict__ v_render_colors,
+                                                        float* __restrict__ v_render_alphas, float inv_count) {
+    __shared__ float red[4];
+    float part = 0.f;
+    const int stride = gridDim.x * blockDim.x;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const float4 rc = render_colors[p];
+        const float w = weight_sum[p];
+        const float den = w + 1.0f;  // base colour weight is always 1 (raw_gs_model.cpp:321-323)
+        const float n0 = rc.x + base_color[3 * p], n1 = rc.y + base_color[3 * p + 1], n2 = rc.z + base_color[3 * p + 2];
+        const float c0 = n0 / den, c1 = n1 / den, c2 = n2 / den;
+        rgb[3 * p] = c0; rgb[3 * p + 1] = c1; rgb[3 * p + 2] = c2;
+        if (depth) {
+            const float ref = ref_depth_raw[p];
+            const float bw = ref > 0.f ? 1.f : 0.f;  // depth weight only where the raycast hit (:324-326)
+            depth[p] = (rc.w + ref * bw) / (w + bw);
+        }
+        const float d0 = gt_rgb[3 * p] - c0, d1 = gt_rgb[3 * p + 1] - c1, d2 = gt_rgb[3 * p + 2] - c2;
+        part += fabsf(d0) + fabsf(d1) + fabsf(d2);
+        if (v_render_colors) {
+            // d mean|gt - rgb| / d rgb = -sgn(gt - rgb) / (3P); sgn(0) = 0 as in torch
+            const float g0 = d0 > 0.f ? -inv_count : (d0 < 0.f ? inv_count : 0.f);
+            const float g1 = d1 > 0.f ? -inv_count : (d1 < 0.f ? inv_count : 0.f);
+            const float g2 = d2 > 0.f ? -inv_count : (d2 < 0.f ? inv_count : 0.f);
+            v_render_colors[p] = make_float4(g0 / den, g1 / den, g2 / den, 0.f);
+            const float dd = den * den;
+            v_render_alphas[p] = -(g0 * n0) / dd - (g1 * n1) / dd - (g2 * n2) / dd;
+        }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
+struct AdamArgs {
+    gps_adam_segment seg[GPS_ADAM_MAX_SEGMENTS];
+    float step_size[GPS_ADAM_MAX_SEGMENTS];  // lr / (1 - b1^t), computed in double on the host like libtorch
+    int64_t seg_end[GPS_ADAM_MAX_SEGMENTS];  // exclusive prefix end in the flattened index space
+    int n_segments;
+    float beta1, beta2, one_minus_b1, one_minus_b2, bc2_sqrt, eps;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    const int64_t total = a.seg_end[a.n_segments - 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < GPS_ADAM_MAX_SEGMENTS - 1; k++) s += (k < a.n_segments - 1 && e >= a.seg_end[k]) ? 1 : 0;
+        const int64_t i = e - (s == 0 ? 0 : a.seg_end[s - 1]);
+        const gps_adam_segment& sg = a.seg[s];
+        const float g = sg.grad[i];
+        // exp_avg.mul_(b1).add_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, 1-b2)
+        const float m = fmaf(a.one_minus_b1, g, sg.exp_avg[i] * a.beta1);
+        const float v = fmaf(a.one_minus_b2 * g, g, sg.exp_avg_sq[i] * a.beta2);
+        sg.exp_avg[i] = m;
+        sg.exp_avg_sq[i] = v;
+        // denom = sqrt(v)/sqrt(1-b2^t) + eps ; p.addcdiv_(m, denom, -step_size)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        sg.param[i] = sg.param[i] + (-a.step_size[s] * m) / denom;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_compose_l1(int width, int height, const float* render_colors, const float* weight_sum,
+                   const float* base_color, const float* ref_depth_raw, const float* gt_rgb, float* rgb, float* depth,
+                   float* loss, float* v_render_colors, float* v_render_alphas, gps_stream stream) {
+    GPS_REQUIRE(width > 0 && height > 0);
+    GPS_REQUIRE(render_colors && weight_sum && base_color && gt_rgb && rgb && loss);
+    GPS_REQUIRE(depth == nullptr || ref_depth_raw != nullptr);
+    GPS_REQUIRE((v_render_colors == nullptr) == (v_render_alphas == nullptr));
+    const int P = width * height;
+    hipStream_t s = (hipStream_t)stream;
+    compose_l1_kernel<<<min(1024, gps_div_up(P, 256)), 256, 0, s>>>(P, (const float4*)render_colors, weight_sum,
+                                                                    base_color, ref_depth_raw, gt_rgb, rgb, depth,
+                                                                    loss, (float4*)v_render_colors, v_render_alphas,
+                                                                    1.0f / (3.0f * (float)P));
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_adam_step(const gps_adam_segment* segments, int n_segments, double beta1, double beta2, double eps, int step,
+                  gps_stream stream) {
+    GPS_REQUIRE(segments && n_segments >= 1 && n_segments <= GPS_ADAM_MAX_SEGMENTS && step >= 1);
+    AdamArgs a;
+    int64_t run = 0;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    for (int k = 0; k < n_segments; k++) {
+        GPS_REQUIRE(segments[k].numel >= 0);
+        GPS_REQUIRE(segments[k].numel == 0 ||
+                    (segments[k].param && segments[k].grad && segments[k].exp_avg && segments[k].exp_avg_sq));
+        a.seg[k] = segments[k];
+        a.step_size[k] = (float)(segments[k].lr / bc1);
+        run += segments[k].numel;
+        a.seg_end[k] = run;
+    }
+    for (int k = n_segments; k < GPS_ADAM_MAX_SEGMENTS; k++) { a.seg[k] = segments[0]; a.step_size[k] = 0.f; a.seg_end[k] = run; }
+    if (run == 0) return GPS_OK;
+    a.n_segments = n_segments;
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+    a.one_minus_b1 = (float)(1.0 - beta1);
+    a.one_minus_b2 = (float)(1.0 - beta2);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = (float)eps;
+    adam_kernel<<<min((int64_t)4096, (int64_t)gps_div_up(run, 256)), 256, 0, (hipStream_t)stream>>>(a);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// Op-level projection and spherical-harmonics kernels (one thread per Gaussian).
+//
+// gps_proj_fwd / gps_proj_bwd  <- gsplat::fully_fused_projection_{fwd,bwd}_tensor
+// gps_sh_fwd   / gps_sh_bwd    <- gsplat::compute_sh_{fwd,bwd}_tensor
+//
+// These are HBM-streaming kernels (~70 B/Gaussian for projection, ~220 B for SH):
+// 256-thread workgroups, grid >> 256 CUs for N >= 100k, no LDS, no atomics
+// (C = 1 camera so the reference's warp-reduce + atomicAdd degenerates to a
+// plain store; the reference's zeros_like memsets are folded into the stores).
+#include "splat_math.hpp"
+
+using namespace gps;
+
+__global__ __launch_bounds__(256) void proj_fwd_kernel(int N, const float* __restrict__ means,
+                                                       const float* __restrict__ quats,
+                                                       const float* __restrict__ scales,
+                                                       const float* __restrict__ viewmat, const float* __restrict__ K,
+                                                       int W, int H, float eps2d, float near_plane, float far_plane,
+                                                       float radius_clip, int32_t* __restrict__ radii,
+                                                       float* __restrict__ means2d, float* __restrict__ depths,
+                                                       float* __restrict__ conics) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Cam cam;
+    cam_from_arrays(viewmat, K, W, H, cam);
+    float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    const float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (size_t)i);
+    float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    Proj o = project_gaussian(cam, p, q, s, eps2d, near_plane, far_plane, radius_clip);
+    radii[i] = o.radius;
+    *reinterpret_cast<float2*>(means2d + 2 * (size_t)i) = make_float2(o.mx, o.my);
+    depths[i] = o.z;
+    conics[3 * i] = o.ca; conics[3 * i + 1] = o.cb; conics[3 * i + 2] = o.cc;
+}
+
+__global__ __launch_bounds__(256) void proj_bwd_kernel(int N, const float* __restrict__ means,
+                                                       const float* __restrict__ quats,
+                                                       const float* __restrict__ scales,
+                                                       const float* __restrict__ viewmat, const float* __restrict__ K,
+                                                       int W, int H, const int32_t* __restrict__ radii,
+                                                       const float* __restrict__ conics,
+                                                       const float* __restrict__ v_means2d,
+                                                       const float* __restrict__ v_depths,
+                                                       const float* __restrict__ v_conics, float* __restrict__ v_means,
+                                                       float* __restrict__ v_quats, float* __restrict__ v_scales) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float vp[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    if (radii[i] > 0) {
+        Cam cam;
+        cam_from_arrays(viewmat, K, W, H, cam);
+        float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        const float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (size_t)i);
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float conic[3] = {conics[3 * i], conics[3 * i + 1], conics[3 * i + 2]};
+        float vm2[2] = {v_means2d[2 * i], v_means2d[2 * i + 1]};
+        float vc[3] = {v_conics[3 * i], v_conics[3 * i + 1], v_conics[3 * i + 2]};
+        project_gaussian_vjp(cam, p, q, s, conic, vm2, v_depths[i], vc, vp, vq, vs);
+    }
+    v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
+    *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+    v_scales[3 * i] = vs[0]; v_scales[3 * i + 1] = vs[1]; v_scales[3 * i + 2] = vs[2];
+}
+
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int N, int K, const float* __restrict__ dirs,
+                                                     const float* __restrict__ coeffs,
+                                                     const uint8_t* __restrict__ masks, float* __restrict__ colors) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (masks == nullptr || masks[i]) {
+        float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+        float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+        float Y[NB];
+        sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
+        const float* cf = coeffs + (size_t)i * K * 3;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            r += Y[k] * cf[3 * k];
+            g += Y[k] * cf[3 * k + 1];
+            b += Y[k] * cf[3 * k + 2];
+        }
+    }
+    colors[3 * i] = r; colors[3 * i + 1] = g; colors[3 * i + 2] = b;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int K, const float* __restrict__ dirs,
+                                                     const float* __restrict__ coeffs,
+                                                     const uint8_t* __restrict__ masks,
+                                                     const float* __restrict__ v_colors, float* __restrict__ v_coeffs,
+                                                     float* __restrict__ v_dirs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float* vcf = v_coeffs + (size_t)i * K * 3;
+    bool on = (masks == nullptr || masks[i]);
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (on) {
+        float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+        float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+        float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+        float vr = v_colors[3 * i], vg = v_colors[3 * i + 1], vb = v_colors[3 * i + 2];
+        float Y[NB];
+        sh_basis<DEG>(x, y, z, Y);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            vcf[3 * k] = Y[k] * vr; vcf[3 * k + 1] = Y[k] * vg; vcf[3 * k + 2] = Y[k] * vb;
+        }
+        if (v_dirs != nullptr && DEG >= 1) {
+            float dX[NB], dY[NB], dZ[NB];
+            sh_basis_grad<DEG>(x, y, z, dX, dY, dZ);
+            const float* cf = coeffs + (size_t)i * K * 3;
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+            for (int k = 1; k < NB; k++) {
+                float w = cf[3 * k] * vr + cf[3 * k + 1] * vg + cf[3 * k + 2] * vb;
+                gx += dX[k] * w; gy += dY[k] * w; gz += dZ[k] * w;
+            }
+            float d = gx * x + gy * y + gz * z;
+            vd[0] = (gx - d * x) * inorm; vd[1] = (gy - d * y) * inorm; vd[2] = (gz - d * z) * inorm;
+        }
+    }
+    for (int k = on ? NB : 0; k < K; k++) { vcf[3 * k] = 0.f; vcf[3 * k + 1] = 0.f; vcf[3 * k + 2] = 0.f; }
+    if (v_dirs != nullptr) { v_dirs[3 * i] = vd[0]; v_dirs[3 * i + 1] = vd[1]; v_dirs[3 * i + 2] = vd[2]; }
+}
+
+extern "C" {
+
+int gps_proj_fwd(int N, const float* means, const float* quats, const float* scales, const float* viewmat,
+                 const float* K, int width, int height, float eps2d, float near_plane, float far_plane,
+                 float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics, gps_stream stream) {
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means && quats && scales && viewmat && K && radii && means2d && depths && conics);
+    proj_fwd_kernel<<<gps_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(N, means, quats, scales, viewmat, K, width,
+                                                                         height, eps2d, near_plane, far_plane,
+                                                                         radius_clip, radii, means2d, depths, conics);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_proj_bwd(int N, const float* means, const float* quats, const float* scales, const float* viewmat,
+                 const float* K, int width, int height, float eps2d, const int32_t* radii, const float* conics,
+                 const float* v_means2d, const float* v_depths, const float* v_conics, float* v_means,
+                 float* v_quats, float* v_scales, gps_stream stream) {
+    (void)eps2d;
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means && quats && scales && viewmat && K && radii && conics && v_means2d && v_depths && v_conics &&
+                v_means && v_quats && v_scales);
+    proj_bwd_kernel<<<gps_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(N, means, quats, scales, viewmat, K, width,
+                                                                         height, radii, conics, v_means2d, v_depths,
+                                                                         v_conics, v_means, v_quats, v_scales);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_sh_fwd(int N, int K, int degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks,
+               float* colors, gps_stream stream) {
+    GPS_REQUIRE(N >= 0 && degrees_to_use >= 0 && degrees_to_use <= 4 && K >= sh_num_bases(degrees_to_use));
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(dirs && coeffs && colors);
+    dim3 g(gps_div_up(N, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (degrees_to_use) {
+        case 0: sh_fwd_kernel<0><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, colors); break;
+        case 1: sh_fwd_kernel<1><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, colors); break;
+        case 2: sh_fwd_kernel<2><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, colors); break;
+        case 3: sh_fwd_kernel<3><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, colors); break;
+        default: sh_fwd_kernel<4><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, colors); break;
+    }
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_sh_bwd(int N, int K, int degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks,
+               const float* v_colors, float* v_coeffs, float* v_dirs, gps_stream stream) {
+    GPS_REQUIRE(N >= 0 && degrees_to_use >= 0 && degrees_to_use <= 4 && K >= sh_num_bases(degrees_to_use));
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(dirs && coeffs && v_colors && v_coeffs);
+    dim3 g(gps_div_up(N, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (degrees_to_use) {
+        case 0: sh_bwd_kernel<0><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 1: sh_bwd_kernel<1><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 2: sh_bwd_kernel<2><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        case 3: sh_bwd_kernel<3><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+        default: sh_bwd_kernel<4><<<g, b, 0, s>>>(N, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
+    }
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+const char* gps_version(void) { return "gps-slam-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

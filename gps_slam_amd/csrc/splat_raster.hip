@@ -1,0 +1,250 @@
+// `ges` rasterizer: order-independent depth-cut weighted splat (forward) and the
+// Gaussian-parallel backward over each Gaussian's 2r x 2r pixel box.
+//
+// gps_raster_ges_fwd    <- gsplat::rasterize_to_pixels_fwd_ges_tensor
+//                          (gsplat/rasterizer/rasterize_to_pixels_fwd_ges.cu:18-221)
+// gps_raster_ges_bwd_gs <- gsplat::rasterize_to_pixels_bwd_ges_gs_parallel_tensor
+//                          (gsplat/rasterizer/rasterize_to_pixels_bwd_ges_new_parallel.cu:18-201)
+//
+// Forward: one 256-thread workgroup (4 wave64) per 16x16 tile; wave w owns pixel
+// rows 4w..4w+3.  The tile's sorted Gaussian list is staged through LDS in
+// batches of 256 complete records {xy, conic, opacity, depth, rgb} (40 B) so the
+// per-pixel loop reads only LDS (broadcast reads, conflict free) -- the
+// reference re-reads the depth/colour channels from global memory for every
+// (pixel, Gaussian) pair (:165-166).  No MFMA: this is not a contraction.
+//
+// Backward: the reference gives each 32-lane warp 32 consecutive 32-pixel groups
+// and issues 10 atomics per group.  Here a wave64 takes 32 consecutive groups as
+// two contiguous runs of 16 (one per half-wave), keeps the 10 partial sums in
+// registers while consecutive groups belong to the same Gaussian, and only
+// reduces (within the 32-lane half) + atomically adds when the Gaussian changes:
+// ~N_visible x 10 atomics instead of n_groups x 10.  Pixel/box semantics
+// (int() truncation, +1 offsets, i > y_max guard) are the reference's.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TILE_THREADS = 256;
+
+
+template <int TILE>
+__global__ __launch_bounds__(TILE_THREADS) void raster_ges_fwd_kernel(
+    const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
+    float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+    static_assert(TILE == 16, "one thread per pixel of a 16x16 tile");
+    __shared__ float4 rec0[TILE_THREADS];
+    __shared__ float4 rec1[TILE_THREADS];
+    __shared__ float2 rec2[TILE_THREADS];
+
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int tid = threadIdx.x;
+    const int i = ty * TILE + (tid >> 4), j = tx * TILE + (tid & 15);
+    const bool inside = (i < H) && (j < W);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const int pix = i * W + j;
+
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+
+    // pixels outside the image never pass the depth test
+    const float cut = inside ? ref_depth[pix] + delta_depth : -3.0e38f;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, wsum = 0.f;
+    int cur_idx = 0;
+
+    for (int batch_start = range_start; batch_start < range_end; batch_start += TILE_THREADS) {
+        __syncthreads();  // previous batch fully consumed
+        const int idx = batch_start + tid;
+        if (idx < range_end) {
+            const int g = flatten_ids[idx];
+            const float2 xy = means2d[g];
+            const float4 c = colors[g];
+            const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+            rec0[tid] = make_float4(xy.x, xy.y, ca, cb);
+            rec1[tid] = make_float4(cc, opacities[g], c.w, c.x);
+            rec2[tid] = make_float2(c.y, c.z);
+        }
+        __syncthreads();
+        const int batch_size = min(TILE_THREADS, range_end - batch_start);
+        for (int t = 0; t < batch_size; ++t) {
+            const float4 a = rec0[t];
+            const float4 b = rec1[t];
+            const float dx = a.x - px, dy = a.y - py;
+            const float sigma = 0.5f * (a.z * dx * dx + b.x * dy * dy) + a.w * dx * dy;
+            const float alpha = fminf(0.999f, b.y * __expf(-sigma));
+            const bool hit = !(b.z > cut) && !(sigma < 0.f) && !(alpha < 1.f / 255.f);
+            if (hit) {
+                const float2 gb = rec2[t];
+                o0 += b.w * alpha; o1 += gb.x * alpha; o2 += gb.y * alpha; o3 += b.z * alpha;
+                wsum += alpha;
+                cur_idx = batch_start + t;
+            }
+        }
+    }
+    if (inside) {
+        render_colors[pix] = make_float4(o0, o1, o2, o3);
+        render_alphas[pix] = wsum;
+        if (last_ids) last_ids[pix] = cur_idx;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restrict__ v_means2d,
+                                                        float* __restrict__ v_conics, float* __restrict__ v_colors,
+                                                        float* __restrict__ v_opacities) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < 4 * N; k += stride) {
+        v_colors[k] = 0.f;
+        if (k < 3 * N) v_conics[k] = 0.f;
+        if (k < 2 * N) v_means2d[k] = 0.f;
+        if (k < N) v_opacities[k] = 0.f;
+    }
+}
+
+// sum over the 32 lanes of a half-wave (xor offsets < 32 never cross the half boundary)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct Acc { float c0, c1, c2, c3, ka, kb, kc, mx, my, op; };
+
+__device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, float* __restrict__ v_means2d,
+                                          float* __restrict__ v_conics, float* __restrict__ v_colors,
+                                          float* __restrict__ v_opacities) {
+    float s0 = half_sum(a.c0), s1 = half_sum(a.c1), s2 = half_sum(a.c2), s3 = half_sum(a.c3);
+    float s4 = half_sum(a.ka), s5 = half_sum(a.kb), s6 = half_sum(a.kc);
+    float s7 = half_sum(a.mx), s8 = half_sum(a.my), s9 = half_sum(a.op);
+    if (g >= 0) {
+        // spread the 10 atomics over 10 lanes of the half instead of serialising them on lane 0
+        float v = hl == 0 ? s0 : hl == 1 ? s1 : hl == 2 ? s2 : hl == 3 ? s3 : hl == 4 ? s4 : hl == 5 ? s5
+                : hl == 6 ? s6 : hl == 7 ? s7 : hl == 8 ? s8 : s9;
+        float* dst = hl < 4 ? v_colors + 4 * (size_t)g + hl
+                   : hl < 7 ? v_conics + 3 * (size_t)g + (hl - 4)
+                   : hl < 9 ? v_means2d + 2 * (size_t)g + (hl - 7)
+                            : v_opacities + g;
+        if (hl < 10 && v != 0.f) atomicAdd(dst, v);
+    }
+    a.c0 = a.c1 = a.c2 = a.c3 = a.ka = a.kb = a.kc = a.mx = a.my = a.op = 0.f;
+}
+
+__global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
+    const int32_t* __restrict__ group_gs_ids, const int32_t* __restrict__ group_starts,
+    const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
+    const float* __restrict__ opacities, const int32_t* __restrict__ radiis, const float* __restrict__ ref_depth,
+    const int64_t* __restrict__ counts, float delta_depth, int W, int H, const float4* __restrict__ v_render_colors,
+    const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d, float* __restrict__ v_conics,
+    float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    const int n_groups = (int)counts[1];
+    const int n_tasks = (n_groups + 31) >> 5;  // 32 groups per wave task
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, hl = lane & 31;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+
+    for (int task = wave_global; task < n_tasks; task += n_waves) {
+        Acc acc;
+        acc.c0 = acc.c1 = acc.c2 = acc.c3 = acc.ka = acc.kb = acc.kc = acc.mx = acc.my = acc.op = 0.f;
+        int cur_g = -1;
+        // Gaussian parameters (uniform across the half-wave)
+        float gx = 0.f, gy = 0.f, opac = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+        float4 rgbd = make_float4(0.f, 0.f, 0.f, 0.f);
+        int x_min = 0, y_min = 0, y_max = 0, bw = 1;
+        const int first = task * 32 + half * 16;
+        for (int s = 0; s < 16; ++s) {
+            const int gid = first + s;
+            const bool live = gid < n_groups;
+            const int g = live ? group_gs_ids[gid] : -1;
+            // `g != cur_g` is uniform inside a 32-lane half; flush_acc only shuffles within the half,
+            // so the two halves may diverge here safely.
+            if (g != cur_g) {
+                flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
+                cur_g = g;
+                if (g >= 0) {
+                    const float2 xy = means2d[g];
+                    gx = xy.x; gy = xy.y;
+                    opac = opacities[g];
+                    ca = conics[3 * g]; cb = conics[3 * g + 1]; cc = conics[3 * g + 2];
+                    rgbd = colors[g];
+                    const int r = radiis[g];
+                    x_min = (int)gx - r; y_min = (int)gy - r; y_max = (int)gy + r;
+                    bw = 2 * r;  // x_max - x_min
+                }
+            }
+            if (g < 0) continue;
+            const uint32_t pid = (uint32_t)(gid - group_starts[gid]) * 32u + (uint32_t)hl;
+            const int j = x_min + 1 + (int)(pid % (uint32_t)bw);
+            const int i = y_min + 1 + (int)(pid / (uint32_t)bw);
+            bool valid = (i < H) && (j < W) && (i >= 0) && (j >= 0) && !(i > y_max);
+            if (valid) {
+                const int pix = i * W + j;
+                const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                const float dx = gx - px, dy = gy - py;
+                const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                const float vis = __expf(-sigma);
+                const float alpha = fminf(0.999f, opac * vis);
+                if (!(sigma < 0.f) && !(alpha < 1.f / 255.f) && !(rgbd.w > ref_depth[pix] + delta_depth)) {
+                    const float4 vc = v_render_colors[pix];
+                    acc.c0 += alpha * vc.x; acc.c1 += alpha * vc.y; acc.c2 += alpha * vc.z; acc.c3 += alpha * vc.w;
+                    float v_alpha = rgbd.x * vc.x + rgbd.y * vc.y + rgbd.z * vc.z + rgbd.w * vc.w + v_render_alphas[pix];
+                    if (opac * vis <= 0.999f) {
+                        const float v_sigma = -opac * vis * v_alpha;
+                        acc.ka += 0.5f * v_sigma * dx * dx;
+                        acc.kb += v_sigma * dx * dy;
+                        acc.kc += 0.5f * v_sigma * dy * dy;
+                        acc.mx += v_sigma * (ca * dx + cb * dy);
+                        acc.my += v_sigma * (cb * dx + cc * dy);
+                        acc.op += vis * v_alpha;
+                    }
+                }
+            }
+        }
+        flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_raster_ges_fwd(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                       const float* ref_depth_map, int width, int height, int tile_size, const int32_t* tile_offsets,
+                       const int32_t* flatten_ids, const int64_t* counts, float delta_depth, float* render_colors,
+                       float* render_alphas, int32_t* last_ids, gps_stream stream) {
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    GPS_REQUIRE(tile_size == 16);  // every shipped config uses 16 (raw_gs_model.h); other sizes are rejected loudly
+    GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
+    GPS_REQUIRE(N == 0 || (means2d && conics && colors && opacities));
+    const int tw = gps_div_up(width, tile_size), th = gps_div_up(height, tile_size);
+    raster_ges_fwd_kernel<16><<<tw * th, TILE_THREADS, 0, (hipStream_t)stream>>>(
+        (const float2*)means2d, conics, (const float4*)colors, opacities, ref_depth_map, width, height, tw, th,
+        tile_offsets, flatten_ids, counts, delta_depth, (float4*)render_colors, render_alphas, last_ids);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, const float* colors,
+                          const float* opacities, const int32_t* radii, const float* ref_depth_map, int width,
+                          int height, const int32_t* group_gs_ids, const int32_t* group_starts, const int64_t* counts,
+                          float delta_depth, const float* v_render_colors, const float* v_render_alphas,
+                          float* v_means2d, float* v_conics, float* v_colors, float* v_opacities, gps_stream stream) {
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means2d && conics && colors && opacities && radii && ref_depth_map && group_gs_ids && group_starts &&
+                counts && v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities);
+    hipStream_t s = (hipStream_t)stream;
+    zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
+                                                                                 v_opacities);
+    raster_ges_bwd_gs_kernel<<<2048, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
+                                                  (const float4*)colors, opacities, radii, ref_depth_map, counts,
+                                                  delta_depth, width, height, (const float4*)v_render_colors,
+                                                  v_render_alphas, v_means2d, v_conics, v_colors, v_opacities);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // extern "C"
