@@ -37,6 +37,9 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or _LIBPATH
+    # torch ships its own libamdhip64.so.7; it must be the (single) HIP runtime of the process so that the
+    # streams and device pointers torch hands us are valid inside libgpsslam_hip.so -> import torch first.
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise RuntimeError(
             "gps_slam_amd: %s not found. Build it with `python -m gps_slam_amd._build` "

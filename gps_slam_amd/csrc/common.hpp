@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/gps_slam_hip.h"
 
@@ -12,8 +13,15 @@
 #define GPS_LAUNCH_CHECK()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
-        if (e__ != hipSuccess) return GPS_ERR_LAUNCH;        \
+        if (e__ != hipSuccess) {                             \
+            fprintf(stderr, "[gps_slam_hip] %s:%d launch failed: %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return GPS_ERR_LAUNCH;                           \
+        }                                                    \
     } while (0)
+
+// hipGetLastError() is per-thread and shared with every other HIP user in the process (e.g. torch);
+// clear whatever was left behind so GPS_LAUNCH_CHECK only reports our own launches.
+#define GPS_ENTER() (void)hipGetLastError()
 
 #define GPS_REQUIRE(cond)                 \
     do {                                  \

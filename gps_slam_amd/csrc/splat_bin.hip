@@ -346,10 +346,11 @@ int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, 
                              int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids,
                              int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets, int64_t* counts,
                              void* workspace, int64_t workspace_bytes, gps_stream stream) {
+    GPS_ENTER();
     GPS_REQUIRE(N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
     GPS_REQUIRE(isect_capacity > 0 && isect_capacity < (1ll << 31) && group_capacity > 0 && group_capacity < (1ll << 31));
-    GPS_REQUIRE(tiles_per_gauss && flatten_ids && group_gs_ids && group_starts && tile_offsets && counts && workspace);
-    GPS_REQUIRE(N == 0 || (means2d && radii));
+    GPS_REQUIRE(flatten_ids && group_gs_ids && group_starts && tile_offsets && counts && workspace);
+    GPS_REQUIRE(N == 0 || (means2d && radii && tiles_per_gauss));
     const int n_tiles = tile_width * tile_height;
     GPS_REQUIRE(n_tiles <= (1 << 16));
     if (workspace_bytes < gps_isect_workspace_bytes(N, isect_capacity)) return GPS_ERR_CAPACITY;

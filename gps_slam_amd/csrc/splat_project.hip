@@ -134,6 +134,7 @@ extern "C" {
 int gps_proj_fwd(int N, const float* means, const float* quats, const float* scales, const float* viewmat,
                  const float* K, int width, int height, float eps2d, float near_plane, float far_plane,
                  float radius_clip, int32_t* radii, float* means2d, float* depths, float* conics, gps_stream stream) {
+    GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(means && quats && scales && viewmat && K && radii && means2d && depths && conics);
@@ -148,6 +149,7 @@ int gps_proj_bwd(int N, const float* means, const float* quats, const float* sca
                  const float* K, int width, int height, float eps2d, const int32_t* radii, const float* conics,
                  const float* v_means2d, const float* v_depths, const float* v_conics, float* v_means,
                  float* v_quats, float* v_scales, gps_stream stream) {
+    GPS_ENTER();
     (void)eps2d;
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
     if (N == 0) return GPS_OK;
@@ -162,6 +164,7 @@ int gps_proj_bwd(int N, const float* means, const float* quats, const float* sca
 
 int gps_sh_fwd(int N, int K, int degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks,
                float* colors, gps_stream stream) {
+    GPS_ENTER();
     GPS_REQUIRE(N >= 0 && degrees_to_use >= 0 && degrees_to_use <= 4 && K >= sh_num_bases(degrees_to_use));
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(dirs && coeffs && colors);
@@ -180,6 +183,7 @@ int gps_sh_fwd(int N, int K, int degrees_to_use, const float* dirs, const float*
 
 int gps_sh_bwd(int N, int K, int degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks,
                const float* v_colors, float* v_coeffs, float* v_dirs, gps_stream stream) {
+    GPS_ENTER();
     GPS_REQUIRE(N >= 0 && degrees_to_use >= 0 && degrees_to_use <= 4 && K >= sh_num_bases(degrees_to_use));
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(dirs && coeffs && v_colors && v_coeffs);

@@ -215,6 +215,7 @@ int gps_raster_ges_fwd(int N, const float* means2d, const float* conics, const f
                        const float* ref_depth_map, int width, int height, int tile_size, const int32_t* tile_offsets,
                        const int32_t* flatten_ids, const int64_t* counts, float delta_depth, float* render_colors,
                        float* render_alphas, int32_t* last_ids, gps_stream stream) {
+    GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
     GPS_REQUIRE(tile_size == 16);  // every shipped config uses 16 (raw_gs_model.h); other sizes are rejected loudly
     GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
@@ -232,6 +233,7 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
                           int height, const int32_t* group_gs_ids, const int32_t* group_starts, const int64_t* counts,
                           float delta_depth, const float* v_render_colors, const float* v_render_alphas,
                           float* v_means2d, float* v_conics, float* v_colors, float* v_opacities, gps_stream stream) {
+    GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(means2d && conics && colors && opacities && radii && ref_depth_map && group_gs_ids && group_starts &&

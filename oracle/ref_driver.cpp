@@ -1,0 +1,202 @@
+// ref_driver.cpp -- drives the REFERENCE's own ITMLib CPU engine (compiled from
+// /root/reference by oracle/ref_build.sh) over a synthetic RGB-D sequence and dumps
+// everything the TSDF parity tests compare against.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is original code; it only *uses* the reference's public C++ API the way
+// slam/InfiniTAM_tools.cpp:3-67 and slam/slam_pipeline.cpp:362-371 do
+// (ITMBasicEngine ctor, turnOffTracking, gtC2wPoses, ProcessFrame, runRaycast,
+// GetFreeImage/GetFreeVertex).  Private render-state members are read through the
+// usual `#define private public` test hack -- no reference source is modified.
+//
+// usage: itm_ref <input.bin> <output.bin>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <stdexcept>
+#include <limits>
+
+#define private public
+#define protected public
+#include "ITMLib/ITMLibDefines.h"
+#include "ITMLib/Core/ITMBasicEngine.h"
+#include "ITMLib/Objects/RenderStates/ITMRenderState_VH.h"
+#undef private
+#undef protected
+
+using namespace ITMLib;
+
+static FILE *g_out;
+
+static void chunk(const char *name, int frame, const void *data, int64_t nbytes) {
+    char nm[32];
+    memset(nm, 0, sizeof(nm));
+    strncpy(nm, name, 31);
+    fwrite(nm, 1, 32, g_out);
+    int32_t f = frame;
+    fwrite(&f, 4, 1, g_out);
+    fwrite(&nbytes, 8, 1, g_out);
+    if (nbytes) fwrite(data, 1, (size_t)nbytes, g_out);
+}
+
+static uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+
+struct Header {
+    int32_t magic, W, H, nframes, nfree, dump_vba_every;
+    float fx, fy, cx, cy, voxel, mu, vfmin, vfmax;
+};
+
+typedef ITMBasicEngine<ITMVoxel, ITMVoxelIndex> Engine;
+
+static void dump_scene(Engine *eng, int frame, bool full_vba) {
+    ITMScene<ITMVoxel, ITMVoxelIndex> *scene = eng->GetScene();
+    const ITMHashEntry *ht = scene->index.GetEntries();
+    const ITMVoxel *vba = scene->localVBA.GetVoxelBlocks();
+    const int total = ITMVoxelBlockHash::noTotalEntries;
+    std::vector<int32_t> rows;
+    uint32_t crc = 0;
+    std::vector<unsigned char> blocks;
+    for (int i = 0; i < total; i++) {
+        const ITMHashEntry &e = ht[i];
+        if (e.ptr == -2 && e.offset == 0 && e.pos.x == 0 && e.pos.y == 0 && e.pos.z == 0) continue;
+        rows.push_back(i); rows.push_back(e.pos.x); rows.push_back(e.pos.y); rows.push_back(e.pos.z);
+        rows.push_back(e.offset); rows.push_back(e.ptr);
+        if (e.ptr >= 0) {
+            const unsigned char *b = (const unsigned char *)(vba + (size_t)e.ptr * SDF_BLOCK_SIZE3);
+            for (int v = 0; v < SDF_BLOCK_SIZE3; v++) crc = crc32_update(crc, b + v * sizeof(ITMVoxel), 7);  // skip the pad byte
+            if (full_vba) blocks.insert(blocks.end(), b, b + sizeof(ITMVoxel) * SDF_BLOCK_SIZE3);
+        }
+    }
+    chunk("hash", frame, rows.data(), (int64_t)rows.size() * 4);
+    chunk("vba_crc", frame, &crc, 4);
+    if (full_vba) chunk("vba", frame, blocks.data(), (int64_t)blocks.size());
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 2; }
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) { perror("input"); return 2; }
+    g_out = fopen(argv[2], "wb");
+    Header h;
+    if (fread(&h, sizeof(h), 1, in) != 1 || h.magic != 0x47505331) { fprintf(stderr, "bad header\n"); return 2; }
+    const int P = h.W * h.H;
+    int32_t sizes[2] = {(int32_t)sizeof(ITMVoxel), (int32_t)sizeof(ITMHashEntry)};
+    chunk("sizeof", -1, sizes, 8);
+
+    ITMRGBDCalib calib;
+    calib.intrinsics_rgb.SetFrom(h.W, h.H, h.fx, h.fy, h.cx, h.cy);
+    calib.intrinsics_d = calib.intrinsics_rgb;
+    calib.disparityCalib.SetStandard();
+
+    ITMLibSettings *settings = new ITMLibSettings();
+    settings->deviceType = ITMLibSettings::DEVICE_CPU;
+    settings->createMeshingEngine = false;
+    settings->sceneParams.voxelSize = h.voxel;
+    settings->sceneParams.mu = h.mu;
+    settings->sceneParams.viewFrustum_min = h.vfmin;
+    settings->sceneParams.viewFrustum_max = h.vfmax;
+
+    Vector2i dims(h.W, h.H);
+    Engine *eng = new Engine(settings, calib, dims, dims);
+    eng->turnOffTracking();
+
+    std::vector<ITMUChar4Image *> rgbs(h.nframes);
+    std::vector<ITMShortImage *> depths(h.nframes);
+    std::vector<ORUtils::Matrix4<float> *> poses(h.nframes);
+    for (int f = 0; f < h.nframes; f++) {
+        rgbs[f] = new ITMUChar4Image(dims, true, false);
+        depths[f] = new ITMShortImage(dims, true, false);
+        if (fread(rgbs[f]->GetData(MEMORYDEVICE_CPU), 4, P, in) != (size_t)P) return 3;
+        if (fread(depths[f]->GetData(MEMORYDEVICE_CPU), 2, P, in) != (size_t)P) return 3;
+        float c2w[16];
+        if (fread(c2w, 4, 16, in) != 16) return 3;
+        // row-major 4x4 -> ORUtils column-major storage (cv_utils tensorToInfiMatrix4 does the same transpose)
+        ORUtils::Matrix4<float> *m = new ORUtils::Matrix4<float>();
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) m->m[c * 4 + r] = c2w[r * 4 + c];
+        poses[f] = m;
+    }
+    struct Free { int32_t frame; float c2w[16]; };
+    std::vector<Free> frees(h.nfree);
+    for (int k = 0; k < h.nfree; k++) {
+        if (fread(&frees[k].frame, 4, 1, in) != 1) return 3;
+        if (fread(frees[k].c2w, 4, 16, in) != 16) return 3;
+    }
+    fclose(in);
+    eng->gtC2wPoses = poses;
+
+    for (int f = 0; f < h.nframes; f++) {
+        eng->ProcessFrame(rgbs[f], depths[f]);
+        ITMTrackingState *ts = eng->GetTrackingState();
+        ORUtils::Matrix4<float> M = ts->pose_d->GetM(), invM = ts->pose_d->GetInvM();
+        chunk("M", f, M.m, 64);
+        chunk("invM", f, invM.m, 64);
+        ITMRenderState_VH *rs = (ITMRenderState_VH *)eng->renderState_live;
+        ITMScene<ITMVoxel, ITMVoxelIndex> *scene = eng->GetScene();
+        int32_t counts[3] = {rs->noVisibleEntries, scene->localVBA.lastFreeBlockId, scene->index.GetLastFreeExcessListId()};
+        chunk("counts", f, counts, 12);
+        chunk("visible_ids", f, rs->GetVisibleEntryIDs(), (int64_t)rs->noVisibleEntries * 4);
+        {
+            const unsigned char *vt = rs->GetEntriesVisibleType();
+            std::vector<int32_t> nz;
+            for (int i = 0; i < ITMVoxelBlockHash::noTotalEntries; i++)
+                if (vt[i]) { nz.push_back(i); nz.push_back(vt[i]); }
+            chunk("vis_type_nz", f, nz.data(), (int64_t)nz.size() * 4);
+        }
+        bool full = (h.dump_vba_every > 0 && ((f + 1) % h.dump_vba_every == 0)) || f == h.nframes - 1;
+        dump_scene(eng, f, full);
+        chunk("depth_f", f, eng->GetView()->depth->GetData(MEMORYDEVICE_CPU), (int64_t)P * 4);
+        chunk("minmax", f, rs->renderingRangeImage->GetData(MEMORYDEVICE_CPU), (int64_t)P * 8);
+        chunk("raycast", f, rs->raycastResult->GetData(MEMORYDEVICE_CPU), (int64_t)P * 16);
+        chunk("icp_points", f, ts->pointCloud->locations->GetData(MEMORYDEVICE_CPU), (int64_t)P * 16);
+        chunk("icp_normals", f, ts->pointCloud->colours->GetData(MEMORYDEVICE_CPU), (int64_t)P * 16);
+
+        for (int k = 0; k < h.nfree; k++) {
+            if (frees[k].frame != f) continue;
+            // slam_pipeline.cpp:362-371 path: SE3Pose from the stored pose, then runRaycast(pose, intrinsics)
+            ORUtils::Matrix4<float> c2w;
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) c2w.m[c * 4 + r] = frees[k].c2w[r * 4 + c];
+            ORUtils::SE3Pose pose;
+            pose.SetInvM(c2w);
+            pose.Coerce();
+            ITMIntrinsics intr = calib.intrinsics_d;
+            eng->runRaycast(&pose, &intr);
+            ITMRenderState_VH *fs = (ITMRenderState_VH *)eng->renderState_freeview;
+            ORUtils::Matrix4<float> fM = pose.GetM(), fInv = pose.GetInvM();
+            int tag = f * 1000 + k;
+            chunk("fv_M", tag, fM.m, 64);
+            chunk("fv_invM", tag, fInv.m, 64);
+            int32_t nv = fs->noVisibleEntries;
+            chunk("fv_counts", tag, &nv, 4);
+            chunk("fv_visible_ids", tag, fs->GetVisibleEntryIDs(), (int64_t)nv * 4);
+            chunk("fv_minmax", tag, fs->renderingRangeImage->GetData(MEMORYDEVICE_CPU), (int64_t)P * 8);
+            chunk("fv_raycast", tag, eng->GetFreeVertex()->GetData(MEMORYDEVICE_CPU), (int64_t)P * 16);
+            chunk("fv_colour", tag, eng->GetFreeImage()->GetData(MEMORYDEVICE_CPU), (int64_t)P * 4);
+        }
+    }
+    fclose(g_out);
+    return 0;
+}

@@ -6,6 +6,8 @@ Tolerances (fp32 work; the reference itself uses fast-math intrinsics and float 
   gradients                     rtol 2e-3, atol 2e-4 * max|ref|
 Integer outputs of the binning (tile counts, sorted ids, group table, offsets) are bit-exact.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -166,8 +168,13 @@ def test_raster_ges_fwd_bwd(N, W, H):
     tm2, tcon, tcol, top, tref = T(m2)[None], T(conics)[None], T(colors)[None], T(opac)[:, None], T(ref_depth)[None, ..., None]
     rc, ra, last = ops.rasterize_to_pixels_fwd_ges(tm2, tcon, tcol, top, tref, W, H, TS, isect, delta,
                                                    want_last_ids=True)
-    np.testing.assert_allclose(N_(rc)[0], e_rc, rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(N_(ra)[0, ..., 0], e_ra, rtol=2e-4, atol=2e-4)
+    # a (pixel, Gaussian) pair whose alpha sits within an ulp of 1/255 can be kept by expf and dropped by
+    # __expf (or vice versa): such a flip moves a pixel by <= alpha*colour ~ 4e-3*|c|.  Allow <= 1e-5 of the
+    # pixels to differ by that much, everything else must agree to rounding.
+    for got, ref in ((N_(rc)[0], e_rc), (N_(ra)[0, ..., 0], e_ra)):
+        bad = np.abs(got - ref) > (2e-4 * np.abs(ref) + 2e-4)
+        assert bad.mean() <= 1e-5, bad.mean()
+        assert np.abs(got - ref).max() < 0.05
     assert (N_(last)[0] == e_last).mean() > 0.999
     assert e_ra.max() > 1.0  # the scene actually covers pixels
     rng = np.random.default_rng(3)
@@ -252,8 +259,8 @@ def test_adam_matches_libtorch_sequence():
             bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
             m.mul_(b1).add_(g, alpha=1 - b1)
             v.mul_(b2).addcmul_(g, g, value=1 - b2)
-            denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)  # libtorch: std::sqrt(bias_correction2)
             p.addcdiv_(m, denom, value=-(lr / bc1))
         ops.adam_step(P, G, M, V, lrs, step, (b1, b2), eps)
         for a, b in zip(P + M + V, Pe + Me + Ve):
-            torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-12)
+            assert torch.equal(a, b), "fused Adam must be bit-identical to the ATen op sequence"
