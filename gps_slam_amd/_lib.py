@@ -10,6 +10,17 @@ _lib = None
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
 
+class TsdfState(C.Structure):
+    """gps_tsdf_state (include/gps_slam_hip.h)"""
+    _fields_ = [("width", i32), ("height", i32), ("fx", f32), ("fy", f32), ("cx", f32), ("cy", f32),
+                ("voxel_size", f32), ("mu", f32), ("view_frustum_min", f32), ("view_frustum_max", f32),
+                ("max_w", i32), ("n_blocks", i32), ("n_buckets", i32), ("n_excess", i32),
+                ("vba", vp), ("vba_alloc_list", vp), ("hash", vp), ("excess_list", vp), ("counters", vp),
+                ("alloc_prio", vp), ("scan_scratch", vp), ("visible_type", vp), ("visible_ids", vp), ("depth", vp),
+                ("rgb", vp), ("minmax", vp), ("raycast", vp), ("icp_points", vp), ("icp_normals", vp),
+                ("fv_visible_ids", vp), ("fv_minmax", vp), ("fv_raycast", vp), ("fv_colour", vp)]
+
+
 class AdamSegment(C.Structure):
     _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", f64)]
 
@@ -28,6 +39,18 @@ PROTOTYPES = {
                                     vp]),
     "gps_compose_l1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_adam_step": (i32, [C.POINTER(AdamSegment), i32, f64, f64, f64, i32, vp]),
+    "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
+    "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),
+    "gps_tsdf_allocate": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
+    "gps_tsdf_integrate": (i32, [C.POINTER(TsdfState), vp, vp]),
+    "gps_tsdf_expected_depths": (i32, [C.POINTER(TsdfState), vp, i32, vp]),
+    "gps_tsdf_raycast": (i32, [C.POINTER(TsdfState), vp, i32, i32, vp]),
+    "gps_tsdf_icp_maps": (i32, [C.POINTER(TsdfState), vp, vp]),
+    "gps_tsdf_find_visible": (i32, [C.POINTER(TsdfState), vp, vp]),
+    "gps_tsdf_render_colour": (i32, [C.POINTER(TsdfState), vp]),
+    "gps_tsdf_process_frame": (i32, [C.POINTER(TsdfState), vp, vp, vp, vp]),
+    "gps_tsdf_free_raycast": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
+    "gps_pose_from_c2w": (i32, [vp, vp, vp]),
 }
 
 

@@ -1,0 +1,460 @@
+// TSDF voxel-block-hash fusion for gfx950: depth conversion, hash allocation + visible list,
+// integration.  Compiled with -ffp-contract=off: voxel updates end in a truncating (short)(x*32767)
+// store, so every mul/add must round exactly like the CPU engine (IEEE div/sqrt are hipcc defaults).
+//
+// What each kernel computes follows the reference's per-element code
+//   InfiniTAM/ITMLib/Engines/Reconstruction/Shared/ITMSceneReconstructionEngine_Shared.h
+// (line-level restatement: oracle/tsdf_oracle.c).  How it is parallelised is new:
+//
+//  * Allocation is DETERMINISTIC.  The reference CUDA kernel lets racing pixels overwrite
+//    entriesAllocType/blockCoords (last writer wins, order undefined) and hands out blocks with
+//    atomicSub (order undefined).  Here each pixel posts atomicMax(prio[slot], (pixel, step)) so
+//    the winner is the last requester in scan order -- exactly what the single-threaded CPU
+//    engine produces -- and the winner's block coordinates are re-derived from (pixel, step) in
+//    the allocation sweep.  Blocks / excess entries are handed out by an ordered prefix sum over
+//    the hash slots (ascending slot index, like ITMSceneReconstructionEngine_CPU.tpp:196-265),
+//    so even `ptr` and `offset` match the CPU engine bit for bit.
+//  * The visible list is built by an ordered stream compaction (count -> scan -> write) and stays
+//    on the device: nothing is copied back to size the next launch (the reference blocks on a
+//    12-byte cudaMemcpy, ..._CUDA.tcu:197); dependent kernels are persistent and grid-stride
+//    over counters[GPS_TSDF_N_VISIBLE].
+//  * Integration: one 512-thread workgroup (8 wave64) per visible block, one voxel per lane, the
+//    4 KiB block streams through registers as coalesced 8-byte lanes (512 B per wave access).
+#include "tsdf_common.hpp"
+
+using namespace gpst;
+
+namespace {
+
+// ---------------------------------------------------------------- reset
+__global__ __launch_bounds__(256) void reset_kernel(TsdfState s) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nvox = (int64_t)s.n_blocks * BLK3;
+    const uint64_t empty = 0x0000000000007FFFull;  // sdf = 32767, everything else 0
+    uint64_t* v = reinterpret_cast<uint64_t*>(s.vba);
+    for (int64_t i = tid; i < nvox; i += stride) v[i] = empty;
+    const int n_total = s.n_buckets + s.n_excess;
+    for (int64_t i = tid; i < n_total; i += stride) {
+        gps_hash_entry e;
+        e.pos[0] = e.pos[1] = e.pos[2] = 0; e.pad_ = 0; e.offset = 0; e.ptr = -2;
+        s.hash[i] = e;
+        s.visible_type[i] = 0;
+        s.alloc_prio[i] = 0u;
+    }
+    for (int64_t i = tid; i < s.n_blocks; i += stride) s.vba_alloc_list[i] = (int32_t)i;
+    for (int64_t i = tid; i < s.n_excess; i += stride) s.excess_list[i] = (int32_t)i;
+    if (tid < 16) {
+        int v0 = 0;
+        if (tid == GPS_TSDF_LAST_FREE_BLOCK) v0 = s.n_blocks - 1;
+        if (tid == GPS_TSDF_LAST_FREE_EXCESS) v0 = s.n_excess - 1;
+        s.counters[tid] = v0;
+    }
+}
+
+// ---------------------------------------------------------------- view building
+__global__ __launch_bounds__(256) void convert_depth_kernel(int P, const int16_t* __restrict__ in, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    int16_t d = in[i];
+    out[i] = d <= 0 ? -1.0f : (float)d * (1.0f / 1000.0f) + 0.0f;
+}
+
+// ---------------------------------------------------------------- allocation requests
+// Steps along the truncation band of one depth pixel (Shared.h:207-323).  The geometry is
+// recomputed by the allocation sweep from (loc, step) via the same function, so both see the
+// identical fp32 sequence.
+struct BandWalk {
+    float px, py, pz;      // current point in block units
+    float dx, dy, dz;
+    int n_steps;
+};
+
+__device__ __forceinline__ bool band_begin(const TsdfState& s, const Mat4& invM, int x, int y, BandWalk& w) {
+    const float depth_measure = s.depth[x + y * s.width];
+    const float mu = s.mu;
+    if (depth_measure <= 0 || (depth_measure - mu) < 0 || (depth_measure - mu) < s.view_frustum_min ||
+        (depth_measure + mu) > s.view_frustum_max)
+        return false;
+    const float inv_fx = 1.0f / s.fx, inv_fy = 1.0f / s.fy;
+    const float oneOverVoxelSize = 1.0f / (s.voxel_size * BLK);
+    float cz = depth_measure;
+    float cx = cz * (((float)x - s.cx) * inv_fx);
+    float cy = cz * (((float)y - s.cy) * inv_fy);
+    float norm = sqrtf(cx * cx + cy * cy + cz * cz);
+    float sc = 1.0f - mu / norm;
+    float qx, qy, qz;
+    mul_point(invM, cx * sc, cy * sc, cz * sc, 1.0f, qx, qy, qz);
+    w.px = qx * oneOverVoxelSize; w.py = qy * oneOverVoxelSize; w.pz = qz * oneOverVoxelSize;
+    sc = 1.0f + mu / norm;
+    mul_point(invM, cx * sc, cy * sc, cz * sc, 1.0f, qx, qy, qz);
+    float ex = qx * oneOverVoxelSize, ey = qy * oneOverVoxelSize, ez = qz * oneOverVoxelSize;
+    w.dx = ex - w.px; w.dy = ey - w.py; w.dz = ez - w.pz;
+    norm = sqrtf(w.dx * w.dx + w.dy * w.dy + w.dz * w.dz);
+    w.n_steps = (int)ceilf(2.0f * norm);
+    const float dn = (float)(w.n_steps - 1);
+    w.dx /= dn; w.dy /= dn; w.dz /= dn;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void mark_previous_visible_kernel(TsdfState s) {
+    const int n = s.counters[GPS_TSDF_N_VISIBLE];
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s.visible_type[s.visible_ids[i]] = 3;
+}
+
+__global__ __launch_bounds__(256) void alloc_request_kernel(TsdfState s, Mat4 invM) {
+    const int loc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (loc >= s.width * s.height) return;
+    const int y = loc / s.width, x = loc - y * s.width;
+    BandWalk w;
+    if (!band_begin(s, invM, x, y, w)) return;
+    const int steps = min(w.n_steps, MAX_BAND_STEPS);
+    for (int i = 0; i < steps; i++) {
+        const int bx = (int)(short)floorf(w.px), by = (int)(short)floorf(w.py), bz = (int)(short)floorf(w.pz);
+        int hashIdx = hash_index(bx, by, bz, s.n_buckets - 1);
+        gps_hash_entry he = s.hash[hashIdx];
+        bool found = false;
+        if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
+            s.visible_type[hashIdx] = (he.ptr == -1) ? 2 : 1;
+            found = true;
+        }
+        if (!found) {
+            if (he.ptr >= -1) {
+                while (he.offset >= 1) {
+                    hashIdx = s.n_buckets + he.offset - 1;
+                    he = s.hash[hashIdx];
+                    if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
+                        s.visible_type[hashIdx] = (he.ptr == -1) ? 2 : 1;
+                        found = true;
+                        break;
+                    }
+                }
+            }
+            // last requester in (pixel, step) order wins the slot, like the sequential CPU loop
+            if (!found) atomicMax(&s.alloc_prio[hashIdx], ((uint32_t)(loc + 1) << BAND_STEP_BITS) | (uint32_t)i);
+        }
+        w.px += w.dx; w.py += w.dy; w.pz += w.dz;
+    }
+}
+
+// ---------------------------------------------------------------- ordered sweeps over the hash slots
+constexpr int SWEEP = 1024;  // slots per workgroup
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* ws /*[17]*/, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = wave_incl_scan_i(v);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int sv = lane < 16 ? ws[lane] : 0;
+        int si = wave_incl_scan_i(sv);
+        if (lane < 16) ws[lane] = si - sv;
+        if (lane == 63) ws[16] = si;
+    }
+    __syncthreads();
+    int r = ws[wave] + incl - v;
+    total = ws[16];
+    __syncthreads();
+    return r;
+}
+
+// request type of a slot given the PRE-allocation table: empty bucket -> 1 (ordered), occupied chain end -> 2
+__device__ __forceinline__ int request_type(const TsdfState& s, int idx) {
+    if (s.alloc_prio[idx] == 0u) return 0;
+    return s.hash[idx].ptr < -1 ? 1 : 2;
+}
+
+__global__ __launch_bounds__(SWEEP) void alloc_count_kernel(TsdfState s, int32_t* __restrict__ blk1, int32_t* __restrict__ blk2) {
+    __shared__ int ws[17];
+    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    const int n_total = s.n_buckets + s.n_excess;
+    const int t = idx < n_total ? request_type(s, idx) : 0;
+    int tot1, tot2;
+    block_excl_scan_1024(t == 1, ws, tot1);
+    block_excl_scan_1024(t == 2, ws, tot2);
+    if (threadIdx.x == 0) { blk1[blockIdx.x] = tot1; blk2[blockIdx.x] = tot2; }
+}
+
+// single workgroup: exclusive scan of up to two arrays of per-block counts, totals to out_tot[0..1]
+__global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __restrict__ a, int32_t* __restrict__ b,
+                                                          int32_t* __restrict__ out_tot) {
+    __shared__ int ws[17];
+    const int per = (nblk + 1023) / 1024;
+    const int lo = min(nblk, (int)threadIdx.x * per), hi = min(nblk, lo + per);
+    for (int which = 0; which < 2; which++) {
+        int32_t* arr = which == 0 ? a : b;
+        if (arr == nullptr) continue;
+        int sum = 0;
+        for (int k = lo; k < hi; k++) sum += arr[k];
+        int total;
+        int run = block_excl_scan_1024(sum, ws, total);
+        for (int k = lo; k < hi; k++) { int v = arr[k]; arr[k] = run; run += v; }
+        if (threadIdx.x == 0) out_tot[which] = total;
+    }
+}
+
+__global__ __launch_bounds__(SWEEP) void alloc_apply_kernel(TsdfState s, Mat4 invM, const int32_t* __restrict__ blk1,
+                                                           const int32_t* __restrict__ blk2) {
+    __shared__ int ws[17];
+    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    const int n_total = s.n_buckets + s.n_excess;
+    const uint32_t prio = idx < n_total ? s.alloc_prio[idx] : 0u;
+    const int t = prio == 0u ? 0 : (s.hash[idx].ptr < -1 ? 1 : 2);
+    int tot;
+    const int c1 = blk1[blockIdx.x] + block_excl_scan_1024(t == 1, ws, tot);
+    const int c2 = blk2[blockIdx.x] + block_excl_scan_1024(t == 2, ws, tot);
+    if (t == 0) return;
+    s.alloc_prio[idx] = 0u;  // leave the scratch clean for the next frame
+    // state of the sequential allocator when it reaches this slot (CPU.tpp:196-265): every earlier
+    // type-1 request and the first E type-2 requests consumed one voxel block each.
+    const int lastBlock = s.counters[GPS_TSDF_LAST_FREE_BLOCK], lastExcess = s.counters[GPS_TSDF_LAST_FREE_EXCESS];
+    const int E = lastExcess + 1;
+    const int vbaIdx = lastBlock - (c1 + min(c2, E));
+    const int exlIdx = lastExcess - c2;
+    // winner's block coordinates, re-derived from (pixel, step)
+    const int loc = (int)(prio >> BAND_STEP_BITS) - 1, step = (int)(prio & ((1u << BAND_STEP_BITS) - 1u));
+    const int y = loc / s.width, x = loc - y * s.width;
+    BandWalk w;
+    band_begin(s, invM, x, y, w);
+    for (int i = 0; i < step; i++) { w.px += w.dx; w.py += w.dy; w.pz += w.dz; }
+    gps_hash_entry ne;
+    ne.pos[0] = (short)floorf(w.px); ne.pos[1] = (short)floorf(w.py); ne.pos[2] = (short)floorf(w.pz);
+    ne.pad_ = 0; ne.offset = 0;
+    if (t == 1) {
+        if (vbaIdx >= 0) {
+            ne.ptr = s.vba_alloc_list[vbaIdx];
+            s.hash[idx] = ne;
+            s.visible_type[idx] = 1;  // "new entry is visible" (Shared.h:311)
+            atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
+        } else {
+            s.visible_type[idx] = 0;
+        }
+    } else {
+        if (vbaIdx >= 0 && exlIdx >= 0) {
+            ne.ptr = s.vba_alloc_list[vbaIdx];
+            const int exlOffset = s.excess_list[exlIdx];
+            s.hash[idx].offset = exlOffset + 1;
+            s.hash[s.n_buckets + exlOffset] = ne;
+            s.visible_type[s.n_buckets + exlOffset] = 1;
+            atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
+            atomicAdd(&s.counters[GPS_TSDF_SCRATCH1], 1);
+        }
+    }
+}
+
+// visibility predicates for the two ordered compactions
+enum { VIS_LIVE = 0, VIS_FREE = 1 };
+
+template <int MODE>
+__device__ __forceinline__ bool slot_visible(const TsdfState& s, const Mat4& M, int idx, bool update) {
+    if (MODE == VIS_LIVE) {
+        // CPU.tpp:268-306: type 3 (visible last frame) is re-tested against the frustum, types 1/2 stay
+        uint8_t vt = s.visible_type[idx];
+        if (vt == 3) {
+            const gps_hash_entry he = s.hash[idx];
+            if (!block_visible(s, M, he.pos[0], he.pos[1], he.pos[2])) vt = 0;
+            if (update) s.visible_type[idx] = vt;
+        }
+        return vt > 0;
+    } else {
+        // Visualisation CPU.tpp:36-74 / buildCompleteVisibleList_device: every allocated block inside the frustum
+        const gps_hash_entry he = s.hash[idx];
+        return he.ptr >= 0 && block_visible(s, M, he.pos[0], he.pos[1], he.pos[2]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SWEEP) void visible_count_kernel(TsdfState s, Mat4 M, int32_t* __restrict__ blk,
+                                                             uint8_t* __restrict__ flags) {
+    __shared__ int ws[17];
+    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    const int n_total = s.n_buckets + s.n_excess;
+    if (MODE == VIS_LIVE && blockIdx.x == 0 && threadIdx.x == 0) {
+        // fold the allocation bookkeeping of this frame into the counters (ordered after alloc_apply)
+        s.counters[GPS_TSDF_LAST_FREE_BLOCK] -= s.counters[GPS_TSDF_SCRATCH0];
+        s.counters[GPS_TSDF_LAST_FREE_EXCESS] -= s.counters[GPS_TSDF_SCRATCH1];
+        s.counters[GPS_TSDF_SCRATCH0] = 0;
+        s.counters[GPS_TSDF_SCRATCH1] = 0;
+    }
+    const bool v = idx < n_total ? slot_visible<MODE>(s, M, idx, true) : false;
+    if (idx < n_total) flags[idx] = v ? 1 : 0;
+    int tot;
+    block_excl_scan_1024(v ? 1 : 0, ws, tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const int32_t* __restrict__ blk,
+                                                             const uint8_t* __restrict__ flags,
+                                                             int32_t* __restrict__ out_ids, int cap) {
+    __shared__ int ws[17];
+    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    const int n_total = s.n_buckets + s.n_excess;
+    const bool v = idx < n_total ? flags[idx] != 0 : false;
+    int tot;
+    const int pos = blk[blockIdx.x] + block_excl_scan_1024(v ? 1 : 0, ws, tot);
+    if (v && pos < cap) out_ids[pos] = idx;
+}
+
+// ---------------------------------------------------------------- integration
+__global__ __launch_bounds__(BLK3) void integrate_kernel(TsdfState s, Mat4 M) {
+    const int n_visible = s.counters[GPS_TSDF_N_VISIBLE];
+    const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7, lz = threadIdx.x >> 6;
+    const int W = s.width, H = s.height;
+    const float mu = s.mu;
+    for (int e = blockIdx.x; e < n_visible; e += gridDim.x) {
+        const gps_hash_entry he = s.hash[s.visible_ids[e]];
+        if (he.ptr < 0) continue;  // uniform across the workgroup
+        uint64_t* slot = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + threadIdx.x;
+        const float pmx = (float)(he.pos[0] * BLK + lx) * s.voxel_size;
+        const float pmy = (float)(he.pos[1] * BLK + ly) * s.voxel_size;
+        const float pmz = (float)(he.pos[2] * BLK + lz) * s.voxel_size;
+        float cx, cy, cz;
+        mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
+        if (cz <= 0) continue;
+        const float ix = s.fx * cx / cz + s.cx, iy = s.fy * cy / cz + s.cy;
+        if ((ix < 1) || (ix > W - 2) || (iy < 1) || (iy > H - 2)) continue;
+        const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
+        if (dm <= 0.0f) continue;
+        const float eta = dm - cz;
+        if (eta < -mu) continue;
+        uint64_t raw = *slot;
+        // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
+        const int16_t sdf = (int16_t)(raw & 0xFFFF);
+        const int oldW = (int)((raw >> 16) & 0xFF);
+        float oldF = (float)sdf / 32767.0f;
+        float newF = (1.0f < eta / mu) ? 1.0f : eta / mu;
+        int newW = 1;
+        newF = oldW * oldF + newW * newF;
+        newW = oldW + newW;
+        newF /= newW;
+        newW = (newW < s.max_w) ? newW : s.max_w;
+        raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
+        if (!((eta > mu) || (fabsf(eta / mu) > 0.25f))) {
+            // colour: rgb camera == depth camera (trafo_rgb_to_depth is identity, InfiniTAM_tools.cpp:6-10)
+            const float rx = ix, ry = iy;  // same projection, same rounding sequence
+            if (!((rx < 1) || (rx > W - 2) || (ry < 1) || (ry > H - 2))) {
+                const int px = (int)floorf(rx), py = (int)floorf(ry);
+                const float dx = rx - (float)px, dy = ry - (float)py;
+                const uchar4* img = reinterpret_cast<const uchar4*>(s.rgb);
+                const uchar4 a = img[px + py * W];
+                uchar4 b = make_uchar4(0, 0, 0, 0), c = b, d = b;
+                if (dx != 0) b = img[(px + 1) + py * W];
+                if (dy != 0) c = img[px + (py + 1) * W];
+                if (dx != 0 && dy != 0) d = img[(px + 1) + (py + 1) * W];
+                const float oldWc = (float)((raw >> 48) & 0xFF);
+                const float sumW = oldWc + 1.0f;
+                const float maxWf = (float)(uint8_t)s.max_w;
+                const float cw = (sumW < maxWf) ? sumW : maxWf;
+                uint64_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float fa = k == 0 ? a.x : k == 1 ? a.y : a.z, fb = k == 0 ? b.x : k == 1 ? b.y : b.z;
+                    const float fc = k == 0 ? c.x : k == 1 ? c.y : c.z, fd = k == 0 ? d.x : k == 1 ? d.y : d.z;
+                    // ((a*(1-dx))*(1-dy) + (b*dx)*(1-dy)) + (c*(1-dx))*dy) + (d*dx)*dy  (ITMPixelUtils.h:25-26)
+                    const float m = ((fa * (1.0f - dx) * (1.0f - dy) + fb * dx * (1.0f - dy)) + fc * (1.0f - dx) * dy) +
+                                    fd * dx * dy;
+                    const float meas = m / 255.0f;
+                    const float oldC = (float)((raw >> (24 + 8 * k)) & 0xFF) / 255.0f;
+                    float newC = oldC * oldWc + meas * 1.0f;
+                    newC /= sumW;
+                    const float sc = newC * 255.0f;
+                    int vi = (int)((sc < 0) ? (sc - 0.5f) : (sc + 0.5f));
+                    vi = max(0, min(255, vi));
+                    packed |= (uint64_t)vi << (24 + 8 * k);
+                }
+                raw = (raw & ~0x00FFFFFFFF000000ull) | packed | ((uint64_t)(uint8_t)cw << 48);
+            }
+        }
+        *slot = raw;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_tsdf_reset(const gps_tsdf_state* sp, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    reset_kernel<<<4096, 256, 0, (hipStream_t)stream>>>(s);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_convert_depth(const gps_tsdf_state* sp, const int16_t* depth_mm, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && depth_mm != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    const int P = sp->width * sp->height;
+    convert_depth_kernel<<<gps_div_up(P, 256), 256, 0, (hipStream_t)stream>>>(P, depth_mm, sp->depth);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_allocate(const gps_tsdf_state* sp, const float* M, const float* invM, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && M != nullptr && invM != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    // the (pixel, step) priority packs the step into BAND_STEP_BITS bits
+    {
+        const float band_blocks = 2.0f * s.mu / (s.voxel_size * BLK);
+        GPS_REQUIRE((int)ceilf(2.0f * band_blocks) + 2 < MAX_BAND_STEPS);
+        GPS_REQUIRE((int64_t)s.width * s.height + 1 < (1ll << (32 - BAND_STEP_BITS)));
+    }
+    Mat4 m = load_mat(M), im = load_mat(invM);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = s.width * s.height;
+    const int n_total = s.n_buckets + s.n_excess;
+    const int nblk = gps_div_up(n_total, SWEEP);
+    int32_t* blk1 = s.scan_scratch;
+    int32_t* blk2 = s.scan_scratch + nblk;
+    int32_t* blkv = s.scan_scratch + 2 * nblk;
+    int32_t* tot = s.scan_scratch + 3 * nblk;  // [2] totals scratch
+    mark_previous_visible_kernel<<<256, 256, 0, st>>>(s);
+    alloc_request_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(s, im);
+    alloc_count_kernel<<<nblk, SWEEP, 0, st>>>(s, blk1, blk2);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blk1, blk2, tot);
+    alloc_apply_kernel<<<nblk, SWEEP, 0, st>>>(s, im, blk1, blk2);
+    // ordered visible list (byte flags live behind the per-block counts in scan_scratch)
+    uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
+    visible_count_kernel<VIS_LIVE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE]);
+    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.visible_ids, s.n_blocks);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_find_visible(const gps_tsdf_state* sp, const float* M, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && M != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    Mat4 m = load_mat(M);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_total = s.n_buckets + s.n_excess;
+    const int nblk = gps_div_up(n_total, SWEEP);
+    int32_t* blkv = s.scan_scratch + 2 * nblk;
+    uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
+    visible_count_kernel<VIS_FREE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE_FREE]);
+    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.fv_visible_ids, s.n_blocks);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && M != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    // persistent grid: 8 wave64 per workgroup, up to 4 workgroups per CU resident; strides over the visible list
+    integrate_kernel<<<2048, BLK3, 0, (hipStream_t)stream>>>(s, load_mat(M));
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // extern "C"

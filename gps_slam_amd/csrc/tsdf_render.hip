@@ -1,0 +1,494 @@
+// TSDF rendering for gfx950: expected-depth (min/max) image, ray casting through the voxel-block
+// hash, ICP point/normal maps, colour rendering; plus the frame-level entry points.
+// Compiled with -ffp-contract=off (ray positions are compared bit-for-bit with the CPU engine).
+//
+// Per-element maths: InfiniTAM/ITMLib/Engines/Visualisation/Shared/ITMVisualisationEngine_Shared.h and
+// Objects/Scene/ITMRepresentationAccess.h (restated line by line in oracle/tsdf_oracle.c).
+//
+// Differences in organisation from the reference CUDA back-end:
+//  * CreateExpectedDepths does not materialise the <= 262,144 "rendering block" list nor copy its
+//    length to the host (…_CUDA.tcu:137-184): each visible block projects its 8 corners and
+//    min/max-es its bounding box straight into the 1/8-resolution image with integer atomics
+//    (positive floats order like their bit patterns).  Identical result unless the reference's
+//    MAX_RENDERING_BLOCKS cap would have been hit, which is flagged in counters[GPS_TSDF_OVERFLOW].
+//  * All kernels read their sizes from the device counters: no blocking readback anywhere.
+#include <math.h>
+
+#include "tsdf_common.hpp"
+
+using namespace gpst;
+
+namespace {
+
+__global__ __launch_bounds__(256) void minmax_init_kernel(int P, float2* __restrict__ mm, int32_t* counters) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) mm[i] = make_float2(FAR_AWAY, VERY_CLOSE);
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[GPS_TSDF_RENDER_BLOCKS] = 0;
+}
+
+// ProjectSingleBlock (Shared.h:36-91) + the fill loop of CreateExpectedDepths (CPU.tpp:168-184)
+__global__ __launch_bounds__(256) void expected_depths_kernel(TsdfState s, Mat4 M, const int32_t* __restrict__ vis_ids,
+                                                             int count_slot, float2* __restrict__ mm) {
+    const int n = s.counters[count_slot];
+    const int stride = gridDim.x * blockDim.x;
+    const int W = s.width, H = s.height;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const gps_hash_entry he = s.hash[vis_ids[k]];
+        if (he.ptr < 0) continue;
+        int ulx = W / MINMAX_SUB, uly = H / MINMAX_SUB, lrx = -1, lry = -1;
+        float zmin = FAR_AWAY, zmax = VERY_CLOSE;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            short tx = he.pos[0], ty = he.pos[1], tz = he.pos[2];
+            tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
+            float px, py, pz;
+            mul_point(M, (float)tx * (float)BLK * s.voxel_size, (float)ty * (float)BLK * s.voxel_size,
+                      (float)tz * (float)BLK * s.voxel_size, 1.0f, px, py, pz);
+            if (pz < 1e-6) continue;
+            const float u = (s.fx * px / pz + s.cx) / MINMAX_SUB;
+            const float v = (s.fy * py / pz + s.cy) / MINMAX_SUB;
+            if (ulx > floorf(u)) ulx = (int)floorf(u);
+            if (lrx < ceilf(u)) lrx = (int)ceilf(u);
+            if (uly > floorf(v)) uly = (int)floorf(v);
+            if (lry < ceilf(v)) lry = (int)ceilf(v);
+            if (zmin > pz) zmin = pz;
+            if (zmax < pz) zmax = pz;
+        }
+        if (ulx < 0) ulx = 0;
+        if (uly < 0) uly = 0;
+        if (lrx >= W) lrx = W - 1;
+        if (lry >= H) lry = H - 1;
+        if (ulx > lrx) continue;
+        if (uly > lry) continue;
+        if (zmin < VERY_CLOSE) zmin = VERY_CLOSE;
+        if (zmax < VERY_CLOSE) continue;
+        const int rbx = (int)ceilf((float)(lrx - ulx + 1) / 16.0f), rby = (int)ceilf((float)(lry - uly + 1) / 16.0f);
+        const int before = atomicAdd(&s.counters[GPS_TSDF_RENDER_BLOCKS], rbx * rby);
+        if (before + rbx * rby >= MAX_RENDERING_BLOCKS) s.counters[GPS_TSDF_OVERFLOW] = 1;
+        for (int y = uly; y <= lry; ++y)
+            for (int x = ulx; x <= lrx; ++x) {
+                uint32_t* p = reinterpret_cast<uint32_t*>(&mm[x + y * W]);
+                atomicMin(p, __float_as_uint(zmin));      // both strictly positive
+                atomicMax(p + 1, __float_as_uint(zmax));
+            }
+    }
+}
+
+// ---------------------------------------------------------------- voxel access (ITMRepresentationAccess.h)
+struct BlockCache { int bx, by, bz, ptr; };
+
+__device__ __forceinline__ uint64_t read_voxel_raw(const TsdfState& s, int px, int py, int pz, int& vmIndex,
+                                                   BlockCache& c) {
+    const int bx = ((px < 0) ? px - BLK + 1 : px) / BLK;
+    const int by = ((py < 0) ? py - BLK + 1 : py) / BLK;
+    const int bz = ((pz < 0) ? pz - BLK + 1 : pz) / BLK;
+    const int lin = px + (py - bx) * BLK + (pz - by) * BLK * BLK - bz * BLK3;
+    const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
+    if (bx == c.bx && by == c.by && bz == c.bz) { vmIndex = 1; return vox[c.ptr + lin]; }  // :89-93 (vmIndex = true)
+    int hashIdx = hash_index(bx, by, bz, s.n_buckets - 1);
+    while (true) {
+        const gps_hash_entry he = s.hash[hashIdx];
+        if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= 0) {
+            c.bx = bx; c.by = by; c.bz = bz; c.ptr = he.ptr * BLK3;
+            vmIndex = hashIdx + 1;
+            return vox[c.ptr + lin];
+        }
+        if (he.offset < 1) break;
+        hashIdx = s.n_buckets + he.offset - 1;
+    }
+    vmIndex = 0;
+    return 0x7FFFull;  // TVoxel(): sdf 32767, weights / colour 0
+}
+__device__ __forceinline__ float vox_sdf(uint64_t raw) { return (float)(int16_t)(raw & 0xFFFF); }
+__device__ __forceinline__ float vox_wdepth(uint64_t raw) { return (float)((raw >> 16) & 0xFF); }
+__device__ __forceinline__ float roundf_ref(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }
+
+template <bool WITH_CONF>
+__device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, float py, float pz, int& vmIndex,
+                                                 BlockCache& c, float& conf) {
+    const float fx_ = floorf(px), fy_ = floorf(py), fz_ = floorf(pz);
+    const float cx = px - fx_, cy = py - fy_, cz = pz - fz_;
+    const int ix = (int)fx_, iy = (int)fy_, iz = (int)fz_;
+    uint64_t r;
+    float v1, v2, res1, res2, v1c = 0.f, v2c = 0.f, res1c = 0.f, res2c = 0.f;
+#define RV(dx, dy, dz) read_voxel_raw(s, ix + dx, iy + dy, iz + dz, vmIndex, c)
+    r = RV(0, 0, 0); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
+    r = RV(1, 0, 0); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
+    res1 = (1.0f - cx) * v1 + cx * v2;
+    if (WITH_CONF) res1c = (1.0f - cx) * v1c + cx * v2c;
+    r = RV(0, 1, 0); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
+    r = RV(1, 1, 0); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
+    res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v1 + cx * v2);
+    if (WITH_CONF) res1c = (1.0f - cy) * res1c + cy * ((1.0f - cx) * v1c + cx * v2c);
+    r = RV(0, 0, 1); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
+    r = RV(1, 0, 1); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
+    res2 = (1.0f - cx) * v1 + cx * v2;
+    if (WITH_CONF) res2c = (1.0f - cx) * v1c + cx * v2c;
+    r = RV(0, 1, 1); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
+    r = RV(1, 1, 1); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
+    res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
+    if (WITH_CONF) res2c = (1.0f - cy) * res2c + cy * ((1.0f - cx) * v1c + cx * v2c);
+#undef RV
+    vmIndex = 1;
+    if (WITH_CONF) conf = (1.0f - cz) * res1c + cz * res2c;
+    return ((1.0f - cz) * res1 + cz * res2) / 32767.0f;
+}
+
+// castRay (Shared.h:122-221); 16x16 pixel workgroups so that a wave's rays stay inside a 16x4 patch
+template <bool MODIFY_VISIBLE>
+__global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
+                                                     float4* __restrict__ rays) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= s.width || y >= s.height) return;
+    const int W = s.width;
+    const int loc2 = (int)floorf((float)x / MINMAX_SUB) + (int)floorf((float)y / MINMAX_SUB) * W;
+    const float2 mm = minmax[loc2];
+    const float oneOverVoxelSize = 1.0f / s.voxel_size;
+    const float ipx = 1.0f / s.fx, ipy = 1.0f / s.fy, ipz = -s.cx, ipw = -s.cy;
+    const float stepScale = s.mu * oneOverVoxelSize;
+    float cz = mm.x;
+    float cx = cz * (((float)x + ipz) * ipx);
+    float cy = cz * (((float)y + ipw) * ipy);
+    float l2 = 0; l2 += cx * cx; l2 += cy * cy; l2 += cz * cz;
+    float totalLength = sqrtf(l2) * oneOverVoxelSize;
+    float qx, qy, qz;
+    mul_point(invM, cx, cy, cz, 1.0f, qx, qy, qz);
+    const float sx = qx * oneOverVoxelSize, sy = qy * oneOverVoxelSize, sz = qz * oneOverVoxelSize;
+    cz = mm.y;
+    cx = cz * (((float)x + ipz) * ipx);
+    cy = cz * (((float)y + ipw) * ipy);
+    l2 = 0; l2 += cx * cx; l2 += cy * cy; l2 += cz * cz;
+    const float totalLengthMax = sqrtf(l2) * oneOverVoxelSize;
+    mul_point(invM, cx, cy, cz, 1.0f, qx, qy, qz);
+    float rx = qx * oneOverVoxelSize - sx, ry = qy * oneOverVoxelSize - sy, rz = qz * oneOverVoxelSize - sz;
+    const float dn = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+    rx *= dn; ry *= dn; rz *= dn;
+    float px = sx, py = sy, pz = sz;
+    BlockCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
+    float sdfValue = 1.0f, confidence = 0.f, stepLength;
+    int vmIndex = 0;
+    while (totalLength < totalLengthMax) {
+        const uint64_t raw = read_voxel_raw(s, (int)roundf_ref(px), (int)roundf_ref(py), (int)roundf_ref(pz), vmIndex, cache);
+        sdfValue = vox_sdf(raw) / 32767.0f;
+        if (MODIFY_VISIBLE) { if (vmIndex) s.visible_type[vmIndex - 1] = 1; }  // incl. the vmIndex==1 cache-hit quirk
+        if (!vmIndex) {
+            stepLength = BLK;
+        } else {
+            if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
+                float dummy;
+                sdfValue = read_sdf_interp<false>(s, px, py, pz, vmIndex, cache, dummy);
+            }
+            if (sdfValue <= 0.0f) break;
+            const float a = sdfValue * stepScale;
+            stepLength = (a < 1.0f) ? 1.0f : a;
+        }
+        px += stepLength * rx; py += stepLength * ry; pz += stepLength * rz;
+        totalLength += stepLength;
+    }
+    bool found;
+    if (sdfValue <= 0.0f) {
+        stepLength = sdfValue * stepScale;
+        px += stepLength * rx; py += stepLength * ry; pz += stepLength * rz;
+        sdfValue = read_sdf_interp<true>(s, px, py, pz, vmIndex, cache, confidence);
+        stepLength = sdfValue * stepScale;
+        px += stepLength * rx; py += stepLength * ry; pz += stepLength * rz;
+        found = true;
+    } else {
+        found = false;
+    }
+    rays[x + y * W] = make_float4(px, py, pz, found ? confidence + 1.0f : 0.0f);
+}
+
+// processPixelICP<useSmoothing = true, flipNormals = false> (Shared.h:252-330, 438-480)
+__global__ __launch_bounds__(256) void icp_kernel(TsdfState s, Mat4 invM, const float4* __restrict__ pr,
+                                                 float4* __restrict__ points, float4* __restrict__ normals) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int W = s.width, H = s.height;
+    if (x >= W || y >= H) return;
+    const int loc = x + y * W;
+    const float4 point = pr[loc];
+    bool found = point.w > 0.0f;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (found && (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3)) found = false;
+    if (found) {
+        float4 xp = pr[(x + 2) + y * W], yp = pr[x + (y + 2) * W], xm = pr[(x - 2) + y * W], ym = pr[x + (y - 2) * W];
+        float dxx = 0.f, dxy = 0.f, dxz = 0.f, dyx = 0.f, dyy = 0.f, dyz = 0.f;
+        bool doPlus1 = false;
+        if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) doPlus1 = true;
+        else {
+            dxx = xp.x - xm.x; dxy = xp.y - xm.y; dxz = xp.z - xm.z;
+            dyx = yp.x - ym.x; dyy = yp.y - ym.y; dyz = yp.z - ym.z;
+            const float la = dxx * dxx + dxy * dxy + dxz * dxz, lb = dyx * dyx + dyy * dyy + dyz * dyz;
+            const float ld = (la < lb) ? lb : la;
+            if (ld * s.voxel_size * s.voxel_size > (0.15f * 0.15f)) doPlus1 = true;
+        }
+        if (doPlus1) {
+            xp = pr[(x + 1) + y * W]; yp = pr[x + (y + 1) * W]; xm = pr[(x - 1) + y * W]; ym = pr[x + (y - 1) * W];
+            dxx = xp.x - xm.x; dxy = xp.y - xm.y; dxz = xp.z - xm.z;
+            dyx = yp.x - ym.x; dyy = yp.y - ym.y; dyz = yp.z - ym.z;
+            if (xp.w <= 0 || yp.w <= 0 || xm.w <= 0 || ym.w <= 0) found = false;
+        }
+        if (found) {
+            nx = -(dxy * dyz - dxz * dyy);
+            ny = -(dxz * dyx - dxx * dyz);
+            nz = -(dxx * dyy - dxy * dyx);
+            const float ns = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+            nx *= ns; ny *= ns; nz *= ns;
+            const float angle = nx * (-invM.m[8]) + ny * (-invM.m[9]) + nz * (-invM.m[10]);
+            if (!(angle > 0.0)) found = false;
+        }
+    }
+    if (found) {
+        points[loc] = make_float4(point.x * s.voxel_size, point.y * s.voxel_size, point.z * s.voxel_size, point.w);
+        normals[loc] = make_float4(nx, ny, nz, 0.0f);
+    } else {
+        const float4 o = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        points[loc] = o; normals[loc] = o;
+    }
+}
+
+// readFromSDF_color4u_interpolated, GPS-SLAM variant renormalised over w_color >= 1
+// (ITMRepresentationAccess.h:344-423) + drawPixelColour (Shared.h:384-394)
+__global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* __restrict__ rays, uchar4* __restrict__ out) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= s.width || y >= s.height) return;
+    const int loc = x + y * s.width;
+    const float4 r = rays[loc];
+    if (!(r.w > 0)) { out[loc] = make_uchar4(0, 0, 0, 0); return; }
+    const float fx_ = floorf(r.x), fy_ = floorf(r.y), fz_ = floorf(r.z);
+    const float cx = r.x - fx_, cy = r.y - fy_, cz = r.z - fz_;
+    const int ix = (int)fx_, iy = (int)fy_, iz = (int)fz_;
+    BlockCache c = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, wsum = 0.f;
+    int vm;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+        const uint64_t raw = read_voxel_raw(s, ix + dx, iy + dy, iz + dz, vm, c);
+        if (((raw >> 48) & 0xFF) >= 1) {
+            const float wx = dx ? cx : (1.0f - cx), wy = dy ? cy : (1.0f - cy), wz = dz ? cz : (1.0f - cz);
+            const float w = wx * wy * wz;
+            r0 += w * (float)((raw >> 24) & 0xFF);
+            r1 += w * (float)((raw >> 32) & 0xFF);
+            r2 += w * (float)((raw >> 40) & 0xFF);
+            wsum += w;
+        }
+    }
+    r0 /= wsum; r1 /= wsum; r2 /= wsum;
+    const float c0 = r0 / 255.0f, c1 = r1 / 255.0f, c2 = r2 / 255.0f;
+    out[loc] = make_uchar4((unsigned char)(c0 * 255.0f), (unsigned char)(c1 * 255.0f), (unsigned char)(c2 * 255.0f), 255);
+}
+
+// ---------------------------------------------------------------- host-side pose algebra (ORUtils::SE3Pose)
+// General 4x4 inverse by cofactors in the operation order of ORUtils/Matrix.h:177-238.
+bool mat4_inverse(const float* a, float* out) {
+    float s[16], t[12];
+    for (int i = 0; i < 4; i++) { s[i] = a[i * 4]; s[i + 4] = a[i * 4 + 1]; s[i + 8] = a[i * 4 + 2]; s[i + 12] = a[i * 4 + 3]; }
+    t[0] = s[10] * s[15]; t[1] = s[11] * s[14]; t[2] = s[9] * s[15]; t[3] = s[11] * s[13];
+    t[4] = s[9] * s[14]; t[5] = s[10] * s[13]; t[6] = s[8] * s[15]; t[7] = s[11] * s[12];
+    t[8] = s[8] * s[14]; t[9] = s[10] * s[12]; t[10] = s[8] * s[13]; t[11] = s[9] * s[12];
+    out[0] = (t[0] * s[5] + t[3] * s[6] + t[4] * s[7]) - (t[1] * s[5] + t[2] * s[6] + t[5] * s[7]);
+    out[1] = (t[1] * s[4] + t[6] * s[6] + t[9] * s[7]) - (t[0] * s[4] + t[7] * s[6] + t[8] * s[7]);
+    out[2] = (t[2] * s[4] + t[7] * s[5] + t[10] * s[7]) - (t[3] * s[4] + t[6] * s[5] + t[11] * s[7]);
+    out[3] = (t[5] * s[4] + t[8] * s[5] + t[11] * s[6]) - (t[4] * s[4] + t[9] * s[5] + t[10] * s[6]);
+    const float det = s[0] * out[0] + s[1] * out[1] + s[2] * out[2] + s[3] * out[3];
+    if (det == 0.0f) return false;
+    out[4] = (t[1] * s[1] + t[2] * s[2] + t[5] * s[3]) - (t[0] * s[1] + t[3] * s[2] + t[4] * s[3]);
+    out[5] = (t[0] * s[0] + t[7] * s[2] + t[8] * s[3]) - (t[1] * s[0] + t[6] * s[2] + t[9] * s[3]);
+    out[6] = (t[3] * s[0] + t[6] * s[1] + t[11] * s[3]) - (t[2] * s[0] + t[7] * s[1] + t[10] * s[3]);
+    out[7] = (t[4] * s[0] + t[9] * s[1] + t[10] * s[2]) - (t[5] * s[0] + t[8] * s[1] + t[11] * s[2]);
+    t[0] = s[2] * s[7]; t[1] = s[3] * s[6]; t[2] = s[1] * s[7]; t[3] = s[3] * s[5];
+    t[4] = s[1] * s[6]; t[5] = s[2] * s[5]; t[6] = s[0] * s[7]; t[7] = s[3] * s[4];
+    t[8] = s[0] * s[6]; t[9] = s[2] * s[4]; t[10] = s[0] * s[5]; t[11] = s[1] * s[4];
+    out[8] = (t[0] * s[13] + t[3] * s[14] + t[4] * s[15]) - (t[1] * s[13] + t[2] * s[14] + t[5] * s[15]);
+    out[9] = (t[1] * s[12] + t[6] * s[14] + t[9] * s[15]) - (t[0] * s[12] + t[7] * s[14] + t[8] * s[15]);
+    out[10] = (t[2] * s[12] + t[7] * s[13] + t[10] * s[15]) - (t[3] * s[12] + t[6] * s[13] + t[11] * s[15]);
+    out[11] = (t[5] * s[12] + t[8] * s[13] + t[11] * s[14]) - (t[4] * s[12] + t[9] * s[13] + t[10] * s[14]);
+    out[12] = (t[2] * s[10] + t[5] * s[11] + t[1] * s[9]) - (t[4] * s[11] + t[0] * s[9] + t[3] * s[10]);
+    out[13] = (t[8] * s[11] + t[0] * s[8] + t[7] * s[10]) - (t[6] * s[10] + t[9] * s[11] + t[1] * s[8]);
+    out[14] = (t[6] * s[9] + t[11] * s[11] + t[3] * s[8]) - (t[10] * s[11] + t[2] * s[8] + t[7] * s[9]);
+    out[15] = (t[10] * s[10] + t[4] * s[8] + t[9] * s[9]) - (t[8] * s[9] + t[11] * s[10] + t[5] * s[8]);
+    const float inv = 1 / det;
+    for (int i = 0; i < 16; i++) out[i] = out[i] * inv;
+    return true;
+}
+
+inline float dot3(const float* a, const float* b) { float r = 0; r += a[0] * b[0]; r += a[1] * b[1]; r += a[2] * b[2]; return r; }
+
+// exponential map se(3) -> SE(3) with the reference's small-angle branches (SE3Pose.cpp:92-158)
+void pose_exp(const float* prm, float* M) {
+    const float one_6th = 1.0f / 6.0f, one_20th = 1.0f / 20.0f;
+    const float t[3] = {prm[0], prm[1], prm[2]}, w[3] = {prm[3], prm[4], prm[5]};
+    const float theta_sq = dot3(w, w);
+    const float theta = sqrtf(theta_sq);
+    const float cr[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};
+    float A, B, T[3];
+    if (theta_sq < 1e-8f) {
+        A = 1.0f - one_6th * theta_sq; B = 0.5f;
+        for (int k = 0; k < 3; k++) T[k] = t[k] + 0.5f * cr[k];
+    } else {
+        float C;
+        if (theta_sq < 1e-6f) {
+            C = one_6th * (1.0f - one_20th * theta_sq);
+            A = 1.0f - theta_sq * C;
+            B = 0.5f - 0.25f * one_6th * theta_sq;
+        } else {
+            const float it = 1.0f / theta;
+            A = sinf(theta) * it;
+            B = (1.0f - cosf(theta)) * (it * it);
+            C = (1.0f - A) * (it * it);
+        }
+        const float c2[3] = {w[1] * cr[2] - w[2] * cr[1], w[2] * cr[0] - w[0] * cr[2], w[0] * cr[1] - w[1] * cr[0]};
+        for (int k = 0; k < 3; k++) T[k] = t[k] + B * cr[k] + C * c2[k];
+    }
+    const float wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+    M[0] = 1.0f - B * (wy2 + wz2); M[5] = 1.0f - B * (wx2 + wz2); M[10] = 1.0f - B * (wx2 + wy2);
+    float a = A * w[2], b = B * (w[0] * w[1]);
+    M[4] = b - a; M[1] = b + a;
+    a = A * w[1]; b = B * (w[0] * w[2]);
+    M[8] = b + a; M[2] = b - a;
+    a = A * w[0]; b = B * (w[1] * w[2]);
+    M[9] = b - a; M[6] = b + a;
+    M[12] = T[0]; M[13] = T[1]; M[14] = T[2];
+    M[3] = 0.0f; M[7] = 0.0f; M[11] = 0.0f; M[15] = 1.0f;
+}
+
+// logarithm SE(3) -> se(3) (SE3Pose.cpp:160-243)
+void pose_log(const float* M, float* prm) {
+    const float T[3] = {M[12], M[13], M[14]};
+    float rot[3];
+    const float cos_angle = (M[0] + M[5] + M[10] - 1.0f) * 0.5f;
+    rot[0] = (M[6] - M[9]) * 0.5f; rot[1] = (M[8] - M[2]) * 0.5f; rot[2] = (M[1] - M[4]) * 0.5f;
+    const float sin_abs = sqrtf(dot3(rot, rot));
+    const double kSqrtHalf = 0.707106781186547524401;
+    if ((double)cos_angle > kSqrtHalf) {
+        if (sin_abs) { const float p = asinf(sin_abs) / sin_abs; rot[0] *= p; rot[1] *= p; rot[2] *= p; }
+    } else if ((double)cos_angle > -kSqrtHalf) {
+        const float p = acosf(cos_angle) / sin_abs;
+        rot[0] *= p; rot[1] *= p; rot[2] *= p;
+    } else {
+        const float angle = (float)3.14159265358979323846 - asinf(sin_abs);
+        const float d0 = M[0] - cos_angle, d1 = M[5] - cos_angle, d2 = M[10] - cos_angle;
+        float r2[3];
+        if (fabsf(d0) > fabsf(d1) && fabsf(d0) > fabsf(d2)) {
+            r2[0] = d0; r2[1] = (M[1] + M[4]) * 0.5f; r2[2] = (M[8] + M[2]) * 0.5f;
+        } else if (fabsf(d1) > fabsf(d2)) {
+            r2[0] = (M[1] + M[4]) * 0.5f; r2[1] = d1; r2[2] = (M[6] + M[9]) * 0.5f;
+        } else {
+            r2[0] = (M[8] + M[2]) * 0.5f; r2[1] = (M[6] + M[9]) * 0.5f; r2[2] = d2;
+        }
+        if (dot3(r2, rot) < 0.0f) { r2[0] *= -1.0f; r2[1] *= -1.0f; r2[2] *= -1.0f; }
+        const float len = sqrtf(dot3(r2, r2));
+        if (len == 0) { r2[0] = r2[1] = r2[2] = 0; } else { r2[0] /= len; r2[1] /= len; r2[2] /= len; }
+        rot[0] = angle * r2[0]; rot[1] = angle * r2[1]; rot[2] = angle * r2[2];
+    }
+    float shtot = 0.5f;
+    const float theta = sqrtf(dot3(rot, rot));
+    if (theta > 0.00001f) shtot = sinf(theta * 0.5f) / theta;
+    const float half[6] = {0.0f, 0.0f, 0.0f, rot[0] * -0.5f, rot[1] * -0.5f, rot[2] * -0.5f};
+    float HM[16];
+    pose_exp(half, HM);
+    float rt[3];
+    for (int r = 0; r < 3; r++) rt[r] = HM[r] * T[0] + HM[r + 4] * T[1] + HM[r + 8] * T[2];
+    float param;
+    if (theta > 0.001f) param = dot3(T, rot) * (1 - 2 * shtot) / dot3(rot, rot);
+    else param = dot3(T, rot) / 24;
+    for (int k = 0; k < 3; k++) { rt[k] -= rot[k] * param; }
+    for (int k = 0; k < 3; k++) rt[k] /= 2 * shtot;
+    prm[0] = rt[0]; prm[1] = rt[1]; prm[2] = rt[2];
+    prm[3] = rot[0]; prm[4] = rot[1]; prm[5] = rot[2];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_view, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && M != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = s.width * s.height;
+    float2* mm = reinterpret_cast<float2*>(free_view ? s.fv_minmax : s.minmax);
+    minmax_init_kernel<<<gps_div_up(P, 256 * 4), 256, 0, st>>>(P, mm, s.counters);
+    expected_depths_kernel<<<256, 256, 0, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
+                                                free_view ? GPS_TSDF_N_VISIBLE_FREE : GPS_TSDF_N_VISIBLE, mm);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && invM != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16));
+    const float2* mm = reinterpret_cast<const float2*>(free_view ? s.fv_minmax : s.minmax);
+    float4* rays = reinterpret_cast<float4*>(free_view ? s.fv_raycast : s.raycast);
+    if (update_visible)
+        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays);
+    else
+        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_icp_maps(const gps_tsdf_state* sp, const float* invM, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && invM != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16));
+    icp_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), reinterpret_cast<const float4*>(s.raycast),
+                                                     reinterpret_cast<float4*>(s.icp_points),
+                                                     reinterpret_cast<float4*>(s.icp_normals));
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_render_colour(const gps_tsdf_state* sp, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16));
+    colour_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(s, reinterpret_cast<const float4*>(s.fv_raycast),
+                                                        reinterpret_cast<uchar4*>(s.fv_colour));
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_process_frame(const gps_tsdf_state* s, const int16_t* depth_mm, const float* M, const float* invM,
+                           gps_stream stream) {
+    int r;
+    if ((r = gps_tsdf_convert_depth(s, depth_mm, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_allocate(s, M, invM, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_integrate(s, M, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_expected_depths(s, M, 0, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_raycast(s, invM, 0, 1, stream)) != GPS_OK) return r;
+    return gps_tsdf_icp_maps(s, invM, stream);
+}
+
+int gps_tsdf_free_raycast(const gps_tsdf_state* s, const float* M, const float* invM, gps_stream stream) {
+    int r;
+    if ((r = gps_tsdf_find_visible(s, M, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_expected_depths(s, M, 1, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_raycast(s, invM, 1, 0, stream)) != GPS_OK) return r;
+    return gps_tsdf_render_colour(s, stream);
+}
+
+int gps_pose_from_c2w(const float* c2w_row_major, float* M, float* invM) {
+    if (!c2w_row_major || !M || !invM) return GPS_ERR_ARG;
+    float c2w[16], M0[16], prm[6];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) c2w[c * 4 + r] = c2w_row_major[r * 4 + c];
+    if (!mat4_inverse(c2w, M0)) return GPS_ERR_ARG;  // SetInvM
+    pose_log(M0, prm);                               // SetParamsFromModelView (twice: SetInvM, then Coerce)
+    pose_log(M0, prm);
+    pose_exp(prm, M);                                // SetModelViewFromParams
+    if (!mat4_inverse(M, invM)) return GPS_ERR_ARG;  // GetInvM
+    return GPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""Host-side mirror of the reference's TSDF engine surface on top of the C-ABI:
+ITMBasicEngine<ITMVoxel_s_rgb, ITMVoxelBlockHash> (InfiniTAM/ITMLib/Core/ITMBasicEngine.{h,tpp}) as
+configured by createTsdfEngine (slam/InfiniTAM_tools.cpp:3-67) and driven by CLIEngine::ProcessFrame
+(slam/TsdfFusion/CLIEngine.cpp:34-58) and SLAMPipeline::runRaycastByCam (slam/slam_pipeline.cpp:362-415).
+
+Owns the device buffers (torch tensors; the reference owns them through ORUtils::MemoryBlock), fills the
+gps_tsdf_state struct once and afterwards only passes pointers.  All compute is in libgpsslam_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import TsdfState, check, lib
+
+# reference capacities (ITMLib/Objects/Scene/ITMVoxelBlockHash.h:18-22)
+SDF_LOCAL_BLOCK_NUM = 0x40000
+SDF_BUCKET_NUM = 0x100000
+SDF_EXCESS_LIST_SIZE = 0x20000
+
+VOXEL_DT = np.dtype([("sdf", "<i2"), ("w_depth", "u1"), ("clr", "u1", (3,)), ("w_color", "u1"), ("pad", "u1")])
+HASH_DT = np.dtype([("pos", "<i2", (3,)), ("pad", "<i2"), ("offset", "<i4"), ("ptr", "<i4")])
+
+
+def pose_from_c2w(c2w):
+    """ORUtils::SE3Pose: SetInvM(c2w); Coerce(); -> (M, invM) as float32[16] in ORUtils layout (host only)."""
+    c = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(4, 4))
+    M = np.zeros(16, np.float32)
+    invM = np.zeros(16, np.float32)
+    check(lib.gps_pose_from_c2w(c.ctypes.data, M.ctypes.data, invM.ctypes.data), "gps_pose_from_c2w")
+    return M, invM
+
+
+class TsdfEngine:
+    """ITMBasicEngine with tracking switched off (use_gt_pose: true in every shipped config)."""
+
+    def __init__(self, width, height, fx, fy, cx, cy, voxel_size=0.005, mu=0.02, view_frustum_min=0.2,
+                 view_frustum_max=10.0, n_blocks=SDF_LOCAL_BLOCK_NUM, n_buckets=SDF_BUCKET_NUM,
+                 n_excess=SDF_EXCESS_LIST_SIZE, device="cuda:0"):
+        self.W, self.H = int(width), int(height)
+        self.device = torch.device(device)
+        self.voxel_size = float(voxel_size)
+        d = self.device
+        P = self.W * self.H
+        n_total = n_buckets + n_excess
+        nblk = (n_total + 1023) // 1024
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=d)
+        self.vba = z(n_blocks * 512 * 8, torch.uint8)
+        self.vba_alloc_list = z(n_blocks, torch.int32)
+        self.hash = z(n_total * 16, torch.uint8)
+        self.excess_list = z(n_excess, torch.int32)
+        self.counters = z(16, torch.int32)
+        self.alloc_prio = z(n_total, torch.int32)
+        self.scan_scratch = z(3 * nblk + 16 + (n_total + 3) // 4, torch.int32)
+        self.visible_type = z(n_total, torch.uint8)
+        self.visible_ids = z(n_blocks, torch.int32)
+        self.depth = z(P, torch.float32)
+        self.rgb = z(P * 4, torch.uint8)
+        self.minmax = z(P * 2, torch.float32)
+        self.raycast = z(P * 4, torch.float32)
+        self.icp_points = z(P * 4, torch.float32)
+        self.icp_normals = z(P * 4, torch.float32)
+        self.fv_visible_ids = z(n_blocks, torch.int32)
+        self.fv_minmax = z(P * 2, torch.float32)
+        self.fv_raycast = z(P * 4, torch.float32)
+        self.fv_colour = z(P * 4, torch.uint8)
+        self.depth_mm = z(P, torch.int16)
+        s = TsdfState()
+        s.width, s.height = self.W, self.H
+        s.fx, s.fy, s.cx, s.cy = float(fx), float(fy), float(cx), float(cy)
+        s.voxel_size, s.mu = float(voxel_size), float(mu)
+        s.view_frustum_min, s.view_frustum_max = float(view_frustum_min), float(view_frustum_max)
+        s.max_w = 100  # ITMLibSettings.cpp:10
+        s.n_blocks, s.n_buckets, s.n_excess = n_blocks, n_buckets, n_excess
+        for name in ("vba", "vba_alloc_list", "hash", "excess_list", "counters", "alloc_prio", "scan_scratch",
+                     "visible_type", "visible_ids", "depth", "rgb", "minmax", "raycast", "icp_points", "icp_normals",
+                     "fv_visible_ids", "fv_minmax", "fv_raycast", "fv_colour"):
+            setattr(s, name, getattr(self, name).data_ptr())
+        self.state = s
+        self.n_blocks, self.n_buckets, self.n_excess, self.n_total = n_blocks, n_buckets, n_excess, n_total
+        self.frames_processed = 0
+        # ITMBasicEngine::camPoses / gtC2wPoses (ITMBasicEngine.h:54-56)
+        self.camPoses = []
+        self.reset()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        check(lib.gps_tsdf_reset(C.byref(self.state), self._stream()), "gps_tsdf_reset")
+        self.frames_processed = 0
+        self.camPoses = []
+
+    # ---- ITMBasicEngine::ProcessFrame (tracking off: pose := gtC2wPoses[framesProcessed]; Coerce())
+    def ProcessFrame(self, rgb_u8, depth_mm_i16, gt_c2w):
+        """rgb_u8: uint8 [H,W,4] (or [H,W,3]) device tensor; depth_mm_i16: int16 [H,W] millimetres; gt_c2w 4x4."""
+        if rgb_u8.shape[-1] == 3:
+            rgb_u8 = torch.cat([rgb_u8, torch.full_like(rgb_u8[..., :1], 255)], -1)
+        self.rgb.copy_(rgb_u8.reshape(-1), non_blocking=True)
+        self.depth_mm.copy_(depth_mm_i16.reshape(-1), non_blocking=True)
+        M, invM = pose_from_c2w(gt_c2w)
+        check(lib.gps_tsdf_process_frame(C.byref(self.state), self.depth_mm.data_ptr(), M.ctypes.data,
+                                         invM.ctypes.data, self._stream()), "gps_tsdf_process_frame")
+        self.camPoses.append((M, invM))
+        self.frames_processed += 1
+        return M, invM
+
+    # ---- ITMBasicEngine::runRaycast(pose, intrinsics) + GetFreeImage / GetFreeVertex
+    def runRaycast(self, c2w=None, pose=None):
+        M, invM = pose if pose is not None else pose_from_c2w(c2w)
+        check(lib.gps_tsdf_free_raycast(C.byref(self.state), M.ctypes.data, invM.ctypes.data, self._stream()),
+              "gps_tsdf_free_raycast")
+        return M, invM
+
+    def GetFreeImage(self):
+        return self.fv_colour.view(self.H, self.W, 4)
+
+    def GetFreeVertex(self):
+        return self.fv_raycast.view(self.H, self.W, 4)
+
+    def GetLiveVertex(self):
+        return self.raycast.view(self.H, self.W, 4)
+
+    def getVoxelSize(self):
+        return self.voxel_size
+
+    # ---- host views for tests / persistence (sync)
+    def counters_host(self):
+        return self.counters.cpu().numpy()
+
+    def hash_host(self):
+        return self.hash.cpu().numpy().view(HASH_DT)
+
+    def vba_host(self, ptrs):
+        idx = torch.as_tensor(np.asarray(ptrs, dtype=np.int64), device=self.device)
+        return self.vba.view(self.n_blocks, 512 * 8)[idx].cpu().numpy().view(VOXEL_DT).reshape(-1, 512)

@@ -166,6 +166,120 @@ typedef struct {
 GPS_API int gps_adam_step(const gps_adam_segment *segments, int n_segments, double beta1, double beta2, double eps, int step,
                   gps_stream stream);
 
+/* ------------------------------------------------------------------ */
+/* TSDF: voxel-block-hash fusion and raycast (InfiniTAM ITMLib path)   */
+/* ------------------------------------------------------------------ */
+
+/* Storage layouts are the reference's (sizes checked by compiling it: 8 and 16 bytes). */
+typedef struct {            /* ITMLib/Objects/Scene/ITMVoxelTypes.h:41-69 (ITMVoxel_s_rgb) */
+    int16_t sdf;            /* (short)(f * 32767), initial 32767 */
+    uint8_t w_depth;
+    uint8_t clr[3];
+    uint8_t w_color;
+    uint8_t pad_;
+} gps_voxel;
+
+typedef struct {            /* ITMLib/Objects/Scene/ITMVoxelBlockHash.h:36-48 (ITMHashEntry) */
+    int16_t pos[3];
+    int16_t pad_;
+    int32_t offset;         /* 1-based link into the excess list, 0 = none */
+    int32_t ptr;            /* >= 0 voxel block, -1 swapped out, -2 empty */
+} gps_hash_entry;
+
+/* indices into gps_tsdf_state.counters (device int32[16]) */
+enum {
+    GPS_TSDF_LAST_FREE_BLOCK = 0,  /* ITMLocalVBA::lastFreeBlockId */
+    GPS_TSDF_LAST_FREE_EXCESS = 1, /* ITMVoxelBlockHash::lastFreeExcessListId */
+    GPS_TSDF_N_VISIBLE = 2,        /* renderState_live->noVisibleEntries */
+    GPS_TSDF_N_VISIBLE_FREE = 3,   /* renderState_freeview->noVisibleEntries */
+    GPS_TSDF_RENDER_BLOCKS = 4,    /* rendering blocks requested by the last CreateExpectedDepths */
+    GPS_TSDF_OVERFLOW = 5,         /* non-zero: MAX_RENDERING_BLOCKS (262144) exceeded -> min/max image not reference-exact */
+    GPS_TSDF_SCRATCH0 = 6,
+    GPS_TSDF_SCRATCH1 = 7
+};
+
+/* All pointers are device memory owned by the caller (the reference owns the same buffers through
+ * ORUtils::MemoryBlock: ITMLocalVBA, ITMVoxelBlockHash, ITMRenderState_VH, ITMView, ITMTrackingState). */
+typedef struct {
+    /* geometry / parameters (ITMSceneParams, ITMIntrinsics::projectionParamsSimple) */
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    float voxel_size, mu, view_frustum_min, view_frustum_max;
+    int32_t max_w;                   /* 100, ITMLibSettings.cpp:10 */
+    /* capacities (reference: 0x40000 blocks, 0x100000 buckets (power of two), 0x20000 excess) */
+    int32_t n_blocks, n_buckets, n_excess;
+    /* scene */
+    gps_voxel *vba;                  /* [n_blocks * 512] */
+    int32_t *vba_alloc_list;         /* [n_blocks] */
+    gps_hash_entry *hash;            /* [n_buckets + n_excess] */
+    int32_t *excess_list;            /* [n_excess] */
+    int32_t *counters;               /* [16] */
+    /* allocation scratch */
+    uint32_t *alloc_prio;            /* [n_buckets + n_excess], zero between calls */
+    int32_t *scan_scratch;           /* [4 * ceil((n_buckets+n_excess)/1024) + 16] */
+    /* live render state + view */
+    uint8_t *visible_type;           /* [n_buckets + n_excess] */
+    int32_t *visible_ids;            /* [n_blocks] */
+    float *depth;                    /* [H*W] metres, -1 invalid */
+    const uint8_t *rgb;              /* [H*W*4] uchar4 */
+    float *minmax;                   /* [H*W*2] */
+    float *raycast;                  /* [H*W*4] voxel-unit xyz + confidence+1 */
+    float *icp_points, *icp_normals; /* [H*W*4] */
+    /* free-view render state */
+    int32_t *fv_visible_ids;         /* [n_blocks] */
+    float *fv_minmax;                /* [H*W*2] */
+    float *fv_raycast;               /* [H*W*4] */
+    uint8_t *fv_colour;              /* [H*W*4] uchar4 */
+} gps_tsdf_state;
+
+/* ITMSceneReconstructionEngine::ResetScene (Reconstruction/CUDA/ITMSceneReconstructionEngine_CUDA.tcu:52-80) */
+GPS_API int gps_tsdf_reset(const gps_tsdf_state *s, gps_stream stream);
+
+/* ITMViewBuilder::UpdateView depth conversion (ViewBuilding/Shared/ITMViewBuilder_Shared.h:27-36):
+ * depth_mm int16[H*W] -> s->depth (d <= 0 ? -1 : d * 0.001f). */
+GPS_API int gps_tsdf_convert_depth(const gps_tsdf_state *s, const int16_t *depth_mm, gps_stream stream);
+
+/* ITMSceneReconstructionEngine::AllocateSceneFromDepth (…_CUDA.tcu:95-201 / CPU.tpp:129-341): hash-block
+ * allocation from s->depth + visible list.  Deterministic: identical to the single-threaded CPU engine
+ * (bucket collisions resolved by last pixel in scan order; blocks handed out in ascending slot order).
+ * M / invM: host float[16], ORUtils layout m[col*4+row] (pose_d->GetM() and its inverse). */
+GPS_API int gps_tsdf_allocate(const gps_tsdf_state *s, const float *M, const float *invM, gps_stream stream);
+
+/* ITMSceneReconstructionEngine::IntegrateIntoScene (…_CUDA.tcu:203-250,348-383; Shared:8-54,105-174) */
+GPS_API int gps_tsdf_integrate(const gps_tsdf_state *s, const float *M, gps_stream stream);
+
+/* ITMVisualisationEngine::CreateExpectedDepths (Visualisation/CUDA/…_CUDA.tcu:137-184); free_view selects the
+ * render state (0 = live, 1 = free view). */
+GPS_API int gps_tsdf_expected_depths(const gps_tsdf_state *s, const float *M, int free_view, gps_stream stream);
+
+/* GenericRaycast / castRay (…_CUDA.tcu:186-225, Shared:122-221).  update_visible = 1 reproduces
+ * CreateICPMaps' modifyVisibleEntries = true (only meaningful for the live state). */
+GPS_API int gps_tsdf_raycast(const gps_tsdf_state *s, const float *invM, int free_view, int update_visible,
+                             gps_stream stream);
+
+/* renderICP_device<false> with smoothing (ITMVisualisationHelpers_CUDA.h:71-81, Shared:438-480) on the live raycast */
+GPS_API int gps_tsdf_icp_maps(const gps_tsdf_state *s, const float *invM, gps_stream stream);
+
+/* ITMVisualisationEngine::FindVisibleBlocks for a free view (…_CUDA.tcu:77-92, buildCompleteVisibleList_device) */
+GPS_API int gps_tsdf_find_visible(const gps_tsdf_state *s, const float *M, gps_stream stream);
+
+/* renderColour_device (ITMVisualisationHelpers_CUDA.h:227-245) on the free-view raycast -> s->fv_colour */
+GPS_API int gps_tsdf_render_colour(const gps_tsdf_state *s, gps_stream stream);
+
+/* ITMBasicEngine::ProcessFrame with tracking off (Core/ITMBasicEngine.tpp:260-385) = convert_depth + allocate +
+ * integrate + expected_depths(live) + raycast(live, update_visible) + icp_maps, on one stream, no host sync. */
+GPS_API int gps_tsdf_process_frame(const gps_tsdf_state *s, const int16_t *depth_mm, const float *M, const float *invM,
+                                   gps_stream stream);
+
+/* ITMBasicEngine::runRaycast(pose, intrinsics) (Core/ITMBasicEngine.tpp:519-525) = find_visible +
+ * expected_depths(free) + raycast(free) + render_colour. */
+GPS_API int gps_tsdf_free_raycast(const gps_tsdf_state *s, const float *M, const float *invM, gps_stream stream);
+
+/* Host-side pose algebra of ORUtils::SE3Pose as used by ITMBasicEngine.tpp:278-279 and slam_pipeline.cpp:367-371:
+ * pose.SetInvM(c2w); pose.Coerce(); -> M = pose.GetM(), invM = pose.GetInvM().
+ * c2w is row-major (tensor layout); M/invM use the ORUtils layout.  Pure host code, no GPU. */
+GPS_API int gps_pose_from_c2w(const float *c2w_row_major, float *M, float *invM);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,149 @@
+"""GPU parity of the TSDF path, through the C-ABI: bit-exact against (i) the golden dumps of the reference's own
+ITMLib CPU engine and (ii) the CPU oracle on larger seeded sequences (640x480 / 5 mm voxels).
+Integer results (hash slots, block coordinates, ptr/offset, visible lists, voxel payloads, colours) AND float
+images (depth, min/max, raycast points, ICP maps) must match bit for bit."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+from tests.test_oracle_tsdf import bits_equal, check_frame, check_free_view, crc_of_blocks  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tsdf_*.npz")))
+
+
+class EngineView:
+    """Adapts gps_slam_amd.tsdf_engine.TsdfEngine to the accessor interface the oracle checks use."""
+
+    def __init__(self, eng):
+        self.e = eng
+
+    def _c(self):
+        return self.e.counters_host()
+
+    n_visible = property(lambda s: int(s._c()[2]))
+    last_free_block = property(lambda s: int(s._c()[0]))
+    last_free_excess = property(lambda s: int(s._c()[1]))
+    fv_n_visible = property(lambda s: int(s._c()[3]))
+
+    def visible_ids(self):
+        return self.e.visible_ids.cpu().numpy()[:self.n_visible]
+
+    def fv_visible_ids(self):
+        return self.e.fv_visible_ids.cpu().numpy()[:self.fv_n_visible]
+
+    def visible_type(self):
+        return self.e.visible_type.cpu().numpy()
+
+    def hash_rows(self):
+        h = self.e.hash_host()
+        keep = ~((h["ptr"] == -2) & (h["offset"] == 0) & (h["pos"] == 0).all(1))
+        idx = np.nonzero(keep)[0]
+        e = h[idx]
+        return np.concatenate([idx[:, None], e["pos"].astype(np.int64), e["offset"][:, None], e["ptr"][:, None]],
+                              1).astype(np.int32)
+
+    def allocated_blocks(self):
+        h = self.e.hash_host()
+        ptr = h["ptr"][h["ptr"] >= 0]
+        v = self.e.vba_host(ptr)
+        return v.view(np.uint8).reshape(v.shape + (8,))[..., :7]
+
+    def image(self, name):
+        H, W = self.e.H, self.e.W
+        t = {"minmax": (self.e.minmax, (H, W, 2)), "raycast": (self.e.raycast, (H, W, 4)),
+             "icp_points": (self.e.icp_points, (H, W, 4)), "icp_normals": (self.e.icp_normals, (H, W, 4)),
+             "depth": (self.e.depth, (H, W)), "fv_minmax": (self.e.fv_minmax, (H, W, 2)),
+             "fv_raycast": (self.e.fv_raycast, (H, W, 4)), "fv_colour": (self.e.fv_colour, (H, W, 4))}[name]
+        return t[0].cpu().numpy().reshape(t[1])
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_engine_reproduces_reference_golden(path):
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    g = np.load(path)
+    get = lambda k, f: g["%s@%d" % (k, f)]
+    W, H = int(g["W"]), int(g["H"])
+    eng = TsdfEngine(W, H, float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"]), float(g["voxel"]),
+                     float(g["mu"]), float(g["vf_min"]), float(g["vf_max"]))
+    v = EngineView(eng)
+    n = g["rgb"].shape[0]
+    for f in range(n):
+        M, invM = eng.ProcessFrame(_dev(g["rgb"][f]), _dev(g["depth"][f].astype(np.int16)), g["c2w"][f])
+        assert bits_equal(M, get("M", f)) and bits_equal(invM, get("invM", f))  # host pose algebra (SE3Pose)
+        check_frame(v, get, f)
+        for k, fr in enumerate(g["free_frames"]):
+            if fr == f:
+                tag = f * 1000 + k
+                fM, fInv = eng.runRaycast(g["free_c2w"][k])
+                assert bits_equal(fM, get("fv_M", tag)) and bits_equal(fInv, get("fv_invM", tag))
+                check_free_view(v, get, tag)
+    assert bits_equal(v.allocated_blocks()[::8], get("vba", n - 1))
+    assert int(v._c()[5]) == 0  # no rendering-block overflow
+
+
+@pytest.mark.parametrize("W,H,voxel,mu,frames", [(640, 480, 0.005, 0.02, 3), (320, 240, 0.01, 0.04, 6)])
+def test_engine_matches_oracle_full_size(W, H, voxel, mu, frames):
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    from oracle import tsdf_ref as R
+    seq = synth.make_sequence(W, H, frames, step_deg=1.0)
+    o = R.TsdfOracle(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel, mu, 0.2, 10.0)
+    eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel, mu, 0.2, 10.0)
+    v = EngineView(eng)
+
+    def same_frame():
+        assert [v.n_visible, v.last_free_block, v.last_free_excess] == [o.n_visible, o.last_free_block, o.last_free_excess]
+        assert bits_equal(v.visible_ids(), o.visible_ids())
+        assert bits_equal(v.hash_rows(), o.hash_rows())
+        assert bits_equal(v.visible_type(), o.visible_type())
+        for name in ("depth", "minmax", "raycast", "icp_points", "icp_normals"):
+            assert bits_equal(v.image(name), o.image(name)), name
+        assert crc_of_blocks(v.allocated_blocks()) == crc_of_blocks(o.allocated_blocks())
+
+    for f in range(frames):
+        M, invM = eng.ProcessFrame(_dev(seq["rgb"][f]), _dev(seq["depth"][f].astype(np.int16)), seq["c2w"][f])
+        oM, oInv = R.pose_from_c2w(seq["c2w"][f])
+        assert bits_equal(M, oM) and bits_equal(invM, oInv)
+        o.process_frame(seq["rgb"][f], seq["depth"][f], oM, oInv)
+        same_frame()
+    assert v.n_visible > 1000 and (v.image("raycast")[..., 3] > 0).mean() > 0.8
+    fM, fInv = eng.runRaycast(seq["c2w"][0])
+    o.free_raycast(fM, fInv)
+    assert v.fv_n_visible == o.fv_n_visible
+    assert bits_equal(v.fv_visible_ids(), o.fv_visible_ids())
+    for name in ("fv_minmax", "fv_raycast", "fv_colour"):
+        assert bits_equal(v.image(name), o.image(name)), name
+    o.close()
+
+
+def test_integration_is_idempotent_in_weight_and_converges():
+    """Size-independent property at full size: fusing the SAME frame twice keeps every allocated block, raises
+    w_depth by exactly one where the voxel was updated, and leaves sdf unchanged up to the truncating store."""
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    W, H = 640, 480
+    seq = synth.make_sequence(W, H, 1)
+    eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0)
+    v = EngineView(eng)
+    rgb, d = _dev(seq["rgb"][0]), _dev(seq["depth"][0].astype(np.int16))
+    eng.ProcessFrame(rgb, d, seq["c2w"][0])
+    h1, b1 = v.hash_rows(), v.allocated_blocks().copy()
+    eng.ProcessFrame(rgb, d, seq["c2w"][0])
+    h2, b2 = v.hash_rows(), v.allocated_blocks()
+    # second pass may only add blocks that lost a same-frame bucket collision
+    assert h2.shape[0] >= h1.shape[0] and (h2.shape[0] - h1.shape[0]) < 0.10 * h1.shape[0]
+    keep = np.isin(h2[:, 0], h1[:, 0]) & (h2[:, 5] >= 0)
+    b2k = b2[keep[h2[:, 5] >= 0]]
+    w1, w2 = b1[..., 2].astype(int), b2k[..., 2].astype(int)
+    assert set(np.unique(w2 - w1)) <= {0, 1}
+    s1 = b1[..., :2].copy().view(np.int16)[..., 0].astype(int)
+    s2 = b2k[..., :2].copy().view(np.int16)[..., 0].astype(int)
+    upd = (w2 - w1) == 1
+    assert np.abs(s2 - s1)[upd & (w1 > 0)].max() <= 1
