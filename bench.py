@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""bench.py -- SLAM frames/s of the GPS-SLAM hot path on MI355X.
+
+One "step" = one SLAM frame of SLAMPipeline::SLAMTrainCams (slam/slam_pipeline.cpp:69-132) on synthetic
+640x480 RGB-D with ~200k Gaussians: TSDF fuse + live raycast every frame; every 10th frame the <= 9 free-view
+raycasts, new-Gaussian sampling, 20 optimise iterations (forward, L1, backward, Adam) and the prune.
+Inputs (rgb uint8, depth int16 mm, GT poses) are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU, each rank runs an INDEPENDENT scene (different seed)
+-> weak scaling, no data-path collective; barrier + max-over-ranks timing only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def build_scene(W, H, n_frames, n_gauss, seed, device):
+    """Synthetic room sequence + a Gaussian model pre-populated on the scene surfaces."""
+    from tests import synth
+    from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
+    from gps_slam_amd.slam_pipeline import SLAMPipeline, compute_normal_map
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    seq = synth.make_sequence(W, H, n_frames, step_deg=0.25 + 0.01 * (seed % 7))
+    fx, fy, cx, cy = seq["fx"], seq["fy"], seq["cx"], seq["cy"]
+    eng = TsdfEngine(W, H, fx, fy, cx, cy, voxel_size=0.005, mu=0.02, view_frustum_min=0.2, view_frustum_max=10.0,
+                     device=device)
+    model = SLAMGaussianModel(dict(isect_capacity=8 << 20), device=device)
+    pipe = SLAMPipeline(eng, model, seed=seed)
+    rgb_dev = torch.as_tensor(seq["rgb"]).to(device)
+    depth_dev = torch.as_tensor(seq["depth"].astype(np.int16)).to(device)
+    cams = []
+    for k in range(n_frames):
+        img = rgb_dev[k].float() / 255.0
+        dep = (depth_dev[k].float() / 1000.0).unsqueeze(-1)
+        cams.append(Camera(k, W, H, fx, fy, cx, cy, seq["c2w"][k], image=img, depth=dep, device=device))
+    # pre-populate: back-project a few views' depth to world points (colour from the image, normals from Sobel)
+    g = torch.Generator(device=device).manual_seed(seed)
+    pts, cols, nrm = [], [], []
+    ys, xs = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    for k in range(0, n_frames, max(1, n_frames // 6)):
+        d = cams[k].depth[..., 0]
+        c2w = cams[k].c2w.to(device)
+        pc = torch.stack([(xs - cx) / fx * d, (ys - cy) / fy * d, d], -1)
+        pw = pc @ c2w[:3, :3].T + c2w[:3, 3]
+        n = compute_normal_map(pw)
+        ok = (d > 0.3).reshape(-1)
+        pts.append(pw.reshape(-1, 3)[ok]); cols.append(cams[k].image.reshape(-1, 3)[ok]); nrm.append(n.reshape(-1, 3)[ok])
+    pts, cols, nrm = torch.cat(pts), torch.cat(cols), torch.cat(nrm)
+    sel = torch.randperm(pts.shape[0], device=device, generator=g)[:n_gauss]
+    new = model.init_params(pts[sel].contiguous(), cols[sel].contiguous(), nrm[sel].contiguous())
+    # view-dependent detail so all 16 SH bands carry signal
+    new["featuresRest"] = (torch.randn(new["featuresRest"].shape, device=device, generator=g) * 0.02).contiguous()
+    model.add_params(new)
+    return seq, eng, model, pipe, cams, rgb_dev, depth_dev
+
+
+def iteration_bytes(N, Nv, I, G, P, T):
+    """Algorithmic (compulsory) HBM bytes of one optimise iteration, SURVEY.md 8(d)."""
+    return (68 * N + 217 * Nv + 24 * N + 44 * I + 8 * G + 4 * T + 44 * I + 28 * P + 40 * P + 52 * G + 24 * P + 40 * G +
+            408 * Nv + 116 * Nv + 40 * N + 28 * 59 * N)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=200000)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    W, H, K, Wm = args.width, args.height, args.steps, args.warmup
+    n_frames = K + Wm + 1
+    seq, eng, model, pipe, cams, rgb_dev, depth_dev = build_scene(W, H, n_frames, args.gaussians, 1234 + rank, device)
+
+    def run(lo, hi):
+        for i in range(lo, hi):
+            pipe.process_frame(i, cams[i], rgb_dev[i], depth_dev[i])
+
+    run(0, Wm)  # untimed warm-up (includes the first allocation-heavy frames and one optimise block)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(Wm, Wm + K)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+
+    out = None
+    if rank == 0:
+        from bench_kernels import dominant_kernel_roofline, cpu_baseline
+        N = model.getGaussianNum()
+        roof = dominant_kernel_roofline(model, pipe, eng, cams, device, HBM_PEAK_GBS)
+        out = {
+            "metric": "SLAM frames/sec @640x480, ~200k Gaussians; render PSNR vs ref",
+            "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic room0-like RGB-D %dx%d, TSDF 5mm voxels + ges splat optimise, GT pose "
+                                   "(use_gt_pose=true as in every shipped config), ~%dk Gaussians; independent scene per GPU"
+                                   % (W, H, N // 1000),
+                       "gaussians": N, "local_opt_interval": 10, "local_opt_iters": 20,
+                       "frames_per_step": 1, "stats": pipe.stats},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(seq, W, H)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

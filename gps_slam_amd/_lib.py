@@ -39,6 +39,10 @@ PROTOTYPES = {
                                     vp]),
     "gps_compose_l1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_adam_step": (i32, [C.POINTER(AdamSegment), i32, f64, f64, f64, i32, vp]),
+    "gps_gauss_preprocess_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32,
+                                       i32, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_gauss_preprocess_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_allocate": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
@@ -51,6 +55,7 @@ PROTOTYPES = {
     "gps_tsdf_process_frame": (i32, [C.POINTER(TsdfState), vp, vp, vp, vp]),
     "gps_tsdf_free_raycast": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
     "gps_pose_from_c2w": (i32, [vp, vp, vp]),
+    "gps_raycast_to_maps": (i32, [i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
 }
 
 

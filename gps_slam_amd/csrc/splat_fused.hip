@@ -1,0 +1,215 @@
+// Model-level fused kernels: everything RawGaussianModel::gesForward does per Gaussian before
+// binning (src/raw_gs_model.cpp:207-286) in ONE pass over the parameters, and its adjoint.
+//
+//   forward : scales = exp(log_scales); FullyFusedProjection; radii = clamp_max(radii, max_gs_radii);
+//             dirs = means - cam_T; SphericalHarmonicsNew(deg, dirs, cat(dc, rest), radii > 0);
+//             colors = cat(clamp_min(sh + 0.5, 0), depths); opac = sigmoid(opacities)
+//   backward: the libtorch autograd chain of the same ops, given the rasterizer's gradients.
+//
+// The reference runs ~12 libtorch kernels forward (+ a 38 MB torch::cat of the SH coefficients every
+// iteration, raw_gs_model.cpp:253) and ~20 backward; here each direction is one HBM stream:
+// forward reads 59 floats/Gaussian and writes 15, backward reads the same + 10 gradient floats and writes
+// the 59 parameter gradients (plain stores, no memsets, no atomics).
+// The per-Gaussian math is splat_math.hpp, shared with the op-level kernels the parity tests pin.
+#include "splat_math.hpp"
+
+using namespace gps;
+
+namespace {
+
+struct FusedIn {
+    const float* means;       // [N,3]
+    const float* log_scales;  // [N,3]
+    const float* quats;       // [N,4]
+    const float* opac_logit;  // [N]
+    const float* sh_dc;       // [N,3]
+    const float* sh_rest;     // [N,K-1,3]
+    const float* viewmat;     // [16] device
+    const float* Kmat;        // [9] device
+    const float* cam_pos;     // [3] device (c2w translation, raw_gs_model.cpp:202)
+    int N, K, W, H, max_radii;
+    float eps2d, near_plane, far_plane, radius_clip;
+};
+
+template <int DEG>
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t* __restrict__ radii,
+                                                             float* __restrict__ means2d, float* __restrict__ depths,
+                                                             float* __restrict__ conics, float* __restrict__ colors,
+                                                             float* __restrict__ opac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.N) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    Cam cam;
+    cam_from_arrays(in.viewmat, in.Kmat, in.W, in.H, cam);
+    const float p[3] = {in.means[3 * i], in.means[3 * i + 1], in.means[3 * i + 2]};
+    const float4 q4 = *reinterpret_cast<const float4*>(in.quats + 4 * (size_t)i);
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float s[3] = {expf(in.log_scales[3 * i]), expf(in.log_scales[3 * i + 1]), expf(in.log_scales[3 * i + 2])};
+    Proj o = project_gaussian(cam, p, q, s, in.eps2d, in.near_plane, in.far_plane, in.radius_clip);
+    if (in.max_radii > 0) o.radius = min(o.radius, in.max_radii);
+    radii[i] = o.radius;
+    *reinterpret_cast<float2*>(means2d + 2 * (size_t)i) = make_float2(o.mx, o.my);
+    depths[i] = o.z;
+    conics[3 * i] = o.ca; conics[3 * i + 1] = o.cb; conics[3 * i + 2] = o.cc;
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (o.radius > 0) {
+        const float dx = p[0] - in.cam_pos[0], dy = p[1] - in.cam_pos[1], dz = p[2] - in.cam_pos[2];
+        const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+        float Y[NB];
+        sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
+        r = Y[0] * in.sh_dc[3 * i]; g = Y[0] * in.sh_dc[3 * i + 1]; b = Y[0] * in.sh_dc[3 * i + 2];
+        const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+            r += Y[k] * cf[3 * (k - 1)]; g += Y[k] * cf[3 * (k - 1) + 1]; b += Y[k] * cf[3 * (k - 1) + 2];
+        }
+        r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
+    }
+    *reinterpret_cast<float4*>(colors + 4 * (size_t)i) = make_float4(r, g, b, o.z);
+    opac[i] = 1.f / (1.f + expf(-in.opac_logit[i]));
+}
+
+template <int DEG>
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, const int32_t* __restrict__ radii,
+                                                             const float* __restrict__ conics,
+                                                             const float* __restrict__ v_means2d,
+                                                             const float* __restrict__ v_conics,
+                                                             const float* __restrict__ v_colors,
+                                                             const float* __restrict__ v_opac,
+                                                             float* __restrict__ v_means,
+                                                             float* __restrict__ v_log_scales,
+                                                             float* __restrict__ v_quats,
+                                                             float* __restrict__ v_opac_logit,
+                                                             float* __restrict__ v_sh_dc,
+                                                             float* __restrict__ v_sh_rest) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.N) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float vp[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    float vdc[3] = {0.f, 0.f, 0.f};
+    float* vrest = v_sh_rest + (size_t)i * (in.K - 1) * 3;
+    const bool vis = radii[i] > 0;
+    int written = 0;  // number of sh_rest bands written below
+    if (vis) {
+        Cam cam;
+        cam_from_arrays(in.viewmat, in.Kmat, in.W, in.H, cam);
+        const float p[3] = {in.means[3 * i], in.means[3 * i + 1], in.means[3 * i + 2]};
+        const float4 q4 = *reinterpret_cast<const float4*>(in.quats + 4 * (size_t)i);
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float s[3] = {expf(in.log_scales[3 * i]), expf(in.log_scales[3 * i + 1]), expf(in.log_scales[3 * i + 2])};
+        const float conic[3] = {conics[3 * i], conics[3 * i + 1], conics[3 * i + 2]};
+        const float vm2[2] = {v_means2d[2 * i], v_means2d[2 * i + 1]};
+        const float vc[3] = {v_conics[3 * i], v_conics[3 * i + 1], v_conics[3 * i + 2]};
+        const float4 vcol = *reinterpret_cast<const float4*>(v_colors + 4 * (size_t)i);
+        // depth channel of `colors` is the projection's depth output (raw_gs_model.cpp:286)
+        project_gaussian_vjp(cam, p, q, s, conic, vm2, vcol.w, vc, vp, vq, vs);
+        // SH: recompute the un-clamped colour to evaluate clamp_min's mask (grad passes where sh + 0.5 >= 0)
+        const float dx = p[0] - in.cam_pos[0], dy = p[1] - in.cam_pos[1], dz = p[2] - in.cam_pos[2];
+        const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+        float Y[NB];
+        sh_basis<DEG>(x, y, z, Y);
+        const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
+        float c0 = Y[0] * in.sh_dc[3 * i], c1 = Y[0] * in.sh_dc[3 * i + 1], c2 = Y[0] * in.sh_dc[3 * i + 2];
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+            c0 += Y[k] * cf[3 * (k - 1)]; c1 += Y[k] * cf[3 * (k - 1) + 1]; c2 += Y[k] * cf[3 * (k - 1) + 2];
+        }
+        const float vr = (c0 + 0.5f >= 0.f) ? vcol.x : 0.f;
+        const float vg = (c1 + 0.5f >= 0.f) ? vcol.y : 0.f;
+        const float vb = (c2 + 0.5f >= 0.f) ? vcol.z : 0.f;
+        vdc[0] = Y[0] * vr; vdc[1] = Y[0] * vg; vdc[2] = Y[0] * vb;
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+            vrest[3 * (k - 1)] = Y[k] * vr; vrest[3 * (k - 1) + 1] = Y[k] * vg; vrest[3 * (k - 1) + 2] = Y[k] * vb;
+        }
+        written = NB - 1;
+        if (DEG >= 1) {
+            float dX[NB], dY[NB], dZ[NB];
+            sh_basis_grad<DEG>(x, y, z, dX, dY, dZ);
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+            for (int k = 1; k < NB; k++) {
+                const float w = cf[3 * (k - 1)] * vr + cf[3 * (k - 1) + 1] * vg + cf[3 * (k - 1) + 2] * vb;
+                gx += dX[k] * w; gy += dY[k] * w; gz += dZ[k] * w;
+            }
+            const float d = gx * x + gy * y + gz * z;
+            // dirs = means - cam_T  ->  v_means += v_dirs
+            vp[0] += (gx - d * x) * inorm; vp[1] += (gy - d * y) * inorm; vp[2] += (gz - d * z) * inorm;
+        }
+        // scales = exp(log_scales)
+        vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2];
+    }
+    for (int k = written; k < in.K - 1; k++) { vrest[3 * k] = 0.f; vrest[3 * k + 1] = 0.f; vrest[3 * k + 2] = 0.f; }
+    v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
+    v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
+    *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+    v_sh_dc[3 * i] = vdc[0]; v_sh_dc[3 * i + 1] = vdc[1]; v_sh_dc[3 * i + 2] = vdc[2];
+    // opac = sigmoid(logit): receives gradient for every Gaussian the rasterizer touched (0 otherwise)
+    const float o = 1.f / (1.f + expf(-in.opac_logit[i]));
+    v_opac_logit[i] = v_opac[i] * o * (1.f - o);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_gauss_preprocess_fwd(int N, int K, int sh_degree, const float* means, const float* log_scales,
+                             const float* quats, const float* opac_logit, const float* sh_dc, const float* sh_rest,
+                             const float* viewmat, const float* Kmat, const float* cam_pos, int width, int height,
+                             float eps2d, float near_plane, float far_plane, float radius_clip, int max_gs_radii,
+                             int32_t* radii, float* means2d, float* depths, float* conics, float* colors,
+                             float* opacities, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
+    GPS_REQUIRE(radii && means2d && depths && conics && colors && opacities);
+    FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
+                  max_gs_radii, eps2d, near_plane, far_plane, radius_clip};
+    dim3 g(gps_div_up(N, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (sh_degree) {
+        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
+        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
+        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
+        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
+        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
+    }
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float* means, const float* log_scales,
+                             const float* quats, const float* opac_logit, const float* sh_dc, const float* sh_rest,
+                             const float* viewmat, const float* Kmat, const float* cam_pos, int width, int height,
+                             float eps2d, const int32_t* radii, const float* conics, const float* v_means2d,
+                             const float* v_conics, const float* v_colors, const float* v_opacities, float* v_means,
+                             float* v_log_scales, float* v_quats, float* v_opac_logit, float* v_sh_dc,
+                             float* v_sh_rest, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
+    GPS_REQUIRE(radii && conics && v_means2d && v_conics && v_colors && v_opacities);
+    GPS_REQUIRE(v_means && v_log_scales && v_quats && v_opac_logit && v_sh_dc && (K == 1 || v_sh_rest));
+    FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
+                  0, eps2d, 0.f, 0.f, 0.f};
+    dim3 g(gps_div_up(N, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+#define GPS_BWD(D)                                                                                              \
+    preprocess_bwd_kernel<D><<<g, b, 0, s>>>(in, radii, conics, v_means2d, v_conics, v_colors, v_opacities, v_means, \
+                                             v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest)
+    switch (sh_degree) {
+        case 0: GPS_BWD(0); break;
+        case 1: GPS_BWD(1); break;
+        case 2: GPS_BWD(2); break;
+        case 3: GPS_BWD(3); break;
+        default: GPS_BWD(4); break;
+    }
+#undef GPS_BWD
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // extern "C"

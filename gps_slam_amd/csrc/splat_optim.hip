@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void compose_l1_kernel(int P, const float4* __
             const float bw = ref > 0.f ? 1.f : 0.f;  // depth weight only where the raycast hit (:324-326)
             depth[p] = (rc.w + ref * bw) / (w + bw);
         }
+        if (gt_rgb == nullptr) continue;  // render-only call (NoGradGuard paths of the reference)
         const float d0 = gt_rgb[3 * p] - c0, d1 = gt_rgb[3 * p + 1] - c1, d2 = gt_rgb[3 * p + 2] - c2;
         part += fabsf(d0) + fabsf(d1) + fabsf(d2);
         if (v_render_colors) {
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void compose_l1_kernel(int P, const float4* __
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
+    if (threadIdx.x == 0 && loss != nullptr) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
 }
 
 struct AdamArgs {
@@ -95,7 +96,9 @@ int gps_compose_l1(int width, int height, const float* render_colors, const floa
                    float* loss, float* v_render_colors, float* v_render_alphas, gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(width > 0 && height > 0);
-    GPS_REQUIRE(render_colors && weight_sum && base_color && gt_rgb && rgb && loss);
+    GPS_REQUIRE(render_colors && weight_sum && base_color && rgb);
+    GPS_REQUIRE(gt_rgb == nullptr || loss != nullptr);
+    GPS_REQUIRE(gt_rgb != nullptr || v_render_colors == nullptr);
     GPS_REQUIRE(depth == nullptr || ref_depth_raw != nullptr);
     GPS_REQUIRE((v_render_colors == nullptr) == (v_render_alphas == nullptr));
     const int P = width * height;

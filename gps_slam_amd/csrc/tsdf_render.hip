@@ -279,6 +279,29 @@ __global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* 
     out[loc] = make_uchar4((unsigned char)(c0 * 255.0f), (unsigned char)(c1 * 255.0f), (unsigned char)(c2 * 255.0f), 255);
 }
 
+
+// runRaycastByCam glue (slam/slam_pipeline.cpp:386-403 + cv_utils.cpp:322-341) in one pass:
+// colour uchar4 -> float3 / 255; vertex = xyz * [w > 0] * voxel_size; confidence = w;
+// depth = z of (w2c * [vertex, 1]) / w-row, forced to 0 where vertex.sum() == 0.
+__global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* __restrict__ rays,
+                                                          const uchar4* __restrict__ colour, float voxel_size, Mat4 w2c_rm,
+                                                          float* __restrict__ color_map, float* __restrict__ vertex_map,
+                                                          float* __restrict__ conf_map, float* __restrict__ depth_map) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 r = rays[i];
+    const uchar4 c = colour[i];
+    color_map[3 * i] = (float)c.x / 255.0f; color_map[3 * i + 1] = (float)c.y / 255.0f; color_map[3 * i + 2] = (float)c.z / 255.0f;
+    const float keep = r.w > 0 ? 1.0f : 0.0f;
+    const float vx = (r.x * keep) * voxel_size, vy = (r.y * keep) * voxel_size, vz = (r.z * keep) * voxel_size;
+    vertex_map[3 * i] = vx; vertex_map[3 * i + 1] = vy; vertex_map[3 * i + 2] = vz;
+    conf_map[i] = r.w;
+    const float* m = w2c_rm.m;  // row-major here
+    const float tz = m[8] * vx + m[9] * vy + m[10] * vz + m[11] * 1.0f;
+    const float tw = m[12] * vx + m[13] * vy + m[14] * vz + m[15] * 1.0f;
+    depth_map[i] = ((vx + vy) + vz == 0.0f) ? 0.0f : tz / tw;
+}
+
 // ---------------------------------------------------------------- host-side pose algebra (ORUtils::SE3Pose)
 // General 4x4 inverse by cofactors in the operation order of ORUtils/Matrix.h:177-238.
 bool mat4_inverse(const float* a, float* out) {
@@ -476,6 +499,19 @@ int gps_tsdf_free_raycast(const gps_tsdf_state* s, const float* M, const float* 
     if ((r = gps_tsdf_expected_depths(s, M, 1, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_raycast(s, invM, 1, 0, stream)) != GPS_OK) return r;
     return gps_tsdf_render_colour(s, stream);
+}
+
+int gps_raycast_to_maps(int width, int height, const float* rays, const uint8_t* colour, float voxel_size,
+                        const float* w2c_row_major, float* color_map, float* vertex_map, float* confidence_map,
+                        float* depth_map, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(width > 0 && height > 0 && rays && colour && w2c_row_major && color_map && vertex_map && confidence_map && depth_map);
+    const int P = width * height;
+    raycast_maps_kernel<<<gps_div_up(P, 256), 256, 0, (hipStream_t)stream>>>(
+        P, reinterpret_cast<const float4*>(rays), reinterpret_cast<const uchar4*>(colour), voxel_size,
+        load_mat(w2c_row_major), color_map, vertex_map, confidence_map, depth_map);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
 }
 
 int gps_pose_from_c2w(const float* c2w_row_major, float* M, float* invM) {

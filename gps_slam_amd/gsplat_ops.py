@@ -197,13 +197,15 @@ def compose_l1(render_colors, weight_sum, base_color, ref_depth_raw, gt_rgb, nee
     """Fused raw_gs_model.cpp:318-326 + computeLoss (:369-417, L1 only) + backward.
     -> rgb[H,W,3], depth[H,W,1]|None, loss[1], v_render_colors[1,H,W,4]|None, v_render_alphas[1,H,W,1]|None"""
     render_colors, weight_sum = _f32c(render_colors), _f32c(weight_sum)
-    base_color, gt_rgb = _f32c(base_color), _f32c(gt_rgb)
+    base_color = _f32c(base_color)
+    gt_rgb = None if gt_rgb is None else _f32c(gt_rgb)
+    need_grad = need_grad and gt_rgb is not None
     H, W = render_colors.shape[-3], render_colors.shape[-2]
     dev = render_colors.device
     rgb = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((H, W, 1), dtype=torch.float32, device=dev) if need_depth else None
     ref = _f32c(ref_depth_raw) if need_depth else None
-    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev) if gt_rgb is not None else None
     v_rc = torch.empty_like(render_colors) if need_grad else None
     v_ra = torch.empty_like(weight_sum) if need_grad else None
     check(lib.gps_compose_l1(W, H, _ptr(render_colors), _ptr(weight_sum), _ptr(base_color), _ptr(ref), _ptr(gt_rgb),
@@ -223,3 +225,42 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, lrs, step, betas=(0.9, 0.999
         segs[k].numel, segs[k].lr = p.numel(), float(lrs[k])
     check(lib.gps_adam_step(segs, n, float(betas[0]), float(betas[1]), float(eps), int(step), _stream()),
           "gps_adam_step")
+
+
+# ----------------------------------------------------------------------------- fused model-level kernels
+def gauss_preprocess_fwd(means, log_scales, quats, opac_logit, sh_dc, sh_rest, sh_degree, viewmat, Kmat, cam_pos,
+                         width, height, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, max_gs_radii=100,
+                         out=None):
+    """One pass of raw_gs_model.cpp:207-286 (see include/gps_slam_hip.h: gps_gauss_preprocess_fwd).
+    -> radii[N] i32 (clamped), means2d[N,2], depths[N], conics[N,3], colors[N,4], opacities[N]"""
+    N = means.shape[0]
+    K = 1 + (sh_rest.shape[1] if sh_rest is not None and sh_rest.numel() else 0)
+    dev = means.device
+    if out is None:
+        out = (torch.empty(N, dtype=torch.int32, device=dev), torch.empty((N, 2), dtype=torch.float32, device=dev),
+               torch.empty(N, dtype=torch.float32, device=dev), torch.empty((N, 3), dtype=torch.float32, device=dev),
+               torch.empty((N, 4), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev))
+    radii, means2d, depths, conics, colors, opac = out
+    check(lib.gps_gauss_preprocess_fwd(N, K, sh_degree, _ptr(means), _ptr(log_scales), _ptr(quats), _ptr(opac_logit),
+                                       _ptr(sh_dc), _ptr(sh_rest), _ptr(viewmat), _ptr(Kmat), _ptr(cam_pos), width,
+                                       height, eps2d, near_plane, far_plane, radius_clip, int(max_gs_radii), _ptr(radii),
+                                       _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors), _ptr(opac), _stream()),
+          "gps_gauss_preprocess_fwd")
+    return out
+
+
+def gauss_preprocess_bwd(means, log_scales, quats, opac_logit, sh_dc, sh_rest, sh_degree, viewmat, Kmat, cam_pos,
+                         width, height, eps2d, radii, conics, v_means2d, v_conics, v_colors, v_opacities, out=None):
+    """Adjoint of gauss_preprocess_fwd -> v_means, v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest"""
+    N = means.shape[0]
+    K = 1 + (sh_rest.shape[1] if sh_rest is not None and sh_rest.numel() else 0)
+    if out is None:
+        out = (torch.empty_like(means), torch.empty_like(log_scales), torch.empty_like(quats),
+               torch.empty_like(opac_logit), torch.empty_like(sh_dc), torch.empty_like(sh_rest))
+    v_means, v_ls, v_q, v_ol, v_dc, v_rest = out
+    check(lib.gps_gauss_preprocess_bwd(N, K, sh_degree, _ptr(means), _ptr(log_scales), _ptr(quats), _ptr(opac_logit),
+                                       _ptr(sh_dc), _ptr(sh_rest), _ptr(viewmat), _ptr(Kmat), _ptr(cam_pos), width,
+                                       height, eps2d, _ptr(radii), _ptr(conics), _ptr(v_means2d), _ptr(v_conics),
+                                       _ptr(v_colors), _ptr(v_opacities), _ptr(v_means), _ptr(v_ls), _ptr(v_q),
+                                       _ptr(v_ol), _ptr(v_dc), _ptr(v_rest), _stream()), "gps_gauss_preprocess_bwd")
+    return out

@@ -139,7 +139,8 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
  *   loss  = mean |gt - rgb|  over H*W*3
  * In : render_colors[H,W,4], weight_sum[H,W], base_color[H,W,3], ref_depth_raw[H,W], gt_rgb[H,W,3]
  * Out: rgb[H,W,3], depth[H,W] (may be NULL), loss[1] (device float, accumulated: caller zeroes it),
- *      v_render_colors[H,W,4], v_render_alphas[H,W] (NULL to skip the backward half). */
+ *      v_render_colors[H,W,4], v_render_alphas[H,W] (NULL to skip the backward half).
+ * gt_rgb == NULL renders only (rgb/depth), as the reference's NoGradGuard call sites do. */
 GPS_API int gps_compose_l1(int width, int height, const float *render_colors, const float *weight_sum,
                    const float *base_color, const float *ref_depth_raw, const float *gt_rgb, float *rgb,
                    float *depth, float *loss, float *v_render_colors, float *v_render_alphas, gps_stream stream);
@@ -165,6 +166,34 @@ typedef struct {
  * step is the 1-based step count t. */
 GPS_API int gps_adam_step(const gps_adam_segment *segments, int n_segments, double beta1, double beta2, double eps, int step,
                   gps_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* Splat: fused per-Gaussian pre-/post-processing (model level)        */
+/* ------------------------------------------------------------------ */
+
+/* Everything RawGaussianModel::gesForward does per Gaussian before binning (src/raw_gs_model.cpp:207-286) in one
+ * pass: exp(log_scales) -> projection -> radii clamp (max_gs_radii, 0 = off) -> dirs = means - cam_pos ->
+ * SH (coefficients given as the model stores them: sh_dc[N,3] + sh_rest[N,K-1,3], no torch::cat) ->
+ * colors[N,4] = {clamp_min(sh + 0.5, 0), depth} -> opacities[N] = sigmoid(opac_logit).
+ * viewmat[16], Kmat[9], cam_pos[3] are device arrays. */
+GPS_API int gps_gauss_preprocess_fwd(int N, int K, int sh_degree, const float *means, const float *log_scales,
+                                     const float *quats, const float *opac_logit, const float *sh_dc,
+                                     const float *sh_rest, const float *viewmat, const float *Kmat,
+                                     const float *cam_pos, int width, int height, float eps2d, float near_plane,
+                                     float far_plane, float radius_clip, int max_gs_radii, int32_t *radii,
+                                     float *means2d, float *depths, float *conics, float *colors, float *opacities,
+                                     gps_stream stream);
+
+/* Adjoint of gps_gauss_preprocess_fwd == the libtorch autograd chain cat/clamp_min/SH/projection/exp/sigmoid
+ * backward (gsplat_wapper.hpp:56-95,156-240 + ATen), writing all six parameter gradients in one pass. */
+GPS_API int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float *means, const float *log_scales,
+                                     const float *quats, const float *opac_logit, const float *sh_dc,
+                                     const float *sh_rest, const float *viewmat, const float *Kmat,
+                                     const float *cam_pos, int width, int height, float eps2d, const int32_t *radii,
+                                     const float *conics, const float *v_means2d, const float *v_conics,
+                                     const float *v_colors, const float *v_opacities, float *v_means,
+                                     float *v_log_scales, float *v_quats, float *v_opac_logit, float *v_sh_dc,
+                                     float *v_sh_rest, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* TSDF: voxel-block-hash fusion and raycast (InfiniTAM ITMLib path)   */
@@ -274,6 +303,13 @@ GPS_API int gps_tsdf_process_frame(const gps_tsdf_state *s, const int16_t *depth
 /* ITMBasicEngine::runRaycast(pose, intrinsics) (Core/ITMBasicEngine.tpp:519-525) = find_visible +
  * expected_depths(free) + raycast(free) + render_colour. */
 GPS_API int gps_tsdf_free_raycast(const gps_tsdf_state *s, const float *M, const float *invM, gps_stream stream);
+
+/* SLAMPipeline::runRaycastByCam tensor glue (slam/slam_pipeline.cpp:386-403, src/cv_utils.cpp:322-341) fused:
+ * rays float4[H*W] + colour uchar4[H*W] (device) -> color_map[H,W,3] (/255), vertex_map[H,W,3] (metres, 0 where no hit),
+ * confidence_map[H,W,1], depth_map[H,W,1] = camera-space z under w2c (host float[16], ROW-major), 0 where no hit. */
+GPS_API int gps_raycast_to_maps(int width, int height, const float *rays, const uint8_t *colour, float voxel_size,
+                                const float *w2c_row_major, float *color_map, float *vertex_map,
+                                float *confidence_map, float *depth_map, gps_stream stream);
 
 /* Host-side pose algebra of ORUtils::SE3Pose as used by ITMBasicEngine.tpp:278-279 and slam_pipeline.cpp:367-371:
  * pose.SetInvM(c2w); pose.Coerce(); -> M = pose.GetM(), invM = pose.GetInvM().
