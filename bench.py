@@ -82,20 +82,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from gps_slam_amd.dist_util import Group, env_ranks, scene_seed
+    rank, local_rank, world = env_ranks()
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))
+    grp = Group(backend="nccl", device=device)  # RCCL; used for barrier + max-over-ranks only
 
     W, H, K, Wm = args.width, args.height, args.steps, args.warmup
     n_frames = K + Wm + 1
-    seq, eng, model, pipe, cams, rgb_dev, depth_dev = build_scene(W, H, n_frames, args.gaussians, 1234 + rank, device)
+    seq, eng, model, pipe, cams, rgb_dev, depth_dev = build_scene(W, H, n_frames, args.gaussians, scene_seed(rank), device)
 
     def run(lo, hi):
         for i in range(lo, hi):
@@ -103,20 +99,14 @@ def main():
 
     run(0, Wm)  # untimed warm-up (includes the first allocation-heavy frames and one optimise block)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    grp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(Wm, Wm + K)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    grp.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    dt = grp.max_over_ranks(time.perf_counter() - t0)
 
     out = None
     if rank == 0:
@@ -138,8 +128,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(seq, W, H)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -232,15 +232,17 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
                           const float* opacities, const int32_t* radii, const float* ref_depth_map, int width,
                           int height, const int32_t* group_gs_ids, const int32_t* group_starts, const int64_t* counts,
                           float delta_depth, const float* v_render_colors, const float* v_render_alphas,
-                          float* v_means2d, float* v_conics, float* v_colors, float* v_opacities, gps_stream stream) {
+                          float* v_means2d, float* v_conics, float* v_colors, float* v_opacities, int accumulate,
+                          gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(means2d && conics && colors && opacities && radii && ref_depth_map && group_gs_ids && group_starts &&
                 counts && v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities);
     hipStream_t s = (hipStream_t)stream;
-    zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
-                                                                                 v_opacities);
+    if (!accumulate)
+        zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
+                                                                                     v_opacities);
     raster_ges_bwd_gs_kernel<<<2048, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
                                                   (const float4*)colors, opacities, radii, ref_depth_map, counts,
                                                   delta_depth, width, height, (const float4*)v_render_colors,

@@ -175,19 +175,24 @@ def rasterize_to_pixels_fwd_ges(means2d, conics, colors, opacities, ref_depth_ma
 
 
 def rasterize_to_pixels_bwd_ges_gs_parallel(means2d, conics, colors, opacities, radii, ref_depth_map, width, height,
-                                            isect, delta_depth, v_render_colors, v_render_alphas):
+                                            isect, delta_depth, v_render_colors, v_render_alphas, out=None,
+                                            accumulate=False):
     """gsplat::rasterize_to_pixels_bwd_ges_gs_parallel_tensor (rasterize_to_pixels_bwd_ges_new_parallel.cu:203-385)
     -> v_means2d[1,N,2], v_conics[1,N,3], v_colors[1,N,4], v_opacities (shape of opacities)"""
     means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
     ref_depth_map, v_render_colors, v_render_alphas = _f32c(ref_depth_map), _f32c(v_render_colors), _f32c(v_render_alphas)
     radii = radii.contiguous()
     N = opacities.numel()
-    v_m, v_c, v_col, v_o = (torch.empty_like(means2d), torch.empty_like(conics), torch.empty_like(colors),
-                            torch.empty_like(opacities))
+    if out is None:
+        assert not accumulate
+        out = (torch.empty_like(means2d), torch.empty_like(conics), torch.empty_like(colors),
+               torch.empty_like(opacities))
+    v_m, v_c, v_col, v_o = out
     check(lib.gps_raster_ges_bwd_gs(N, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(radii),
                                     _ptr(ref_depth_map), width, height, _ptr(isect.group_gs_ids),
                                     _ptr(isect.group_starts), _ptr(isect.counts), delta_depth, _ptr(v_render_colors),
-                                    _ptr(v_render_alphas), _ptr(v_m), _ptr(v_c), _ptr(v_col), _ptr(v_o), _stream()),
+                                    _ptr(v_render_alphas), _ptr(v_m), _ptr(v_c), _ptr(v_col), _ptr(v_o),
+                                    1 if accumulate else 0, _stream()),
           "gps_raster_ges_bwd_gs")
     return v_m, v_c, v_col, v_o
 

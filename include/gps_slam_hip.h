@@ -119,14 +119,14 @@ GPS_API int gps_raster_ges_fwd(int N, const float *means2d, const float *conics,
 /* replaces gsplat::rasterize_to_pixels_bwd_ges_gs_parallel_tensor
  * (rasterize_to_pixels_bwd_ges_new_parallel.cu:203-385): Gaussian-parallel backward over the
  * 2r x 2r integer pixel box of every Gaussian.  n_groups is read from counts[1].
- * v_means2d[N,2] v_conics[N,3] v_colors[N,4] v_opacities[N] are zero-filled by this call and then
- * accumulated. */
+ * v_means2d[N,2] v_conics[N,3] v_colors[N,4] v_opacities[N]: accumulate == 0 -> zero-filled by this call and then
+ * accumulated (the reference's zeros_like + atomicAdd); accumulate != 0 -> added to what the buffers hold. */
 GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *conics, const float *colors,
                           const float *opacities, const int32_t *radii, const float *ref_depth_map, int width,
                           int height, const int32_t *group_gs_ids, const int32_t *group_starts,
                           const int64_t *counts, float delta_depth, const float *v_render_colors,
                           const float *v_render_alphas, float *v_means2d, float *v_conics, float *v_colors,
-                          float *v_opacities, gps_stream stream);
+                          float *v_opacities, int accumulate, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* Splat: compose + L1 loss (fused replacement of libtorch glue)       */
