@@ -21,6 +21,23 @@ class TsdfState(C.Structure):
                 ("fv_visible_ids", vp), ("fv_minmax", vp), ("fv_raycast", vp), ("fv_colour", vp)]
 
 
+class SplatStep(C.Structure):
+    """gps_splat_step (include/gps_slam_hip.h)"""
+    _fields_ = ([(n, i32) for n in ("N", "K", "sh_degree", "width", "height", "max_gs_radii")] +
+                [(n, f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "delta_depth")] +
+                [(n, vp) for n in ("means", "log_scales", "quats", "opac_logit", "sh_dc", "sh_rest", "viewmat", "Kmat",
+                                   "cam_pos", "ref_depth_clamped", "base_color", "gt_rgb", "radii", "means2d", "depths",
+                                   "conics", "colors", "opacities")] +
+                [(n, i64) for n in ("isect_capacity", "group_capacity", "workspace_bytes")] +
+                [(n, vp) for n in ("tiles_per_gauss", "flatten_ids", "group_gs_ids", "group_starts", "tile_offsets",
+                                   "counts", "workspace", "render_colors", "weight_sum", "rgb", "loss",
+                                   "v_render_colors", "v_render_alphas", "v_means2d", "v_conics", "v_colors",
+                                   "v_opacities")] +
+                [(p + n, vp) for p in ("g_", "m_", "v_") for n in ("means", "log_scales", "quats", "opac_logit", "sh_dc",
+                                                                   "sh_rest")] +
+                [("lr", f64 * 6), ("beta1", f64), ("beta2", f64), ("adam_eps", f64)])
+
+
 class AdamSegment(C.Structure):
     _fields_ = [("param", vp), ("grad", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("numel", i64), ("lr", f64)]
 
@@ -55,7 +72,9 @@ PROTOTYPES = {
     "gps_tsdf_process_frame": (i32, [C.POINTER(TsdfState), vp, vp, vp, vp]),
     "gps_tsdf_free_raycast": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
     "gps_pose_from_c2w": (i32, [vp, vp, vp]),
-    "gps_raycast_to_maps": (i32, [i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
+    "gps_raycast_to_maps": (i32, [i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_splat_render": (i32, [C.POINTER(SplatStep), vp]),
+    "gps_splat_train_step": (i32, [C.POINTER(SplatStep), i32, vp]),
 }
 
 

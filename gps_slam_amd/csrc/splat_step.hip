@@ -1,0 +1,59 @@
+// One optimise iteration of SLAMPipeline::localOptimize (slam/slam_pipeline.cpp:247-254):
+//   model.forward -> computeLoss -> loss.backward() -> optimizersStep() -> optimizersZeroGrad()
+// as ONE C-ABI call that enqueues the whole kernel chain on a stream (and the render-only half for the
+// NoGradGuard call sites).  It only sequences the entry points the parity tests pin individually; it exists so
+// that a host in any language pays one FFI crossing per iteration instead of ~10, and so that the chain can be
+// captured into a hipGraph by the caller (nothing here allocates or synchronises).
+#include "common.hpp"
+
+extern "C" {
+
+int gps_splat_render(const gps_splat_step* a, gps_stream stream) {
+    GPS_REQUIRE(a != nullptr);
+    const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
+    int r;
+    r = gps_gauss_preprocess_fwd(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
+                                 a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
+                                 a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
+                                 a->depths, a->conics, a->colors, a->opacities, stream);
+    if (r != GPS_OK) return r;
+    r = gps_isect_tiles_no_depth(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
+                                 a->tiles_per_gauss, nullptr, a->flatten_ids, a->group_gs_ids, a->group_starts,
+                                 a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
+    if (r != GPS_OK) return r;
+    r = gps_raster_ges_fwd(a->N, a->means2d, a->conics, a->colors, a->opacities, a->ref_depth_clamped, a->width,
+                           a->height, 16, a->tile_offsets, a->flatten_ids, a->counts, a->delta_depth, a->render_colors,
+                           a->weight_sum, nullptr, stream);
+    return r;
+}
+
+int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stream) {
+    GPS_REQUIRE(a != nullptr && adam_step >= 1);
+    GPS_REQUIRE(a->gt_rgb && a->loss && a->v_render_colors && a->v_render_alphas);
+    int r = gps_splat_render(a, stream);
+    if (r != GPS_OK) return r;
+    r = gps_compose_l1(a->width, a->height, a->render_colors, a->weight_sum, a->base_color, nullptr, a->gt_rgb, a->rgb,
+                       nullptr, a->loss, a->v_render_colors, a->v_render_alphas, stream);
+    if (r != GPS_OK) return r;
+    r = gps_raster_ges_bwd_gs(a->N, a->means2d, a->conics, a->colors, a->opacities, a->radii, a->ref_depth_clamped,
+                              a->width, a->height, a->group_gs_ids, a->group_starts, a->counts, a->delta_depth,
+                              a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
+                              a->v_opacities, 0, stream);
+    if (r != GPS_OK) return r;
+    r = gps_gauss_preprocess_bwd(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
+                                 a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d, a->radii,
+                                 a->conics, a->v_means2d, a->v_conics, a->v_colors, a->v_opacities, a->g_means,
+                                 a->g_log_scales, a->g_quats, a->g_opac_logit, a->g_sh_dc, a->g_sh_rest, stream);
+    if (r != GPS_OK) return r;
+    gps_adam_segment seg[6] = {
+        {a->means, a->g_means, a->m_means, a->v_means, (int64_t)a->N * 3, a->lr[0]},
+        {a->log_scales, a->g_log_scales, a->m_log_scales, a->v_log_scales, (int64_t)a->N * 3, a->lr[1]},
+        {a->quats, a->g_quats, a->m_quats, a->v_quats, (int64_t)a->N * 4, a->lr[2]},
+        {a->sh_dc, a->g_sh_dc, a->m_sh_dc, a->v_sh_dc, (int64_t)a->N * 3, a->lr[3]},
+        {a->sh_rest, a->g_sh_rest, a->m_sh_rest, a->v_sh_rest, (int64_t)a->N * (a->K - 1) * 3, a->lr[4]},
+        {a->opac_logit, a->g_opac_logit, a->m_opac_logit, a->v_opac_logit, (int64_t)a->N, a->lr[5]},
+    };
+    return gps_adam_step(seg, 6, a->beta1, a->beta2, a->adam_eps, adam_step, stream);
+}
+
+}  // extern "C"

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* 
 __global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* __restrict__ rays,
                                                           const uchar4* __restrict__ colour, float voxel_size, Mat4 w2c_rm,
                                                           float* __restrict__ color_map, float* __restrict__ vertex_map,
-                                                          float* __restrict__ conf_map, float* __restrict__ depth_map) {
+                                                          float* __restrict__ conf_map, float* __restrict__ depth_map,
+                                                          float* __restrict__ depth_clamped) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const float4 r = rays[i];
@@ -299,7 +300,9 @@ __global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* 
     const float* m = w2c_rm.m;  // row-major here
     const float tz = m[8] * vx + m[9] * vy + m[10] * vz + m[11] * 1.0f;
     const float tw = m[12] * vx + m[13] * vy + m[14] * vz + m[15] * 1.0f;
-    depth_map[i] = ((vx + vy) + vz == 0.0f) ? 0.0f : tz / tw;
+    const float dz = ((vx + vy) + vz == 0.0f) ? 0.0f : tz / tw;
+    depth_map[i] = dz;
+    if (depth_clamped) depth_clamped[i] = dz < 0.01f ? 1000.0f : dz;
 }
 
 // ---------------------------------------------------------------- host-side pose algebra (ORUtils::SE3Pose)
@@ -503,13 +506,13 @@ int gps_tsdf_free_raycast(const gps_tsdf_state* s, const float* M, const float* 
 
 int gps_raycast_to_maps(int width, int height, const float* rays, const uint8_t* colour, float voxel_size,
                         const float* w2c_row_major, float* color_map, float* vertex_map, float* confidence_map,
-                        float* depth_map, gps_stream stream) {
+                        float* depth_map, float* depth_map_clamped, gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(width > 0 && height > 0 && rays && colour && w2c_row_major && color_map && vertex_map && confidence_map && depth_map);
     const int P = width * height;
     raycast_maps_kernel<<<gps_div_up(P, 256), 256, 0, (hipStream_t)stream>>>(
         P, reinterpret_cast<const float4*>(rays), reinterpret_cast<const uchar4*>(colour), voxel_size,
-        load_mat(w2c_row_major), color_map, vertex_map, confidence_map, depth_map);
+        load_mat(w2c_row_major), color_map, vertex_map, confidence_map, depth_map, depth_map_clamped);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

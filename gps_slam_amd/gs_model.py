@@ -13,7 +13,10 @@ import math
 
 import torch
 
+import ctypes as C
+
 from . import gsplat_ops as ops
+from ._lib import SplatStep, check, lib
 
 C0 = 0.28209479177387814  # gsplat_wapper.cpp:117
 
@@ -134,6 +137,9 @@ class RawGaussianModel:
         self._opt = None
         self._isect = None
         self._bufs = {}
+        self._step = None
+        self._step_key = None
+        self._step_bufs = None
 
     # ------------------------------------------------------------------ parameters
     def getGaussianNum(self):
@@ -194,26 +200,83 @@ class RawGaussianModel:
                self.lrs["featuresRest"], self.lrs["opacities"]]
         self._opt = dict(m=[torch.zeros_like(t) for t in params], v=[torch.zeros_like(t) for t in params],
                          g=[torch.empty_like(t) for t in params], lrs=lrs, step=0)
+        self._step = None  # re-bind the step struct to the fresh state
 
-    def train_step(self, cam, ref_depth, base_color, gt_rgb):
-        """model.forward -> computeLoss -> loss.backward -> optimizersStep/ZeroGrad (slam_pipeline.cpp:247-254)"""
+    def _step_struct(self, W, H):
+        """Persistent gps_splat_step for the current N / image size (rebuilt after add/prune)."""
         p = self.opt_gs_params
-        st = self._render(cam, ref_depth, base_color)
-        rgb, _, loss, v_rc, v_ra = ops.compose_l1(st["render_colors"], st["weight_sum"], base_color, ref_depth, gt_rgb,
-                                                 need_depth=False)
-        v_m2, v_con, v_col, v_op = ops.rasterize_to_pixels_bwd_ges_gs_parallel(
-            st["means2d"], st["conics"], st["colors"], st["opac"], st["radii"], st["ref_clamped"], st["W"], st["H"],
-            self._isect, self.delta_depth, v_rc, v_ra)
+        N = p.getGaussianNum()
+        key = (N, W, H, p.means.data_ptr())
+        if self._step is not None and self._step_key == key:
+            return self._step
+        d = self.device
+        tw, th = math.ceil(W / self.tile_size), math.ceil(H / self.tile_size)
+        icap = int(self.isect_capacity or max(1 << 20, 16 * N))
+        gcap = 2 * icap
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=d)
+        i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=d)
+        B = dict(radii=i32(N), means2d=f(N, 2), depths=f(N), conics=f(N, 3), colors=f(N, 4), opacities=f(N),
+                 tiles_per_gauss=i32(N), flatten_ids=i32(icap), group_gs_ids=i32(gcap), group_starts=i32(gcap),
+                 tile_offsets=i32(th * tw), counts=torch.zeros(4, dtype=torch.int64, device=d),
+                 workspace=torch.empty(int(lib.gps_isect_workspace_bytes(N, icap)), dtype=torch.uint8, device=d),
+                 render_colors=f(1, H, W, 4), weight_sum=f(1, H, W, 1), rgb=f(H, W, 3), loss=torch.zeros(1, device=d),
+                 v_render_colors=f(1, H, W, 4), v_render_alphas=f(1, H, W, 1), v_means2d=f(N, 2), v_conics=f(N, 3),
+                 v_colors=f(N, 4), v_opacities=f(N))
+        st = SplatStep()
+        st.N, st.K, st.sh_degree, st.width, st.height = N, 1 + p.featuresRest.shape[1], self.degreesToUse, W, H
+        st.max_gs_radii = int(self.max_gs_radii)
+        st.eps2d, st.near_plane, st.far_plane, st.radius_clip = self.eps2d, self.near_plane, self.far_plane, self.radius_clip
+        st.delta_depth = self.delta_depth
+        for name, t in (("means", p.means), ("log_scales", p.scales), ("quats", p.quats), ("opac_logit", p.opacities),
+                        ("sh_dc", p.featuresDc), ("sh_rest", p.featuresRest)):
+            assert t.is_contiguous()
+            setattr(st, name, t.data_ptr())
+        for name, t in B.items():
+            setattr(st, name, t.data_ptr())
+        st.isect_capacity, st.group_capacity, st.workspace_bytes = icap, gcap, B["workspace"].numel()
+        st.beta1, st.beta2, st.adam_eps = 0.9, 0.999, 1e-15
+        self._step, self._step_key, self._step_bufs = st, key, B
+        self._bind_optimizer()
+        return st
+
+    def _bind_optimizer(self):
+        st, o = self._step, self._opt
+        if st is None or o is None:
+            return
+        order = (0, 1, 2, 5, 3, 4)  # struct order means, log_scales, quats, opac_logit, sh_dc, sh_rest vs NAMES order
+        names = ("means", "log_scales", "quats", "opac_logit", "sh_dc", "sh_rest")
+        for n, k in zip(names, order):
+            setattr(st, "g_" + n, o["g"][k].data_ptr())
+            setattr(st, "m_" + n, o["m"][k].data_ptr())
+            setattr(st, "v_" + n, o["v"][k].data_ptr())
+        lr = o["lrs"]
+        # lr order in the struct: means, log_scales, quats, sh_dc, sh_rest, opac_logit == NAMES order
+        for j in range(6):
+            st.lr[j] = float(lr[j])
+
+    def _bind_camera(self, st, cam, ref_depth_clamped, base_color, gt_rgb):
+        c = cam.toGPU()
+        st.viewmat, st.Kmat, st.cam_pos = c["viewmat"].data_ptr(), c["K"].data_ptr(), c["cam_pos"].data_ptr()
+        st.ref_depth_clamped = ref_depth_clamped.data_ptr()
+        st.base_color = base_color.data_ptr()
+        st.gt_rgb = 0 if gt_rgb is None else gt_rgb.data_ptr()
+
+    def train_step(self, cam, ref_depth, base_color, gt_rgb, ref_depth_clamped=None):
+        """model.forward -> computeLoss -> loss.backward -> optimizersStep/ZeroGrad (slam_pipeline.cpp:247-254) as one
+        C-ABI call (gps_splat_train_step).  The L1 loss accumulates in a device scalar (read with last_loss())."""
+        if ref_depth_clamped is None:
+            ref_depth_clamped = torch.where(ref_depth < 0.01, torch.full_like(ref_depth, 1000.0), ref_depth)
+        st = self._step_struct(cam.width, cam.height)
+        self._bind_camera(st, cam, ref_depth_clamped, base_color, gt_rgb)
         o = self._opt
-        g = o["g"]
-        c = st["cam"]
-        ops.gauss_preprocess_bwd(p.means, p.scales, p.quats, p.opacities.view(-1), p.featuresDc, p.featuresRest,
-                                 self.degreesToUse, c["viewmat"], c["K"], c["cam_pos"], st["W"], st["H"], self.eps2d,
-                                 st["radii"], st["conics"], v_m2, v_con, v_col, v_op,
-                                 out=(g[0], g[1], g[2], g[5].view(-1), g[3], g[4]))
         o["step"] += 1
-        ops.adam_step(p.tensors(), g, o["m"], o["v"], o["lrs"], o["step"], (0.9, 0.999), 1e-15)
-        return loss
+        check(lib.gps_splat_train_step(C.byref(st), o["step"],
+                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+              "gps_splat_train_step")
+        self._keep = (ref_depth_clamped, base_color, gt_rgb)  # keep the tensors alive until the next call
+
+    def loss_sum(self):
+        return self._step_bufs["loss"]
 
     # ------------------------------------------------------------------ structure edits (every 10 frames)
     def prunePoints(self, delete_mask):
@@ -227,6 +290,7 @@ class RawGaussianModel:
                 self._opt[k] = [t[keep].contiguous() for t in self._opt[k]]
         self._isect = None
         self._bufs = {}
+        self._step = None
 
 
 class SLAMGaussianModel(RawGaussianModel):
@@ -257,6 +321,7 @@ class SLAMGaussianModel(RawGaussianModel):
             setattr(p, n, new[n] if cur is None else torch.cat([cur, new[n]], 0))
         self._isect = None
         self._bufs = {}
+        self._step = None
 
     def addGaussians(self, cam, frame_maps, sample_mask, new_gs_sample_ratio, frame_num, generator=None):
         """slam/slam_gs_model.cpp:5-56"""

@@ -1,0 +1,125 @@
+"""Mirror of gsplat/gsplat_wapper.{hpp,cpp}: the autograd operator surface raw_gs_model.cpp programs against.
+
+Same class / function names, argument order and tensor shapes as the reference's torch::autograd::Function
+classes; forward/backward call the C-ABI launchers in gsplat_ops.py.  (The optimisation loop itself uses the fused
+gps_splat_train_step; these classes are the drop-in surface and what the end-to-end gradient test differentiates.)
+"""
+import torch
+
+from . import gsplat_ops as ops
+
+
+class SphericalHarmonicsNew(torch.autograd.Function):
+    """gsplat_wapper.hpp:16-95: apply(sh_degree, dirs[...,3], coeffs[...,K,3], masks[...]) -> colors[...,3]"""
+
+    @staticmethod
+    def forward(ctx, sh_degree, dirs, coeffs, masks):
+        colors = ops.compute_sh_fwd(sh_degree, dirs, coeffs, masks)
+        ctx.save_for_backward(dirs, coeffs, masks)
+        ctx.sh_degree, ctx.K = sh_degree, coeffs.shape[-2]
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        dirs, coeffs, masks = ctx.saved_tensors
+        compute_v_dirs = ctx.needs_input_grad[1]
+        v_coeffs, v_dirs = ops.compute_sh_bwd(ctx.K, ctx.sh_degree, dirs, coeffs, masks, v_colors.contiguous(),
+                                              compute_v_dirs)
+        return None, v_dirs, v_coeffs, None
+
+
+class FullyFusedProjection(torch.autograd.Function):
+    """gsplat_wapper.hpp:97-241: apply(means, covars(None), quats, scales, viewmats[C,4,4], Ks[C,3,3], width, height,
+    eps2d, near_plane, far_plane, radius_clip, calc_compensations, camera_model)
+    -> radii, means2d, depths, conics, compensations(None)"""
+
+    @staticmethod
+    def forward(ctx, means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                radius_clip, calc_compensations, camera_model):
+        if covars is not None or calc_compensations or camera_model != "pinhole":
+            raise RuntimeError("gfx950 path implements the configuration GPS-SLAM ships (raw_gs_model.h:283-288)")
+        radii, means2d, depths, conics = ops.fully_fused_projection_fwd(means, quats, scales, viewmats, Ks, width,
+                                                                        height, eps2d, near_plane, far_plane, radius_clip)
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics)
+        ctx.cfg = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics):
+        means, quats, scales, viewmats, Ks, radii, conics = ctx.saved_tensors
+        width, height, eps2d = ctx.cfg
+        v_means, v_quats, v_scales = ops.fully_fused_projection_bwd(means, quats, scales, viewmats, Ks, width, height,
+                                                                    eps2d, radii, conics, v_means2d.contiguous(),
+                                                                    v_depths.contiguous(), v_conics.contiguous())
+        return (v_means, None, v_quats, v_scales) + (None,) * 10
+
+
+class RasterizeToPixelsGes_NewParallel(torch.autograd.Function):
+    """gsplat_wapper.hpp:489-620: apply(means2d, conics, colors, opacities, radiis, ref_depth_map, base_color_map,
+    backgrounds, masks, width, height, tile_size, isect_offsets, flatten_ids, group_gs_ids, group_starts, absgrad,
+    delta_depth) -> render_colors[1,H,W,4], weight_sum[1,H,W,1].
+    isect_offsets/flatten_ids/group_* are the fields of the IsectResult returned by isectTilesNoDepth (they stay on
+    the device together with their counts)."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, radiis, ref_depth_map, base_color_map, backgrounds, masks,
+                width, height, tile_size, isect, absgrad, delta_depth):
+        if backgrounds is not None or masks is not None or absgrad:
+            raise RuntimeError("backgrounds / masks / absgrad are never used by GPS-SLAM and are not implemented")
+        rc, ra, _ = ops.rasterize_to_pixels_fwd_ges(means2d, conics, colors, opacities, ref_depth_map, width, height,
+                                                    tile_size, isect, delta_depth)
+        ctx.save_for_backward(means2d, conics, colors, opacities, radiis, ref_depth_map)
+        ctx.cfg = (width, height, isect, delta_depth)
+        return rc, ra
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        means2d, conics, colors, opacities, radiis, ref_depth_map = ctx.saved_tensors
+        width, height, isect, delta_depth = ctx.cfg
+        v_m, v_c, v_col, v_o = ops.rasterize_to_pixels_bwd_ges_gs_parallel(
+            means2d, conics, colors, opacities, radiis, ref_depth_map, width, height, isect, delta_depth,
+            v_render_colors.contiguous(), v_render_alphas.contiguous())
+        return (v_m, v_c, v_col, v_o) + (None,) * 11
+
+
+def isectTilesNoDepth(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, **kw):
+    """gsplat_wapper.cpp:55-85 (+ the offsets of isectOffsetEncodeNoDepth, computed in the same sync-free call)."""
+    return ops.isect_tiles_no_depth(means2d, radii, tile_size, tile_width, tile_height, **kw)
+
+
+def isectOffsetEncodeNoDepth(isect, n_cameras, tile_width, tile_height):
+    """gsplat_wapper.cpp:88-91"""
+    assert n_cameras == 1
+    return isect.isect_offsets
+
+
+def ges_forward(params, cam_dev, width, height, ref_depth, base_color, sh_degree=3, max_gs_radii=100, delta_depth=0.1,
+                tile_size=16, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0):
+    """RawGaussianModel::gesForward (src/raw_gs_model.cpp:188-367) written against the operator surface above, with
+    the reference's libtorch glue as torch ops -- differentiable through autograd."""
+    import math
+    means, log_scales, quats, dc, rest, opac_logit = params
+    tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
+    ref_clamped = torch.where(ref_depth < 0.01, torch.full_like(ref_depth, 1000.0), ref_depth)
+    scales = torch.exp(log_scales)
+    radii, means2d, depths, conics = FullyFusedProjection.apply(
+        means, None, quats, scales, cam_dev["viewmat"].unsqueeze(0), cam_dev["K"].unsqueeze(0), width, height, eps2d,
+        near_plane, far_plane, radius_clip, False, "pinhole")
+    if max_gs_radii > 0:
+        radii = torch.clamp_max(radii, max_gs_radii)
+    shs = torch.cat([dc[:, None, :], rest], 1)
+    dirs = means - cam_dev["cam_pos"][None, :]
+    colors = SphericalHarmonicsNew.apply(sh_degree, dirs.unsqueeze(0), shs.unsqueeze(0), radii > 0)
+    colors = torch.clamp_min(colors + 0.5, 0.0)
+    isect = isectTilesNoDepth(means2d, radii, depths, tile_size, tw, th)
+    colors = torch.cat([colors, depths.unsqueeze(-1)], 2)
+    rc, ws = RasterizeToPixelsGes_NewParallel.apply(means2d, conics, colors, torch.sigmoid(opac_logit), radii,
+                                                    ref_clamped, base_color, None, None, width, height, tile_size,
+                                                    isect, False, delta_depth)
+    raw_rgb, raw_depth = rc[..., :3], rc[..., 3:]
+    bcw = torch.ones_like(ws)
+    rgb = (raw_rgb + base_color * bcw) / (ws + bcw)
+    bdw = torch.zeros_like(ws).masked_fill(ref_depth > 0, 1)
+    depth = (raw_depth + ref_depth * bdw) / (ws + bdw)
+    return dict(rgb=rgb[0], depth=depth[0], alpha=ws[0], radiis=radii[0], means2d=means2d)

@@ -99,13 +99,16 @@ class SLAMPipeline:
         vertex = torch.empty((H, W, 3), device=d)
         conf = torch.empty((H, W, 1), device=d)
         depth = torch.empty((H, W, 1), device=d)
+        depth_c = torch.empty((H, W, 1), device=d)
         w2c = np.ascontiguousarray(pose_inv(cam.c2w).numpy().astype(np.float32))  # poseInv(cam.c2w): dataset pose (:398)
         check(lib.gps_raycast_to_maps(W, H, eng.fv_raycast.data_ptr(), eng.fv_colour.data_ptr(), eng.getVoxelSize(),
                                       w2c.ctypes.data, color.data_ptr(), vertex.data_ptr(), conf.data_ptr(),
-                                      depth.data_ptr(), C.c_void_p(torch.cuda.current_stream(d).cuda_stream)),
+                                      depth.data_ptr(), depth_c.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream(d).cuda_stream)),
               "gps_raycast_to_maps")
         self.stats["raycasts"] += 1
-        return dict(color_map=color, vertex_map=vertex, confidence_map=conf, depth_map=depth)
+        return dict(color_map=color, vertex_map=vertex, confidence_map=conf, depth_map=depth,
+                    depth_map_clamped=depth_c)
 
     # ------------------------------------------------------------------ frame bookkeeping (updateFrameList :319-360)
     def updateFrameList(self):
@@ -171,7 +174,8 @@ class SLAMPipeline:
         for _ in range(self.cfg["local_opt_iters"]):
             idx, cam = loader.getNext()
             rc = self.opt_raycast_list[idx]
-            model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image)
+            model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image,
+                             ref_depth_clamped=rc["depth_map_clamped"])
             self.stats["opt_iters"] += 1
 
     # ------------------------------------------------------------------ removeRedundantGs :564-586

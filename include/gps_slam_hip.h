@@ -196,6 +196,48 @@ GPS_API int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float *m
                                      float *v_sh_rest, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
+/* Splat: one optimise iteration / one render as a single call         */
+/* ------------------------------------------------------------------ */
+
+/* Everything one iteration of SLAMPipeline::localOptimize touches (slam/slam_pipeline.cpp:247-254).  All pointers
+ * are device memory owned by the caller; sizes follow the op-level entry points above. */
+typedef struct {
+    int32_t N, K, sh_degree, width, height, max_gs_radii;
+    float eps2d, near_plane, far_plane, radius_clip, delta_depth;
+    /* parameters (updated in place by the Adam step) */
+    float *means, *log_scales, *quats, *opac_logit, *sh_dc, *sh_rest;
+    /* camera (device): viewmat[16] row-major world->camera, Kmat[9], cam_pos[3] */
+    const float *viewmat, *Kmat, *cam_pos;
+    /* per-camera images: TSDF raycast depth clamped (ref < 0.01 -> 1000, raw_gs_model.cpp:207), raycast colour,
+     * ground-truth image */
+    const float *ref_depth_clamped, *base_color, *gt_rgb;
+    /* per-Gaussian intermediates */
+    int32_t *radii;
+    float *means2d, *depths, *conics, *colors, *opacities;
+    /* binning */
+    int64_t isect_capacity, group_capacity, workspace_bytes;
+    int32_t *tiles_per_gauss, *flatten_ids, *group_gs_ids, *group_starts, *tile_offsets;
+    int64_t *counts;
+    void *workspace;
+    /* images */
+    float *render_colors, *weight_sum, *rgb, *loss, *v_render_colors, *v_render_alphas;
+    /* rasterizer gradients */
+    float *v_means2d, *v_conics, *v_colors, *v_opacities;
+    /* parameter gradients and Adam state, same order as the parameters */
+    float *g_means, *g_log_scales, *g_quats, *g_opac_logit, *g_sh_dc, *g_sh_rest;
+    float *m_means, *m_log_scales, *m_quats, *m_opac_logit, *m_sh_dc, *m_sh_rest;
+    float *v_means, *v_log_scales, *v_quats, *v_opac_logit, *v_sh_dc, *v_sh_rest;
+    double lr[6]; /* means, log_scales, quats, sh_dc, sh_rest, opac_logit */
+    double beta1, beta2, adam_eps;
+} gps_splat_step;
+
+/* gesForward up to the rasterizer (preprocess -> binning -> ges forward): fills render_colors / weight_sum. */
+GPS_API int gps_splat_render(const gps_splat_step *a, gps_stream stream);
+
+/* forward + L1 loss + backward + fused Adam step number `adam_step` (1-based); `loss` must be zeroed by the caller. */
+GPS_API int gps_splat_train_step(const gps_splat_step *a, int adam_step, gps_stream stream);
+
+/* ------------------------------------------------------------------ */
 /* TSDF: voxel-block-hash fusion and raycast (InfiniTAM ITMLib path)   */
 /* ------------------------------------------------------------------ */
 
@@ -306,10 +348,13 @@ GPS_API int gps_tsdf_free_raycast(const gps_tsdf_state *s, const float *M, const
 
 /* SLAMPipeline::runRaycastByCam tensor glue (slam/slam_pipeline.cpp:386-403, src/cv_utils.cpp:322-341) fused:
  * rays float4[H*W] + colour uchar4[H*W] (device) -> color_map[H,W,3] (/255), vertex_map[H,W,3] (metres, 0 where no hit),
- * confidence_map[H,W,1], depth_map[H,W,1] = camera-space z under w2c (host float[16], ROW-major), 0 where no hit. */
+ * confidence_map[H,W,1], depth_map[H,W,1] = camera-space z under w2c (host float[16], ROW-major), 0 where no hit;
+ * depth_map_clamped (optional) = where(depth < 0.01, 1000, depth), the form the rasterizer consumes
+ * (raw_gs_model.cpp:205-207). */
 GPS_API int gps_raycast_to_maps(int width, int height, const float *rays, const uint8_t *colour, float voxel_size,
                                 const float *w2c_row_major, float *color_map, float *vertex_map,
-                                float *confidence_map, float *depth_map, gps_stream stream);
+                                float *confidence_map, float *depth_map, float *depth_map_clamped,
+                                gps_stream stream);
 
 /* Host-side pose algebra of ORUtils::SE3Pose as used by ITMBasicEngine.tpp:278-279 and slam_pipeline.cpp:367-371:
  * pose.SetInvM(c2w); pose.Coerce(); -> M = pose.GetM(), invM = pose.GetInvM().
