@@ -24,32 +24,38 @@ def _time_launches(fn, n, stream):
 def dominant_kernel_roofline(model, pipe, eng, cams, device, hbm_peak_gbs):
     """Dominant kernel of the step = the Gaussian-parallel ges backward (raster_ges_bwd_gs_kernel): it has the
     largest share of GPU time per SLAM frame (2 launches/frame; see profiles/).  Measured live with events on the
-    stream the C-ABI launches on (torch's current stream), on the last optimisation camera of the run.
-    Also reports the forward rasterizer, the live raycast and the fused Adam for context (`others`)."""
+    stream the C-ABI launches on (torch's current stream), on the last optimisation camera of the run, through the
+    same C-ABI entry point with accumulate=1 (exactly one kernel per call).  `others` lists the forward rasterizer."""
     import json
-    from gps_slam_amd import gsplat_ops as ops
+    from gps_slam_amd._lib import lib
     stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
     cam = pipe.opt_cam_list[-1] if pipe.opt_cam_list else cams[-1]
     rc = pipe.opt_raycast_list[-1] if pipe.opt_raycast_list else pipe.runRaycastByCam(cam)
-    st = model._render(cam, rc["depth_map"], rc["color_map"])
-    ni, ng = model._isect.sizes()
-    W, H = st["W"], st["H"]
+    if model._opt is None:
+        model.initOptimizers(-1, 1.0)
+    model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+    torch.cuda.synchronize()
+    B, st = model._B, model._step
+    counts = B["counts"].cpu().tolist()
+    ni, ng, nvis = int(counts[0]), int(counts[1]), int(counts[3])
+    W, H, N = st.width, st.height, st.N
     P = W * H
-    N = model.getGaussianNum()
-    rgb, _, loss, v_rc, v_ra = ops.compose_l1(st["render_colors"], st["weight_sum"], rc["color_map"], rc["depth_map"],
-                                             cam.image, need_depth=False)
+    ref = rc["depth_map_clamped"]
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    pp = model.opt_gs_params
 
     def fwd():
-        ops.rasterize_to_pixels_fwd_ges(st["means2d"], st["conics"], st["colors"], st["opac"], st["ref_clamped"], W, H,
-                                        model.tile_size, model._isect, model.delta_depth)
+        lib.gps_raster_ges_fwd(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(ref),
+                               W, H, 16, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]),
+                               model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), None, sp)
 
-    gbuf = (torch.zeros_like(st["means2d"]), torch.zeros_like(st["conics"]), torch.zeros_like(st["colors"]),
-            torch.zeros_like(st["opac"]))
-
-    def bwd():  # accumulate=True: exactly one launch of raster_ges_bwd_gs_kernel, no zero-fill kernel
-        ops.rasterize_to_pixels_bwd_ges_gs_parallel(st["means2d"], st["conics"], st["colors"], st["opac"], st["radii"],
-                                                    st["ref_clamped"], W, H, model._isect, model.delta_depth, v_rc, v_ra,
-                                                    out=gbuf, accumulate=True)
+    def bwd():
+        lib.gps_raster_ges_bwd_gs(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]),
+                                  ptr(B["radii"]), ptr(ref), W, H, ptr(B["group_gs_ids"]), ptr(B["group_starts"]),
+                                  ptr(B["counts"]), model.delta_depth, ptr(B["v_render_colors"]),
+                                  ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]),
+                                  ptr(B["v_opacities"]), 1, sp)
 
     t_bwd = _time_launches(bwd, 50, stream)
     t_fwd = _time_launches(fwd, 50, stream)
@@ -68,7 +74,7 @@ def dominant_kernel_roofline(model, pipe, eng, cams, device, hbm_peak_gbs):
     return {"bound": "hbm", "kernel": "raster_ges_bwd_gs_kernel", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
             "frac": ach / hbm_peak_gbs, "traffic": traffic, "avg_launch_us": t_bwd * 1e6,
             "algorithmic_bytes": alg_bwd, "units": {"n_groups": ng, "pixels": P, "n_isects": ni, "gaussians": N,
-                                                    "n_visible": int(model._isect.counts[3])},
+                                                    "n_visible": nvis},
             "note": "rasterization is ALU/LDS-issue bound (exp + ~40 flop per pixel-Gaussian pair), not a stream; "
                     "the HBM fraction is reported because it is the contract's yardstick",
             "others": {"raster_ges_fwd_kernel": {"avg_launch_us": t_fwd * 1e6, "algorithmic_bytes": alg_fwd,

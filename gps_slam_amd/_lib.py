@@ -73,6 +73,8 @@ PROTOTYPES = {
     "gps_tsdf_free_raycast": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
     "gps_pose_from_c2w": (i32, [vp, vp, vp]),
     "gps_raycast_to_maps": (i32, [i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_knn_mean_dist2": (i32, [i32, vp, vp, vp]),
+    "gps_normal_map": (i32, [i32, i32, vp, vp, vp]),
     "gps_splat_render": (i32, [C.POINTER(SplatStep), vp]),
     "gps_splat_train_step": (i32, [C.POINTER(SplatStep), i32, vp]),
 }

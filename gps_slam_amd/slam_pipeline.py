@@ -45,26 +45,14 @@ class RandomSelector:
         return v  # (originalIndex, value)
 
 
-def feature_gradient(img):
-    """tensor_math.cpp:217-248 (Sobel with replicate padding, no normalisation)"""
-    H, W, Cn = img.shape
-    wx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=img.dtype, device=img.device).view(1, 1, 3, 3)
-    wy = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=img.dtype, device=img.device).view(1, 1, 3, 3)
-    x = img.permute(2, 0, 1).reshape(-1, 1, H, W)
-    x = torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate")
-    dx = torch.nn.functional.conv2d(x, wx).squeeze(1).permute(1, 2, 0)
-    dy = torch.nn.functional.conv2d(x, wy).squeeze(1).permute(1, 2, 0)
-    return dx, dy
-
-
 def compute_normal_map(vertex_map):
-    """tensor_math.cpp:278-300"""
+    """computeNormalMap (tensor_math.cpp:278-300) -> gps_normal_map"""
     H, W, _ = vertex_map.shape
-    dx, dy = feature_gradient(vertex_map)
-    normal = torch.cross(dy.reshape(-1, 3), dx.reshape(-1, 3), dim=-1).view(H, W, 3)
-    normal = normal / (torch.norm(normal, 2, -1, True) + 1e-8)
-    invalid = vertex_map[:, :, 2] <= 0
-    return torch.where(invalid.unsqueeze(-1), torch.zeros_like(normal), normal)
+    vertex_map = vertex_map.contiguous()
+    out = torch.empty_like(vertex_map)
+    check(lib.gps_normal_map(W, H, vertex_map.data_ptr(), out.data_ptr(),
+                             C.c_void_p(torch.cuda.current_stream(vertex_map.device).cuda_stream)), "gps_normal_map")
+    return out
 
 
 class SLAMPipeline:

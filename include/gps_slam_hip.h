@@ -196,6 +196,19 @@ GPS_API int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float *m
                                      float *v_sh_rest, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
+/* Splat: Gaussian creation helpers (every local_opt_interval frames)  */
+/* ------------------------------------------------------------------ */
+
+/* replaces distCUDA2 (gsplat/rasterizer/simple_knn.cu:191-240; called from raw_gs_param.cpp:28):
+ * mean_dist2[i] = mean of the squared distances from points[i] to its 3 nearest other points (FLT_MAX terms if
+ * P < 4, as in the reference).  Exact, no scratch memory, no host sync. */
+GPS_API int gps_knn_mean_dist2(int P, const float *points, float *mean_dist2, gps_stream stream);
+
+/* replaces computeNormalMap (src/tensor_math.cpp:278-300 + featureGradient :217-248): vertex_map[H,W,3] ->
+ * normal_map[H,W,3] (Sobel, replicate padding, cross(dy,dx) normalised, 0 where vertex z <= 0). */
+GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float *normal_map, gps_stream stream);
+
+/* ------------------------------------------------------------------ */
 /* Splat: one optimise iteration / one render as a single call         */
 /* ------------------------------------------------------------------ */
 

@@ -272,4 +272,4 @@ def test_adam_matches_libtorch_sequence():
             assert ne.float().mean().item() < 1e-4
             if ne.any():
                 ulp = torch.abs(a[ne].view(torch.int32) - b[ne].view(torch.int32)).max().item()
-                assert ulp <= step  # a one-ulp difference made in an earlier step persists
+                assert ulp <= 4  # a one-ulp difference made in an earlier step persists and can compound
