@@ -60,6 +60,7 @@ PROTOTYPES = {
                                        i32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_gauss_preprocess_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_tsdf_scratch_bytes": (i64, [i32, i32, i32, i32]),
     "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_allocate": (i32, [C.POINTER(TsdfState), vp, vp, vp]),

@@ -204,23 +204,23 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     if (threadIdx.x < bins) hist[(size_t)threadIdx.x * nblk_cap + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void radix_scan_kernel(const int64_t* __restrict__ counts, int bits,
-                                                                 int nblk_cap, uint32_t* __restrict__ hist) {
+// One workgroup per digit: exclusive scan of that digit's per-block counts (row d of hist) and the digit total.
+// The cross-digit base is added by the scatter kernel (it scans the <= 256 totals in LDS), so no single-workgroup
+// serial scan over bins x blocks is needed.
+__global__ __launch_bounds__(256) void radix_scan_kernel(const int64_t* __restrict__ counts, int nblk_cap,
+                                                        uint32_t* __restrict__ hist, uint32_t* __restrict__ digit_total) {
     __shared__ int ws[17];
     const int n = (int)counts[0];
     const int nblk = (n + SORT_TILE - 1) / SORT_TILE;
-    const int total = nblk << bits;  // digit-major order: e = d * nblk + b
-    const int per = (total + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int lo = min(total, (int)threadIdx.x * per), hi = min(total, lo + per);
+    uint32_t* row = hist + (size_t)blockIdx.x * nblk_cap;
+    const int per = (nblk + 255) / 256;
+    const int lo = min(nblk, (int)threadIdx.x * per), hi = min(nblk, lo + per);
     int s = 0;
-    for (int e = lo; e < hi; e++) { int d = e / nblk, b = e - d * nblk; s += (int)hist[(size_t)d * nblk_cap + b]; }
+    for (int b = lo; b < hi; b++) s += (int)row[b];
     int tot;
     int run = block_excl_scan(s, ws, tot);
-    for (int e = lo; e < hi; e++) {
-        int d = e / nblk, b = e - d * nblk;
-        size_t a = (size_t)d * nblk_cap + b;
-        int v = (int)hist[a]; hist[a] = (uint32_t)run; run += v;
-    }
+    for (int b = lo; b < hi; b++) { int v = (int)row[b]; row[b] = (uint32_t)run; run += v; }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = (uint32_t)tot;
 }
 
 // Each wave owns a contiguous 512-item slice; inside it items are visited in index order
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
                                                                     const int64_t* __restrict__ counts, int shift,
                                                                     int bits, int nblk_cap,
                                                                     const uint32_t* __restrict__ hist,
+                                                                    const uint32_t* __restrict__ digit_total,
                                                                     uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t wavecnt[SORT_THREADS / 64][256];
@@ -264,8 +265,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    // exclusive scan of the digit totals (bins <= 256 == blockDim.x): every workgroup recomputes it, it is 256 adds
+    __shared__ int dws[17];
+    int dtot;
+    const int dval = (int)threadIdx.x < bins ? (int)digit_total[threadIdx.x] : 0;
+    const int dexcl = block_excl_scan(dval, dws, dtot);
     if ((int)threadIdx.x < bins) {
-        uint32_t run = hist[(size_t)threadIdx.x * nblk_cap + blockIdx.x];
+        uint32_t run = (uint32_t)dexcl + hist[(size_t)threadIdx.x * nblk_cap + blockIdx.x];
         digitbase[threadIdx.x] = run;
         uint32_t acc = 0;
         for (int w = 0; w < SORT_THREADS / 64; w++) { uint32_t c = wavecnt[w][threadIdx.x]; wavecnt[w][threadIdx.x] = acc; acc += c; }
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void offsets_kernel(const uint32_t* __restrict
 
 struct Workspace {
     int32_t *groups_per_gauss, *blk_tiles, *blk_groups, *blk_vis;
-    uint32_t *keys_a, *vals_a, *keys_b, *vals_b, *hist;
+    uint32_t *keys_a, *vals_a, *keys_b, *vals_b, *hist, *digit_total;
     int nblkN, nblkI;
 };
 
@@ -328,6 +334,7 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
     p = take((size_t)cap * 4); if (w) w->keys_b = (uint32_t*)p;
     p = take((size_t)cap * 4); if (w) w->vals_b = (uint32_t*)p;
     p = take((size_t)256 * nblkI * 4); if (w) w->hist = (uint32_t*)p;
+    p = take((size_t)256 * 4); if (w) w->digit_total = (uint32_t*)p;
     if (w) { w->nblkN = nblkN; w->nblkI = nblkI; }
     return off;
 }
@@ -374,20 +381,20 @@ int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, 
     const uint32_t* sorted_keys;
     if (bits_total <= 8) {
         radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, counts, 0, bits_total, w.nblkI, w.hist);
-        radix_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(counts, bits_total, w.nblkI, w.hist);
+        radix_scan_kernel<<<1 << bits_total, 256, 0, s>>>(counts, w.nblkI, w.hist, w.digit_total);
         radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, w.vals_a, counts, 0, bits_total, w.nblkI,
-                                                                    w.hist, w.keys_b, (uint32_t*)flatten_ids);
+                                                                    w.hist, w.digit_total, w.keys_b, (uint32_t*)flatten_ids);
         sorted_keys = w.keys_b;
     } else {
         int b1 = (bits_total + 1) / 2, b2 = bits_total - b1;
         radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, counts, 0, b1, w.nblkI, w.hist);
-        radix_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(counts, b1, w.nblkI, w.hist);
+        radix_scan_kernel<<<1 << b1, 256, 0, s>>>(counts, w.nblkI, w.hist, w.digit_total);
         radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, w.vals_a, counts, 0, b1, w.nblkI,
-                                                                     w.hist, w.keys_b, w.vals_b);
+                                                                     w.hist, w.digit_total, w.keys_b, w.vals_b);
         radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_b, counts, b1, b2, w.nblkI, w.hist);
-        radix_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(counts, b2, w.nblkI, w.hist);
+        radix_scan_kernel<<<1 << b2, 256, 0, s>>>(counts, w.nblkI, w.hist, w.digit_total);
         radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_b, w.vals_b, counts, b1, b2, w.nblkI,
-                                                                    w.hist, w.keys_a, (uint32_t*)flatten_ids);
+                                                                    w.hist, w.digit_total, w.keys_a, (uint32_t*)flatten_ids);
         sorted_keys = w.keys_a;
     }
     offsets_kernel<<<512, 256, 0, s>>>(sorted_keys, counts, n_tiles, tile_offsets, isect_ids);

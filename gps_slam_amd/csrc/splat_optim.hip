@@ -62,28 +62,47 @@ struct AdamArgs {
     float beta1, beta2, one_minus_b1, one_minus_b2, inv_bc2_sqrt, eps;
 };
 
+__device__ __forceinline__ void adam_update(const AdamArgs& a, int s, float g, float& m, float& v, float& p) {
+    // Rounding sequence measured against ATen on gfx950 (scratch/adam_probe.py, 2^20 samples, 100% bitwise):
+    //   add_(g, alpha)        -> fma(alpha, g, m*b1)
+    //   addcmul_(g, g, value) -> fma(value, g*g, v*b2)
+    //   sqrt()/c              -> sqrt * float(1/c)   ; add_(eps) unfused
+    //   addcdiv_(m, d, value) -> fma(value, m/d, p)   (m/d IEEE-correct here, as nvcc's --prec-div default)
+    m = fmaf(a.one_minus_b1, g, __fmul_rn(m, a.beta1));
+    v = fmaf(a.one_minus_b2, __fmul_rn(g, g), __fmul_rn(v, a.beta2));
+    const float denom = __fadd_rn(__fmul_rn(sqrtf(v), a.inv_bc2_sqrt), a.eps);
+    p = fmaf(-a.step_size[s], __fdiv_rn(m, denom), p);
+}
+
+// One float4 per thread-iteration when the segment allows it (all parameter tensors are 16-byte aligned torch
+// allocations; a segment's tail of < 4 elements falls back to scalars): 7 x 16-byte streams per lane.
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-    const int64_t total = a.seg_end[a.n_segments - 1];
+    const int64_t total4 = a.seg_end[a.n_segments - 1];  // in units of 4 elements, per-segment padded (see host)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += stride) {
         int s = 0;
 #pragma unroll
         for (int k = 0; k < GPS_ADAM_MAX_SEGMENTS - 1; k++) s += (k < a.n_segments - 1 && e >= a.seg_end[k]) ? 1 : 0;
-        const int64_t i = e - (s == 0 ? 0 : a.seg_end[s - 1]);
+        const int64_t i4 = e - (s == 0 ? 0 : a.seg_end[s - 1]);
         const gps_adam_segment& sg = a.seg[s];
-        const float g = sg.grad[i];
-        // exp_avg.mul_(b1).add_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, 1-b2)
-        // Rounding sequence measured against ATen on gfx950 (scratch/adam_probe.py, 2^20 samples, 100% bitwise):
-        //   add_(g, alpha)        -> fma(alpha, g, m*b1)
-        //   addcmul_(g, g, value) -> fma(value, g*g, v*b2)
-        //   sqrt()/c              -> sqrt * float(1/c)   ; add_(eps) unfused
-        //   addcdiv_(m, d, value) -> fma(value, m/d, p)
-        const float m = fmaf(a.one_minus_b1, g, __fmul_rn(sg.exp_avg[i], a.beta1));
-        const float v = fmaf(a.one_minus_b2, __fmul_rn(g, g), __fmul_rn(sg.exp_avg_sq[i], a.beta2));
-        sg.exp_avg[i] = m;
-        sg.exp_avg_sq[i] = v;
-        const float denom = __fadd_rn(__fmul_rn(sqrtf(v), a.inv_bc2_sqrt), a.eps);
-        sg.param[i] = fmaf(-a.step_size[s], __fdiv_rn(m, denom), sg.param[i]);
+        const int64_t i = i4 * 4;
+        if (i + 4 <= sg.numel) {
+            const float4 g = *reinterpret_cast<const float4*>(sg.grad + i);
+            float4 m = *reinterpret_cast<float4*>(sg.exp_avg + i);
+            float4 v = *reinterpret_cast<float4*>(sg.exp_avg_sq + i);
+            float4 p = *reinterpret_cast<float4*>(sg.param + i);
+            adam_update(a, s, g.x, m.x, v.x, p.x); adam_update(a, s, g.y, m.y, v.y, p.y);
+            adam_update(a, s, g.z, m.z, v.z, p.z); adam_update(a, s, g.w, m.w, v.w, p.w);
+            *reinterpret_cast<float4*>(sg.exp_avg + i) = m;
+            *reinterpret_cast<float4*>(sg.exp_avg_sq + i) = v;
+            *reinterpret_cast<float4*>(sg.param + i) = p;
+        } else {
+            for (int64_t j = i; j < sg.numel; j++) {
+                float m = sg.exp_avg[j], v = sg.exp_avg_sq[j], p = sg.param[j];
+                adam_update(a, s, sg.grad[j], m, v, p);
+                sg.exp_avg[j] = m; sg.exp_avg_sq[j] = v; sg.param[j] = p;
+            }
+        }
     }
 }
 
@@ -125,7 +144,9 @@ int gps_adam_step(const gps_adam_segment* segments, int n_segments, double beta1
                     (segments[k].param && segments[k].grad && segments[k].exp_avg && segments[k].exp_avg_sq));
         a.seg[k] = segments[k];
         a.step_size[k] = (float)(segments[k].lr / bc1);
-        run += segments[k].numel;
+        GPS_REQUIRE((((uintptr_t)segments[k].param | (uintptr_t)segments[k].grad | (uintptr_t)segments[k].exp_avg |
+                      (uintptr_t)segments[k].exp_avg_sq) & 15) == 0);  // float4 path
+        run += (segments[k].numel + 3) / 4;
         a.seg_end[k] = run;
     }
     for (int k = n_segments; k < GPS_ADAM_MAX_SEGMENTS; k++) { a.seg[k] = segments[0]; a.step_size[k] = 0.f; a.seg_end[k] = run; }

@@ -18,8 +18,8 @@
 //    on the device: nothing is copied back to size the next launch (the reference blocks on a
 //    12-byte cudaMemcpy, ..._CUDA.tcu:197); dependent kernels are persistent and grid-stride
 //    over counters[GPS_TSDF_N_VISIBLE].
-//  * Integration: one 512-thread workgroup (8 wave64) per visible block, one voxel per lane, the
-//    4 KiB block streams through registers as coalesced 8-byte lanes (512 B per wave access).
+//  * Integration: one wave64 per visible block walking its 8 z-slices (coalesced 512-byte slice
+//    accesses, 8-byte voxel per lane), ~8k blocks in flight to hide the per-block header latency.
 #include "tsdf_common.hpp"
 
 using namespace gpst;
@@ -297,46 +297,55 @@ __global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const
 }
 
 // ---------------------------------------------------------------- integration
-__global__ __launch_bounds__(BLK3) void integrate_kernel(TsdfState s, Mat4 M) {
+// One wave64 per visible block: the wave walks the 8 z-slices (lane = (x, y) of the 8x8 slice), so a slice is one
+// coalesced 512-byte access and the per-block header chain (visible_ids -> hash entry) is paid once per 512 voxels
+// while 8 waves per SIMD keep ~8k independent blocks in flight chip-wide (the per-block dependent-load latency, not
+// bandwidth, bounded the earlier one-workgroup-per-block layout).
+__global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
     const int n_visible = s.counters[GPS_TSDF_N_VISIBLE];
-    const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7, lz = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
     const int W = s.width, H = s.height;
     const float mu = s.mu;
-    for (int e = blockIdx.x; e < n_visible; e += gridDim.x) {
+    const uchar4* img = reinterpret_cast<const uchar4*>(s.rgb);
+    for (int e = wave; e < n_visible; e += n_waves) {
         const gps_hash_entry he = s.hash[s.visible_ids[e]];
-        if (he.ptr < 0) continue;  // uniform across the workgroup
-        uint64_t* slot = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + threadIdx.x;
+        if (he.ptr < 0) continue;  // uniform across the wave
+        uint64_t* blk = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + lane;
         const float pmx = (float)(he.pos[0] * BLK + lx) * s.voxel_size;
         const float pmy = (float)(he.pos[1] * BLK + ly) * s.voxel_size;
-        const float pmz = (float)(he.pos[2] * BLK + lz) * s.voxel_size;
-        float cx, cy, cz;
-        mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
-        if (cz <= 0) continue;
-        const float ix = s.fx * cx / cz + s.cx, iy = s.fy * cy / cz + s.cy;
-        if ((ix < 1) || (ix > W - 2) || (iy < 1) || (iy > H - 2)) continue;
-        const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
-        if (dm <= 0.0f) continue;
-        const float eta = dm - cz;
-        if (eta < -mu) continue;
-        uint64_t raw = *slot;
-        // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
-        const int16_t sdf = (int16_t)(raw & 0xFFFF);
-        const int oldW = (int)((raw >> 16) & 0xFF);
-        float oldF = (float)sdf / 32767.0f;
-        float newF = (1.0f < eta / mu) ? 1.0f : eta / mu;
-        int newW = 1;
-        newF = oldW * oldF + newW * newF;
-        newW = oldW + newW;
-        newF /= newW;
-        newW = (newW < s.max_w) ? newW : s.max_w;
-        raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
-        if (!((eta > mu) || (fabsf(eta / mu) > 0.25f))) {
-            // colour: rgb camera == depth camera (trafo_rgb_to_depth is identity, InfiniTAM_tools.cpp:6-10)
-            const float rx = ix, ry = iy;  // same projection, same rounding sequence
-            if (!((rx < 1) || (rx > W - 2) || (ry < 1) || (ry > H - 2))) {
-                const int px = (int)floorf(rx), py = (int)floorf(ry);
-                const float dx = rx - (float)px, dy = ry - (float)py;
-                const uchar4* img = reinterpret_cast<const uchar4*>(s.rgb);
+#pragma unroll 2
+        for (int lz = 0; lz < BLK; lz++) {
+            uint64_t* slot = blk + lz * 64;
+            const float pmz = (float)(he.pos[2] * BLK + lz) * s.voxel_size;
+            float cx, cy, cz;
+            mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
+            if (cz <= 0) continue;
+            const float ix = s.fx * cx / cz + s.cx, iy = s.fy * cy / cz + s.cy;
+            if ((ix < 1) || (ix > W - 2) || (iy < 1) || (iy > H - 2)) continue;
+            const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
+            if (dm <= 0.0f) continue;
+            const float eta = dm - cz;
+            if (eta < -mu) continue;
+            uint64_t raw = *slot;
+            // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
+            const int16_t sdf = (int16_t)(raw & 0xFFFF);
+            const int oldW = (int)((raw >> 16) & 0xFF);
+            float oldF = (float)sdf / 32767.0f;
+            float newF = (1.0f < eta / mu) ? 1.0f : eta / mu;
+            int newW = 1;
+            newF = oldW * oldF + newW * newF;
+            newW = oldW + newW;
+            newF /= newW;
+            newW = (newW < s.max_w) ? newW : s.max_w;
+            raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
+            if (!((eta > mu) || (fabsf(eta / mu) > 0.25f))) {
+                // colour: rgb camera == depth camera (trafo_rgb_to_depth is identity, InfiniTAM_tools.cpp:6-10), so the
+                // colour projection repeats the depth projection's rounding sequence exactly
+                const int px = (int)floorf(ix), py = (int)floorf(iy);
+                const float dx = ix - (float)px, dy = iy - (float)py;
                 const uchar4 a = img[px + py * W];
                 uchar4 b = make_uchar4(0, 0, 0, 0), c = b, d = b;
                 if (dx != 0) b = img[(px + 1) + py * W];
@@ -365,8 +374,8 @@ __global__ __launch_bounds__(BLK3) void integrate_kernel(TsdfState s, Mat4 M) {
                 }
                 raw = (raw & ~0x00FFFFFFFF000000ull) | packed | ((uint64_t)(uint8_t)cw << 48);
             }
+            *slot = raw;
         }
-        *slot = raw;
     }
 }
 
@@ -451,8 +460,8 @@ int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stre
     GPS_REQUIRE(sp != nullptr && M != nullptr);
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
-    // persistent grid: 8 wave64 per workgroup, up to 4 workgroups per CU resident; strides over the visible list
-    integrate_kernel<<<2048, BLK3, 0, (hipStream_t)stream>>>(s, load_mat(M));
+    // persistent grid of 8192 waves (one block per wave at a time), strides over the visible list
+    integrate_kernel<<<2048, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

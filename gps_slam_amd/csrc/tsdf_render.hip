@@ -20,19 +20,26 @@ using namespace gpst;
 
 namespace {
 
-__global__ __launch_bounds__(256) void minmax_init_kernel(int P, float2* __restrict__ mm, int32_t* counters) {
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) mm[i] = make_float2(FAR_AWAY, VERY_CLOSE);
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[GPS_TSDF_RENDER_BLOCKS] = 0;
-}
+// CreateExpectedDepths in two passes without global atomics:
+//  A) each workgroup keeps a private copy of the 1/8-resolution min/max image in LDS (<= 160 KB: 640x480 -> 81x61x8 B
+//     = 39 KB), strides over the visible list, projects the 8 block corners (ProjectSingleBlock, Shared.h:36-91) and
+//     min/max-es the bounding box with LDS integer atomics (positive floats order like their bit patterns), then
+//     writes its image to a partial buffer with plain coalesced stores;
+//  B) one thread per pixel reduces the partials and writes the full-resolution-stride image the raycaster indexes
+//     (x/8 + (y/8)*W), initialising every other pixel to (FAR_AWAY, VERY_CLOSE) like the reference's memset kernel.
+constexpr int ED_GROUPS = 64;
 
-// ProjectSingleBlock (Shared.h:36-91) + the fill loop of CreateExpectedDepths (CPU.tpp:168-184)
-__global__ __launch_bounds__(256) void expected_depths_kernel(TsdfState s, Mat4 M, const int32_t* __restrict__ vis_ids,
-                                                             int count_slot, float2* __restrict__ mm) {
+__global__ __launch_bounds__(256) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
+                                                                     const int32_t* __restrict__ vis_ids, int count_slot,
+                                                                     int sw, int sh, uint2* __restrict__ partial) {
+    extern __shared__ uint2 img[];  // [sw*sh] {min bits, max bits}
     const int n = s.counters[count_slot];
-    const int stride = gridDim.x * blockDim.x;
     const int W = s.width, H = s.height;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const uint2 init = make_uint2(__float_as_uint(FAR_AWAY), __float_as_uint(VERY_CLOSE));
+    for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) img[i] = init;
+    __syncthreads();
+    int my_blocks = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const gps_hash_entry he = s.hash[vis_ids[k]];
         if (he.ptr < 0) continue;
         int ulx = W / MINMAX_SUB, uly = H / MINMAX_SUB, lrx = -1, lry = -1;
@@ -62,16 +69,42 @@ __global__ __launch_bounds__(256) void expected_depths_kernel(TsdfState s, Mat4 
         if (uly > lry) continue;
         if (zmin < VERY_CLOSE) zmin = VERY_CLOSE;
         if (zmax < VERY_CLOSE) continue;
-        const int rbx = (int)ceilf((float)(lrx - ulx + 1) / 16.0f), rby = (int)ceilf((float)(lry - uly + 1) / 16.0f);
-        const int before = atomicAdd(&s.counters[GPS_TSDF_RENDER_BLOCKS], rbx * rby);
-        if (before + rbx * rby >= MAX_RENDERING_BLOCKS) s.counters[GPS_TSDF_OVERFLOW] = 1;
+        my_blocks += (int)ceilf((float)(lrx - ulx + 1) / 16.0f) * (int)ceilf((float)(lry - uly + 1) / 16.0f);
+        // the bounding box can only leave the sw x sh window in degenerate projections (the reference clamps to the
+        // FULL image size, Shared.h:77-80); those pixels are never read by the raycaster -> clip to the window
+        lrx = min(lrx, sw - 1); lry = min(lry, sh - 1);
         for (int y = uly; y <= lry; ++y)
             for (int x = ulx; x <= lrx; ++x) {
-                uint32_t* p = reinterpret_cast<uint32_t*>(&mm[x + y * W]);
-                atomicMin(p, __float_as_uint(zmin));      // both strictly positive
-                atomicMax(p + 1, __float_as_uint(zmax));
+                atomicMin(&img[x + y * sw].x, __float_as_uint(zmin));
+                atomicMax(&img[x + y * sw].y, __float_as_uint(zmax));
             }
     }
+    const int tot = wave_sum_i(my_blocks);
+    if ((threadIdx.x & 63) == 0 && tot) {
+        const int before = atomicAdd(&s.counters[GPS_TSDF_RENDER_BLOCKS], tot);
+        if (before + tot >= MAX_RENDERING_BLOCKS) s.counters[GPS_TSDF_OVERFLOW] = 1;
+    }
+    __syncthreads();
+    uint2* out = partial + (size_t)blockIdx.x * sw * sh;
+    for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) out[i] = img[i];
+}
+
+__global__ __launch_bounds__(256) void expected_depths_reduce_kernel(int W, int H, int sw, int sh, int groups,
+                                                                    const uint2* __restrict__ partial,
+                                                                    float2* __restrict__ mm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int y = i / W, x = i - y * W;
+    float2 r = make_float2(FAR_AWAY, VERY_CLOSE);
+    if (x < sw && y < sh) {
+        uint32_t lo = __float_as_uint(FAR_AWAY), hi = __float_as_uint(VERY_CLOSE);
+        for (int g = 0; g < groups; g++) {
+            const uint2 p = partial[(size_t)g * sw * sh + x + y * sw];
+            lo = min(lo, p.x); hi = max(hi, p.y);
+        }
+        r = make_float2(__uint_as_float(lo), __uint_as_float(hi));
+    }
+    mm[i] = r;
 }
 
 // ---------------------------------------------------------------- voxel access (ITMRepresentationAccess.h)
@@ -436,12 +469,31 @@ int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_
     TsdfState s = *sp;
     hipStream_t st = (hipStream_t)stream;
     const int P = s.width * s.height;
+    // window of the 1/8-resolution image that bounding boxes can touch: [0, W/8] x [0, H/8] (ceil of a coordinate
+    // just inside the image) -- anything further is clipped (never read by the raycaster)
+    const int sw = s.width / MINMAX_SUB + 2, sh = s.height / MINMAX_SUB + 2;
+    const size_t lds = (size_t)sw * sh * sizeof(uint2);
+    GPS_REQUIRE(lds <= 160 * 1024);
+    const int n_total = s.n_buckets + s.n_excess;
+    const int nblk = gps_div_up(n_total, 1024);
+    // partial images live behind the sweep scratch (3*nblk + 16 ints + n_total flag bytes), see gps_tsdf_scratch_bytes
+    uint2* partial = reinterpret_cast<uint2*>(s.scan_scratch + 3 * nblk + 16 + (n_total + 3) / 4 + 2);
     float2* mm = reinterpret_cast<float2*>(free_view ? s.fv_minmax : s.minmax);
-    minmax_init_kernel<<<gps_div_up(P, 256 * 4), 256, 0, st>>>(P, mm, s.counters);
-    expected_depths_kernel<<<256, 256, 0, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
-                                                free_view ? GPS_TSDF_N_VISIBLE_FREE : GPS_TSDF_N_VISIBLE, mm);
+    hipMemsetAsync(&s.counters[GPS_TSDF_RENDER_BLOCKS], 0, sizeof(int32_t), st);
+    expected_depths_partial_kernel<<<ED_GROUPS, 256, lds, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
+                                                                free_view ? GPS_TSDF_N_VISIBLE_FREE : GPS_TSDF_N_VISIBLE,
+                                                                sw, sh, partial);
+    expected_depths_reduce_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(s.width, s.height, sw, sh, ED_GROUPS, partial, mm);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
+}
+
+int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_excess) {
+    if (width <= 0 || height <= 0 || n_buckets <= 0 || n_excess <= 0) return GPS_ERR_ARG;
+    const int64_t n_total = (int64_t)n_buckets + n_excess;
+    const int64_t nblk = (n_total + 1023) / 1024;
+    const int64_t sw = width / MINMAX_SUB + 2, sh = height / MINMAX_SUB + 2;
+    return 4 * (3 * nblk + 16 + (n_total + 3) / 4 + 2) + (int64_t)ED_GROUPS * sw * sh * 8 + 64;
 }
 
 int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, gps_stream stream) {

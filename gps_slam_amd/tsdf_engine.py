@@ -51,7 +51,7 @@ class TsdfEngine:
         self.excess_list = z(n_excess, torch.int32)
         self.counters = z(16, torch.int32)
         self.alloc_prio = z(n_total, torch.int32)
-        self.scan_scratch = z(3 * nblk + 16 + (n_total + 3) // 4, torch.int32)
+        self.scan_scratch = z((int(lib.gps_tsdf_scratch_bytes(self.W, self.H, n_buckets, n_excess)) + 3) // 4, torch.int32)
         self.visible_type = z(n_total, torch.uint8)
         self.visible_ids = z(n_blocks, torch.int32)
         self.depth = z(P, torch.float32)

@@ -300,7 +300,7 @@ typedef struct {
     int32_t *counters;               /* [16] */
     /* allocation scratch */
     uint32_t *alloc_prio;            /* [n_buckets + n_excess], zero between calls */
-    int32_t *scan_scratch;           /* [4 * ceil((n_buckets+n_excess)/1024) + 16] */
+    int32_t *scan_scratch;           /* gps_tsdf_scratch_bytes(width, height, n_buckets, n_excess) bytes */
     /* live render state + view */
     uint8_t *visible_type;           /* [n_buckets + n_excess] */
     int32_t *visible_ids;            /* [n_blocks] */
@@ -315,6 +315,9 @@ typedef struct {
     float *fv_raycast;               /* [H*W*4] */
     uint8_t *fv_colour;              /* [H*W*4] uchar4 */
 } gps_tsdf_state;
+
+/* Size in bytes of gps_tsdf_state.scan_scratch (sweep counts + flags + per-workgroup min/max partial images). */
+GPS_API int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_excess);
 
 /* ITMSceneReconstructionEngine::ResetScene (Reconstruction/CUDA/ITMSceneReconstructionEngine_CUDA.tcu:52-80) */
 GPS_API int gps_tsdf_reset(const gps_tsdf_state *s, gps_stream stream);

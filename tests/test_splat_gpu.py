@@ -270,6 +270,4 @@ def test_adam_matches_libtorch_sequence():
         for a, b in zip(P, Pe):
             ne = a != b
             assert ne.float().mean().item() < 1e-4
-            if ne.any():
-                ulp = torch.abs(a[ne].view(torch.int32) - b[ne].view(torch.int32)).max().item()
-                assert ulp <= 4  # a one-ulp difference made in an earlier step persists and can compound
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=3e-8)  # 1 ulp of the update term (cancellation p ~ -update)
