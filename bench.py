@@ -37,11 +37,12 @@ def build_scene(W, H, n_frames, n_gauss, seed, device):
                      device=device)
     model = SLAMGaussianModel(dict(isect_capacity=8 << 20), device=device)
     pipe = SLAMPipeline(eng, model, seed=seed)
-    rgb_dev = torch.as_tensor(seq["rgb"]).to(device)
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)  # uchar4 frames
+    rgb_dev = torch.as_tensor(rgba).to(device)
     depth_dev = torch.as_tensor(seq["depth"].astype(np.int16)).to(device)
     cams = []
     for k in range(n_frames):
-        img = rgb_dev[k].float() / 255.0
+        img = rgb_dev[k][..., :3].float() / 255.0
         dep = (depth_dev[k].float() / 1000.0).unsqueeze(-1)
         cams.append(Camera(k, W, H, fx, fy, cx, cy, seq["c2w"][k], image=img, depth=dep, device=device))
     # pre-populate: back-project a few views' depth to world points (colour from the image, normals from Sobel)

@@ -27,7 +27,7 @@ class SplatStep(C.Structure):
                 [(n, f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "delta_depth")] +
                 [(n, vp) for n in ("means", "log_scales", "quats", "opac_logit", "sh_dc", "sh_rest", "viewmat", "Kmat",
                                    "cam_pos", "ref_depth_clamped", "base_color", "gt_rgb", "radii", "means2d", "depths",
-                                   "conics", "colors", "opacities")] +
+                                   "conics", "colors", "opacities", "records")] +
                 [(n, i64) for n in ("isect_capacity", "group_capacity", "workspace_bytes")] +
                 [(n, vp) for n in ("tiles_per_gauss", "flatten_ids", "group_gs_ids", "group_starts", "tile_offsets",
                                    "counts", "workspace", "render_colors", "weight_sum", "rgb", "loss",
@@ -57,7 +57,8 @@ PROTOTYPES = {
     "gps_compose_l1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_adam_step": (i32, [C.POINTER(AdamSegment), i32, f64, f64, f64, i32, vp]),
     "gps_gauss_preprocess_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32,
-                                       i32, vp, vp, vp, vp, vp, vp, vp]),
+                                       i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_raster_ges_fwd_rec": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp]),
     "gps_gauss_preprocess_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_tsdf_scratch_bytes": (i64, [i32, i32, i32, i32]),

@@ -35,7 +35,7 @@ template <int DEG>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t* __restrict__ radii,
                                                              float* __restrict__ means2d, float* __restrict__ depths,
                                                              float* __restrict__ conics, float* __restrict__ colors,
-                                                             float* __restrict__ opac) {
+                                                             float* __restrict__ opac, float4* __restrict__ recs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= in.N) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
         r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
     }
     *reinterpret_cast<float4*>(colors + 4 * (size_t)i) = make_float4(r, g, b, o.z);
-    opac[i] = 1.f / (1.f + expf(-in.opac_logit[i]));
+    const float op = 1.f / (1.f + expf(-in.opac_logit[i]));
+    opac[i] = op;
+    if (recs) pack_record(o, r, g, b, op, recs + 3 * (size_t)i);
 }
 
 template <int DEG>
@@ -159,22 +161,23 @@ int gps_gauss_preprocess_fwd(int N, int K, int sh_degree, const float* means, co
                              const float* viewmat, const float* Kmat, const float* cam_pos, int width, int height,
                              float eps2d, float near_plane, float far_plane, float radius_clip, int max_gs_radii,
                              int32_t* radii, float* means2d, float* depths, float* conics, float* colors,
-                             float* opacities, gps_stream stream) {
+                             float* opacities, float* records, gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
     GPS_REQUIRE(radii && means2d && depths && conics && colors && opacities);
+    float4* recs = reinterpret_cast<float4*>(records);
     FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
                   max_gs_radii, eps2d, near_plane, far_plane, radius_clip};
     dim3 g(gps_div_up(N, 256)), b(256);
     hipStream_t s = (hipStream_t)stream;
     switch (sh_degree) {
-        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
-        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
-        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
-        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
-        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities); break;
+        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
+        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
+        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
+        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
+        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
     }
     GPS_LAUNCH_CHECK();
     return GPS_OK;

@@ -234,6 +234,35 @@ __device__ __forceinline__ void project_gaussian_vjp(const Cam& cam, const float
     v_q[3] = (n3 - d * qz) * inv_norm;
 }
 
+// Packed per-Gaussian record the record-streaming rasterizer reads with scalar loads (3 x float4 = 48 B).
+// The last two words hold conservative integer pixel bounds of the region where opac * exp(-sigma) >= 1/255:
+// sigma <= tau = ln(255 * opac) is an ellipse with half-extents sqrt(2 tau cc / det), sqrt(2 tau ca / det)
+// (det = ca*cc - cb^2); they are inflated by 1 % + 0.01 px so that rounding of exp can never exclude a contributing
+// pixel, and an empty box (hi < lo) is stored when opac < 1/255 or the Gaussian is culled.
+__device__ __forceinline__ void pack_record(const Proj& o, float r, float g, float b, float opac, float4* rec) {
+    float ex = -1.f, ey = -1.f;
+    if (o.radius > 0) {
+        const float tau = logf(255.f * opac);
+        const float det = o.ca * o.cc - o.cb * o.cb;
+        if (tau > 0.f && det > 0.f) {
+            ex = sqrtf(2.f * tau * o.cc / det) * 1.01f + 0.01f;
+            ey = sqrtf(2.f * tau * o.ca / det) * 1.01f + 0.01f;
+        }
+    }
+    int x_lo = 1, x_hi = 0, y_lo = 1, y_hi = 0;  // empty
+    if (ex >= 0.f) {
+        // pixel j has centre j + 0.5: j_lo = floor(mx - ex - 0.5), j_hi = ceil(mx + ex - 0.5), clamped to int16
+        x_lo = (int)fmaxf(fminf(floorf(o.mx - ex - 0.5f), 32767.f), -32768.f);
+        x_hi = (int)fmaxf(fminf(ceilf(o.mx + ex - 0.5f), 32767.f), -32768.f);
+        y_lo = (int)fmaxf(fminf(floorf(o.my - ey - 0.5f), 32767.f), -32768.f);
+        y_hi = (int)fmaxf(fminf(ceilf(o.my + ey - 0.5f), 32767.f), -32768.f);
+    }
+    const int xb = (x_lo & 0xffff) | (x_hi << 16), yb = (y_lo & 0xffff) | (y_hi << 16);
+    rec[0] = make_float4(o.mx, o.my, o.ca, o.cb);
+    rec[1] = make_float4(o.cc, opac, o.z, r);
+    rec[2] = make_float4(g, b, __int_as_float(xb), __int_as_float(yb));
+}
+
 // ---------------- spherical harmonics ----------------
 __host__ __device__ inline int sh_num_bases(int degree) { return (degree + 1) * (degree + 1); }
 

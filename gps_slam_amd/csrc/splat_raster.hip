@@ -92,6 +92,83 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_ges_fwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward, record-streaming variant used by the fused model path.
+//
+// Every lane of a wave needs the SAME Gaussian record, so the record does not have to go through LDS or VGPRs at
+// all: it is fetched with SCALAR loads (s_load_dwordx4 through the per-CU scalar cache) into SGPRs and the per-pixel
+// VALU ops take the SGPRs as operands.  Each wave64 (a 16x4 pixel strip) walks the tile's sorted list on its own:
+//   * 64 Gaussian ids per coalesced vector load, broadcast one at a time with v_readlane;
+//   * the 48-byte packed record {xy, conic, opac, depth, rgb, extent} of the NEXT Gaussian is requested while the
+//     current one is evaluated (1-deep software prefetch of the dependent id -> record chain);
+//   * wave-uniform culling: the record carries the half-extents of the region where opac*exp(-sigma) >= 1/255
+//     (inflated by 1 % + 0.01 px); if that box misses the wave's strip the whole pair evaluation is skipped with a
+//     scalar branch.  The test is conservative, so the result equals the un-culled loop.
+// No LDS, no __syncthreads: the 4 waves of a tile never wait for each other.
+// record = 3 x float4: a = {mx, my, ca, cb}  b = {cc, opac, depth, r}  c = {g, b, xbounds, ybounds}, the bounds being
+// two int16 pixel indices each (lo | hi << 16), see pack_record() in splat_math.hpp
+
+__global__ __launch_bounds__(256) void raster_ges_fwd_rec_kernel(const float4* __restrict__ recs,
+                                                                const float* __restrict__ ref_depth, int W, int H,
+                                                                int tw, int th,
+                                                                const int32_t* __restrict__ tile_offsets,
+                                                                const int32_t* __restrict__ flatten_ids,
+                                                                const int64_t* __restrict__ counts, float delta_depth,
+                                                                float4* __restrict__ render_colors,
+                                                                float* __restrict__ render_alphas) {
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = ty * 16 + wave * 4 + (lane >> 4), j = tx * 16 + (lane & 15);
+    const bool inside = (i < H) && (j < W);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const int pix = i * W + j;
+    // first pixel column / row of this wave's 16x4 strip (wave uniform, kept in SGPRs)
+    const int col0 = tx * 16, row0 = __builtin_amdgcn_readfirstlane(ty * 16 + wave * 4);
+
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+    const float cut = inside ? ref_depth[pix] + delta_depth : -3.0e38f;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, wsum = 0.f;
+
+    for (int base = range_start; base < range_end; base += 64) {
+        const int cnt = min(64, range_end - base);
+        const int my_id = (lane < cnt) ? flatten_ids[base + lane] : 0;
+        int g = __builtin_amdgcn_readlane(my_id, 0);
+        float4 ra = recs[3 * (size_t)g], rb = recs[3 * (size_t)g + 1], rc = recs[3 * (size_t)g + 2];
+        for (int t = 0; t < cnt; ++t) {
+            const float4 a = ra, b = rb, c = rc;
+            float4 na = a, nb = b, nc = c;
+            if (t + 1 < cnt) {  // request the next record now (uniform id -> scalar loads) ...
+                g = __builtin_amdgcn_readlane(my_id, (t + 1) & 63);
+                na = recs[3 * (size_t)g]; nb = recs[3 * (size_t)g + 1]; nc = recs[3 * (size_t)g + 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // ... and do not let the register hand-over below move up to it
+            // conservative wave-level cull: integer pixel bounds of the alpha >= 1/255 box, scalar compares
+            const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
+            const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16;
+            const int y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
+            if (!(x_hi < col0 || x_lo > col0 + 15 || y_hi < row0 || y_lo > row0 + 3)) {
+                const float dx = a.x - px, dy = a.y - py;
+                const float sigma = 0.5f * (a.z * dx * dx + b.x * dy * dy) + a.w * dx * dy;
+                const float alpha = fminf(0.999f, b.y * __expf(-sigma));
+                const bool hit = !(b.z > cut) && !(sigma < 0.f) && !(alpha < 1.f / 255.f);
+                if (hit) {
+                    o0 += b.w * alpha; o1 += c.x * alpha; o2 += c.y * alpha; o3 += b.z * alpha;
+                    wsum += alpha;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ra = na; rb = nb; rc = nc;
+        }
+    }
+    if (inside) {
+        render_colors[pix] = make_float4(o0, o1, o2, o3);
+        render_alphas[pix] = wsum;
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restrict__ v_means2d,
                                                         float* __restrict__ v_conics, float* __restrict__ v_colors,
                                                         float* __restrict__ v_opacities) {
@@ -224,6 +301,22 @@ int gps_raster_ges_fwd(int N, const float* means2d, const float* conics, const f
     raster_ges_fwd_kernel<16><<<tw * th, TILE_THREADS, 0, (hipStream_t)stream>>>(
         (const float2*)means2d, conics, (const float4*)colors, opacities, ref_depth_map, width, height, tw, th,
         tile_offsets, flatten_ids, counts, delta_depth, (float4*)render_colors, render_alphas, last_ids);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_map, int width, int height,
+                           const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts,
+                           float delta_depth, float* render_colors, float* render_alphas, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
+    GPS_REQUIRE(N == 0 || records);
+    const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
+    raster_ges_fwd_rec_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>((const float4*)records, ref_depth_map, width,
+                                                                        height, tw, th, tile_offsets, flatten_ids, counts,
+                                                                        delta_depth, (float4*)render_colors,
+                                                                        render_alphas);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -15,15 +15,19 @@ int gps_splat_render(const gps_splat_step* a, gps_stream stream) {
     r = gps_gauss_preprocess_fwd(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
                                  a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
                                  a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
-                                 a->depths, a->conics, a->colors, a->opacities, stream);
+                                 a->depths, a->conics, a->colors, a->opacities, a->records, stream);
     if (r != GPS_OK) return r;
     r = gps_isect_tiles_no_depth(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
                                  a->tiles_per_gauss, nullptr, a->flatten_ids, a->group_gs_ids, a->group_starts,
                                  a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
     if (r != GPS_OK) return r;
-    r = gps_raster_ges_fwd(a->N, a->means2d, a->conics, a->colors, a->opacities, a->ref_depth_clamped, a->width,
-                           a->height, 16, a->tile_offsets, a->flatten_ids, a->counts, a->delta_depth, a->render_colors,
-                           a->weight_sum, nullptr, stream);
+    if (a->records)
+        r = gps_raster_ges_fwd_rec(a->N, a->records, a->ref_depth_clamped, a->width, a->height, a->tile_offsets,
+                                   a->flatten_ids, a->counts, a->delta_depth, a->render_colors, a->weight_sum, stream);
+    else
+        r = gps_raster_ges_fwd(a->N, a->means2d, a->conics, a->colors, a->opacities, a->ref_depth_clamped, a->width,
+                               a->height, 16, a->tile_offsets, a->flatten_ids, a->counts, a->delta_depth,
+                               a->render_colors, a->weight_sum, nullptr, stream);
     return r;
 }
 

@@ -57,11 +57,13 @@ class Camera:
         self._dev = None
 
     def toGPU(self):
+        """curr_cam.toGPU() (slam_pipeline.cpp:84): viewmat = poseInv(c2w_slam), K and the camera position go up in ONE
+        28-float upload; poseInv's 3x3 algebra runs on the host (the reference launches ~8 tiny device kernels for it)."""
         if self._dev is None:
             d = self.device
-            c2w = self.c2w_slam.to(d)
-            self._dev = dict(viewmat=pose_inv(c2w).contiguous(), K=self.K.to(d).contiguous(),
-                             cam_pos=c2w[:3, 3].contiguous())
+            c2w = self.c2w_slam.to(torch.float32)
+            pack = torch.cat([pose_inv(c2w).reshape(-1), self.K.reshape(-1), c2w[:3, 3].reshape(-1)]).to(d)
+            self._dev = dict(viewmat=pack[:16].view(4, 4), K=pack[16:25].view(3, 3), cam_pos=pack[25:28], _pack=pack)
             if self.image is not None:
                 self.image = self.image.to(d)
             if self.depth is not None:
@@ -203,7 +205,7 @@ class RawGaussianModel:
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=d)
             i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=d)
             B = dict(radii=i32(cap), means2d=f(cap, 2), depths=f(cap), conics=f(cap, 3), colors=f(cap, 4),
-                     opacities=f(cap), tiles_per_gauss=i32(cap), flatten_ids=i32(icap), group_gs_ids=i32(gcap),
+                     opacities=f(cap), records=f(cap, 12), tiles_per_gauss=i32(cap), flatten_ids=i32(icap), group_gs_ids=i32(gcap),
                      group_starts=i32(gcap), tile_offsets=i32(th * tw), counts=torch.zeros(4, dtype=torch.int64, device=d),
                      workspace=torch.empty(int(lib.gps_isect_workspace_bytes(cap, icap)), dtype=torch.uint8, device=d),
                      render_colors=f(1, H, W, 4), weight_sum=f(1, H, W, 1), rgb=f(H, W, 3), depth=f(H, W, 1),
@@ -350,8 +352,8 @@ class SLAMGaussianModel(RawGaussianModel):
         num_select = int(n * new_gs_sample_ratio)
         if num_select <= 0:
             return 0
-        # uniformly random subset of num_select pixels (the reference: torch::randperm(n)[:num_select]); drawn as the
-        # argsort of iid uniforms, which avoids randperm's slow CUDA path (9 ms for n ~ 3e4 on ROCm)
-        perm = torch.argsort(torch.rand(n, device=verts.device, generator=generator))[:num_select]
+        # uniformly random subset of num_select pixels (the reference: torch::randperm(n)[:num_select]).  Drawn on the
+        # host: n is already known there (masked_select synced) and the CUDA randperm/sort path stalls for ms on ROCm.
+        perm = torch.randperm(n, generator=generator)[:num_select].to(verts.device)  # CPU generator: n is host-known
         self.add_params(self.init_params(verts[perm].contiguous(), cols[perm], norms[perm]))
         return num_select

@@ -235,7 +235,7 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, lrs, step, betas=(0.9, 0.999
 # ----------------------------------------------------------------------------- fused model-level kernels
 def gauss_preprocess_fwd(means, log_scales, quats, opac_logit, sh_dc, sh_rest, sh_degree, viewmat, Kmat, cam_pos,
                          width, height, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, max_gs_radii=100,
-                         out=None):
+                         out=None, records=None):
     """One pass of raw_gs_model.cpp:207-286 (see include/gps_slam_hip.h: gps_gauss_preprocess_fwd).
     -> radii[N] i32 (clamped), means2d[N,2], depths[N], conics[N,3], colors[N,4], opacities[N]"""
     N = means.shape[0]
@@ -249,7 +249,8 @@ def gauss_preprocess_fwd(means, log_scales, quats, opac_logit, sh_dc, sh_rest, s
     check(lib.gps_gauss_preprocess_fwd(N, K, sh_degree, _ptr(means), _ptr(log_scales), _ptr(quats), _ptr(opac_logit),
                                        _ptr(sh_dc), _ptr(sh_rest), _ptr(viewmat), _ptr(Kmat), _ptr(cam_pos), width,
                                        height, eps2d, near_plane, far_plane, radius_clip, int(max_gs_radii), _ptr(radii),
-                                       _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors), _ptr(opac), _stream()),
+                                       _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors), _ptr(opac),
+                                       _ptr(records), _stream()),
           "gps_gauss_preprocess_fwd")
     return out
 
@@ -269,3 +270,15 @@ def gauss_preprocess_bwd(means, log_scales, quats, opac_logit, sh_dc, sh_rest, s
                                        _ptr(v_colors), _ptr(v_opacities), _ptr(v_means), _ptr(v_ls), _ptr(v_q),
                                        _ptr(v_ol), _ptr(v_dc), _ptr(v_rest), _stream()), "gps_gauss_preprocess_bwd")
     return out
+
+
+def rasterize_to_pixels_fwd_ges_rec(records, ref_depth_map, width, height, isect, delta_depth):
+    """gps_raster_ges_fwd_rec: the record-streaming forward (same result as rasterize_to_pixels_fwd_ges)."""
+    N = records.shape[0]
+    dev = records.device
+    rc = torch.empty((1, height, width, 4), dtype=torch.float32, device=dev)
+    ra = torch.empty((1, height, width, 1), dtype=torch.float32, device=dev)
+    check(lib.gps_raster_ges_fwd_rec(N, _ptr(records), _ptr(_f32c(ref_depth_map)), width, height,
+                                     _ptr(isect.isect_offsets), _ptr(isect.flatten_ids), _ptr(isect.counts), delta_depth,
+                                     _ptr(rc), _ptr(ra), _stream()), "gps_raster_ges_fwd_rec")
+    return rc, ra

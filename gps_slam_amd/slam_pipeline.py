@@ -63,7 +63,7 @@ class SLAMPipeline:
         self.cfg.update(pipe_cfg or {})
         self.work_mode = work_mode
         self.rng = random.Random(seed)
-        self.gen = torch.Generator(device=model.device).manual_seed(seed)
+        self.gen = torch.Generator().manual_seed(seed)  # host generator (see SLAMGaussianModel.addGaussians)
         self.device = model.device
         self.localframe_cam_window = []
         self.localframe_raycast_window = []

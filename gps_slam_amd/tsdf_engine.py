@@ -93,13 +93,16 @@ class TsdfEngine:
 
     # ---- ITMBasicEngine::ProcessFrame (tracking off: pose := gtC2wPoses[framesProcessed]; Coerce())
     def ProcessFrame(self, rgb_u8, depth_mm_i16, gt_c2w):
-        """rgb_u8: uint8 [H,W,4] (or [H,W,3]) device tensor; depth_mm_i16: int16 [H,W] millimetres; gt_c2w 4x4."""
+        """rgb_u8: uint8 [H,W,4] device tensor (uchar4, as ITMUChar4Image; [H,W,3] is padded with a copy);
+        depth_mm_i16: int16 [H,W] millimetres; gt_c2w 4x4.  The kernels read both tensors in place (the reference
+        uploads the pre-converted ITM images every frame, ITMViewBuilder_CUDA.cu:61-62)."""
         if rgb_u8.shape[-1] == 3:
             rgb_u8 = torch.cat([rgb_u8, torch.full_like(rgb_u8[..., :1], 255)], -1)
-        self.rgb.copy_(rgb_u8.reshape(-1), non_blocking=True)
-        self.depth_mm.copy_(depth_mm_i16.reshape(-1), non_blocking=True)
+        assert rgb_u8.is_contiguous() and depth_mm_i16.is_contiguous()
+        self._frame_inputs = (rgb_u8, depth_mm_i16)  # keep alive while kernels may read them
+        self.state.rgb = rgb_u8.data_ptr()
         M, invM = pose_from_c2w(gt_c2w)
-        check(lib.gps_tsdf_process_frame(C.byref(self.state), self.depth_mm.data_ptr(), M.ctypes.data,
+        check(lib.gps_tsdf_process_frame(C.byref(self.state), depth_mm_i16.data_ptr(), M.ctypes.data,
                                          invM.ctypes.data, self._stream()), "gps_tsdf_process_frame")
         self.camPoses.append((M, invM))
         self.frames_processed += 1

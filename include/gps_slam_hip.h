@@ -116,6 +116,13 @@ GPS_API int gps_raster_ges_fwd(int N, const float *means2d, const float *conics,
                        float delta_depth, float *render_colors, float *render_alphas, int32_t *last_ids,
                        gps_stream stream);
 
+/* Same result as gps_raster_ges_fwd from the packed records written by gps_gauss_preprocess_fwd: every wave64 streams
+ * the tile's list with scalar loads (no LDS, no barriers) and skips, with a conservative wave-uniform test, Gaussians
+ * whose alpha >= 1/255 box misses its 16x4 pixel strip. */
+GPS_API int gps_raster_ges_fwd_rec(int N, const float *records, const float *ref_depth_map, int width, int height,
+                                   const int32_t *tile_offsets, const int32_t *flatten_ids, const int64_t *counts,
+                                   float delta_depth, float *render_colors, float *render_alphas, gps_stream stream);
+
 /* replaces gsplat::rasterize_to_pixels_bwd_ges_gs_parallel_tensor
  * (rasterize_to_pixels_bwd_ges_new_parallel.cu:203-385): Gaussian-parallel backward over the
  * 2r x 2r integer pixel box of every Gaussian.  n_groups is read from counts[1].
@@ -175,14 +182,15 @@ GPS_API int gps_adam_step(const gps_adam_segment *segments, int n_segments, doub
  * pass: exp(log_scales) -> projection -> radii clamp (max_gs_radii, 0 = off) -> dirs = means - cam_pos ->
  * SH (coefficients given as the model stores them: sh_dc[N,3] + sh_rest[N,K-1,3], no torch::cat) ->
  * colors[N,4] = {clamp_min(sh + 0.5, 0), depth} -> opacities[N] = sigmoid(opac_logit).
- * viewmat[16], Kmat[9], cam_pos[3] are device arrays. */
+ * viewmat[16], Kmat[9], cam_pos[3] are device arrays.  records (optional, [N,12] floats): the packed per-Gaussian
+ * record {xy, conic, opac, depth, rgb, int16 pixel bounds of the alpha >= 1/255 box} gps_raster_ges_fwd_rec streams. */
 GPS_API int gps_gauss_preprocess_fwd(int N, int K, int sh_degree, const float *means, const float *log_scales,
                                      const float *quats, const float *opac_logit, const float *sh_dc,
                                      const float *sh_rest, const float *viewmat, const float *Kmat,
                                      const float *cam_pos, int width, int height, float eps2d, float near_plane,
                                      float far_plane, float radius_clip, int max_gs_radii, int32_t *radii,
                                      float *means2d, float *depths, float *conics, float *colors, float *opacities,
-                                     gps_stream stream);
+                                     float *records, gps_stream stream);
 
 /* Adjoint of gps_gauss_preprocess_fwd == the libtorch autograd chain cat/clamp_min/SH/projection/exp/sigmoid
  * backward (gsplat_wapper.hpp:56-95,156-240 + ATen), writing all six parameter gradients in one pass. */
@@ -226,7 +234,7 @@ typedef struct {
     const float *ref_depth_clamped, *base_color, *gt_rgb;
     /* per-Gaussian intermediates */
     int32_t *radii;
-    float *means2d, *depths, *conics, *colors, *opacities;
+    float *means2d, *depths, *conics, *colors, *opacities, *records;
     /* binning */
     int64_t isect_capacity, group_capacity, workspace_bytes;
     int32_t *tiles_per_gauss, *flatten_ids, *group_gs_ids, *group_starts, *tile_offsets;

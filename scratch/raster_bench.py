@@ -1,0 +1,27 @@
+import sys, time, torch, numpy as np, ctypes as C
+sys.path.insert(0,'.')
+import bench
+from gps_slam_amd.dist_util import scene_seed
+from gps_slam_amd._lib import lib
+from bench_kernels import _time_launches
+W,H=640,480
+seq, eng, model, pipe, cams, rgb_dev, depth_dev = bench.build_scene(W,H,32,200000,scene_seed(0),'cuda:0')
+for i in range(31):
+    pipe.process_frame(i, cams[i], rgb_dev[i], depth_dev[i])
+cam = pipe.opt_cam_list[-1]; rc = pipe.opt_raycast_list[-1]
+model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+torch.cuda.synchronize()
+B, st = model._B, model._step
+counts = B["counts"].cpu().tolist(); print('counts', counts, 'N', st.N)
+stream = torch.cuda.current_stream(); sp = C.c_void_p(stream.cuda_stream)
+ptr = lambda t: C.c_void_p(t.data_ptr())
+ref = rc["depth_map_clamped"]; N=st.N
+def fwd1(): lib.gps_raster_ges_fwd(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(ref), W, H, 16, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), None, sp)
+def fwd2(): lib.gps_raster_ges_fwd_rec(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), sp)
+def bwd(): lib.gps_raster_ges_bwd_gs(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(B["radii"]), ptr(ref), W, H, ptr(B["group_gs_ids"]), ptr(B["group_starts"]), ptr(B["counts"]), model.delta_depth, ptr(B["v_render_colors"]), ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]), ptr(B["v_opacities"]), 1, sp)
+for name, fn in (('fwd_lds', fwd1), ('fwd_rec', fwd2), ('bwd', bwd)):
+    print('%-10s %.1f us' % (name, 1e6*_time_launches(fn, 50, stream)))
+offs = B["tile_offsets"].cpu().numpy().astype(np.int64); ni=int(counts[0])
+d = np.diff(np.concatenate([offs, [ni]]))
+print('tile depth: mean %.0f max %d p99 %.0f' % (d.mean(), d.max(), np.percentile(d,99)))
+r = B["radii"][:N].cpu().numpy(); print('radius mean %.1f max %d; visible %d' % (r[r>0].mean(), r.max(), (r>0).sum()))

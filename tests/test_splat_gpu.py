@@ -271,3 +271,28 @@ def test_adam_matches_libtorch_sequence():
             ne = a != b
             assert ne.float().mean().item() < 1e-4
             torch.testing.assert_close(a, b, rtol=1e-6, atol=3e-8)  # 1 ulp of the update term (cancellation p ~ -update)
+
+
+@pytest.mark.parametrize("N,W,H", [(3000, 96, 64), (150000, 640, 480)])
+def test_record_streaming_forward_equals_lds_forward(N, W, H):
+    """gps_raster_ges_fwd_rec (scalar-load records + conservative wave culling) must reproduce gps_raster_ges_fwd: the
+    culling may only skip (pixel, Gaussian) pairs that fail alpha >= 1/255 anyway."""
+    from gps_slam_amd import gsplat_ops as ops
+    TS, delta = 16, 0.1
+    tw, th = (W + TS - 1) // TS, (H + TS - 1) // TS
+    g, vm, K, c2w = _setup(N, W, H, seed=N + 1)
+    rng = np.random.default_rng(N)
+    ref_depth = rng.uniform(1.5, 4.5, (H, W)).astype(np.float32)
+    ref_depth[rng.uniform(size=(H, W)) < 0.1] = 1000.0
+    rec = torch.empty((N, 12), device=_dev())
+    sh = T(g["sh"])
+    radii, m2, depths, conics, colors, opac = ops.gauss_preprocess_fwd(
+        T(g["means"]), T(g["log_scales"]), T(g["quats"]), T(g["opac_logit"]).view(-1), sh[:, 0].contiguous(),
+        sh[:, 1:].contiguous(), 3, T(vm), T(K), T(c2w[:3, 3].copy()), W, H, records=rec)
+    isect = ops.isect_tiles_no_depth(m2.view(1, N, 2), radii.view(1, N), TS, tw, th)
+    tref = T(ref_depth)[None, ..., None]
+    rc1, ra1, _ = ops.rasterize_to_pixels_fwd_ges(m2, conics, colors, opac, tref, W, H, TS, isect, delta)
+    rc2, ra2 = ops.rasterize_to_pixels_fwd_ges_rec(rec, tref, W, H, isect, delta)
+    assert ra1.max().item() > 1.0
+    torch.testing.assert_close(rc2, rc1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ra2, ra1, rtol=1e-5, atol=1e-5)
