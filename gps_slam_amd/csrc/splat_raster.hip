@@ -20,6 +20,8 @@
 // reduces (within the 32-lane half) + atomically adds when the Gaussian changes:
 // ~N_visible x 10 atomics instead of n_groups x 10.  Pixel/box semantics
 // (int() truncation, +1 offsets, i > y_max guard) are the reference's.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -169,6 +171,88 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_rec_kernel(const float4* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward, LDS-staged records + wave-level culling + PPT pixels per lane (fused model path, experimental variants).
+// records = the packed 48-byte per-Gaussian records of gps_gauss_preprocess_fwd (incl. int16 pixel bounds of the
+// alpha >= 1/255 box).  A wave covers a 16 x (4*PPT) pixel region: lane -> column (lane & 15), rows
+// (lane >> 4) * PPT + k.  The bounds test is wave-uniform (all lanes read the same LDS word), so a skipped Gaussian
+// costs one ds_read_b64 + ~6 VALU instead of the ~25-instruction pair evaluation per pixel.
+template <int PPT, bool CULL>
+__global__ __launch_bounds__(256 / PPT) void raster_ges_fwd_v2_kernel(
+    const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
+    float* __restrict__ render_alphas) {
+    constexpr int THREADS = 256 / PPT;
+    constexpr int BATCH = 256;
+    __shared__ float4 r0[BATCH + 1];
+    __shared__ float4 r1[BATCH + 1];
+    __shared__ float4 r2[BATCH + 1];
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = tx * 16 + (lane & 15);
+    const int row_base = ty * 16 + wave * (4 * PPT) + (lane >> 4) * PPT;  // first of this lane's PPT rows
+    const int wrow0 = ty * 16 + wave * (4 * PPT), wrow1 = wrow0 + 4 * PPT - 1, col0 = tx * 16;
+    const float px = (float)j + 0.5f;
+    float py[PPT], cut[PPT], o0[PPT], o1[PPT], o2[PPT], o3[PPT], ws[PPT];
+    bool inside[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int i = row_base + k;
+        inside[k] = (i < H) && (j < W);
+        py[k] = (float)i + 0.5f;
+        cut[k] = inside[k] ? ref_depth[i * W + j] + delta_depth : -3.0e38f;
+        o0[k] = o1[k] = o2[k] = o3[k] = ws[k] = 0.f;
+    }
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+
+    for (int batch_start = range_start; batch_start < range_end; batch_start += BATCH) {
+        __syncthreads();
+        for (int q = tid; q < BATCH; q += THREADS) {
+            const int idx = batch_start + q;
+            if (idx < range_end) {
+                const int g = flatten_ids[idx];
+                r0[q] = recs[3 * (size_t)g]; r1[q] = recs[3 * (size_t)g + 1]; r2[q] = recs[3 * (size_t)g + 2];
+            }
+        }
+        __syncthreads();
+        const int batch_size = min(BATCH, range_end - batch_start);
+        // software pipeline: record t+1 is read from LDS while record t is evaluated (the arrays have one spare slot)
+        float4 a = r0[0], b = r1[0], c = r2[0];
+        for (int t = 0; t < batch_size; ++t) {
+            const float4 na = r0[t + 1], nb = r1[t + 1], nc = r2[t + 1];
+            const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
+            const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16;
+            const int y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
+            const bool skip = CULL && (x_hi < col0 || x_lo > col0 + 15 || y_hi < wrow0 || y_lo > wrow1);  // wave uniform
+            if (!skip) {
+                const float dx = a.x - px;
+                const float adx2 = a.z * dx * dx, bdx = a.w * dx;
+#pragma unroll
+                for (int k = 0; k < PPT; k++) {
+                    const float dy = a.y - py[k];
+                    const float sigma = 0.5f * (adx2 + b.x * dy * dy) + bdx * dy;
+                    const float alpha = fminf(0.999f, b.y * __expf(-sigma));
+                    const bool hit = !(b.z > cut[k]) && !(sigma < 0.f) && !(alpha < 1.f / 255.f);
+                    const float al = hit ? alpha : 0.f;
+                    o0[k] += b.w * al; o1[k] += c.x * al; o2[k] += c.y * al; o3[k] += b.z * al; ws[k] += al;
+                }
+            }
+            a = na; b = nb; c = nc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; k++)
+        if (inside[k]) {
+            const int pix = (row_base + k) * W + j;
+            render_colors[pix] = make_float4(o0[k], o1[k], o2[k], o3[k]);
+            render_alphas[pix] = ws[k];
+        }
+}
+
 __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restrict__ v_means2d,
                                                         float* __restrict__ v_conics, float* __restrict__ v_colors,
                                                         float* __restrict__ v_opacities) {
@@ -209,6 +293,62 @@ __device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, float* __restri
     a.c0 = a.c1 = a.c2 = a.c3 = a.ka = a.kb = a.kc = a.mx = a.my = a.op = 0.f;
 }
 
+// One wave64 task = 32 consecutive 32-pixel groups, as two contiguous runs of 16 (one per half-wave).
+// Phase A: lanes 0..15 of each half fetch their step's group header and Gaussian record and park them in LDS --
+//          ONE global round trip per task instead of one dependent chain per step.
+// Phase B: 16 steps; every lane of a half reads its step's record from LDS (2 distinct addresses per access:
+//          broadcast, conflict free), evaluates its pixel of the 2r x 2r box and accumulates in registers; two steps
+//          are in flight at a time so that their 3+3 pixel gathers overlap.  A half reduces with shuffles and issues
+//          its 10 atomics only when the Gaussian changes.
+struct __attribute__((aligned(16))) BwdRec {
+    float x, y, ca, cb;      // xy, conic a, b
+    float cc, opac, r, g;    // conic c, opacity, colour r, g
+    float b, depth;          // colour b, depth channel
+    int gs_id, pid0;         // Gaussian id (-1 = no group), first pixel slot of the group inside the box
+    int x0, y0, ymax, bw;    // x_min + 1, y_min + 1, y_max, box width 2r
+};
+
+#ifndef BWD_INFLIGHT
+#define BWD_INFLIGHT 2
+#endif
+struct BwdPix { bool on; float alpha, vis, dx, dy; float4 vc; float va; };
+
+__device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, const float* __restrict__ ref_depth,
+                                         float delta_depth, const float4* __restrict__ v_render_colors,
+                                         const float* __restrict__ v_render_alphas, BwdPix& o) {
+    o.on = false;
+    if (R.gs_id < 0) return;
+    const uint32_t pid = (uint32_t)R.pid0 + (uint32_t)hl;
+    const int j = R.x0 + (int)(pid % (uint32_t)R.bw);
+    const int i = R.y0 + (int)(pid / (uint32_t)R.bw);
+    if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && !(i > R.ymax))) return;
+    const int pix = i * W + j;
+    const float rd = ref_depth[pix];
+    o.vc = v_render_colors[pix];
+    o.va = v_render_alphas[pix];
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    o.dx = R.x - px; o.dy = R.y - py;
+    const float sigma = 0.5f * (R.ca * o.dx * o.dx + R.cc * o.dy * o.dy) + R.cb * o.dx * o.dy;
+    o.vis = __expf(-sigma);
+    o.alpha = fminf(0.999f, R.opac * o.vis);
+    o.on = !(sigma < 0.f) && !(o.alpha < 1.f / 255.f) && !(R.depth > rd + delta_depth);
+}
+
+__device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, Acc& acc) {
+    if (!p.on) return;
+    acc.c0 += p.alpha * p.vc.x; acc.c1 += p.alpha * p.vc.y; acc.c2 += p.alpha * p.vc.z; acc.c3 += p.alpha * p.vc.w;
+    const float v_alpha = R.r * p.vc.x + R.g * p.vc.y + R.b * p.vc.z + R.depth * p.vc.w + p.va;
+    if (R.opac * p.vis <= 0.999f) {
+        const float v_sigma = -R.opac * p.vis * v_alpha;
+        acc.ka += 0.5f * v_sigma * p.dx * p.dx;
+        acc.kb += v_sigma * p.dx * p.dy;
+        acc.kc += 0.5f * v_sigma * p.dy * p.dy;
+        acc.mx += v_sigma * (R.ca * p.dx + R.cb * p.dy);
+        acc.my += v_sigma * (R.cb * p.dx + R.cc * p.dy);
+        acc.op += p.vis * v_alpha;
+    }
+}
+
 __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int32_t* __restrict__ group_gs_ids, const int32_t* __restrict__ group_starts,
     const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
@@ -216,71 +356,60 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int64_t* __restrict__ counts, float delta_depth, int W, int H, const float4* __restrict__ v_render_colors,
     const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d, float* __restrict__ v_conics,
     float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    __shared__ BwdRec recs[4][2][16];
     const int n_groups = (int)counts[1];
-    const int n_tasks = (n_groups + 31) >> 5;  // 32 groups per wave task
-    const int lane = threadIdx.x & 63;
+    const int n_tasks = (n_groups + 31) >> 5;
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
     const int half = lane >> 5, hl = lane & 31;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    BwdRec* my = recs[wave_in_wg][half];
 
     for (int task = wave_global; task < n_tasks; task += n_waves) {
+        // ---- phase A: one record per step, fetched by lanes 0..15 of each half
+        if (hl < 16) {
+            const int gid = task * 32 + half * 16 + hl;
+            BwdRec R;
+            R.gs_id = -1;
+            if (gid < n_groups) {
+                const int g = group_gs_ids[gid];
+                const int gstart = group_starts[gid];
+                const float2 xy = means2d[g];
+                const float4 c = colors[g];
+                const int r = radiis[g];
+                R.x = xy.x; R.y = xy.y;
+                R.ca = conics[3 * g]; R.cb = conics[3 * g + 1]; R.cc = conics[3 * g + 2];
+                R.opac = opacities[g];
+                R.r = c.x; R.g = c.y; R.b = c.z; R.depth = c.w;
+                R.gs_id = g;
+                R.pid0 = (gid - gstart) * 32;
+                R.x0 = (int)xy.x - r + 1; R.y0 = (int)xy.y - r + 1; R.ymax = (int)xy.y + r; R.bw = 2 * r;
+            }
+            my[hl] = R;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // ---- phase B
         Acc acc;
         acc.c0 = acc.c1 = acc.c2 = acc.c3 = acc.ka = acc.kb = acc.kc = acc.mx = acc.my = acc.op = 0.f;
         int cur_g = -1;
-        // Gaussian parameters (uniform across the half-wave)
-        float gx = 0.f, gy = 0.f, opac = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
-        float4 rgbd = make_float4(0.f, 0.f, 0.f, 0.f);
-        int x_min = 0, y_min = 0, y_max = 0, bw = 1;
-        const int first = task * 32 + half * 16;
-        for (int s = 0; s < 16; ++s) {
-            const int gid = first + s;
-            const bool live = gid < n_groups;
-            const int g = live ? group_gs_ids[gid] : -1;
-            // `g != cur_g` is uniform inside a 32-lane half; flush_acc only shuffles within the half,
-            // so the two halves may diverge here safely.
-            if (g != cur_g) {
-                flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
-                cur_g = g;
-                if (g >= 0) {
-                    const float2 xy = means2d[g];
-                    gx = xy.x; gy = xy.y;
-                    opac = opacities[g];
-                    ca = conics[3 * g]; cb = conics[3 * g + 1]; cc = conics[3 * g + 2];
-                    rgbd = colors[g];
-                    const int r = radiis[g];
-                    x_min = (int)gx - r; y_min = (int)gy - r; y_max = (int)gy + r;
-                    bw = 2 * r;  // x_max - x_min
+        for (int s = 0; s < 16; s += BWD_INFLIGHT) {
+            BwdPix p[BWD_INFLIGHT];
+#pragma unroll
+            for (int u = 0; u < BWD_INFLIGHT; ++u)
+                bwd_eval(my[s + u], hl, W, H, ref_depth, delta_depth, v_render_colors, v_render_alphas, p[u]);
+#pragma unroll
+            for (int u = 0; u < BWD_INFLIGHT; ++u) {
+                const BwdRec R = my[s + u];
+                if (R.gs_id != cur_g) {
+                    flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
+                    cur_g = R.gs_id;
                 }
-            }
-            if (g < 0) continue;
-            const uint32_t pid = (uint32_t)(gid - group_starts[gid]) * 32u + (uint32_t)hl;
-            const int j = x_min + 1 + (int)(pid % (uint32_t)bw);
-            const int i = y_min + 1 + (int)(pid / (uint32_t)bw);
-            bool valid = (i < H) && (j < W) && (i >= 0) && (j >= 0) && !(i > y_max);
-            if (valid) {
-                const int pix = i * W + j;
-                const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-                const float dx = gx - px, dy = gy - py;
-                const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-                const float vis = __expf(-sigma);
-                const float alpha = fminf(0.999f, opac * vis);
-                if (!(sigma < 0.f) && !(alpha < 1.f / 255.f) && !(rgbd.w > ref_depth[pix] + delta_depth)) {
-                    const float4 vc = v_render_colors[pix];
-                    acc.c0 += alpha * vc.x; acc.c1 += alpha * vc.y; acc.c2 += alpha * vc.z; acc.c3 += alpha * vc.w;
-                    float v_alpha = rgbd.x * vc.x + rgbd.y * vc.y + rgbd.z * vc.z + rgbd.w * vc.w + v_render_alphas[pix];
-                    if (opac * vis <= 0.999f) {
-                        const float v_sigma = -opac * vis * v_alpha;
-                        acc.ka += 0.5f * v_sigma * dx * dx;
-                        acc.kb += v_sigma * dx * dy;
-                        acc.kc += 0.5f * v_sigma * dy * dy;
-                        acc.mx += v_sigma * (ca * dx + cb * dy);
-                        acc.my += v_sigma * (cb * dx + cc * dy);
-                        acc.op += vis * v_alpha;
-                    }
-                }
+                bwd_accum(R, p[u], acc);
             }
         }
         flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -313,10 +442,19 @@ int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_m
     GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
     GPS_REQUIRE(N == 0 || records);
     const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
-    raster_ges_fwd_rec_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>((const float4*)records, ref_depth_map, width,
-                                                                        height, tw, th, tile_offsets, flatten_ids, counts,
-                                                                        delta_depth, (float4*)render_colors,
-                                                                        render_alphas);
+    static const int variant = getenv("GPS_RASTER_FWD_VARIANT") ? atoi(getenv("GPS_RASTER_FWD_VARIANT")) : 3;
+    hipStream_t st = (hipStream_t)stream;
+#define GPS_V2ARGS (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, \
+                   delta_depth, (float4*)render_colors, render_alphas
+    switch (variant) {
+        case 0: raster_ges_fwd_rec_kernel<<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;   // scalar-load streaming
+        case 1: raster_ges_fwd_v2_kernel<1, true><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;   // LDS + cull, 1 px/lane
+        case 3: raster_ges_fwd_v2_kernel<1, false><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;  // LDS, no cull
+        case 4: raster_ges_fwd_v2_kernel<4, false><<<tw * th, 64, 0, st>>>(GPS_V2ARGS); break;   // 4 px/lane, 1 wave/tile
+        case 2: raster_ges_fwd_v2_kernel<2, true><<<tw * th, 128, 0, st>>>(GPS_V2ARGS); break;   // LDS + cull, 2 px/lane
+        default: raster_ges_fwd_v2_kernel<1, false><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;
+    }
+#undef GPS_V2ARGS
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

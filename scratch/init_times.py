@@ -1,5 +1,5 @@
 import sys, time, torch, numpy as np
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from gps_slam_amd.dist_util import scene_seed
 from gps_slam_amd.slam_pipeline import compute_normal_map

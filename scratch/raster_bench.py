@@ -1,5 +1,5 @@
 import sys, time, torch, numpy as np, ctypes as C
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from gps_slam_amd.dist_util import scene_seed
 from gps_slam_amd._lib import lib
@@ -19,7 +19,7 @@ ref = rc["depth_map_clamped"]; N=st.N
 def fwd1(): lib.gps_raster_ges_fwd(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(ref), W, H, 16, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), None, sp)
 def fwd2(): lib.gps_raster_ges_fwd_rec(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), sp)
 def bwd(): lib.gps_raster_ges_bwd_gs(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(B["radii"]), ptr(ref), W, H, ptr(B["group_gs_ids"]), ptr(B["group_starts"]), ptr(B["counts"]), model.delta_depth, ptr(B["v_render_colors"]), ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]), ptr(B["v_opacities"]), 1, sp)
-for name, fn in (('fwd_lds', fwd1), ('fwd_rec', fwd2), ('bwd', bwd)):
+for name, fn in (('fwd_lds', fwd1), ('fwd_rec_var', fwd2), ('bwd', bwd)):
     print('%-10s %.1f us' % (name, 1e6*_time_launches(fn, 50, stream)))
 offs = B["tile_offsets"].cpu().numpy().astype(np.int64); ni=int(counts[0])
 d = np.diff(np.concatenate([offs, [ni]]))
