@@ -87,7 +87,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or _LIBPATH
+    p = path or os.environ.get("GPS_SLAM_HIP_LIB") or _LIBPATH  # env override: A/B builds of the same ABI
     # torch ships its own libamdhip64.so.7; it must be the (single) HIP runtime of the process so that the
     # streams and device pointers torch hands us are valid inside libgpsslam_hip.so -> import torch first.
     import torch  # noqa: F401

@@ -22,7 +22,7 @@ static inline Mat4 load_mat(const float* p) { Mat4 r; for (int i = 0; i < 16; i+
 
 static inline bool state_valid(const gps_tsdf_state& s) {
     if (s.width <= 0 || s.height <= 0 || s.n_blocks <= 0 || s.n_buckets <= 0 || s.n_excess <= 0) return false;
-    if ((s.n_buckets & (s.n_buckets - 1)) != 0) return false;  // hash mask = n_buckets - 1
+    if ((s.n_buckets & (s.n_buckets - 1)) != 0 || s.n_buckets < 32) return false;  // hash mask = n_buckets - 1
     if (!(s.voxel_size > 0.f) || !(s.mu > 0.f) || s.max_w <= 0 || s.max_w > 255) return false;
     return s.vba && s.vba_alloc_list && s.hash && s.excess_list && s.counters && s.alloc_prio && s.scan_scratch &&
            s.visible_type && s.visible_ids && s.depth && s.rgb && s.minmax && s.raycast && s.icp_points &&
@@ -35,6 +35,34 @@ __device__ __forceinline__ void mul_point(const Mat4& M, float x, float y, float
     rx = M.m[0] * x + M.m[4] * y + M.m[8] * z + M.m[12] * w;
     ry = M.m[1] * x + M.m[5] * y + M.m[9] * z + M.m[13] * w;
     rz = M.m[2] * x + M.m[6] * y + M.m[10] * z + M.m[14] * w;
+}
+
+// A hash entry is 16 bytes {short pos[3]; pad; int offset; int ptr}.  Reading it field by field -- or as a uint4
+// the optimiser is free to narrow -- makes the compiler emit one small load per field *at its first use*, i.e. a chain
+// of dependent round trips behind the compares.  load_raw fetches it as one aligned dwordx4; pin() is an empty asm
+// that names all four dwords, so the load stays whole and stays where it was issued.  Batches: issue all load_raw
+// calls first, pin them afterwards (a pin waits for its operands), then decode.
+struct HashEntry { int x, y, z, offset, ptr; };
+__device__ __forceinline__ uint4 load_raw(const gps_hash_entry* __restrict__ h, int idx) {
+    return reinterpret_cast<const uint4*>(h)[idx];
+}
+__device__ __forceinline__ void pin(uint4& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+__device__ __forceinline__ void pin(uint4& a, uint4& b) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
+__device__ __forceinline__ HashEntry decode_entry(const uint4 r) {
+    HashEntry e;
+    e.x = (int)(int16_t)(r.x & 0xFFFFu); e.y = (int)(int16_t)(r.x >> 16); e.z = (int)(int16_t)(r.y & 0xFFFFu);
+    e.offset = (int)r.z; e.ptr = (int)r.w;
+    return e;
+}
+__device__ __forceinline__ HashEntry load_entry(const gps_hash_entry* __restrict__ h, int idx) {
+    uint4 r = load_raw(h, idx);
+    pin(r);
+    return decode_entry(r);
+}
+__device__ __forceinline__ bool entry_is(const HashEntry& e, int bx, int by, int bz) {
+    return (e.x == bx) & (e.y == by) & (e.z == bz);
 }
 
 // ITMRepresentationAccess.h:8-11

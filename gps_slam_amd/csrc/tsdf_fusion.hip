@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void alloc_request_kernel(TsdfState s, Mat4 in
     for (int i = 0; i < steps; i++) {
         const int bx = (int)(short)floorf(w.px), by = (int)(short)floorf(w.py), bz = (int)(short)floorf(w.pz);
         int hashIdx = hash_index(bx, by, bz, s.n_buckets - 1);
-        gps_hash_entry he = s.hash[hashIdx];
+        HashEntry he = load_entry(s.hash, hashIdx);
         bool found = false;
-        if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
+        if (entry_is(he, bx, by, bz) & (he.ptr >= -1)) {
             s.visible_type[hashIdx] = (he.ptr == -1) ? 2 : 1;
             found = true;
         }
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void alloc_request_kernel(TsdfState s, Mat4 in
             if (he.ptr >= -1) {
                 while (he.offset >= 1) {
                     hashIdx = s.n_buckets + he.offset - 1;
-                    he = s.hash[hashIdx];
-                    if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
+                    he = load_entry(s.hash, hashIdx);
+                    if (entry_is(he, bx, by, bz) & (he.ptr >= -1)) {
                         s.visible_type[hashIdx] = (he.ptr == -1) ? 2 : 1;
                         found = true;
                         break;
@@ -252,15 +252,15 @@ __device__ __forceinline__ bool slot_visible(const TsdfState& s, const Mat4& M, 
         // CPU.tpp:268-306: type 3 (visible last frame) is re-tested against the frustum, types 1/2 stay
         uint8_t vt = s.visible_type[idx];
         if (vt == 3) {
-            const gps_hash_entry he = s.hash[idx];
-            if (!block_visible(s, M, he.pos[0], he.pos[1], he.pos[2])) vt = 0;
+            const HashEntry he = load_entry(s.hash, idx);
+            if (!block_visible(s, M, he.x, he.y, he.z)) vt = 0;
             if (update) s.visible_type[idx] = vt;
         }
         return vt > 0;
     } else {
         // Visualisation CPU.tpp:36-74 / buildCompleteVisibleList_device: every allocated block inside the frustum
-        const gps_hash_entry he = s.hash[idx];
-        return he.ptr >= 0 && block_visible(s, M, he.pos[0], he.pos[1], he.pos[2]);
+        const HashEntry he = load_entry(s.hash, idx);
+        return he.ptr >= 0 && block_visible(s, M, he.x, he.y, he.z);
     }
 }
 
@@ -311,15 +311,15 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
     const float mu = s.mu;
     const uchar4* img = reinterpret_cast<const uchar4*>(s.rgb);
     for (int e = wave; e < n_visible; e += n_waves) {
-        const gps_hash_entry he = s.hash[s.visible_ids[e]];
+        const HashEntry he = load_entry(s.hash, s.visible_ids[e]);
         if (he.ptr < 0) continue;  // uniform across the wave
         uint64_t* blk = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + lane;
-        const float pmx = (float)(he.pos[0] * BLK + lx) * s.voxel_size;
-        const float pmy = (float)(he.pos[1] * BLK + ly) * s.voxel_size;
+        const float pmx = (float)(he.x * BLK + lx) * s.voxel_size;
+        const float pmy = (float)(he.y * BLK + ly) * s.voxel_size;
 #pragma unroll 2
         for (int lz = 0; lz < BLK; lz++) {
             uint64_t* slot = blk + lz * 64;
-            const float pmz = (float)(he.pos[2] * BLK + lz) * s.voxel_size;
+            const float pmz = (float)(he.z * BLK + lz) * s.voxel_size;
             float cx, cy, cz;
             mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
             if (cz <= 0) continue;

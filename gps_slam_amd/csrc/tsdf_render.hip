@@ -40,13 +40,13 @@ __global__ __launch_bounds__(256) void expected_depths_partial_kernel(TsdfState 
     __syncthreads();
     int my_blocks = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const gps_hash_entry he = s.hash[vis_ids[k]];
+        const HashEntry he = load_entry(s.hash, vis_ids[k]);
         if (he.ptr < 0) continue;
         int ulx = W / MINMAX_SUB, uly = H / MINMAX_SUB, lrx = -1, lry = -1;
         float zmin = FAR_AWAY, zmax = VERY_CLOSE;
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
-            short tx = he.pos[0], ty = he.pos[1], tz = he.pos[2];
+            short tx = (short)he.x, ty = (short)he.y, tz = (short)he.z;
             tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
             float px, py, pz;
             mul_point(M, (float)tx * (float)BLK * s.voxel_size, (float)ty * (float)BLK * s.voxel_size,
@@ -109,62 +109,128 @@ __global__ __launch_bounds__(256) void expected_depths_reduce_kernel(int W, int 
 
 // ---------------------------------------------------------------- voxel access (ITMRepresentationAccess.h)
 struct BlockCache { int bx, by, bz, ptr; };
+#ifndef GPS_RAYCAST_SKIP
+#define GPS_RAYCAST_SKIP 4
+#endif
+constexpr int SKIP = GPS_RAYCAST_SKIP;  // free-space look-ahead of the raycaster (0 = off)
 
-__device__ __forceinline__ uint64_t read_voxel_raw(const TsdfState& s, int px, int py, int pz, int& vmIndex,
-                                                   BlockCache& c) {
-    const int bx = ((px < 0) ? px - BLK + 1 : px) / BLK;
-    const int by = ((py < 0) ? py - BLK + 1 : py) / BLK;
-    const int bz = ((pz < 0) ? pz - BLK + 1 : pz) / BLK;
-    const int lin = px + (py - bx) * BLK + (pz - by) * BLK * BLK - bz * BLK3;
-    const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
-    if (bx == c.bx && by == c.by && bz == c.bz) { vmIndex = 1; return vox[c.ptr + lin]; }  // :89-93 (vmIndex = true)
-    int hashIdx = hash_index(bx, by, bz, s.n_buckets - 1);
+__device__ __forceinline__ int floor_div_blk(int v) { return ((v < 0) ? v - BLK + 1 : v) / BLK; }
+
+// findVoxel (ITMRepresentationAccess.h:81-113) split into "which block" and "which voxel".  resolve_with_head returns
+// the first voxel index of block (bx,by,bz) or -1 with the reference's cache and vmIndex side effects (cache hit ->
+// vmIndex = 1; hash hit -> vmIndex = entry + 1 and the cache moves; miss -> vmIndex = 0).  The bucket-head entry is
+// passed in: callers fetch the heads of everything they are about to look up in ONE batch of independent loads, then
+// replay the lookups in the reference's order from registers (only excess-list chains, which are rare, cost further
+// round trips), then issue the voxel loads together.  A wave therefore pays ~2 memory round trips per lookup group
+// instead of one per lane-divergent branch.
+__device__ __forceinline__ int resolve_with_head(const TsdfState& s, int bx, int by, int bz, HashEntry he, int hashIdx,
+                                                 int& vmIndex, BlockCache& c) {
+    if (bx == c.bx && by == c.by && bz == c.bz) { vmIndex = 1; return c.ptr; }  // :89-93 (vmIndex = true)
     while (true) {
-        const gps_hash_entry he = s.hash[hashIdx];
-        if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= 0) {
+        if (entry_is(he, bx, by, bz) & (he.ptr >= 0)) {
             c.bx = bx; c.by = by; c.bz = bz; c.ptr = he.ptr * BLK3;
             vmIndex = hashIdx + 1;
-            return vox[c.ptr + lin];
+            return c.ptr;
         }
         if (he.offset < 1) break;
         hashIdx = s.n_buckets + he.offset - 1;
+        he = load_entry(s.hash, hashIdx);
     }
     vmIndex = 0;
-    return 0x7FFFull;  // TVoxel(): sdf 32767, weights / colour 0
+    return -1;
+}
+
+__device__ __forceinline__ int resolve_block(const TsdfState& s, int px, int py, int pz, int& lin, int& vmIndex,
+                                             BlockCache& c) {
+    const int bx = floor_div_blk(px), by = floor_div_blk(py), bz = floor_div_blk(pz);
+    lin = px + (py - bx) * BLK + (pz - by) * BLK * BLK - bz * BLK3;
+    if (bx == c.bx && by == c.by && bz == c.bz) { vmIndex = 1; return c.ptr; }
+    const int hashIdx = hash_index(bx, by, bz, s.n_buckets - 1);
+    return resolve_with_head(s, bx, by, bz, load_entry(s.hash, hashIdx), hashIdx, vmIndex, c);
+}
+
+constexpr uint64_t EMPTY_VOXEL = 0x7FFFull;  // TVoxel(): sdf 32767, weights / colour 0
+
+__device__ __forceinline__ uint64_t read_voxel_raw(const TsdfState& s, int px, int py, int pz, int& vmIndex,
+                                                   BlockCache& c) {
+    int lin;
+    const int base = resolve_block(s, px, py, pz, lin, vmIndex, c);
+    return base >= 0 ? reinterpret_cast<const uint64_t*>(s.vba)[base + lin] : EMPTY_VOXEL;
 }
 __device__ __forceinline__ float vox_sdf(uint64_t raw) { return (float)(int16_t)(raw & 0xFFFF); }
 __device__ __forceinline__ float vox_wdepth(uint64_t raw) { return (float)((raw >> 16) & 0xFF); }
 __device__ __forceinline__ float roundf_ref(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }
 
+// the trilinear blend of readFromSDF_float_interpolated, in the reference's operation order; r[dx + 2*dy + 4*dz]
+template <bool WITH_CONF>
+__device__ __forceinline__ float blend_corners(const uint64_t (&r)[8], float cx, float cy, float cz, float& conf) {
+    float res1 = (1.0f - cx) * vox_sdf(r[0]) + cx * vox_sdf(r[1]);
+    res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * vox_sdf(r[2]) + cx * vox_sdf(r[3]));
+    float res2 = (1.0f - cx) * vox_sdf(r[4]) + cx * vox_sdf(r[5]);
+    res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * vox_sdf(r[6]) + cx * vox_sdf(r[7]));
+    if (WITH_CONF) {
+        float c1 = (1.0f - cx) * vox_wdepth(r[0]) + cx * vox_wdepth(r[1]);
+        c1 = (1.0f - cy) * c1 + cy * ((1.0f - cx) * vox_wdepth(r[2]) + cx * vox_wdepth(r[3]));
+        float c2 = (1.0f - cx) * vox_wdepth(r[4]) + cx * vox_wdepth(r[5]);
+        c2 = (1.0f - cy) * c2 + cy * ((1.0f - cx) * vox_wdepth(r[6]) + cx * vox_wdepth(r[7]));
+        conf = (1.0f - cz) * c1 + cz * c2;
+    }
+    return ((1.0f - cz) * res1 + cz * res2) / 32767.0f;
+}
+
+// readFromSDF_float_interpolated / readWithConfidenceFromSDF_float_interpolated (ITMRepresentationAccess.h:117-187).
+// The reference reads the eight corners one after the other through the block cache.  Here:
+//  * cell inside one block (local coordinates <= 6, 67% of cells): after the first lookup either the cache holds that
+//    block and all eight voxels are loaded together, or the block is unallocated and the other seven lookups would fail
+//    exactly like the first (no side effects, cache untouched);
+//  * cell straddling blocks: the eight bucket heads are fetched together, the eight lookups are replayed in the
+//    reference's order from registers (identical cache evolution), then the eight voxels are loaded together.
 template <bool WITH_CONF>
 __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, float py, float pz, int& vmIndex,
                                                  BlockCache& c, float& conf) {
     const float fx_ = floorf(px), fy_ = floorf(py), fz_ = floorf(pz);
     const float cx = px - fx_, cy = py - fy_, cz = pz - fz_;
     const int ix = (int)fx_, iy = (int)fy_, iz = (int)fz_;
-    uint64_t r;
-    float v1, v2, res1, res2, v1c = 0.f, v2c = 0.f, res1c = 0.f, res2c = 0.f;
-#define RV(dx, dy, dz) read_voxel_raw(s, ix + dx, iy + dy, iz + dz, vmIndex, c)
-    r = RV(0, 0, 0); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
-    r = RV(1, 0, 0); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
-    res1 = (1.0f - cx) * v1 + cx * v2;
-    if (WITH_CONF) res1c = (1.0f - cx) * v1c + cx * v2c;
-    r = RV(0, 1, 0); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
-    r = RV(1, 1, 0); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
-    res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v1 + cx * v2);
-    if (WITH_CONF) res1c = (1.0f - cy) * res1c + cy * ((1.0f - cx) * v1c + cx * v2c);
-    r = RV(0, 0, 1); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
-    r = RV(1, 0, 1); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
-    res2 = (1.0f - cx) * v1 + cx * v2;
-    if (WITH_CONF) res2c = (1.0f - cx) * v1c + cx * v2c;
-    r = RV(0, 1, 1); v1 = vox_sdf(r); if (WITH_CONF) v1c = vox_wdepth(r);
-    r = RV(1, 1, 1); v2 = vox_sdf(r); if (WITH_CONF) v2c = vox_wdepth(r);
-    res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
-    if (WITH_CONF) res2c = (1.0f - cy) * res2c + cy * ((1.0f - cx) * v1c + cx * v2c);
-#undef RV
+    const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
+    uint64_t r[8];  // x fastest: r[dx + 2*dy + 4*dz]
+    if ((ix & 7) < 7 && (iy & 7) < 7 && (iz & 7) < 7) {
+        int lin;
+        const int base = resolve_block(s, ix, iy, iz, lin, vmIndex, c);
+        if (base >= 0) {
+            const uint64_t* v = vox + base + lin;
+            r[0] = v[0]; r[1] = v[1]; r[2] = v[BLK]; r[3] = v[BLK + 1];
+            r[4] = v[BLK * BLK]; r[5] = v[BLK * BLK + 1]; r[6] = v[BLK * BLK + BLK]; r[7] = v[BLK * BLK + BLK + 1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = EMPTY_VOXEL;
+        }
+    } else {
+        int kx[8], ky[8], kz[8], hidx[8], idx[8];
+        uint4 hraw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            kx[k] = floor_div_blk(ix + (k & 1)); ky[k] = floor_div_blk(iy + ((k >> 1) & 1));
+            kz[k] = floor_div_blk(iz + (k >> 2));
+            hidx[k] = hash_index(kx[k], ky[k], kz[k], s.n_buckets - 1);
+            hraw[k] = load_raw(s.hash, hidx[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) pin(hraw[k], hraw[k + 1]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int vx = ix + (k & 1), vy = iy + ((k >> 1) & 1), vz = iz + (k >> 2);
+            const int lin = vx + (vy - kx[k]) * BLK + (vz - ky[k]) * BLK * BLK - kz[k] * BLK3;
+            const int base = resolve_with_head(s, kx[k], ky[k], kz[k], decode_entry(hraw[k]), hidx[k], vmIndex, c);
+            idx[k] = base >= 0 ? base + lin : -1;
+        }
+        uint64_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = vox[idx[k] >= 0 ? idx[k] : 0];  // unconditional: one batch, no branches
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = idx[k] >= 0 ? t[k] : EMPTY_VOXEL;
+    }
     vmIndex = 1;
-    if (WITH_CONF) conf = (1.0f - cz) * res1c + cz * res2c;
-    return ((1.0f - cz) * res1 + cz * res2) / 32767.0f;
+    return blend_corners<WITH_CONF>(r, cx, cy, cz, conf);
 }
 
 // castRay (Shared.h:122-221); 16x16 pixel workgroups so that a wave's rays stay inside a 16x4 patch
@@ -200,16 +266,117 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     BlockCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
     float sdfValue = 1.0f, confidence = 0.f, stepLength;
     int vmIndex = 0;
+#ifdef GPS_RAYCAST_STATS
+    int n_un = 0, n_co = 0, n_in = 0;
+    const uint64_t t_start = wall_clock64();
+    uint64_t tk_heads = 0, tk_vox = 0, tk_interp = 0, tk_tail = 0, tk0;
+#define TICK0() (tk0 = wall_clock64())
+#define TICK(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tk0; tk0 = now_; } while (0)
+#else
+#define TICK0()
+#define TICK(acc)
+#endif
+    const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
     while (totalLength < totalLengthMax) {
-        const uint64_t raw = read_voxel_raw(s, (int)roundf_ref(px), (int)roundf_ref(py), (int)roundf_ref(pz), vmIndex, cache);
+        // Candidate positions: [0] is this step's sample; [1..SKIP] are where the next steps land IF this and the
+        // following lookups fail (a failed lookup always advances by one block edge, stepLength = 8 voxels) -- the same
+        // float additions in the same order as the one-lookup-per-step loop.  A lane whose sample is in its cached
+        // block needs no bucket at all; the others fetch all 1+SKIP bucket heads in one batch.
+        TICK0();
+        float qx[SKIP + 1], qy[SKIP + 1], qz[SKIP + 1], ql[SKIP + 1];
+        int kx[SKIP + 1], ky[SKIP + 1], kz[SKIP + 1], hidx[SKIP + 1];
+        uint4 hraw[SKIP + 1] = {};
+        HashEntry head[SKIP + 1];
+        qx[0] = px; qy[0] = py; qz[0] = pz; ql[0] = totalLength;
+#pragma unroll
+        for (int j = 1; j <= SKIP; j++) {
+            qx[j] = qx[j - 1] + (float)BLK * rx; qy[j] = qy[j - 1] + (float)BLK * ry; qz[j] = qz[j - 1] + (float)BLK * rz;
+            ql[j] = ql[j - 1] + (float)BLK;
+        }
+        const int vx = (int)roundf_ref(px), vy = (int)roundf_ref(py), vz = (int)roundf_ref(pz);
+        kx[0] = floor_div_blk(vx); ky[0] = floor_div_blk(vy); kz[0] = floor_div_blk(vz);
+        const int lin = vx + (vy - kx[0]) * BLK + (vz - ky[0]) * BLK * BLK - kz[0] * BLK3;
+        const bool cached = kx[0] == cache.bx && ky[0] == cache.by && kz[0] == cache.bz;
+        if (!cached) {
+#pragma unroll
+            for (int j = 0; j <= SKIP; j++) {
+                if (j > 0) {
+                    kx[j] = floor_div_blk((int)roundf_ref(qx[j])); ky[j] = floor_div_blk((int)roundf_ref(qy[j]));
+                    kz[j] = floor_div_blk((int)roundf_ref(qz[j]));
+                }
+                hidx[j] = hash_index(kx[j], ky[j], kz[j], s.n_buckets - 1);
+                hraw[j] = load_raw(s.hash, hidx[j]);
+            }
+#pragma unroll
+            for (int j = 0; j + 1 <= SKIP; j += 2) pin(hraw[j], hraw[j + 1]);
+            if ((SKIP & 1) == 0) pin(hraw[SKIP]);
+        }
+#pragma unroll
+        for (int j = 0; j <= SKIP; j++) head[j] = decode_entry(hraw[j]);
+        int base;
+        if (cached) { vmIndex = 1; base = cache.ptr; }
+        else base = resolve_with_head(s, kx[0], ky[0], kz[0], head[0], hidx[0], vmIndex, cache);
+#ifdef GPS_RAYCAST_STATS
+        asm volatile("" : "+v"(base));
+        TICK(tk_heads);
+#endif
+        // The sample voxel round(p) is a corner of the interpolation cell [floor(p), floor(p)+1]^3.  If that cell lies
+        // inside one block it is this block, so its eight voxels ride along with the sample in the same round trip and
+        // the interpolated read below -- whose corner lookups would all hit the cache that now holds this block --
+        // needs no memory access at all.
+        const float ffx = floorf(px), ffy = floorf(py), ffz = floorf(pz);
+        const int cix = (int)ffx, ciy = (int)ffy, ciz = (int)ffz;
+        const bool cell_in_block = (cix & 7) < 7 && (ciy & 7) < 7 && (ciz & 7) < 7;
+        uint64_t raw = EMPTY_VOXEL;
+        uint64_t corner[8];
+        if (base >= 0) {  // (skipped entirely by a wave whose live lanes are all in free space)
+            raw = vox[base + lin];
+            if (cell_in_block) {
+                const uint64_t* v = vox + base + (cix & 7) + (ciy & 7) * BLK + (ciz & 7) * BLK * BLK;
+                corner[0] = v[0]; corner[1] = v[1]; corner[2] = v[BLK]; corner[3] = v[BLK + 1];
+                corner[4] = v[BLK * BLK]; corner[5] = v[BLK * BLK + 1]; corner[6] = v[BLK * BLK + BLK];
+                corner[7] = v[BLK * BLK + BLK + 1];
+            }
+        }
         sdfValue = vox_sdf(raw) / 32767.0f;
+#ifdef GPS_RAYCAST_STATS
+        asm volatile("" : "+v"(sdfValue));
+        TICK(tk_vox);
+#endif
         if (MODIFY_VISIBLE) { if (vmIndex) s.visible_type[vmIndex - 1] = 1; }  // incl. the vmIndex==1 cache-hit quirk
+#ifdef GPS_RAYCAST_STATS
+        if (!vmIndex) n_un++; else if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) n_in++; else n_co++;
+#endif
         if (!vmIndex) {
             stepLength = BLK;
+            // advance over the candidates that are plainly unallocated steps inside the range (not the cached block,
+            // head entry is another block or free, no excess chain); the first one that is anything else is sampled by
+            // the next iteration.  (One batch per iteration: an inner run-to-completion loop would serialise the lanes.)
+            int adv = 0;
+#pragma unroll
+            for (int j = 1; j <= SKIP; j++) {
+                const bool plain = ql[j] < totalLengthMax &&
+                                   !(kx[j] == cache.bx && ky[j] == cache.by && kz[j] == cache.bz) &&
+                                   !(entry_is(head[j], kx[j], ky[j], kz[j]) & (head[j].ptr >= 0)) && head[j].offset < 1;
+                if (adv == j - 1 && plain) adv = j;
+            }
+#pragma unroll
+            for (int j = 1; j <= SKIP; j++)
+                if (adv == j) { px = qx[j]; py = qy[j]; pz = qz[j]; totalLength = ql[j]; }
         } else {
             if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
                 float dummy;
-                sdfValue = read_sdf_interp<false>(s, px, py, pz, vmIndex, cache, dummy);
+                TICK0();
+                if (cell_in_block) {
+                    sdfValue = blend_corners<false>(corner, px - ffx, py - ffy, pz - ffz, dummy);
+                    vmIndex = 1;
+                } else {
+                    sdfValue = read_sdf_interp<false>(s, px, py, pz, vmIndex, cache, dummy);
+                }
+#ifdef GPS_RAYCAST_STATS
+                asm volatile("" : "+v"(sdfValue));
+                TICK(tk_interp);
+#endif
             }
             if (sdfValue <= 0.0f) break;
             const float a = sdfValue * stepScale;
@@ -217,6 +384,10 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
         }
         px += stepLength * rx; py += stepLength * ry; pz += stepLength * rz;
         totalLength += stepLength;
+#ifdef GPS_RAYCAST_STATS
+        asm volatile("" : "+v"(totalLength));
+        TICK(tk_tail);
+#endif
     }
     bool found;
     if (sdfValue <= 0.0f) {
@@ -229,6 +400,16 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     } else {
         found = false;
     }
+#ifdef GPS_RAYCAST_STATS
+    const uint64_t t_end = wall_clock64();
+#ifdef GPS_RAYCAST_STATS_SECTIONS
+    rays[x + y * W] = make_float4((float)(tk_tail), (float)tk_heads, (float)tk_vox, (float)(wall_clock64() - t_start));
+#else
+    rays[x + y * W] = make_float4((float)(n_un + n_co + n_in), (float)n_un, __uint_as_float((uint32_t)t_start),
+                                  __uint_as_float((uint32_t)t_end));
+#endif
+    return;
+#endif
     rays[x + y * W] = make_float4(px, py, pz, found ? confidence + 1.0f : 0.0f);
 }
 
