@@ -253,6 +253,102 @@ __global__ __launch_bounds__(256 / PPT) void raster_ges_fwd_v2_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward, packed-math variant (the fused path's default).  The pair evaluation is VALU bound (PMC: ~23 wave
+// instructions per Gaussian x 64-pixel strip), so the lever is instructions per pixel:
+//   * each lane owns TWO horizontally adjacent pixels and evaluates them with v_pk_{add,mul,fma}_f32 -- dy, c*dy^2 and
+//     b*dy are shared by the pair, everything in dx and the five accumulators are 2-wide: ~25 VALU per Gaussian for
+//     128 pixels instead of ~23 per 64;
+//   * the staging step rewrites the record for the inner loop once per tile: conic pre-multiplied by log2(e) (and 1/2),
+//     opacity as -log2(opacity) folded into the exponent, so alpha = exp2(-(sigma' - log2 o)) is one v_exp_f32;
+//   * a 16x16 tile is covered by two waves (16x8 pixels each); to keep four waves per workgroup in flight the batch's
+//     Gaussian list is split in two halves, waves {0,1} and {2,3} each take one, and the partial sums are added
+//     through LDS at the end in a fixed order (deterministic; the sum is order independent in exact arithmetic).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
+    const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
+    float* __restrict__ render_alphas) {
+    constexpr int BATCH = 256;
+    __shared__ float4 r0[BATCH];   // {mx, my, 0.5*ca*log2e, cb*log2e}
+    __shared__ float4 r1[BATCH];   // {0.5*cc*log2e, -log2(opac), depth, r}
+    __shared__ float2 r2[BATCH];   // {g, b}
+    __shared__ float part[128 * 10];
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int list_half = wave >> 1, pix_half = wave & 1;
+    const int row = ty * 16 + pix_half * 8 + (lane >> 3), col = tx * 16 + 2 * (lane & 7);
+    const bool in0 = (row < H) && (col < W), in1 = (row < H) && (col + 1 < W);
+    const v2f px = {(float)col + 0.5f, (float)col + 1.5f};
+    const float py = (float)row + 0.5f;
+    const float cut0 = in0 ? ref_depth[row * W + col] + delta_depth : -3.0e38f;
+    const float cut1 = in1 ? ref_depth[row * W + col + 1] + delta_depth : -3.0e38f;
+    v2f o0 = {0.f, 0.f}, o1 = o0, o2 = o0, o3 = o0, ws = o0;
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    for (int batch_start = range_start; batch_start < range_end; batch_start += BATCH) {
+        __syncthreads();
+        {
+            const int idx = batch_start + tid;
+            if (idx < range_end) {
+                const size_t g = (size_t)flatten_ids[idx];
+                const float4 a = recs[3 * g], b = recs[3 * g + 1], c = recs[3 * g + 2];
+                r0[tid] = make_float4(a.x, a.y, 0.5f * LOG2E * a.z, LOG2E * a.w);
+                r1[tid] = make_float4(0.5f * LOG2E * b.x, -__log2f(b.y), b.z, b.w);
+                r2[tid] = make_float2(c.x, c.y);
+            }
+        }
+        __syncthreads();
+        const int n = min(BATCH, range_end - batch_start);
+        // wave-uniform bounds -> scalar loop counter
+        const int lo = __builtin_amdgcn_readfirstlane(list_half ? (n >> 1) : 0);
+        const int hi = __builtin_amdgcn_readfirstlane(list_half ? n : (n >> 1));
+#pragma unroll 2
+        for (int t = lo; t < hi; ++t) {
+            const float4 a = r0[t], b = r1[t];
+            const float2 c = r2[t];
+            const float dy = a.y - py;
+            const v2f dx = a.x - px;
+            const float cdy2 = b.x * dy * dy, bdy = a.w * dy;
+            const v2f w = a.z * dx + bdy;
+            const v2f sig = w * dx + cdy2;          // sigma * log2(e)
+            const v2f e = sig + b.y;                // sigma' - log2(opacity)
+            const float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.x));
+            const float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.y));
+            const bool hit0 = !(b.z > cut0) && !(sig.x < 0.f) && !(al0 < 1.f / 255.f);
+            const bool hit1 = !(b.z > cut1) && !(sig.y < 0.f) && !(al1 < 1.f / 255.f);
+            const v2f al = {hit0 ? al0 : 0.f, hit1 ? al1 : 0.f};
+            o0 += b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += b.z * al; ws += al;
+        }
+    }
+    // second list half -> LDS -> first list half adds and stores
+    const int slot = (pix_half * 64 + lane) * 10;
+    if (list_half) {
+        part[slot + 0] = o0.x; part[slot + 1] = o1.x; part[slot + 2] = o2.x; part[slot + 3] = o3.x; part[slot + 4] = ws.x;
+        part[slot + 5] = o0.y; part[slot + 6] = o1.y; part[slot + 7] = o2.y; part[slot + 8] = o3.y; part[slot + 9] = ws.y;
+    }
+    __syncthreads();
+    if (!list_half) {
+        const int pix = row * W + col;
+        if (in0) {
+            render_colors[pix] = make_float4(o0.x + part[slot + 0], o1.x + part[slot + 1], o2.x + part[slot + 2],
+                                             o3.x + part[slot + 3]);
+            render_alphas[pix] = ws.x + part[slot + 4];
+        }
+        if (in1) {
+            render_colors[pix + 1] = make_float4(o0.y + part[slot + 5], o1.y + part[slot + 6], o2.y + part[slot + 7],
+                                                 o3.y + part[slot + 8]);
+            render_alphas[pix + 1] = ws.y + part[slot + 9];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restrict__ v_means2d,
                                                         float* __restrict__ v_conics, float* __restrict__ v_colors,
                                                         float* __restrict__ v_opacities) {
@@ -442,17 +538,17 @@ int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_m
     GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
     GPS_REQUIRE(N == 0 || records);
     const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
-    static const int variant = getenv("GPS_RASTER_FWD_VARIANT") ? atoi(getenv("GPS_RASTER_FWD_VARIANT")) : 3;
+    static const int variant = getenv("GPS_RASTER_FWD_VARIANT") ? atoi(getenv("GPS_RASTER_FWD_VARIANT")) : 5;
     hipStream_t st = (hipStream_t)stream;
 #define GPS_V2ARGS (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, \
                    delta_depth, (float4*)render_colors, render_alphas
     switch (variant) {
         case 0: raster_ges_fwd_rec_kernel<<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;   // scalar-load streaming
         case 1: raster_ges_fwd_v2_kernel<1, true><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;   // LDS + cull, 1 px/lane
-        case 3: raster_ges_fwd_v2_kernel<1, false><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;  // LDS, no cull
         case 4: raster_ges_fwd_v2_kernel<4, false><<<tw * th, 64, 0, st>>>(GPS_V2ARGS); break;   // 4 px/lane, 1 wave/tile
         case 2: raster_ges_fwd_v2_kernel<2, true><<<tw * th, 128, 0, st>>>(GPS_V2ARGS); break;   // LDS + cull, 2 px/lane
-        default: raster_ges_fwd_v2_kernel<1, false><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;
+        case 3: raster_ges_fwd_v2_kernel<1, false><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;  // LDS, no cull
+        default: raster_ges_fwd_pk_kernel<<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;           // packed math, 2 px/lane
     }
 #undef GPS_V2ARGS
     GPS_LAUNCH_CHECK();
