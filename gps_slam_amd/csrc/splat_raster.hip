@@ -361,10 +361,20 @@ __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restric
     }
 }
 
-// sum over the 32 lanes of a half-wave (xor offsets < 32 never cross the half boundary)
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sum over the 32 lanes of a half-wave with DPP adds (no LDS crossbar traffic): row_shr 1/2/4/8 leave each 16-lane
+// row's total in its lane 15, row_bcast15 restricted to rows 1 and 3 adds the lower row's total into the upper row.
+// The half's total ends up in lane 31 of the half (hl == 31) ONLY.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float half_sum_to_lane31(float v) {
+    v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
     return v;
 }
 
@@ -373,18 +383,24 @@ struct Acc { float c0, c1, c2, c3, ka, kb, kc, mx, my, op; };
 __device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, float* __restrict__ v_means2d,
                                           float* __restrict__ v_conics, float* __restrict__ v_colors,
                                           float* __restrict__ v_opacities) {
-    float s0 = half_sum(a.c0), s1 = half_sum(a.c1), s2 = half_sum(a.c2), s3 = half_sum(a.c3);
-    float s4 = half_sum(a.ka), s5 = half_sum(a.kb), s6 = half_sum(a.kc);
-    float s7 = half_sum(a.mx), s8 = half_sum(a.my), s9 = half_sum(a.op);
-    if (g >= 0) {
-        // spread the 10 atomics over 10 lanes of the half instead of serialising them on lane 0
-        float v = hl == 0 ? s0 : hl == 1 ? s1 : hl == 2 ? s2 : hl == 3 ? s3 : hl == 4 ? s4 : hl == 5 ? s5
-                : hl == 6 ? s6 : hl == 7 ? s7 : hl == 8 ? s8 : s9;
-        float* dst = hl < 4 ? v_colors + 4 * (size_t)g + hl
-                   : hl < 7 ? v_conics + 3 * (size_t)g + (hl - 4)
-                   : hl < 9 ? v_means2d + 2 * (size_t)g + (hl - 7)
-                            : v_opacities + g;
-        if (hl < 10 && v != 0.f) atomicAdd(dst, v);
+    const float s0 = half_sum_to_lane31(a.c0), s1 = half_sum_to_lane31(a.c1), s2 = half_sum_to_lane31(a.c2);
+    const float s3 = half_sum_to_lane31(a.c3), s4 = half_sum_to_lane31(a.ka), s5 = half_sum_to_lane31(a.kb);
+    const float s6 = half_sum_to_lane31(a.kc), s7 = half_sum_to_lane31(a.mx), s8 = half_sum_to_lane31(a.my);
+    const float s9 = half_sum_to_lane31(a.op);
+    if (g >= 0 && hl == 31) {
+        float* vc = v_colors + 4 * (size_t)g;
+        float* vk = v_conics + 3 * (size_t)g;
+        float* vm = v_means2d + 2 * (size_t)g;
+        if (s0 != 0.f) atomicAdd(vc + 0, s0);
+        if (s1 != 0.f) atomicAdd(vc + 1, s1);
+        if (s2 != 0.f) atomicAdd(vc + 2, s2);
+        if (s3 != 0.f) atomicAdd(vc + 3, s3);
+        if (s4 != 0.f) atomicAdd(vk + 0, s4);
+        if (s5 != 0.f) atomicAdd(vk + 1, s5);
+        if (s6 != 0.f) atomicAdd(vk + 2, s6);
+        if (s7 != 0.f) atomicAdd(vm + 0, s7);
+        if (s8 != 0.f) atomicAdd(vm + 1, s8);
+        if (s9 != 0.f) atomicAdd(v_opacities + g, s9);
     }
     a.c0 = a.c1 = a.c2 = a.c3 = a.ka = a.kb = a.kc = a.mx = a.my = a.op = 0.f;
 }
@@ -401,7 +417,8 @@ struct __attribute__((aligned(16))) BwdRec {
     float cc, opac, r, g;    // conic c, opacity, colour r, g
     float b, depth;          // colour b, depth channel
     int gs_id, pid0;         // Gaussian id (-1 = no group), first pixel slot of the group inside the box
-    int x0, y0, ymax, bw;    // x_min + 1, y_min + 1, y_max, box width 2r
+    int x0, y0, bw;          // x_min + 1, y_min + 1, box width 2r (y_max = y0 + bw - 1)
+    float inv_bw;            // 1 / bw: (pid + 0.5) * inv_bw truncates to pid / bw exactly for pid < 2^16
 };
 
 #ifndef BWD_INFLIGHT
@@ -415,9 +432,10 @@ __device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, 
     o.on = false;
     if (R.gs_id < 0) return;
     const uint32_t pid = (uint32_t)R.pid0 + (uint32_t)hl;
-    const int j = R.x0 + (int)(pid % (uint32_t)R.bw);
-    const int i = R.y0 + (int)(pid / (uint32_t)R.bw);
-    if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && !(i > R.ymax))) return;
+    const int q = (int)(((float)pid + 0.5f) * R.inv_bw);  // pid / bw
+    const int j = R.x0 + ((int)pid - q * R.bw);
+    const int i = R.y0 + q;
+    if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw))) return;
     const int pix = i * W + j;
     const float rd = ref_depth[pix];
     o.vc = v_render_colors[pix];
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
                 R.r = c.x; R.g = c.y; R.b = c.z; R.depth = c.w;
                 R.gs_id = g;
                 R.pid0 = (gid - gstart) * 32;
-                R.x0 = (int)xy.x - r + 1; R.y0 = (int)xy.y - r + 1; R.ymax = (int)xy.y + r; R.bw = 2 * r;
+                R.x0 = (int)xy.x - r + 1; R.y0 = (int)xy.y - r + 1; R.bw = 2 * r; R.inv_bw = 1.0f / (float)(2 * r);
             }
             my[hl] = R;
         }
