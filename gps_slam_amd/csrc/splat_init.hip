@@ -22,9 +22,16 @@ __device__ __forceinline__ void keep3(float d, float& b0, float& b1, float& b2) 
     if (b2 > d) { b2 = d; }
 }
 
+// 16 queries x 16 candidate slices per workgroup: thread (q, slice) scans the candidates t == slice (mod 16) of every
+// 256-point LDS tile, so P points give P/16 workgroups (P is only 1e3..1e4 on the per-keyframe path -- one thread per
+// query would leave most of the chip idle); the 16 partial triples of a query are merged through LDS.
+constexpr int KNN_Q = 16, KNN_S = 16;
+
 __global__ __launch_bounds__(KNN_TILE) void knn_kernel(int P, const float* __restrict__ pts, float* __restrict__ out) {
     __shared__ float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
-    const int q = blockIdx.x * KNN_TILE + threadIdx.x;
+    __shared__ float best[KNN_S][KNN_Q][3];
+    const int ql = threadIdx.x & (KNN_Q - 1), slice = threadIdx.x / KNN_Q;
+    const int q = blockIdx.x * KNN_Q + ql;
     const bool live = q < P;
     const float qx = live ? pts[3 * q] : 0.f, qy = live ? pts[3 * q + 1] : 0.f, qz = live ? pts[3 * q + 2] : 0.f;
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
@@ -34,13 +41,21 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(int P, const float* __res
         if (j < P) { sx[threadIdx.x] = pts[3 * j]; sy[threadIdx.x] = pts[3 * j + 1]; sz[threadIdx.x] = pts[3 * j + 2]; }
         __syncthreads();
         const int n = min(KNN_TILE, P - base);
-        for (int t = 0; t < n; t++) {
+#pragma unroll 4
+        for (int t = slice; t < n; t += KNN_S) {
             if (base + t == q) continue;
             const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
             keep3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
         }
     }
-    if (live) out[q] = (b0 + b1 + b2) / 3.0f;
+    best[slice][ql][0] = b0; best[slice][ql][1] = b1; best[slice][ql][2] = b2;
+    __syncthreads();
+    if (slice == 0 && live) {
+        for (int s2 = 1; s2 < KNN_S; s2++) {
+            keep3(best[s2][ql][0], b0, b1, b2); keep3(best[s2][ql][1], b0, b1, b2); keep3(best[s2][ql][2], b0, b1, b2);
+        }
+        out[q] = (b0 + b1 + b2) / 3.0f;
+    }
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -76,7 +91,7 @@ int gps_knn_mean_dist2(int P, const float* points, float* mean_dist2, gps_stream
     GPS_REQUIRE(P >= 0);
     if (P == 0) return GPS_OK;
     GPS_REQUIRE(points && mean_dist2);
-    knn_kernel<<<gps_div_up(P, KNN_TILE), KNN_TILE, 0, (hipStream_t)stream>>>(P, points, mean_dist2);
+    knn_kernel<<<gps_div_up(P, KNN_Q), KNN_TILE, 0, (hipStream_t)stream>>>(P, points, mean_dist2);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
