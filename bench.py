@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host", choices=("cpp", "python"), default="cpp",
+                    help="which host layer drives the C-ABI: the C++/libtorch one (gps_slam_amd/host) or its Python mirror")
     args = ap.parse_args()
 
     from gps_slam_amd.dist_util import Group, env_ranks, scene_seed
@@ -94,9 +96,28 @@ def main():
     n_frames = K + Wm + 1
     seq, eng, model, pipe, cams, rgb_dev, depth_dev = build_scene(W, H, n_frames, args.gaussians, scene_seed(rank), device)
 
-    def run(lo, hi):
-        for i in range(lo, hi):
-            pipe.process_frame(i, cams[i], rgb_dev[i], depth_dev[i])
+    if args.host == "cpp":
+        # same scene, driven by the C++ host layer (what a C++ slam_trainer links against); the Python objects built
+        # above only supply the synthetic inputs and the initial Gaussians
+        import gps_slam_amd._host as H_
+        ceng = H_.ITMBasicEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0)
+        cmodel = H_.SLAMGaussianModel()
+        cmodel.loadConfig(dict(capacity=1 << 19, isect_capacity=8 << 20))
+        cmodel.getGaussianParms().add([t.clone() for t in model.opt_gs_params.tensors()])
+        cpipe = H_.SLAMPipeline(ceng, cmodel, scene_seed(rank))
+        ccams = []
+        for k in range(n_frames):
+            c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k].astype(np.float32)))
+            c.id, c.image, c.depth = k, cams[k].image, cams[k].depth
+            ccams.append(c)
+
+        def run(lo, hi):
+            for i in range(lo, hi):
+                cpipe.processFrame(i, ccams[i], rgb_dev[i], depth_dev[i])
+    else:
+        def run(lo, hi):
+            for i in range(lo, hi):
+                pipe.process_frame(i, cams[i], rgb_dev[i], depth_dev[i])
 
     run(0, Wm)  # untimed warm-up (includes the first allocation-heavy frames and one optimise block)
     torch.cuda.synchronize()
@@ -112,7 +133,24 @@ def main():
     out = None
     if rank == 0:
         from bench_kernels import dominant_kernel_roofline, cpu_baseline
-        N = model.getGaussianNum()
+        if args.host == "cpp":
+            # hand the C++ model's state to the Python mirror for the per-kernel measurement below (same C-ABI, same buffers
+            # layout); the timed region above never touched the Python model
+            N = cmodel.getGaussianNum()
+            cp = cmodel.getGaussianParms()
+            model.opt_gs_params.N = 0
+            model.add_params(dict(means=cp.getMeans(), scales=cp.getScales(), quats=cp.getQuats(),
+                                  featuresDc=cp.getFeaturesDc(), featuresRest=cp.getFeaturesRest(),
+                                  opacities=cp.getOpacities()))
+            oc, orc = cpipe.optCams(), cpipe.optRaycasts()
+            pcam = cams[oc[-1].id]
+            pcam.c2w_slam = oc[-1].c2w_slam.cpu()
+            pcam.invalidate()
+            pipe.opt_cam_list, pipe.opt_raycast_list = [pcam], [orc[-1]]
+            stats = dict(cpipe.stats())
+        else:
+            N = model.getGaussianNum()
+            stats = pipe.stats
         roof = dominant_kernel_roofline(model, pipe, eng, cams, device, HBM_PEAK_GBS)
         out = {
             "metric": "SLAM frames/sec @640x480, ~200k Gaussians; render PSNR vs ref",
@@ -123,7 +161,7 @@ def main():
                                    "(use_gt_pose=true as in every shipped config), ~%dk Gaussians; independent scene per GPU"
                                    % (W, H, N // 1000),
                        "gaussians": N, "local_opt_interval": 10, "local_opt_iters": 20,
-                       "frames_per_step": 1, "stats": pipe.stats},
+                       "frames_per_step": 1, "stats": stats, "host": args.host},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,149 @@
+// pybind11 view of the C++ host layer (module gps_slam_amd._host): lets the Python tests and bench.py drive exactly the
+// C++ classes a C++ slam_trainer would link against.
+#include <torch/extension.h>
+
+#include "slam_pipeline.hpp"
+
+namespace py = pybind11;
+
+static gpsh::Config config_from_dict(const py::dict& d) {
+    gpsh::Config c;
+    for (auto item : d) {
+        const std::string k = py::str(item.first);
+        if (py::isinstance<py::str>(item.second)) c.str[k] = py::str(item.second);
+        else c.num[k] = item.second.cast<double>();
+    }
+    return c;
+}
+
+PYBIND11_MODULE(_host, m) {
+    m.doc() = "C++ host layer of gps_slam_amd over the C-ABI (libgpsslam_hip.so)";
+
+    // ---- operator surface (gsplat_wapper.hpp)
+    m.def("SphericalHarmonicsNew", [](int deg, torch::Tensor dirs, torch::Tensor coeffs, torch::Tensor masks) {
+        return SphericalHarmonicsNew::apply(deg, dirs, coeffs, masks);
+    });
+    m.def("FullyFusedProjection", [](torch::Tensor means, torch::Tensor quats, torch::Tensor scales, torch::Tensor viewmats,
+                                    torch::Tensor Ks, int w, int h, float eps2d, float near_plane, float far_plane,
+                                    float radius_clip) {
+        return FullyFusedProjection::apply(means, c10::nullopt, quats, scales, viewmats, Ks, w, h, eps2d, near_plane,
+                                           far_plane, radius_clip, false, std::string("pinhole"));
+    });
+    m.def("RasterizeToPixelsGes_NewParallel",
+          [](torch::Tensor means2d, torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities, torch::Tensor radiis,
+             torch::Tensor ref_depth_map, torch::Tensor base_color_map, int w, int h, int tile_size,
+             torch::Tensor isect_offsets, torch::Tensor flatten_ids, torch::Tensor group_gs_ids, torch::Tensor group_starts,
+             float delta_depth) {
+              return RasterizeToPixelsGes_NewParallel::apply(means2d, conics, colors, opacities, radiis, ref_depth_map,
+                                                             base_color_map, c10::nullopt, c10::nullopt, w, h, tile_size,
+                                                             isect_offsets, flatten_ids, group_gs_ids, group_starts,
+                                                             false, delta_depth);
+          });
+    m.def("isectTilesNoDepth", &isectTilesNoDepth, py::arg("means2d"), py::arg("radii"), py::arg("depths"),
+          py::arg("tile_size"), py::arg("tile_width"), py::arg("tile_height"), py::arg("sort") = true);
+    m.def("isectOffsetEncodeNoDepth", &isectOffsetEncodeNoDepth);
+    m.def("distCUDA2", &distCUDA2);
+    m.def("simpleKNN", &simpleKNN);
+    m.def("degFromSh", &degFromSh);
+    m.def("numShBases", &numShBases);
+    m.def("rgb2sh", &rgb2sh);
+    m.def("sh2rgb", &sh2rgb);
+    m.def("poseInv", &poseInv);
+    m.def("computeNormalMap", &computeNormalMap);
+
+    // ---- Camera
+    py::class_<Camera>(m, "Camera")
+        .def(py::init<int, int, float, float, float, float, bool, const torch::Tensor&>())
+        .def_readwrite("id", &Camera::id)
+        .def_readwrite("width", &Camera::width)
+        .def_readwrite("height", &Camera::height)
+        .def_readwrite("image", &Camera::image)
+        .def_readwrite("depth", &Camera::depth)
+        .def_readwrite("c2w", &Camera::c2w)
+        .def_readwrite("c2w_slam", &Camera::c2w_slam)
+        .def("toGPU", [](Camera& c) { c.toGPU(); })
+        .def("invalidate", &Camera::invalidate)
+        .def("viewmat", &Camera::viewmat_tensor)
+        .def("K_dev", &Camera::K_tensor)
+        .def("cam_pos", &Camera::cam_pos_tensor);
+
+    // ---- model
+    py::class_<RawGaussianParams>(m, "RawGaussianParams")
+        .def("getGaussianNum", &RawGaussianParams::getGaussianNum)
+        .def("getMeans", &RawGaussianParams::getMeans)
+        .def("getScales", &RawGaussianParams::getScales)
+        .def("getQuats", &RawGaussianParams::getQuats)
+        .def("getFeaturesDc", &RawGaussianParams::getFeaturesDc)
+        .def("getFeaturesRest", &RawGaussianParams::getFeaturesRest)
+        .def("getOpacities", &RawGaussianParams::getOpacities)
+        .def("add", [](RawGaussianParams& p, std::vector<torch::Tensor> t) { p.add(t); })
+        .def("remove", &RawGaussianParams::remove)
+        .def_static("make", &RawGaussianParams::make);
+
+    py::class_<SLAMGaussianModel>(m, "SLAMGaussianModel")
+        .def(py::init<>())
+        .def("loadConfig", [](SLAMGaussianModel& s, const py::dict& d) { s.loadConfig(config_from_dict(d)); })
+        .def("forward", &SLAMGaussianModel::forward, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"))
+        .def("computeLoss", [](SLAMGaussianModel& s, TensorDict& r, const Camera& cam, const py::dict& w) {
+            return s.computeLoss(r, cam, config_from_dict(w));
+        })
+        .def("trainStep", [](SLAMGaussianModel& s, const Camera& cam, const torch::Tensor& ref_depth,
+                             const torch::Tensor& base_color, c10::optional<torch::Tensor> clamped) {
+            s.trainStep(cam, ref_depth, base_color, clamped.has_value() ? *clamped : torch::Tensor());
+        }, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"), py::arg("ref_depth_clamped") = py::none())
+        .def("lossSum", &SLAMGaussianModel::lossSum)
+        .def("initOptimizers", &SLAMGaussianModel::initOptimizers, py::arg("max_iterations") = -1,
+             py::arg("scene_scale") = 1.0f)
+        .def("optimizersStep", &SLAMGaussianModel::optimizersStep)
+        .def("optimizersZeroGrad", &SLAMGaussianModel::optimizersZeroGrad)
+        .def("prunePoints", &SLAMGaussianModel::prunePoints)
+        .def("grads", &SLAMGaussianModel::grads)
+        .def("getGaussianNum", &SLAMGaussianModel::getGaussianNum)
+        .def("getGaussianParms", &SLAMGaussianModel::getGaussianParms, py::return_value_policy::reference_internal)
+        .def("getRealScales", &SLAMGaussianModel::getRealScales)
+        .def("getRealOpacities", &SLAMGaussianModel::getRealOpacities)
+        .def("addGaussians", [](SLAMGaussianModel& s, const Camera& cam, const TensorDict& maps, const torch::Tensor& mask,
+                                float ratio, int frame_num) { return s.addGaussians(cam, maps, mask, ratio, frame_num); });
+
+    // ---- TSDF engine
+    py::class_<ITMBasicEngine>(m, "ITMBasicEngine")
+        .def(py::init([](int w, int h, float fx, float fy, float cx, float cy, float voxel_size, float mu, float vmin,
+                         float vmax) { return new ITMBasicEngine(w, h, fx, fy, cx, cy, voxel_size, mu, vmin, vmax); }),
+             py::arg("width"), py::arg("height"), py::arg("fx"), py::arg("fy"), py::arg("cx"), py::arg("cy"),
+             py::arg("voxel_size") = 0.005f, py::arg("mu") = 0.02f, py::arg("view_frustum_min") = 0.2f,
+             py::arg("view_frustum_max") = 10.0f)
+        .def("pushGtPose", [](ITMBasicEngine& e, const torch::Tensor& c2w) { e.gtC2wPoses.push_back(c2w); })
+        .def("ProcessFrame", [](ITMBasicEngine& e, const torch::Tensor& rgb, const torch::Tensor& depth) {
+            e.ProcessFrame(rgb, depth);
+        })
+        .def("runRaycastC2w", [](ITMBasicEngine& e, const torch::Tensor& c2w) {
+            ORUtils::SE3Pose pose;
+            auto c = c2w.to(torch::kCPU, torch::kFloat32).contiguous();
+            pose.SetInvM(c.data_ptr<float>());
+            e.runRaycast(&pose);
+        })
+        .def("GetFreeImage", [](ITMBasicEngine& e) { return e.GetFreeImage()->tensor(); })
+        .def("GetFreeVertex", [](ITMBasicEngine& e) { return e.GetFreeVertex()->tensor(); })
+        .def("GetLiveVertex", [](ITMBasicEngine& e) { return e.GetLiveVertex()->tensor(); })
+        .def("getVoxelSize", &ITMBasicEngine::getVoxelSize)
+        .def("counters", &ITMBasicEngine::counters)
+        .def_readonly("framesProcessed", &ITMBasicEngine::framesProcessed);
+
+    // ---- pipeline
+    py::class_<SLAMPipeline>(m, "SLAMPipeline")
+        .def(py::init<ITMBasicEngine*, SLAMGaussianModel*, uint64_t>(), py::arg("engine"), py::arg("model"),
+             py::arg("seed") = 1234, py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
+        .def("loadConfig", [](SLAMPipeline& p, const py::dict& d) { p.loadConfig(config_from_dict(d)); })
+        .def("processFrame", &SLAMPipeline::processFrame)
+        .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams)
+        .def("runRaycastByCam", &SLAMPipeline::runRaycastByCam, py::arg("cam"), py::arg("use_cam_depth") = true)
+        .def("stats", [](SLAMPipeline& p) {
+            py::dict d;
+            d["frames"] = p.stats.frames; d["opt_iters"] = p.stats.opt_iters; d["raycasts"] = p.stats.raycasts;
+            d["added"] = p.stats.added; d["pruned"] = p.stats.pruned;
+            return d;
+        })
+        .def("optCams", [](SLAMPipeline& p) { return p.opt_cam_list; })
+        .def("optRaycasts", [](SLAMPipeline& p) { return p.opt_raycast_list; })
+        .def_readwrite("work_mode", &SLAMPipeline::work_mode);
+}

@@ -1,0 +1,341 @@
+#include "raw_gs_model.hpp"
+
+using namespace gpsh;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+using torch::indexing::Slice;
+
+// Parameter order everywhere in this file = RawGaussianParams order:
+//   0 means, 1 scales(log), 2 quats, 3 featuresDc, 4 featuresRest, 5 opacities(logit)
+// gps_splat_step::lr order = means, log_scales, quats, sh_dc, sh_rest, opac_logit (the same).
+
+void RawGaussianModel::loadConfig(const Config& c) {
+    maxSH = (int)c.get("sh_degree", maxSH);
+    degreesToUse = maxSH;
+    shDegreeInterval = (int)c.get("sh_degree_interval", shDegreeInterval);
+    max_gs_radii = (int)c.get("max_gs_radii", max_gs_radii);
+    delta_depth = (float)c.get("delta_depth", delta_depth);
+    maxInitScale = (float)c.get("max_init_scale", maxInitScale);
+    minInitScale = (float)c.get("min_init_scale", minInitScale);
+    defaultOpacities = (float)c.get("default_opacities", defaultOpacities);
+    means_lr = c.get("means_lr", means_lr); scales_lr = c.get("scales_lr", scales_lr);
+    quats_lr = c.get("quats_lr", quats_lr); featuresDc_lr = c.get("featuresDc_lr", featuresDc_lr);
+    featuresRest_lr = c.get("featuresRest_lr", featuresRest_lr); opacities_lr = c.get("opacities_lr", opacities_lr);
+    isect_capacity = (int64_t)c.get("isect_capacity", (double)isect_capacity);
+    render_method = c.gets("render_method", render_method);
+    const int64_t cap = (int64_t)c.get("capacity", 1 << 19);
+    opt_gs_params.reserve(cap, numShBases(maxSH), device);
+}
+
+void RawGaussianModel::updateSH(int curr_iter) {
+    if (curr_iter >= 0 && shDegreeInterval > 0) degreesToUse = std::min<int>(maxSH, curr_iter / shDegreeInterval);
+    else degreesToUse = maxSH;
+}
+
+torch::Tensor RawGaussianModel::clampRefDepth(const torch::Tensor& ref_depth) {
+    return torch::where(ref_depth < 0.01, torch::full_like(ref_depth, 1000.0), ref_depth);
+}
+
+// ------------------------------------------------------------------------------------------------ launch descriptor
+gps_splat_step& RawGaussianModel::stepStruct(int W, int H) {
+    RawGaussianParams& p = opt_gs_params;
+    if (!p.buffer(0).defined()) p.reserve(1 << 19, numShBases(maxSH), device);
+    const int64_t cap = p.capacity();
+    if (step_cap_ != cap || step_w_ != W || step_h_ != H) {
+        const int tw = (W + tile_size - 1) / tile_size, th = (H + tile_size - 1) / tile_size;
+        const int64_t icap = isect_capacity > 0 ? isect_capacity : std::max<int64_t>(1 << 20, 16 * cap);
+        const int64_t gcap = 2 * icap;
+        const auto F = f32(device);
+        const auto I = i32(device);
+        B_.radii = torch::empty({cap}, I);
+        B_.means2d = torch::empty({cap, 2}, F); B_.depths = torch::empty({cap}, F);
+        B_.conics = torch::empty({cap, 3}, F); B_.colors = torch::empty({cap, 4}, F);
+        B_.opacities = torch::empty({cap}, F); B_.records = torch::empty({cap, 12}, F);
+        B_.tiles_per_gauss = torch::empty({cap}, I);
+        B_.flatten_ids = torch::empty({icap}, I);
+        B_.group_gs_ids = torch::empty({gcap}, I); B_.group_starts = torch::empty({gcap}, I);
+        B_.tile_offsets = torch::empty({th * tw}, I);
+        B_.counts = torch::zeros({4}, i64(device));
+        const int64_t ws = gps_isect_workspace_bytes((int)cap, icap);
+        B_.workspace = torch::empty({ws}, u8(device));
+        B_.render_colors = torch::empty({1, H, W, 4}, F); B_.weight_sum = torch::empty({1, H, W, 1}, F);
+        B_.rgb = torch::empty({H, W, 3}, F); B_.depth = torch::empty({H, W, 1}, F);
+        B_.loss = torch::zeros({1}, F);
+        B_.v_render_colors = torch::empty({1, H, W, 4}, F); B_.v_render_alphas = torch::empty({1, H, W, 1}, F);
+        B_.v_means2d = torch::empty({cap, 2}, F); B_.v_conics = torch::empty({cap, 3}, F);
+        B_.v_colors = torch::empty({cap, 4}, F); B_.v_opacities = torch::empty({cap}, F);
+        gps_splat_step& s = step_;
+        s = gps_splat_step{};
+        s.width = W; s.height = H;
+        s.radii = iptr(B_.radii); s.means2d = fptr(B_.means2d); s.depths = fptr(B_.depths);
+        s.conics = fptr(B_.conics); s.colors = fptr(B_.colors); s.opacities = fptr(B_.opacities);
+        s.records = fptr(B_.records);
+        s.isect_capacity = icap; s.group_capacity = gcap; s.workspace_bytes = ws;
+        s.tiles_per_gauss = iptr(B_.tiles_per_gauss); s.flatten_ids = iptr(B_.flatten_ids);
+        s.group_gs_ids = iptr(B_.group_gs_ids); s.group_starts = iptr(B_.group_starts);
+        s.tile_offsets = iptr(B_.tile_offsets); s.counts = ptr<int64_t>(B_.counts); s.workspace = B_.workspace.data_ptr();
+        s.render_colors = fptr(B_.render_colors); s.weight_sum = fptr(B_.weight_sum); s.rgb = fptr(B_.rgb);
+        s.loss = fptr(B_.loss); s.v_render_colors = fptr(B_.v_render_colors); s.v_render_alphas = fptr(B_.v_render_alphas);
+        s.v_means2d = fptr(B_.v_means2d); s.v_conics = fptr(B_.v_conics); s.v_colors = fptr(B_.v_colors);
+        s.v_opacities = fptr(B_.v_opacities);
+        s.beta1 = 0.9; s.beta2 = 0.999; s.adam_eps = 1e-15;
+        step_cap_ = cap; step_w_ = W; step_h_ = H;
+    }
+    gps_splat_step& s = step_;
+    s.N = p.getGaussianNum(); s.K = p.shK(); s.sh_degree = degreesToUse; s.max_gs_radii = max_gs_radii;
+    s.eps2d = eps2d; s.near_plane = near_plane; s.far_plane = far_plane; s.radius_clip = radius_clip;
+    s.delta_depth = delta_depth;
+    s.means = fptr(p.buffer(0)); s.log_scales = fptr(p.buffer(1)); s.quats = fptr(p.buffer(2));
+    s.sh_dc = fptr(p.buffer(3)); s.sh_rest = fptr(p.buffer(4)); s.opac_logit = fptr(p.buffer(5));
+    if (have_opt_ && adam_cap_ == cap) {
+        float** g[6] = {&s.g_means, &s.g_log_scales, &s.g_quats, &s.g_sh_dc, &s.g_sh_rest, &s.g_opac_logit};
+        float** m[6] = {&s.m_means, &s.m_log_scales, &s.m_quats, &s.m_sh_dc, &s.m_sh_rest, &s.m_opac_logit};
+        float** v[6] = {&s.v_means, &s.v_log_scales, &s.v_quats, &s.v_sh_dc, &s.v_sh_rest, &s.v_opac_logit};
+        for (int k = 0; k < 6; k++) {
+            *g[k] = fptr(adam_g_[k]); *m[k] = fptr(adam_m_[k]); *v[k] = fptr(adam_v_[k]);
+            s.lr[k] = lrs_[k];
+        }
+    }
+    return s;
+}
+
+void RawGaussianModel::bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
+                                  const torch::Tensor& base_color, const torch::Tensor& gt_rgb) {
+    TORCH_CHECK(cam.on_device(), "Camera::toGPU() must run before the camera is rendered (slam_pipeline.cpp:84)");
+    check_f32_dev(ref_depth_clamped, "ref_depth");
+    check_f32_dev(base_color, "base_color");
+    st.viewmat = cam.viewmat(); st.Kmat = cam.Kmat(); st.cam_pos = cam.cam_pos();
+    st.ref_depth_clamped = fptr(ref_depth_clamped);
+    st.base_color = fptr(base_color);
+    st.gt_rgb = gt_rgb.defined() ? fptr(gt_rgb) : nullptr;
+    keep_ = {ref_depth_clamped, base_color, gt_rgb};
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+namespace {
+
+// grad-mode gesForward: inputs = the six parameter leaves; outputs = rgb, depth, alpha (views of model buffers).
+// backward: d(rgb, depth, alpha) -> d(render_colors, weight_sum) with a few elementwise ops, then the fused chain
+// raster bwd -> preprocess bwd through the C-ABI.
+struct GesRenderFunction : public torch::autograd::Function<GesRenderFunction> {
+    static tensor_list forward(AutogradContext* ctx, torch::Tensor means, torch::Tensor scales, torch::Tensor quats,
+                               torch::Tensor dc, torch::Tensor rest, torch::Tensor opac, int64_t model_ptr,
+                               int64_t cam_ptr, torch::Tensor ref_depth, torch::Tensor ref_clamped,
+                               torch::Tensor base_color) {
+        auto* model = reinterpret_cast<RawGaussianModel*>(model_ptr);
+        const auto* cam = reinterpret_cast<const Camera*>(cam_ptr);
+        gps_splat_step& st = model->stepStruct(cam->width, cam->height);
+        model->bindCamera(st, *cam, ref_clamped, base_color, torch::Tensor());
+        check(gps_splat_render(&st, current_stream()), "gps_splat_render");
+        auto& B = model->buffers();
+        check(gps_compose_l1(cam->width, cam->height, fptr(B.render_colors), fptr(B.weight_sum), fptr(base_color),
+                             fptr(ref_depth), nullptr, fptr(B.rgb), fptr(B.depth), nullptr, nullptr, nullptr,
+                             current_stream()), "gps_compose_l1");
+        ctx->saved_data["model"] = model_ptr;
+        ctx->saved_data["cam"] = cam_ptr;
+        ctx->save_for_backward({ref_depth, ref_clamped, base_color});
+        (void)means; (void)scales; (void)quats; (void)dc; (void)rest; (void)opac;
+        // fresh tensors: autograd owns its outputs, the model buffers are reused by the next launch
+        return {B.rgb.clone(), B.depth.clone(), B.weight_sum.index({0}).clone()};
+    }
+
+    static tensor_list backward(AutogradContext* ctx, tensor_list g) {
+        auto* model = reinterpret_cast<RawGaussianModel*>(ctx->saved_data["model"].toInt());
+        const auto* cam = reinterpret_cast<const Camera*>(ctx->saved_data["cam"].toInt());
+        auto saved = ctx->get_saved_variables();
+        const torch::Tensor &ref_depth = saved[0], &ref_clamped = saved[1], &base_color = saved[2];
+        auto& B = model->buffers();
+        gps_splat_step& st = model->stepStruct(cam->width, cam->height);
+        const int H = cam->height, W = cam->width;
+        // compose: rgb = (raw_rgb + base)/(Ws + 1); depth = (raw_d + ref*b)/(Ws + b), b = [ref > 0]; alpha = Ws
+        auto Ws = B.weight_sum.index({0});                                   // [H,W,1]
+        auto v_rc = torch::zeros({1, H, W, 4}, Ws.options());
+        auto v_ra = torch::zeros({H, W, 1}, Ws.options());
+        if (g[0].defined()) {
+            auto inv = 1.0 / (Ws + 1.0);
+            v_rc.index_put_({0, Slice(), Slice(), Slice(0, 3)}, g[0] * inv);
+            v_ra -= (g[0] * B.rgb).sum(-1, true) * inv;
+        }
+        if (g[1].defined()) {
+            auto b = (ref_depth > 0).to(torch::kFloat32);
+            auto inv = 1.0 / (Ws + b);
+            inv = torch::where(torch::isfinite(inv), inv, torch::zeros_like(inv));  // Ws = 0, no reference depth
+            v_rc.index_put_({0, Slice(), Slice(), Slice(3, 4)}, g[1] * inv);
+            v_ra -= g[1] * B.depth * inv;
+        }
+        if (g[2].defined()) v_ra += g[2];
+        v_ra = v_ra.unsqueeze(0).contiguous();
+        model->bindCamera(st, *cam, ref_clamped, base_color, torch::Tensor());
+        check(gps_raster_ges_bwd_gs(st.N, st.means2d, st.conics, st.colors, st.opacities, st.radii, st.ref_depth_clamped,
+                                    W, H, st.group_gs_ids, st.group_starts, st.counts, st.delta_depth, fptr(v_rc),
+                                    fptr(v_ra), st.v_means2d, st.v_conics, st.v_colors, st.v_opacities, 0,
+                                    current_stream()), "gps_raster_ges_bwd_gs");
+        RawGaussianParams& p = model->getGaussianParms();
+        tensor_list grads(11);
+        for (int k = 0; k < 6; k++) grads[k] = torch::empty_like(p.buffer(k).slice(0, 0, st.N));
+        check(gps_gauss_preprocess_bwd(st.N, st.K, st.sh_degree, st.means, st.log_scales, st.quats, st.opac_logit,
+                                       st.sh_dc, st.sh_rest, st.viewmat, st.Kmat, st.cam_pos, W, H, st.eps2d, st.radii,
+                                       st.conics, st.v_means2d, st.v_conics, st.v_colors, st.v_opacities,
+                                       fptr(grads[0]), fptr(grads[1]), fptr(grads[2]), fptr(grads[5]), fptr(grads[3]),
+                                       fptr(grads[4]), current_stream()), "gps_gauss_preprocess_bwd");
+        return grads;
+    }
+};
+
+}  // namespace
+
+TensorDict RawGaussianModel::forward(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color) {
+    TORCH_CHECK(render_method == "ges", "UNSUPPORTED RENDER METHOD: ", render_method,
+                " (the `raw` rasterizer is outside the hot path, SURVEY 8(f) rank 2)");
+    return gesForward(cam, ref_depth, base_color);
+}
+
+TensorDict RawGaussianModel::gesForward(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color) {
+    check_f32_dev(ref_depth, "ref_depth");
+    check_f32_dev(base_color, "base_color");
+    auto ref_clamped = clampRefDepth(ref_depth);
+    const int N = getGaussianNum();
+    TensorDict res;
+    if (torch::GradMode::is_enabled() && !leaf_.empty()) {
+        auto out = GesRenderFunction::apply(leaf_[0], leaf_[1], leaf_[2], leaf_[3], leaf_[4], leaf_[5],
+                                            (int64_t)reinterpret_cast<intptr_t>(this),
+                                            (int64_t)reinterpret_cast<intptr_t>(&cam), ref_depth, ref_clamped, base_color);
+        res["rgb"] = out[0]; res["depth"] = out[1]; res["alpha"] = out[2];
+    } else {
+        gps_splat_step& st = stepStruct(cam.width, cam.height);
+        bindCamera(st, cam, ref_clamped, base_color, torch::Tensor());
+        check(gps_splat_render(&st, current_stream()), "gps_splat_render");
+        check(gps_compose_l1(cam.width, cam.height, fptr(B_.render_colors), fptr(B_.weight_sum), fptr(base_color),
+                             fptr(ref_depth), nullptr, fptr(B_.rgb), fptr(B_.depth), nullptr, nullptr, nullptr,
+                             current_stream()), "gps_compose_l1");
+        res["rgb"] = B_.rgb; res["depth"] = B_.depth; res["alpha"] = B_.weight_sum.index({0});
+    }
+    res["radiis"] = B_.radii.slice(0, 0, N);
+    res["means2d"] = B_.means2d.slice(0, 0, N);
+    return res;
+}
+
+TensorDict RawGaussianModel::computeLoss(TensorDict& render_res, const Camera& cam, const Config& w, const torch::Tensor& mask) {
+    TORCH_CHECK(w.get("ssim_weight", 0.0) == 0.0 && w.get("depth_weight", 0.0) == 0.0,
+                "only the L1 term is on the hot path (every shipped config sets ssim / depth weights to 0)");
+    TORCH_CHECK(!mask.defined(), "loss masks are not used by the SLAM loop");
+    TensorDict out;
+    auto l1 = torch::mean(torch::abs(cam.image - render_res.at("rgb")));  // tensor_math.cpp:41-44
+    out["l1_loss"] = l1;
+    out["loss"] = l1 * w.get("l1_weight", 1.0);
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ optimisation
+void RawGaussianModel::setParamsRequireGrad() {
+    leaf_.clear();
+    for (int k = 0; k < RawGaussianParams::NUM; k++) {
+        auto v = opt_gs_params.buffer(k).slice(0, 0, getGaussianNum()).detach();
+        v.set_requires_grad(true);
+        leaf_.push_back(v);
+    }
+}
+
+void RawGaussianModel::initOptimizers(int max_iterations, float scene_scale) {
+    (void)max_iterations;
+    RawGaussianParams& p = opt_gs_params;
+    const int64_t cap = p.capacity();
+    if (!have_opt_ || adam_cap_ != cap) {
+        adam_m_.clear(); adam_v_.clear(); adam_g_.clear();
+        for (int k = 0; k < 6; k++) {
+            adam_m_.push_back(torch::zeros_like(p.buffer(k)));
+            adam_v_.push_back(torch::zeros_like(p.buffer(k)));
+            adam_g_.push_back(torch::zeros_like(p.buffer(k)));
+        }
+        adam_cap_ = cap;
+    } else {
+        const int64_t N = getGaussianNum();
+        for (int k = 0; k < 6; k++) { adam_m_[k].slice(0, 0, N).zero_(); adam_v_[k].slice(0, 0, N).zero_(); }
+    }
+    lrs_[0] = means_lr * scene_scale; lrs_[1] = scales_lr; lrs_[2] = quats_lr; lrs_[3] = featuresDc_lr;
+    lrs_[4] = featuresRest_lr; lrs_[5] = opacities_lr;
+    adam_step_ = 0;
+    have_opt_ = true;
+    setParamsRequireGrad();
+}
+
+void RawGaussianModel::optimizersZeroGrad() {
+    for (auto& t : leaf_) t.mutable_grad() = torch::Tensor();
+}
+
+void RawGaussianModel::optimizersStep() {
+    // the autograd route: gradients sit in the leaves' .grad(); one fused multi-tensor Adam launch
+    TORCH_CHECK(have_opt_, "initOptimizers() first");
+    gps_adam_segment seg[6];
+    const int64_t N = getGaussianNum();
+    std::vector<torch::Tensor> hold;
+    for (int k = 0; k < 6; k++) {
+        TORCH_CHECK(leaf_[k].grad().defined(), "optimizersStep: parameter ", k, " has no gradient");
+        auto g = leaf_[k].grad().contiguous();
+        hold.push_back(g);
+        seg[k].param = fptr(opt_gs_params.buffer(k)); seg[k].grad = fptr(g);
+        seg[k].exp_avg = fptr(adam_m_[k]); seg[k].exp_avg_sq = fptr(adam_v_[k]);
+        seg[k].numel = N * (opt_gs_params.buffer(k).numel() / opt_gs_params.capacity());
+        seg[k].lr = lrs_[k];
+    }
+    adam_step_ += 1;
+    check(gps_adam_step(seg, 6, 0.9, 0.999, 1e-15, adam_step_, current_stream()), "gps_adam_step");
+}
+
+void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color,
+                                 const torch::Tensor& ref_depth_clamped) {
+    TORCH_CHECK(have_opt_ && adam_cap_ == opt_gs_params.capacity(), "initOptimizers() first");
+    TORCH_CHECK(cam.image.defined() && cam.image.is_cuda(), "camera image must be on the device");
+    auto clamped = ref_depth_clamped.defined() ? ref_depth_clamped : clampRefDepth(ref_depth);
+    gps_splat_step& st = stepStruct(cam.width, cam.height);
+    bindCamera(st, cam, clamped, base_color, cam.image);
+    adam_step_ += 1;
+    check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");
+}
+
+std::vector<torch::Tensor> RawGaussianModel::grads() {
+    std::vector<torch::Tensor> out;
+    for (int k = 0; k < 6; k++) out.push_back(adam_g_[k].slice(0, 0, getGaussianNum()));
+    return out;
+}
+
+void RawGaussianModel::prunePoints(const torch::Tensor& deleteMask) {
+    RawGaussianParams& p = opt_gs_params;
+    const int64_t N = p.getGaussianNum();
+    p.remove(deleteMask);
+    auto keep = p.keep_index();
+    const int64_t m = keep.size(0);
+    if (have_opt_ && adam_cap_ == p.capacity()) {
+        for (int k = 0; k < 6; k++) {
+            for (auto* vec : {&adam_m_, &adam_v_}) {
+                auto& t = (*vec)[k];
+                auto tmp = p.alt_[k].slice(0, 0, m);  // the alternate parameter buffer is free scratch right now
+                torch::index_select_out(tmp, t.slice(0, 0, N), 0, keep);
+                t.slice(0, 0, m).copy_(tmp);
+            }
+        }
+    }
+    if (!leaf_.empty()) setParamsRequireGrad();
+}
+
+// ------------------------------------------------------------------------------------------------ addGaussians
+int SLAMGaussianModel::addGaussians(const Camera& cam, const TensorDict& frame_maps, const torch::Tensor& sample_mask,
+                                    float new_gs_sample_ratio, int frame_num, c10::optional<at::Generator> gen) {
+    (void)frame_num;
+    const int64_t H = cam.image.size(0), W = cam.image.size(1);
+    auto m = sample_mask.expand({H, W, 3});
+    auto verts = torch::masked_select(frame_maps.at("vertex_map"), m).reshape({-1, 3});
+    auto cols = torch::masked_select(cam.image, m).reshape({-1, 3});
+    auto norms = torch::masked_select(frame_maps.at("normal_map"), m).reshape({-1, 3});
+    const int64_t n = verts.size(0);
+    const int64_t num_select = (int64_t)(n * new_gs_sample_ratio);
+    if (num_select <= 0) return 0;
+    // uniformly random subset (the reference: torch::randperm(n)[:num_select]); drawn on the host, n is known here
+    auto perm = torch::randperm(n, gen, torch::TensorOptions().dtype(torch::kInt64)).slice(0, 0, num_select).to(verts.device());
+    auto t = RawGaussianParams::make(verts.index_select(0, perm).contiguous(), cols.index_select(0, perm),
+                                     norms.index_select(0, perm), maxSH, defaultOpacities, maxInitScale, minInitScale);
+    if (!opt_gs_params.buffer(0).defined()) opt_gs_params.reserve(1 << 19, numShBases(maxSH), verts.device());
+    opt_gs_params.add(t);
+    if (!leaf_.empty()) setParamsRequireGrad();
+    return (int)num_select;
+}

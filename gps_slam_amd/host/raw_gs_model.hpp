@@ -1,0 +1,103 @@
+// RawGaussianModel (include/raw_gs_model.h:16-258, src/raw_gs_model.cpp) and SLAMGaussianModel::addGaussians
+// (slam/slam_gs_model.cpp:5-56) on the C-ABI.
+//
+// Two routes through one optimise iteration, same kernels underneath:
+//   * the reference's call sequence  forward() -> computeLoss() -> loss.backward() -> optimizersStep() ->
+//     optimizersZeroGrad()  works unchanged: in grad mode gesForward returns tensors whose grad_fn runs the fused
+//     backward chain (raster bwd -> preprocess bwd) and leaves the gradients in the parameters' .grad();
+//   * trainStep() is the same iteration as ONE C-ABI call (gps_splat_train_step: 10 launch sites, no host sync, no
+//     autograd graph) -- what SLAMPipeline::localOptimize uses.
+#pragma once
+#include "raw_gs_param.hpp"
+
+class RawGaussianModel {
+public:
+    RawGaussianModel() = default;
+    ~RawGaussianModel() = default;
+
+    void loadConfig(const gpsh::Config& config);  // MODEL section keys of configs/release/*/*.yaml
+    void updateSH(int curr_iter = -1);            // raw_gs_model.h:30-36
+
+    // raw_gs_model.h:38-50.  -> {"rgb"[H,W,3], "depth"[H,W,1], "alpha"[H,W,1], "radiis"[N], "means2d"[N,2]}
+    TensorDict forward(const Camera& cam, const torch::Tensor& ref_depth = torch::Tensor(),
+                       const torch::Tensor& base_color = torch::Tensor());
+    TensorDict gesForward(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color);
+    // raw_gs_model.cpp:369-417 with the weights every shipped config uses (L1 only; ssim / depth weights 0):
+    // -> {"loss", "l1_loss"}
+    TensorDict computeLoss(TensorDict& render_res, const Camera& cam, const gpsh::Config& weight_configs,
+                           const torch::Tensor& mask = torch::Tensor());
+
+    // One optimise iteration as a single C-ABI call; the L1 loss accumulates in lossSum().
+    void trainStep(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color,
+                   const torch::Tensor& ref_depth_clamped = torch::Tensor());
+    torch::Tensor lossSum() const { return B_.loss; }
+
+    void initOptimizers(int max_iterations = -1, float scene_scale = 1);  // raw_gs_model.cpp:654-675
+    void optimizersZeroGrad();
+    void optimizersStep();
+    void prunePoints(const torch::Tensor& deleteMask);  // raw_gs_model.cpp:635-644 (+ removeFromOptimizer)
+    void setParamsRequireGrad();
+
+    RawGaussianParams& getGaussianParms() { return opt_gs_params; }
+    int getMaxSH() const { return maxSH; }
+    torch::Tensor getMeans() { return opt_gs_params.getMeans(); }
+    torch::Tensor getScales() { return opt_gs_params.getScales(); }
+    torch::Tensor getQuats() { return opt_gs_params.getQuats(); }
+    torch::Tensor getFeaturesDc() { return opt_gs_params.getFeaturesDc(); }
+    torch::Tensor getFeaturesRest() { return opt_gs_params.getFeaturesRest(); }
+    torch::Tensor getOpacities() { return opt_gs_params.getOpacities(); }
+    torch::Tensor getRealMeans() { return opt_gs_params.getRealMeans(); }
+    torch::Tensor getRealScales() { return opt_gs_params.getRealScales(); }
+    torch::Tensor getRealOpacities() { return opt_gs_params.getRealOpacities(); }
+    int getGaussianNum() { return opt_gs_params.getGaussianNum(); }
+    std::string getRenderMethod() const { return render_method; }
+    std::vector<torch::Tensor> grads();  // gradients of the last iteration, reference parameter order
+
+    static torch::Tensor clampRefDepth(const torch::Tensor& ref_depth);  // raw_gs_model.cpp:205-207
+
+    RawGaussianParams opt_gs_params;
+    torch::Device device = torch::kCUDA;
+
+    // raw_gs_model.h:283-288 + MODEL section defaults (configs/release/replica/office0.yaml)
+    int maxSH = 3, degreesToUse = 3, shDegreeInterval = 0;
+    int max_gs_radii = 100, tile_size = 16;
+    float eps2d = 0.3f, near_plane = 0.01f, far_plane = 1e10f, radius_clip = 0.0f, delta_depth = 0.1f;
+    float maxInitScale = 0.01f, minInitScale = -1.0f, defaultOpacities = 0.5f;
+    double means_lr = 1.6e-4, scales_lr = 5e-3, quats_lr = 1e-3, featuresDc_lr = 2.5e-3, featuresRest_lr = 5e-4,
+           opacities_lr = 5e-2;
+    int64_t isect_capacity = 0;  // 0 -> max(1M, 16 * capacity)
+    std::string render_method = "ges";
+
+    // implementation detail, public for the autograd node
+    struct Buffers {
+        torch::Tensor radii, means2d, depths, conics, colors, opacities, records, tiles_per_gauss, flatten_ids,
+            group_gs_ids, group_starts, tile_offsets, counts, workspace, render_colors, weight_sum, rgb, depth, loss,
+            v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors, v_opacities;
+    };
+    gps_splat_step& stepStruct(int W, int H);
+    void bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
+                    const torch::Tensor& base_color, const torch::Tensor& gt_rgb);
+    Buffers& buffers() { return B_; }
+
+protected:
+    Buffers B_;
+    gps_splat_step step_{};
+    int64_t step_cap_ = -1;
+    int step_w_ = 0, step_h_ = 0;
+    // Adam state: capacity-sized exp_avg / exp_avg_sq / grad buffers in reference parameter order + step count
+    std::vector<torch::Tensor> adam_m_, adam_v_, adam_g_;
+    double lrs_[RawGaussianParams::NUM] = {0, 0, 0, 0, 0, 0};
+    int64_t adam_cap_ = -1;
+    int adam_step_ = 0;
+    bool have_opt_ = false;
+    std::vector<torch::Tensor> leaf_;  // parameter leaves handed to autograd by the last grad-mode forward
+    std::vector<torch::Tensor> keep_;  // inputs of the last launch, kept alive until the next one
+};
+
+class SLAMGaussianModel : public RawGaussianModel {
+public:
+    // slam_gs_model.cpp:5-56: sample new Gaussians where sample_mask is set.  frame_maps: "vertex_map", "normal_map".
+    // Returns the number of Gaussians added.  `seed_gen` drives the random subset (host generator: n is host-known).
+    int addGaussians(const Camera& cam, const TensorDict& frame_maps, const torch::Tensor& sample_mask,
+                     float new_gs_sample_ratio, int frame_num, c10::optional<at::Generator> seed_gen = c10::nullopt);
+};

@@ -1,0 +1,134 @@
+#include "raw_gs_param.hpp"
+
+using namespace gpsh;
+using torch::indexing::Slice;
+
+// ------------------------------------------------------------------------------------------------ Camera
+Camera::Camera(int width, int height, float fx, float fy, float cx, float cy, bool has_depth, const torch::Tensor& c2w)
+    : width(width), height(height), fx(fx), fy(fy), cx(cx), cy(cy), has_depth(has_depth), c2w(c2w) {
+    c2w_slam = c2w;
+    K = torch::tensor({{fx, 0.0f, cx}, {0.0f, fy, cy}, {0.0f, 0.0f, 1.0f}}, torch::kFloat32);
+}
+
+torch::Tensor poseInv(const torch::Tensor& c2w) {
+    auto R = c2w.index({Slice(0, 3), Slice(0, 3)});
+    auto T = c2w.index({Slice(0, 3), Slice(3, 4)});
+    auto Rinv = R.transpose(0, 1);
+    auto out = torch::eye(4, c2w.options());
+    out.index_put_({Slice(0, 3), Slice(0, 3)}, Rinv);
+    out.index_put_({Slice(0, 3), Slice(3, 4)}, torch::matmul(-Rinv, T));
+    return out;
+}
+
+void Camera::toGPU(const torch::Device& device) {
+    if (!pack_.defined()) {
+        auto c = c2w_slam.to(torch::kCPU, torch::kFloat32).contiguous();
+        auto host = torch::empty({28}, torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
+        float* h = host.data_ptr<float>();
+        const float* m = c.data_ptr<float>();
+        // viewmat = [R^T | -R^T t] row-major
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) h[4 * r + k] = m[4 * k + r];
+            h[4 * r + 3] = -(m[0 * 4 + r] * m[3] + m[1 * 4 + r] * m[7] + m[2 * 4 + r] * m[11]);
+        }
+        h[12] = h[13] = h[14] = 0.f; h[15] = 1.f;
+        auto Kc = K.to(torch::kCPU, torch::kFloat32).contiguous();
+        for (int k = 0; k < 9; k++) h[16 + k] = Kc.data_ptr<float>()[k];
+        h[25] = m[3]; h[26] = m[7]; h[27] = m[11];
+        pack_ = host.to(device, /*non_blocking=*/true);
+    }
+    if (image.defined() && !image.is_cuda()) image = image.to(device);
+    if (depth.defined() && !depth.is_cuda()) depth = depth.to(device);
+}
+
+// ------------------------------------------------------------------------------------------------ params
+namespace {
+
+// tensor_math.cpp:184-201 computeQuat + quaternionFromAxisAngle
+torch::Tensor compute_quat(const torch::Tensor& init_vec, const torch::Tensor& target_vec) {
+    auto axis = torch::cross(init_vec, target_vec, 1);
+    axis = axis / (torch::norm(axis, 2, {-1}, true) + 1e-8);
+    auto angle = torch::acos(torch::sum(init_vec * target_vec, 1)).unsqueeze(-1);
+    auto naxis = axis / (torch::norm(axis, 2, {-1}, true) + 1e-8);
+    auto half = angle / 2;
+    return torch::cat({torch::cos(half), naxis * torch::sin(half)}, 1);
+}
+
+const int64_t TAIL[RawGaussianParams::NUM][2] = {{3, 0}, {3, 0}, {4, 0}, {3, 0}, {15, 3}, {1, 0}};
+
+}  // namespace
+
+std::vector<torch::Tensor> RawGaussianParams::make(const torch::Tensor& xyz, const torch::Tensor& rgb,
+                                                   const torch::Tensor& normals, int max_sh_degree, float init_opacs,
+                                                   float max_scale, float min_scale) {
+    const int64_t P = xyz.size(0);
+    const auto opt = xyz.options();
+    auto raw_scales = torch::sqrt(distCUDA2(xyz));
+    raw_scales = torch::clamp(raw_scales, min_scale, max_scale).unsqueeze(1).repeat({1, 3});
+    auto quats = torch::ones({P, 4}, opt);
+    if (normals.defined()) {
+        raw_scales.index_put_({Slice(), 2}, raw_scales.index({Slice(), 2}) * 0.1);
+        auto z_axis = torch::zeros_like(raw_scales);
+        z_axis.index_put_({Slice(), 2}, 1.0);
+        quats = compute_quat(z_axis, normals);
+    }
+    const int K = numShBases(max_sh_degree);
+    auto shs = torch::zeros({P, K, 3}, opt);
+    shs.index_put_({Slice(), 0, Slice(0, 3)}, rgb2sh(rgb));
+    auto opac = torch::logit(init_opacs * torch::ones({P, 1}, opt));
+    return {xyz, raw_scales.log(), quats, shs.index({Slice(), 0, Slice()}).contiguous(),
+            shs.index({Slice(), Slice(1, K), Slice()}).contiguous(), opac};
+}
+
+void RawGaussianParams::reserve(int64_t capacity, int sh_k, const torch::Device& device) {
+    if (capacity <= cap_ && sh_k == K_ && buf_[0].defined()) return;
+    device_ = device;
+    const int old_k = K_;
+    K_ = sh_k;
+    for (int k = 0; k < NUM; k++) {
+        std::vector<int64_t> shape = {capacity};
+        if (k == 4) { shape.push_back(K_ - 1); shape.push_back(3); }
+        else shape.push_back(TAIL[k][0]);
+        auto nb = torch::empty(shape, f32(device));
+        if (N_ > 0 && buf_[k].defined() && old_k == K_) nb.slice(0, 0, N_).copy_(buf_[k].slice(0, 0, N_));
+        buf_[k] = nb;
+        alt_[k] = torch::empty_like(nb);
+    }
+    if (old_k != K_) N_ = 0;
+    cap_ = capacity;
+}
+
+void RawGaussianParams::init(const torch::Tensor& xyz, const torch::Tensor& rgb, const torch::Tensor& normals,
+                             int max_sh_degree, float init_opacs, float max_scale, float min_scale, int exposure_num) {
+    auto t = make(xyz, rgb, normals, max_sh_degree, init_opacs, max_scale, min_scale);
+    reserve(std::max<int64_t>(cap_, std::max<int64_t>(1 << 19, 2 * xyz.size(0))), numShBases(max_sh_degree), xyz.device());
+    N_ = 0;
+    add(t);
+    exposure = torch::eye(3, 4, xyz.options()).unsqueeze(0).repeat({exposure_num, 1, 1});  // raw_gs_param.cpp:70-73
+}
+
+void RawGaussianParams::add(const std::vector<torch::Tensor>& t) {
+    TORCH_CHECK((int)t.size() == NUM, "expected ", NUM, " tensors");
+    const int64_t n = t[0].size(0);
+    if (!buf_[0].defined() || N_ + n > cap_)
+        reserve(std::max<int64_t>(2 * cap_, std::max<int64_t>(1 << 19, N_ + n)), K_, t[0].device());
+    for (int k = 0; k < NUM; k++) buf_[k].slice(0, N_, N_ + n).copy_(t[k]);
+    N_ += n;
+}
+
+void RawGaussianParams::add(const RawGaussianParams& other) {
+    std::vector<torch::Tensor> t;
+    for (int k = 0; k < NUM; k++) t.push_back(other.view(k));
+    add(t);
+}
+
+void RawGaussianParams::remove(const torch::Tensor& mask) {
+    keep_idx_ = torch::nonzero(~mask).squeeze(1);
+    const int64_t m = keep_idx_.size(0);
+    for (int k = 0; k < NUM; k++) {
+        auto dst = alt_[k].slice(0, 0, m);
+        torch::index_select_out(dst, buf_[k].slice(0, 0, N_), 0, keep_idx_);
+        std::swap(buf_[k], alt_[k]);
+    }
+    N_ = m;
+}

@@ -1,0 +1,198 @@
+#include "slam_pipeline.hpp"
+
+#include <cmath>
+
+using namespace gpsh;
+using torch::indexing::Slice;
+
+torch::Tensor computeNormalMap(const torch::Tensor& vertex_map_in) {
+    auto vertex_map = vertex_map_in.contiguous();
+    check_f32_dev(vertex_map, "vertex_map");
+    const int H = (int)vertex_map.size(0), W = (int)vertex_map.size(1);
+    auto out = torch::empty_like(vertex_map);
+    check(gps_normal_map(W, H, fptr(vertex_map), fptr(out), current_stream()), "gps_normal_map");
+    return out;
+}
+
+SLAMPipeline::SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model_, uint64_t seed)
+    : main_engine(tsdf_engine), model(model_), rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {
+    device = model->device;
+    voxel_size = main_engine->getVoxelSize();
+}
+
+void SLAMPipeline::loadConfig(const Config& c) {
+    new_gs_sample_ratio = (float)c.get("new_gs_sample_ratio", new_gs_sample_ratio);
+    color_error_thres = (float)c.get("color_error_thres", color_error_thres);
+    localframe_cam_window_length = (int)c.get("localframe_cam_window_length", localframe_cam_window_length);
+    localframe_cam_window_interval = (int)c.get("localframe_cam_window_interval", localframe_cam_window_interval);
+    local_opt_iters = (int)c.get("local_opt_iters", local_opt_iters);
+    local_opt_interval = (int)c.get("local_opt_interval", local_opt_interval);
+    keyframe_theta_thres = (float)c.get("keyframe_theta_thres", keyframe_theta_thres);
+    keyframe_trans_thres = (float)c.get("keyframe_trans_thres", keyframe_trans_thres);
+    keyframe_select_max = (int)c.get("keyframe_select_max", keyframe_select_max);
+    depth_vis_max = (float)c.get("depth_vis_max", depth_vis_max);
+    depth_vis_min = (float)c.get("depth_vis_min", depth_vis_min);
+    alpha_vis_max = (float)c.get("alpha_vis_max", alpha_vis_max);
+    large_scale_thres = (float)c.get("large_scale_thres", large_scale_thres);
+    small_scale_thres = (float)c.get("small_scale_thres", small_scale_thres);
+    low_opac_thres = (float)c.get("low_opac_thres", low_opac_thres);
+    scene_scale = (float)c.get("scene_scale", scene_scale);
+    work_mode = c.gets("work_mode", work_mode);
+}
+
+// ------------------------------------------------------------------ raycast -> tensors (runRaycastByCam :362-415)
+TensorDict SLAMPipeline::runRaycastByCam(const Camera& cam, bool use_cam_depth) {
+    (void)use_cam_depth;
+    ITMBasicEngine* eng = main_engine;
+    ORUtils::SE3Pose pose;
+    if (cam.id >= 0 && cam.id < (int)eng->camPoses.size()) {
+        pose = eng->camPoses[cam.id];
+    } else {
+        auto c = cam.c2w.to(torch::kCPU, torch::kFloat32).contiguous();
+        pose.SetInvM(c.data_ptr<float>());
+        pose.Coerce();
+    }
+    eng->runRaycast(&pose);
+    const int H = cam.height, W = cam.width;
+    const auto F = f32(device);
+    TensorDict m;
+    m["color_map"] = torch::empty({H, W, 3}, F);
+    m["vertex_map"] = torch::empty({H, W, 3}, F);
+    m["confidence_map"] = torch::empty({H, W, 1}, F);
+    m["depth_map"] = torch::empty({H, W, 1}, F);
+    m["depth_map_clamped"] = torch::empty({H, W, 1}, F);
+    auto w2c = poseInv(cam.c2w.to(torch::kCPU, torch::kFloat32)).contiguous();  // poseInv(cam.c2w): dataset pose (:398)
+    check(gps_raycast_to_maps(W, H, reinterpret_cast<const float*>(eng->GetFreeVertex()->GetData(MEMORYDEVICE_CUDA)),
+                              reinterpret_cast<const uint8_t*>(eng->GetFreeImage()->GetData(MEMORYDEVICE_CUDA)),
+                              eng->getVoxelSize(), w2c.data_ptr<float>(), fptr(m["color_map"]), fptr(m["vertex_map"]),
+                              fptr(m["confidence_map"]), fptr(m["depth_map"]), fptr(m["depth_map_clamped"]),
+                              current_stream()), "gps_raycast_to_maps");
+    stats.raycasts++;
+    return m;
+}
+
+// ------------------------------------------------------------------ frame bookkeeping (updateFrameList :319-360)
+void SLAMPipeline::updateFrameList() {
+    if (curr_frame_id == 0) return;
+    if (curr_frame_id % localframe_cam_window_interval == 0) {
+        localframe_cam_window.push_back(curr_cam);
+        if ((int)localframe_cam_window.size() == localframe_cam_window_length + 1) localframe_cam_window.pop_front();
+    }
+    bool is_key = false;
+    if (keyframe_cam_list.empty()) {
+        is_key = true;
+    } else {
+        const Camera& last = keyframe_cam_list.back();
+        auto a = last.c2w_slam.to(torch::kCPU, torch::kFloat32).contiguous();
+        auto b = curr_cam.c2w_slam.to(torch::kCPU, torch::kFloat32).contiguous();
+        const float* A = a.data_ptr<float>();
+        const float* B = b.data_ptr<float>();
+        float tr = 0.f;  // trace(Rp^T Rc)
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) tr += A[4 * k + r] * B[4 * k + r];
+        const float cos_t = std::max(-1.0f, std::min(1.0f, (tr - 1.f) / 2.f));
+        const float theta = std::acos(cos_t) * 180.0f / (float)M_PI;
+        const float dx = A[3] - B[3], dy = A[7] - B[7], dz = A[11] - B[11];
+        const float trans = std::sqrt(dx * dx + dy * dy + dz * dz);
+        is_key = theta > keyframe_theta_thres || trans > keyframe_trans_thres;
+    }
+    if (is_key) keyframe_cam_list.push_back(curr_cam);
+}
+
+void SLAMPipeline::localFrameRaycast() {
+    localframe_raycast_window.clear();
+    for (const Camera& cam : localframe_cam_window) localframe_raycast_window.push_back(runRaycastByCam(cam));
+}
+
+void SLAMPipeline::keyFrameRaycast() {
+    opt_cam_list.assign(localframe_cam_window.begin(), localframe_cam_window.end());
+    opt_raycast_list.assign(localframe_raycast_window.begin(), localframe_raycast_window.end());
+    const int n = std::min<int>(keyframe_select_max, (int)keyframe_cam_list.size());
+    RandomSelector<Camera> sel(keyframe_cam_list, rng_);
+    for (int k = 0; k < n; k++) {
+        const Camera* cam = sel.getNext().second;
+        opt_cam_list.push_back(*cam);
+        opt_raycast_list.push_back(runRaycastByCam(*cam));
+    }
+}
+
+// ------------------------------------------------------------------ initNewGaussians :450-526
+void SLAMPipeline::initNewGaussians(TensorDict& rm) {
+    torch::NoGradGuard no_grad;
+    Camera& cam = curr_cam;
+    const auto &depth = rm.at("depth_map"), &color = rm.at("color_map"), &vertex = rm.at("vertex_map");
+    int frame_num = local_opt_interval;
+    auto valid = (depth > depth_vis_min) & (depth < depth_vis_max);
+    valid = valid & ~((vertex.sum(2) == 0).unsqueeze(-1));
+    torch::Tensor mask;
+    if (model->getGaussianNum() == 0) {
+        auto err = torch::mean(torch::abs(color - cam.image), -1, true);
+        mask = (err > color_error_thres) & valid;
+        frame_num += 1;
+    } else {
+        auto res = model->forward(cam, depth, color);
+        auto err = torch::mean(torch::abs(res.at("rgb") - cam.image), -1, true);
+        mask = (err > color_error_thres) & valid & (res.at("alpha") < alpha_vis_max);
+    }
+    rm["normal_map"] = computeNormalMap(vertex);
+    stats.added += model->addGaussians(cam, rm, mask, new_gs_sample_ratio, frame_num, gen_);
+}
+
+// ------------------------------------------------------------------ localOptimize :195-289
+void SLAMPipeline::localOptimize() {
+    if (model->getGaussianNum() == 0) return;
+    model->initOptimizers(-1, scene_scale);
+    RandomSelector<Camera> loader(opt_cam_list, rng_);
+    for (int it = 0; it < local_opt_iters; it++) {
+        auto pick = loader.getNext();
+        const Camera& cam = *pick.second;
+        TensorDict& rc = opt_raycast_list[pick.first];
+        model->trainStep(cam, rc.at("depth_map"), rc.at("color_map"), rc.at("depth_map_clamped"));
+        stats.opt_iters++;
+    }
+}
+
+// ------------------------------------------------------------------ removeRedundantGs :564-586
+void SLAMPipeline::removeRedundantGs() {
+    torch::NoGradGuard no_grad;
+    if (model->getGaussianNum() == 0) return;
+    auto smax = std::get<0>(model->getRealScales().max(-1));
+    auto mask = (smax < small_scale_thres) | (smax > large_scale_thres) |
+                (model->getRealOpacities().squeeze(-1) < low_opac_thres);
+    const int64_t n = mask.sum().item<int64_t>();  // the reference syncs 5 times here for its printf; once is enough
+    if (n > 0) {
+        model->prunePoints(mask);
+        stats.pruned += n;
+    }
+}
+
+// ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
+void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
+    curr_frame_id = i;
+    if ((int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed) main_engine->gtC2wPoses.push_back(cam.c2w);
+    ITMTrackingState* ts = main_engine->ProcessFrame(rgb_u8, depth_mm_i16);
+    // est_pose = pose_d->GetInvM() (:81-82): ORUtils column-major -> row-major tensor
+    auto est = torch::empty({4, 4}, torch::kFloat32);
+    const float* invM = ts->pose_d->GetInvM();
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) est.data_ptr<float>()[4 * r + c] = invM[4 * c + r];
+    cam.c2w_slam = est;
+    cam.invalidate();
+    cam.toGPU(device);
+    curr_cam = cam;
+    updateFrameList();
+    stats.frames++;
+    if (work_mode == "recon") return;
+    if (i % local_opt_interval == 0 && i > 0) {
+        localFrameRaycast();
+        keyFrameRaycast();
+        initNewGaussians(localframe_raycast_window.back());
+        localOptimize();
+        removeRedundantGs();
+    }
+}
+
+void SLAMPipeline::SLAMTrainCams(std::vector<Camera>& cams, const std::vector<torch::Tensor>& rgb_u8,
+                                 const std::vector<torch::Tensor>& depth_mm_i16) {
+    for (size_t i = 0; i < cams.size(); i++) processFrame((int)i, cams[i], rgb_u8[i], depth_mm_i16[i]);
+}

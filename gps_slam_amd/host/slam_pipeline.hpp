@@ -1,0 +1,90 @@
+// SLAMPipeline (slam/slam_pipeline.{h,cpp}): the per-frame loop that drives the hot path.
+//
+//    SLAMTrainCams      :52-173   per frame: TSDF ProcessFrame; every local_opt_interval frames:
+//    localFrameRaycast  :417-448  runRaycastByCam for the <= 2 window frames
+//    keyFrameRaycast    :528-561  + <= 7 random keyframes
+//    initNewGaussians   :450-526  error-mask sampling -> addGaussians
+//    localOptimize      :195-289  20 x (forward, L1, backward, 7 x Adam)
+//    removeRedundantGs  :564-586  prune by scale / opacity
+//
+// All compute goes through the C-ABI (RawGaussianModel, ITMBasicEngine); this file is bookkeeping.  Random choices the
+// reference seeds from std::random_device (dataset_reader.h:39) are seeded here so that runs are reproducible.
+#pragma once
+#include <deque>
+#include <random>
+
+#include "raw_gs_model.hpp"
+#include "tsdf_engine.hpp"
+
+// dataset_reader.h:26-100 (uniform branch): draw without replacement, refill when exhausted
+template <class T>
+class RandomSelector {
+public:
+    RandomSelector(const std::vector<T>& items, std::mt19937_64& rng) : rng_(rng) {
+        for (size_t i = 0; i < items.size(); i++) original_.push_back({(int)i, &items[i]});
+        current_ = original_;
+    }
+    std::pair<int, const T*> getNext() {
+        if (current_.empty()) current_ = original_;
+        std::uniform_int_distribution<size_t> d(0, current_.size() - 1);
+        const size_t i = d(rng_);
+        auto v = current_[i];
+        current_[i] = current_.back();
+        current_.pop_back();
+        return v;
+    }
+
+private:
+    std::vector<std::pair<int, const T*>> original_, current_;
+    std::mt19937_64& rng_;
+};
+
+torch::Tensor computeNormalMap(const torch::Tensor& vertex_map);  // src/tensor_math.cpp:278-300 -> gps_normal_map
+
+class SLAMPipeline {
+public:
+    SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model, uint64_t seed = 1234);
+
+    void loadConfig(const gpsh::Config& config);  // PIPELINE section keys
+
+    // body of the SLAMTrainCams frame loop (:69-132) for frame i
+    void processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16);
+    void SLAMTrainCams(std::vector<Camera>& cams, const std::vector<torch::Tensor>& rgb_u8,
+                       const std::vector<torch::Tensor>& depth_mm_i16);
+
+    TensorDict runRaycastByCam(const Camera& cam, bool use_cam_depth = true);  // :362-415
+    void updateFrameList();                                                    // :319-360
+    void localFrameRaycast();
+    void keyFrameRaycast();
+    void initNewGaussians(TensorDict& raycast_maps);
+    void localOptimize();
+    void removeRedundantGs();
+
+    torch::Device device = torch::kCUDA;
+    std::string work_mode = "train";
+    ITMBasicEngine* main_engine;
+    SLAMGaussianModel* model;
+    float voxel_size;
+
+    int curr_frame_id = -1;
+    int localframe_cam_window_length = 2, localframe_cam_window_interval = 5;
+    int local_opt_iters = 20, local_opt_interval = 10;
+    int keyframe_select_max = 7;
+    Camera curr_cam;
+    std::deque<Camera> localframe_cam_window;
+    std::deque<TensorDict> localframe_raycast_window;
+    std::vector<Camera> keyframe_cam_list;
+    std::vector<Camera> opt_cam_list;
+    std::vector<TensorDict> opt_raycast_list;
+    float keyframe_theta_thres = 30.0f, keyframe_trans_thres = 0.3f;
+    float new_gs_sample_ratio = 0.25f, color_error_thres = 0.05f;
+    float depth_vis_max = 5.0f, depth_vis_min = 0.0f, alpha_vis_max = 5.0f;
+    float large_scale_thres = 0.1f, small_scale_thres = 0.003f, low_opac_thres = 0.005f;
+    float scene_scale = 1.1f * 3.0f;
+
+    struct Stats { int64_t frames = 0, opt_iters = 0, raycasts = 0, added = 0, pruned = 0; } stats;
+
+private:
+    std::mt19937_64 rng_;
+    at::Generator gen_;
+};

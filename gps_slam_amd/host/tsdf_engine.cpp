@@ -1,0 +1,92 @@
+#include "tsdf_engine.hpp"
+
+using namespace gpsh;
+
+namespace {
+torch::Tensor zeros_bytes(int64_t n, const torch::Device& d) { return torch::zeros({n}, u8(d)); }
+}  // namespace
+
+ITMBasicEngine::ITMBasicEngine(int width, int height, float fx, float fy, float cx, float cy, float voxel_size, float mu,
+                               float view_frustum_min, float view_frustum_max, int n_blocks, int n_buckets,
+                               int n_excess, torch::Device device)
+    : device_(device),
+      free_image_(width, height, torch::Tensor()),
+      free_vertex_(width, height, torch::Tensor()),
+      live_vertex_(width, height, torch::Tensor()) {
+    const int64_t P = (int64_t)width * height, n_total = (int64_t)n_buckets + n_excess;
+    const auto F = f32(device), I = i32(device);
+    vba_ = zeros_bytes((int64_t)n_blocks * 512 * 8, device);
+    vba_alloc_list_ = torch::zeros({n_blocks}, I);
+    hash_ = zeros_bytes(n_total * 16, device);
+    excess_list_ = torch::zeros({n_excess}, I);
+    counters_ = torch::zeros({16}, I);
+    alloc_prio_ = torch::zeros({n_total}, I);
+    scan_scratch_ = zeros_bytes(gps_tsdf_scratch_bytes(width, height, n_buckets, n_excess) + 16, device);
+    visible_type_ = zeros_bytes(n_total, device);
+    visible_ids_ = torch::zeros({n_blocks}, I);
+    depth_ = torch::zeros({P}, F);
+    minmax_ = torch::zeros({P * 2}, F);
+    raycast_ = torch::zeros({P * 4}, F);
+    icp_points_ = torch::zeros({P * 4}, F);
+    icp_normals_ = torch::zeros({P * 4}, F);
+    fv_visible_ids_ = torch::zeros({n_blocks}, I);
+    fv_minmax_ = torch::zeros({P * 2}, F);
+    fv_raycast_ = torch::zeros({P * 4}, F);
+    fv_colour_ = zeros_bytes(P * 4, device);
+    gps_tsdf_state& s = state_;
+    s.width = width; s.height = height;
+    s.fx = fx; s.fy = fy; s.cx = cx; s.cy = cy;
+    s.voxel_size = voxel_size; s.mu = mu; s.view_frustum_min = view_frustum_min; s.view_frustum_max = view_frustum_max;
+    s.max_w = 100;  // ITMLibSettings.cpp:10
+    s.n_blocks = n_blocks; s.n_buckets = n_buckets; s.n_excess = n_excess;
+    s.vba = reinterpret_cast<gps_voxel*>(vba_.data_ptr());
+    s.vba_alloc_list = iptr(vba_alloc_list_);
+    s.hash = reinterpret_cast<gps_hash_entry*>(hash_.data_ptr());
+    s.excess_list = iptr(excess_list_);
+    s.counters = iptr(counters_);
+    s.alloc_prio = reinterpret_cast<uint32_t*>(alloc_prio_.data_ptr());
+    s.scan_scratch = reinterpret_cast<int32_t*>(scan_scratch_.data_ptr());
+    s.visible_type = ptr<uint8_t>(visible_type_);
+    s.visible_ids = iptr(visible_ids_);
+    s.depth = fptr(depth_);
+    s.rgb = nullptr;
+    s.minmax = fptr(minmax_); s.raycast = fptr(raycast_);
+    s.icp_points = fptr(icp_points_); s.icp_normals = fptr(icp_normals_);
+    s.fv_visible_ids = iptr(fv_visible_ids_); s.fv_minmax = fptr(fv_minmax_); s.fv_raycast = fptr(fv_raycast_);
+    s.fv_colour = ptr<uint8_t>(fv_colour_);
+    // the state must be complete for gps_tsdf_reset's validity check: point rgb at the colour buffer until a frame arrives
+    s.rgb = ptr<uint8_t>(fv_colour_);
+    free_image_ = ITMUChar4Image(width, height, fv_colour_);
+    free_vertex_ = ITMFloat4Image(width, height, fv_raycast_);
+    live_vertex_ = ITMFloat4Image(width, height, raycast_);
+    resetAll();
+}
+
+void ITMBasicEngine::resetAll() {
+    check(gps_tsdf_reset(&state_, current_stream()), "gps_tsdf_reset");
+    framesProcessed = 0;
+    camPoses.clear();
+}
+
+ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
+    TORCH_CHECK(turnOffTracking, "the ICP tracker is outside the hot path (SURVEY 8(f) rank 1): use_gt_pose only");
+    TORCH_CHECK((int)gtC2wPoses.size() > framesProcessed, "gtC2wPoses must hold the pose of frame ", framesProcessed);
+    TORCH_CHECK(rgb_u8.is_cuda() && rgb_u8.scalar_type() == torch::kUInt8 && rgb_u8.is_contiguous() &&
+                    rgb_u8.size(-1) == 4, "rgb must be a contiguous uint8 [H,W,4] device tensor (uchar4)");
+    TORCH_CHECK(depth_mm_i16.is_cuda() && depth_mm_i16.scalar_type() == torch::kInt16 && depth_mm_i16.is_contiguous(),
+                "depth must be a contiguous int16 [H,W] device tensor (millimetres)");
+    frame_inputs_ = {rgb_u8, depth_mm_i16};  // keep alive while kernels may read them
+    state_.rgb = ptr<uint8_t>(rgb_u8);
+    auto c2w = gtC2wPoses[framesProcessed].to(torch::kCPU, torch::kFloat32).contiguous();
+    pose_d_.SetInvM(c2w.data_ptr<float>());
+    pose_d_.Coerce();
+    check(gps_tsdf_process_frame(&state_, ptr<int16_t>(depth_mm_i16), pose_d_.GetM(), pose_d_.GetInvM(),
+                                 current_stream()), "gps_tsdf_process_frame");
+    camPoses.push_back(pose_d_);
+    framesProcessed++;
+    return &tracking_state_;
+}
+
+void ITMBasicEngine::runRaycast(ORUtils::SE3Pose* pose) {
+    check(gps_tsdf_free_raycast(&state_, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
+}

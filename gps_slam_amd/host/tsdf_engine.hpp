@@ -1,0 +1,93 @@
+// The TSDF engine surface SLAMPipeline drives (slam/slam_pipeline.cpp:69-83, 362-415; slam/InfiniTAM_tools.cpp:3-67;
+// ITMLib/Core/ITMBasicEngine.{h,tpp}) on the C-ABI.  ITMBasicEngine<ITMVoxel_s_rgb, ITMVoxelBlockHash> as the
+// shipped configs run it: tracking off (use_gt_pose: true), no swapping, no meshing on the hot path.
+//
+// The engine owns the device buffers (through libtorch, where the reference uses ORUtils::MemoryBlock), fills the
+// gps_tsdf_state once and afterwards only passes pointers.  Method and member names follow the reference so that
+// slam_pipeline-style code reads the same: ProcessFrame, runRaycast, GetFreeImage, GetFreeVertex, getVoxelSize,
+// GetTrackingState()->pose_d->GetInvM(), camPoses, gtC2wPoses.
+#pragma once
+#include "gps_host_common.hpp"
+
+enum MemoryDeviceType { MEMORYDEVICE_CPU, MEMORYDEVICE_CUDA };
+
+namespace ORUtils {
+
+// ORUtils/SE3Pose.h as used here: SetInvM(c2w) + Coerce() -> GetM / GetInvM (ORUtils column-major float[16])
+class SE3Pose {
+public:
+    SE3Pose() { for (int i = 0; i < 16; i++) M_[i] = invM_[i] = (i % 5 == 0) ? 1.f : 0.f; }
+    void SetInvM(const float* c2w_row_major) { gpsh::check(gps_pose_from_c2w(c2w_row_major, M_, invM_), "gps_pose_from_c2w"); }
+    void Coerce() {}  // done by gps_pose_from_c2w
+    const float* GetM() const { return M_; }
+    const float* GetInvM() const { return invM_; }
+
+private:
+    float M_[16], invM_[16];
+};
+
+// ORUtils/Image.h as the pipeline uses it: a device image whose GetData(MEMORYDEVICE_CUDA) pointer torch::from_blob
+// can wrap (src/cv_utils.cpp:324-336)
+template <class T>
+class Image {
+public:
+    struct { int x, y; } noDims;
+    Image(int w, int h, torch::Tensor storage) : storage_(storage) { noDims.x = w; noDims.y = h; }
+    T* GetData(MemoryDeviceType t) const {
+        TORCH_CHECK(t == MEMORYDEVICE_CUDA, "the engine keeps images on the device only");
+        return reinterpret_cast<T*>(storage_.data_ptr());
+    }
+    const torch::Tensor& tensor() const { return storage_; }
+
+private:
+    torch::Tensor storage_;
+};
+
+}  // namespace ORUtils
+
+struct Vector4u { unsigned char x, y, z, w; };
+struct Vector4f { float x, y, z, w; };
+typedef ORUtils::Image<Vector4u> ITMUChar4Image;
+typedef ORUtils::Image<Vector4f> ITMFloat4Image;
+
+struct ITMTrackingState { ORUtils::SE3Pose* pose_d; };
+
+class ITMBasicEngine {
+public:
+    // capacities: ITMLib/Objects/Scene/ITMVoxelBlockHash.h:18-22
+    ITMBasicEngine(int width, int height, float fx, float fy, float cx, float cy, float voxel_size = 0.005f,
+                   float mu = 0.02f, float view_frustum_min = 0.2f, float view_frustum_max = 10.0f,
+                   int n_blocks = 0x40000, int n_buckets = 0x100000, int n_excess = 0x20000,
+                   torch::Device device = torch::kCUDA);
+
+    void resetAll();
+    // ITMBasicEngine::ProcessFrame with tracking off: pose := gtC2wPoses[framesProcessed] (ITMBasicEngine.tpp:260-385).
+    // rgb uint8[H,W,4] (uchar4) and depth int16[H,W] (mm) device tensors are read in place.
+    ITMTrackingState* ProcessFrame(const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16);
+    // ITMBasicEngine::runRaycast(pose, intrinsics) (ITMBasicEngine.tpp:519-525)
+    void runRaycast(ORUtils::SE3Pose* pose);
+    ITMUChar4Image* GetFreeImage() { return &free_image_; }
+    ITMFloat4Image* GetFreeVertex() { return &free_vertex_; }
+    ITMFloat4Image* GetLiveVertex() { return &live_vertex_; }
+    float getVoxelSize() const { return state_.voxel_size; }
+    ITMTrackingState* GetTrackingState() { return &tracking_state_; }
+    const gps_tsdf_state& state() const { return state_; }
+    torch::Tensor counters() const { return counters_; }
+
+    std::vector<ORUtils::SE3Pose> camPoses;       // pose used for every processed frame
+    std::vector<torch::Tensor> gtC2wPoses;         // dataset poses, [4,4] float CPU tensors (push before ProcessFrame)
+    bool turnOffTracking = true;
+    int framesProcessed = 0;
+
+private:
+    gps_tsdf_state state_{};
+    torch::Device device_;
+    torch::Tensor vba_, vba_alloc_list_, hash_, excess_list_, counters_, alloc_prio_, scan_scratch_, visible_type_,
+        visible_ids_, depth_, minmax_, raycast_, icp_points_, icp_normals_, fv_visible_ids_, fv_minmax_, fv_raycast_,
+        fv_colour_;
+    std::vector<torch::Tensor> frame_inputs_;
+    ORUtils::SE3Pose pose_d_;
+    ITMTrackingState tracking_state_{&pose_d_};
+    ITMUChar4Image free_image_;
+    ITMFloat4Image free_vertex_, live_vertex_;
+};

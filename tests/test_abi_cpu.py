@@ -50,3 +50,30 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_cpp_host_layer_builds_loads_and_mirrors_the_reference_surface():
+    """gps_slam_amd/host (C++/libtorch over the C-ABI) builds with g++ and exposes the reference's operator surface
+    (gsplat/gsplat_wapper.hpp), model (include/raw_gs_model.h), engine and pipeline names.  No compute without a GPU."""
+    from gps_slam_amd import _build, _build_host, _lib
+    _build.build()
+    _lib.load_library()
+    _build_host.build()
+    import gps_slam_amd._host as h
+    for name in ("SphericalHarmonicsNew", "FullyFusedProjection", "RasterizeToPixelsGes_NewParallel", "isectTilesNoDepth",
+                 "isectOffsetEncodeNoDepth", "distCUDA2", "simpleKNN", "degFromSh", "numShBases", "rgb2sh", "sh2rgb",
+                 "Camera", "SLAMGaussianModel", "ITMBasicEngine", "SLAMPipeline"):
+        assert hasattr(h, name), name
+    assert [h.numShBases(d) for d in range(5)] == [1, 4, 9, 16, 25] and h.degFromSh(16) == 3
+    import torch
+    rgb = torch.tensor([[0.25, 0.5, 1.0]])
+    assert torch.allclose(h.sh2rgb(h.rgb2sh(rgb)), rgb)
+    m = h.SLAMGaussianModel()
+    for meth in ("forward", "computeLoss", "trainStep", "initOptimizers", "optimizersStep", "optimizersZeroGrad",
+                 "prunePoints", "addGaussians", "getGaussianNum"):
+        assert hasattr(m, meth), meth
+    # host-side pose algebra runs without a GPU: poseInv(c2w) @ c2w == I
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([0.3, -0.2, 1.5])
+    c2w[:3, :3] = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    assert torch.allclose(h.poseInv(c2w) @ c2w, torch.eye(4), atol=1e-6)
