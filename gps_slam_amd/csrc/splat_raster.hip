@@ -380,27 +380,39 @@ __device__ __forceinline__ float half_sum_to_lane31(float v) {
 
 struct Acc { float c0, c1, c2, c3, ka, kb, kc, mx, my, op; };
 
-__device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, float* __restrict__ v_means2d,
+// s_k (valid in lane 31 of the half) -> lane 31 - k of the half: row_shl:k moves lane 31's value down k lanes
+template <int K>
+__device__ __forceinline__ float spread(float packed, float sk, int hl) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(sk), 0x100 + K, 0xF, 0xF, true);
+    return hl == 31 - K ? __int_as_float(moved) : packed;
+}
+
+// Reduce the half-wave's 10 partial sums and add them to Gaussian g's gradient rows.  The ten totals are spread over
+// lanes 31..22 of the half (lane 31 - k holds total k) so that ONE memory instruction writes all of them.
+//   exclusive = this half-wave saw every pixel group of g (the segment neither touches the start nor the end of the
+//   half's 16-group run) and the arrays were zeroed by this launch: a plain store, no read-modify-write at the L2.
+//   otherwise: float atomics (another half-wave may hold the rest of g, or the caller accumulates across launches).
+__device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, bool exclusive, float* __restrict__ v_means2d,
                                           float* __restrict__ v_conics, float* __restrict__ v_colors,
                                           float* __restrict__ v_opacities) {
-    const float s0 = half_sum_to_lane31(a.c0), s1 = half_sum_to_lane31(a.c1), s2 = half_sum_to_lane31(a.c2);
-    const float s3 = half_sum_to_lane31(a.c3), s4 = half_sum_to_lane31(a.ka), s5 = half_sum_to_lane31(a.kb);
-    const float s6 = half_sum_to_lane31(a.kc), s7 = half_sum_to_lane31(a.mx), s8 = half_sum_to_lane31(a.my);
-    const float s9 = half_sum_to_lane31(a.op);
-    if (g >= 0 && hl == 31) {
-        float* vc = v_colors + 4 * (size_t)g;
-        float* vk = v_conics + 3 * (size_t)g;
-        float* vm = v_means2d + 2 * (size_t)g;
-        if (s0 != 0.f) atomicAdd(vc + 0, s0);
-        if (s1 != 0.f) atomicAdd(vc + 1, s1);
-        if (s2 != 0.f) atomicAdd(vc + 2, s2);
-        if (s3 != 0.f) atomicAdd(vc + 3, s3);
-        if (s4 != 0.f) atomicAdd(vk + 0, s4);
-        if (s5 != 0.f) atomicAdd(vk + 1, s5);
-        if (s6 != 0.f) atomicAdd(vk + 2, s6);
-        if (s7 != 0.f) atomicAdd(vm + 0, s7);
-        if (s8 != 0.f) atomicAdd(vm + 1, s8);
-        if (s9 != 0.f) atomicAdd(v_opacities + g, s9);
+    float v = half_sum_to_lane31(a.c0);
+    v = spread<1>(v, half_sum_to_lane31(a.c1), hl);
+    v = spread<2>(v, half_sum_to_lane31(a.c2), hl);
+    v = spread<3>(v, half_sum_to_lane31(a.c3), hl);
+    v = spread<4>(v, half_sum_to_lane31(a.ka), hl);
+    v = spread<5>(v, half_sum_to_lane31(a.kb), hl);
+    v = spread<6>(v, half_sum_to_lane31(a.kc), hl);
+    v = spread<7>(v, half_sum_to_lane31(a.mx), hl);
+    v = spread<8>(v, half_sum_to_lane31(a.my), hl);
+    v = spread<9>(v, half_sum_to_lane31(a.op), hl);
+    const int k = 31 - hl;  // which total this lane holds
+    if (g >= 0 && k < 10) {
+        float* dst = k < 4 ? v_colors + 4 * (size_t)g + k
+                   : k < 7 ? v_conics + 3 * (size_t)g + (k - 4)
+                   : k < 9 ? v_means2d + 2 * (size_t)g + (k - 7)
+                           : v_opacities + g;
+        if (exclusive) *dst = v;
+        else if (v != 0.f) atomicAdd(dst, v);
     }
     a.c0 = a.c1 = a.c2 = a.c3 = a.ka = a.kb = a.kc = a.mx = a.my = a.op = 0.f;
 }
@@ -437,9 +449,13 @@ __device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, 
     const int i = R.y0 + q;
     if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw))) return;
     const int pix = i * W + j;
+#ifdef GPS_EXP_NO_GATHER
+    const float rd = 1000.f; o.vc = make_float4(0.1f, 0.2f, 0.3f, (float)pix * 1e-9f); o.va = 0.5f;
+#else
     const float rd = ref_depth[pix];
     o.vc = v_render_colors[pix];
     o.va = v_render_alphas[pix];
+#endif
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     o.dx = R.x - px; o.dy = R.y - py;
     const float sigma = 0.5f * (R.ca * o.dx * o.dx + R.cc * o.dy * o.dy) + R.cb * o.dx * o.dy;
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const float* __restrict__ opacities, const int32_t* __restrict__ radiis, const float* __restrict__ ref_depth,
     const int64_t* __restrict__ counts, float delta_depth, int W, int H, const float4* __restrict__ v_render_colors,
     const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d, float* __restrict__ v_conics,
-    float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, int plain_ok) {
     __shared__ BwdRec recs[4][2][16];
     const int n_groups = (int)counts[1];
     const int n_tasks = (n_groups + 31) >> 5;
@@ -507,6 +523,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
         Acc acc;
         acc.c0 = acc.c1 = acc.c2 = acc.c3 = acc.ka = acc.kb = acc.kc = acc.mx = acc.my = acc.op = 0.f;
         int cur_g = -1;
+        bool first_seg = true;  // the current segment began at step 0 of the run (it may continue a neighbour's)
         for (int s = 0; s < 16; s += BWD_INFLIGHT) {
             BwdPix p[BWD_INFLIGHT];
 #pragma unroll
@@ -516,13 +533,16 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
             for (int u = 0; u < BWD_INFLIGHT; ++u) {
                 const BwdRec R = my[s + u];
                 if (R.gs_id != cur_g) {
-                    flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
+                    // the segment that ends here started after step 0 and ends before the run does
+                    if (cur_g >= 0)
+                        flush_acc(acc, cur_g, hl, plain_ok && !first_seg, v_means2d, v_conics, v_colors, v_opacities);
+                    first_seg = cur_g < 0;  // still no Gaussian seen (cannot happen after a real segment)
                     cur_g = R.gs_id;
                 }
                 bwd_accum(R, p[u], acc);
             }
         }
-        flush_acc(acc, cur_g, hl, v_means2d, v_conics, v_colors, v_opacities);
+        if (cur_g >= 0) flush_acc(acc, cur_g, hl, false, v_means2d, v_conics, v_colors, v_opacities);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -588,10 +608,11 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
     if (!accumulate)
         zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
                                                                                      v_opacities);
-    raster_ges_bwd_gs_kernel<<<2048, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
+    static const int bwd_blocks = getenv("GPS_BWD_BLOCKS") ? atoi(getenv("GPS_BWD_BLOCKS")) : 4096;
+    raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
                                                   (const float4*)colors, opacities, radii, ref_depth_map, counts,
                                                   delta_depth, width, height, (const float4*)v_render_colors,
-                                                  v_render_alphas, v_means2d, v_conics, v_colors, v_opacities);
+                                                  v_render_alphas, v_means2d, v_conics, v_colors, v_opacities, accumulate ? 0 : 1);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
