@@ -301,6 +301,7 @@ __global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const
 // coalesced 512-byte access and the per-block header chain (visible_ids -> hash entry) is paid once per 512 voxels
 // while 8 waves per SIMD keep ~8k independent blocks in flight chip-wide (the per-block dependent-load latency, not
 // bandwidth, bounded the earlier one-workgroup-per-block layout).
+template <bool FAST_DIV>
 __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
     const int n_visible = s.counters[GPS_TSDF_N_VISIBLE];
     const int lane = threadIdx.x & 63;
@@ -309,6 +310,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
     const int n_waves = (gridDim.x * blockDim.x) >> 6;
     const int W = s.width, H = s.height;
     const float mu = s.mu;
+    const float inv_mu = 1.0f / mu;                       // RN(1/mu), RN(1/255), RN(1/32767) for div_known
+    const float inv_255 = 1.0f / 255.0f, inv_32767 = 1.0f / 32767.0f;
     const uchar4* img = reinterpret_cast<const uchar4*>(s.rgb);
     for (int e = wave; e < n_visible; e += n_waves) {
         const HashEntry he = load_entry(s.hash, s.visible_ids[e]);
@@ -323,7 +326,15 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
             float cx, cy, cz;
             mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
             if (cz <= 0) continue;
-            const float ix = s.fx * cx / cz + s.cx, iy = s.fy * cy / cz + s.cy;
+            float ix, iy;
+            if (FAST_DIV && cz >= 1e-4f) {  // (wave-uniform in practice; tiny cz would overflow the unscaled sequence)
+                const float rz = refined_rcp(cz);
+                ix = div_shared(s.fx * cx, cz, rz) + s.cx;
+                iy = div_shared(s.fy * cy, cz, rz) + s.cy;
+            } else {
+                ix = s.fx * cx / cz + s.cx;
+                iy = s.fy * cy / cz + s.cy;
+            }
             if ((ix < 1) || (ix > W - 2) || (iy < 1) || (iy > H - 2)) continue;
             const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
             if (dm <= 0.0f) continue;
@@ -333,15 +344,17 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
             // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
             const int16_t sdf = (int16_t)(raw & 0xFFFF);
             const int oldW = (int)((raw >> 16) & 0xFF);
-            float oldF = (float)sdf / 32767.0f;
-            float newF = (1.0f < eta / mu) ? 1.0f : eta / mu;
+            float oldF = FAST_DIV ? div_known((float)sdf, 32767.0f, inv_32767) : (float)sdf / 32767.0f;
+            const float eta_mu = FAST_DIV ? div_known(eta, mu, inv_mu) : eta / mu;
+            float newF = (1.0f < eta_mu) ? 1.0f : eta_mu;
             int newW = 1;
             newF = oldW * oldF + newW * newF;
             newW = oldW + newW;
-            newF /= newW;
+            if (FAST_DIV) { const float fw = (float)newW; newF = div_shared(newF, fw, refined_rcp(fw)); }
+            else newF /= newW;
             newW = (newW < s.max_w) ? newW : s.max_w;
             raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
-            if (!((eta > mu) || (fabsf(eta / mu) > 0.25f))) {
+            if (!((eta > mu) || (fabsf(eta_mu) > 0.25f))) {
                 // colour: rgb camera == depth camera (trafo_rgb_to_depth is identity, InfiniTAM_tools.cpp:6-10), so the
                 // colour projection repeats the depth projection's rounding sequence exactly
                 const int px = (int)floorf(ix), py = (int)floorf(iy);
@@ -355,6 +368,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
                 const float sumW = oldWc + 1.0f;
                 const float maxWf = (float)(uint8_t)s.max_w;
                 const float cw = (sumW < maxWf) ? sumW : maxWf;
+                const float rsum = FAST_DIV ? refined_rcp(sumW) : 0.f;
                 uint64_t packed = 0;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -363,10 +377,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
                     // ((a*(1-dx))*(1-dy) + (b*dx)*(1-dy)) + (c*(1-dx))*dy) + (d*dx)*dy  (ITMPixelUtils.h:25-26)
                     const float m = ((fa * (1.0f - dx) * (1.0f - dy) + fb * dx * (1.0f - dy)) + fc * (1.0f - dx) * dy) +
                                     fd * dx * dy;
-                    const float meas = m / 255.0f;
-                    const float oldC = (float)((raw >> (24 + 8 * k)) & 0xFF) / 255.0f;
+                    const float oldByte = (float)((raw >> (24 + 8 * k)) & 0xFF);
+                    const float meas = FAST_DIV ? div_known(m, 255.0f, inv_255) : m / 255.0f;
+                    const float oldC = FAST_DIV ? div_known(oldByte, 255.0f, inv_255) : oldByte / 255.0f;
                     float newC = oldC * oldWc + meas * 1.0f;
-                    newC /= sumW;
+                    if (FAST_DIV) newC = div_shared(newC, sumW, rsum);
+                    else newC /= sumW;
                     const float sc = newC * 255.0f;
                     int vi = (int)((sc < 0) ? (sc - 0.5f) : (sc + 0.5f));
                     vi = max(0, min(255, vi));
@@ -461,7 +477,9 @@ int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stre
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
     // persistent grid of 8192 waves (one block per wave at a time), strides over the visible list
-    integrate_kernel<<<2048, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
+    // the fast exact divisions need mu's significand not to be all ones (div_known_safe); any other mu takes the generic path
+    if (div_known_safe(s.mu)) integrate_kernel<true><<<2048, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
+    else integrate_kernel<false><<<2048, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
