@@ -233,11 +233,14 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
     return blend_corners<WITH_CONF>(r, cx, cy, cz, conf);
 }
 
-// castRay (Shared.h:122-221); 16x16 pixel workgroups so that a wave's rays stay inside a 16x4 patch
+// castRay (Shared.h:122-221); 16x16 pixel workgroups of four 8x8 wave patches
 template <bool MODIFY_VISIBLE>
 __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
                                                      float4* __restrict__ rays) {
-    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    // one wave64 = one 8x8 pixel patch = exactly one cell of the 1/8-resolution min/max image: all 64 rays share their
+    // [min, max] range, so their free-space runs and step counts stay close (a 16x4 strip straddles two cells)
+    const int wave_in_wg = threadIdx.x >> 6, lane_ = threadIdx.x & 63;
+    const int x = blockIdx.x * 16 + (wave_in_wg & 1) * 8 + (lane_ & 7), y = blockIdx.y * 16 + (wave_in_wg >> 1) * 8 + (lane_ >> 3);
     if (x >= s.width || y >= s.height) return;
     const int W = s.width;
     const int loc2 = (int)floorf((float)x / MINMAX_SUB) + (int)floorf((float)y / MINMAX_SUB) * W;
