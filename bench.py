@@ -58,7 +58,7 @@ def build_scene(W, H, n_frames, n_gauss, seed, device):
         ok = (d > 0.3).reshape(-1)
         pts.append(pw.reshape(-1, 3)[ok]); cols.append(cams[k].image.reshape(-1, 3)[ok]); nrm.append(n.reshape(-1, 3)[ok])
     pts, cols, nrm = torch.cat(pts), torch.cat(cols), torch.cat(nrm)
-    sel = torch.randperm(pts.shape[0], device=device, generator=g)[:n_gauss]
+    sel = torch.randperm(pts.shape[0], device=device, generator=g)[:n_gauss].sort().values  # (view, pixel) order, as addGaussians appends
     new = model.init_params(pts[sel].contiguous(), cols[sel].contiguous(), nrm[sel].contiguous())
     # view-dependent detail so all 16 SH bands carry signal
     new["featuresRest"] = (torch.randn(new["featuresRest"].shape, device=device, generator=g) * 0.02).contiguous()

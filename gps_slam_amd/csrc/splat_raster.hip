@@ -491,11 +491,16 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int n_tasks = (n_groups + 31) >> 5;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
     const int half = lane >> 5, hl = lane & 31;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD ONE contiguous eighth of the task
+    // list instead of a stride-8 comb through all of it: Gaussians with neighbouring ids cover neighbouring pixels, so
+    // an XCD then gathers from one band of the gradient image, which its 4 MB L2 can hold.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;   // gridDim.x % 8 == 0
+    const int per_xcd = (n_tasks + 7) >> 3;
+    const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tasks, xcd_lo + per_xcd);
+    const int wave_in_xcd = slot * 4 + wave_in_wg, waves_per_xcd = wgs_per_xcd * 4;
     BwdRec* my = recs[wave_in_wg][half];
 
-    for (int task = wave_global; task < n_tasks; task += n_waves) {
+    for (int task = xcd_lo + wave_in_xcd; task < xcd_hi; task += waves_per_xcd) {
         // ---- phase A: one record per step, fetched by lanes 0..15 of each half
         if (hl < 16) {
             const int gid = task * 32 + half * 16 + hl;

@@ -354,6 +354,10 @@ class SLAMGaussianModel(RawGaussianModel):
             return 0
         # uniformly random subset of num_select pixels (the reference: torch::randperm(n)[:num_select]).  Drawn on the
         # host: n is already known there (masked_select synced) and the CUDA randperm/sort path stalls for ms on ROCm.
-        perm = torch.randperm(n, generator=generator)[:num_select].to(verts.device)  # CPU generator: n is host-known
+        # The subset is the reference's; its ORDER is not: appended in pixel order instead of permutation order, so that
+        # Gaussians with neighbouring ids splat onto neighbouring pixels.  The Gaussian-parallel backward walks Gaussians in
+        # id order and gathers the gradient image per pixel -- with random ids every XCD's 4 MB L2 thrashes over the whole
+        # 7 MB image (rocprofv3 FETCH_SIZE: 190 MB per launch); with pixel order its working set is a narrow band.
+        perm = torch.randperm(n, generator=generator)[:num_select].sort().values.to(verts.device)  # CPU generator: n is host-known
         self.add_params(self.init_params(verts[perm].contiguous(), cols[perm], norms[perm]))
         return num_select

@@ -331,7 +331,11 @@ int SLAMGaussianModel::addGaussians(const Camera& cam, const TensorDict& frame_m
     const int64_t num_select = (int64_t)(n * new_gs_sample_ratio);
     if (num_select <= 0) return 0;
     // uniformly random subset (the reference: torch::randperm(n)[:num_select]); drawn on the host, n is known here
-    auto perm = torch::randperm(n, gen, torch::TensorOptions().dtype(torch::kInt64)).slice(0, 0, num_select).to(verts.device());
+    // The subset is the reference's; the ORDER is pixel order, not permutation order: Gaussians with neighbouring ids then
+    // splat onto neighbouring pixels, which keeps the gradient-image gathers of the Gaussian-parallel backward inside each
+    // XCD's L2 (with random ids every XCD sweeps the whole 7 MB image: rocprofv3 FETCH_SIZE 190 MB per launch).
+    auto perm = std::get<0>(torch::randperm(n, gen, torch::TensorOptions().dtype(torch::kInt64)).slice(0, 0, num_select).sort())
+                    .to(verts.device());
     auto t = RawGaussianParams::make(verts.index_select(0, perm).contiguous(), cols.index_select(0, perm),
                                      norms.index_select(0, perm), maxSH, defaultOpacities, maxInitScale, minInitScale);
     if (!opt_gs_params.buffer(0).defined()) opt_gs_params.reserve(1 << 19, numShBases(maxSH), verts.device());
