@@ -151,6 +151,22 @@ def main():
         else:
             N = model.getGaussianNum()
             stats = pipe.stats
+        # render quality of the state the timed run ended in (after the timed region): PSNR of the composed render and of
+        # the TSDF raycast colour alone against the input images of the last optimisation cameras
+        # (formula: scripts/utils/image_utils.py:19-21).  Synthetic scene -> an absolute figure, not the Replica number.
+        def _psnr(a, b):
+            return float(-10.0 * torch.log10(((a.clamp(0, 1) - b) ** 2).mean()))
+        with torch.no_grad():
+            if args.host == "cpp":
+                views = list(zip(cpipe.optCams(), cpipe.optRaycasts()))[-5:]
+                fwd = lambda c, rc: cmodel.forward(c, rc["depth_map"], rc["color_map"])["rgb"]
+            else:
+                views = list(zip(pipe.opt_cam_list, pipe.opt_raycast_list))[-5:]
+                fwd = lambda c, rc: model.forward(c, rc["depth_map"], rc["color_map"])["rgb"]
+            psnr_render = [_psnr(fwd(c, rc), c.image) for c, rc in views]
+            psnr_tsdf = [_psnr(rc["color_map"], c.image) for c, rc in views]
+        quality = {"views": len(views), "render_psnr_db_vs_input": sum(psnr_render) / max(1, len(views)),
+                   "tsdf_colour_psnr_db_vs_input": sum(psnr_tsdf) / max(1, len(views))}
         roof = dominant_kernel_roofline(model, pipe, eng, cams, device, HBM_PEAK_GBS)
         out = {
             "metric": "SLAM frames/sec @640x480, ~200k Gaussians; render PSNR vs ref",
@@ -161,7 +177,7 @@ def main():
                                    "(use_gt_pose=true as in every shipped config), ~%dk Gaussians; independent scene per GPU"
                                    % (W, H, N // 1000),
                        "gaussians": N, "local_opt_interval": 10, "local_opt_iters": 20,
-                       "frames_per_step": 1, "stats": stats, "host": args.host},
+                       "frames_per_step": 1, "stats": stats, "host": args.host, "quality": quality},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
