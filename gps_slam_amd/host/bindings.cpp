@@ -91,6 +91,7 @@ PYBIND11_MODULE(_host, m) {
                              const torch::Tensor& base_color, c10::optional<torch::Tensor> clamped) {
             s.trainStep(cam, ref_depth, base_color, clamped.has_value() ? *clamped : torch::Tensor());
         }, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"), py::arg("ref_depth_clamped") = py::none())
+        .def("reserveWorkspace", &SLAMGaussianModel::reserveWorkspace)
         .def("lossSum", &SLAMGaussianModel::lossSum)
         .def("initOptimizers", &SLAMGaussianModel::initOptimizers, py::arg("max_iterations") = -1,
              py::arg("scene_scale") = 1.0f)

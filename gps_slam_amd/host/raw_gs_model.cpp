@@ -259,6 +259,15 @@ void RawGaussianModel::initOptimizers(int max_iterations, float scene_scale) {
     setParamsRequireGrad();
 }
 
+void RawGaussianModel::reserveWorkspace(int width, int height) {
+    stepStruct(width, height);
+    const bool had = have_opt_;
+    const int step = adam_step_;
+    initOptimizers(-1, 1.0f);  // allocates m / v / g at capacity
+    have_opt_ = had;           // ... but leaves the optimiser logically un-initialised if it was
+    adam_step_ = step;
+}
+
 void RawGaussianModel::optimizersZeroGrad() {
     for (auto& t : leaf_) t.mutable_grad() = torch::Tensor();
 }

@@ -32,6 +32,9 @@ public:
                    const torch::Tensor& ref_depth_clamped = torch::Tensor());
     torch::Tensor lossSum() const { return B_.loss; }
 
+    // Allocate everything an iteration at this image size needs (intermediates, Adam state) now instead of lazily on the
+    // first forward / initOptimizers -- keeps one-off hipMalloc + memset time out of the frame loop.
+    void reserveWorkspace(int width, int height);
     void initOptimizers(int max_iterations = -1, float scene_scale = 1);  // raw_gs_model.cpp:654-675
     void optimizersZeroGrad();
     void optimizersStep();
