@@ -206,3 +206,39 @@ def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():
     err_render = (res["rgb"] - cams[0].image).abs().mean().item()
     err_tsdf = (rcs[0]["color_map"] - cams[0].image).abs().mean().item()
     assert err_render <= err_tsdf * 1.02, (err_render, err_tsdf)
+
+
+def test_full_loop_at_1280x720_cpp_host():
+    """BASELINE configs[3] geometry (1280x720, 80x45 = 3600 tiles -> 12 sort bits, 921,600 rays): one keyframe block of the
+    whole loop through the C++ host; TSDF state equals the Python host's, the optimised render beats the TSDF colour."""
+    h = _host()
+    from gps_slam_amd.tsdf_engine import TsdfEngine, pose_from_c2w
+    W, Hh, n = 1280, 720, 11
+    seq = synth.make_sequence(W, Hh, n, step_deg=0.5)
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
+    rgb = torch.as_tensor(rgba).to(DEV)
+    dep = torch.as_tensor(seq["depth"].astype(np.int16)).to(DEV)
+    eng_c = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    model_c = h.SLAMGaussianModel()
+    model_c.loadConfig(dict(capacity=1 << 19))
+    pipe_c = h.SLAMPipeline(eng_c, model_c, 3)
+    eng_p = TsdfEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.01, mu=0.04, device=DEV)
+    for i in range(n):
+        cam = h.Camera(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        cam.id = i
+        cam.image = rgb[i][..., :3].float() / 255.0
+        cam.depth = (dep[i].float() / 1000.0).unsqueeze(-1)
+        pipe_c.processFrame(i, cam, rgb[i], dep[i])
+        eng_p.ProcessFrame(rgb[i], dep[i], seq["c2w"][i])
+    torch.cuda.synchronize()
+    st = pipe_c.stats()
+    assert st["frames"] == n and st["opt_iters"] == 20 and st["added"] > 1000
+    assert torch.equal(eng_c.counters().cpu()[:3], eng_p.counters.cpu()[:3])  # [3] = free-view list, pipeline only
+    assert torch.equal(eng_c.GetLiveVertex().view(-1), eng_p.raycast.view(-1))
+    cams, rcs = pipe_c.optCams(), pipe_c.optRaycasts()
+    with torch.no_grad():
+        res = model_c.forward(cams[-1], rcs[-1]["depth_map"], rcs[-1]["color_map"])
+    assert torch.isfinite(res["rgb"]).all()
+    err_render = (res["rgb"] - cams[-1].image).abs().mean().item()
+    err_tsdf = (rcs[-1]["color_map"] - cams[-1].image).abs().mean().item()
+    assert err_render <= err_tsdf * 1.02, (err_render, err_tsdf)
