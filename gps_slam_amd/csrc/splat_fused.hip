@@ -31,6 +31,29 @@ struct FusedIn {
     float eps2d, near_plane, far_plane, radius_clip;
 };
 
+// The SH coefficients are 45 of the 59 floats of a Gaussian.  A thread-per-Gaussian read of its own 180-byte row touches 64
+// different cache lines per load instruction (the TA serialises them); in the BACKWARD the workgroup's 256 rows -- one
+// contiguous 46 KB block -- are copied to LDS with coalesced float4 loads and each thread reads its row from there (row stride 45
+// words: odd, conflict free).  The backward writes its 45 gradients into the same LDS row and the block is stored back
+// coalesced.
+__device__ __forceinline__ void stage_rows_in(float* __restrict__ lds, const float* __restrict__ g, int64_t first_float,
+                                              int n_floats) {
+    // first_float is a multiple of 4 (256 rows per workgroup); n_floats may have a tail at the last workgroup
+    const float4* g4 = reinterpret_cast<const float4*>(g + first_float);
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    const int n4 = n_floats >> 2;
+    for (int e = threadIdx.x; e < n4; e += blockDim.x) l4[e] = g4[e];
+    for (int e = (n4 << 2) + threadIdx.x; e < n_floats; e += blockDim.x) lds[e] = g[first_float + e];
+}
+__device__ __forceinline__ void stage_rows_out(const float* __restrict__ lds, float* __restrict__ g, int64_t first_float,
+                                               int n_floats) {
+    float4* g4 = reinterpret_cast<float4*>(g + first_float);
+    const float4* l4 = reinterpret_cast<const float4*>(lds);
+    const int n4 = n_floats >> 2;
+    for (int e = threadIdx.x; e < n4; e += blockDim.x) g4[e] = l4[e];
+    for (int e = (n4 << 2) + threadIdx.x; e < n_floats; e += blockDim.x) g[first_float + e] = lds[e];
+}
+
 template <int DEG>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t* __restrict__ radii,
                                                              float* __restrict__ means2d, float* __restrict__ depths,
@@ -58,6 +81,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
         float Y[NB];
         sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
         r = Y[0] * in.sh_dc[3 * i]; g = Y[0] * in.sh_dc[3 * i + 1]; b = Y[0] * in.sh_dc[3 * i + 2];
+        // (direct reads: only visible Gaussians need their row here, staging all 256 through LDS measured slower)
         const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
 #pragma unroll
         for (int k = 1; k < NB; k++) {
@@ -84,13 +108,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, const i
                                                              float* __restrict__ v_opac_logit,
                                                              float* __restrict__ v_sh_dc,
                                                              float* __restrict__ v_sh_rest) {
+    extern __shared__ float sh_tile[];  // in: this workgroup's sh_rest rows; out: their gradients (same rows, in place)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= in.N) return;
+    const int row = (in.K - 1) * 3;
+    const int rows_here = min((int)blockDim.x, in.N - (int)(blockIdx.x * blockDim.x));
+    const int64_t tile_first = (int64_t)blockIdx.x * blockDim.x * row;
+    if (in.K > 1) {
+        stage_rows_in(sh_tile, in.sh_rest, tile_first, rows_here * row);
+        __syncthreads();
+    }
+    const bool live = i < in.N;
     constexpr int NB = (DEG + 1) * (DEG + 1);
     float vp[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
     float vdc[3] = {0.f, 0.f, 0.f};
-    float* vrest = v_sh_rest + (size_t)i * (in.K - 1) * 3;
-    const bool vis = radii[i] > 0;
+    float* vrest = sh_tile + threadIdx.x * row;
+    const bool vis = live && radii[i] > 0;
     int written = 0;  // number of sh_rest bands written below
     if (vis) {
         Cam cam;
@@ -111,7 +143,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, const i
         const float x = dx * inorm, y = dy * inorm, z = dz * inorm;
         float Y[NB];
         sh_basis<DEG>(x, y, z, Y);
-        const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
+        const float* cf = sh_tile + threadIdx.x * row;  // read completely before vrest (the same row) is written
         float c0 = Y[0] * in.sh_dc[3 * i], c1 = Y[0] * in.sh_dc[3 * i + 1], c2 = Y[0] * in.sh_dc[3 * i + 2];
 #pragma unroll
         for (int k = 1; k < NB; k++) {
@@ -121,11 +153,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, const i
         const float vg = (c1 + 0.5f >= 0.f) ? vcol.y : 0.f;
         const float vb = (c2 + 0.5f >= 0.f) ? vcol.z : 0.f;
         vdc[0] = Y[0] * vr; vdc[1] = Y[0] * vg; vdc[2] = Y[0] * vb;
-#pragma unroll
-        for (int k = 1; k < NB; k++) {
-            vrest[3 * (k - 1)] = Y[k] * vr; vrest[3 * (k - 1) + 1] = Y[k] * vg; vrest[3 * (k - 1) + 2] = Y[k] * vb;
-        }
-        written = NB - 1;
         if (DEG >= 1) {
             float dX[NB], dY[NB], dZ[NB];
             sh_basis_grad<DEG>(x, y, z, dX, dY, dZ);
@@ -139,10 +166,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, const i
             // dirs = means - cam_T  ->  v_means += v_dirs
             vp[0] += (gx - d * x) * inorm; vp[1] += (gy - d * y) * inorm; vp[2] += (gz - d * z) * inorm;
         }
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+            vrest[3 * (k - 1)] = Y[k] * vr; vrest[3 * (k - 1) + 1] = Y[k] * vg; vrest[3 * (k - 1) + 2] = Y[k] * vb;
+        }
+        written = NB - 1;
         // scales = exp(log_scales)
         vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2];
     }
-    for (int k = written; k < in.K - 1; k++) { vrest[3 * k] = 0.f; vrest[3 * k + 1] = 0.f; vrest[3 * k + 2] = 0.f; }
+    if (live)
+        for (int k = written; k < in.K - 1; k++) { vrest[3 * k] = 0.f; vrest[3 * k + 1] = 0.f; vrest[3 * k + 2] = 0.f; }
+    if (in.K > 1) {
+        __syncthreads();
+        stage_rows_out(sh_tile, v_sh_rest, tile_first, rows_here * row);
+    }
+    if (!live) return;
     v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
     v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
     *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
@@ -199,9 +237,11 @@ int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float* means, co
     FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
                   0, eps2d, 0.f, 0.f, 0.f};
     dim3 g(gps_div_up(N, 256)), b(256);
+    const size_t lds = (size_t)256 * (K - 1) * 3 * sizeof(float);
+    GPS_REQUIRE(lds <= 65536);
     hipStream_t s = (hipStream_t)stream;
 #define GPS_BWD(D)                                                                                              \
-    preprocess_bwd_kernel<D><<<g, b, 0, s>>>(in, radii, conics, v_means2d, v_conics, v_colors, v_opacities, v_means, \
+    preprocess_bwd_kernel<D><<<g, b, lds, s>>>(in, radii, conics, v_means2d, v_conics, v_colors, v_opacities, v_means, \
                                              v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest)
     switch (sh_degree) {
         case 0: GPS_BWD(0); break;

@@ -19,7 +19,12 @@ ref = rc["depth_map_clamped"]; N=st.N
 def fwd1(): lib.gps_raster_ges_fwd(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(ref), W, H, 16, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), None, sp)
 def fwd2(): lib.gps_raster_ges_fwd_rec(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]), ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), sp)
 def bwd(): lib.gps_raster_ges_bwd_gs(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(B["radii"]), ptr(ref), W, H, ptr(B["group_gs_ids"]), ptr(B["group_starts"]), ptr(B["counts"]), model.delta_depth, ptr(B["v_render_colors"]), ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]), ptr(B["v_opacities"]), 1, sp)
-for name, fn in (('fwd_lds', fwd1), ('fwd_rec_var', fwd2), ('bwd', bwd)):
+pp = model.opt_gs_params
+cam_d = cam.toGPU()
+def pre_f(): lib.gps_gauss_preprocess_fwd(N, pp.K, 3, ptr(pp._buf["means"]), ptr(pp._buf["scales"]), ptr(pp._buf["quats"]), ptr(pp._buf["opacities"]), ptr(pp._buf["featuresDc"]), ptr(pp._buf["featuresRest"]), ptr(cam_d["viewmat"]), ptr(cam_d["K"]), ptr(cam_d["cam_pos"]), W, H, 0.3, 0.01, 1e10, 0.0, 100, ptr(B["radii"]), ptr(B["means2d"]), ptr(B["depths"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(B["records"]), sp)
+o = model._opt
+def pre_b(): lib.gps_gauss_preprocess_bwd(N, pp.K, 3, ptr(pp._buf["means"]), ptr(pp._buf["scales"]), ptr(pp._buf["quats"]), ptr(pp._buf["opacities"]), ptr(pp._buf["featuresDc"]), ptr(pp._buf["featuresRest"]), ptr(cam_d["viewmat"]), ptr(cam_d["K"]), ptr(cam_d["cam_pos"]), W, H, 0.3, ptr(B["radii"]), ptr(B["conics"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]), ptr(B["v_opacities"]), ptr(o["g"][0]), ptr(o["g"][1]), ptr(o["g"][2]), ptr(o["g"][5]), ptr(o["g"][3]), ptr(o["g"][4]), sp)
+for name, fn in (('fwd_lds', fwd1), ('fwd_rec_var', fwd2), ('bwd', bwd), ('pre_fwd', pre_f), ('pre_bwd', pre_b)):
     print('%-10s %.1f us' % (name, 1e6*_time_launches(fn, 50, stream)))
 offs = B["tile_offsets"].cpu().numpy().astype(np.int64); ni=int(counts[0])
 d = np.diff(np.concatenate([offs, [ni]]))
