@@ -35,7 +35,7 @@ class SplatStep(C.Structure):
                                    "v_opacities")] +
                 [(p + n, vp) for p in ("g_", "m_", "v_") for n in ("means", "log_scales", "quats", "opac_logit", "sh_dc",
                                                                    "sh_rest")] +
-                [("lr", f64 * 6), ("beta1", f64), ("beta2", f64), ("adam_eps", f64)])
+                [("lr", f64 * 6), ("beta1", f64), ("beta2", f64), ("adam_eps", f64), ("fuse_sh_rest_adam", i32)])
 
 
 class AdamSegment(C.Structure):
@@ -61,6 +61,8 @@ PROTOTYPES = {
     "gps_raster_ges_fwd_rec": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp]),
     "gps_gauss_preprocess_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_gauss_preprocess_bwd_adam": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp,
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, i32, vp]),
     "gps_tsdf_scratch_bytes": (i64, [i32, i32, i32, i32]),
     "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),

@@ -9,6 +9,7 @@
 #include <math.h>
 
 #include "common.hpp"
+#include "splat_adam.hpp"
 
 namespace {
 
@@ -63,15 +64,8 @@ struct AdamArgs {
 };
 
 __device__ __forceinline__ void adam_update(const AdamArgs& a, int s, float g, float& m, float& v, float& p) {
-    // Rounding sequence measured against ATen on gfx950 (scratch/adam_probe.py, 2^20 samples, 100% bitwise):
-    //   add_(g, alpha)        -> fma(alpha, g, m*b1)
-    //   addcmul_(g, g, value) -> fma(value, g*g, v*b2)
-    //   sqrt()/c              -> sqrt * float(1/c)   ; add_(eps) unfused
-    //   addcdiv_(m, d, value) -> fma(value, m/d, p)   (m/d IEEE-correct here, as nvcc's --prec-div default)
-    m = fmaf(a.one_minus_b1, g, __fmul_rn(m, a.beta1));
-    v = fmaf(a.one_minus_b2, __fmul_rn(g, g), __fmul_rn(v, a.beta2));
-    const float denom = __fadd_rn(__fmul_rn(sqrtf(v), a.inv_bc2_sqrt), a.eps);
-    p = fmaf(-a.step_size[s], __fdiv_rn(m, denom), p);
+    gps::AdamScalars sc = {a.beta1, a.beta2, a.one_minus_b1, a.one_minus_b2, a.inv_bc2_sqrt, a.eps, a.step_size[s]};
+    gps::adam_update(sc, g, m, v, p);
 }
 
 // One float4 per thread-iteration when the segment allows it (all parameter tensors are 16-byte aligned torch

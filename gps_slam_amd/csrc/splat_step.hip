@@ -5,6 +5,7 @@
 // that a host in any language pays one FFI crossing per iteration instead of ~10, and so that the chain can be
 // captured into a hipGraph by the caller (nothing here allocates or synchronises).
 #include "common.hpp"
+#include "splat_adam.hpp"
 
 extern "C" {
 
@@ -44,20 +45,24 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
                               a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
                               a->v_opacities, 0, stream);
     if (r != GPS_OK) return r;
-    r = gps_gauss_preprocess_bwd(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
-                                 a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d, a->radii,
-                                 a->conics, a->v_means2d, a->v_conics, a->v_colors, a->v_opacities, a->g_means,
-                                 a->g_log_scales, a->g_quats, a->g_opac_logit, a->g_sh_dc, a->g_sh_rest, stream);
+    const bool fuse = a->fuse_sh_rest_adam != 0 && a->K > 1;
+    r = gps::preprocess_bwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
+                                   a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d, a->radii,
+                                   a->conics, a->v_means2d, a->v_conics, a->v_colors, a->v_opacities, a->g_means,
+                                   a->g_log_scales, a->g_quats, a->g_opac_logit, a->g_sh_dc, fuse ? nullptr : a->g_sh_rest,
+                                   fuse ? a->sh_rest : nullptr, fuse ? a->m_sh_rest : nullptr,
+                                   fuse ? a->v_sh_rest : nullptr,
+                                   gps::adam_scalars(a->lr[4], a->beta1, a->beta2, a->adam_eps, adam_step), stream);
     if (r != GPS_OK) return r;
     gps_adam_segment seg[6] = {
         {a->means, a->g_means, a->m_means, a->v_means, (int64_t)a->N * 3, a->lr[0]},
         {a->log_scales, a->g_log_scales, a->m_log_scales, a->v_log_scales, (int64_t)a->N * 3, a->lr[1]},
         {a->quats, a->g_quats, a->m_quats, a->v_quats, (int64_t)a->N * 4, a->lr[2]},
         {a->sh_dc, a->g_sh_dc, a->m_sh_dc, a->v_sh_dc, (int64_t)a->N * 3, a->lr[3]},
-        {a->sh_rest, a->g_sh_rest, a->m_sh_rest, a->v_sh_rest, (int64_t)a->N * (a->K - 1) * 3, a->lr[4]},
         {a->opac_logit, a->g_opac_logit, a->m_opac_logit, a->v_opac_logit, (int64_t)a->N, a->lr[5]},
+        {a->sh_rest, a->g_sh_rest, a->m_sh_rest, a->v_sh_rest, (int64_t)a->N * (a->K - 1) * 3, a->lr[4]},
     };
-    return gps_adam_step(seg, 6, a->beta1, a->beta2, a->adam_eps, adam_step, stream);
+    return gps_adam_step(seg, fuse ? 5 : 6, a->beta1, a->beta2, a->adam_eps, adam_step, stream);
 }
 
 }  // extern "C"

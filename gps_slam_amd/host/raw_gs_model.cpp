@@ -22,6 +22,7 @@ void RawGaussianModel::loadConfig(const Config& c) {
     quats_lr = c.get("quats_lr", quats_lr); featuresDc_lr = c.get("featuresDc_lr", featuresDc_lr);
     featuresRest_lr = c.get("featuresRest_lr", featuresRest_lr); opacities_lr = c.get("opacities_lr", opacities_lr);
     isect_capacity = (int64_t)c.get("isect_capacity", (double)isect_capacity);
+    fuse_sh_rest_adam = c.get("fuse_sh_rest_adam", fuse_sh_rest_adam ? 1.0 : 0.0) != 0.0;
     render_method = c.gets("render_method", render_method);
     const int64_t cap = (int64_t)c.get("capacity", 1 << 19);
     opt_gs_params.reserve(cap, numShBases(maxSH), device);
@@ -298,6 +299,7 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
     auto clamped = ref_depth_clamped.defined() ? ref_depth_clamped : clampRefDepth(ref_depth);
     gps_splat_step& st = stepStruct(cam.width, cam.height);
     bindCamera(st, cam, clamped, base_color, cam.image);
+    st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 1 : 0;
     adam_step_ += 1;
     check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");
 }

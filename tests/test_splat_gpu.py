@@ -304,3 +304,47 @@ def test_record_streaming_forward_equals_lds_forward(N, W, H):
         print("streaming-vs-lds: max %.3g, frac over tol %.3g" % (d.max().item(), bad.float().mean().item()))
         assert bad.float().mean().item() <= 2e-5
         assert d.max().item() < 0.05
+
+
+def test_fused_sh_rest_adam_is_bit_identical_to_separate_step():
+    """gps_gauss_preprocess_bwd_adam (Adam step of sh_rest inside the backward kernel, gradient kept in LDS) must leave
+    exactly the parameter / exp_avg / exp_avg_sq that gps_gauss_preprocess_bwd + gps_adam_step produce, for several steps,
+    and the same other gradients.  N is not a multiple of the workgroup rows (tail tile)."""
+    import ctypes as C
+    from gps_slam_amd import gsplat_ops as ops
+    from gps_slam_amd._lib import check, lib
+    N, W, H = 10007, 160, 120
+    g, vm, K, c2w = _setup(N, W, H, seed=11)
+    sh = T(g["sh"])
+    P = dict(means=T(g["means"]), ls=T(g["log_scales"]), q=T(g["quats"]), ol=T(g["opac_logit"]).view(-1).contiguous(),
+             dc=sh[:, 0].contiguous(), rest=sh[:, 1:].contiguous())
+    vmT, KT, cp = T(vm), T(K), T(c2w[:3, 3].copy())
+    radii, m2, depths, conics, colors, opac = ops.gauss_preprocess_fwd(P["means"], P["ls"], P["q"], P["ol"], P["dc"], P["rest"],
+                                                                      3, vmT, KT, cp, W, H)
+    gen = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(_dev())
+    v_m2, v_con, v_col, v_op = rnd(N, 2), rnd(N, 3), rnd(N, 4), rnd(N)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    # A: separate
+    restA, mA, vA = P["rest"].clone(), torch.zeros_like(P["rest"]), torch.zeros_like(P["rest"])
+    # B: fused
+    restB, mB, vB = P["rest"].clone(), torch.zeros_like(P["rest"]), torch.zeros_like(P["rest"])
+    for step in (1, 2, 3):
+        gA = ops.gauss_preprocess_bwd(P["means"], P["ls"], P["q"], P["ol"], P["dc"], restA, 3, vmT, KT, cp, W, H, 0.3, radii,
+                                      conics, v_m2, v_con, v_col, v_op)
+        ops.adam_step([restA], [gA[5]], [mA], [vA], [5e-4], step)
+        outB = [torch.empty_like(x) for x in gA[:5]]
+        g_restB = torch.empty_like(restB)
+        check(lib.gps_gauss_preprocess_bwd_adam(N, 16, 3, p(P["means"]), p(P["ls"]), p(P["q"]), p(P["ol"]), p(P["dc"]), p(restB),
+                                                p(vmT), p(KT), p(cp), W, H, 0.3, p(radii), p(conics), p(v_m2), p(v_con),
+                                                p(v_col), p(v_op), p(outB[0]), p(outB[1]), p(outB[2]), p(outB[3]), p(outB[4]),
+                                                p(g_restB) if step == 2 else None, p(mB), p(vB), 5e-4, 0.9, 0.999, 1e-15, step,
+                                                st), "gps_gauss_preprocess_bwd_adam")
+        torch.cuda.synchronize()
+        assert torch.equal(restA, restB) and torch.equal(mA, mB) and torch.equal(vA, vB), step
+        for a, b in zip(gA[:5], outB):
+            assert torch.equal(a, b)
+        if step == 2:
+            assert torch.equal(g_restB, gA[5])
+    assert (restA != P["rest"]).any()
