@@ -62,7 +62,7 @@ PROTOTYPES = {
     "gps_gauss_preprocess_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_gauss_preprocess_bwd_adam": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp,
-                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, i32, vp]),
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, vp, f64, f64, f64, i32, vp]),
     "gps_tsdf_scratch_bytes": (i64, [i32, i32, i32, i32]),
     "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),

@@ -41,6 +41,7 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
                           const int32_t* radii, const float* conics, const float* v_means2d, const float* v_conics,
                           const float* v_colors, const float* v_opacities, float* v_means, float* v_log_scales,
                           float* v_quats, float* v_opac_logit, float* v_sh_dc, float* v_sh_rest, float* adam_param,
-                          float* adam_m, float* adam_v, AdamScalars sc, gps_stream stream);
+                          float* adam_m, float* adam_v, AdamScalars sc, const gps_adam_segment* small5,
+                          const float* small_step, gps_stream stream);
 
 }  // namespace gps

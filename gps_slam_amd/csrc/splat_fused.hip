@@ -108,7 +108,29 @@ struct FusedAdam {
     float* exp_avg;     // its Adam state
     float* exp_avg_sq;
     AdamScalars sc;
+    // optionally also the five small tensors (means, log_scales, quats, sh_dc, opac_logit: 14 floats per Gaussian), stepped
+    // by the thread that owns the Gaussian right after it has their gradients in registers -> no adam_kernel launch at all
+    int small;
+    float* sp[5];
+    float* sm[5];
+    float* sv[5];
+    float sstep[5];     // lr_k / (1 - beta1^t)
 };
+
+template <int L>
+__device__ __forceinline__ void adam_row(const FusedAdam& ad, int k, int i, const float* g) {
+    AdamScalars sc = ad.sc;
+    sc.step_size = ad.sstep[k];
+    float* p = ad.sp[k] + (size_t)i * L;
+    float* m = ad.sm[k] + (size_t)i * L;
+    float* v = ad.sv[k] + (size_t)i * L;
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+        float pc = p[c], mc = m[c], vc = v[c];
+        adam_update(sc, g[c], mc, vc, pc);
+        p[c] = pc; m[c] = mc; v[c] = vc;
+    }
+}
 
 // (fuse is a RUN-TIME flag on purpose: one instantiation per degree -> the gradient math is the same machine code in both
 // modes, so the two paths agree bit for bit; as a template parameter the compiler contracted the SH polynomials differently.)
@@ -222,13 +244,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
         }
     }
     if (!live) return;
-    v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
-    v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
-    *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
-    v_sh_dc[3 * i] = vdc[0]; v_sh_dc[3 * i + 1] = vdc[1]; v_sh_dc[3 * i + 2] = vdc[2];
     // opac = sigmoid(logit): receives gradient for every Gaussian the rasterizer touched (0 otherwise)
     const float o = 1.f / (1.f + expf(-in.opac_logit[i]));
-    v_opac_logit[i] = v_opac[i] * o * (1.f - o);
+    const float vo = v_opac[i] * o * (1.f - o);
+    if (v_means) {  // gradient outputs (optional when the small tensors are stepped below)
+        v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
+        v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
+        *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        v_sh_dc[3 * i] = vdc[0]; v_sh_dc[3 * i + 1] = vdc[1]; v_sh_dc[3 * i + 2] = vdc[2];
+        v_opac_logit[i] = vo;
+    }
+    if (ad.small) {  // every read of this Gaussian's parameters is done: step them in place
+        adam_row<3>(ad, 0, i, vp); adam_row<3>(ad, 1, i, vs); adam_row<4>(ad, 2, i, vq); adam_row<3>(ad, 3, i, vdc);
+        adam_row<1>(ad, 4, i, &vo);
+    }
 }
 
 }  // namespace
@@ -243,19 +272,33 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
                           const int32_t* radii, const float* conics, const float* v_means2d, const float* v_conics,
                           const float* v_colors, const float* v_opacities, float* v_means, float* v_log_scales,
                           float* v_quats, float* v_opac_logit, float* v_sh_dc, float* v_sh_rest, float* adam_param,
-                          float* adam_m, float* adam_v, AdamScalars sc, gps_stream stream) {
+                          float* adam_m, float* adam_v, AdamScalars sc, const gps_adam_segment* small5,
+                          const float* small_step, gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
     GPS_REQUIRE(radii && conics && v_means2d && v_conics && v_colors && v_opacities);
-    GPS_REQUIRE(v_means && v_log_scales && v_quats && v_opac_logit && v_sh_dc);
+    const bool grads_out = v_means != nullptr;
+    GPS_REQUIRE(grads_out ? (v_log_scales && v_quats && v_opac_logit && v_sh_dc) : (small5 != nullptr));
     const bool fuse = adam_param != nullptr && K > 1;
     GPS_REQUIRE(!fuse || (adam_param == sh_rest && adam_m && adam_v));
     GPS_REQUIRE(fuse || K == 1 || v_sh_rest);
     FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
                   0, eps2d, 0.f, 0.f, 0.f};
-    FusedAdam ad = {adam_param, adam_m, adam_v, sc};
+    FusedAdam ad = {};
+    ad.param = adam_param; ad.exp_avg = adam_m; ad.exp_avg_sq = adam_v; ad.sc = sc;
+    if (small5) {
+        // order: means, log_scales, quats, sh_dc, opac_logit -- and they must be THE parameters this kernel reads
+        GPS_REQUIRE(small5[0].param == means && small5[1].param == log_scales && small5[2].param == quats &&
+                    small5[3].param == sh_dc && small5[4].param == opac_logit && small_step);
+        ad.small = 1;
+        for (int k = 0; k < 5; k++) {
+            GPS_REQUIRE(small5[k].exp_avg && small5[k].exp_avg_sq);
+            ad.sp[k] = small5[k].param; ad.sm[k] = small5[k].exp_avg; ad.sv[k] = small5[k].exp_avg_sq;
+            ad.sstep[k] = small_step[k];
+        }
+    }
     const int threads = fuse ? GPS_FUSED_ADAM_THREADS : 256;
     dim3 g(gps_div_up(N, threads)), b(threads);
     const size_t lds = (size_t)threads * (K - 1) * 3 * sizeof(float) * (fuse ? 2 : 1);  // parameter (+ gradient) rows
@@ -318,7 +361,7 @@ int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float* means, co
     return gps::preprocess_bwd_launch(N, K, sh_degree, means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat,
                                       cam_pos, width, height, eps2d, radii, conics, v_means2d, v_conics, v_colors,
                                       v_opacities, v_means, v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest,
-                                      nullptr, nullptr, nullptr, gps::AdamScalars{}, stream);
+                                      nullptr, nullptr, nullptr, gps::AdamScalars{}, nullptr, nullptr, stream);
 }
 
 int gps_gauss_preprocess_bwd_adam(int N, int K, int sh_degree, const float* means, const float* log_scales,
@@ -327,13 +370,18 @@ int gps_gauss_preprocess_bwd_adam(int N, int K, int sh_degree, const float* mean
                                   float eps2d, const int32_t* radii, const float* conics, const float* v_means2d,
                                   const float* v_conics, const float* v_colors, const float* v_opacities, float* v_means,
                                   float* v_log_scales, float* v_quats, float* v_opac_logit, float* v_sh_dc,
-                                  float* v_sh_rest, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
-                                  double beta2, double eps, int step, gps_stream stream) {
+                                  float* v_sh_rest, float* exp_avg, float* exp_avg_sq, double lr,
+                                  const gps_adam_segment* small5, double beta1, double beta2, double eps, int step,
+                                  gps_stream stream) {
     GPS_REQUIRE(K > 1 && sh_rest && exp_avg && exp_avg_sq && step >= 1);
+    float sstep[5] = {0, 0, 0, 0, 0};
+    if (small5)
+        for (int k = 0; k < 5; k++) sstep[k] = gps::adam_scalars(small5[k].lr, beta1, beta2, eps, step).step_size;
     return gps::preprocess_bwd_launch(N, K, sh_degree, means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat,
                                       cam_pos, width, height, eps2d, radii, conics, v_means2d, v_conics, v_colors,
                                       v_opacities, v_means, v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest,
-                                      sh_rest, exp_avg, exp_avg_sq, gps::adam_scalars(lr, beta1, beta2, eps, step), stream);
+                                      sh_rest, exp_avg, exp_avg_sq, gps::adam_scalars(lr, beta1, beta2, eps, step), small5,
+                                      small5 ? sstep : nullptr, stream);
 }
 
 }  // extern "C"

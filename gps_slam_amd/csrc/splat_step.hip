@@ -45,15 +45,8 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
                               a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
                               a->v_opacities, 0, stream);
     if (r != GPS_OK) return r;
-    const bool fuse = a->fuse_sh_rest_adam != 0 && a->K > 1;
-    r = gps::preprocess_bwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
-                                   a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d, a->radii,
-                                   a->conics, a->v_means2d, a->v_conics, a->v_colors, a->v_opacities, a->g_means,
-                                   a->g_log_scales, a->g_quats, a->g_opac_logit, a->g_sh_dc, fuse ? nullptr : a->g_sh_rest,
-                                   fuse ? a->sh_rest : nullptr, fuse ? a->m_sh_rest : nullptr,
-                                   fuse ? a->v_sh_rest : nullptr,
-                                   gps::adam_scalars(a->lr[4], a->beta1, a->beta2, a->adam_eps, adam_step), stream);
-    if (r != GPS_OK) return r;
+    const int mode = a->K > 1 ? a->fuse_sh_rest_adam : 0;
+    const bool fuse = mode >= 1, all = mode >= 2;
     gps_adam_segment seg[6] = {
         {a->means, a->g_means, a->m_means, a->v_means, (int64_t)a->N * 3, a->lr[0]},
         {a->log_scales, a->g_log_scales, a->m_log_scales, a->v_log_scales, (int64_t)a->N * 3, a->lr[1]},
@@ -62,6 +55,17 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
         {a->opac_logit, a->g_opac_logit, a->m_opac_logit, a->v_opac_logit, (int64_t)a->N, a->lr[5]},
         {a->sh_rest, a->g_sh_rest, a->m_sh_rest, a->v_sh_rest, (int64_t)a->N * (a->K - 1) * 3, a->lr[4]},
     };
+    float sstep[5];
+    for (int k = 0; k < 5; k++) sstep[k] = gps::adam_scalars(seg[k].lr, a->beta1, a->beta2, a->adam_eps, adam_step).step_size;
+    r = gps::preprocess_bwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
+                                   a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d, a->radii,
+                                   a->conics, a->v_means2d, a->v_conics, a->v_colors, a->v_opacities,
+                                   all ? nullptr : a->g_means, a->g_log_scales, a->g_quats, a->g_opac_logit, a->g_sh_dc,
+                                   fuse ? nullptr : a->g_sh_rest, fuse ? a->sh_rest : nullptr,
+                                   fuse ? a->m_sh_rest : nullptr, fuse ? a->v_sh_rest : nullptr,
+                                   gps::adam_scalars(a->lr[4], a->beta1, a->beta2, a->adam_eps, adam_step),
+                                   all ? seg : nullptr, all ? sstep : nullptr, stream);
+    if (r != GPS_OK || all) return r;
     return gps_adam_step(seg, fuse ? 5 : 6, a->beta1, a->beta2, a->adam_eps, adam_step, stream);
 }
 

@@ -299,7 +299,7 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
     auto clamped = ref_depth_clamped.defined() ? ref_depth_clamped : clampRefDepth(ref_depth);
     gps_splat_step& st = stepStruct(cam.width, cam.height);
     bindCamera(st, cam, clamped, base_color, cam.image);
-    st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 1 : 0;
+    st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 2 : 0;  // all six tensors stepped inside the backward kernel
     adam_step_ += 1;
     check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");
 }

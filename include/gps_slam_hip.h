@@ -206,7 +206,10 @@ GPS_API int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float *m
 /* gps_gauss_preprocess_bwd with the Adam step of sh_rest applied in the same kernel (what gps_splat_train_step runs when
  * gps_splat_step.fuse_sh_rest_adam is set): sh_rest, exp_avg, exp_avg_sq [N,K-1,3] are updated in place exactly as
  * gps_adam_step would with the gradient gps_gauss_preprocess_bwd computes (bit-identical); v_sh_rest may be NULL (the
- * gradient then never leaves the chip) or a buffer to also receive it.  Other gradients as gps_gauss_preprocess_bwd. */
+ * gradient then never leaves the chip) or a buffer to also receive it.  Other gradients as gps_gauss_preprocess_bwd.
+ * small5 (optional): five segments {means, log_scales, quats, sh_dc, opac_logit} (param = the arrays passed above, with
+ * exp_avg / exp_avg_sq / lr; .grad unused) to be stepped in the same kernel as well -- no separate Adam launch is needed
+ * then, and the five v_* outputs may be NULL. */
 GPS_API int gps_gauss_preprocess_bwd_adam(int N, int K, int sh_degree, const float *means, const float *log_scales,
                                           const float *quats, const float *opac_logit, const float *sh_dc,
                                           float *sh_rest, const float *viewmat, const float *Kmat, const float *cam_pos,
@@ -214,8 +217,8 @@ GPS_API int gps_gauss_preprocess_bwd_adam(int N, int K, int sh_degree, const flo
                                           const float *v_means2d, const float *v_conics, const float *v_colors,
                                           const float *v_opacities, float *v_means, float *v_log_scales, float *v_quats,
                                           float *v_opac_logit, float *v_sh_dc, float *v_sh_rest, float *exp_avg,
-                                          float *exp_avg_sq, double lr, double beta1, double beta2, double eps, int step,
-                                          gps_stream stream);
+                                          float *exp_avg_sq, double lr, const gps_adam_segment *small5, double beta1,
+                                          double beta2, double eps, int step, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* Splat: Gaussian creation helpers (every local_opt_interval frames)  */
@@ -264,9 +267,11 @@ typedef struct {
     float *v_means, *v_log_scales, *v_quats, *v_opac_logit, *v_sh_dc, *v_sh_rest;
     double lr[6]; /* means, log_scales, quats, sh_dc, sh_rest, opac_logit */
     double beta1, beta2, adam_eps;
-    /* 1: gps_splat_train_step applies the Adam step of sh_rest (45 of the 59 parameters) inside the preprocessing
-     * backward kernel -- its gradient never goes to HBM, so g_sh_rest is NOT written.  0: every gradient is written and
-     * all six tensors are stepped by the multi-tensor Adam kernel.  The parameter update is bit-identical either way. */
+    /* 0: every gradient is written and all six tensors are stepped by the multi-tensor Adam kernel.
+     * 1: the Adam step of sh_rest (45 of the 59 parameters) happens inside the preprocessing backward kernel -- its gradient
+     *    never goes to HBM, g_sh_rest is NOT written; the other five tensors go through the Adam kernel.
+     * 2: all six tensors are stepped inside the backward kernel (no Adam launch; no g_* is written).
+     * The parameter update is bit-identical in all three modes. */
     int32_t fuse_sh_rest_adam;
 } gps_splat_step;
 

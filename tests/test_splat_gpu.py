@@ -306,45 +306,64 @@ def test_record_streaming_forward_equals_lds_forward(N, W, H):
         assert d.max().item() < 0.05
 
 
-def test_fused_sh_rest_adam_is_bit_identical_to_separate_step():
-    """gps_gauss_preprocess_bwd_adam (Adam step of sh_rest inside the backward kernel, gradient kept in LDS) must leave
-    exactly the parameter / exp_avg / exp_avg_sq that gps_gauss_preprocess_bwd + gps_adam_step produce, for several steps,
-    and the same other gradients.  N is not a multiple of the workgroup rows (tail tile)."""
+def test_fused_adam_is_bit_identical_to_separate_step():
+    """gps_gauss_preprocess_bwd_adam (Adam step inside the backward kernel: sh_rest on the LDS tiles, optionally the five
+    small tensors per thread) must leave exactly the parameters / exp_avg / exp_avg_sq that gps_gauss_preprocess_bwd +
+    gps_adam_step produce, for several steps, and the same gradients where they are requested.  N is not a multiple of the
+    workgroup rows (tail tile)."""
     import ctypes as C
     from gps_slam_amd import gsplat_ops as ops
-    from gps_slam_amd._lib import check, lib
+    from gps_slam_amd._lib import AdamSegment, check, lib
     N, W, H = 10007, 160, 120
     g, vm, K, c2w = _setup(N, W, H, seed=11)
     sh = T(g["sh"])
-    P = dict(means=T(g["means"]), ls=T(g["log_scales"]), q=T(g["quats"]), ol=T(g["opac_logit"]).view(-1).contiguous(),
-             dc=sh[:, 0].contiguous(), rest=sh[:, 1:].contiguous())
+    names = ("means", "ls", "q", "ol", "dc", "rest")
+    P0 = dict(means=T(g["means"]), ls=T(g["log_scales"]), q=T(g["quats"]), ol=T(g["opac_logit"]).view(-1).contiguous(),
+              dc=sh[:, 0].contiguous(), rest=sh[:, 1:].contiguous())
+    lrs = dict(means=1.6e-4, ls=5e-3, q=1e-3, ol=5e-2, dc=2.5e-3, rest=5e-4)
     vmT, KT, cp = T(vm), T(K), T(c2w[:3, 3].copy())
-    radii, m2, depths, conics, colors, opac = ops.gauss_preprocess_fwd(P["means"], P["ls"], P["q"], P["ol"], P["dc"], P["rest"],
-                                                                      3, vmT, KT, cp, W, H)
     gen = torch.Generator().manual_seed(5)
     rnd = lambda *s: torch.randn(*s, generator=gen).to(_dev())
     v_m2, v_con, v_col, v_op = rnd(N, 2), rnd(N, 3), rnd(N, 4), rnd(N)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
-    # A: separate
-    restA, mA, vA = P["rest"].clone(), torch.zeros_like(P["rest"]), torch.zeros_like(P["rest"])
-    # B: fused
-    restB, mB, vB = P["rest"].clone(), torch.zeros_like(P["rest"]), torch.zeros_like(P["rest"])
-    for step in (1, 2, 3):
-        gA = ops.gauss_preprocess_bwd(P["means"], P["ls"], P["q"], P["ol"], P["dc"], restA, 3, vmT, KT, cp, W, H, 0.3, radii,
-                                      conics, v_m2, v_con, v_col, v_op)
-        ops.adam_step([restA], [gA[5]], [mA], [vA], [5e-4], step)
-        outB = [torch.empty_like(x) for x in gA[:5]]
-        g_restB = torch.empty_like(restB)
-        check(lib.gps_gauss_preprocess_bwd_adam(N, 16, 3, p(P["means"]), p(P["ls"]), p(P["q"]), p(P["ol"]), p(P["dc"]), p(restB),
-                                                p(vmT), p(KT), p(cp), W, H, 0.3, p(radii), p(conics), p(v_m2), p(v_con),
-                                                p(v_col), p(v_op), p(outB[0]), p(outB[1]), p(outB[2]), p(outB[3]), p(outB[4]),
-                                                p(g_restB) if step == 2 else None, p(mB), p(vB), 5e-4, 0.9, 0.999, 1e-15, step,
-                                                st), "gps_gauss_preprocess_bwd_adam")
-        torch.cuda.synchronize()
-        assert torch.equal(restA, restB) and torch.equal(mA, mB) and torch.equal(vA, vB), step
-        for a, b in zip(gA[:5], outB):
-            assert torch.equal(a, b)
-        if step == 2:
-            assert torch.equal(g_restB, gA[5])
-    assert (restA != P["rest"]).any()
+    for fuse_small in (False, True):
+        A = {k: v.clone() for k, v in P0.items()}   # separate kernels
+        B = {k: v.clone() for k, v in P0.items()}   # fused
+        mA, vA = {k: torch.zeros_like(v) for k, v in A.items()}, {k: torch.zeros_like(v) for k, v in A.items()}
+        mB, vB = {k: torch.zeros_like(v) for k, v in B.items()}, {k: torch.zeros_like(v) for k, v in B.items()}
+        stepped = names if fuse_small else ("rest",)
+        for step in (1, 2, 3):
+            # the projected state both paths consume (parameters move every step when the small tensors are stepped)
+            radii, m2, depths, conics, colors, opac = ops.gauss_preprocess_fwd(A["means"], A["ls"], A["q"], A["ol"], A["dc"],
+                                                                              A["rest"], 3, vmT, KT, cp, W, H)
+            gA = ops.gauss_preprocess_bwd(A["means"], A["ls"], A["q"], A["ol"], A["dc"], A["rest"], 3, vmT, KT, cp, W, H, 0.3,
+                                          radii, conics, v_m2, v_con, v_col, v_op)
+            gmap = dict(means=gA[0], ls=gA[1], q=gA[2], ol=gA[3], dc=gA[4], rest=gA[5])
+            ops.adam_step([A[k] for k in stepped], [gmap[k] for k in stepped], [mA[k] for k in stepped],
+                          [vA[k] for k in stepped], [lrs[k] for k in stepped], step)
+            want_g = step == 2 or not fuse_small
+            outB = [torch.empty_like(x) for x in gA[:5]]
+            g_restB = torch.empty_like(B["rest"])
+            small = None
+            if fuse_small:
+                small = (AdamSegment * 5)()
+                for j, k in enumerate(("means", "ls", "q", "dc", "ol")):
+                    small[j].param, small[j].exp_avg, small[j].exp_avg_sq = B[k].data_ptr(), mB[k].data_ptr(), vB[k].data_ptr()
+                    small[j].numel, small[j].lr = B[k].numel(), lrs[k]
+            og = [p(x) if want_g else None for x in outB]
+            check(lib.gps_gauss_preprocess_bwd_adam(N, 16, 3, p(B["means"]), p(B["ls"]), p(B["q"]), p(B["ol"]), p(B["dc"]),
+                                                    p(B["rest"]), p(vmT), p(KT), p(cp), W, H, 0.3, p(radii), p(conics), p(v_m2),
+                                                    p(v_con), p(v_col), p(v_op), og[0], og[1], og[2], og[3], og[4],
+                                                    p(g_restB) if step == 2 else None, p(mB["rest"]), p(vB["rest"]), lrs["rest"],
+                                                    small, 0.9, 0.999, 1e-15, step, st), "gps_gauss_preprocess_bwd_adam")
+            torch.cuda.synchronize()
+            for k in names:
+                assert torch.equal(A[k], B[k]) and torch.equal(mA[k], mB[k]) and torch.equal(vA[k], vB[k]), (fuse_small, step, k)
+            if want_g:
+                for a, b in zip(gA[:5], outB):
+                    assert torch.equal(a, b)
+            if step == 2:
+                assert torch.equal(g_restB, gA[5])
+        for k in stepped:
+            assert (A[k] != P0[k]).any(), k
