@@ -82,6 +82,45 @@ def dominant_kernel_roofline(model, pipe, eng, cams, device, hbm_peak_gbs):
 
 
 def cpu_baseline(seq, W, H, max_seconds=20.0):
+    """CPU baseline of the TSDF-only `recon` loop (BASELINE config[0]).  Preferred: the REFERENCE's own ITMLib CPU engine,
+    oracle/_ref/itm_ref_omp (compiled from the reference sources like upstream, -O3 + OpenMP; the binary travels with the
+    snapshot), on a bounded sample of the same sequence with one OpenMP thread per physical core -> kind "reference".
+    Fallback when the binary is absent: the bit-exact single-thread C restatement -> kind "port"."""
+    from oracle import tsdf_ref as R
+    if os.path.exists(R.BIN_OMP):
+        cores = _physical_cores()
+        probe = R.time_reference(seq, 4, 0.005, 0.02, 0.2, 10.0, threads=cores)
+        per = max(1e-3, probe["seconds"] / probe["frames"])
+        n = int(max(6, min(seq["rgb"].shape[0], 1 + max_seconds / per)))
+        res = R.time_reference(seq, n, 0.005, 0.02, 0.2, 10.0, threads=cores)
+        one = R.time_reference(seq, min(n, 8), 0.005, 0.02, 0.2, 10.0, threads=1)
+        return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": cores, "kind": "reference",
+                "sample": "%d ProcessFrame calls (TSDF fuse + live raycast + ICP maps, tracking off, no Gaussians) of the same "
+                          "%dx%d synthetic sequence by the reference's ITMLib CPU engine (oracle/_ref/itm_ref_omp: g++ -O3 "
+                          "-fopenmp as upstream), OMP_NUM_THREADS=%d, first frame excluded; single thread: %.2f frames/s; "
+                          "host CPU: %s" % (res["frames"], W, H, cores, one["frames"] / one["seconds"], _cpu_name())}
+    return cpu_baseline_port(seq, W, H, max_seconds)
+
+
+def _physical_cores():
+    try:
+        pairs = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip() and phys is not None and core is not None:
+                pairs.add((phys, core)); phys = core = None
+        if pairs:
+            return min(len(pairs), len(os.sched_getaffinity(0)))
+    except OSError:
+        pass
+    return max(1, len(os.sched_getaffinity(0)) // 2)
+
+
+def cpu_baseline_port(seq, W, H, max_seconds=20.0):
     """ProcessFrame of the reference's ITMLib CPU path (config[0]: TSDF-only `recon` loop), timed through the
     bit-exact C restatement (oracle/tsdf_oracle.c; the reference sources do not exist on the GPU box).
     Scalar single-thread port -> cores = 1.  Bounded sample: as many 640x480 frames as fit in ~max_seconds."""

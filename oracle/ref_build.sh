@@ -10,7 +10,7 @@ REF="${GPS_REFERENCE_ROOT:-/root/reference}/InfiniTAM"
 OUT="$HERE/_ref"
 mkdir -p "$OUT/obj"
 [ -d "$REF" ] || { echo "reference not present: $REF" >&2; exit 0; }
-if [ -x "$OUT/itm_ref" ] && [ "$OUT/itm_ref" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT/itm_ref" -nt "$HERE/ref_build.sh" ]; then exit 0; fi
+if [ -x "$OUT/itm_ref" ] && [ -x "$OUT/itm_ref_omp" ] && [ "$OUT/itm_ref_omp" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT/itm_ref_omp" -nt "$HERE/ref_build.sh" ]; then exit 0; fi
 CXX="${CXX:-g++}"
 FLAGS="-O2 -std=c++17 -DCOMPILE_WITHOUT_CUDA -ffp-contract=off -w -I$REF"
 SRCS=(
@@ -43,3 +43,24 @@ wait
 $CXX $FLAGS -c "$HERE/ref_driver.cpp" -o "$OUT/obj/ref_driver.o"
 $CXX -o "$OUT/itm_ref" "$OUT/obj/ref_driver.o" "${objs[@]}" -lpthread
 echo "built $OUT/itm_ref"
+
+# Second binary, built the way upstream builds its CPU path (InfiniTAM/CMakeLists.txt:25, cmake/UseOpenMP.cmake:5-13:
+# -O3 + OpenMP; no -march=native because the binary travels to another host): only used by bench.py's cpu_baseline
+# (timing mode of ref_driver), never by parity tests.
+OFLAGS="-O3 -std=c++17 -DCOMPILE_WITHOUT_CUDA -DWITH_OPENMP -fopenmp -w -I$REF"
+mkdir -p "$OUT/obj_omp"
+oobjs=()
+i=0
+for s in "${SRCS[@]}"; do
+  o="$OUT/obj_omp/$(echo "$s" | md5sum | cut -c1-8)_$(basename "${s%.cpp}").o"
+  oobjs+=("$o")
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ]; then
+    $CXX $OFLAGS -c "$s" -o "$o" &
+    i=$((i+1))
+    if [ $((i % 8)) -eq 0 ]; then wait; fi
+  fi
+done
+wait
+$CXX $OFLAGS -c "$HERE/ref_driver.cpp" -o "$OUT/obj_omp/ref_driver.o"
+$CXX -fopenmp -o "$OUT/itm_ref_omp" "$OUT/obj_omp/ref_driver.o" "${oobjs[@]}" -lpthread
+echo "built $OUT/itm_ref_omp"

@@ -8,7 +8,9 @@
 // GetFreeImage/GetFreeVertex).  Private render-state members are read through the
 // usual `#define private public` test hack -- no reference source is modified.
 //
-// usage: itm_ref <input.bin> <output.bin>
+// usage: itm_ref <input.bin> <output.bin>          dump mode (parity fixtures)
+//        itm_ref <input.bin> - time              timing mode: ProcessFrame loop only, prints one JSON line
+//                                                (frames after the first; the CPU baseline of bench.py)
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +25,10 @@
 #include <algorithm>
 #include <stdexcept>
 #include <limits>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define private public
 #define protected public
@@ -37,6 +43,7 @@ using namespace ITMLib;
 static FILE *g_out;
 
 static void chunk(const char *name, int frame, const void *data, int64_t nbytes) {
+    if (!g_out) return;  // timing mode
     char nm[32];
     memset(nm, 0, sizeof(nm));
     strncpy(nm, name, 31);
@@ -98,7 +105,7 @@ int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 2; }
     FILE *in = fopen(argv[1], "rb");
     if (!in) { perror("input"); return 2; }
-    g_out = fopen(argv[2], "wb");
+    g_out = std::string(argv[2]) == "-" ? nullptr : fopen(argv[2], "wb");
     Header h;
     if (fread(&h, sizeof(h), 1, in) != 1 || h.magic != 0x47505331) { fprintf(stderr, "bad header\n"); return 2; }
     const int P = h.W * h.H;
@@ -146,6 +153,23 @@ int main(int argc, char **argv) {
     }
     fclose(in);
     eng->gtC2wPoses = poses;
+
+    if (argc >= 4 && std::string(argv[3]) == "time") {
+        // CLIEngine::ProcessFrame loop of the TSDF-only `recon` mode (slam/TsdfFusion/CLIEngine.cpp:34-58); the first
+        // frame (bulk allocation) is excluded, as BASELINE.md prescribes
+        struct timespec t0, t1;
+        eng->ProcessFrame(rgbs[0], depths[0]);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int f = 1; f < h.nframes; f++) eng->ProcessFrame(rgbs[f], depths[f]);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        int threads = 1;
+#ifdef _OPENMP
+        threads = omp_get_max_threads();
+#endif
+        printf("{\"frames\": %d, \"seconds\": %.6f, \"threads\": %d}\n", h.nframes - 1, sec, threads);
+        return 0;
+    }
 
     for (int f = 0; f < h.nframes; f++) {
         eng->ProcessFrame(rgbs[f], depths[f]);

@@ -16,6 +16,42 @@ def available():
     return os.path.exists(BIN)
 
 
+BIN_OMP = os.path.join(_HERE, "_ref", "itm_ref_omp")
+
+
+def _write_input(f, seq, n, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0):
+    W, H = seq["W"], seq["H"]
+    f.write(struct.pack("<6i8f", 0x47505331, W, H, n, len(free_views), dump_vba_every, seq["fx"], seq["fy"],
+                        seq["cx"], seq["cy"], voxel, mu, vfmin, vfmax))
+    for k in range(n):
+        rgba = np.concatenate([seq["rgb"][k], np.full((H, W, 1), 255, np.uint8)], -1)
+        f.write(np.ascontiguousarray(rgba).tobytes())
+        f.write(np.ascontiguousarray(seq["depth"][k].astype(np.int16)).tobytes())
+        f.write(np.ascontiguousarray(seq["c2w"][k], dtype=np.float32).tobytes())
+    for fr, c2w in free_views:
+        f.write(struct.pack("<i", fr))
+        f.write(np.ascontiguousarray(c2w, dtype=np.float32).tobytes())
+
+
+def time_reference(seq, n_frames, voxel, mu, vfmin, vfmax, threads=None, openmp=True):
+    """Time the reference's own ProcessFrame loop (TSDF-only `recon` mode) on the first n_frames of seq with the timing
+    mode of ref_driver.  openmp=True uses itm_ref_omp (built like upstream: -O3 + OpenMP) with `threads` OpenMP threads.
+    -> dict(frames, seconds, threads) or None if the binary is not there."""
+    import json
+    binary = BIN_OMP if openmp else BIN
+    if not os.path.exists(binary):
+        return None
+    env = dict(os.environ)
+    if threads:
+        env["OMP_NUM_THREADS"] = str(int(threads))
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "in.bin")
+        with open(fin, "wb") as f:
+            _write_input(f, seq, n_frames, voxel, mu, vfmin, vfmax)
+        out = subprocess.check_output([binary, fin, "-", "time"], env=env, timeout=600).decode()
+    return json.loads(out.strip().splitlines()[-1])
+
+
 def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0):
     """seq: dict from tests.synth.make_sequence; free_views: list of (frame_idx, c2w[4,4]).
     returns {(name, frame): np.ndarray(bytes)} decoded by `decode`."""
