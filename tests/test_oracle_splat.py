@@ -274,3 +274,30 @@ def test_gaussian_parallel_backward_box_semantics():
     assert inside.sum() > 20
     np.testing.assert_allclose(got[2][inside], exact[2][inside], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(got[3][inside], exact[3][inside], rtol=1e-3, atol=1e-4)
+
+
+def test_oracle_reproduces_committed_splat_golden():
+    """tests/golden/splat_96x64_n300.npz (made by tests/golden/make_splat_golden.py from this oracle after the cross-checks
+    above) freezes the restatement: integer outputs exactly, float outputs to a few ulp (libm differences between hosts)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "splat_96x64_n300.npz"))
+    Wg, Hg, TSg = int(G["W"]), int(G["H"]), int(G["TS"])
+    twg, thg = (Wg + TSg - 1) // TSg, (Hg + TSg - 1) // TSg
+    scales = np.exp(G["log_scales"]).astype(np.float32)
+    radii, m2, depths, conics = orc.proj_fwd(G["means"], G["quats"], scales, G["viewmat"], G["K"], Wg, Hg)
+    radii = np.minimum(radii, 100).astype(np.int32)
+    assert np.array_equal(radii, G["radii"])
+    np.testing.assert_allclose(m2, G["means2d"], rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(conics, G["conics"], rtol=2e-5, atol=1e-7)
+    tpg, ids, flat, ggs, gst, offs = orc.isect_tiles(G["means2d"], G["radii"], TSg, twg, thg)
+    for a, b in ((tpg, "tiles_per_gauss"), (ids, "isect_ids"), (flat, "flatten_ids"), (ggs, "group_gs_ids"),
+                 (gst, "group_starts"), (offs, "offsets")):
+        assert np.array_equal(a, G[b]), b
+    rc, ra, _ = orc.raster_ges_fwd(G["means2d"], G["conics"], G["colors"], G["opac"], G["ref_depth"], Wg, Hg, TSg,
+                                   G["offsets"], G["flatten_ids"], 0.1)
+    np.testing.assert_allclose(rc, G["render_colors"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ra, G["weight_sum"], rtol=1e-5, atol=1e-6)
+    got = orc.raster_ges_bwd_gs(G["means2d"], G["conics"], G["colors"], G["opac"], G["radii"], G["ref_depth"], Wg, Hg,
+                                G["group_gs_ids"], G["group_starts"], 0.1, G["v_rc"], G["v_ra"])
+    for a, name in zip(got, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        np.testing.assert_allclose(a, G[name], rtol=1e-4, atol=1e-5 * np.abs(G[name]).max(), err_msg=name)

@@ -367,3 +367,40 @@ def test_fused_adam_is_bit_identical_to_separate_step():
                 assert torch.equal(g_restB, gA[5])
         for k in stepped:
             assert (A[k] != P0[k]).any(), k
+
+
+def test_hip_chain_matches_committed_splat_golden():
+    """The HIP operators on the inputs of tests/golden/splat_96x64_n300.npz against the frozen oracle outputs (no oracle
+    call here: fixture only).  Binning exactly; floats at the documented tolerances."""
+    import os
+    from gps_slam_amd import gsplat_ops as ops
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "splat_96x64_n300.npz"))
+    W, H, TS = int(G["W"]), int(G["H"]), int(G["TS"])
+    tw, th = (W + TS - 1) // TS, (H + TS - 1) // TS
+    scales = np.exp(G["log_scales"]).astype(np.float32)
+    radii, m2, depths, conics = ops.fully_fused_projection_fwd(T(G["means"]), T(G["quats"]), T(scales), T(G["viewmat"])[None],
+                                                               T(G["K"])[None], W, H)
+    radii = radii.clamp_max(100)
+    assert np.array_equal(N_(radii)[0], G["radii"])
+    np.testing.assert_allclose(N_(m2)[0], G["means2d"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(N_(conics)[0], G["conics"], rtol=2e-3, atol=1e-6)
+    # downstream operators on the FIXTURE's projected state, so that every stage is compared on identical inputs
+    isect = ops.isect_tiles_no_depth(T(G["means2d"])[None], T(G["radii"])[None], TS, tw, th, want_isect_ids=True)
+    tpg, ids, flat, ggs, gst, offs = isect.trimmed()
+    assert np.array_equal(N_(tpg)[0], G["tiles_per_gauss"]) and np.array_equal(N_(ids), G["isect_ids"])
+    assert np.array_equal(N_(flat), G["flatten_ids"]) and np.array_equal(N_(ggs), G["group_gs_ids"])
+    assert np.array_equal(N_(gst), G["group_starts"]) and np.array_equal(N_(offs).reshape(-1), G["offsets"].reshape(-1))
+    tref = T(G["ref_depth"])[None, ..., None]
+    rc, ra, _ = ops.rasterize_to_pixels_fwd_ges(T(G["means2d"])[None], T(G["conics"])[None], T(G["colors"])[None],
+                                                T(G["opac"])[:, None], tref, W, H, TS, isect, 0.1)
+    for got, ref in ((N_(rc)[0], G["render_colors"]), (N_(ra)[0, ..., 0], G["weight_sum"])):
+        bad = np.abs(got - ref) > (2e-4 * np.abs(ref) + 2e-4)
+        assert bad.mean() <= 2e-4 and np.abs(got - ref).max() < 0.05
+    o = ops.rasterize_to_pixels_bwd_ges_gs_parallel(T(G["means2d"])[None], T(G["conics"])[None], T(G["colors"])[None],
+                                                    T(G["opac"])[:, None], T(G["radii"])[None], tref, W, H, isect, 0.1,
+                                                    T(G["v_rc"])[None], T(G["v_ra"])[None, ..., None])
+    for got, name in zip(o, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        ref = G[name]
+        got = N_(got).reshape(ref.shape)
+        bad = np.abs(got - ref) > (2e-3 * np.abs(ref) + 5e-4 * np.abs(ref).max())
+        assert bad.mean() < 2e-3, (name, bad.mean())
