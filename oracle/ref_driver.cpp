@@ -9,6 +9,7 @@
 // usual `#define private public` test hack -- no reference source is modified.
 //
 // usage: itm_ref <input.bin> <output.bin>          dump mode (parity fixtures)
+//        itm_ref <input.bin> <output.bin> track    same dump with the default tracker ON (poses estimated, not given)
 //        itm_ref <input.bin> - time              timing mode: ProcessFrame loop only, prints one JSON line
 //                                                (frames after the first; the CPU baseline of bench.py)
 #include <cmath>
@@ -127,7 +128,10 @@ int main(int argc, char **argv) {
 
     Vector2i dims(h.W, h.H);
     Engine *eng = new Engine(settings, calib, dims, dims);
-    eng->turnOffTracking();
+    // "track" mode keeps the default tracker of ITMLibSettings (depth-only extended tracker) active; otherwise poses come
+    // from gtC2wPoses exactly as slam/InfiniTAM_tools.cpp:59-62 sets the engine up for use_gt_pose: true
+    const bool track_mode = argc >= 4 && std::string(argv[3]) == "track";
+    if (!track_mode) eng->turnOffTracking();
 
     std::vector<ITMUChar4Image *> rgbs(h.nframes);
     std::vector<ITMShortImage *> depths(h.nframes);
@@ -177,6 +181,7 @@ int main(int argc, char **argv) {
         ORUtils::Matrix4<float> M = ts->pose_d->GetM(), invM = ts->pose_d->GetInvM();
         chunk("M", f, M.m, 64);
         chunk("invM", f, invM.m, 64);
+        if (track_mode) { float sc[2] = {ts->trackerScore, (float)ts->framesProcessed}; chunk("trk_score", f, sc, 8); }
         ITMRenderState_VH *rs = (ITMRenderState_VH *)eng->renderState_live;
         ITMScene<ITMVoxel, ITMVoxelIndex> *scene = eng->GetScene();
         int32_t counts[3] = {rs->noVisibleEntries, scene->localVBA.lastFreeBlockId, scene->index.GetLastFreeExcessListId()};

@@ -64,12 +64,25 @@ typedef struct {
     V2 *fv_minmax;
     V4 *fv_raycast;
     uint8_t *fv_colour; /* uchar4 */
+    /* tracking state (ITMTrackingState): pose_d, pose_pointCloud, age_pointCloud, framesProcessed */
+    float pose_M[16], pose_invM[16], pose_pc_M[16];
+    int age_point_cloud, trk_frames;
+    float trk_diag[16];
+    float *trk_scratch;
 } Tsdf;
 
 /* ---------------- construction / reset: Engines/Reconstruction/CPU/ITMSceneReconstructionEngine_CPU.tpp:26-50 ------------- */
 static Voxel empty_voxel(void) { Voxel v; memset(&v, 0, sizeof(v)); v.sdf = 32767; return v; }
 
+static void tracking_reset(Tsdf *t) { /* ITMTrackingState::Reset (Objects/Tracking/ITMTrackingState.h:92-99) */
+    for (int i = 0; i < 16; i++) t->pose_M[i] = t->pose_invM[i] = t->pose_pc_M[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    t->age_point_cloud = -1;
+    t->trk_frames = 0;
+    memset(t->trk_diag, 0, sizeof(t->trk_diag));
+}
+
 ORC_API void orc_tsdf_reset(Tsdf *t) {
+    tracking_reset(t);
     Voxel e = empty_voxel();
     for (size_t i = 0; i < (size_t)t->n_blocks * BLK3; i++) t->vba[i] = e;
     for (int i = 0; i < t->n_blocks; i++) t->vba_alloc_list[i] = i;
@@ -778,8 +791,349 @@ ORC_API void orc_tsdf_free_raycast(Tsdf *t, const float *M, const float *invM) {
     render_colour(t, t->fv_raycast, t->fv_colour);
 }
 
-/* accessors for the python side */
+/* ======================================================================================================================
+ * ExtendedTracker, depth only -- the tracker ITMLibSettings.cpp:54-57 configures ("type=extended,levels=rrbb,useDepth=1,
+ * minstep=1e-4,outlierSpaceC=0.1,outlierSpaceF=0.004,numiterC=20,numiterF=50,tukeyCutOff=8,framesToSkip=20,
+ * framesToWeight=50") and ITMBasicEngine runs when use_gt_pose is false.
+ *   ITMLib/Trackers/Interface/ITMExtendedTracker.cpp:143-177 (SetupLevels), :216-268 (PrepareForEvaluation),
+ *   :293-375 (ComputeDelta / HasConverged / ApplyDelta), :470-665 (TrackCamera), :377-468 (UpdatePoseQuality: score only);
+ *   Trackers/Shared/ITMExtendedTracker_Shared.h:51-143, 298-328 (per point); Trackers/CPU/ITMExtendedTracker_CPU.cpp:46-156
+ *   (accumulation in scan order); Engines/LowLevel/Shared/ITMLowLevelEngine_Shared.h:48-69 (depth pyramid);
+ *   Utils/ITMPixelUtils.h:78-106 (bilinear with holes); ORUtils/Cholesky.h.
+ * Stateless: everything comes in through arguments, so the same function pins the HIP tracker in tests.
+ * ==================================================================================================================== */
+#define TRK_MAX_LEVELS 8
+enum { TRK_ROTATION = 0, TRK_TRANSLATION = 1, TRK_BOTH = 2, TRK_NONE = 3 };
+
+typedef struct {
+    int n_levels;
+    int iter_type[TRK_MAX_LEVELS];    /* level 0 = finest */
+    int n_iter[TRK_MAX_LEVELS];
+    float space_thresh[TRK_MAX_LEVELS];
+    float term_thresh, tukey_cutoff, vf_min, vf_max;
+    int frames_to_skip, frames_to_weight;
+} TrackCfg;
+
+/* levels string as in the config ("rrbb": parsed from the END, so level 0 = 'b'); SetupLevels' float stepping */
+ORC_API void orc_track_config(const char *levels, int num_iter_coarse, int num_iter_fine, float thresh_coarse,
+                              float thresh_fine, float term_thresh, float tukey, int frames_to_skip, int frames_to_weight,
+                              float vf_min, float vf_max, TrackCfg *c) {
+    int n = (int)strlen(levels);
+    c->n_levels = n;
+    for (int i = n - 1, k = 0; i >= 0; --i, ++k)
+        c->iter_type[k] = levels[i] == 'r' ? TRK_ROTATION : levels[i] == 't' ? TRK_TRANSLATION : levels[i] == 'b' ? TRK_BOTH : TRK_NONE;
+    {
+        float step = (float)(num_iter_coarse - num_iter_fine) / (float)(n - 1);
+        float val = (float)num_iter_coarse;
+        for (int l = n - 1; l >= 0; l--) { c->n_iter[l] = (int)round(val); val -= step; }
+    }
+    {
+        float step = (float)(thresh_coarse - thresh_fine) / (float)(n - 1);
+        float val = thresh_coarse;
+        for (int l = n - 1; l >= 0; l--) { c->space_thresh[l] = val; val -= step; }
+    }
+    c->term_thresh = term_thresh; c->tukey_cutoff = tukey; c->frames_to_skip = frames_to_skip;
+    c->frames_to_weight = frames_to_weight; c->vf_min = vf_min; c->vf_max = vf_max;
+}
+
+ORC_API void orc_filter_subsample_with_holes(const float *in, int w_in, int h_in, float *out) {
+    int w = w_in / 2, h = h_in / 2;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+        float acc = 0.0f, good = 0.0f, v;
+        v = in[(2 * x + 0) + (2 * y + 0) * w_in]; if (v > 0.0f) { acc += v; good++; }
+        v = in[(2 * x + 1) + (2 * y + 0) * w_in]; if (v > 0.0f) { acc += v; good++; }
+        v = in[(2 * x + 0) + (2 * y + 1) * w_in]; if (v > 0.0f) { acc += v; good++; }
+        v = in[(2 * x + 1) + (2 * y + 1) * w_in]; if (v > 0.0f) { acc += v; good++; }
+        if (good > 0) acc /= good;
+        out[x + y * w] = acc;
+    }
+}
+
+static V4 bilinear_with_holes(const V4 *src, float px, float py, int W) {
+    const short ix = (short)floorf(px), iy = (short)floorf(py);
+    const float dx = px - (float)ix, dy = py - (float)iy;
+    const V4 a = src[ix + iy * W], b = src[(ix + 1) + iy * W], c = src[ix + (iy + 1) * W], d = src[(ix + 1) + (iy + 1) * W];
+    V4 r;
+    if (a.w < 0 || b.w < 0 || c.w < 0 || d.w < 0) { r.x = 0; r.y = 0; r.z = 0; r.w = -1.0f; return r; }
+    r.x = (a.x * (1.0f - dx) * (1.0f - dy) + b.x * dx * (1.0f - dy) + c.x * (1.0f - dx) * dy + d.x * dx * dy);
+    r.y = (a.y * (1.0f - dx) * (1.0f - dy) + b.y * dx * (1.0f - dy) + c.y * (1.0f - dx) * dy + d.y * dx * dy);
+    r.z = (a.z * (1.0f - dx) * (1.0f - dy) + b.z * dx * (1.0f - dy) + c.z * (1.0f - dx) * dy + d.z * dx * dy);
+    r.w = (a.w * (1.0f - dx) * (1.0f - dy) + b.w * dx * (1.0f - dy) + c.w * (1.0f - dx) * dy + d.w * dx * dy);
+    return r;
+}
+
+/* computePerPointGH_exDepth_Ab; returns 0 if the point does not contribute.  A has 6 (both) or 3 entries. */
+static int track_point_Ab(float *A, float *b, float *depth_weight, int x, int y, float depth, const float *view_intr,
+                          int sceneW, int sceneH, const float *scene_intr, const float *approxInvPose, const float *scenePose,
+                          const V4 *points, const V4 *normals, float space_thresh, const TrackCfg *c, int iter_type,
+                          int use_weights) {
+    *depth_weight = 0;
+    if (depth <= 1e-8f) return 0;
+    V4 p, q;
+    p.x = depth * (((float)x - view_intr[2]) / view_intr[0]);
+    p.y = depth * (((float)y - view_intr[3]) / view_intr[1]);
+    p.z = depth; p.w = 1.0f;
+    p = m4_mul_v4(approxInvPose, p); p.w = 1.0f;
+    q = m4_mul_v4(scenePose, p);
+    if (q.z <= 0.0f) return 0;
+    const float u = scene_intr[0] * q.x / q.z + scene_intr[2];
+    const float v = scene_intr[1] * q.y / q.z + scene_intr[3];
+    if (!((u >= 0.0f) && (u <= sceneW - 2) && (v >= 0.0f) && (v <= sceneH - 2))) return 0;
+    const V4 cp = bilinear_with_holes(points, u, v, sceneW);
+    if (cp.w < 0.0f) return 0;
+    const float dx = cp.x - p.x, dy = cp.y - p.y, dz = cp.z - p.z;
+    const float dist = dx * dx + dy * dy + dz * dz;
+    if (dist > c->tukey_cutoff * space_thresh) return 0;
+    const V4 n = bilinear_with_holes(normals, u, v, sceneW);
+    float w = 1.0f - (depth - c->vf_min) / (c->vf_max - c->vf_min);
+    w = w > 0.0f ? w : 0.0f;  /* MAX(0.0f, .) */
+    w *= w;
+    if (use_weights) {
+        if (cp.w < c->frames_to_skip) return 0;
+        w *= (cp.w - c->frames_to_skip) / c->frames_to_weight;
+    }
+    *depth_weight = w;
+    *b = n.x * dx + n.y * dy + n.z * dz;
+    if (iter_type == TRK_ROTATION || iter_type == TRK_BOTH) {
+        A[0] = +p.z * n.y - p.y * n.z;
+        A[1] = -p.z * n.x + p.x * n.z;
+        A[2] = +p.y * n.x - p.x * n.y;
+        if (iter_type == TRK_BOTH) { A[3] = n.x; A[4] = n.y; A[5] = n.z; }
+    } else {
+        A[0] = n.x; A[1] = n.y; A[2] = n.z;
+    }
+    return 1;
+}
+
+static float trk_rho(float r, float h) { float t = fabsf(r) - h; t = t > 0.0f ? t : 0.0f; return r * r - t * t; }
+static float trk_rho_deriv(float r, float h) { float cl = r < -h ? -h : (r > h ? h : r); return 2.0f * cl; }
+static float trk_rho_deriv2(float r, float h) { return fabsf(r) < h ? 2.0f : 0.0f; }
+
+/* ITMExtendedTracker_CPU::ComputeGandH_Depth: scan-order float accumulation; hessian is 6x6 (only noPara x noPara filled) */
+ORC_API int orc_track_gh_depth(const float *depth, int vw, int vh, const float *view_intr, const V4 *points, const V4 *normals,
+                               int sw, int sh, const float *scene_intr, const float *approxInvPose, const float *scenePose,
+                               const TrackCfg *c, int level, int frames_processed, float *f_out, float *nabla, float *hessian) {
+    const int iter_type = c->iter_type[level];
+    if (iter_type == TRK_NONE) return 0;
+    const int short_it = iter_type != TRK_BOTH;
+    const int noPara = short_it ? 3 : 6, noParaSQ = short_it ? 6 : 21;
+    float sumH[21], sumN[6], sumF = 0.0f;
+    int n_valid = 0;
+    memset(sumH, 0, sizeof(sumH)); memset(sumN, 0, sizeof(sumN));
+    const int use_weights = frames_processed >= 100;
+    const float thr = c->space_thresh[level];
+    for (int y = 0; y < vh; y++) for (int x = 0; x < vw; x++) {
+        float A[6], b, w;
+        if (!track_point_Ab(A, &b, &w, x, y, depth[x + y * vw], view_intr, sw, sh, scene_intr, approxInvPose, scenePose, points,
+                            normals, thr, c, iter_type, use_weights)) continue;
+        n_valid++;
+        sumF += trk_rho(b, thr) * w;
+        for (int r = 0, counter = 0; r < noPara; r++) {
+            sumN[r] += trk_rho_deriv(b, thr) * w * A[r];
+            for (int cc = 0; cc <= r; cc++, counter++) sumH[counter] += trk_rho_deriv2(b, thr) * w * A[r] * A[cc];
+        }
+    }
+    (void)noParaSQ;
+    for (int r = 0, counter = 0; r < noPara; r++) for (int cc = 0; cc <= r; cc++, counter++) hessian[r + cc * 6] = sumH[counter];
+    for (int r = 0; r < noPara; ++r) for (int cc = r + 1; cc < noPara; cc++) hessian[r + cc * 6] = hessian[cc + r * 6];
+    memcpy(nabla, sumN, noPara * sizeof(float));
+    *f_out = sumF;
+    return n_valid;
+}
+
+/* ORUtils::Cholesky (GenericCholesky<float>) */
+typedef struct { float ch[36]; int size; } Chol;
+static void chol_init(Chol *k, const float *mat, int size) {
+    k->size = size;
+    for (int i = 0; i < size * size; i++) k->ch[i] = mat[i];
+    for (int c = 0; c < size; c++) {
+        float inv_diag = 1;
+        for (int r = c; r < size; r++) {
+            float val = k->ch[c + r * size];
+            for (int c2 = 0; c2 < c; c2++) val -= k->ch[c + c2 * size] * k->ch[c2 + r * size];
+            if (r == c) { k->ch[c + r * size] = val; inv_diag = 1.0f / val; }
+            else { k->ch[r + c * size] = val; k->ch[c + r * size] = val * inv_diag; }
+        }
+    }
+}
+static void chol_backsub(const Chol *k, float *result, const float *v) {
+    const int size = k->size;
+    float y[6];
+    for (int i = 0; i < size; i++) {
+        float val = v[i];
+        for (int j = 0; j < i; j++) val -= k->ch[j + i * size] * y[j];
+        y[i] = val;
+    }
+    for (int i = 0; i < size; i++) y[i] /= k->ch[i + i * size];
+    for (int i = size - 1; i >= 0; i--) {
+        float val = y[i];
+        for (int j = i + 1; j < size; j++) val -= k->ch[i + j * size] * result[j];
+        result[i] = val;
+    }
+}
+static float chol_det(const Chol *k) {
+    float ret = 1.0f;
+    for (int i = 0; i < k->size; ++i) ret *= k->ch[i + i * k->size];
+    return ret * ret;
+}
+
+static void m4_mul(const float *a, const float *b, float *out) { /* ORUtils/Matrix.h Matrix4 operator* : out = a * b */
+    float r[16];
+    for (int col = 0; col < 4; col++) for (int row = 0; row < 4; row++) {
+        float acc = 0;
+        for (int k = 0; k < 4; k++) acc += a[k * 4 + row] * b[col * 4 + k];
+        r[col * 4 + row] = acc;
+    }
+    memcpy(out, r, sizeof(r));
+}
+
+/* pose_d->SetInvM(m); Coerce(); -> M, invM (ORUtils layout in and out) */
+static void pose_set_invM_coerce(const float *invM_in, float *M, float *invM) {
+    float rm[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) rm[r * 4 + c] = invM_in[c * 4 + r];
+    orc_pose_from_c2w(rm, M, invM);
+}
+
+/* ITMExtendedTracker::TrackCamera for useDepth && !useColour.
+ * depth0: view->depth [H*W] (metres, <= 0 invalid); points/normals: trackingState->pointCloud (CreateICPMaps output, full
+ * resolution); scenePose = pose_pointCloud->GetM(); pose_M in/out = pose_d->GetM(); pose_invM out.
+ * diag[0..n_levels-1] = iterations run per level, diag[8] = noValidPoints of the last accepted evaluation,
+ * diag[9] = its f, diag[10] = trackerScore (finalResidual_v2).  scratch: >= (W/2)*(H/2)*4/3 floats.
+ * Returns the tracker-level framesProcessed to carry to the next call. */
+ORC_API int orc_track_camera(int W, int H, const float *intr /* fx fy cx cy */, const float *depth0, const V4 *points,
+                             const V4 *normals, const float *scenePose, float *pose_M, float *pose_invM, const TrackCfg *c,
+                             int frames_processed, float *scratch, float *diag) {
+    /* PrepareForEvaluation: depth pyramid; intrinsics halve per level; the scene side always stays at level 0 */
+    const float *dl[TRK_MAX_LEVELS];
+    int lw[TRK_MAX_LEVELS], lh[TRK_MAX_LEVELS];
+    float lintr[TRK_MAX_LEVELS][4];
+    dl[0] = depth0; lw[0] = W; lh[0] = H;
+    memcpy(lintr[0], intr, 16);
+    float *sp = scratch;
+    for (int l = 1; l < c->n_levels; l++) {
+        lw[l] = lw[l - 1] / 2; lh[l] = lh[l - 1] / 2;
+        orc_filter_subsample_with_holes(dl[l - 1], lw[l - 1], lh[l - 1], sp);
+        dl[l] = sp; sp += lw[l] * lh[l];
+        for (int k = 0; k < 4; k++) lintr[l][k] = lintr[l - 1][k] * 0.5f;
+    }
+    float hessian_good[36], nabla_good[6], hessian_depth_good[36], f_depth_good = 0;
+    int nvalid_depth_good = 0;
+    memset(hessian_good, 0, sizeof(hessian_good)); memset(nabla_good, 0, sizeof(nabla_good));
+    memset(hessian_depth_good, 0, sizeof(hessian_depth_good));
+    float M[16], invM[16];
+    memcpy(M, pose_M, 64);
+    orc_mat4_inv(M, invM);
+    int last_type = TRK_NONE;
+    for (int k = 0; k < 16; k++) diag[k] = 0;
+    for (int level = c->n_levels - 1; level >= 0; level--) {
+        const int it = c->iter_type[level];
+        if (it == TRK_NONE) continue;
+        last_type = it;
+        float approxInvPose[16], lastGoodM[16], lastGoodInvM[16];
+        memcpy(approxInvPose, invM, 64);
+        memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
+        float f_old = 3.402823466e+38f, lambda = 1.0f;
+        for (int iter = 0; iter < c->n_iter[level]; iter++) {
+            float hessian_depth[36], nabla_depth[6], f_depth = 0.f;
+            memset(hessian_depth, 0, sizeof(hessian_depth)); memset(nabla_depth, 0, sizeof(nabla_depth));
+            int nvalid = orc_track_gh_depth(dl[level], lw[level], lh[level], lintr[level], points, normals, W, H, lintr[0],
+                                            approxInvPose, scenePose, c, level, frames_processed, &f_depth, nabla_depth,
+                                            hessian_depth);
+            if (nvalid > 100) {
+                for (int i = 0; i < 36; ++i) hessian_depth[i] /= nvalid;
+                for (int i = 0; i < 6; ++i) nabla_depth[i] /= nvalid;
+                f_depth /= nvalid;
+            } else {
+                f_depth = 3.402823466e+38f;
+            }
+            diag[level] += 1;
+            if ((nvalid <= 0) || (f_depth >= f_old)) {
+                memcpy(M, lastGoodM, 64); memcpy(invM, lastGoodInvM, 64);
+                memcpy(approxInvPose, invM, 64);
+                lambda *= 10.0f;
+            } else {
+                memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
+                f_old = f_depth;
+                memcpy(hessian_good, hessian_depth, sizeof(hessian_good));
+                memcpy(nabla_good, nabla_depth, sizeof(nabla_good));
+                lambda /= 10.0f;
+                nvalid_depth_good = nvalid; f_depth_good = f_depth;
+                memcpy(hessian_depth_good, hessian_depth, sizeof(hessian_depth));
+            }
+            float A[36];
+            for (int i = 0; i < 36; ++i) A[i] = hessian_good[i];
+            for (int i = 0; i < 6; ++i) A[i + i * 6] *= 1.0f + lambda;
+            float step[6] = {0, 0, 0, 0, 0, 0};
+            Chol ch;
+            if (it != TRK_BOTH) {
+                float small[9];
+                for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) small[r + cc * 3] = A[r + cc * 6];
+                chol_init(&ch, small, 3);
+            } else {
+                chol_init(&ch, A, 6);
+            }
+            chol_backsub(&ch, step, nabla_good);
+            float s6[6] = {0, 0, 0, 0, 0, 0};
+            if (it == TRK_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
+            else if (it == TRK_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
+            else { for (int i = 0; i < 6; i++) s6[i] = step[i]; }
+            float Tinc[16];
+            Tinc[0 * 4 + 0] = 1.0f;   Tinc[1 * 4 + 0] = s6[2];  Tinc[2 * 4 + 0] = -s6[1]; Tinc[3 * 4 + 0] = s6[3];
+            Tinc[0 * 4 + 1] = -s6[2]; Tinc[1 * 4 + 1] = 1.0f;   Tinc[2 * 4 + 1] = s6[0];  Tinc[3 * 4 + 1] = s6[4];
+            Tinc[0 * 4 + 2] = s6[1];  Tinc[1 * 4 + 2] = -s6[0]; Tinc[2 * 4 + 2] = 1.0f;   Tinc[3 * 4 + 2] = s6[5];
+            Tinc[0 * 4 + 3] = 0.0f;   Tinc[1 * 4 + 3] = 0.0f;   Tinc[2 * 4 + 3] = 0.0f;   Tinc[3 * 4 + 3] = 1.0f;
+            m4_mul(Tinc, approxInvPose, approxInvPose);
+            pose_set_invM_coerce(approxInvPose, M, invM);
+            memcpy(approxInvPose, invM, 64);
+            int converged = 1;
+            for (int i = 0; i < 6; i++) if (fabs(step[i]) > c->term_thresh) { converged = 0; break; }
+            if (converged) break;
+        }
+    }
+    memcpy(pose_M, M, 64); memcpy(pose_invM, invM, 64);
+    /* UpdatePoseQuality: the residual score; the SVM verdict only feeds failure modes that are off by default
+     * (ITMLibSettings.cpp:42 behaviourOnFailure = FAILUREMODE_IGNORE) */
+    {
+        int n_max = 0;
+        for (int i = 0; i < W * H; i++) if (depth0[i] > 0.0f) n_max++;  /* CountValidDepths */
+        float score = sqrtf(((float)nvalid_depth_good * f_depth_good + (float)(n_max - nvalid_depth_good) * c->space_thresh[0]) /
+                            (float)n_max);
+        diag[8] = (float)nvalid_depth_good; diag[9] = f_depth_good; diag[10] = score;
+        float det = 0.0f;
+        if (last_type == TRK_BOTH) { Chol ch; chol_init(&ch, hessian_depth_good, 6); det = chol_det(&ch); if (isnan(det)) det = 0.0f; }
+        diag[11] = det;
+    }
+    return frames_processed;
+}
+
 #define GETTER(name, type, expr) ORC_API type orc_tsdf_##name(Tsdf *t) { return expr; }
+
+/* ITMBasicEngine::ProcessFrame with trackingActive (Core/ITMBasicEngine.tpp:260-385), default failure mode IGNORE:
+ * UpdateView -> TrackingController::Track (skipped while there is no point cloud) -> fusion -> Prepare
+ * (CreateExpectedDepths + CreateICPMaps, pose_pointCloud := pose_d; Core/ITMTrackingController.h:71-105). */
+ORC_API void orc_tsdf_process_frame_tracked(Tsdf *t, const uint8_t *rgb4, const int16_t *depth_mm, const TrackCfg *cfg,
+                                            float *M_out, float *invM_out) {
+    memcpy(t->rgb, rgb4, 4 * (size_t)t->W * t->H);
+    convert_depth(t, depth_mm);
+    if (t->age_point_cloud != -1) {  /* HasValidPointCloud */
+        if (t->age_point_cloud >= 0) t->trk_frames++; else t->trk_frames = 0;
+        if (!t->trk_scratch) t->trk_scratch = (float *)malloc(sizeof(float) * (size_t)t->W * t->H);
+        const float intr[4] = {t->fx, t->fy, t->cx, t->cy};
+        orc_track_camera(t->W, t->H, intr, t->depth, t->icp_points, t->icp_normals, t->pose_pc_M, t->pose_M, t->pose_invM, cfg,
+                         t->trk_frames, t->trk_scratch, t->trk_diag);
+    }
+    allocate_scene_from_depth(t, t->pose_M, t->pose_invM);
+    integrate(t, t->pose_M);
+    create_expected_depths(t, t->pose_M, t->visible_ids, t->n_visible, t->minmax);
+    generic_raycast(t, t->pose_invM, t->minmax, t->raycast, t->visible_type);
+    icp_maps(t, t->pose_invM);
+    memcpy(t->pose_pc_M, t->pose_M, 64);
+    t->age_point_cloud = (t->age_point_cloud == -1) ? -2 : 0;
+    memcpy(M_out, t->pose_M, 64); memcpy(invM_out, t->pose_invM, 64);
+}
+GETTER(trk_diag, void *, t->trk_diag)
+
+/* accessors for the python side */
 GETTER(n_visible, int, t->n_visible)
 GETTER(fv_n_visible, int, t->fv_n_visible)
 GETTER(last_free_block, int, t->last_free_block)

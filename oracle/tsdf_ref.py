@@ -52,7 +52,7 @@ def time_reference(seq, n_frames, voxel, mu, vfmin, vfmax, threads=None, openmp=
     return json.loads(out.strip().splitlines()[-1])
 
 
-def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0):
+def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0, track=False):
     """seq: dict from tests.synth.make_sequence; free_views: list of (frame_idx, c2w[4,4]).
     returns {(name, frame): np.ndarray(bytes)} decoded by `decode`."""
     W, H = seq["W"], seq["H"]
@@ -70,7 +70,7 @@ def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0):
             for fr, c2w in free_views:
                 f.write(struct.pack("<i", fr))
                 f.write(np.ascontiguousarray(c2w, dtype=np.float32).tobytes())
-        subprocess.check_call([BIN, fin, fout])
+        subprocess.check_call([BIN, fin, fout] + (["track"] if track else []))
         raw = open(fout, "rb").read()
     out = {}
     off = 0
@@ -87,7 +87,7 @@ _DT = {"M": np.float32, "invM": np.float32, "counts": np.int32, "visible_ids": n
        "hash": np.int32, "vba_crc": np.uint32, "vba": np.uint8, "depth_f": np.float32, "minmax": np.float32,
        "raycast": np.float32, "icp_points": np.float32, "icp_normals": np.float32, "fv_M": np.float32,
        "fv_invM": np.float32, "fv_counts": np.int32, "fv_visible_ids": np.int32, "fv_minmax": np.float32,
-       "fv_raycast": np.float32, "fv_colour": np.uint8, "sizeof": np.int32}
+       "fv_raycast": np.float32, "fv_colour": np.uint8, "sizeof": np.int32, "trk_score": np.float32}
 
 
 def decode(chunks, W, H):
@@ -134,7 +134,7 @@ def _lib():
         _LIB = C.CDLL(so)
         _LIB.orc_tsdf_create.restype = C.c_void_p
         for n in ("hash", "vba", "visible_ids", "visible_type", "minmax", "raycast", "icp_points", "icp_normals",
-                  "depth", "fv_visible_ids", "fv_minmax", "fv_raycast", "fv_colour"):
+                  "depth", "fv_visible_ids", "fv_minmax", "fv_raycast", "fv_colour", "trk_diag"):
             getattr(_LIB, "orc_tsdf_" + n).restype = C.c_void_p
     return _LIB
 
@@ -147,6 +147,39 @@ def pose_from_c2w(c2w):
     _lib().orc_pose_from_c2w(c2w.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p),
                              invM.ctypes.data_as(C.c_void_p))
     return M, invM
+
+
+class TrackCfg(C.Structure):
+    """TrackCfg of tsdf_oracle.c"""
+    _fields_ = [("n_levels", C.c_int), ("iter_type", C.c_int * 8), ("n_iter", C.c_int * 8), ("space_thresh", C.c_float * 8),
+                ("term_thresh", C.c_float), ("tukey_cutoff", C.c_float), ("vf_min", C.c_float), ("vf_max", C.c_float),
+                ("frames_to_skip", C.c_int), ("frames_to_weight", C.c_int)]
+
+
+def track_config(vf_min, vf_max, levels="rrbb", num_iter_coarse=20, num_iter_fine=50, thresh_coarse=0.1, thresh_fine=0.004,
+                 term_thresh=1e-4, tukey=8.0, frames_to_skip=20, frames_to_weight=50):
+    """The tracker configuration of ITMLibSettings.cpp:54-57 (defaults) -> TrackCfg"""
+    c = TrackCfg()
+    _lib().orc_track_config(levels.encode(), num_iter_coarse, num_iter_fine, C.c_float(thresh_coarse), C.c_float(thresh_fine),
+                            C.c_float(term_thresh), C.c_float(tukey), frames_to_skip, frames_to_weight, C.c_float(vf_min),
+                            C.c_float(vf_max), C.byref(c))
+    return c
+
+
+def track_camera(W, H, intr, depth, points, normals, scene_pose_M, pose_M, cfg, frames_processed):
+    """orc_track_camera on raw arrays -> (M, invM, diag[16])"""
+    depth = np.ascontiguousarray(depth, np.float32)
+    points, normals = np.ascontiguousarray(points, np.float32), np.ascontiguousarray(normals, np.float32)
+    intr = np.ascontiguousarray(intr, np.float32)
+    sp = np.ascontiguousarray(scene_pose_M, np.float32)
+    M = np.ascontiguousarray(pose_M, np.float32).copy()
+    invM = np.zeros(16, np.float32)
+    scratch = np.zeros(W * H, np.float32)
+    diag = np.zeros(16, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib().orc_track_camera(W, H, p(intr), p(depth), p(points), p(normals), p(sp), p(M), p(invM), C.byref(cfg),
+                            int(frames_processed), p(scratch), p(diag))
+    return M, invM, diag
 
 
 class TsdfOracle:
@@ -173,6 +206,20 @@ class TsdfOracle:
         M, invM = np.ascontiguousarray(M, np.float32), np.ascontiguousarray(invM, np.float32)
         _lib().orc_tsdf_process_frame(self.h, rgba.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
                                       M.ctypes.data_as(C.c_void_p), invM.ctypes.data_as(C.c_void_p))
+
+    def process_frame_tracked(self, rgb, depth_u16, cfg):
+        """ProcessFrame with the depth-only ExtendedTracker active (pose estimated); cfg = track_config(...).
+        -> (M, invM) of the frame, ORUtils layout."""
+        H, W = self.H, self.W
+        rgba = np.ascontiguousarray(np.concatenate([rgb, np.full((H, W, 1), 255, np.uint8)], -1))
+        d = np.ascontiguousarray(depth_u16.astype(np.int16))
+        M, invM = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        _lib().orc_tsdf_process_frame_tracked(self.h, rgba.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                              C.byref(cfg), M.ctypes.data_as(C.c_void_p), invM.ctypes.data_as(C.c_void_p))
+        return M, invM
+
+    def track_diag(self):
+        return self._arr("trk_diag", np.float32, (16,)).copy()
 
     def free_raycast(self, M, invM):
         M, invM = np.ascontiguousarray(M, np.float32), np.ascontiguousarray(invM, np.float32)
