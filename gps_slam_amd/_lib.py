@@ -21,6 +21,18 @@ class TsdfState(C.Structure):
                 ("fv_visible_ids", vp), ("fv_minmax", vp), ("fv_raycast", vp), ("fv_colour", vp)]
 
 
+class TrackConfig(C.Structure):
+    """gps_track_config"""
+    _fields_ = [("n_levels", i32), ("iter_type", i32 * 8), ("n_iter", i32 * 8), ("space_thresh", f32 * 8),
+                ("term_thresh", f32), ("tukey_cutoff", f32), ("frames_to_skip", i32), ("frames_to_weight", i32)]
+
+
+class TrackState(C.Structure):
+    """gps_track_state (host memory)"""
+    _fields_ = [("pose_M", f32 * 16), ("pose_invM", f32 * 16), ("pose_pc_M", f32 * 16), ("age_point_cloud", i32),
+                ("frames_processed", i32), ("diag", f32 * 16)]
+
+
 class SplatStep(C.Structure):
     """gps_splat_step (include/gps_slam_hip.h)"""
     _fields_ = ([(n, i32) for n in ("N", "K", "sh_degree", "width", "height", "max_gs_radii")] +
@@ -65,6 +77,12 @@ PROTOTYPES = {
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, vp, f64, f64, f64, i32, vp]),
     "gps_tsdf_scratch_bytes": (i64, [i32, i32, i32, i32]),
     "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
+    "gps_track_config_init": (i32, [C.POINTER(TrackConfig), C.c_char_p, i32, i32, f32, f32, f32, f32, i32, i32]),
+    "gps_track_state_reset": (i32, [C.POINTER(TrackState)]),
+    "gps_track_scratch_bytes": (i64, [i32, i32]),
+    "gps_tsdf_track_camera": (i32, [C.POINTER(TsdfState), C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64, vp]),
+    "gps_tsdf_process_frame_tracked": (i32, [C.POINTER(TsdfState), vp, C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64,
+                                             vp]),
     "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_allocate": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
     "gps_tsdf_integrate": (i32, [C.POINTER(TsdfState), vp, vp]),

@@ -114,6 +114,19 @@ PYBIND11_MODULE(_host, m) {
              py::arg("voxel_size") = 0.005f, py::arg("mu") = 0.02f, py::arg("view_frustum_min") = 0.2f,
              py::arg("view_frustum_max") = 10.0f)
         .def("pushGtPose", [](ITMBasicEngine& e, const torch::Tensor& c2w) { e.gtC2wPoses.push_back(c2w); })
+        .def("turnOffTracking", &ITMBasicEngine::turnOffTracking)
+        .def("turnOnTracking", [](ITMBasicEngine& e) { e.turnOnTracking(); })
+        .def("lastPose", [](ITMBasicEngine& e) {
+            auto t = torch::empty({2, 16}, torch::kFloat32);
+            const ORUtils::SE3Pose& p = e.camPoses.back();
+            for (int i = 0; i < 16; i++) { t[0][i] = p.GetM()[i]; t[1][i] = p.GetInvM()[i]; }
+            return t;
+        })
+        .def("trackDiag", [](ITMBasicEngine& e) {
+            auto t = torch::empty({16}, torch::kFloat32);
+            for (int i = 0; i < 16; i++) t[i] = e.trackState().diag[i];
+            return t;
+        })
         .def("ProcessFrame", [](ITMBasicEngine& e, const torch::Tensor& rgb, const torch::Tensor& depth) {
             e.ProcessFrame(rgb, depth);
         })
@@ -132,8 +145,8 @@ PYBIND11_MODULE(_host, m) {
 
     // ---- pipeline
     py::class_<SLAMPipeline>(m, "SLAMPipeline")
-        .def(py::init<ITMBasicEngine*, SLAMGaussianModel*, uint64_t>(), py::arg("engine"), py::arg("model"),
-             py::arg("seed") = 1234, py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
+        .def(py::init<ITMBasicEngine*, SLAMGaussianModel*, uint64_t, bool>(), py::arg("engine"), py::arg("model"),
+             py::arg("seed") = 1234, py::arg("use_gt_pose") = true, py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
         .def("loadConfig", [](SLAMPipeline& p, const py::dict& d) { p.loadConfig(config_from_dict(d)); })
         .def("processFrame", &SLAMPipeline::processFrame)
         .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams)

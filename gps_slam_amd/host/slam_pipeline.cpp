@@ -14,8 +14,9 @@ torch::Tensor computeNormalMap(const torch::Tensor& vertex_map_in) {
     return out;
 }
 
-SLAMPipeline::SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model_, uint64_t seed)
+SLAMPipeline::SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model_, uint64_t seed, bool use_gt_pose)
     : main_engine(tsdf_engine), model(model_), rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {
+    if (use_gt_pose) main_engine->turnOffTracking();
     device = model->device;
     voxel_size = main_engine->getVoxelSize();
 }
@@ -169,7 +170,8 @@ void SLAMPipeline::removeRedundantGs() {
 // ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
 void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     curr_frame_id = i;
-    if ((int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed) main_engine->gtC2wPoses.push_back(cam.c2w);
+    if (!main_engine->trackingActive && (int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed)
+        main_engine->gtC2wPoses.push_back(cam.c2w);
     ITMTrackingState* ts = main_engine->ProcessFrame(rgb_u8, depth_mm_i16);
     // est_pose = pose_d->GetInvM() (:81-82): ORUtils column-major -> row-major tensor
     auto est = torch::empty({4, 4}, torch::kFloat32);

@@ -43,7 +43,9 @@ torch::Tensor computeNormalMap(const torch::Tensor& vertex_map);  // src/tensor_
 
 class SLAMPipeline {
 public:
-    SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model, uint64_t seed = 1234);
+    // use_gt_pose: TSDF.use_gt_pose of the configs (true in every shipped one) -> engine->turnOffTracking(), as
+    // createTsdfEngine does (InfiniTAM_tools.cpp:59-62); false keeps the depth tracker active
+    SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model, uint64_t seed = 1234, bool use_gt_pose = true);
 
     void loadConfig(const gpsh::Config& config);  // PIPELINE section keys
 

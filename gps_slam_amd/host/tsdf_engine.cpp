@@ -66,22 +66,39 @@ void ITMBasicEngine::resetAll() {
     check(gps_tsdf_reset(&state_, current_stream()), "gps_tsdf_reset");
     framesProcessed = 0;
     camPoses.clear();
+    check(gps_track_state_reset(&track_state_), "gps_track_state_reset");
+}
+
+void ITMBasicEngine::turnOnTracking(const char* levels, int numIterC, int numIterF, float outlierSpaceC, float outlierSpaceF,
+                                    float minstep, float tukeyCutOff, int framesToSkip, int framesToWeight) {
+    check(gps_track_config_init(&track_cfg_, levels, numIterC, numIterF, outlierSpaceC, outlierSpaceF, minstep, tukeyCutOff,
+                                framesToSkip, framesToWeight), "gps_track_config_init");
+    if (!track_scratch_.defined())
+        track_scratch_ = torch::empty({gps_track_scratch_bytes(state_.width, state_.height)}, u8(device_));
+    trackingActive = true;
 }
 
 ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
-    TORCH_CHECK(turnOffTracking, "the ICP tracker is outside the hot path (SURVEY 8(f) rank 1): use_gt_pose only");
-    TORCH_CHECK((int)gtC2wPoses.size() > framesProcessed, "gtC2wPoses must hold the pose of frame ", framesProcessed);
     TORCH_CHECK(rgb_u8.is_cuda() && rgb_u8.scalar_type() == torch::kUInt8 && rgb_u8.is_contiguous() &&
                     rgb_u8.size(-1) == 4, "rgb must be a contiguous uint8 [H,W,4] device tensor (uchar4)");
     TORCH_CHECK(depth_mm_i16.is_cuda() && depth_mm_i16.scalar_type() == torch::kInt16 && depth_mm_i16.is_contiguous(),
                 "depth must be a contiguous int16 [H,W] device tensor (millimetres)");
     frame_inputs_ = {rgb_u8, depth_mm_i16};  // keep alive while kernels may read them
     state_.rgb = ptr<uint8_t>(rgb_u8);
-    auto c2w = gtC2wPoses[framesProcessed].to(torch::kCPU, torch::kFloat32).contiguous();
-    pose_d_.SetInvM(c2w.data_ptr<float>());
-    pose_d_.Coerce();
-    check(gps_tsdf_process_frame(&state_, ptr<int16_t>(depth_mm_i16), pose_d_.GetM(), pose_d_.GetInvM(),
-                                 current_stream()), "gps_tsdf_process_frame");
+    if (trackingActive) {
+        if (!track_scratch_.defined()) turnOnTracking();  // ITMLibSettings defaults
+        check(gps_tsdf_process_frame_tracked(&state_, ptr<int16_t>(depth_mm_i16), &track_cfg_, &track_state_,
+                                             track_scratch_.data_ptr(), track_scratch_.numel(), current_stream()),
+              "gps_tsdf_process_frame_tracked");
+        pose_d_.SetBoth(track_state_.pose_M, track_state_.pose_invM);
+    } else {
+        TORCH_CHECK((int)gtC2wPoses.size() > framesProcessed, "gtC2wPoses must hold the pose of frame ", framesProcessed);
+        auto c2w = gtC2wPoses[framesProcessed].to(torch::kCPU, torch::kFloat32).contiguous();
+        pose_d_.SetInvM(c2w.data_ptr<float>());
+        pose_d_.Coerce();
+        check(gps_tsdf_process_frame(&state_, ptr<int16_t>(depth_mm_i16), pose_d_.GetM(), pose_d_.GetInvM(),
+                                     current_stream()), "gps_tsdf_process_frame");
+    }
     camPoses.push_back(pose_d_);
     framesProcessed++;
     return &tracking_state_;

@@ -18,6 +18,7 @@ class SE3Pose {
 public:
     SE3Pose() { for (int i = 0; i < 16; i++) M_[i] = invM_[i] = (i % 5 == 0) ? 1.f : 0.f; }
     void SetInvM(const float* c2w_row_major) { gpsh::check(gps_pose_from_c2w(c2w_row_major, M_, invM_), "gps_pose_from_c2w"); }
+    void SetBoth(const float* M, const float* invM) { for (int i = 0; i < 16; i++) { M_[i] = M[i]; invM_[i] = invM[i]; } }
     void Coerce() {}  // done by gps_pose_from_c2w
     const float* GetM() const { return M_; }
     const float* GetInvM() const { return invM_; }
@@ -74,9 +75,18 @@ public:
     const gps_tsdf_state& state() const { return state_; }
     torch::Tensor counters() const { return counters_; }
 
+    // ITMBasicEngine::turnOffTracking (ITMBasicEngine.tpp:532; createTsdfEngine calls it when use_gt_pose is true,
+    // InfiniTAM_tools.cpp:59-62): poses then come from gtC2wPoses.  With tracking active (the reference's default) the
+    // depth-only ExtendedTracker of ITMLibSettings.cpp:54-57 estimates them (gps_tsdf_process_frame_tracked).
+    void turnOffTracking() { trackingActive = false; }
+    void turnOnTracking(const char* levels = "rrbb", int numIterC = 20, int numIterF = 50, float outlierSpaceC = 0.1f,
+                        float outlierSpaceF = 0.004f, float minstep = 1e-4f, float tukeyCutOff = 8.0f, int framesToSkip = 20,
+                        int framesToWeight = 50);
+    const gps_track_state& trackState() const { return track_state_; }
+
     std::vector<ORUtils::SE3Pose> camPoses;       // pose used for every processed frame
     std::vector<torch::Tensor> gtC2wPoses;         // dataset poses, [4,4] float CPU tensors (push before ProcessFrame)
-    bool turnOffTracking = true;
+    bool trackingActive = true;
     int framesProcessed = 0;
 
 private:
@@ -86,6 +96,9 @@ private:
         visible_ids_, depth_, minmax_, raycast_, icp_points_, icp_normals_, fv_visible_ids_, fv_minmax_, fv_raycast_,
         fv_colour_;
     std::vector<torch::Tensor> frame_inputs_;
+    gps_track_config track_cfg_{};
+    gps_track_state track_state_{};
+    torch::Tensor track_scratch_;
     ORUtils::SE3Pose pose_d_;
     ITMTrackingState tracking_state_{&pose_d_};
     ITMUChar4Image free_image_;

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import TsdfState, check, lib
+from ._lib import TrackConfig, TrackState, TsdfState, check, lib
 
 # reference capacities (ITMLib/Objects/Scene/ITMVoxelBlockHash.h:18-22)
 SDF_LOCAL_BLOCK_NUM = 0x40000
@@ -107,6 +107,40 @@ class TsdfEngine:
         self.camPoses.append((M, invM))
         self.frames_processed += 1
         return M, invM
+
+    # ---- ITMBasicEngine::ProcessFrame with the tracker ON (use_gt_pose: false)
+    def turnOnTracking(self, levels="rrbb", num_iter_coarse=20, num_iter_fine=50, thresh_coarse=0.1, thresh_fine=0.004,
+                       term_thresh=1e-4, tukey_cutoff=8.0, frames_to_skip=20, frames_to_weight=50):
+        """Depth-only ExtendedTracker with the parameters of ITMLibSettings.cpp:54-57 (defaults)."""
+        self.track_cfg = TrackConfig()
+        check(lib.gps_track_config_init(C.byref(self.track_cfg), levels.encode(), num_iter_coarse, num_iter_fine, thresh_coarse,
+                                        thresh_fine, term_thresh, tukey_cutoff, frames_to_skip, frames_to_weight),
+              "gps_track_config_init")
+        self.track_state = TrackState()
+        check(lib.gps_track_state_reset(C.byref(self.track_state)), "gps_track_state_reset")
+        nbytes = int(lib.gps_track_scratch_bytes(self.W, self.H))
+        self.track_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def ProcessFrameTracked(self, rgb_u8, depth_mm_i16):
+        """-> (M, invM) estimated by the tracker (ORUtils layout, numpy float32[16]).  Host-synchronous (see
+        gps_tsdf_track_camera)."""
+        if rgb_u8.shape[-1] == 3:
+            rgb_u8 = torch.cat([rgb_u8, torch.full_like(rgb_u8[..., :1], 255)], -1)
+        assert rgb_u8.is_contiguous() and depth_mm_i16.is_contiguous()
+        self._frame_inputs = (rgb_u8, depth_mm_i16)
+        self.state.rgb = rgb_u8.data_ptr()
+        check(lib.gps_tsdf_process_frame_tracked(C.byref(self.state), depth_mm_i16.data_ptr(), C.byref(self.track_cfg),
+                                                 C.byref(self.track_state), self.track_scratch.data_ptr(),
+                                                 self.track_scratch.numel(), self._stream()),
+              "gps_tsdf_process_frame_tracked")
+        M = np.array(self.track_state.pose_M, dtype=np.float32)
+        invM = np.array(self.track_state.pose_invM, dtype=np.float32)
+        self.camPoses.append((M, invM))
+        self.frames_processed += 1
+        return M, invM
+
+    def track_diag(self):
+        return np.array(self.track_state.diag, dtype=np.float32)
 
     # ---- ITMBasicEngine::runRaycast(pose, intrinsics) + GetFreeImage / GetFreeVertex
     def runRaycast(self, c2w=None, pose=None):

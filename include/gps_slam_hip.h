@@ -408,6 +408,58 @@ GPS_API int gps_raycast_to_maps(int width, int height, const float *rays, const 
  * c2w is row-major (tensor layout); M/invM use the ORUtils layout.  Pure host code, no GPU. */
 GPS_API int gps_pose_from_c2w(const float *c2w_row_major, float *M, float *invM);
 
+/* ------------------------------------------------------------------ */
+/* TSDF: camera tracking (depth-only ExtendedTracker, use_gt_pose = false) */
+/* ------------------------------------------------------------------ */
+
+#define GPS_TRACK_MAX_LEVELS 8
+
+/* ITMExtendedTracker configuration after SetupLevels (Trackers/Interface/ITMExtendedTracker.cpp:143-177).  Level 0 is the
+ * finest.  iter_type: 0 rotation only, 1 translation only, 2 both, 3 none (TrackerIterationType). */
+typedef struct {
+    int32_t n_levels;
+    int32_t iter_type[GPS_TRACK_MAX_LEVELS];
+    int32_t n_iter[GPS_TRACK_MAX_LEVELS];
+    float space_thresh[GPS_TRACK_MAX_LEVELS];
+    float term_thresh, tukey_cutoff;
+    int32_t frames_to_skip, frames_to_weight;
+} gps_track_config;
+
+/* ITMTrackingState as the tracker uses it (host memory): pose_d (M / invM), pose_pointCloud (M), age_pointCloud,
+ * framesProcessed; diag = {iterations run on level 0..7, noValidPoints, f, trackerScore, det(H), ...} of the last call.
+ * Matrices in ORUtils layout m[col*4 + row]. */
+typedef struct {
+    float pose_M[16], pose_invM[16], pose_pc_M[16];
+    int32_t age_point_cloud, frames_processed;
+    float diag[16];
+} gps_track_state;
+
+/* Builds the configuration from the reference's tracker string parameters (ITMLibSettings.cpp:54-57 default:
+ * levels "rrbb", numiterC 20, numiterF 50, outlierSpaceC 0.1, outlierSpaceF 0.004, minstep 1e-4, tukeyCutOff 8,
+ * framesToSkip 20, framesToWeight 50). */
+GPS_API int gps_track_config_init(gps_track_config *c, const char *levels, int num_iter_coarse, int num_iter_fine,
+                                  float thresh_coarse, float thresh_fine, float term_thresh, float tukey_cutoff,
+                                  int frames_to_skip, int frames_to_weight);
+
+/* ITMTrackingState::Reset: identity poses, no point cloud yet. */
+GPS_API int gps_track_state_reset(gps_track_state *ts);
+
+/* Device scratch (depth pyramid levels >= 1, reduction partials) for images of this size. */
+GPS_API int64_t gps_track_scratch_bytes(int width, int height);
+
+/* ITMExtendedTracker::TrackCamera (useDepth, !useColour): refines ts->pose_M / pose_invM against the ICP maps of the last
+ * raycast (s->icp_points / s->icp_normals, rendered from ts->pose_pc_M) using s->depth.  HOST-SYNCHRONOUS: like the
+ * reference's GPU tracker it reads 32 accumulated floats back per Levenberg-Marquardt iteration and runs the 6x6 solve and
+ * the SE3 update on the host (ITMExtendedTracker_CUDA.cu + ITMExtendedTracker.cpp:470-665). */
+GPS_API int gps_tsdf_track_camera(const gps_tsdf_state *s, const gps_track_config *cfg, gps_track_state *ts, void *scratch,
+                                  int64_t scratch_bytes, gps_stream stream);
+
+/* ITMBasicEngine::ProcessFrame with tracking active and the default failure mode (Core/ITMBasicEngine.tpp:260-385):
+ * convert_depth -> track (once a point cloud exists) -> allocate + integrate -> expected depths + raycast + ICP maps at
+ * the tracked pose; updates ts (pose_pointCloud := pose_d, age_pointCloud, framesProcessed). */
+GPS_API int gps_tsdf_process_frame_tracked(const gps_tsdf_state *s, const int16_t *depth_mm, const gps_track_config *cfg,
+                                           gps_track_state *ts, void *scratch, int64_t scratch_bytes, gps_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,21 @@ def test_full_loop_at_1280x720_cpp_host():
     err_render = (res["rgb"] - cams[-1].image).abs().mean().item()
     err_tsdf = (rcs[-1]["color_map"] - cams[-1].image).abs().mean().item()
     assert err_render <= err_tsdf * 1.02, (err_render, err_tsdf)
+
+
+def test_cpp_engine_tracks_like_the_reference():
+    """C++ ITMBasicEngine with tracking left ON (the reference's default; createTsdfEngine switches it off only for
+    use_gt_pose): poses against the reference CPU engine's (tests/golden/track_320x240.npz)."""
+    import os
+    h = _host()
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_320x240.npz"))
+    W, Hh, n = int(G["W"]), int(G["H"]), int(G["n_frames"])
+    seq = synth.make_sequence(W, Hh, n, step_deg=float(G["step_deg"]))
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
+    eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], float(G["voxel"]), float(G["mu"]),
+                           float(G["vf_min"]), float(G["vf_max"]))
+    for f in range(n):
+        eng.ProcessFrame(T(rgba[f]), T(seq["depth"][f].astype(np.int16)))
+        pose = eng.lastPose().numpy()
+        assert np.abs(pose[0] - G["M"][f]).max() < 2e-5 and np.abs(pose[1] - G["invM"][f]).max() < 2e-5, f
+    assert eng.trackDiag()[8] > 10000  # inliers of the last accepted evaluation
