@@ -9,7 +9,7 @@
 // Split exactly like the reference's GPU tracker: the per-pixel residual / Jacobian evaluation and its reduction are
 // kernels, the 6x6 Levenberg-Marquardt bookkeeping (Cholesky, step, SE3 coercion, accept / reject) is host code fed by one
 // 32-float read-back per iteration.  The reduction is a fixed two-stage tree (per-thread register sums -> wave -> workgroup
-// -> one pass over <= 256 workgroup partials), so results are reproducible run to run; they differ from the CPU engine's
+// -> 32 row-group sums over the <= 128 workgroup partials, added in fixed order), so results are reproducible run to run; they differ from the CPU engine's
 // scan-order sums only by float re-association (poses agree to ~1e-6, tests/test_tsdf_gpu.py).
 #include <math.h>
 #include <string.h>
@@ -21,7 +21,7 @@ using namespace gpst;
 namespace {
 
 constexpr int TRK_ROTATION = 0, TRK_TRANSLATION = 1, TRK_BOTH = 2, TRK_NONE = 3;
-constexpr int GH_WGS = 256, GH_SLOTS = 32;  // partial[GH_WGS][GH_SLOTS]: 0 = count, 1 = f, 2.. = nabla, then lower-tri hessian
+constexpr int GH_WGS = 128, GH_SLOTS = 32;   // few workgroups: 1200 same-address ticket atomics cost more than the longer per-thread loops  // partial[GH_WGS][GH_SLOTS]: 0 = count, 1 = f, 2.. = nabla, then lower-tri hessian
 
 __global__ __launch_bounds__(256) void subsample_with_holes_kernel(const float* __restrict__ in, int w_in, int w, int h,
                                                                    float* __restrict__ out) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
         w *= (cp.w - a.frames_to_skip) / a.frames_to_weight;
     }
     const float b = n.x * dx + n.y * dy + n.z * dz;
-    float A[NP];
+    float A[6];
     if (ITER == TRK_TRANSLATION) {
         A[0] = n.x; A[1] = n.y; A[2] = n.z;
     } else {
@@ -127,10 +127,16 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
     }
 }
 
+// One launch per LM iteration: every workgroup leaves its partial sums, the LAST one to finish (atomic ticket) adds the
+// partials in workgroup order -- a fixed tree, independent of which workgroup happens to be last -- and publishes the 32
+// totals: to device memory and, if the caller provided a pinned host mailbox, straight into host memory followed by a
+// sequence number the host spins on (no hipMemcpy + stream synchronise per iteration).
 template <int ITER>
-__global__ __launch_bounds__(256) void track_gh_kernel(GhArgs a, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void track_gh_kernel(GhArgs a, float* __restrict__ partial, int* __restrict__ ticket,
+                                                       float* __restrict__ result, volatile float* mailbox, int seq) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ;
     __shared__ float red[4][GH_SLOTS];
+    __shared__ int is_last;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0f;
@@ -151,14 +157,49 @@ __global__ __launch_bounds__(256) void track_gh_kernel(GhArgs a, float* __restri
     if (threadIdx.x < GH_SLOTS)
         partial[blockIdx.x * GH_SLOTS + threadIdx.x] =
             threadIdx.x < NV ? ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) : 0.0f;
-}
-
-__global__ __launch_bounds__(64) void track_reduce_kernel(const float* __restrict__ partial, int n_wgs, float* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= GH_SLOTS) return;
-    float s = 0.0f;
-    for (int b = 0; b < n_wgs; b++) s += partial[b * GH_SLOTS + k];  // fixed order
-    out[k] = s;
+    __threadfence();  // partials visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    {
+        // 256 threads: thread (q, r) adds the q-th float4 of rows r, r + 32, r + 64, ... (independent 16-byte loads, issued
+        // eight at a time), then the 32 row-group sums of every slot are added in fixed order
+        __shared__ float4 group[32][8];
+        const int q = threadIdx.x & 7, r = threadIdx.x >> 3;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v* p4 = reinterpret_cast<const f4v*>(partial);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int rows = (int)gridDim.x;
+        for (int b = r; b < rows; b += 32 * 8) {
+            f4v v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int row = b + 32 * k;
+                const f4v zero = {0.f, 0.f, 0.f, 0.f};
+                v[k] = row < rows ? __builtin_nontemporal_load(&p4[row * 8 + q]) : zero;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+        }
+        group[r][q] = s;
+        __syncthreads();
+        if (threadIdx.x < GH_SLOTS) {
+            const float* g = reinterpret_cast<const float*>(group);
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; k++) t += g[k * GH_SLOTS + threadIdx.x];
+            result[threadIdx.x] = t;
+            if (mailbox) mailbox[threadIdx.x] = t;
+        }
+    }
+    if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch
+    if (mailbox) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { mailbox[GH_SLOTS] = __int_as_float(seq); __threadfence_system(); }
+    }
 }
 
 // ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
@@ -216,10 +257,12 @@ bool set_invM_coerce(const float* invM_in, float* M, float* invM) {  // pose_d->
     return gps_pose_from_c2w(rm, M, invM) == GPS_OK;
 }
 
+inline int float_bits(float f) { int i; memcpy(&i, &f, 4); return i; }
+
 struct Scratch {
     float* level[GPS_TRACK_MAX_LEVELS];  // [0] unused (= s.depth)
     float *partial, *result;
-    int* count;
+    int *count, *ticket;
 };
 
 size_t carve(Scratch* w, char* base, int W, int H) {
@@ -234,6 +277,7 @@ size_t carve(Scratch* w, char* base, int W, int H) {
     char* p = take((size_t)GH_WGS * GH_SLOTS * sizeof(float)); if (w) w->partial = (float*)p;
     p = take(GH_SLOTS * sizeof(float)); if (w) w->result = (float*)p;
     p = take(sizeof(int)); if (w) w->count = (int*)p;
+    p = take(sizeof(int)); if (w) w->ticket = (int*)p;
     return off;
 }
 
@@ -304,6 +348,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
         for (int k = 0; k < 4; k++) lintr[l][k] = lintr[l - 1][k] * 0.5f;
     }
     if (hipMemsetAsync(w.count, 0, sizeof(int), st) != hipSuccess) return GPS_ERR_LAUNCH;
+    if (hipMemsetAsync(w.ticket, 0, sizeof(int), st) != hipSuccess) return GPS_ERR_LAUNCH;
     count_valid_kernel<<<128, 256, 0, st>>>(s.depth, W * H, w.count);
     GPS_LAUNCH_CHECK();
 
@@ -315,6 +360,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     int last_type = TRK_NONE;
     for (int k = 0; k < 16; k++) ts->diag[k] = 0;
     const int use_weights = ts->frames_processed >= 100;
+    static int mail_seq = 0;  // sequence numbers are process-wide so a stale mailbox value can never match
 
     for (int level = c->n_levels - 1; level >= 0; level--) {
         const int it = c->iter_type[level];
@@ -337,15 +383,26 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             a.vf_max = s.view_frustum_max; a.use_weights = use_weights; a.frames_to_skip = c->frames_to_skip;
             a.frames_to_weight = c->frames_to_weight;
             const int n_wgs = min(GH_WGS, gps_div_up(a.vw * a.vh, 256));
-            if (it == TRK_ROTATION) track_gh_kernel<TRK_ROTATION><<<n_wgs, 256, 0, st>>>(a, w.partial);
-            else if (it == TRK_TRANSLATION) track_gh_kernel<TRK_TRANSLATION><<<n_wgs, 256, 0, st>>>(a, w.partial);
-            else track_gh_kernel<TRK_BOTH><<<n_wgs, 256, 0, st>>>(a, w.partial);
-            track_reduce_kernel<<<1, 64, 0, st>>>(w.partial, n_wgs, w.result);
+            volatile float* mailbox = reinterpret_cast<volatile float*>(ts->host_mailbox);
+            const int seq = ++mail_seq;
+            if (it == TRK_ROTATION) track_gh_kernel<TRK_ROTATION><<<n_wgs, 256, 0, st>>>(a, w.partial, w.ticket, w.result, mailbox, seq);
+            else if (it == TRK_TRANSLATION) track_gh_kernel<TRK_TRANSLATION><<<n_wgs, 256, 0, st>>>(a, w.partial, w.ticket, w.result, mailbox, seq);
+            else track_gh_kernel<TRK_BOTH><<<n_wgs, 256, 0, st>>>(a, w.partial, w.ticket, w.result, mailbox, seq);
             GPS_LAUNCH_CHECK();
             float host[GH_SLOTS];
-            // the reference's GPU tracker reads its 32 accumulators back every iteration as well
-            if (hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
-            if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+            if (mailbox) {
+                // spin on the sequence number the kernel writes last (bounded: fall back to a stream synchronise)
+                bool got = false;
+                for (long spin = 0; spin < 200000000L; spin++) {
+                    if (float_bits(mailbox[GH_SLOTS]) == seq) { got = true; break; }
+                }
+                if (!got && hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+                for (int k = 0; k < GH_SLOTS; k++) host[k] = mailbox[k];
+            } else {
+                // the reference's GPU tracker reads its 32 accumulators back every iteration as well
+                if (hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+                if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+            }
 
             float hessian_depth[36] = {0}, nabla_depth[6] = {0};
             const int nvalid = (int)host[0];

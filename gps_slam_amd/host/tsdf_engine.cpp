@@ -67,14 +67,18 @@ void ITMBasicEngine::resetAll() {
     framesProcessed = 0;
     camPoses.clear();
     check(gps_track_state_reset(&track_state_), "gps_track_state_reset");
+    if (track_mailbox_.defined()) track_state_.host_mailbox = track_mailbox_.data_ptr();
 }
 
 void ITMBasicEngine::turnOnTracking(const char* levels, int numIterC, int numIterF, float outlierSpaceC, float outlierSpaceF,
                                     float minstep, float tukeyCutOff, int framesToSkip, int framesToWeight) {
     check(gps_track_config_init(&track_cfg_, levels, numIterC, numIterF, outlierSpaceC, outlierSpaceF, minstep, tukeyCutOff,
                                 framesToSkip, framesToWeight), "gps_track_config_init");
-    if (!track_scratch_.defined())
+    if (!track_scratch_.defined()) {
         track_scratch_ = torch::empty({gps_track_scratch_bytes(state_.width, state_.height)}, u8(device_));
+        track_mailbox_ = torch::zeros({64}, torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
+    }
+    track_state_.host_mailbox = track_mailbox_.data_ptr();
     trackingActive = true;
 }
 

@@ -98,7 +98,7 @@ private:
     std::vector<torch::Tensor> frame_inputs_;
     gps_track_config track_cfg_{};
     gps_track_state track_state_{};
-    torch::Tensor track_scratch_;
+    torch::Tensor track_scratch_, track_mailbox_;
     ORUtils::SE3Pose pose_d_;
     ITMTrackingState tracking_state_{&pose_d_};
     ITMUChar4Image free_image_;

@@ -120,6 +120,8 @@ class TsdfEngine:
         check(lib.gps_track_state_reset(C.byref(self.track_state)), "gps_track_state_reset")
         nbytes = int(lib.gps_track_scratch_bytes(self.W, self.H))
         self.track_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._mailbox = torch.zeros(64, dtype=torch.float32).pin_memory()  # kernel -> host accumulators, no memcpy
+        self.track_state.host_mailbox = self._mailbox.data_ptr()
 
     def ProcessFrameTracked(self, rgb_u8, depth_mm_i16):
         """-> (M, invM) estimated by the tracker (ORUtils layout, numpy float32[16]).  Host-synchronous (see

@@ -432,6 +432,10 @@ typedef struct {
     float pose_M[16], pose_invM[16], pose_pc_M[16];
     int32_t age_point_cloud, frames_processed;
     float diag[16];
+    /* optional: >= 256 bytes of PINNED, device-visible host memory (hipHostMalloc / torch pinned tensor).  If set, every
+     * LM iteration's 32 accumulators are written straight into it by the kernel and the host spins on a sequence number
+     * instead of paying hipMemcpy + stream synchronise per iteration; NULL = the memcpy path. */
+    void *host_mailbox;
 } gps_track_state;
 
 /* Builds the configuration from the reference's tracker string parameters (ITMLibSettings.cpp:54-57 default:
