@@ -32,6 +32,10 @@ def build_scene(W, H, n_frames, n_gauss, seed, device):
     from gps_slam_amd.slam_pipeline import SLAMPipeline, compute_normal_map
     from gps_slam_amd.tsdf_engine import TsdfEngine
     seq = synth.make_sequence(W, H, n_frames, step_deg=0.25 + 0.01 * (seed % 7))
+    # world := first camera (what a tracked run uses as its world, ITMTrackingState::Reset starts at the identity), so
+    # that the given poses and the tracked poses live in the same frame
+    c0inv = np.linalg.inv(seq["c2w"][0].astype(np.float64))
+    seq["c2w"] = np.stack([(c0inv @ c.astype(np.float64)) for c in seq["c2w"]]).astype(np.float32)
     fx, fy, cx, cy = seq["fx"], seq["fy"], seq["cx"], seq["cy"]
     eng = TsdfEngine(W, H, fx, fy, cx, cy, voxel_size=0.005, mu=0.02, view_frustum_min=0.2, view_frustum_max=10.0,
                      device=device)
@@ -115,6 +119,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gt-pose", action="store_true",
+                    help="use_gt_pose: true (what every shipped config sets: the tracker is off, poses are given).  Default: the "
+                         "depth-only ExtendedTracker estimates the pose of every frame, as BASELINE configs[2] "
+                         "(\"full track + TSDF + Gaussian optimize\") describes")
     ap.add_argument("--host", choices=("cpp", "python"), default="cpp",
                     help="which host layer drives the C-ABI: the C++/libtorch one (gps_slam_amd/host) or its Python mirror")
     args = ap.parse_args()
@@ -129,6 +137,9 @@ def main():
     W, H, K, Wm = args.width, args.height, args.steps, args.warmup
     n_frames = K + Wm + 1
     seq, eng, model, pipe, cams, rgb_dev, depth_dev = build_scene(W, H, n_frames, args.gaussians, scene_seed(rank), device)
+    pipe.use_gt_pose = args.gt_pose
+    if not args.gt_pose:
+        eng.turnOnTracking()
 
     if args.host == "cpp":
         # same scene, driven by the C++ host layer (what a C++ slam_trainer links against); the Python objects built
@@ -138,7 +149,7 @@ def main():
         cmodel = H_.SLAMGaussianModel()
         cmodel.loadConfig(dict(capacity=1 << 19, isect_capacity=8 << 20))
         cmodel.getGaussianParms().add([t.clone() for t in model.opt_gs_params.tensors()])
-        cpipe = H_.SLAMPipeline(ceng, cmodel, scene_seed(rank))
+        cpipe = H_.SLAMPipeline(ceng, cmodel, scene_seed(rank), args.gt_pose)
         ccams = []
         for k in range(n_frames):
             c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k].astype(np.float32)))
@@ -216,7 +227,7 @@ def main():
         # loop over the same timed frames on a fresh engine gives the fusion share, the rest is the Gaussian share
         if args.host == "cpp":
             e2 = H_.ITMBasicEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0)
-            p2 = H_.SLAMPipeline(e2, H_.SLAMGaussianModel(), 1)
+            p2 = H_.SLAMPipeline(e2, H_.SLAMGaussianModel(), 1, args.gt_pose)
             p2.work_mode = "recon"
             step2 = lambda i: p2.processFrame(i, ccams[i], rgb_dev[i], depth_dev[i])
         else:
@@ -224,7 +235,7 @@ def main():
             from gps_slam_amd.slam_pipeline import SLAMPipeline as _P
             from gps_slam_amd.tsdf_engine import TsdfEngine as _E
             p2 = _P(_E(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.005, mu=0.02, device=device),
-                    _M(device=device), work_mode="recon")
+                    _M(device=device), work_mode="recon", use_gt_pose=args.gt_pose)
             step2 = lambda i: p2.process_frame(i, cams[i], rgb_dev[i], depth_dev[i])
         for i in range(Wm):
             step2(i)
@@ -243,11 +254,12 @@ def main():
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic room0-like RGB-D %dx%d, TSDF 5mm voxels + ges splat optimise, GT pose "
-                                   "(use_gt_pose=true as in every shipped config), ~%dk Gaussians; independent scene per GPU"
-                                   % (W, H, N // 1000),
+            "config": {"workload": "synthetic room0-like RGB-D %dx%d: %s + TSDF fuse (5mm voxels) + ges splat optimise, ~%dk "
+                                   "Gaussians; independent scene per GPU"
+                                   % (W, H, "given poses (use_gt_pose=true, as every shipped config)" if args.gt_pose else
+                                      "depth ICP tracking (ExtendedTracker, use_gt_pose=false)", N // 1000),
                        "gaussians": N, "local_opt_interval": 10, "local_opt_iters": 20,
-                       "frames_per_step": 1, "stats": stats, "host": args.host, "quality": quality, "split": split},
+                       "frames_per_step": 1, "stats": stats, "host": args.host, "use_gt_pose": bool(args.gt_pose), "quality": quality, "split": split},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

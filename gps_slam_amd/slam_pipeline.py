@@ -56,12 +56,17 @@ def compute_normal_map(vertex_map):
 
 
 class SLAMPipeline:
-    def __init__(self, tsdf_engine, model, pipe_cfg=None, seed=1234, work_mode="train"):
+    def __init__(self, tsdf_engine, model, pipe_cfg=None, seed=1234, work_mode="train", use_gt_pose=True):
         self.tsdf = tsdf_engine
         self.model = model
         self.cfg = dict(DEFAULT_PIPE)
         self.cfg.update(pipe_cfg or {})
         self.work_mode = work_mode
+        # TSDF.use_gt_pose of the configs (true in every shipped one; createTsdfEngine then calls turnOffTracking,
+        # InfiniTAM_tools.cpp:59-62); False keeps the depth-only ExtendedTracker active
+        self.use_gt_pose = use_gt_pose
+        if not use_gt_pose and not hasattr(tsdf_engine, "track_cfg"):
+            tsdf_engine.turnOnTracking()
         self.rng = random.Random(seed)
         self.gen = torch.Generator().manual_seed(seed)  # host generator (see SLAMGaussianModel.addGaussians)
         self.device = model.device
@@ -182,7 +187,10 @@ class SLAMPipeline:
     # ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
     def process_frame(self, i, cam, rgb_u8_dev, depth_mm_dev):
         self.curr_frame_id = i
-        M, invM = self.tsdf.ProcessFrame(rgb_u8_dev, depth_mm_dev, cam.c2w.numpy())
+        if self.use_gt_pose:
+            M, invM = self.tsdf.ProcessFrame(rgb_u8_dev, depth_mm_dev, cam.c2w.numpy())
+        else:
+            M, invM = self.tsdf.ProcessFrameTracked(rgb_u8_dev, depth_mm_dev)
         # est_pose = pose_d->GetInvM() (:81-82): ORUtils layout -> row-major tensor
         cam.c2w_slam = torch.from_numpy(invM.reshape(4, 4).T.copy())
         cam.invalidate()
