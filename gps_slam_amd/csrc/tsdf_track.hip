@@ -7,11 +7,12 @@
 //   (per-iteration reduction + 32-float read-back); Engines/LowLevel/Shared/ITMLowLevelEngine_Shared.h:48-69.
 //
 // Split exactly like the reference's GPU tracker: the per-pixel residual / Jacobian evaluation and its reduction are
-// kernels, the 6x6 Levenberg-Marquardt bookkeeping (Cholesky, step, SE3 coercion, accept / reject) is host code fed by one
-// 32-float read-back per iteration.  The reduction is a fixed two-stage tree (per-thread register sums -> wave -> workgroup
+// kernels, the 6x6 Levenberg-Marquardt bookkeeping (Cholesky, step, SE3 coercion, accept / reject) is host code fed by 32
+// floats per iteration (written by the kernel straight into a pinned host mailbox the host spins on).  The reduction is a fixed two-stage tree (per-thread register sums -> wave -> workgroup
 // -> 32 row-group sums over the <= 128 workgroup partials, added in fixed order), so results are reproducible run to run; they differ from the CPU engine's
 // scan-order sums only by float re-association (poses agree to ~1e-6, tests/test_tsdf_gpu.py).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "tsdf_common.hpp"
@@ -21,7 +22,8 @@ using namespace gpst;
 namespace {
 
 constexpr int TRK_ROTATION = 0, TRK_TRANSLATION = 1, TRK_BOTH = 2, TRK_NONE = 3;
-constexpr int GH_WGS = 128, GH_SLOTS = 32;   // few workgroups: 1200 same-address ticket atomics cost more than the longer per-thread loops  // partial[GH_WGS][GH_SLOTS]: 0 = count, 1 = f, 2.. = nabla, then lower-tri hessian
+constexpr int GH_MAX_WGS = 2048;
+constexpr int GH_WGS = 512, GH_SLOTS = 32;  // partial[GH_WGS][GH_SLOTS]: 0 = count, 1 = f, 2.. = nabla, then lower-tri hessian
 
 __global__ __launch_bounds__(256) void subsample_with_holes_kernel(const float* __restrict__ in, int w_in, int w, int h,
                                                                    float* __restrict__ out) {
@@ -127,16 +129,55 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
     }
 }
 
-// One launch per LM iteration: every workgroup leaves its partial sums, the LAST one to finish (atomic ticket) adds the
-// partials in workgroup order -- a fixed tree, independent of which workgroup happens to be last -- and publishes the 32
-// totals: to device memory and, if the caller provided a pinned host mailbox, straight into host memory followed by a
-// sequence number the host spins on (no hipMemcpy + stream synchronise per iteration).
+// 256 threads: thread (q, r) adds the q-th float4 of rows r, r + 32, r + 64, ... (independent 16-byte loads, issued eight
+// at a time), then the 32 row-group sums of every slot are added in fixed order; totals -> result (+ host mailbox)
+__device__ __forceinline__ void final_sum(const float* __restrict__ partial, int rows, float* __restrict__ result,
+                                          volatile float* mailbox) {
+    __shared__ float4 group[32][8];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const f4v* p4 = reinterpret_cast<const f4v*>(partial);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = r; b < rows; b += 32 * 8) {
+        f4v v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int row = b + 32 * k;
+            const f4v zero = {0.f, 0.f, 0.f, 0.f};
+            v[k] = row < rows ? __builtin_nontemporal_load(&p4[row * 8 + q]) : zero;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+    }
+    group[r][q] = s;
+    __syncthreads();
+    if (threadIdx.x < GH_SLOTS) {
+        const float* g = reinterpret_cast<const float*>(group);
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; k++) t += g[k * GH_SLOTS + threadIdx.x];
+        result[threadIdx.x] = t;
+        if (mailbox) mailbox[threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void track_sum_kernel(const float* __restrict__ partial, int rows, float* __restrict__ result,
+                                                       volatile float* mailbox, int seq) {
+    final_sum(partial, rows, result, mailbox);
+    if (mailbox) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { mailbox[GH_SLOTS] = __int_as_float(seq); __threadfence_system(); }
+    }
+}
+
+// Per LM iteration: this kernel leaves one row of partial sums per workgroup, track_sum_kernel adds the rows in a fixed
+// order (a last-block-done ticket inside this kernel was measured slower than the second launch: one device-scope atomic
+// per workgroup on a single address plus the fences cost more than ~5 us of launch).
 template <int ITER>
-__global__ __launch_bounds__(256) void track_gh_kernel(GhArgs a, float* __restrict__ partial, int* __restrict__ ticket,
-                                                       float* __restrict__ result, volatile float* mailbox, int seq) {
+__global__ __launch_bounds__(256) void track_gh_kernel(GhArgs a, float* __restrict__ partial) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ;
     __shared__ float red[4][GH_SLOTS];
-    __shared__ int is_last;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0f;
@@ -157,49 +198,6 @@ __global__ __launch_bounds__(256) void track_gh_kernel(GhArgs a, float* __restri
     if (threadIdx.x < GH_SLOTS)
         partial[blockIdx.x * GH_SLOTS + threadIdx.x] =
             threadIdx.x < NV ? ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) : 0.0f;
-    __threadfence();  // partials visible device-wide before the ticket is taken
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    {
-        // 256 threads: thread (q, r) adds the q-th float4 of rows r, r + 32, r + 64, ... (independent 16-byte loads, issued
-        // eight at a time), then the 32 row-group sums of every slot are added in fixed order
-        __shared__ float4 group[32][8];
-        const int q = threadIdx.x & 7, r = threadIdx.x >> 3;
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        const f4v* p4 = reinterpret_cast<const f4v*>(partial);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int rows = (int)gridDim.x;
-        for (int b = r; b < rows; b += 32 * 8) {
-            f4v v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int row = b + 32 * k;
-                const f4v zero = {0.f, 0.f, 0.f, 0.f};
-                v[k] = row < rows ? __builtin_nontemporal_load(&p4[row * 8 + q]) : zero;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
-        }
-        group[r][q] = s;
-        __syncthreads();
-        if (threadIdx.x < GH_SLOTS) {
-            const float* g = reinterpret_cast<const float*>(group);
-            float t = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 32; k++) t += g[k * GH_SLOTS + threadIdx.x];
-            result[threadIdx.x] = t;
-            if (mailbox) mailbox[threadIdx.x] = t;
-        }
-    }
-    if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch
-    if (mailbox) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) { mailbox[GH_SLOTS] = __int_as_float(seq); __threadfence_system(); }
-    }
 }
 
 // ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
@@ -262,7 +260,7 @@ inline int float_bits(float f) { int i; memcpy(&i, &f, 4); return i; }
 struct Scratch {
     float* level[GPS_TRACK_MAX_LEVELS];  // [0] unused (= s.depth)
     float *partial, *result;
-    int *count, *ticket;
+    int* count;
 };
 
 size_t carve(Scratch* w, char* base, int W, int H) {
@@ -274,10 +272,9 @@ size_t carve(Scratch* w, char* base, int W, int H) {
         char* p = take((size_t)(lw > 0 && lh > 0 ? lw * lh : 1) * sizeof(float));
         if (w) w->level[l] = (float*)p;
     }
-    char* p = take((size_t)GH_WGS * GH_SLOTS * sizeof(float)); if (w) w->partial = (float*)p;
+    char* p = take((size_t)GH_MAX_WGS * GH_SLOTS * sizeof(float)); if (w) w->partial = (float*)p;
     p = take(GH_SLOTS * sizeof(float)); if (w) w->result = (float*)p;
     p = take(sizeof(int)); if (w) w->count = (int*)p;
-    p = take(sizeof(int)); if (w) w->ticket = (int*)p;
     return off;
 }
 
@@ -348,7 +345,6 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
         for (int k = 0; k < 4; k++) lintr[l][k] = lintr[l - 1][k] * 0.5f;
     }
     if (hipMemsetAsync(w.count, 0, sizeof(int), st) != hipSuccess) return GPS_ERR_LAUNCH;
-    if (hipMemsetAsync(w.ticket, 0, sizeof(int), st) != hipSuccess) return GPS_ERR_LAUNCH;
     count_valid_kernel<<<128, 256, 0, st>>>(s.depth, W * H, w.count);
     GPS_LAUNCH_CHECK();
 
@@ -385,9 +381,10 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             const int n_wgs = min(GH_WGS, gps_div_up(a.vw * a.vh, 256));
             volatile float* mailbox = reinterpret_cast<volatile float*>(ts->host_mailbox);
             const int seq = ++mail_seq;
-            if (it == TRK_ROTATION) track_gh_kernel<TRK_ROTATION><<<n_wgs, 256, 0, st>>>(a, w.partial, w.ticket, w.result, mailbox, seq);
-            else if (it == TRK_TRANSLATION) track_gh_kernel<TRK_TRANSLATION><<<n_wgs, 256, 0, st>>>(a, w.partial, w.ticket, w.result, mailbox, seq);
-            else track_gh_kernel<TRK_BOTH><<<n_wgs, 256, 0, st>>>(a, w.partial, w.ticket, w.result, mailbox, seq);
+            if (it == TRK_ROTATION) track_gh_kernel<TRK_ROTATION><<<n_wgs, 256, 0, st>>>(a, w.partial);
+            else if (it == TRK_TRANSLATION) track_gh_kernel<TRK_TRANSLATION><<<n_wgs, 256, 0, st>>>(a, w.partial);
+            else track_gh_kernel<TRK_BOTH><<<n_wgs, 256, 0, st>>>(a, w.partial);
+            track_sum_kernel<<<1, 256, 0, st>>>(w.partial, n_wgs, w.result, mailbox, seq);
             GPS_LAUNCH_CHECK();
             float host[GH_SLOTS];
             if (mailbox) {
