@@ -668,3 +668,148 @@ ORC_API void orc_raster_ges_bwd_exact(int W, int H, int tile_size, int tw, int t
                 }
         }
 }
+
+/* ====================================================================================================================
+ * `raw` render method: depth-sorted tile binning + front-to-back alpha compositing.
+ *   gsplat/rasterizer/isect_tiles.cu:30-130 (key = tile_id << 32 | bits(depth)), :160-340 (radix sort over 32+tile bits),
+ *   :343-430 (offset encode); rasterize_to_pixels_fwd.cu:18-203; rasterize_to_pixels_bwd.cu:20-297.  COLOR_DIM = 4
+ *   (rgb + depth, raw_gs_model.cpp:117), one camera, no masks.
+ * ================================================================================================================== */
+
+/* isectTiles: isect_ids (sorted), flatten_ids (sorted) and offsets[th*tw].  Stable: equal (tile, depth) keys keep
+ * Gaussian-index order, as a stable LSD radix sort of the reference's expansion order does. */
+ORC_API void orc_isect_tiles_depth(int N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+                                   int tw, int th, int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids,
+                                   int32_t *offsets) {
+    const int n_tiles = tw * th;
+    int64_t *ids = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_isects > 0 ? n_isects : 1));
+    int32_t *flat = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_isects > 0 ? n_isects : 1));
+    int64_t cur = 0;
+    for (int i = 0; i < N; i++) {
+        if (radii[i] <= 0) continue;
+        uint32_t mn[2], mx[2];
+        tile_bbox(means2d + 2 * i, radii[i], (uint32_t)tile_size, (uint32_t)tw, (uint32_t)th, mn, mx);
+        int32_t dbits;
+        memcpy(&dbits, &depths[i], 4);
+        for (int32_t ty = (int32_t)mn[1]; ty < (int32_t)mx[1]; ++ty)
+            for (int32_t tx = (int32_t)mn[0]; tx < (int32_t)mx[0]; ++tx) {
+                ids[cur] = (((int64_t)ty * tw + tx) << 32) | (int64_t)dbits;
+                flat[cur] = i;
+                ++cur;
+            }
+    }
+    /* stable sort by the 64-bit key: LSD over 16-bit digits (4 passes), like cub's stable radix sort */
+    int64_t *ids2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_isects > 0 ? n_isects : 1));
+    int32_t *flat2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_isects > 0 ? n_isects : 1));
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * 65537);
+    for (int pass = 0; pass < 4; pass++) {
+        memset(cnt, 0, sizeof(int64_t) * 65537);
+        const int shift = 16 * pass;
+        for (int64_t k = 0; k < n_isects; k++) cnt[(((uint64_t)ids[k]) >> shift & 0xFFFF) + 1]++;
+        for (int d = 0; d < 65536; d++) cnt[d + 1] += cnt[d];
+        for (int64_t k = 0; k < n_isects; k++) {
+            int64_t pos = cnt[((uint64_t)ids[k]) >> shift & 0xFFFF]++;
+            ids2[pos] = ids[k]; flat2[pos] = flat[k];
+        }
+        int64_t *ti = ids; ids = ids2; ids2 = ti;
+        int32_t *tf = flat; flat = flat2; flat2 = tf;
+    }
+    memcpy(isect_ids, ids, sizeof(int64_t) * (size_t)n_isects);
+    memcpy(flatten_ids, flat, sizeof(int32_t) * (size_t)n_isects);
+    /* offsets[t] = first position whose tile id >= t */
+    {
+        int64_t k = 0;
+        for (int t = 0; t < n_tiles; t++) {
+            while (k < n_isects && (ids[k] >> 32) < t) k++;
+            offsets[t] = (int32_t)k;
+        }
+    }
+    free(cnt); free(ids); free(flat); free(ids2); free(flat2);
+}
+
+/* rasterize_to_pixels_fwd.cu:92-203.  backgrounds may be NULL.  render_alphas = 1 - T. */
+ORC_API void orc_raster_raw_fwd(int W, int H, int tile_size, int tw, int th, int64_t n_isects, const float *means2d,
+                                const float *conics, const float *colors /*[N,4]*/, const float *opacities,
+                                const float *backgrounds /*[4] or NULL*/, const int32_t *offsets,
+                                const int32_t *flatten_ids, float *render_colors, float *render_alphas, int32_t *last_ids) {
+    for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+        const int tile_id = (i / tile_size) * tw + (j / tile_size);
+        const int32_t range_start = offsets[tile_id];
+        const int32_t range_end = (tile_id == tw * th - 1) ? (int32_t)n_isects : offsets[tile_id + 1];
+        const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+        float T = 1.0f, out[4] = {0, 0, 0, 0};
+        uint32_t cur_idx = 0;
+        for (int32_t idx = range_start; idx < range_end; idx++) {
+            const int32_t g = flatten_ids[idx];
+            const float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+            const float sigma = 0.5f * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
+            float alpha = opacities[g] * expf(-sigma);
+            alpha = alpha < 0.999f ? alpha : 0.999f;
+            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+            const float next_T = T * (1.0f - alpha);
+            if (next_T <= 1e-4) break;  /* (double literal in the reference: float <= 1e-4 promotes) */
+            const float vis = alpha * T;
+            for (int k = 0; k < 4; k++) out[k] += colors[4 * g + k] * vis;
+            cur_idx = (uint32_t)idx;
+            T = next_T;
+        }
+        const int pix = i * W + j;
+        render_alphas[pix] = 1.0f - T;
+        for (int k = 0; k < 4; k++) render_colors[4 * pix + k] = backgrounds ? out[k] + T * backgrounds[k] : out[k];
+        last_ids[pix] = (int32_t)cur_idx;
+    }
+}
+
+/* rasterize_to_pixels_bwd.cu:72-297: per pixel, back to front from last_ids.  Outputs are accumulated (zero them first). */
+ORC_API void orc_raster_raw_bwd(int W, int H, int tile_size, int tw, int th, int64_t n_isects, const float *means2d,
+                                const float *conics, const float *colors, const float *opacities, const float *backgrounds,
+                                const int32_t *offsets, const int32_t *flatten_ids, const float *render_alphas,
+                                const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                                float *v_means2d_abs /* or NULL */, float *v_means2d, float *v_conics, float *v_colors,
+                                float *v_opacities) {
+    (void)n_isects; (void)th;
+    for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+        const int tile_id = (i / tile_size) * tw + (j / tile_size);
+        const int32_t range_start = offsets[tile_id];
+        const int pix = i * W + j;
+        const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+        const float T_final = 1.0f - render_alphas[pix];
+        float T = T_final, buffer[4] = {0, 0, 0, 0};
+        const int32_t bin_final = last_ids[pix];
+        const float *vc = v_render_colors + 4 * pix;
+        const float va = v_render_alphas[pix];
+        for (int32_t idx = bin_final; idx >= range_start; idx--) {
+            const int32_t g = flatten_ids[idx];
+            const float cx = conics[3 * g], cy = conics[3 * g + 1], cz = conics[3 * g + 2];
+            const float opac = opacities[g];
+            const float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+            const float sigma = 0.5f * (cx * dx * dx + cz * dy * dy) + cy * dx * dy;
+            const float vis = expf(-sigma);
+            float alpha = opac * vis; alpha = alpha < 0.999f ? alpha : 0.999f;
+            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+            const float ra = 1.0f / (1.0f - alpha);
+            T *= ra;
+            const float fac = alpha * T;
+            for (int k = 0; k < 4; k++) v_colors[4 * g + k] += fac * vc[k];
+            float v_alpha = 0.f;
+            for (int k = 0; k < 4; k++) v_alpha += (colors[4 * g + k] * T - buffer[k] * ra) * vc[k];
+            v_alpha += T_final * ra * va;
+            if (backgrounds) {
+                float accum = 0.f;
+                for (int k = 0; k < 4; k++) accum += backgrounds[k] * vc[k];
+                v_alpha += -T_final * ra * accum;
+            }
+            if (opac * vis <= 0.999f) {
+                const float v_sigma = -opac * vis * v_alpha;
+                v_conics[3 * g] += 0.5f * v_sigma * dx * dx;
+                v_conics[3 * g + 1] += v_sigma * dx * dy;
+                v_conics[3 * g + 2] += 0.5f * v_sigma * dy * dy;
+                const float gx = v_sigma * (cx * dx + cy * dy), gy = v_sigma * (cy * dx + cz * dy);
+                v_means2d[2 * g] += gx; v_means2d[2 * g + 1] += gy;
+                if (v_means2d_abs) { v_means2d_abs[2 * g] += fabsf(gx); v_means2d_abs[2 * g + 1] += fabsf(gy); }
+                v_opacities[g] += vis * v_alpha;
+            }
+            for (int k = 0; k < 4; k++) buffer[k] += colors[4 * g + k] * fac;
+        }
+    }
+}

@@ -155,3 +155,57 @@ def raster_ges_bwd_exact(means2d, conics, colors, opacities, ref_depth, W, H, ti
                                     _p(colors), _p(opacities), _p(ref_depth), _p(offsets), _p(flatten_ids),
                                     _p(v_render_colors), _p(v_render_alphas), _p(v_m), _p(v_c), _p(v_col), _p(v_o))
     return v_m, v_c, v_col, v_o
+
+
+# ----------------------------------------------------------------------------- `raw` render method
+def isect_tiles_depth(means2d, radii, depths, tile_size, tw, th):
+    """isectTiles + isectOffsetEncode (depth-keyed): -> tiles_per_gauss, isect_ids(sorted), flatten_ids(sorted), offsets"""
+    means2d, radii, depths = _f32(means2d), _i32(radii), _f32(depths)
+    N = radii.shape[0]
+    tpg = np.zeros(N, np.int32)
+    gpg = np.zeros(N, np.int32)
+    ni, ng = C.c_int64(0), C.c_int64(0)
+    _lib().orc_isect_count(C.c_int(N), _p(means2d), _p(radii), C.c_int(tile_size), C.c_int(tw), C.c_int(th), _p(tpg),
+                           _p(gpg), C.byref(ni), C.byref(ng))
+    ni = ni.value
+    isect_ids = np.zeros(max(ni, 1), np.int64)
+    flatten_ids = np.zeros(max(ni, 1), np.int32)
+    offsets = np.zeros((th, tw), np.int32)
+    _lib().orc_isect_tiles_depth(C.c_int(N), _p(means2d), _p(radii), _p(depths), C.c_int(tile_size), C.c_int(tw),
+                                 C.c_int(th), C.c_int64(ni), _p(isect_ids), _p(flatten_ids), _p(offsets))
+    return tpg, isect_ids[:ni], flatten_ids[:ni], offsets
+
+
+def raster_raw_fwd(means2d, conics, colors, opacities, W, H, tile_size, offsets, flatten_ids, backgrounds=None):
+    """-> render_colors[H,W,4], render_alphas[H,W], last_ids[H,W]"""
+    means2d, conics, colors, opacities = _f32(means2d), _f32(conics), _f32(colors), _f32(opacities)
+    offsets, flatten_ids = _i32(offsets), _i32(flatten_ids)
+    th, tw = offsets.shape
+    bg = None if backgrounds is None else _f32(backgrounds)
+    rc = np.zeros((H, W, 4), np.float32)
+    ra = np.zeros((H, W), np.float32)
+    last = np.zeros((H, W), np.int32)
+    _lib().orc_raster_raw_fwd(C.c_int(W), C.c_int(H), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                              C.c_int64(flatten_ids.shape[0]), _p(means2d), _p(conics), _p(colors), _p(opacities),
+                              _p(bg) if bg is not None else None, _p(offsets), _p(flatten_ids), _p(rc), _p(ra), _p(last))
+    return rc, ra, last
+
+
+def raster_raw_bwd(means2d, conics, colors, opacities, W, H, tile_size, offsets, flatten_ids, render_alphas, last_ids,
+                   v_render_colors, v_render_alphas, backgrounds=None, absgrad=False):
+    """-> v_means2d[N,2], v_conics[N,3], v_colors[N,4], v_opacities[N] (+ v_means2d_abs if absgrad)"""
+    means2d, conics, colors, opacities = _f32(means2d), _f32(conics), _f32(colors), _f32(opacities)
+    offsets, flatten_ids = _i32(offsets), _i32(flatten_ids)
+    th, tw = offsets.shape
+    N = opacities.shape[0]
+    bg = None if backgrounds is None else _f32(backgrounds)
+    ra, last = _f32(render_alphas), _i32(last_ids)
+    v_rc, v_ra = _f32(v_render_colors), _f32(v_render_alphas)
+    v_m, v_c, v_col, v_o = (np.zeros((N, 2), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32),
+                            np.zeros(N, np.float32))
+    v_abs = np.zeros((N, 2), np.float32) if absgrad else None
+    _lib().orc_raster_raw_bwd(C.c_int(W), C.c_int(H), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                              C.c_int64(flatten_ids.shape[0]), _p(means2d), _p(conics), _p(colors), _p(opacities),
+                              _p(bg) if bg is not None else None, _p(offsets), _p(flatten_ids), _p(ra), _p(last), _p(v_rc),
+                              _p(v_ra), _p(v_abs) if absgrad else None, _p(v_m), _p(v_c), _p(v_col), _p(v_o))
+    return (v_m, v_c, v_col, v_o, v_abs) if absgrad else (v_m, v_c, v_col, v_o)

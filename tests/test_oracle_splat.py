@@ -301,3 +301,88 @@ def test_oracle_reproduces_committed_splat_golden():
                                 G["group_gs_ids"], G["group_starts"], 0.1, G["v_rc"], G["v_ra"])
     for a, name in zip(got, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
         np.testing.assert_allclose(a, G[name], rtol=1e-4, atol=1e-5 * np.abs(G[name]).max(), err_msg=name)
+
+
+# ----------------------------------------------------------------------------- `raw` render method
+def _dense_raw(means2d, conics, colors, opac, depths, radii, bg, Wd, Hd):
+    """Dense float64 front-to-back compositing: every pixel sees every visible Gaussian in (depth, index) order, with the
+    reference's per-pair rejection rules and its termination rule T * (1 - alpha) <= 1e-4 (exclusive)."""
+    vis = torch.nonzero(radii > 0).squeeze(1)
+    order = vis[torch.argsort(depths[vis], stable=True)]
+    ys, xs = torch.meshgrid(torch.arange(Hd, dtype=torch.float64) + 0.5, torch.arange(Wd, dtype=torch.float64) + 0.5, indexing="ij")
+    T = torch.ones(Hd, Wd, dtype=torch.float64)
+    done = torch.zeros(Hd, Wd, dtype=torch.bool)
+    out = torch.zeros(Hd, Wd, 4, dtype=torch.float64)
+    for g in order.tolist():
+        dx, dy = means2d[g, 0] - xs, means2d[g, 1] - ys
+        sigma = 0.5 * (conics[g, 0] * dx * dx + conics[g, 2] * dy * dy) + conics[g, 1] * dx * dy
+        alpha = torch.clamp_max(opac[g] * torch.exp(-sigma), 0.999)
+        ok = (sigma >= 0) & (alpha >= 1.0 / 255.0) & ~done
+        # pixels outside the Gaussian's tile footprint never see it in the tiled version: reject by the 3-sigma radius box
+        ok = ok & (dx.abs() <= radii[g] + 16) & (dy.abs() <= radii[g] + 16)
+        next_T = T * (1 - alpha)
+        stop = ok & (next_T <= 1e-4)
+        done = done | stop
+        use = ok & ~stop
+        out = out + torch.where(use[..., None], colors[g][None, None, :] * (alpha * T)[..., None], torch.zeros(1, dtype=torch.float64))
+        T = torch.where(use, next_T, T)
+    if bg is not None:
+        out = out + T[..., None] * bg
+    return out, 1 - T
+
+
+def _raw_scene(N=250, seed=9):
+    g = scenes.random_gaussians(N, seed=seed, scale_range=(0.02, 0.12))
+    c2w, K = scenes.default_camera(W, H, seed=seed)
+    vm = scenes.pose_inv(c2w)
+    scales = np.exp(g["log_scales"]).astype(np.float32)
+    radii, m2, depths, conics = orc.proj_fwd(g["means"], g["quats"], scales, vm, K, W, H)
+    rng = np.random.default_rng(seed)
+    colors = np.concatenate([rng.uniform(0, 1, (N, 3)), depths[:, None]], 1).astype(np.float32)
+    opac = rng.uniform(0.05, 0.95, N).astype(np.float32)
+    return radii, m2, depths, conics, colors, opac
+
+
+def test_raw_binning_is_depth_sorted_and_stable():
+    radii, m2, depths, conics, colors, opac = _raw_scene()
+    depths = depths.copy()
+    depths[10] = depths[11] = depths[12]  # ties keep index order
+    tpg, ids, flat, offs = orc.isect_tiles_depth(m2, radii, depths, TS, TW, TH)
+    assert len(ids) == tpg.sum() and np.all(np.diff(ids) >= 0)
+    tiles = (ids >> 32).astype(np.int64)
+    for t in range(TW * TH):
+        lo, hi = offs.reshape(-1)[t], (offs.reshape(-1)[t + 1] if t + 1 < TW * TH else len(ids))
+        assert np.all(tiles[lo:hi] == t)
+        d = depths[flat[lo:hi]]
+        assert np.all(np.diff(d) >= 0)
+        same = np.nonzero(np.diff(d) == 0)[0]
+        assert np.all(flat[lo:hi][same] < flat[lo:hi][same + 1])
+    assert np.array_equal((ids & 0xFFFFFFFF).astype(np.uint32), depths[flat].view(np.uint32))
+
+
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_raw_forward_and_backward_match_dense_compositing(with_bg):
+    radii, m2, depths, conics, colors, opac = _raw_scene()
+    bg = np.array([0.2, 0.4, 0.6, 0.0], np.float32) if with_bg else None
+    tpg, ids, flat, offs = orc.isect_tiles_depth(m2, radii, depths, TS, TW, TH)
+    rc, ra, last = orc.raster_raw_fwd(m2, conics, colors, opac, W, H, TS, offs, flat, backgrounds=bg)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    tm2, tcon, tcol, top = t(m2), t(conics), t(colors), t(opac)
+    d_rc, d_ra = _dense_raw(tm2, tcon, tcol, top, torch.tensor(depths), torch.tensor(radii), None if bg is None else torch.tensor(bg, dtype=torch.float64), W, H)
+    # a pair within float rounding of a threshold (alpha = 1/255, T = 1e-4) may flip: allow a handful of pixels
+    for got, ref in ((rc, d_rc.detach().numpy()), (ra, d_ra.detach().numpy())):
+        bad = np.abs(got - ref) > (1e-4 * np.abs(ref) + 1e-4)
+        assert bad.mean() < 2e-3, bad.mean()
+    assert ra.max() > 0.9 and (last > 0).any()
+    rng = np.random.default_rng(1)
+    v_rc = rng.normal(size=(H, W, 4)).astype(np.float32)
+    v_ra = rng.normal(size=(H, W)).astype(np.float32)
+    (d_rc * torch.tensor(v_rc, dtype=torch.float64)).sum().backward(retain_graph=True)
+    (d_ra * torch.tensor(v_ra, dtype=torch.float64)).sum().backward()
+    out = orc.raster_raw_bwd(m2, conics, colors, opac, W, H, TS, offs, flat, ra, last, v_rc, v_ra, backgrounds=bg, absgrad=True)
+    for got, ref, name in zip(out[:4], (tm2.grad, tcon.grad, tcol.grad, top.grad), ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        ref = ref.numpy().reshape(got.shape)
+        scale = np.abs(ref).max()
+        bad = np.abs(got - ref) > (5e-3 * np.abs(ref) + 2e-3 * scale)
+        assert bad.mean() < 0.02, (name, bad.mean(), scale)
+    assert np.all(out[4] >= np.abs(out[0]) - 1e-6)  # absgrad dominates |grad|
