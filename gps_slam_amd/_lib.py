@@ -63,6 +63,10 @@ PROTOTYPES = {
     "gps_sh_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_isect_workspace_bytes": (i64, [i32, i64]),
     "gps_isect_tiles_no_depth": (i32, [i32, vp, vp, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "gps_isect_tiles": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "gps_raster_raw_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_raster_raw_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                 vp]),
     "gps_raster_ges_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
     "gps_raster_ges_bwd_gs": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp,
                                     i32, vp]),

@@ -68,21 +68,27 @@ __global__ __launch_bounds__(BIN_BLOCK) void count_kernel(int N, const float* __
                                                          int32_t* __restrict__ groups_per_gauss,
                                                          int32_t* __restrict__ blk_tiles,
                                                          int32_t* __restrict__ blk_groups,
-                                                         int32_t* __restrict__ blk_vis) {
+                                                         int32_t* __restrict__ blk_vis,
+                                                         const uint32_t* __restrict__ order,
+                                                         int32_t* __restrict__ tiles_by_rank) {
+    // order != NULL (depth-keyed binning of the `raw` method): thread i handles the Gaussian of depth rank i; its tile
+    // count also goes to tiles_by_rank[i], which is what the expansion scans; no pixel groups are produced
     __shared__ int red[3][BIN_BLOCK / 64];
     int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
     int t = 0, g = 0, vis = 0;
     if (i < N) {
-        int r = radii[i];
+        const int gi = order ? (int)order[i] : i;
+        int r = radii[gi];
         if (r > 0) {
-            float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
+            float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)gi);
             TileBox b = tile_bbox(m.x, m.y, r, tile_size, tw, th);
             t = (int)((b.y1 - b.y0) * (b.x1 - b.x0));
             float rf = (float)r;
-            g = (int)((4 * rf * rf + 32 - 1) / 32);  // fp32 expression of isect_tiles_no_depth.cu:87
+            if (!order) g = (int)((4 * rf * rf + 32 - 1) / 32);  // fp32 expression of isect_tiles_no_depth.cu:87
             vis = 1;
         }
-        tiles_per_gauss[i] = t;
+        tiles_per_gauss[gi] = t;
+        if (order) tiles_by_rank[i] = t;
         groups_per_gauss[i] = g;
     }
     int ts = wave_sum_i(t), gs = wave_sum_i(g), vs = wave_sum_i(vis);
@@ -137,20 +143,24 @@ __global__ __launch_bounds__(BIN_BLOCK) void expand_kernel(int N, const float* _
                                                           int64_t group_cap, uint32_t* __restrict__ keys,
                                                           uint32_t* __restrict__ vals,
                                                           int32_t* __restrict__ group_gs_ids,
-                                                          int32_t* __restrict__ group_starts) {
+                                                          int32_t* __restrict__ group_starts,
+                                                          const uint32_t* __restrict__ order) {
+    // order != NULL: thread i expands the Gaussian of depth rank i (tiles_per_gauss is then indexed by rank)
     __shared__ int ws[17];
     __shared__ int pre_t[BIN_BLOCK + 1];
     __shared__ int pre_g[BIN_BLOCK + 1];
-    __shared__ uint32_t box_x0[BIN_BLOCK], box_y0[BIN_BLOCK], box_w[BIN_BLOCK];
+    __shared__ uint32_t box_x0[BIN_BLOCK], box_y0[BIN_BLOCK], box_w[BIN_BLOCK], box_id[BIN_BLOCK];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * BIN_BLOCK + tid;
     int t = 0, g = 0;
     if (i < N) {
+        const int gi = order ? (int)order[i] : i;
+        box_id[tid] = (uint32_t)gi;
         t = tiles_per_gauss[i];
         g = groups_per_gauss[i];
         if (t > 0) {
-            float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)i);
-            TileBox b = tile_bbox(m.x, m.y, radii[i], tile_size, tw, th);
+            float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)gi);
+            TileBox b = tile_bbox(m.x, m.y, radii[gi], tile_size, tw, th);
             box_x0[tid] = b.x0; box_y0[tid] = b.y0; box_w[tid] = b.x1 - b.x0;
         }
     }
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(BIN_BLOCK) void expand_kernel(int N, const float* _
         uint32_t w = box_w[lo];
         uint32_t ty = box_y0[lo] + (uint32_t)k / w, tx = box_x0[lo] + (uint32_t)k % w;
         int64_t o = base_t + j;
-        if (o < isect_cap) { keys[o] = ty * (uint32_t)tw + tx; vals[o] = (uint32_t)(blockIdx.x * BIN_BLOCK + lo); }
+        if (o < isect_cap) { keys[o] = ty * (uint32_t)tw + tx; vals[o] = box_id[lo]; }
     }
     // one thread per output group
     for (int j = tid; j < tot_g; j += BIN_BLOCK) {
@@ -293,7 +303,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 // isect_tiles_no_depth.cu:373-425
 __global__ __launch_bounds__(256) void offsets_kernel(const uint32_t* __restrict__ keys,
                                                      const int64_t* __restrict__ counts, int n_tiles,
-                                                     int32_t* __restrict__ offsets, int64_t* __restrict__ isect_ids) {
+                                                     int32_t* __restrict__ offsets, int64_t* __restrict__ isect_ids,
+                                                     const float* __restrict__ depths,
+                                                     const int32_t* __restrict__ flatten_ids) {
     const int n = (int)counts[0];
     const int stride = gridDim.x * blockDim.x;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -303,7 +315,9 @@ __global__ __launch_bounds__(256) void offsets_kernel(const uint32_t* __restrict
     }
     for (int idx = gid; idx < n; idx += stride) {
         int cur = (int)keys[idx];
-        if (isect_ids) isect_ids[idx] = (int64_t)cur;
+        if (isect_ids)  // isect_tiles.cu:98-109: tile id in the high word, the depth's bit pattern in the low word
+            isect_ids[idx] = depths ? (((int64_t)cur << 32) | (int64_t)(uint32_t)__float_as_int(depths[flatten_ids[idx]]))
+                                    : (int64_t)cur;
         int prev = idx > 0 ? (int)keys[idx - 1] : -1;
         for (int t = prev + 1; t <= cur; t++) offsets[t] = idx;
         if (idx == n - 1)
@@ -311,9 +325,32 @@ __global__ __launch_bounds__(256) void offsets_kernel(const uint32_t* __restrict
     }
 }
 
+// ---------------- depth mode helpers (isect_tiles.cu: key = tile << 32 | bits(depth)) ----------------
+// Sorting 64-bit (tile, depth) keys over all I intersections would take 6 radix passes over I items.  Equivalent and much
+// cheaper: sort the N Gaussians by depth once (4 passes over N << I items, invisible ones last), expand them in that order,
+// then the usual stable sort by tile id (2 passes over I) leaves every tile's list in (depth, index) order.
+__global__ __launch_bounds__(256) void depth_keys_kernel(int N, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        int64_t* __restrict__ count_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { count_n[0] = N; count_n[1] = 0; count_n[2] = 0; count_n[3] = 0; }
+    if (i >= N) return;
+    keys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // visible depths are positive floats
+    vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void copy_u32_kernel(int n, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 struct Workspace {
     int32_t *groups_per_gauss, *blk_tiles, *blk_groups, *blk_vis;
     uint32_t *keys_a, *vals_a, *keys_b, *vals_b, *hist, *digit_total;
+    uint32_t* order;         // depth mode: Gaussian id by depth rank
+    int32_t* tiles_by_rank;  // depth mode: tile count by depth rank
+    int64_t* count_n;        // depth mode: {N, 0, 0, 0} for the radix kernels
+    int32_t* dummy_groups;
     int nblkN, nblkI;
 };
 
@@ -335,6 +372,10 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
     p = take((size_t)cap * 4); if (w) w->vals_b = (uint32_t*)p;
     p = take((size_t)256 * nblkI * 4); if (w) w->hist = (uint32_t*)p;
     p = take((size_t)256 * 4); if (w) w->digit_total = (uint32_t*)p;
+    p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->order = (uint32_t*)p;
+    p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->tiles_by_rank = (int32_t*)p;
+    p = take(4 * sizeof(int64_t)); if (w) w->count_n = (int64_t*)p;
+    p = take(256); if (w) w->dummy_groups = (int32_t*)p;
     if (w) { w->nblkN = nblkN; w->nblkI = nblkI; }
     return off;
 }
@@ -348,34 +389,54 @@ int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity) {
     return (int64_t)carve(nullptr, nullptr, N, isect_capacity);
 }
 
-int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
-                             int tile_height, int64_t isect_capacity, int64_t group_capacity,
-                             int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids,
-                             int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets, int64_t* counts,
-                             void* workspace, int64_t workspace_bytes, gps_stream stream) {
+static int isect_impl(int N, const float* means2d, const int32_t* radii, const float* depths /* NULL: no-depth variant */,
+                      int tile_size, int tile_width, int tile_height, int64_t isect_capacity, int64_t group_capacity,
+                      int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* group_gs_ids,
+                      int32_t* group_starts, int32_t* tile_offsets, int64_t* counts, void* workspace, int64_t workspace_bytes,
+                      gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
     GPS_REQUIRE(isect_capacity > 0 && isect_capacity < (1ll << 31) && group_capacity > 0 && group_capacity < (1ll << 31));
-    GPS_REQUIRE(flatten_ids && group_gs_ids && group_starts && tile_offsets && counts && workspace);
+    GPS_REQUIRE(flatten_ids && tile_offsets && counts && workspace);
+    GPS_REQUIRE(depths || (group_gs_ids && group_starts));
     GPS_REQUIRE(N == 0 || (means2d && radii && tiles_per_gauss));
     const int n_tiles = tile_width * tile_height;
     GPS_REQUIRE(n_tiles <= (1 << 16));
     if (workspace_bytes < gps_isect_workspace_bytes(N, isect_capacity)) return GPS_ERR_CAPACITY;
+    GPS_REQUIRE(!depths || N <= isect_capacity);  // the Gaussian sort borrows the intersection buffers
     Workspace w;
     carve(&w, (char*)workspace, N, isect_capacity);
     hipStream_t s = (hipStream_t)stream;
+    const uint32_t* order = nullptr;
+    if (depths && N > 0) {
+        depth_keys_kernel<<<gps_div_up(N, 256), 256, 0, s>>>(N, radii, depths, w.keys_a, w.vals_a, w.count_n);
+        uint32_t *ka = w.keys_a, *va = w.vals_a, *kb = w.keys_b, *vb = w.vals_b;
+        const int nblkN_sort = gps_div_up(N, SORT_TILE);
+        for (int pass = 0; pass < 4; pass++) {
+            radix_hist_kernel<<<nblkN_sort, SORT_THREADS, 0, s>>>(ka, w.count_n, 8 * pass, 8, w.nblkI, w.hist);
+            radix_scan_kernel<<<256, 256, 0, s>>>(w.count_n, w.nblkI, w.hist, w.digit_total);
+            radix_scatter_kernel<<<nblkN_sort, SORT_THREADS, 0, s>>>(ka, va, w.count_n, 8 * pass, 8, w.nblkI, w.hist,
+                                                                    w.digit_total, kb, vb);
+            uint32_t* t = ka; ka = kb; kb = t;
+            t = va; va = vb; vb = t;
+        }
+        copy_u32_kernel<<<gps_div_up(N, 256), 256, 0, s>>>(N, va, w.order);  // (4 passes: va == w.vals_a again)
+        order = w.order;
+    }
+    int32_t* tpg_scan = order ? w.tiles_by_rank : tiles_per_gauss;
+    if (!group_gs_ids) { group_gs_ids = w.dummy_groups; group_starts = w.dummy_groups; }
 
     if (N > 0)
         count_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
                                                    tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
-                                                   w.blk_vis);
+                                                   w.blk_vis, order, w.tiles_by_rank);
     scan_blocks_kernel<<<1, SCAN_THREADS, 0, s>>>(N > 0 ? w.nblkN : 0, w.blk_tiles, w.blk_groups, w.blk_vis,
                                                   isect_capacity, group_capacity, counts);
     if (N > 0)
         expand_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
-                                                    tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
+                                                    tpg_scan, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
                                                     isect_capacity, group_capacity, w.keys_a, w.vals_a, group_gs_ids,
-                                                    group_starts);
+                                                    group_starts, order);
     int bits_total = 1;
     while ((1 << bits_total) < n_tiles) bits_total++;
     const uint32_t* sorted_keys;
@@ -397,9 +458,31 @@ int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, 
                                                                     w.hist, w.digit_total, w.keys_a, (uint32_t*)flatten_ids);
         sorted_keys = w.keys_a;
     }
-    offsets_kernel<<<512, 256, 0, s>>>(sorted_keys, counts, n_tiles, tile_offsets, isect_ids);
+    offsets_kernel<<<512, 256, 0, s>>>(sorted_keys, counts, n_tiles, tile_offsets, isect_ids, depths, flatten_ids);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
+}
+
+int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
+                             int tile_height, int64_t isect_capacity, int64_t group_capacity,
+                             int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids,
+                             int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets, int64_t* counts,
+                             void* workspace, int64_t workspace_bytes, gps_stream stream) {
+    GPS_REQUIRE(group_gs_ids && group_starts);
+    return isect_impl(N, means2d, radii, nullptr, tile_size, tile_width, tile_height, isect_capacity, group_capacity,
+                      tiles_per_gauss, isect_ids, flatten_ids, group_gs_ids, group_starts, tile_offsets, counts, workspace,
+                      workspace_bytes, stream);
+}
+
+int gps_isect_tiles(int N, const float* means2d, const int32_t* radii, const float* depths, int tile_size, int tile_width,
+                    int tile_height, int64_t isect_capacity, int32_t* tiles_per_gauss, int64_t* isect_ids,
+                    int32_t* flatten_ids, int32_t* tile_offsets, int64_t* counts, void* workspace, int64_t workspace_bytes,
+                    gps_stream stream) {
+    GPS_REQUIRE(N == 0 || depths);
+    static const float dummy_depth = 1.0f;
+    return isect_impl(N, means2d, radii, depths ? depths : &dummy_depth, tile_size, tile_width, tile_height, isect_capacity,
+                      1 << 20, tiles_per_gauss, isect_ids, flatten_ids, nullptr, nullptr, tile_offsets, counts, workspace,
+                      workspace_bytes, stream);
 }
 
 }  // extern "C"

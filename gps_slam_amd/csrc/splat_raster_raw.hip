@@ -1,0 +1,274 @@
+// `raw` render method: classic front-to-back alpha compositing over depth-sorted tile lists.
+//   rasterize_to_pixels_fwd.cu:18-203  -> raster_raw_fwd_kernel
+//   rasterize_to_pixels_bwd.cu:20-297  -> raster_raw_bwd_kernel
+// COLOR_DIM = 4 (rgb + depth, raw_gs_model.cpp:117), one camera, no tile masks; backgrounds optional.
+//
+// Both kernels: one workgroup (4 wave64) per 16x16 tile, one pixel per lane, the tile's depth-sorted list staged through
+// LDS in batches of 256 records.  Unlike the order-independent `ges` sum, compositing is a sequential recurrence in T per
+// pixel, so the inner loop keeps the reference's structure; what changes for gfx950 is the gradient reduction of the
+// backward: per Gaussian the 10 partial gradients of a wave's 64 pixels are summed with DPP adds (no LDS crossbar), the 4
+// waves of the tile accumulate into an LDS gradient tile with ds_add_f32, and ONE pass per batch adds the tile's 256 x 10
+// totals to global memory -- 10 global atomics per (tile, Gaussian) pair instead of the reference's 10 per (warp, Gaussian)
+// (8 warps per tile).
+#include "common.hpp"
+
+
+
+namespace {
+
+constexpr int RAW_BATCH = 256;
+
+struct RawRec {  // 48 bytes
+    float x, y, opac, ca;
+    float cb, cc, c0, c1;
+    float c2, c3;
+    int id, pad;
+};
+
+__device__ __forceinline__ RawRec load_rec(int g, const float2* __restrict__ means2d, const float* __restrict__ conics,
+                                           const float4* __restrict__ colors, const float* __restrict__ opacities) {
+    RawRec r;
+    const float2 xy = means2d[g];
+    const float4 c = colors[g];
+    r.x = xy.x; r.y = xy.y; r.opac = opacities[g];
+    r.ca = conics[3 * g]; r.cb = conics[3 * g + 1]; r.cc = conics[3 * g + 2];
+    r.c0 = c.x; r.c1 = c.y; r.c2 = c.z; r.c3 = c.w;
+    r.id = g; r.pad = 0;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void raster_raw_fwd_kernel(
+    const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ backgrounds, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids, const int64_t* __restrict__ counts,
+    float4* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+    __shared__ RawRec recs[RAW_BATCH];
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int tid = threadIdx.x;
+    const int i = ty * 16 + (tid >> 4), j = tx * 16 + (tid & 15);
+    const bool inside = (i < H) && (j < W);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+    bool done = !inside;
+    float T = 1.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    uint32_t cur_idx = 0;
+    for (int batch_start = range_start; batch_start < range_end; batch_start += RAW_BATCH) {
+        if (__syncthreads_count(done) >= (int)blockDim.x) break;  // also the barrier before the LDS tile is overwritten
+        const int idx = batch_start + tid;
+        if (idx < range_end) recs[tid] = load_rec(flatten_ids[idx], means2d, conics, colors, opacities);
+        __syncthreads();
+        const int n = min(RAW_BATCH, range_end - batch_start);
+        for (int t = 0; t < n && !done; ++t) {
+            const RawRec r = recs[t];
+            const float dx = r.x - px, dy = r.y - py;
+            const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
+            const float alpha = fminf(0.999f, r.opac * __expf(-sigma));
+            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+            const float next_T = T * (1.0f - alpha);
+            if ((double)next_T <= 1e-4) { done = true; break; }  // the reference compares against the double literal
+            const float vis = alpha * T;
+            o0 += r.c0 * vis; o1 += r.c1 * vis; o2 += r.c2 * vis; o3 += r.c3 * vis;
+            cur_idx = (uint32_t)(batch_start + t);
+            T = next_T;
+        }
+    }
+    if (inside) {
+        const int pix = i * W + j;
+        render_alphas[pix] = 1.0f - T;
+        if (backgrounds) { o0 += T * backgrounds[0]; o1 += T * backgrounds[1]; o2 += T * backgrounds[2]; o3 += T * backgrounds[3]; }
+        render_colors[pix] = make_float4(o0, o1, o2, o3);
+        last_ids[pix] = (int32_t)cur_idx;
+    }
+}
+
+// full-wave sum with DPP adds; the total lands in lane 63 only
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_raw(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add_raw<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_add_raw<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_add_raw<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_add_raw<0x118, 0xF>(v);  // row_shr:8
+    v = dpp_add_raw<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+    v = dpp_add_raw<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
+    return v;
+}
+
+__global__ __launch_bounds__(256) void zero_raw_grads_kernel(int N, float* __restrict__ v_means2d, float* __restrict__ v_conics,
+                                                            float* __restrict__ v_colors, float* __restrict__ v_opacities,
+                                                            float* __restrict__ v_abs) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < 4 * N; k += stride) {
+        v_colors[k] = 0.f;
+        if (k < 3 * N) v_conics[k] = 0.f;
+        if (k < 2 * N) { v_means2d[k] = 0.f; if (v_abs) v_abs[k] = 0.f; }
+        if (k < N) v_opacities[k] = 0.f;
+    }
+}
+
+template <bool ABS>
+__global__ __launch_bounds__(256) void raster_raw_bwd_kernel(
+    const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ backgrounds, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids, const int64_t* __restrict__ counts,
+    const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids, const float4* __restrict__ v_render_colors,
+    const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d,
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    constexpr int NG = ABS ? 12 : 10;  // rgb d | conic abc | xy | opac | (|x| |y|)
+    __shared__ RawRec recs[RAW_BATCH];
+    __shared__ float grad[RAW_BATCH][NG];
+    __shared__ int tile_last;
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = ty * 16 + (tid >> 4), j = tx * 16 + (tid & 15);
+    const bool inside = (i < H) && (j < W);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const int pix = inside ? i * W + j : 0;
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+    if (range_end <= range_start) return;
+    const float T_final = inside ? 1.0f - render_alphas[pix] : 1.0f;
+    float T = T_final;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;  // colour accumulated BEHIND the current Gaussian
+    const int bin_final = inside ? last_ids[pix] : -1;
+    const float4 vc = inside ? v_render_colors[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float va = inside ? v_render_alphas[pix] : 0.f;
+    float bg_dot = 0.f;
+    if (backgrounds) bg_dot = backgrounds[0] * vc.x + backgrounds[1] * vc.y + backgrounds[2] * vc.z + backgrounds[3] * vc.w;
+    // nothing behind the tile's furthest contributing Gaussian matters: start the walk there
+    if (tid == 0) tile_last = -1;
+    __syncthreads();
+    {
+        int m = bin_final;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if (lane == 0) atomicMax(&tile_last, m);
+    }
+    __syncthreads();
+    const int walk_end = min(range_end - 1, tile_last);  // inclusive
+    for (int batch_end = walk_end; batch_end >= range_start; batch_end -= RAW_BATCH) {
+        __syncthreads();
+        const int n = min(RAW_BATCH, batch_end + 1 - range_start);
+        if (tid < n) recs[tid] = load_rec(flatten_ids[batch_end - tid], means2d, conics, colors, opacities);  // [0] = furthest back
+        for (int k = tid; k < RAW_BATCH * NG; k += 256) (&grad[0][0])[k] = 0.f;
+        __syncthreads();
+        for (int t = 0; t < n; ++t) {
+            bool valid = inside && (batch_end - t <= bin_final);
+            const RawRec r = recs[t];
+            const float dx = r.x - px, dy = r.y - py;
+            const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
+            const float vis = __expf(-sigma);
+            const float alpha = fminf(0.999f, r.opac * vis);
+            valid = valid && !(sigma < 0.f || alpha < 1.f / 255.f);
+            if (!__any(valid)) continue;  // wave uniform
+            float g[NG];
+#pragma unroll
+            for (int k = 0; k < NG; k++) g[k] = 0.f;
+            if (valid) {
+                const float ra = 1.0f / (1.0f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                g[0] = fac * vc.x; g[1] = fac * vc.y; g[2] = fac * vc.z; g[3] = fac * vc.w;
+                float v_alpha = (r.c0 * T - b0 * ra) * vc.x + (r.c1 * T - b1 * ra) * vc.y + (r.c2 * T - b2 * ra) * vc.z +
+                                (r.c3 * T - b3 * ra) * vc.w;
+                v_alpha += T_final * ra * va;
+                if (backgrounds) v_alpha += -T_final * ra * bg_dot;
+                if (r.opac * vis <= 0.999f) {
+                    const float v_sigma = -r.opac * vis * v_alpha;
+                    g[4] = 0.5f * v_sigma * dx * dx;
+                    g[5] = v_sigma * dx * dy;
+                    g[6] = 0.5f * v_sigma * dy * dy;
+                    g[7] = v_sigma * (r.ca * dx + r.cb * dy);
+                    g[8] = v_sigma * (r.cb * dx + r.cc * dy);
+                    g[9] = vis * v_alpha;
+                    if (ABS) { g[10] = fabsf(g[7]); g[11] = fabsf(g[8]); }
+                }
+                b0 += r.c0 * fac; b1 += r.c1 * fac; b2 += r.c2 * fac; b3 += r.c3 * fac;
+            }
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                const float s = wave_sum_to_lane63(g[k]);
+                if (lane == 63 && s != 0.f) atomicAdd(&grad[t][k], s);  // ds_add_f32: the 4 waves of the tile meet here
+            }
+        }
+        __syncthreads();
+        // one pass per batch: the tile's totals go to global memory, 10 (12) atomics per Gaussian that received anything
+        if (tid < n) {
+            const int gid = recs[tid].id;
+            const float* gt = grad[tid];
+            float* vcol = v_colors + 4 * (size_t)gid;
+            float* vk = v_conics + 3 * (size_t)gid;
+            float* vm = v_means2d + 2 * (size_t)gid;
+            if (gt[0] != 0.f) atomicAdd(vcol + 0, gt[0]);
+            if (gt[1] != 0.f) atomicAdd(vcol + 1, gt[1]);
+            if (gt[2] != 0.f) atomicAdd(vcol + 2, gt[2]);
+            if (gt[3] != 0.f) atomicAdd(vcol + 3, gt[3]);
+            if (gt[4] != 0.f) atomicAdd(vk + 0, gt[4]);
+            if (gt[5] != 0.f) atomicAdd(vk + 1, gt[5]);
+            if (gt[6] != 0.f) atomicAdd(vk + 2, gt[6]);
+            if (gt[7] != 0.f) atomicAdd(vm + 0, gt[7]);
+            if (gt[8] != 0.f) atomicAdd(vm + 1, gt[8]);
+            if (gt[9] != 0.f) atomicAdd(v_opacities + gid, gt[9]);
+            if (ABS) {
+                if (gt[10] != 0.f) atomicAdd(v_means2d_abs + 2 * (size_t)gid + 0, gt[10]);
+                if (gt[11] != 0.f) atomicAdd(v_means2d_abs + 2 * (size_t)gid + 1, gt[11]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_raster_raw_fwd(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                       const float* backgrounds, int width, int height, int tile_size, const int32_t* tile_offsets,
+                       const int32_t* flatten_ids, const int64_t* counts, float* render_colors, float* render_alphas,
+                       int32_t* last_ids, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    GPS_REQUIRE(tile_size == 16);
+    GPS_REQUIRE(tile_offsets && flatten_ids && counts && render_colors && render_alphas && last_ids);
+    GPS_REQUIRE(N == 0 || (means2d && conics && colors && opacities));
+    const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
+    raster_raw_fwd_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>(
+        (const float2*)means2d, conics, (const float4*)colors, opacities, backgrounds, width, height, tw, th, tile_offsets,
+        flatten_ids, counts, (float4*)render_colors, render_alphas, last_ids);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_raster_raw_bwd(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                       const float* backgrounds, int width, int height, int tile_size, const int32_t* tile_offsets,
+                       const int32_t* flatten_ids, const int64_t* counts, const float* render_alphas, const int32_t* last_ids,
+                       const float* v_render_colors, const float* v_render_alphas, float* v_means2d_abs, float* v_means2d,
+                       float* v_conics, float* v_colors, float* v_opacities, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    GPS_REQUIRE(tile_size == 16);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means2d && conics && colors && opacities && tile_offsets && flatten_ids && counts && render_alphas && last_ids &&
+                v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities);
+    const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
+    hipStream_t s = (hipStream_t)stream;
+    zero_raw_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors, v_opacities,
+                                                                                    v_means2d_abs);
+#define GPS_RAW_BWD_ARGS (const float2*)means2d, conics, (const float4*)colors, opacities, backgrounds, width, height, tw, th, \
+                         tile_offsets, flatten_ids, counts, render_alphas, last_ids, (const float4*)v_render_colors,          \
+                         v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities
+    if (v_means2d_abs) raster_raw_bwd_kernel<true><<<tw * th, 256, 0, s>>>(GPS_RAW_BWD_ARGS);
+    else raster_raw_bwd_kernel<false><<<tw * th, 256, 0, s>>>(GPS_RAW_BWD_ARGS);
+#undef GPS_RAW_BWD_ARGS
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // extern "C"

@@ -154,6 +154,30 @@ def isect_tiles_no_depth(means2d, radii, tile_size, tile_width, tile_height, ise
     return r
 
 
+def isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, isect_capacity=None, want_isect_ids=True):
+    """isectTiles + isectOffsetEncode (gsplat_wapper.cpp:3-48, isect_tiles.cu:30-430): depth-keyed binning for the `raw`
+    render method, one sync-free call.  means2d[1,N,2], radii[1,N] (clamped), depths[1,N]."""
+    means2d, depths = _f32c(means2d), _f32c(depths)
+    radii = radii.contiguous()
+    assert radii.dtype == torch.int32
+    N = radii.numel()
+    dev = means2d.device
+    icap = int(isect_capacity or max(1 << 20, 16 * N))
+    r = IsectResult()
+    r.tiles_per_gauss = torch.empty((1, N), dtype=torch.int32, device=dev)
+    r.isect_ids = torch.empty(icap, dtype=torch.int64, device=dev) if want_isect_ids else None
+    r.flatten_ids = torch.empty(icap, dtype=torch.int32, device=dev)
+    r.group_gs_ids = r.group_starts = None
+    r.isect_offsets = torch.empty((1, tile_height, tile_width), dtype=torch.int32, device=dev)
+    r.counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    r.tile_width, r.tile_height = tile_width, tile_height
+    ws = _workspace(dev, lib.gps_isect_workspace_bytes(N, icap))
+    check(lib.gps_isect_tiles(N, _ptr(means2d), _ptr(radii), _ptr(depths), tile_size, tile_width, tile_height, icap,
+                              _ptr(r.tiles_per_gauss), _ptr(r.isect_ids), _ptr(r.flatten_ids), _ptr(r.isect_offsets),
+                              _ptr(r.counts), _ptr(ws), ws.numel(), _stream()), "gps_isect_tiles")
+    return r
+
+
 # ----------------------------------------------------------------------------- rasterizer
 def rasterize_to_pixels_fwd_ges(means2d, conics, colors, opacities, ref_depth_map, width, height, tile_size,
                                 isect, delta_depth, want_last_ids=False):
@@ -282,3 +306,43 @@ def rasterize_to_pixels_fwd_ges_rec(records, ref_depth_map, width, height, isect
                                      _ptr(isect.isect_offsets), _ptr(isect.flatten_ids), _ptr(isect.counts), delta_depth,
                                      _ptr(rc), _ptr(ra), _stream()), "gps_raster_ges_fwd_rec")
     return rc, ra
+
+
+# ----------------------------------------------------------------------------- `raw` rasterizer
+def rasterize_to_pixels_fwd(means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect):
+    """gsplat::rasterize_to_pixels_fwd_tensor (rasterize_to_pixels_fwd.cu:206-376), COLOR_DIM = 4, one camera.
+    -> render_colors[1,H,W,4], render_alphas[1,H,W,1] (= 1 - T), last_ids[1,H,W]"""
+    means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
+    backgrounds = _f32c(backgrounds) if backgrounds is not None else None
+    assert colors.shape[-1] == 4, "the raw path renders rgb + depth (raw_gs_model.cpp:117)"
+    N = opacities.numel()
+    dev = means2d.device
+    rc = torch.empty((1, height, width, 4), dtype=torch.float32, device=dev)
+    ra = torch.empty((1, height, width, 1), dtype=torch.float32, device=dev)
+    last = torch.empty((1, height, width), dtype=torch.int32, device=dev)
+    check(lib.gps_raster_raw_fwd(N, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(backgrounds), width,
+                                 height, tile_size, _ptr(isect.isect_offsets), _ptr(isect.flatten_ids), _ptr(isect.counts),
+                                 _ptr(rc), _ptr(ra), _ptr(last), _stream()), "gps_raster_raw_fwd")
+    return rc, ra, last
+
+
+def rasterize_to_pixels_bwd(means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect, render_alphas,
+                            last_ids, v_render_colors, v_render_alphas, absgrad=False):
+    """gsplat::rasterize_to_pixels_bwd_tensor (rasterize_to_pixels_bwd.cu:299-470)
+    -> v_means2d_abs[1,N,2] | None, v_means2d[1,N,2], v_conics[1,N,3], v_colors[1,N,4], v_opacities (shape of opacities)"""
+    means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
+    backgrounds = _f32c(backgrounds) if backgrounds is not None else None
+    render_alphas, v_render_colors, v_render_alphas = _f32c(render_alphas), _f32c(v_render_colors), _f32c(v_render_alphas)
+    last_ids = last_ids.contiguous()
+    N = opacities.numel()
+    v_means2d = torch.empty_like(means2d)
+    v_abs = torch.empty_like(means2d) if absgrad else None
+    v_conics = torch.empty_like(conics)
+    v_colors = torch.empty_like(colors)
+    v_opac = torch.empty_like(opacities)
+    check(lib.gps_raster_raw_bwd(N, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(backgrounds), width,
+                                 height, tile_size, _ptr(isect.isect_offsets), _ptr(isect.flatten_ids), _ptr(isect.counts),
+                                 _ptr(render_alphas), _ptr(last_ids), _ptr(v_render_colors), _ptr(v_render_alphas),
+                                 _ptr(v_abs), _ptr(v_means2d), _ptr(v_conics), _ptr(v_colors), _ptr(v_opac), _stream()),
+          "gps_raster_raw_bwd")
+    return v_abs, v_means2d, v_conics, v_colors, v_opac

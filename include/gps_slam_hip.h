@@ -136,6 +136,38 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
                           float *v_opacities, int accumulate, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
+/* Splat: `raw` render method (front-to-back alpha compositing)         */
+/* ------------------------------------------------------------------ */
+
+/* replaces isectTiles + isectOffsetEncode (gsplat_wapper.cpp:3-48, isect_tiles.cu:30-430): depth-keyed binning.  Every
+ * tile's list comes out ordered by (depth, Gaussian index) -- the order a stable sort of the reference's
+ * (tile_id << 32 | bits(depth)) keys gives.  isect_ids (optional) receives exactly those 64-bit keys, sorted.
+ * counts / workspace / capacities as gps_isect_tiles_no_depth (gps_isect_workspace_bytes sizes the workspace for both). */
+GPS_API int gps_isect_tiles(int N, const float *means2d, const int32_t *radii, const float *depths, int tile_size,
+                            int tile_width, int tile_height, int64_t isect_capacity, int32_t *tiles_per_gauss,
+                            int64_t *isect_ids, int32_t *flatten_ids, int32_t *tile_offsets, int64_t *counts,
+                            void *workspace, int64_t workspace_bytes, gps_stream stream);
+
+/* replaces rasterize_to_pixels_fwd_tensor (rasterize_to_pixels_fwd.cu:18-376), COLOR_DIM = 4 (rgb + depth), one camera,
+ * no tile masks: front-to-back compositing with transmittance T, a pixel stops when T * (1 - alpha) <= 1e-4.
+ * backgrounds: device float[4] or NULL.  Out: render_colors[H,W,4] (+ T * background), render_alphas[H,W] = 1 - T,
+ * last_ids[H,W] = position (in flatten_ids) of the last Gaussian that contributed. */
+GPS_API int gps_raster_raw_fwd(int N, const float *means2d, const float *conics, const float *colors,
+                               const float *opacities, const float *backgrounds, int width, int height, int tile_size,
+                               const int32_t *tile_offsets, const int32_t *flatten_ids, const int64_t *counts,
+                               float *render_colors, float *render_alphas, int32_t *last_ids, gps_stream stream);
+
+/* replaces rasterize_to_pixels_bwd_tensor (rasterize_to_pixels_bwd.cu:20-511): per pixel back to front from last_ids.
+ * Out (zero-filled by this call): v_means2d[N,2], v_conics[N,3], v_colors[N,4], v_opacities[N]; v_means2d_abs[N,2] if
+ * not NULL (absgrad). */
+GPS_API int gps_raster_raw_bwd(int N, const float *means2d, const float *conics, const float *colors,
+                               const float *opacities, const float *backgrounds, int width, int height, int tile_size,
+                               const int32_t *tile_offsets, const int32_t *flatten_ids, const int64_t *counts,
+                               const float *render_alphas, const int32_t *last_ids, const float *v_render_colors,
+                               const float *v_render_alphas, float *v_means2d_abs, float *v_means2d, float *v_conics,
+                               float *v_colors, float *v_opacities, gps_stream stream);
+
+/* ------------------------------------------------------------------ */
 /* Splat: compose + L1 loss (fused replacement of libtorch glue)       */
 /* ------------------------------------------------------------------ */
 

@@ -196,6 +196,82 @@ def test_raster_ges_fwd_bwd(N, W, H):
     assert torch.equal(rc, rc2) and torch.equal(ra, ra2)
 
 
+@pytest.mark.parametrize("N,W,H,with_bg", [(3000, 96, 64, True), (100000, 640, 480, False), (4000, 50, 37, True)])
+def test_raw_binning_and_raster_fwd_bwd(N, W, H, with_bg):
+    """`raw` render method: depth-keyed binning bit-exact, front-to-back compositing forward/backward vs the oracle."""
+    from gps_slam_amd import gsplat_ops as ops
+    from oracle import splat_ref as orc
+    TS = 16
+    tw, th = (W + TS - 1) // TS, (H + TS - 1) // TS
+    radii, m2, depths, conics, colors, opac, _ = _raster_state(N, W, H, seed=N + 1)
+    if N == 3000:  # equal depths inside a tile: ties must come out in Gaussian-index order (stable sort)
+        depths[::7] = depths[0]
+        colors[:, 3] = depths
+    bg = np.array([0.2, 0.4, 0.1, 0.0], np.float32) if with_bg else None
+    e_tpg, e_ids, e_flat, e_offs = orc.isect_tiles_depth(m2, radii, depths, TS, tw, th)
+    isect = ops.isect_tiles(T(m2)[None], T(radii)[None], T(depths)[None], TS, tw, th)
+    ni, _ = isect.sizes()
+    assert ni == e_flat.shape[0]
+    assert np.array_equal(N_(isect.tiles_per_gauss)[0], e_tpg)
+    assert np.array_equal(N_(isect.isect_ids)[:ni], e_ids)
+    assert np.array_equal(N_(isect.flatten_ids)[:ni], e_flat)
+    assert np.array_equal(N_(isect.isect_offsets)[0], e_offs)
+    e_rc, e_ra, e_last = orc.raster_raw_fwd(m2, conics, colors, opac, W, H, TS, e_offs, e_flat, backgrounds=bg)
+    tm2, tcon, tcol, top = T(m2)[None], T(conics)[None], T(colors)[None], T(opac)[None]
+    tbg = None if bg is None else T(bg)[None]
+    rc, ra, last = ops.rasterize_to_pixels_fwd(tm2, tcon, tcol, top, tbg, W, H, TS, isect)
+    # threshold decisions (alpha >= 1/255, T(1-alpha) <= 1e-4) can flip between expf and __expf for isolated pairs
+    for got, ref in ((N_(rc)[0], e_rc), (N_(ra)[0, ..., 0], e_ra)):
+        bad = np.abs(got - ref) > (2e-4 * np.abs(ref) + 2e-4)
+        assert bad.mean() <= 2e-5, bad.mean()
+        assert np.abs(got - ref).max() < 0.05
+    assert (N_(last)[0] == e_last).mean() > 0.999
+    assert e_ra.max() > 0.9
+    # backward on the oracle's forward state (so both walk exactly the same lists)
+    rng = np.random.default_rng(5)
+    v_rc = rng.normal(size=(H, W, 4)).astype(np.float32)
+    v_ra = rng.normal(size=(H, W)).astype(np.float32)
+    e = orc.raster_raw_bwd(m2, conics, colors, opac, W, H, TS, e_offs, e_flat, e_ra, e_last, v_rc, v_ra, backgrounds=bg,
+                           absgrad=True)
+    o = ops.rasterize_to_pixels_bwd(tm2, tcon, tcol, top, tbg, W, H, TS, isect, T(e_ra)[None, ..., None], T(e_last)[None],
+                                    T(v_rc)[None], T(v_ra)[None, ..., None], absgrad=True)
+    got = dict(zip(("v_abs", "v_means2d", "v_conics", "v_colors", "v_opacities"), o))
+    ref = dict(zip(("v_means2d", "v_conics", "v_colors", "v_opacities", "v_abs"), e))
+    for name in ref:
+        g_, r_ = N_(got[name]).reshape(ref[name].shape), ref[name]
+        scale = np.abs(r_).max()
+        assert scale > 0
+        bad = np.abs(g_ - r_) > (2e-3 * np.abs(r_) + 5e-4 * scale)
+        assert bad.mean() < 1e-4, (name, bad.mean())
+    # without absgrad the other four gradients are the same numbers up to atomic order
+    o2 = ops.rasterize_to_pixels_bwd(tm2, tcon, tcol, top, tbg, W, H, TS, isect, T(e_ra)[None, ..., None], T(e_last)[None],
+                                     T(v_rc)[None], T(v_ra)[None, ..., None])
+    assert o2[0] is None
+    for a, b in zip(o[1:], o2[1:]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+    # the forward is deterministic
+    rc2, ra2, last2 = ops.rasterize_to_pixels_fwd(tm2, tcon, tcol, top, tbg, W, H, TS, isect)
+    assert torch.equal(rc, rc2) and torch.equal(ra, ra2) and torch.equal(last, last2)
+
+
+def test_raw_raster_empty_scene():
+    from gps_slam_amd import gsplat_ops as ops
+    W, H, TS = 64, 48, 16
+    m2 = torch.zeros((1, 4, 2), device=_dev())
+    radii = torch.zeros((1, 4), dtype=torch.int32, device=_dev())
+    isect = ops.isect_tiles(m2, radii, torch.ones((1, 4), device=_dev()), TS, 4, 3)
+    assert isect.sizes()[0] == 0
+    bg = torch.tensor([[0.5, 0.25, 0.125, 0.0]], device=_dev())
+    rc, ra, last = ops.rasterize_to_pixels_fwd(m2, torch.ones((1, 4, 3), device=_dev()), torch.ones((1, 4, 4), device=_dev()),
+                                               torch.ones((1, 4), device=_dev()), bg, W, H, TS, isect)
+    assert float(ra.abs().max()) == 0.0 and int(last.abs().max()) == 0
+    assert torch.equal(rc, bg.expand(1, H, W, 4).reshape(1, H, W, 4))
+    o = ops.rasterize_to_pixels_bwd(m2, torch.ones((1, 4, 3), device=_dev()), torch.ones((1, 4, 4), device=_dev()),
+                                    torch.ones((1, 4), device=_dev()), bg, W, H, TS, isect, ra, last, torch.ones_like(rc),
+                                    torch.ones_like(ra), absgrad=True)
+    assert all(float(t.abs().max()) == 0.0 for t in o)
+
+
 def test_raster_linearity_in_colour():
     """Size-independent property: the ges forward is linear in the colour channels."""
     from gps_slam_amd import gsplat_ops as ops
