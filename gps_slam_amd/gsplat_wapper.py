@@ -123,3 +123,67 @@ def ges_forward(params, cam_dev, width, height, ref_depth, base_color, sh_degree
     bdw = torch.zeros_like(ws).masked_fill(ref_depth > 0, 1)
     depth = (raw_depth + ref_depth * bdw) / (ws + bdw)
     return dict(rgb=rgb[0], depth=depth[0], alpha=ws[0], radiis=radii[0], means2d=means2d)
+
+
+# ----------------------------------------------------------------------------- `raw` render method
+class RasterizeToPixels(torch.autograd.Function):
+    """gsplat_wapper.hpp:243-353: apply(means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
+    isect, absgrad) -> render_colors[1,H,W,4], render_alphas[1,H,W,1].  `isect` is the IsectResult of isectTiles.
+    As in the reference the backward runs without the backgrounds (gsplat_wapper.hpp:307-315) and v_backgrounds is
+    sum(v_render_colors * (1 - render_alphas))."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size, isect, absgrad):
+        if masks is not None:
+            raise RuntimeError("tile masks are never used by GPS-SLAM and are not implemented")
+        rc, ra, last = ops.rasterize_to_pixels_fwd(means2d, conics, colors, opacities, backgrounds, width, height,
+                                                   tile_size, isect)
+        ctx.save_for_backward(means2d, conics, colors, opacities, ra, last)
+        ctx.cfg = (width, height, tile_size, isect, absgrad)
+        return rc, ra
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        means2d, conics, colors, opacities, ra, last = ctx.saved_tensors
+        width, height, tile_size, isect, absgrad = ctx.cfg
+        v_abs, v_m, v_c, v_col, v_o = ops.rasterize_to_pixels_bwd(
+            means2d, conics, colors, opacities, None, width, height, tile_size, isect, ra, last,
+            v_render_colors.contiguous(), v_render_alphas.contiguous(), absgrad=absgrad)
+        v_bg = None
+        if ctx.needs_input_grad[4]:
+            v_bg = (v_render_colors * (1.0 - ra)).sum((1, 2))
+        return (v_m, v_c, v_col, v_o, v_bg) + (None,) * 6
+
+
+def isectTiles(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True, **kw):
+    """gsplat_wapper.cpp:15-43 (+ the offsets of isectOffsetEncode, computed in the same sync-free call)."""
+    assert sort
+    return ops.isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, **kw)
+
+
+def isectOffsetEncode(isect, n_cameras, tile_width, tile_height):
+    """gsplat_wapper.cpp:45-48"""
+    assert n_cameras == 1
+    return isect.isect_offsets
+
+
+def raw_forward(params, cam_dev, width, height, sh_degree=3, tile_size=16, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+                radius_clip=0.0, backgrounds=None, abs_grad=False):
+    """RawGaussianModel::rawForward (src/raw_gs_model.cpp:43-185) on the operator surface above."""
+    import math
+    means, log_scales, quats, dc, rest, opac_logit = params
+    tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
+    radii, means2d, depths, conics = FullyFusedProjection.apply(
+        means, None, quats, torch.exp(log_scales), cam_dev["viewmat"].unsqueeze(0), cam_dev["K"].unsqueeze(0), width, height,
+        eps2d, near_plane, far_plane, radius_clip, False, "pinhole")
+    shs = torch.cat([dc[:, None, :], rest], 1)
+    dirs = means - cam_dev["cam_pos"][None, :]
+    colors = SphericalHarmonicsNew.apply(sh_degree, dirs.unsqueeze(0), shs.unsqueeze(0), radii > 0)
+    colors = torch.clamp_min(colors + 0.5, 0.0)
+    isect = isectTiles(means2d, radii, depths, tile_size, tw, th)
+    colors = torch.cat([colors, depths.unsqueeze(-1)], 2)
+    rc, ra = RasterizeToPixels.apply(means2d, conics, colors, torch.sigmoid(opac_logit), backgrounds, None, width, height,
+                                     tile_size, isect, abs_grad)
+    rgb, raw_depth = rc[..., :3], rc[..., 3:]
+    depth = raw_depth / ra.clamp(1e-10)
+    return dict(rgb=rgb[0], depth=depth[0], alpha=ra[0], radiis=radii[0], means2d=means2d)

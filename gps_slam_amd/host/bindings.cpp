@@ -39,6 +39,16 @@ PYBIND11_MODULE(_host, m) {
                                                              isect_offsets, flatten_ids, group_gs_ids, group_starts,
                                                              false, delta_depth);
           });
+    m.def("RasterizeToPixels",
+          [](torch::Tensor means2d, torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities,
+             c10::optional<torch::Tensor> backgrounds, int w, int h, int tile_size, torch::Tensor isect_offsets,
+             torch::Tensor flatten_ids, bool absgrad) {
+              return RasterizeToPixels::apply(means2d, conics, colors, opacities, backgrounds, c10::nullopt, w, h, tile_size,
+                                              isect_offsets, flatten_ids, absgrad);
+          });
+    m.def("isectTiles", &isectTiles, py::arg("means2d"), py::arg("radii"), py::arg("depths"), py::arg("tile_size"),
+          py::arg("tile_width"), py::arg("tile_height"), py::arg("sort") = true);
+    m.def("isectOffsetEncode", &isectOffsetEncode);
     m.def("isectTilesNoDepth", &isectTilesNoDepth, py::arg("means2d"), py::arg("radii"), py::arg("depths"),
           py::arg("tile_size"), py::arg("tile_width"), py::arg("tile_height"), py::arg("sort") = true);
     m.def("isectOffsetEncodeNoDepth", &isectOffsetEncodeNoDepth);
@@ -84,6 +94,11 @@ PYBIND11_MODULE(_host, m) {
         .def(py::init<>())
         .def("loadConfig", [](SLAMGaussianModel& s, const py::dict& d) { s.loadConfig(config_from_dict(d)); })
         .def("forward", &SLAMGaussianModel::forward, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"))
+        .def("rawForward", &SLAMGaussianModel::rawForward)
+        .def("setBackgrounds", [](SLAMGaussianModel& s, c10::optional<torch::Tensor> bg) {
+            s.backgrounds = bg.has_value() ? *bg : torch::Tensor();
+        })
+        .def_readwrite("render_method", &SLAMGaussianModel::render_method)
         .def("computeLoss", [](SLAMGaussianModel& s, TensorDict& r, const Camera& cam, const py::dict& w) {
             return s.computeLoss(r, cam, config_from_dict(w));
         })

@@ -162,6 +162,64 @@ tensor_list RasterizeToPixelsGes_NewParallel::backward(AutogradContext* ctx, ten
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------ raw rasterizer
+tensor_list RasterizeToPixels::forward(AutogradContext* ctx, torch::Tensor means2d, torch::Tensor conics, torch::Tensor colors,
+                                       torch::Tensor opacities, c10::optional<torch::Tensor> backgrounds,
+                                       c10::optional<torch::Tensor> masks, int width, int height, int tile_size,
+                                       torch::Tensor isect_offsets, torch::Tensor flatten_ids, bool absgrad) {
+    TORCH_CHECK(!(masks.has_value() && masks->defined()), "tile masks are never used by GPS-SLAM and are not implemented");
+    means2d = contig_f32(means2d, "means2d"); conics = contig_f32(conics, "conics");
+    colors = contig_f32(colors, "colors"); opacities = contig_f32(opacities, "opacities");
+    TORCH_CHECK(colors.size(-1) == 4, "the raw path renders rgb + depth (raw_gs_model.cpp:117)");
+    TORCH_CHECK(means2d.size(0) == 1, "single camera (C == 1)");
+    isect_offsets = isect_offsets.contiguous(); flatten_ids = flatten_ids.contiguous();
+    torch::Tensor bg;
+    if (backgrounds.has_value() && backgrounds->defined()) {
+        bg = contig_f32(*backgrounds, "backgrounds");
+        TORCH_CHECK(bg.numel() == 4, "backgrounds[1,4]");
+    }
+    const int N = (int)opacities.numel();
+    const auto dev = means2d.device();
+    auto counts = counts_for(flatten_ids.numel(), 0, dev);
+    auto rc = torch::empty({1, height, width, 4}, f32(dev));
+    auto ra = torch::empty({1, height, width, 1}, f32(dev));
+    auto last = torch::empty({1, height, width}, i32(dev));
+    check(gps_raster_raw_fwd(N, fptr(means2d), fptr(conics), fptr(colors), fptr(opacities), bg.defined() ? fptr(bg) : nullptr,
+                             width, height, tile_size, iptr(isect_offsets), iptr(flatten_ids), ptr<int64_t>(counts), fptr(rc),
+                             fptr(ra), iptr(last), current_stream()), "gps_raster_raw_fwd");
+    ctx->save_for_backward({means2d, conics, colors, opacities, isect_offsets, flatten_ids, ra, last, counts});
+    ctx->saved_data["width"] = (int64_t)width;
+    ctx->saved_data["height"] = (int64_t)height;
+    ctx->saved_data["tile_size"] = (int64_t)tile_size;
+    ctx->saved_data["absgrad"] = absgrad;
+    return {rc, ra};
+}
+
+tensor_list RasterizeToPixels::backward(AutogradContext* ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    const torch::Tensor &means2d = s[0], &conics = s[1], &colors = s[2], &opacities = s[3], &isect_offsets = s[4],
+                        &flatten_ids = s[5], &render_alphas = s[6], &last_ids = s[7], &counts = s[8];
+    const int width = (int)ctx->saved_data["width"].toInt(), height = (int)ctx->saved_data["height"].toInt();
+    const int tile_size = (int)ctx->saved_data["tile_size"].toInt();
+    const bool absgrad = ctx->saved_data["absgrad"].toBool();
+    const int N = (int)opacities.numel();
+    auto v_rc = g[0].defined() ? contig_f32(g[0], "v_render_colors") : torch::zeros({1, height, width, 4}, means2d.options());
+    auto v_ra = g[1].defined() ? contig_f32(g[1], "v_render_alphas") : torch::zeros({1, height, width, 1}, means2d.options());
+    auto v_means2d = torch::empty_like(means2d), v_conics = torch::empty_like(conics);
+    auto v_colors = torch::empty_like(colors), v_opacities = torch::empty_like(opacities);
+    torch::Tensor v_abs;
+    if (absgrad) v_abs = torch::empty_like(means2d);
+    // backgrounds = NULL: the reference's backward never receives them (gsplat_wapper.hpp:307)
+    check(gps_raster_raw_bwd(N, fptr(means2d), fptr(conics), fptr(colors), fptr(opacities), nullptr, width, height, tile_size,
+                             iptr(isect_offsets), iptr(flatten_ids), ptr<int64_t>(counts), fptr(render_alphas),
+                             iptr(last_ids), fptr(v_rc), fptr(v_ra), absgrad ? fptr(v_abs) : nullptr, fptr(v_means2d),
+                             fptr(v_conics), fptr(v_colors), fptr(v_opacities), current_stream()), "gps_raster_raw_bwd");
+    tensor_list out(12);
+    out[0] = v_means2d; out[1] = v_conics; out[2] = v_colors; out[3] = v_opacities;
+    if (ctx->needs_input_grad(4)) out[4] = (v_rc * (1.0 - render_alphas)).sum({1, 2});
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------------ binning
 variable_list isectTilesNoDepth(torch::Tensor means2d, torch::Tensor radii, torch::Tensor depths, int tile_size,
                                 int tile_width, int tile_height, bool sort) {
@@ -200,6 +258,42 @@ torch::Tensor isectOffsetEncodeNoDepth(torch::Tensor isect_ids, int n_cameras, i
     // offsets[t] = first position whose tile id is >= t (isect_tiles_no_depth.cu:373-425): a lower bound per tile
     auto tiles = torch::arange((int64_t)tile_width * tile_height, isect_ids.options());
     auto off = torch::searchsorted(isect_ids.contiguous(), tiles, /*out_int32=*/true, /*right=*/false);
+    return off.view({1, tile_height, tile_width});
+}
+
+variable_list isectTiles(torch::Tensor means2d, torch::Tensor radii, torch::Tensor depths, int tile_size, int tile_width,
+                         int tile_height, bool sort) {
+    TORCH_CHECK(sort, "isectTiles: the unsorted variant is never used by GPS-SLAM");
+    means2d = contig_f32(means2d, "means2d");
+    depths = contig_f32(depths, "depths");
+    radii = radii.contiguous();
+    TORCH_CHECK(radii.scalar_type() == torch::kInt32, "radii must be int32");
+    TORCH_CHECK(means2d.size(0) == 1, "single camera (C == 1)");
+    const int N = (int)radii.numel();
+    const auto dev = means2d.device();
+    const int64_t icap = std::max<int64_t>(1 << 20, 16 * (int64_t)N);
+    auto tiles_per_gauss = torch::empty({1, N}, i32(dev));
+    auto isect_ids = torch::empty({icap}, i64(dev));
+    auto flatten_ids = torch::empty({icap}, i32(dev));
+    auto offsets = torch::empty({1, tile_height, tile_width}, i32(dev));
+    auto counts = torch::zeros({4}, i64(dev));
+    const int64_t ws_bytes = gps_isect_workspace_bytes(N, icap);
+    auto ws = torch::empty({ws_bytes}, u8(dev));
+    check(gps_isect_tiles(N, fptr(means2d), iptr(radii), fptr(depths), tile_size, tile_width, tile_height, icap,
+                          iptr(tiles_per_gauss), ptr<int64_t>(isect_ids), iptr(flatten_ids), iptr(offsets),
+                          ptr<int64_t>(counts), ws.data_ptr(), ws_bytes, current_stream()), "gps_isect_tiles");
+    auto c = counts.cpu();
+    const int64_t* h = c.data_ptr<int64_t>();
+    TORCH_CHECK(h[2] == 0, "isectTiles: intersection capacity exceeded");
+    using torch::indexing::Slice;
+    return {tiles_per_gauss, isect_ids.index({Slice(0, h[0])}), flatten_ids.index({Slice(0, h[0])})};
+}
+
+torch::Tensor isectOffsetEncode(torch::Tensor isect_ids, int n_cameras, int tile_width, int tile_height) {
+    TORCH_CHECK(n_cameras == 1, "single camera (C == 1)");
+    // offsets[t] = first position whose key is >= (t << 32) (isect_tiles.cu:359-430)
+    auto firsts = torch::arange((int64_t)tile_width * tile_height, isect_ids.options()) * ((int64_t)1 << 32);
+    auto off = torch::searchsorted(isect_ids.contiguous(), firsts, /*out_int32=*/true, /*right=*/false);
     return off.view({1, tile_height, tile_width});
 }
 

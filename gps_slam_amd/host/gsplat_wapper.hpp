@@ -42,6 +42,22 @@ struct RasterizeToPixelsGes_NewParallel : public torch::autograd::Function<Raste
                                                  torch::autograd::tensor_list grad_outputs);
 };
 
+// gsplat_wapper.hpp:243-353: apply(means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
+// isect_offsets, flatten_ids, absgrad) -> {render_colors[1,H,W,4], render_alphas[1,H,W,1]}.  As in the reference the
+// backward runs WITHOUT the backgrounds (gsplat_wapper.hpp:307-315 passes an empty optional) and v_backgrounds is the
+// sum of v_render_colors * (1 - render_alphas).  masks throw (never used); absgrad computes v_means2d_abs, which the
+// reference discards (:323-326 overwrites means2d with |means2d| instead -- not reproduced).
+struct RasterizeToPixels : public torch::autograd::Function<RasterizeToPixels> {
+    static torch::autograd::tensor_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor means2d,
+                                                torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities,
+                                                c10::optional<torch::Tensor> backgrounds,
+                                                c10::optional<torch::Tensor> masks, int width, int height,
+                                                int tile_size, torch::Tensor isect_offsets, torch::Tensor flatten_ids,
+                                                bool absgrad);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
 using torch::autograd::variable_list;
 
 // gsplat_wapper.cpp:55-85: -> {tiles_per_gauss[1,N], isect_ids i64[I], flatten_ids i32[I], group_gs_ids i32[G],
@@ -51,6 +67,12 @@ variable_list isectTilesNoDepth(torch::Tensor means2d, torch::Tensor radii, torc
 
 // gsplat_wapper.cpp:88-91: sorted isect_ids (tile id in the low 32 bits) -> offsets[C, tile_height, tile_width]
 torch::Tensor isectOffsetEncodeNoDepth(torch::Tensor isect_ids, int n_cameras, int tile_width, int tile_height);
+
+// gsplat_wapper.cpp:15-43: depth-keyed binning -> {tiles_per_gauss[1,N], isect_ids i64[I] (tile << 32 | depth bits,
+// sorted), flatten_ids i32[I]}; gsplat_wapper.cpp:45-48: offsets[C, tile_height, tile_width] from the sorted keys
+variable_list isectTiles(torch::Tensor means2d, torch::Tensor radii, torch::Tensor depths, int tile_size, int tile_width,
+                         int tile_height, bool sort = true);
+torch::Tensor isectOffsetEncode(torch::Tensor isect_ids, int n_cameras, int tile_width, int tile_height);
 
 // gsplat_wapper.cpp:50-53 -> distCUDA2 (simple_knn.h:21): mean squared distance to the 3 nearest neighbours
 torch::Tensor distCUDA2(const torch::Tensor& points);

@@ -186,9 +186,53 @@ struct GesRenderFunction : public torch::autograd::Function<GesRenderFunction> {
 }  // namespace
 
 TensorDict RawGaussianModel::forward(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color) {
-    TORCH_CHECK(render_method == "ges", "UNSUPPORTED RENDER METHOD: ", render_method,
-                " (the `raw` rasterizer is outside the hot path, SURVEY 8(f) rank 2)");
+    if (render_method == "raw") return rawForward(cam);  // raw_gs_model.h:35-47
+    TORCH_CHECK(render_method == "ges", "UNSUPPORTED RENDER METHOD: ", render_method);
     return gesForward(cam, ref_depth, base_color);
+}
+
+// raw_gs_model.cpp:43-185: projection -> SH colours -> depth-keyed binning -> front-to-back compositing, composed from
+// the operator-level autograd Functions exactly as the reference composes them (the `raw` method is not on the SLAM loop's
+// path, so it does not get the fused step struct; every stage is still one C-ABI call).
+TensorDict RawGaussianModel::rawForward(const Camera& cam) {
+    const int N = getGaussianNum();
+    const bool grad = torch::GradMode::is_enabled() && !leaf_.empty();
+    auto P = [&](int k) { return grad ? leaf_[k] : opt_gs_params.view(k); };
+    auto c2w = cam.c2w.to(torch::kCPU, torch::kFloat32).contiguous();  // the dataset pose, not c2w_slam (:56)
+    auto viewMat = poseInv(c2w).to(device);
+    auto cam_T = c2w.index({Slice(0, 3), Slice(3, 4)}).to(device);
+    auto Ks = cam.K.to(device, torch::kFloat32);
+    auto world_means = P(0).contiguous();
+    auto world_scales = torch::exp(P(1)).contiguous();
+    auto proj = FullyFusedProjection::apply(world_means, c10::nullopt, P(2), world_scales, viewMat.unsqueeze(0), Ks.unsqueeze(0),
+                                            cam.width, cam.height, eps2d, near_plane, far_plane, radius_clip, false,
+                                            std::string("pinhole"));
+    auto radiis = proj[0], means2d = proj[1], depths = proj[2], conics = proj[3];
+    auto shs = torch::cat({P(3).view({N, 1, 3}), P(4)}, 1);
+    auto viewDirs = world_means - cam_T.transpose(0, 1);
+    auto colors = SphericalHarmonicsNew::apply(degreesToUse, viewDirs.unsqueeze(0), shs.unsqueeze(0), radiis > 0);
+    colors = torch::clamp_min(colors + 0.5f, 0.0f);
+    const int tile_width = (int)std::ceil(float(cam.width) / float(tile_size));
+    const int tile_height = (int)std::ceil(float(cam.height) / float(tile_size));
+    auto isec = isectTiles(means2d, radiis, depths, tile_size, tile_width, tile_height);
+    auto isect_offsets = isectOffsetEncode(isec[1], 1, tile_width, tile_height);
+    colors = torch::cat({colors, depths.unsqueeze(-1)}, 2);
+    c10::optional<torch::Tensor> bg;
+    if (backgrounds.defined()) bg = backgrounds;
+    auto rast = RasterizeToPixels::apply(means2d, conics, colors, torch::sigmoid(P(5)), bg, c10::nullopt, cam.width, cam.height,
+                                         tile_size, isect_offsets, isec[2], abs_grad);
+    auto render_colors = rast[0], render_alphas = rast[1];
+    const int64_t last_dim = render_colors.size(-1);
+    auto rgb = render_colors.slice(-1, 0, last_dim - 1);
+    auto raw_depth = render_colors.slice(-1, last_dim - 1);
+    auto expected_depth = raw_depth / render_alphas.clamp(1e-10);
+    TensorDict res;
+    res["rgb"] = rgb[0];
+    res["depth"] = expected_depth[0];
+    res["alpha"] = render_alphas[0];
+    res["radiis"] = radiis[0];
+    res["means2d"] = means2d;
+    return res;
 }
 
 TensorDict RawGaussianModel::gesForward(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color) {

@@ -22,6 +22,7 @@ public:
     TensorDict forward(const Camera& cam, const torch::Tensor& ref_depth = torch::Tensor(),
                        const torch::Tensor& base_color = torch::Tensor());
     TensorDict gesForward(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color);
+    TensorDict rawForward(const Camera& cam);  // raw_gs_model.cpp:43-185 (render_method "raw")
     // raw_gs_model.cpp:369-417 with the weights every shipped config uses (L1 only; ssim / depth weights 0):
     // -> {"loss", "l1_loss"}
     TensorDict computeLoss(TensorDict& render_res, const Camera& cam, const gpsh::Config& weight_configs,
@@ -73,6 +74,8 @@ public:
     // The parameter update is bit-identical either way.
     bool fuse_sh_rest_adam = true;
     std::string render_method = "ges";
+    bool abs_grad = false;       // raw_gs_model.h:293
+    torch::Tensor backgrounds;   // raw_gs_model.h:295 ([1,4] device tensor; undefined = none)
 
     // implementation detail, public for the autograd node
     struct Buffers {
