@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void raster_raw_fwd_kernel(
     const int tile_id = blockIdx.x;
     const int ty = tile_id / tw, tx = tile_id - ty * tw;
     const int tid = threadIdx.x;
-    const int i = ty * 16 + (tid >> 4), j = tx * 16 + (tid & 15);
+    // one 8x8 pixel patch per wave: compact footprints make the wave-uniform skips (all lanes done / no lane touched) fire
+    const int i = ty * 16 + ((tid >> 7) << 3) + ((tid >> 3) & 7), j = tx * 16 + (((tid >> 6) & 1) << 3) + (tid & 7);
     const bool inside = (i < H) && (j < W);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const int n_isects = (int)counts[0];
@@ -59,20 +60,31 @@ __global__ __launch_bounds__(256) void raster_raw_fwd_kernel(
         if (__syncthreads_count(done) >= (int)blockDim.x) break;  // also the barrier before the LDS tile is overwritten
         const int idx = batch_start + tid;
         if (idx < range_end) recs[tid] = load_rec(flatten_ids[idx], means2d, conics, colors, opacities);
+        else recs[tid] = RawRec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1, 0};  // opacity 0: never contributes
         __syncthreads();
         const int n = min(RAW_BATCH, range_end - batch_start);
-        for (int t = 0; t < n && !done; ++t) {
-            const RawRec r = recs[t];
-            const float dx = r.x - px, dy = r.y - py;
-            const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
-            const float alpha = fminf(0.999f, r.opac * __expf(-sigma));
-            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
-            const float next_T = T * (1.0f - alpha);
-            if ((double)next_T <= 1e-4) { done = true; break; }  // the reference compares against the double literal
-            const float vis = alpha * T;
-            o0 += r.c0 * vis; o1 += r.c1 * vis; o2 += r.c2 * vis; o3 += r.c3 * vis;
-            cur_idx = (uint32_t)(batch_start + t);
-            T = next_T;
+        if (__all(done)) continue;  // this wave's patch is finished; keep taking part in the barriers
+        // Branch-free body (a finished or untouched pixel adds weight 0), wave-uniform exit test every 4 Gaussians.  The
+        // reference compares the float next_T with the double literal 1e-4; the largest float that passes is 1e-4f.
+        for (int t0 = 0; t0 < n; t0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u;  // may run up to 3 past n: those slots hold null records
+                const RawRec r = recs[t];
+                const float dx = r.x - px, dy = r.y - py;
+                const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
+                const float alpha = fminf(0.999f, r.opac * __expf(-sigma));
+                const bool ok = !done && sigma >= 0.f && alpha >= 1.f / 255.f;
+                const float next_T = T * (1.0f - alpha);
+                const bool stop = ok && next_T <= 1e-4f;
+                const bool use = ok && !stop;
+                done = done || stop;
+                const float vis = use ? alpha * T : 0.f;
+                o0 += r.c0 * vis; o1 += r.c1 * vis; o2 += r.c2 * vis; o3 += r.c3 * vis;
+                cur_idx = use ? (uint32_t)(batch_start + t) : cur_idx;
+                T = use ? next_T : T;
+            }
+            if (__all(done)) break;
         }
     }
     if (inside) {
@@ -84,20 +96,40 @@ __global__ __launch_bounds__(256) void raster_raw_fwd_kernel(
     }
 }
 
-// full-wave sum with DPP adds; the total lands in lane 63 only
-template <int CTRL, int ROW_MASK>
+// ---- wave64 reduction of the per-pixel gradient vector, 12 values at a time
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows between TWO registers in one
+// instruction, so "swap, add" halves the lane span of two values at once: 12 values -> 6 registers (two values each, one
+// per half-wave) -> 3 registers (four values each, one per row) in 9 swaps + 9 adds; the remaining sum inside each 16-lane
+// row is 4 DPP row_shr adds per register.  30 VALU ops per Gaussian instead of 72 for twelve full DPP reductions, and the
+// totals come out in lane 15 of each row: 3 ds_add_f32 (4 lanes each) instead of 12.
+__device__ __forceinline__ float sum_halves(float a, float b) {  // lanes 0-31: a summed over halves; lanes 32-63: b
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_row_pairs(float a, float b) {  // rows: {a01, b01, a23, b23}
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
 __device__ __forceinline__ float dpp_add_raw(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+    v = dpp_add_raw<0x111>(v);  // row_shr:1
+    v = dpp_add_raw<0x112>(v);  // row_shr:2
+    v = dpp_add_raw<0x114>(v);  // row_shr:4
+    v = dpp_add_raw<0x118>(v);  // row_shr:8
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_masked(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
     return v + __int_as_float(moved);
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add_raw<0x111, 0xF>(v);  // row_shr:1
-    v = dpp_add_raw<0x112, 0xF>(v);  // row_shr:2
-    v = dpp_add_raw<0x114, 0xF>(v);  // row_shr:4
-    v = dpp_add_raw<0x118, 0xF>(v);  // row_shr:8
-    v = dpp_add_raw<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
-    v = dpp_add_raw<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
-    return v;
+// values (a, b, c, d) -> one register whose rows 0..3 end up holding the wave totals of (a, c, b, d) in lane 15
+__device__ __forceinline__ float reduce4(float a, float b, float c, float d) {
+    return row_sum_to_lane15(sum_row_pairs(sum_halves(a, b), sum_halves(c, d)));
 }
 
 __global__ __launch_bounds__(256) void zero_raw_grads_kernel(int N, float* __restrict__ v_means2d, float* __restrict__ v_conics,
@@ -120,14 +152,16 @@ __global__ __launch_bounds__(256) void raster_raw_bwd_kernel(
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids, const float4* __restrict__ v_render_colors,
     const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d,
     float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities) {
-    constexpr int NG = ABS ? 12 : 10;  // rgb d | conic abc | xy | opac | (|x| |y|)
+    constexpr int NG = 12;  // rgb d | conic abc | xy | opac | (|x| |y|)
     __shared__ RawRec recs[RAW_BATCH];
     __shared__ float grad[RAW_BATCH][NG];
     __shared__ int tile_last;
     const int tile_id = blockIdx.x;
     const int ty = tile_id / tw, tx = tile_id - ty * tw;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i = ty * 16 + (tid >> 4), j = tx * 16 + (tid & 15);
+    const int row_slot = ((lane >> 4) & 1) * 2 + (lane >> 5);  // which value of a reduce4 group this lane's row ends up with
+    // one 8x8 pixel patch per wave: compact footprints make the wave-uniform skips (all lanes done / no lane touched) fire
+    const int i = ty * 16 + ((tid >> 7) << 3) + ((tid >> 3) & 7), j = tx * 16 + (((tid >> 6) & 1) << 3) + (tid & 7);
     const bool inside = (i < H) && (j < W);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     const int pix = inside ? i * W + j : 0;
@@ -161,42 +195,52 @@ __global__ __launch_bounds__(256) void raster_raw_bwd_kernel(
         for (int k = tid; k < RAW_BATCH * NG; k += 256) (&grad[0][0])[k] = 0.f;
         __syncthreads();
         for (int t = 0; t < n; ++t) {
-            bool valid = inside && (batch_end - t <= bin_final);
             const RawRec r = recs[t];
             const float dx = r.x - px, dy = r.y - py;
             const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
-            const float vis = __expf(-sigma);
-            const float alpha = fminf(0.999f, r.opac * vis);
-            valid = valid && !(sigma < 0.f || alpha < 1.f / 255.f);
-            if (!__any(valid)) continue;  // wave uniform
-            float g[NG];
-#pragma unroll
-            for (int k = 0; k < NG; k++) g[k] = 0.f;
-            if (valid) {
-                const float ra = 1.0f / (1.0f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                g[0] = fac * vc.x; g[1] = fac * vc.y; g[2] = fac * vc.z; g[3] = fac * vc.w;
-                float v_alpha = (r.c0 * T - b0 * ra) * vc.x + (r.c1 * T - b1 * ra) * vc.y + (r.c2 * T - b2 * ra) * vc.z +
-                                (r.c3 * T - b3 * ra) * vc.w;
-                v_alpha += T_final * ra * va;
-                if (backgrounds) v_alpha += -T_final * ra * bg_dot;
-                if (r.opac * vis <= 0.999f) {
-                    const float v_sigma = -r.opac * vis * v_alpha;
-                    g[4] = 0.5f * v_sigma * dx * dx;
-                    g[5] = v_sigma * dx * dy;
-                    g[6] = 0.5f * v_sigma * dy * dy;
-                    g[7] = v_sigma * (r.ca * dx + r.cb * dy);
-                    g[8] = v_sigma * (r.cb * dx + r.cc * dy);
-                    g[9] = vis * v_alpha;
-                    if (ABS) { g[10] = fabsf(g[7]); g[11] = fabsf(g[8]); }
-                }
-                b0 += r.c0 * fac; b1 += r.c1 * fac; b2 += r.c2 * fac; b3 += r.c3 * fac;
+            const float vis_raw = __expf(-sigma);
+            const float alpha_raw = fminf(0.999f, r.opac * vis_raw);
+            const bool valid = inside && (batch_end - t <= bin_final) && sigma >= 0.f && alpha_raw >= 1.f / 255.f;
+            if (!__any(valid)) continue;  // wave uniform: no pixel of this 8x8 patch is touched
+            // Branch-free from here: a pixel the Gaussian does not contribute to runs with alpha = vis = 0, which leaves
+            // T and the colour behind untouched and makes all of its gradient terms exact zeros.
+            const float alpha = valid ? alpha_raw : 0.f;
+            const float vis = valid ? vis_raw : 0.f;
+            const float d = 1.0f - alpha;
+            float ra = __builtin_amdgcn_rcpf(d);
+            ra = fmaf(fmaf(-d, ra, 1.0f), ra, ra);  // one Newton step: 1/(1-alpha) to rounding, 3 ops instead of IEEE div's 11
+            T *= ra;
+            const float fac = alpha * T;
+            const float g0 = fac * vc.x, g1 = fac * vc.y, g2 = fac * vc.z, g3 = fac * vc.w;
+            float v_alpha = (r.c0 * T - b0 * ra) * vc.x + (r.c1 * T - b1 * ra) * vc.y + (r.c2 * T - b2 * ra) * vc.z +
+                            (r.c3 * T - b3 * ra) * vc.w;
+            v_alpha += T_final * ra * (va - bg_dot);  // bg_dot = 0 without backgrounds
+            const float ov = r.opac * vis;
+            const bool unclamped = ov <= 0.999f;
+            const float v_sigma = unclamped ? -ov * v_alpha : 0.f;
+            const float g4 = 0.5f * v_sigma * dx * dx;
+            const float g5 = v_sigma * dx * dy;
+            const float g6 = 0.5f * v_sigma * dy * dy;
+            const float g7 = v_sigma * (r.ca * dx + r.cb * dy);
+            const float g8 = v_sigma * (r.cb * dx + r.cc * dy);
+            const float g9 = unclamped ? vis * v_alpha : 0.f;
+            b0 += r.c0 * fac; b1 += r.c1 * fac; b2 += r.c2 * fac; b3 += r.c3 * fac;
+            // rows of z0 / z1 hold the totals of (g0,g2,g1,g3) / (g4,g6,g5,g7) in lane 15; ds_add_f32: the 4 waves of the
+            // tile meet in the LDS gradient tile
+            const float z0 = reduce4(g0, g1, g2, g3);
+            const float z1 = reduce4(g4, g5, g6, g7);
+            if ((lane & 15) == 15) {
+                float* gt = &grad[t][row_slot];
+                atomicAdd(gt, z0);
+                atomicAdd(gt + 4, z1);
             }
-#pragma unroll
-            for (int k = 0; k < NG; k++) {
-                const float s = wave_sum_to_lane63(g[k]);
-                if (lane == 63 && s != 0.f) atomicAdd(&grad[t][k], s);  // ds_add_f32: the 4 waves of the tile meet here
+            if (ABS) {
+                const float z2 = reduce4(g8, g9, fabsf(g7), fabsf(g8));  // rows: g8 |g7| g9 |g8| -> slots 8 10 9 11
+                if ((lane & 15) == 15) atomicAdd(&grad[t][8 + row_slot], z2);
+            } else {
+                // two values left: one per half-wave, row sums, then row 0 -> 1 and row 2 -> 3 (row_bcast15)
+                const float z2 = dpp_add_masked<0x142, 0xA>(row_sum_to_lane15(sum_halves(g8, g9)));
+                if ((lane & 31) == 31) atomicAdd(&grad[t][8 + (lane >> 5)], z2);
             }
         }
         __syncthreads();
