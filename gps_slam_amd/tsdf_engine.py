@@ -163,6 +163,50 @@ class TsdfEngine:
     def getVoxelSize(self):
         return self.voxel_size
 
+    # ---- meshing (ITMBasicEngine::SaveSceneToMesh, Core/ITMBasicEngine.tpp:105-117)
+    def MeshScene(self, max_triangles=1 << 24):
+        """ITMMeshingEngine::MeshScene -> (triangles float32 [max_triangles, 7, 3] device tensor, counts int64[2] device):
+        counts[0] = noTotalTriangles.  Rows: p0 p1 p2 c0 c1 c2 clr (ITMMesh::Triangle).  No host sync."""
+        tri = torch.empty((max_triangles, 7, 3), dtype=torch.float32, device=self.device)
+        counts = torch.zeros(2, dtype=torch.int64, device=self.device)
+        nbytes = int(lib.gps_tsdf_mesh_workspace_bytes(C.byref(self.state)))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(lib.gps_tsdf_mesh_scene(C.byref(self.state), max_triangles, tri.data_ptr(), counts.data_ptr(), ws.data_ptr(), nbytes,
+                                      self._stream()), "gps_tsdf_mesh_scene")
+        return tri, counts
+
+    def SaveSceneToMesh(self, file_name, max_triangles=1 << 24):
+        """MeshScene + ITMMesh::WritePLY (Objects/Meshing/ITMMesh.h:39-106): ascii PLY, 3 vertices per triangle with uchar
+        colours (static_cast<unsigned char>(c * 255)), then the faces."""
+        tri, counts = self.MeshScene(max_triangles)
+        n = int(counts[0].item())
+        from . import tsdf_io
+        tsdf_io.write_mesh_ply(file_name, tri[:n].cpu().numpy())
+        return n
+
+    # ---- persistence (ITMBasicEngine::SaveToFile / LoadFromFile, Core/ITMBasicEngine.tpp:119-171): formats in tsdf_io.py
+    def SaveToFile(self, save_output_directory):
+        import os
+        from . import tsdf_io
+        d = save_output_directory if save_output_directory.endswith("/") else save_output_directory + "/"
+        os.makedirs(d + "Relocaliser/", exist_ok=True)
+        c = self.counters_host()
+        tsdf_io.save_scene(d + "Scene/", self.vba.cpu().numpy(), self.vba_alloc_list.cpu().numpy(), c[0],
+                           self.hash.cpu().numpy(), self.excess_list.cpu().numpy(), c[1])
+
+    def LoadFromFile(self, save_input_directory):
+        from . import tsdf_io
+        d = save_input_directory if save_input_directory.endswith("/") else save_input_directory + "/"
+        self.reset()  # resetAll() (ITMBasicEngine.tpp:146)
+        sc = tsdf_io.load_scene(d + "Scene/", self.n_blocks, self.n_total, self.n_excess)
+        self.vba.copy_(torch.from_numpy(sc["vba"]).to(self.device))
+        self.vba_alloc_list.copy_(torch.from_numpy(sc["alloc_list"].copy()).to(self.device))
+        self.hash.copy_(torch.from_numpy(sc["hash"]).to(self.device))
+        self.excess_list.copy_(torch.from_numpy(sc["excess_list"].copy()).to(self.device))
+        c = self.counters.cpu()
+        c[0], c[1] = sc["last_free_block"], sc["last_free_excess"]
+        self.counters.copy_(c)
+
     # ---- host views for tests / persistence (sync)
     def counters_host(self):
         return self.counters.cpu().numpy()
@@ -173,3 +217,4 @@ class TsdfEngine:
     def vba_host(self, ptrs):
         idx = torch.as_tensor(np.asarray(ptrs, dtype=np.int64), device=self.device)
         return self.vba.view(self.n_blocks, 512 * 8)[idx].cpu().numpy().view(VOXEL_DT).reshape(-1, 512)
+

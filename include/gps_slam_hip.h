@@ -441,6 +441,25 @@ GPS_API int gps_raycast_to_maps(int width, int height, const float *rays, const 
 GPS_API int gps_pose_from_c2w(const float *c2w_row_major, float *M, float *invM);
 
 /* ------------------------------------------------------------------ */
+/* TSDF: meshing (marching cubes over the allocated voxel blocks)       */
+/* ------------------------------------------------------------------ */
+
+/* One triangle as ITMMesh::Triangle stores it (Objects/Meshing/ITMMesh.h:18-21): p0 p1 p2 (metres), c0 c1 c2 (vertex
+ * colours in [0,1]), clr (colour of the cube's origin voxel) -- 21 floats. */
+#define GPS_MESH_TRIANGLE_FLOATS 21
+
+/* Scratch bytes gps_tsdf_mesh_scene needs for this state's capacities (-1 on a bad state). */
+GPS_API int64_t gps_tsdf_mesh_workspace_bytes(const gps_tsdf_state *s);
+
+/* replaces ITMMeshingEngine_CUDA<TVoxel, ITMVoxelBlockHash>::MeshScene (Engines/Meshing/CUDA/ITMMeshingEngine_CUDA.tcu:43-80,
+ * 101-134; Shared/ITMMeshingEngine_Shared.h:279-471).  triangles: device float[max_triangles][21].
+ * counts: device int64[2] = {noTotalTriangles = min(generated, max_triangles - 1) as the reference clamps it, generated}.
+ * Triangle ORDER is the reference CPU engine's (hash entry, z, y, x, case table), identical every run -- the reference's
+ * CUDA engine appends with atomicAdd in arrival order.  No host synchronisation. */
+GPS_API int gps_tsdf_mesh_scene(const gps_tsdf_state *s, int64_t max_triangles, float *triangles, int64_t *counts,
+                                void *workspace, int64_t workspace_bytes, gps_stream stream);
+
+/* ------------------------------------------------------------------ */
 /* TSDF: camera tracking (depth-only ExtendedTracker, use_gt_pose = false) */
 /* ------------------------------------------------------------------ */
 

@@ -12,6 +12,12 @@
 //        itm_ref <input.bin> <output.bin> track    same dump with the default tracker ON (poses estimated, not given)
 //        itm_ref <input.bin> - time              timing mode: ProcessFrame loop only, prints one JSON line
 //                                                (frames after the first; the CPU baseline of bench.py)
+//        itm_ref <input.bin> <output.bin> mesh   dump + the CPU meshing engine's triangles of the final scene ("mesh"
+//                                                chunk: 9 floats per triangle) and, if GPS_REF_SAVE_DIR is set, the
+//                                                scene's SaveToDirectory files (voxel.dat, alloc.dat, vba.txt, hash.dat,
+//                                                excess.dat, last.txt) and the mesh's WritePLY output (mesh.ply) there
+//        itm_ref mcprobe <output.bin>            marching-cubes case probe: for each of the 256 sign configurations of one
+//                                                cube, the edges (0..11) of the triangles MeshScene emits, in order
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -36,6 +42,8 @@
 #include "ITMLib/ITMLibDefines.h"
 #include "ITMLib/Core/ITMBasicEngine.h"
 #include "ITMLib/Objects/RenderStates/ITMRenderState_VH.h"
+#include "ITMLib/Engines/Meshing/CPU/ITMMeshingEngine_CPU.h"
+#include "ITMLib/Engines/Meshing/CPU/ITMMeshingEngine_CPU.tpp"
 #undef private
 #undef protected
 
@@ -102,8 +110,89 @@ static void dump_scene(Engine *eng, int frame, bool full_vba) {
     if (full_vba) chunk("vba", frame, blocks.data(), (int64_t)blocks.size());
 }
 
+typedef ITMMeshingEngine_CPU<ITMVoxel, ITMVoxelIndex> MeshEngine;
+
+static void dump_mesh(ITMScene<ITMVoxel, ITMVoxelIndex> *scene, int frame, const char *save_dir) {
+    ITMMesh mesh(MEMORYDEVICE_CPU, 1u << 22);
+    MeshEngine me;
+    me.MeshScene(&mesh, scene);
+    const ITMMesh::Triangle *t = mesh.triangles->GetData(MEMORYDEVICE_CPU);
+    std::vector<float> pos((size_t)mesh.noTotalTriangles * 9);
+    for (uint i = 0; i < mesh.noTotalTriangles; i++) {
+        const Vector3f *p[3] = {&t[i].p0, &t[i].p1, &t[i].p2};
+        for (int k = 0; k < 3; k++) { pos[i * 9 + k * 3] = p[k]->x; pos[i * 9 + k * 3 + 1] = p[k]->y; pos[i * 9 + k * 3 + 2] = p[k]->z; }
+    }
+    chunk("mesh", frame, pos.data(), (int64_t)pos.size() * 4);
+    if (save_dir) {
+        std::string d(save_dir);
+        if (d.back() != '/') d += '/';
+        scene->SaveToDirectory(d);
+        mesh.WritePLY((d + "mesh.ply").c_str());
+    }
+}
+
+// One cube (local voxel 3,3,3 of block 0,0,0) with the sign pattern of every case in turn; all other voxels of the block are
+// positive, so the neighbouring cubes emit triangles too -- only triangles whose three vertices lie on edges of OUR cube are
+// kept (a neighbour's triangle always has a vertex off our cube for non-zero sdf values).
+static int mc_probe(const char *out_path) {
+    g_out = fopen(out_path, "wb");
+    ITMSceneParams params(0.02f, 100, 1.0f, 0.2f, 3.0f, false);  // voxel size 1: vertices come out in voxel units
+    ITMScene<ITMVoxel, ITMVoxelIndex> *scene = new ITMScene<ITMVoxel, ITMVoxelIndex>(&params, false, MEMORYDEVICE_CPU);
+    ITMHashEntry *ht = scene->index.GetEntries();
+    ITMHashEntry empty;
+    memset(&empty, 0, sizeof(empty));
+    empty.ptr = -2;
+    for (int i = 0; i < scene->index.noTotalEntries; i++) ht[i] = empty;
+    ht[0].ptr = 0;  // block (0,0,0) hashes to bucket 0
+    ITMVoxel *vb = scene->localVBA.GetVoxelBlocks();
+    static const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    static const int edge_ends[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    std::vector<int8_t> table(256 * 16, -1);
+    ITMMesh mesh(MEMORYDEVICE_CPU, 1u << 16);
+    MeshEngine me;
+    const int B = 3;
+    for (int c = 0; c < 256; c++) {
+        for (int v = 0; v < SDF_BLOCK_SIZE3; v++) { vb[v] = ITMVoxel(); vb[v].sdf = 16000; vb[v].w_depth = 1; }
+        for (int k = 0; k < 8; k++)
+            if (c & (1 << k)) {
+                const int x = B + corner[k][0], y = B + corner[k][1], z = B + corner[k][2];
+                vb[x + y * SDF_BLOCK_SIZE + z * SDF_BLOCK_SIZE * SDF_BLOCK_SIZE].sdf = -8000;
+            }
+        me.MeshScene(&mesh, scene);
+        const ITMMesh::Triangle *t = mesh.triangles->GetData(MEMORYDEVICE_CPU);
+        int n = 0;
+        for (uint i = 0; i < mesh.noTotalTriangles; i++) {
+            const Vector3f *p[3] = {&t[i].p0, &t[i].p1, &t[i].p2};
+            int e[3];
+            bool ours = true;
+            for (int k = 0; k < 3 && ours; k++) {
+                e[k] = -1;
+                for (int ed = 0; ed < 12; ed++) {
+                    const int *a = corner[edge_ends[ed][0]], *b = corner[edge_ends[ed][1]];
+                    // on edge ed: the two coordinates the end points share are equal to them, the third lies strictly between
+                    bool on = true;
+                    const float q[3] = {p[k]->x - B, p[k]->y - B, p[k]->z - B};
+                    for (int d = 0; d < 3; d++) {
+                        if (a[d] == b[d]) on = on && q[d] == (float)a[d];
+                        else on = on && q[d] > 0.f && q[d] < 1.f;
+                    }
+                    if (on) { e[k] = ed; break; }
+                }
+                if (e[k] < 0) ours = false;
+            }
+            if (!ours) continue;
+            if (n + 3 > 15) { fprintf(stderr, "case %d: more than 5 triangles\n", c); return 4; }
+            for (int k = 0; k < 3; k++) table[c * 16 + n++] = (int8_t)e[k];
+        }
+    }
+    chunk("mc_table", -1, table.data(), (int64_t)table.size());
+    fclose(g_out);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 2; }
+    if (std::string(argv[1]) == "mcprobe") return mc_probe(argv[2]);
     FILE *in = fopen(argv[1], "rb");
     if (!in) { perror("input"); return 2; }
     g_out = std::string(argv[2]) == "-" ? nullptr : fopen(argv[2], "wb");
@@ -226,6 +315,7 @@ int main(int argc, char **argv) {
             chunk("fv_colour", tag, eng->GetFreeImage()->GetData(MEMORYDEVICE_CPU), (int64_t)P * 4);
         }
     }
+    if (argc >= 4 && std::string(argv[3]) == "mesh") dump_mesh(eng->GetScene(), h.nframes - 1, getenv("GPS_REF_SAVE_DIR"));
     fclose(g_out);
     return 0;
 }

@@ -1106,6 +1106,71 @@ ORC_API int orc_track_camera(int W, int H, const float *intr /* fx fy cx cy */, 
     return frames_processed;
 }
 
+/* ---------------- meshing: Engines/Meshing/CPU/ITMMeshingEngine_CPU.tpp:8-55, Shared/ITMMeshingEngine_Shared.h:279-471 ----------------
+ * Triangles in the CPU engine's order (hash entry id, then z, y, x, then the case table's order), laid out as ITMMesh::Triangle
+ * (Objects/Meshing/ITMMesh.h:18-21): p0 p1 p2 c0 c1 c2 clr, 21 floats.  Positions follow the CPU engine; the per-vertex colours
+ * and clr are what the CUDA engine additionally stores (ITMMeshingEngine_CUDA.tcu:118-131) -- the CPU engine leaves them 0.
+ * Returns noTotalTriangles (the CPU engine stops advancing at max_triangles - 1). */
+#include "../gps_slam_amd/csrc/mc_cases.inc"
+static const unsigned long long MC_CASES[256] = GPS_MC_CASES_INIT;
+static const int MC_CORNER[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+static const int MC_EDGE[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+
+static void sdf_interp3(const float *p1, const float *p2, float v1, float v2, float *out) { /* Shared.h:359-369 */
+    if (fabsf(0.0f - v1) < 0.00001f) { out[0] = p1[0]; out[1] = p1[1]; out[2] = p1[2]; return; }
+    if (fabsf(0.0f - v2) < 0.00001f) { out[0] = p2[0]; out[1] = p2[1]; out[2] = p2[2]; return; }
+    if (fabsf(v1 - v2) < 0.00001f) { out[0] = p1[0]; out[1] = p1[1]; out[2] = p1[2]; return; }
+    const float f = (0.0f - v1) / (v2 - v1);
+    for (int k = 0; k < 3; k++) out[k] = p1[k] + f * (p2[k] - p1[k]);
+}
+
+ORC_API int64_t orc_tsdf_mesh(const Tsdf *t, int64_t max_triangles, float *tris /* [max_triangles][21] */) {
+    int64_t n = 0;
+    for (int entry = 0; entry < t->n_total; entry++) {
+        const HashEntry he = t->hash[entry];
+        if (he.ptr < 0) continue;
+        const int gx = he.pos[0] * BLK, gy = he.pos[1] * BLK, gz = he.pos[2] * BLK;
+        for (int z = 0; z < BLK; z++) for (int y = 0; y < BLK; y++) for (int x = 0; x < BLK; x++) {
+            float pts[8][3], sdf[8], col[8][3];
+            int ok = 1;
+            for (int k = 0; k < 8 && ok; k++) { /* findPointNeighbors: stops at the first missing / untouched corner */
+                const int px = gx + x + MC_CORNER[k][0], py = gy + y + MC_CORNER[k][1], pz = gz + z + MC_CORNER[k][2];
+                Cache c = {0x7fffffff, 0, 0, 0};
+                int vm;
+                const Voxel v = read_voxel(t, px, py, pz, &vm, &c);
+                pts[k][0] = (float)px; pts[k][1] = (float)py; pts[k][2] = (float)pz;
+                sdf[k] = (float)v.sdf / 32767.0f;
+                for (int q = 0; q < 3; q++) col[k][q] = v.clr[q] / 255.0f;
+                if (!vm || sdf[k] == 1.0f) ok = 0;
+            }
+            if (!ok) continue;
+            int cube = 0;
+            for (int k = 0; k < 8; k++) if (sdf[k] < 0) cube |= 1 << k;
+            const unsigned long long list = MC_CASES[cube];
+            if ((list & 0xF) == 0xF) continue; /* edgeTable[cube] == 0 */
+            float vert[12][3], vcol[12][3];
+            unsigned cut = 0;
+            for (int j = 0; j < 15 && ((list >> (4 * j)) & 0xF) != 0xF; j++) cut |= 1u << ((list >> (4 * j)) & 0xF);
+            for (int e = 0; e < 12; e++) {
+                if (!(cut & (1u << e))) continue;
+                const int a = MC_EDGE[e][0], b = MC_EDGE[e][1];
+                sdf_interp3(pts[a], pts[b], sdf[a], sdf[b], vert[e]);
+                sdf_interp3(col[a], col[b], sdf[a], sdf[b], vcol[e]);
+            }
+            for (int j = 0; j < 15 && ((list >> (4 * j)) & 0xF) != 0xF; j += 3) {
+                float *o = tris + n * 21;
+                for (int q = 0; q < 3; q++) {
+                    const int e = (int)((list >> (4 * (j + q))) & 0xF);
+                    for (int d = 0; d < 3; d++) { o[3 * q + d] = vert[e][d] * t->voxel; o[9 + 3 * q + d] = vcol[e][d]; }
+                }
+                for (int d = 0; d < 3; d++) o[18 + d] = col[0][d]; /* VoxelColorReader::uninterpolate at (x,y,z) */
+                if (n < max_triangles - 1) n++;
+            }
+        }
+    }
+    return n;
+}
+
 #define GETTER(name, type, expr) ORC_API type orc_tsdf_##name(Tsdf *t) { return expr; }
 
 /* ITMBasicEngine::ProcessFrame with trackingActive (Core/ITMBasicEngine.tpp:260-385), default failure mode IGNORE:
@@ -1141,6 +1206,8 @@ GETTER(last_free_excess, int, t->last_free_excess)
 GETTER(n_total, int, t->n_total)
 GETTER(hash, void *, t->hash)
 GETTER(vba, void *, t->vba)
+GETTER(vba_alloc_list, void *, t->vba_alloc_list)
+GETTER(excess_list, void *, t->excess_list)
 GETTER(visible_ids, void *, t->visible_ids)
 GETTER(visible_type, void *, t->visible_type)
 GETTER(minmax, void *, t->minmax)

@@ -52,7 +52,7 @@ def time_reference(seq, n_frames, voxel, mu, vfmin, vfmax, threads=None, openmp=
     return json.loads(out.strip().splitlines()[-1])
 
 
-def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0, track=False):
+def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0, track=False, mesh=False, save_dir=None):
     """seq: dict from tests.synth.make_sequence; free_views: list of (frame_idx, c2w[4,4]).
     returns {(name, frame): np.ndarray(bytes)} decoded by `decode`."""
     W, H = seq["W"], seq["H"]
@@ -70,7 +70,14 @@ def run(seq, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_every=0, track=Fal
             for fr, c2w in free_views:
                 f.write(struct.pack("<i", fr))
                 f.write(np.ascontiguousarray(c2w, dtype=np.float32).tobytes())
-        subprocess.check_call([BIN, fin, fout] + (["track"] if track else []))
+        # mesh=True: the CPU meshing engine's triangles of the final scene ("mesh" chunk [T,3,3]); save_dir: additionally the
+        # reference's own SaveToDirectory files + WritePLY output (mesh.ply) are written there
+        assert not (track and mesh)
+        env = dict(os.environ)
+        if save_dir is not None:
+            env["GPS_REF_SAVE_DIR"] = str(save_dir)
+        subprocess.check_call([BIN, fin, fout] + (["track"] if track else ["mesh"] if mesh else []), env=env,
+                              stdout=subprocess.DEVNULL)
         raw = open(fout, "rb").read()
     out = {}
     off = 0
@@ -87,7 +94,7 @@ _DT = {"M": np.float32, "invM": np.float32, "counts": np.int32, "visible_ids": n
        "hash": np.int32, "vba_crc": np.uint32, "vba": np.uint8, "depth_f": np.float32, "minmax": np.float32,
        "raycast": np.float32, "icp_points": np.float32, "icp_normals": np.float32, "fv_M": np.float32,
        "fv_invM": np.float32, "fv_counts": np.int32, "fv_visible_ids": np.int32, "fv_minmax": np.float32,
-       "fv_raycast": np.float32, "fv_colour": np.uint8, "sizeof": np.int32, "trk_score": np.float32}
+       "fv_raycast": np.float32, "fv_colour": np.uint8, "sizeof": np.int32, "trk_score": np.float32, "mesh": np.float32}
 
 
 def decode(chunks, W, H):
@@ -108,6 +115,8 @@ def decode(chunks, W, H):
             a = a.reshape(-1, 2)
         elif name == "vba":
             a = a.reshape(-1, 512, 8)
+        elif name == "mesh":
+            a = a.reshape(-1, 3, 3)
         res[(name, frame)] = a
     return res
 
@@ -133,7 +142,7 @@ def _lib():
             subprocess.check_call(["make", "-s", "-C", _HERE, so])
         _LIB = C.CDLL(so)
         _LIB.orc_tsdf_create.restype = C.c_void_p
-        for n in ("hash", "vba", "visible_ids", "visible_type", "minmax", "raycast", "icp_points", "icp_normals",
+        for n in ("hash", "vba", "vba_alloc_list", "excess_list", "visible_ids", "visible_type", "minmax", "raycast", "icp_points", "icp_normals",
                   "depth", "fv_visible_ids", "fv_minmax", "fv_raycast", "fv_colour", "trk_diag"):
             getattr(_LIB, "orc_tsdf_" + n).restype = C.c_void_p
     return _LIB
@@ -186,7 +195,7 @@ class TsdfOracle:
     def __init__(self, W, H, fx, fy, cx, cy, voxel, mu, vf_min, vf_max, n_blocks=REF_BLOCKS, n_buckets=REF_BUCKETS,
                  n_excess=REF_EXCESS):
         self.W, self.H = W, H
-        self.n_blocks, self.n_total = n_blocks, n_buckets + n_excess
+        self.n_blocks, self.n_total, self.n_excess = n_blocks, n_buckets + n_excess, n_excess
         self.h = C.c_void_p(_lib().orc_tsdf_create(W, H, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                                    C.c_float(voxel), C.c_float(mu), C.c_float(vf_min),
                                                    C.c_float(vf_max), n_blocks, n_buckets, n_excess))
@@ -252,6 +261,12 @@ class TsdfOracle:
     def vba(self):
         return self._arr("vba", VOXEL_DT, (self.n_blocks, 512))
 
+    def vba_alloc_list(self):
+        return self._arr("vba_alloc_list", np.int32, (self.n_blocks,))
+
+    def excess_list(self):
+        return self._arr("excess_list", np.int32, (self.n_excess,))
+
     def visible_ids(self):
         return self._arr("visible_ids", np.int32, (self.n_blocks,))[:self.n_visible]
 
@@ -268,6 +283,14 @@ class TsdfOracle:
 
     def fv_visible_ids(self):
         return self._arr("fv_visible_ids", np.int32, (self.n_blocks,))[:self.fv_n_visible]
+
+    def mesh(self, max_triangles=1 << 22):
+        """ITMMeshingEngine::MeshScene of the current scene -> float32 [T, 7, 3]: p0 p1 p2 c0 c1 c2 clr (ITMMesh::Triangle)"""
+        buf = np.zeros((max_triangles, 21), np.float32)
+        lib = _lib()
+        lib.orc_tsdf_mesh.restype = C.c_int64
+        n = lib.orc_tsdf_mesh(self.h, C.c_int64(max_triangles), buf.ctypes.data_as(C.c_void_p))
+        return buf[:n].reshape(n, 7, 3).copy()
 
     # canonical views used by every comparison
     def hash_rows(self):

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o bench -- $CMD > gpurun_ou
   echo
   echo "Command: \`rocprofv3 --kernel-trace --stats -- $CMD\` (640x480, C++ host, 120 SLAM frames incl. warm-up)."
   echo "Summarised from the rocpd database with scratch/prof_summary.py. knn_kernel's maximum is the untimed scene set-up"
-  echo "(200k seed Gaussians); raster_ges_fwd_kernel<16> (operator-level forward) only runs in the roofline micro-benchmark."
+  echo "(200k seed Gaussians)."
   echo
   python scratch/prof_summary.py "$(find /tmp/prof_stats -name '*.db' | head -1)" 48
   echo

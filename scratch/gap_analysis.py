@@ -1,30 +1,25 @@
-import sqlite3, sys, re, collections
-db=sqlite3.connect(sys.argv[1]); cur=db.cursor()
-rows=cur.execute("select name,start,end from kernels order by start").fetchall()
-# timed region: find the last convert_depth_kernel occurrences -> frames; use last N frames
-frames=[r[1] for r in rows if 'convert_depth_kernel' in r[0]]
-nf=int(sys.argv[2]) if len(sys.argv)>2 else 100
-t0=frames[-nf]; t1=rows[-1][2]
-sel=[r for r in rows if r[1]>=t0]
-# drop the trailing roofline microbench: stop at the end of the kernel preceding the 50x repeated raster launches
-# (approximation: stop at last adam_kernel end + 5 ms)
-last_adam=max(r[2] for r in sel if 'adam_kernel' in r[0])
-sel=[r for r in sel if r[1]<=last_adam]
-t1=last_adam
-busy=sum(r[2]-r[1] for r in sel)
-wall=t1-t0
-print('frames %d wall %.3f ms (%.3f ms/frame) kernel-busy %.3f ms (%.1f%%) dispatches %d (%.1f/frame)'%(nf,wall/1e6,wall/1e6/nf,busy/1e6,100*busy/wall,len(sel),len(sel)/nf))
-gaps=collections.defaultdict(lambda:[0,0])
-prev=None
-big=[]
-for r in sel:
-    if prev is not None:
-        g=r[1]-prev[2]
-        if g>0:
-            key=re.sub(r'\(.*','',prev[0].replace('(anonymous namespace)::','').replace('void ',''))[:40]+' -> '+re.sub(r'\(.*','',r[0].replace('(anonymous namespace)::','').replace('void ',''))[:40]
-            gaps[key][0]+=g; gaps[key][1]+=1
-    prev=r
-tot=sum(v[0] for v in gaps.values())
-print('total gap %.3f ms'%(tot/1e6))
-for k,v in sorted(gaps.items(), key=lambda kv:-kv[1][0])[:25]:
-    print('%8.3f ms  n=%5d avg %7.1f us  %s'%(v[0]/1e6,v[1],v[0]/v[1]/1e3,k))
+"""GPU idle time between consecutive kernel dispatches of a rocprofv3 kernel trace (rocpd sqlite), attributed to the kernel
+that FOLLOWS the gap.  usage: gap_analysis.py trace.db [t0_frac] -- only dispatches after t0_frac of the run are counted."""
+import re, sqlite3, sys, collections
+db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
+frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+def short(n):
+    n = n.replace("(anonymous namespace)::", ""); n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*", "", n)
+    return (n.split("<")[0] if n.startswith("at::") else n)[:48]
+# timed region of bench.py = its last 100 frames; one convert_depth_kernel per frame -> window of the last 99 frames
+cd = [r[1] for r in rows if "convert_depth" in r[0]]
+off = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # frames to skip at the end (bench.py: 120 of the fusion-only pass)
+t_lo, t_hi = cd[-100 - off], cd[-1 - off]
+rows = [r for r in rows if t_lo <= r[1] < t_hi]
+print("window: %d frames, %.3f ms per frame" % (99, (t_hi - t_lo) / 99e6))
+span = rows[-1][2] - rows[0][1]
+busy = 0; gaps = collections.defaultdict(lambda: [0, 0]); prev_end = rows[0][1]
+for n, s, e in rows:
+    if s > prev_end:
+        g = gaps[short(n)]; g[0] += 1; g[1] += s - prev_end
+    busy += max(0, e - max(s, prev_end)); prev_end = max(prev_end, e)
+print("span %.1f ms, busy %.1f ms (%.0f%%), idle %.1f ms over %d dispatches" % (span / 1e6, busy / 1e6, 100 * busy / span, (span - busy) / 1e6, len(rows)))
+print("idle time by the kernel that follows the gap:")
+for k, (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("  %-50s gaps %5d  total %8.2f ms  avg %6.1f us" % (k, c, t / 1e6, t / c / 1e3))

@@ -18,3 +18,11 @@ print("|---|---|---|---|---|---|---|")
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print("| %s | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (k[:70], a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / tot))
 print("total kernel time %.3f ms over %d dispatches" % (tot / 1e6, len(rows)))
+# the roofline micro-benchmark of bench.py launches the dominant kernel 1 + 50 times at the end of the run: its average is
+# the number bench.py's `roofline.avg_launch_us` must agree with (the whole-run average mixes all scene sizes)
+for kname in ("raster_ges_bwd_gs_kernel", "raster_ges_fwd_pk_kernel"):
+    d = [r[0] for r in cur.execute("select (end-start) from kernels where name like ? order by start", ("%" + kname + "%",))]
+    if len(d) > 50:
+        tail = d[-50:]
+        print("%s: last 50 launches (bench.py roofline micro-benchmark) avg %.2f us, min %.2f, max %.2f" %
+              (kname, sum(tail) / 50e3, min(tail) / 1e3, max(tail) / 1e3))
