@@ -25,6 +25,7 @@ __device__ const unsigned long long mc_cases_dev[256] = GPS_MC_CASES_INIT;
 constexpr int SLOTS = 1024;   // hash slots per workgroup of the list sweeps
 constexpr int NB = 9;         // staged neighbourhood edge
 constexpr int NB3 = NB * NB * NB;
+constexpr int STAGE = 256;    // triangles per LDS staging round of the emit pass (21.5 KB)
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
     const int lane = threadIdx.x & 63;
@@ -130,6 +131,9 @@ __global__ __launch_bounds__(512) void mesh_block_kernel(TsdfState s, const int3
     __shared__ uint8_t present[NB3]; // the block holding that voxel exists (readVoxel's vmIndex != 0)
     __shared__ int nb_ptr[8];
     __shared__ int ws[9];
+    __shared__ float stage[EMIT ? STAGE * 21 : 1];
+    __shared__ int off[EMIT ? 512 : 1];
+    __shared__ unsigned long long cs[EMIT ? 512 : 1];
     const int tid = threadIdx.x;
     const int n_list = min(*n_list_ptr, s.n_blocks);
     for (int b = blockIdx.x; b < n_list; b += gridDim.x) {
@@ -167,18 +171,36 @@ __global__ __launch_bounds__(512) void mesh_block_kernel(TsdfState s, const int3
         if (!EMIT) {
             if (tid == 0) tri_count[b] = total;
         } else {
-            const int gx = he.x * BLK + x, gy = he.y * BLK + y, gz = he.z * BLK + z;
-            const float clr0 = (float)(vox[base].x >> 24) / 255.0f, clr1 = (float)(vox[base].y & 0xFFu) / 255.0f,
-                        clr2 = (float)((vox[base].y >> 8) & 0xFFu) / 255.0f;
-            for (int t = 0; t < n_tri; t++) {
-                const int64_t id = (int64_t)tri_base[b] + first + t;
-                if (id >= max_triangles - 1) break;  // the CPU engine stops advancing at noMaxTriangles - 1
-                float* o = triangles + id * 21;
-                for (int c = 0; c < 3; c++) {
-                    const int e = (int)((cases >> (4 * (3 * t + c))) & 0xF);
+            // Dense emit.  Only a few of the 512 cubes of a block cut the surface (85 triangles per block on the bench scene),
+            // so a thread-per-cube loop leaves most lanes idle behind the busiest one (first version: 660 us).  Instead the
+            // per-cube offsets and case words go to LDS and the block's 3 * total triangle VERTICES are dealt to consecutive
+            // threads (owner cube by binary search in the offsets); vertices are staged in LDS and copied out with
+            // consecutive lanes on consecutive dwords -- the block's triangles are contiguous in the output.
+            off[tid] = first;
+            cs[tid] = cases;
+            const int64_t out_base = (int64_t)tri_base[b];
+            const int64_t room = max_triangles - 1 - out_base;  // the CPU engine stops advancing at noMaxTriangles - 1
+            const int emit_total = (int)(room <= 0 ? 0 : (room < total ? room : total));
+            __syncthreads();
+            for (int r0 = 0; r0 < emit_total; r0 += STAGE) {
+                const int n_round = min(STAGE, emit_total - r0);
+                for (int q = tid; q < 3 * n_round; q += 512) {
+                    const int tri = r0 + q / 3, c = q % 3;
+                    int lo = 0, hi = 511;  // last cube whose first triangle index is <= tri (cubes without triangles repeat the offset)
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (off[mid] <= tri) lo = mid; else hi = mid - 1;
+                    }
+                    const int v = lo, t = tri - off[v];
+                    const unsigned long long vc = cs[v];
+                    const int vx = v & 7, vy = (v >> 3) & 7, vz = v >> 6;
+                    const int vbase = vx + vy * NB + vz * NB * NB;
+                    const int gx = he.x * BLK + vx, gy = he.y * BLK + vy, gz = he.z * BLK + vz;
+                    float* o = stage + (tri - r0) * 21;
+                    const int e = (int)((vc >> (4 * (3 * t + c))) & 0xF);
                     const int ka = edge_a(e), kb = edge_b(e);
-                    const int qa = base + corner_dx(ka) + corner_dy(ka) * NB + corner_dz(ka) * NB * NB;
-                    const int qb = base + corner_dx(kb) + corner_dy(kb) * NB + corner_dz(kb) * NB * NB;
+                    const int qa = vbase + corner_dx(ka) + corner_dy(ka) * NB + corner_dz(ka) * NB * NB;
+                    const int qb = vbase + corner_dx(kb) + corner_dy(kb) * NB + corner_dz(kb) * NB * NB;
                     const uint2 va = vox[qa], vb = vox[qb];
                     const float sa = (float)(int16_t)(va.x & 0xFFFFu) / 32767.0f, sb = (float)(int16_t)(vb.x & 0xFFFFu) / 32767.0f;
                     // sdfInterp: |v1| < 1e-5 -> p1; |v2| < 1e-5 -> p2; |v1 - v2| < 1e-5 -> p1; else p1 + (-v1 / (v2 - v1)) (p2 - p1)
@@ -194,8 +216,15 @@ __global__ __launch_bounds__(512) void mesh_block_kernel(TsdfState s, const int3
                     o[9 + 3 * c + 0] = lerp_or_pick(ar, br, pick, f);
                     o[9 + 3 * c + 1] = lerp_or_pick(ag, bg, pick, f);
                     o[9 + 3 * c + 2] = lerp_or_pick(ab, bb, pick, f);
+                    if (c == 0) {  // VoxelColorReader::uninterpolate at the cube's origin voxel
+                        const uint2 v0 = vox[vbase];
+                        o[18] = (float)(v0.x >> 24) / 255.0f; o[19] = (float)(v0.y & 0xFFu) / 255.0f; o[20] = (float)((v0.y >> 8) & 0xFFu) / 255.0f;
+                    }
                 }
-                o[18] = clr0; o[19] = clr1; o[20] = clr2;  // VoxelColorReader::uninterpolate at the cube's origin voxel
+                __syncthreads();
+                float* dst = triangles + (out_base + r0) * 21;
+                for (int k = tid; k < n_round * 21; k += 512) dst[k] = stage[k];
+                __syncthreads();
             }
         }
         __syncthreads();

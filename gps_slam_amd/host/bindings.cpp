@@ -156,6 +156,11 @@ PYBIND11_MODULE(_host, m) {
         .def("GetLiveVertex", [](ITMBasicEngine& e) { return e.GetLiveVertex()->tensor(); })
         .def("getVoxelSize", &ITMBasicEngine::getVoxelSize)
         .def("counters", &ITMBasicEngine::counters)
+        .def("MeshScene", &ITMBasicEngine::MeshScene, py::arg("maxTriangles") = (int64_t)1 << 24)
+        .def("SaveSceneToMesh", [](ITMBasicEngine& e, const std::string& f, int64_t m) { return e.SaveSceneToMesh(f.c_str(), m); },
+             py::arg("fileName"), py::arg("maxTriangles") = (int64_t)1 << 24)
+        .def("SaveToFile", &ITMBasicEngine::SaveToFile)
+        .def("LoadFromFile", &ITMBasicEngine::LoadFromFile)
         .def_readonly("framesProcessed", &ITMBasicEngine::framesProcessed);
 
     // ---- pipeline
@@ -174,5 +179,11 @@ PYBIND11_MODULE(_host, m) {
         })
         .def("optCams", [](SLAMPipeline& p) { return p.opt_cam_list; })
         .def("optRaycasts", [](SLAMPipeline& p) { return p.opt_raycast_list; })
+        .def_readwrite("workspace_dir", &SLAMPipeline::workspace_dir)
+        .def_readwrite("saved_mesh", &SLAMPipeline::saved_mesh)
+        .def_readwrite("saved_engine", &SLAMPipeline::saved_engine)
+        .def("saveMesh", &SLAMPipeline::saveMesh)
+        .def("saveEngine", &SLAMPipeline::saveEngine)
+        .def("loadEngine", &SLAMPipeline::loadEngine)
         .def_readwrite("work_mode", &SLAMPipeline::work_mode);
 }

@@ -62,6 +62,12 @@ public:
     void localOptimize();
     void removeRedundantGs();
 
+    // slam_pipeline.h:32-49: mesh / engine state files under workspace_dir (empty names are skipped like the reference)
+    std::string workspace_dir = ".", saved_mesh, saved_engine;
+    void saveMesh() { if (!saved_mesh.empty()) main_engine->SaveSceneToMesh((workspace_dir + "/" + saved_mesh).c_str()); }
+    void saveEngine() { if (!saved_engine.empty()) main_engine->SaveToFile(workspace_dir + "/" + saved_engine); }
+    void loadEngine() { main_engine->LoadFromFile(workspace_dir + "/" + saved_engine); }
+
     torch::Device device = torch::kCUDA;
     std::string work_mode = "train";
     ITMBasicEngine* main_engine;

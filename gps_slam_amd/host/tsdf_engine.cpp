@@ -1,5 +1,10 @@
 #include "tsdf_engine.hpp"
 
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <fstream>
+
 using namespace gpsh;
 
 namespace {
@@ -110,4 +115,93 @@ ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, cons
 
 void ITMBasicEngine::runRaycast(ORUtils::SE3Pose* pose) {
     check(gps_tsdf_free_raycast(&state_, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
+}
+
+// ------------------------------------------------------------------------------------------------ meshing
+std::pair<torch::Tensor, torch::Tensor> ITMBasicEngine::MeshScene(int64_t maxTriangles) {
+    auto tri = torch::empty({maxTriangles, 7, 3}, f32(device_));
+    auto counts = torch::zeros({2}, i64(device_));
+    const int64_t ws_bytes = gps_tsdf_mesh_workspace_bytes(&state_);
+    auto ws = torch::empty({ws_bytes}, u8(device_));
+    check(gps_tsdf_mesh_scene(&state_, maxTriangles, fptr(tri), ptr<int64_t>(counts), ws.data_ptr(), ws_bytes, current_stream()),
+          "gps_tsdf_mesh_scene");
+    return {tri, counts};
+}
+
+int64_t ITMBasicEngine::SaveSceneToMesh(const char* fileName, int64_t maxTriangles) {
+    auto mesh = MeshScene(maxTriangles);
+    const int64_t n = mesh.second.cpu().data_ptr<int64_t>()[0];
+    auto host = mesh.first.slice(0, 0, n).cpu().contiguous();
+    const float* t = host.data_ptr<float>();
+    FILE* f = fopen(fileName, "w");
+    TORCH_CHECK(f != nullptr, "SaveSceneToMesh: cannot open ", fileName);
+    fprintf(f, "ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+               "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face %d\n"
+               "property list uchar int vertex_indices\nend_header\n", (int)(n * 3), (int)n);
+    for (int64_t i = 0; i < n; i++) {
+        const float* q = t + i * 21;
+        for (int v = 0; v < 3; v++)
+            fprintf(f, "%f %f %f %d %d %d\n", q[3 * v], q[3 * v + 1], q[3 * v + 2],
+                    static_cast<unsigned char>(q[9 + 3 * v] * 255), static_cast<unsigned char>(q[9 + 3 * v + 1] * 255),
+                    static_cast<unsigned char>(q[9 + 3 * v + 2] * 255));
+    }
+    for (int64_t i = 0; i < n; i++) fprintf(f, "3 %d %d %d\n", (int)(i * 3), (int)(i * 3 + 1), (int)(i * 3 + 2));
+    fclose(f);
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ persistence
+namespace {
+std::string with_slash(const std::string& d) { return (!d.empty() && d.back() == '/') ? d : d + "/"; }
+
+void write_block(const std::string& path, const torch::Tensor& dev, size_t elem_bytes) {
+    auto h = dev.cpu().contiguous();
+    std::ofstream fs(path.c_str(), std::ios::binary);
+    TORCH_CHECK((bool)fs, "Could not open ", path, " for writing");
+    const size_t count = (size_t)h.nbytes() / elem_bytes;  // MemoryBlockPersister::WriteBlock: dataSize, then the elements
+    fs.write(reinterpret_cast<const char*>(&count), sizeof(size_t));
+    fs.write(reinterpret_cast<const char*>(h.data_ptr()), (std::streamsize)h.nbytes());
+    TORCH_CHECK((bool)fs, "Could not write memory block data: ", path);
+}
+
+void read_block(const std::string& path, torch::Tensor& dev, size_t elem_bytes) {
+    std::ifstream fs(path.c_str(), std::ios::binary);
+    TORCH_CHECK((bool)fs, "Could not open ", path, " for reading");
+    size_t count = 0;
+    TORCH_CHECK((bool)fs.read(reinterpret_cast<char*>(&count), sizeof(size_t)), "Could not read memory block size");
+    TORCH_CHECK(count * elem_bytes == (size_t)dev.nbytes(), "Could not read data into a memory block of the wrong size: ", path);
+    auto h = torch::empty_like(dev, dev.options().device(torch::kCPU));
+    TORCH_CHECK((bool)fs.read(reinterpret_cast<char*>(h.data_ptr()), (std::streamsize)h.nbytes()), "Could not read memory block data");
+    dev.copy_(h);
+}
+}  // namespace
+
+void ITMBasicEngine::SaveToFile(const std::string& saveOutputDirectory) {
+    const std::string d = with_slash(saveOutputDirectory), sc = d + "Scene/";
+    mkdir(d.c_str(), 0755); mkdir((d + "Relocaliser/").c_str(), 0755); mkdir(sc.c_str(), 0755);
+    auto c = counters_.cpu();
+    const int32_t* ch = c.data_ptr<int32_t>();
+    write_block(sc + "voxel.dat", vba_, 8);
+    write_block(sc + "alloc.dat", vba_alloc_list_, 4);
+    { std::ofstream ofs((sc + "vba.txt").c_str()); TORCH_CHECK((bool)ofs, "Could not open vba.txt"); ofs << ch[GPS_TSDF_LAST_FREE_BLOCK] << ' ' << (int64_t)state_.n_blocks * 512; }
+    write_block(sc + "hash.dat", hash_, 16);
+    write_block(sc + "excess.dat", excess_list_, 4);
+    { std::ofstream ofs((sc + "last.txt").c_str()); TORCH_CHECK((bool)ofs, "Could not open last.txt"); ofs << ch[GPS_TSDF_LAST_FREE_EXCESS]; }
+}
+
+void ITMBasicEngine::LoadFromFile(const std::string& saveInputDirectory) {
+    const std::string sc = with_slash(saveInputDirectory) + "Scene/";
+    resetAll();
+    read_block(sc + "voxel.dat", vba_, 8);
+    read_block(sc + "alloc.dat", vba_alloc_list_, 4);
+    int last_block = 0, last_excess = 0;
+    int64_t alloc_size = 0;
+    { std::ifstream ifs((sc + "vba.txt").c_str()); TORCH_CHECK((bool)ifs, "Could not open vba.txt for reading"); ifs >> last_block >> alloc_size; }
+    read_block(sc + "hash.dat", hash_, 16);
+    read_block(sc + "excess.dat", excess_list_, 4);
+    { std::ifstream ifs((sc + "last.txt").c_str()); TORCH_CHECK((bool)ifs, "Count not open last.txt for reading"); ifs >> last_excess; }
+    auto c = counters_.cpu();
+    c.data_ptr<int32_t>()[GPS_TSDF_LAST_FREE_BLOCK] = last_block;
+    c.data_ptr<int32_t>()[GPS_TSDF_LAST_FREE_EXCESS] = last_excess;
+    counters_.copy_(c);
 }

@@ -72,6 +72,16 @@ public:
     ITMFloat4Image* GetLiveVertex() { return &live_vertex_; }
     float getVoxelSize() const { return state_.voxel_size; }
     ITMTrackingState* GetTrackingState() { return &tracking_state_; }
+
+    // ITMBasicEngine::SaveSceneToMesh (ITMBasicEngine.tpp:105-117): MeshScene (gps_tsdf_mesh_scene, triangles in the CPU
+    // engine's deterministic order) + ITMMesh::WritePLY (ITMMesh.h:39-106).  Returns noTotalTriangles.
+    int64_t SaveSceneToMesh(const char* fileName, int64_t maxTriangles = (int64_t)1 << 24);
+    // {triangles float[maxTriangles,7,3] (p0 p1 p2 c0 c1 c2 clr), counts int64[2]} on the device, no host sync
+    std::pair<torch::Tensor, torch::Tensor> MeshScene(int64_t maxTriangles = (int64_t)1 << 24);
+    // ITMBasicEngine::SaveToFile / LoadFromFile (ITMBasicEngine.tpp:119-171): <dir>Scene/{voxel.dat, alloc.dat, vba.txt,
+    // hash.dat, excess.dat, last.txt} in the reference's MemoryBlockPersister format (size_t count + raw elements)
+    void SaveToFile(const std::string& saveOutputDirectory);
+    void LoadFromFile(const std::string& saveInputDirectory);
     const gps_tsdf_state& state() const { return state_; }
     torch::Tensor counters() const { return counters_; }
 

@@ -77,6 +77,19 @@ class SLAMPipeline:
         self.curr_frame_id = 0
         self.curr_cam = None
         self.stats = dict(frames=0, opt_iters=0, raycasts=0, added=0, pruned=0)
+        self.workspace_dir, self.saved_mesh, self.saved_engine = ".", "", ""
+
+    # ------------------------------------------------------------------ slam_pipeline.h:32-49
+    def saveMesh(self):
+        if self.saved_mesh:
+            self.tsdf.SaveSceneToMesh(self.workspace_dir + "/" + self.saved_mesh)
+
+    def saveEngine(self):
+        if self.saved_engine:
+            self.tsdf.SaveToFile(self.workspace_dir + "/" + self.saved_engine)
+
+    def loadEngine(self):
+        self.tsdf.LoadFromFile(self.workspace_dir + "/" + self.saved_engine)
 
     # ------------------------------------------------------------------ raycast -> tensors (runRaycastByCam :362-415)
     def runRaycastByCam(self, cam):

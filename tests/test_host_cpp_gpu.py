@@ -327,3 +327,43 @@ def test_cpp_engine_tracks_like_the_reference():
         pose = eng.lastPose().numpy()
         assert np.abs(pose[0] - G["M"][f]).max() < 2e-5 and np.abs(pose[1] - G["invM"][f]).max() < 2e-5, f
     assert eng.trackDiag()[8] > 10000  # inliers of the last accepted evaluation
+
+
+def test_cpp_engine_mesh_and_state_files_equal_python_host(tmp_path):
+    """ITMBasicEngine::SaveSceneToMesh / SaveToFile / LoadFromFile and SLAMPipeline::saveMesh / saveEngine / loadEngine in the
+    C++ host write the same bytes as the Python mirror (which tests/test_tsdf_gpu.py compares with the reference's own files)."""
+    h = _host()
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    W, Hh, n = 96, 72, 3
+    seq = synth.make_sequence(W, Hh, n, step_deg=1.0)
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
+    rgb = torch.as_tensor(rgba).to(DEV)
+    dep = torch.as_tensor(seq["depth"].astype(np.int16)).to(DEV)
+    eng_c = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    eng_c.turnOffTracking()
+    eng_p = TsdfEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.01, mu=0.04, device=DEV)
+    for i in range(n):
+        eng_c.pushGtPose(torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        eng_c.ProcessFrame(rgb[i], dep[i])
+        eng_p.ProcessFrame(rgb[i], dep[i], seq["c2w"][i])
+    pipe = h.SLAMPipeline(eng_c, h.SLAMGaussianModel(), 1)
+    pipe.workspace_dir, pipe.saved_mesh, pipe.saved_engine = str(tmp_path), "c_mesh.ply", "c_state/"
+    pipe.saveMesh()
+    pipe.saveEngine()
+    n_tri = eng_p.SaveSceneToMesh(str(tmp_path / "p_mesh.ply"))
+    eng_p.SaveToFile(str(tmp_path / "p_state"))
+    assert n_tri > 100000
+    assert open(tmp_path / "c_mesh.ply", "rb").read() == open(tmp_path / "p_mesh.ply", "rb").read()
+    for name in ("voxel.dat", "alloc.dat", "vba.txt", "hash.dat", "excess.dat", "last.txt"):
+        a = np.fromfile(tmp_path / "c_state" / "Scene" / name, np.uint8)
+        b = np.fromfile(tmp_path / "p_state" / "Scene" / name, np.uint8)
+        assert a.shape == b.shape and bool((a == b).all()), name
+    tri_c, counts_c = eng_c.MeshScene(1 << 21)
+    # load into a fresh C++ engine through the pipeline: same mesh afterwards
+    eng_2 = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    pipe_2 = h.SLAMPipeline(eng_2, h.SLAMGaussianModel(), 1)
+    pipe_2.workspace_dir, pipe_2.saved_engine = str(tmp_path), "c_state/"
+    pipe_2.loadEngine()
+    tri_2, counts_2 = eng_2.MeshScene(1 << 21)
+    assert torch.equal(counts_c, counts_2) and torch.equal(tri_c[:n_tri], tri_2[:n_tri])
+    assert torch.equal(eng_2.counters()[:2], eng_c.counters()[:2])
