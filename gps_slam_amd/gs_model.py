@@ -122,6 +122,18 @@ class RawGaussianParams:
             self._buf[name][self.N:self.N + n] = new[name]
         self.N += n
 
+    def savePly(self, filename):
+        """RawGaussianParams::savePly (raw_gs_param.cpp:159-217): binary little-endian 3DGS PLY, one float row per Gaussian:
+        x y z | nx ny nz (zeros) | f_dc_0..2 | f_rest_* (channel-major: featuresRest.transpose(1,2)) | opacity | scale_0..2 |
+        rot_0..3 -- raw (log / logit) parameters, as the reference stores them."""
+        write_gaussian_ply(filename, *[t.detach().cpu().numpy() for t in self.tensors()])
+
+    def loadPly(self, filename):
+        """inverse of savePly (the reference has no reader; the 3DGS viewers it targets define the format)"""
+        new = read_gaussian_ply(filename)
+        self.N = 0
+        self.add({k: torch.from_numpy(v).to(self.device) for k, v in new.items()})
+
     def remove(self, keep_idx):
         """RawGaussianParams::remove (raw_gs_param.cpp:148-157): stable compaction into the alternate buffers"""
         m = keep_idx.shape[0]
@@ -129,6 +141,44 @@ class RawGaussianParams:
             torch.index_select(self._buf[name][:self.N], 0, keep_idx, out=self._alt[name][:m])
             self._buf[name], self._alt[name] = self._alt[name], self._buf[name]
         self.N = m
+
+
+def gaussian_ply_properties(n_dc, n_rest):
+    """property names in file order (raw_gs_param.cpp:167-196)"""
+    return (["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(n_dc)] + ["f_rest_%d" % i for i in range(n_rest)] +
+            ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"])
+
+
+def write_gaussian_ply(filename, means, scales, quats, features_dc, features_rest, opacities):
+    """numpy arrays in RawGaussianParams.NAMES order -> the reference's PLY bytes"""
+    import numpy as np
+    n = means.shape[0]
+    rest = np.ascontiguousarray(np.transpose(features_rest, (0, 2, 1))).reshape(n, -1)  # .transpose(1, 2).reshape({N, -1})
+    props = gaussian_ply_properties(features_dc.shape[1], rest.shape[1])
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n + "".join("property float %s\n" % p for p in props) + \
+             "end_header\n"
+    rows = np.concatenate([means, np.zeros((n, 3), np.float32), features_dc, rest, opacities.reshape(n, 1), scales, quats], 1)
+    with open(filename, "wb") as f:
+        f.write(header.encode())
+        f.write(np.ascontiguousarray(rows, dtype="<f4").tobytes())
+
+
+def read_gaussian_ply(filename):
+    import numpy as np
+    raw = open(filename, "rb").read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    lines = raw[:end].decode().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+    n = int(lines[2].split()[-1])
+    props = [l.split()[-1] for l in lines[3:] if l.startswith("property float")]
+    rows = np.frombuffer(raw[end:], "<f4").reshape(n, len(props)).copy()
+    col = {p: i for i, p in enumerate(props)}
+    n_rest = sum(p.startswith("f_rest_") for p in props)
+    pick = lambda names: rows[:, [col[x] for x in names]]
+    rest = pick(["f_rest_%d" % i for i in range(n_rest)]).reshape(n, 3, n_rest // 3).transpose(0, 2, 1)
+    return dict(means=pick(["x", "y", "z"]), scales=pick(["scale_0", "scale_1", "scale_2"]),
+                quats=pick(["rot_0", "rot_1", "rot_2", "rot_3"]), featuresDc=pick(["f_dc_0", "f_dc_1", "f_dc_2"]),
+                featuresRest=np.ascontiguousarray(rest), opacities=pick(["opacity"]))
 
 
 for _n in RawGaussianParams.NAMES:

@@ -88,6 +88,9 @@ PYBIND11_MODULE(_host, m) {
         .def("getOpacities", &RawGaussianParams::getOpacities)
         .def("add", [](RawGaussianParams& p, std::vector<torch::Tensor> t) { p.add(t); })
         .def("remove", &RawGaussianParams::remove)
+        .def("savePly", &RawGaussianParams::savePly)
+        .def("saveTensor", &RawGaussianParams::saveTensor)
+        .def("loadTensor", &RawGaussianParams::loadTensor)
         .def_static("make", &RawGaussianParams::make);
 
     py::class_<SLAMGaussianModel>(m, "SLAMGaussianModel")

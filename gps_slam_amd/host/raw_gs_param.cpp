@@ -1,5 +1,7 @@
 #include "raw_gs_param.hpp"
 
+#include <fstream>
+
 using namespace gpsh;
 using torch::indexing::Slice;
 
@@ -131,4 +133,46 @@ void RawGaussianParams::remove(const torch::Tensor& mask) {
         std::swap(buf_[k], alt_[k]);
     }
     N_ = m;
+}
+
+// ------------------------------------------------------------------------------------------------ persistence
+void RawGaussianParams::savePly(const std::string& filename) const {
+    std::ofstream o(filename, std::ios_base::out | std::ios_base::binary);
+    TORCH_CHECK((bool)o, "savePly: cannot open ", filename);
+    const int64_t numPoints = N_;
+    auto meansCpu = view(0).cpu().contiguous(), scalesCpu = view(1).cpu().contiguous(), quatsCpu = view(2).cpu().contiguous();
+    auto dcCpu = view(3).cpu().contiguous(), opacCpu = view(5).cpu().contiguous();
+    auto restCpu = view(4).cpu().transpose(1, 2).reshape({numPoints, -1}).contiguous();  // channel-major like the reference
+    o << "ply\n" << "format binary_little_endian 1.0\n" << "element vertex " << numPoints << "\n";
+    for (const char* p : {"x", "y", "z", "nx", "ny", "nz"}) o << "property float " << p << "\n";
+    for (int64_t i = 0; i < dcCpu.size(1); i++) o << "property float f_dc_" << i << "\n";
+    for (int64_t i = 0; i < restCpu.size(1); i++) o << "property float f_rest_" << i << "\n";
+    o << "property float opacity\n";
+    for (int i = 0; i < 3; i++) o << "property float scale_" << i << "\n";
+    for (int i = 0; i < 4; i++) o << "property float rot_" << i << "\n";
+    o << "end_header\n";
+    // one row per Gaussian; assembled once instead of seven small writes per point
+    auto rows = torch::cat({meansCpu, torch::zeros({numPoints, 3}), dcCpu, restCpu, opacCpu.view({numPoints, 1}), scalesCpu, quatsCpu}, 1)
+                    .contiguous();
+    o.write(reinterpret_cast<const char*>(rows.data_ptr<float>()), (std::streamsize)rows.nbytes());
+}
+
+void RawGaussianParams::saveTensor(const std::string& filename) const {
+    torch::serialize::OutputArchive archive;
+    static const char* names[NUM] = {"means", "scales", "quats", "featuresDc", "featuresRest", "opacities"};
+    for (int k = 0; k < NUM; k++) archive.write(names[k], view(k).contiguous());
+    archive.write("exposure", exposure.defined() ? exposure : torch::eye(3, 4, f32(device_)).unsqueeze(0));
+    archive.save_to(filename);
+}
+
+void RawGaussianParams::loadTensor(const std::string& filename) {
+    torch::serialize::InputArchive archive;
+    archive.load_from(filename);
+    static const char* names[NUM] = {"means", "scales", "quats", "featuresDc", "featuresRest", "opacities"};
+    std::vector<torch::Tensor> t(NUM);
+    for (int k = 0; k < NUM; k++) { archive.read(names[k], t[k]); t[k] = t[k].to(device_); }
+    archive.read("exposure", exposure);
+    exposure = exposure.to(device_);
+    N_ = 0;
+    add(t);
 }

@@ -61,6 +61,11 @@ public:
     void add(const RawGaussianParams& other);            // raw_gs_param.cpp:123-145
     void add(const std::vector<torch::Tensor>& tensors);  // same, from loose tensors (NUM entries, reference order)
     void remove(const torch::Tensor& mask);               // raw_gs_param.cpp:148-157: mask = rows to delete
+    // raw_gs_param.cpp:159-254: 3DGS PLY (binary little endian, raw parameters, property order of the reference) and the
+    // libtorch archive with the reference's keys (means, scales, quats, featuresDc, featuresRest, opacities, exposure)
+    void savePly(const std::string& filename) const;
+    void saveTensor(const std::string& filename) const;
+    void loadTensor(const std::string& filename);
     void toGPU() {}                                        // buffers always live on the device
     void requireGrad(bool) {}
 

@@ -77,3 +77,33 @@ def test_cpp_host_layer_builds_loads_and_mirrors_the_reference_surface():
     c2w[:3, 3] = torch.tensor([0.3, -0.2, 1.5])
     c2w[:3, :3] = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
     assert torch.allclose(h.poseInv(c2w) @ c2w, torch.eye(4), atol=1e-6)
+
+
+def test_gaussian_ply_format_is_the_reference_layout(tmp_path):
+    """3DGS PLY of RawGaussianParams::savePly (raw_gs_param.cpp:159-217): header text, property order (f_rest channel-major),
+    row size, raw parameters; host code only."""
+    import numpy as np
+    from gps_slam_amd.gs_model import gaussian_ply_properties, read_gaussian_ply, write_gaussian_ply
+    rng = np.random.default_rng(0)
+    n, K = 7, 16
+    t = dict(means=rng.normal(size=(n, 3)), scales=rng.normal(size=(n, 3)), quats=rng.normal(size=(n, 4)),
+             featuresDc=rng.normal(size=(n, 3)), featuresRest=rng.normal(size=(n, K - 1, 3)), opacities=rng.normal(size=(n, 1)))
+    t = {k: v.astype(np.float32) for k, v in t.items()}
+    path = str(tmp_path / "g.ply")
+    write_gaussian_ply(path, t["means"], t["scales"], t["quats"], t["featuresDc"], t["featuresRest"], t["opacities"])
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n")
+    lines = head.decode().split("\n")
+    props = gaussian_ply_properties(3, 45)
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 7"]
+    assert lines[3:-1] == ["property float " + p for p in props] and len(props) == 62
+    assert props[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] and props[9] == "f_rest_0"
+    assert props[54:] == ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    rows = np.frombuffer(body, "<f4").reshape(n, 62)
+    assert np.array_equal(rows[:, :3], t["means"]) and not rows[:, 3:6].any()
+    # f_rest_j for j < 15 is colour channel 0 of SH coefficient j + 1 (transpose(1, 2) before the flatten)
+    assert np.array_equal(rows[:, 9:24], t["featuresRest"][:, :, 0]) and np.array_equal(rows[:, 24:39], t["featuresRest"][:, :, 1])
+    assert np.array_equal(rows[:, 54], t["opacities"][:, 0]) and np.array_equal(rows[:, 58:], t["quats"])
+    back = read_gaussian_ply(path)
+    for k in t:
+        assert np.array_equal(back[k], t[k]), k

@@ -367,3 +367,33 @@ def test_cpp_engine_mesh_and_state_files_equal_python_host(tmp_path):
     tri_2, counts_2 = eng_2.MeshScene(1 << 21)
     assert torch.equal(counts_c, counts_2) and torch.equal(tri_c[:n_tri], tri_2[:n_tri])
     assert torch.equal(eng_2.counters()[:2], eng_c.counters()[:2])
+
+
+def test_gaussian_model_files_cpp_and_python_hosts(tmp_path):
+    """RawGaussianParams::savePly / saveTensor / loadTensor (raw_gs_param.cpp:159-254): the C++ host and the Python mirror write
+    the same PLY bytes, the archive round-trips and is readable by torch.jit.load under the reference's keys."""
+    h = _host()
+    from gps_slam_amd.gs_model import RawGaussianParams, read_gaussian_ply
+    tensors, *_ = _scene(N=3000)
+    m = _cpp_model(h, tensors)
+    p = m.getGaussianParms()
+    p.savePly(str(tmp_path / "c.ply"))
+    pp = RawGaussianParams(device=DEV, capacity=4096)
+    pp.add(dict(zip(RawGaussianParams.NAMES, tensors)))
+    pp.savePly(str(tmp_path / "p.ply"))
+    assert open(tmp_path / "c.ply", "rb").read() == open(tmp_path / "p.ply", "rb").read()
+    back = read_gaussian_ply(str(tmp_path / "c.ply"))
+    for name, t in zip(RawGaussianParams.NAMES, tensors):
+        assert np.array_equal(back[name].reshape(t.shape), t.cpu().numpy()), name
+    p.saveTensor(str(tmp_path / "model.pt"))
+    arch = torch.jit.load(str(tmp_path / "model.pt"), map_location="cpu")
+    keys = {k for k, _ in arch.named_parameters()} | {k for k, _ in arch.named_buffers()} | set(dir(arch))
+    for k in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities", "exposure"):
+        assert k in keys, k
+    m2 = h.SLAMGaussianModel()
+    m2.loadConfig(dict(capacity=1 << 16))
+    m2.getGaussianParms().loadTensor(str(tmp_path / "model.pt"))
+    p2 = m2.getGaussianParms()
+    assert p2.getGaussianNum() == 3000
+    for a, b in zip((p2.getMeans(), p2.getScales(), p2.getQuats(), p2.getFeaturesDc(), p2.getFeaturesRest(), p2.getOpacities()), tensors):
+        assert torch.equal(a, b)
