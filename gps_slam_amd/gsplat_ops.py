@@ -346,3 +346,34 @@ def rasterize_to_pixels_bwd(means2d, conics, colors, opacities, backgrounds, wid
                                  _ptr(v_abs), _ptr(v_means2d), _ptr(v_conics), _ptr(v_colors), _ptr(v_opac), _stream()),
           "gps_raster_raw_bwd")
     return v_abs, v_means2d, v_conics, v_colors, v_opac
+
+
+# ----------------------------------------------------------------------------- fused SSIM
+def fusedssim(C1, C2, img1, img2, train=True, channels_last=False):
+    """gsplat fusedssim (ssim.cu:385-421).  img [B,CH,H,W] (or [B,H,W,CH] with channels_last) -> ssim_map, dm_dmu1,
+    dm_dsigma1_sq, dm_dsigma12 (the three are None when not training), all in the images' layout."""
+    img1, img2 = _f32c(img1), _f32c(img2)
+    assert img1.dim() == 4 and img1.shape == img2.shape
+    if channels_last:
+        B, H, W, CH = img1.shape
+    else:
+        B, CH, H, W = img1.shape
+    m = torch.empty_like(img1)
+    d1, d2, d3 = (torch.empty_like(img1) for _ in range(3)) if train else (None, None, None)
+    check(lib.gps_ssim_fwd(B, CH, H, W, int(channels_last), C1, C2, _ptr(img1), _ptr(img2), _ptr(m), _ptr(d1), _ptr(d2), _ptr(d3),
+                           _stream()), "gps_ssim_fwd")
+    return m, d1, d2, d3
+
+
+def fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, channels_last=False):
+    """gsplat fusedssim_backward (ssim.cu:423-460) -> dL_dimg1"""
+    img1, img2, dL_dmap = _f32c(img1), _f32c(img2), _f32c(dL_dmap)
+    if channels_last:
+        B, H, W, CH = img1.shape
+    else:
+        B, CH, H, W = img1.shape
+    g = torch.empty_like(img1)
+    check(lib.gps_ssim_bwd(B, CH, H, W, int(channels_last), _ptr(img1), _ptr(img2), _ptr(dL_dmap), _ptr(dm_dmu1), _ptr(dm_dsigma1_sq),
+                           _ptr(dm_dsigma12), _ptr(g), _stream()), "gps_ssim_bwd")
+    return g
+

@@ -4,6 +4,7 @@ Same class / function names, argument order and tensor shapes as the reference's
 classes; forward/backward call the C-ABI launchers in gsplat_ops.py.  (The optimisation loop itself uses the fused
 gps_splat_train_step; these classes are the drop-in surface and what the end-to-end gradient test differentiates.)
 """
+import numpy as np
 import torch
 
 from . import gsplat_ops as ops
@@ -187,3 +188,60 @@ def raw_forward(params, cam_dev, width, height, sh_degree=3, tile_size=16, eps2d
     rgb, raw_depth = rc[..., :3], rc[..., 3:]
     depth = raw_depth / ra.clamp(1e-10)
     return dict(rgb=rgb[0], depth=depth[0], alpha=ra[0], radiis=radii[0], means2d=means2d)
+
+
+# ----------------------------------------------------------------------------- fused SSIM
+class FusedSSIMMap(torch.autograd.Function):
+    """gsplat_wapper.hpp:622-677: apply(C1, C2, img1[B,CH,H,W], img2, padding, train) -> ssim_map; padding == "valid" crops 5
+    pixels per side.  Gradient w.r.t. img1 only, like the reference.  Permuted views of [H,W,CH] images (what
+    raw_gs_model.cpp:390-395 passes) are read in place through the channels-last layout of the kernels -- no copy."""
+
+    @staticmethod
+    def forward(ctx, C1, C2, img1, img2, padding="same", train=True):
+        cl = _is_channels_last_view(img1) and _is_channels_last_view(img2)
+        a, b = (img1.permute(0, 2, 3, 1), img2.permute(0, 2, 3, 1)) if cl else (img1.contiguous(), img2.contiguous())
+        m, d1, d2, d3 = ops.fusedssim(C1, C2, a, b, train=train, channels_last=cl)
+        ctx.save_for_backward(a, b, d1, d2, d3)
+        ctx.cfg = (C1, C2, padding, cl)
+        if cl:
+            m = m.permute(0, 3, 1, 2)
+        return m[:, :, 5:-5, 5:-5] if padding == "valid" else m
+
+    @staticmethod
+    def backward(ctx, dL_dmap):
+        a, b, d1, d2, d3 = ctx.saved_tensors
+        C1, C2, padding, cl = ctx.cfg
+        if padding == "valid":
+            B, CH = dL_dmap.shape[:2]
+            full = torch.zeros((B, CH, dL_dmap.shape[2] + 10, dL_dmap.shape[3] + 10), dtype=dL_dmap.dtype, device=dL_dmap.device)
+            full[:, :, 5:-5, 5:-5] = dL_dmap
+            dL_dmap = full
+        if cl:
+            dL_dmap = dL_dmap.permute(0, 2, 3, 1)
+        g = ops.fusedssim_backward(C1, C2, a, b, dL_dmap.contiguous(), d1, d2, d3, channels_last=cl)
+        if cl:
+            g = g.permute(0, 3, 1, 2)
+        return None, None, g, None, None, None
+
+
+def _is_channels_last_view(t):
+    """[B,CH,H,W] tensor whose memory is a contiguous [B,H,W,CH] array (e.g. rgb.permute(2,0,1).unsqueeze(0))"""
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous() and not t.is_contiguous()
+
+
+def compute_loss(render_res, gt_rgb, gt_depth=None, has_depth=False, ssim_weight=0.0, depth_weight=0.0, mask=None):
+    """RawGaussianModel::computeLoss (raw_gs_model.cpp:369-417) -> {"total", "rgb"[, "depth"]}"""
+    rgb = render_res["rgb"]
+    l1 = (gt_rgb[mask] - rgb[mask]).abs().mean() if mask is not None else (gt_rgb - rgb).abs().mean()
+    if ssim_weight > 0:
+        C1, C2 = float(np.float32(0.01 * 0.01)), float(np.float32(0.03 * 0.03))
+        ssim = FusedSSIMMap.apply(C1, C2, rgb.permute(2, 0, 1).unsqueeze(0), gt_rgb.permute(2, 0, 1).unsqueeze(0), "valid", True)
+        rgb_loss = (1.0 - ssim_weight) * l1 + ssim_weight * (1.0 - ssim.mean())
+    else:
+        rgb_loss = l1
+    loss = dict(total=rgb_loss, rgb=rgb_loss)
+    if depth_weight > 0 and has_depth:
+        valid = (gt_depth > 0) & (render_res["depth"] > 0)
+        loss["depth"] = (gt_depth[valid] - render_res["depth"][valid]).abs().mean()
+        loss["total"] = loss["total"] + depth_weight * loss["depth"]
+    return loss

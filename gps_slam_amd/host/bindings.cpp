@@ -46,6 +46,9 @@ PYBIND11_MODULE(_host, m) {
               return RasterizeToPixels::apply(means2d, conics, colors, opacities, backgrounds, c10::nullopt, w, h, tile_size,
                                               isect_offsets, flatten_ids, absgrad);
           });
+    m.def("FusedSSIMMap", [](double C1, double C2, torch::Tensor img1, torch::Tensor img2, std::string padding, bool train) {
+        return FusedSSIMMap::apply(C1, C2, img1, img2, padding, train);
+    });
     m.def("isectTiles", &isectTiles, py::arg("means2d"), py::arg("radii"), py::arg("depths"), py::arg("tile_size"),
           py::arg("tile_width"), py::arg("tile_height"), py::arg("sort") = true);
     m.def("isectOffsetEncode", &isectOffsetEncode);
@@ -171,8 +174,9 @@ PYBIND11_MODULE(_host, m) {
         .def(py::init<ITMBasicEngine*, SLAMGaussianModel*, uint64_t, bool>(), py::arg("engine"), py::arg("model"),
              py::arg("seed") = 1234, py::arg("use_gt_pose") = true, py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
         .def("loadConfig", [](SLAMPipeline& p, const py::dict& d) { p.loadConfig(config_from_dict(d)); })
-        .def("processFrame", &SLAMPipeline::processFrame)
-        .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams)
+        // the optimise loop may run the autograd engine (losses beyond L1): it must not hold the GIL
+        .def("processFrame", &SLAMPipeline::processFrame, py::call_guard<py::gil_scoped_release>())
+        .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams, py::call_guard<py::gil_scoped_release>())
         .def("runRaycastByCam", &SLAMPipeline::runRaycastByCam, py::arg("cam"), py::arg("use_cam_depth") = true)
         .def("stats", [](SLAMPipeline& p) {
             py::dict d;

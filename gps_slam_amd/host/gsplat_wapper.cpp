@@ -220,6 +220,57 @@ tensor_list RasterizeToPixels::backward(AutogradContext* ctx, tensor_list g) {
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------ fused SSIM
+namespace {
+bool channels_last_view(const torch::Tensor& t) {  // [B,CH,H,W] whose memory is a contiguous [B,H,W,CH] array
+    return t.dim() == 4 && !t.is_contiguous() && t.permute({0, 2, 3, 1}).is_contiguous();
+}
+}  // namespace
+
+torch::Tensor FusedSSIMMap::forward(AutogradContext* ctx, double C1, double C2, torch::Tensor img1, torch::Tensor img2,
+                                    std::string padding, bool train) {
+    TORCH_CHECK(img1.dim() == 4 && img1.sizes() == img2.sizes(), "img1 / img2: [B,CH,H,W]");
+    const bool cl = channels_last_view(img1) && channels_last_view(img2);
+    auto a = cl ? img1.permute({0, 2, 3, 1}) : contig_f32(img1, "img1");
+    auto b = cl ? img2.permute({0, 2, 3, 1}) : contig_f32(img2, "img2");
+    check_f32_dev(a, "img1"); check_f32_dev(b, "img2");
+    const int B = (int)img1.size(0), CH = (int)img1.size(1), H = (int)img1.size(2), W = (int)img1.size(3);
+    auto m = torch::empty_like(a);
+    torch::Tensor d1, d2, d3;
+    if (train) { d1 = torch::empty_like(a); d2 = torch::empty_like(a); d3 = torch::empty_like(a); }
+    check(gps_ssim_fwd(B, CH, H, W, cl ? 1 : 0, (float)C1, (float)C2, fptr(a), fptr(b), fptr(m), train ? fptr(d1) : nullptr,
+                       train ? fptr(d2) : nullptr, train ? fptr(d3) : nullptr, current_stream()), "gps_ssim_fwd");
+    if (train) ctx->save_for_backward({a, b, d1, d2, d3});
+    ctx->saved_data["padding"] = padding;
+    ctx->saved_data["cl"] = cl;
+    if (cl) m = m.permute({0, 3, 1, 2});
+    if (padding == "valid") m = m.slice(2, 5, -5).slice(3, 5, -5);
+    return m;
+}
+
+tensor_list FusedSSIMMap::backward(AutogradContext* ctx, tensor_list g) {
+    auto s = ctx->get_saved_variables();
+    TORCH_CHECK(s.size() == 5, "FusedSSIMMap: forward ran with train = false");
+    const torch::Tensor &a = s[0], &b = s[1];
+    const bool cl = ctx->saved_data["cl"].toBool();
+    const std::string padding = ctx->saved_data["padding"].toStringRef();
+    const int B = (int)a.size(0), CH = (int)(cl ? a.size(3) : a.size(1)), H = (int)(cl ? a.size(1) : a.size(2)),
+              W = (int)(cl ? a.size(2) : a.size(3));
+    auto dL = g[0];
+    if (padding == "valid") {
+        auto full = torch::zeros({B, CH, H, W}, a.options());
+        full.slice(2, 5, -5).slice(3, 5, -5).copy_(dL);
+        dL = full;
+    }
+    if (cl) dL = dL.permute({0, 2, 3, 1});
+    dL = dL.contiguous();
+    auto grad = torch::empty_like(a);
+    check(gps_ssim_bwd(B, CH, H, W, cl ? 1 : 0, fptr(a), fptr(b), fptr(dL), fptr(s[2]), fptr(s[3]), fptr(s[4]), fptr(grad),
+                       current_stream()), "gps_ssim_bwd");
+    if (cl) grad = grad.permute({0, 3, 1, 2});
+    return {torch::Tensor(), torch::Tensor(), grad, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+}
+
 // ------------------------------------------------------------------------------------------------ binning
 variable_list isectTilesNoDepth(torch::Tensor means2d, torch::Tensor radii, torch::Tensor depths, int tile_size,
                                 int tile_width, int tile_height, bool sort) {

@@ -58,6 +58,16 @@ struct RasterizeToPixels : public torch::autograd::Function<RasterizeToPixels> {
                                                  torch::autograd::tensor_list grad_outputs);
 };
 
+// gsplat_wapper.hpp:622-677: apply(C1, C2, img1[B,CH,H,W], img2, padding, train) -> ssim_map ("valid" crops 5 px per side);
+// gradient w.r.t. img1 only.  Permuted views of [H,W,CH] images (raw_gs_model.cpp:390-395) are read in place through the
+// kernels' channels-last layout instead of being copied to planar form.
+struct FusedSSIMMap : public torch::autograd::Function<FusedSSIMMap> {
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, double C1, double C2, torch::Tensor img1,
+                                 torch::Tensor img2, std::string padding, bool train);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
 using torch::autograd::variable_list;
 
 // gsplat_wapper.cpp:55-85: -> {tiles_per_gauss[1,N], isect_ids i64[I], flatten_ids i32[I], group_gs_ids i32[G],

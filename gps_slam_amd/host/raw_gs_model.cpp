@@ -261,13 +261,36 @@ TensorDict RawGaussianModel::gesForward(const Camera& cam, const torch::Tensor& 
 }
 
 TensorDict RawGaussianModel::computeLoss(TensorDict& render_res, const Camera& cam, const Config& w, const torch::Tensor& mask) {
-    TORCH_CHECK(w.get("ssim_weight", 0.0) == 0.0 && w.get("depth_weight", 0.0) == 0.0,
-                "only the L1 term is on the hot path (every shipped config sets ssim / depth weights to 0)");
-    TORCH_CHECK(!mask.defined(), "loss masks are not used by the SLAM loop");
+    // raw_gs_model.cpp:369-417: L1 (+ SSIM with the fused kernel, + masked depth L1) -> {"total", "rgb"[, "depth"]};
+    // "loss" / "l1_loss" are kept as aliases for callers of the first version of this host layer
+    auto gt_rgb = cam.image.to(device);
+    const auto& rendered_rgb = render_res.at("rgb");
+    auto l1 = mask.defined() ? torch::mean(torch::abs(gt_rgb.masked_select(mask) - rendered_rgb.masked_select(mask)))
+                             : torch::mean(torch::abs(gt_rgb - rendered_rgb));  // tensor_math.cpp:41-44
+    torch::Tensor rgb_loss;
+    const float ssimWeight = (float)w.get("ssim_weight", 0.0);
+    if (ssimWeight > 0) {
+        const float C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+        auto ssimLoss = 1.0f - FusedSSIMMap::apply((double)C1, (double)C2, rendered_rgb.permute({2, 0, 1}).unsqueeze(0),
+                                                   gt_rgb.permute({2, 0, 1}).unsqueeze(0), std::string("valid"), true).mean();
+        rgb_loss = (1.0f - ssimWeight) * l1 + ssimWeight * ssimLoss;
+    } else {
+        rgb_loss = l1 * w.get("l1_weight", 1.0);
+    }
     TensorDict out;
-    auto l1 = torch::mean(torch::abs(cam.image - render_res.at("rgb")));  // tensor_math.cpp:41-44
+    out["total"] = rgb_loss;
+    out["rgb"] = rgb_loss;
+    const float depth_weight = (float)w.get("depth_weight", 0.0);
+    if (depth_weight > 0 && cam.has_depth) {
+        auto gt_depth = cam.depth.to(device);
+        const auto& rendered_depth = render_res.at("depth");
+        auto valid = (gt_depth > 0) & (rendered_depth > 0);
+        auto depthLoss = torch::mean(torch::abs(gt_depth.masked_select(valid) - rendered_depth.masked_select(valid)));
+        out["depth"] = depthLoss;
+        out["total"] = out["total"] + depth_weight * depthLoss;
+    }
     out["l1_loss"] = l1;
-    out["loss"] = l1 * w.get("l1_weight", 1.0);
+    out["loss"] = out["total"];
     return out;
 }
 

@@ -39,6 +39,8 @@ void SLAMPipeline::loadConfig(const Config& c) {
     low_opac_thres = (float)c.get("low_opac_thres", low_opac_thres);
     scene_scale = (float)c.get("scene_scale", scene_scale);
     work_mode = c.gets("work_mode", work_mode);
+    ssim_weight = (float)c.get("ssim_weight", ssim_weight);    // LOSS section of the configs (office0.yaml:37-39)
+    depth_weight = (float)c.get("depth_weight", depth_weight);
 }
 
 // ------------------------------------------------------------------ raycast -> tensors (runRaycastByCam :362-415)
@@ -148,7 +150,18 @@ void SLAMPipeline::localOptimize() {
         auto pick = loader.getNext();
         const Camera& cam = *pick.second;
         TensorDict& rc = opt_raycast_list[pick.first];
-        model->trainStep(cam, rc.at("depth_map"), rc.at("color_map"), rc.at("depth_map_clamped"));
+        if (ssim_weight > 0 || depth_weight > 0) {
+            // losses beyond L1: the reference's own sequence (slam_pipeline.cpp:247-254) through the autograd route
+            Config wc;
+            wc.num["ssim_weight"] = ssim_weight; wc.num["depth_weight"] = depth_weight;
+            auto res = model->forward(cam, rc.at("depth_map"), rc.at("color_map"));
+            auto loss = model->computeLoss(res, cam, wc);
+            loss.at("total").backward();
+            model->optimizersStep();
+            model->optimizersZeroGrad();
+        } else {
+            model->trainStep(cam, rc.at("depth_map"), rc.at("color_map"), rc.at("depth_map_clamped"));
+        }
         stats.opt_iters++;
     }
 }

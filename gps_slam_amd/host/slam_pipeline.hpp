@@ -89,6 +89,7 @@ public:
     float depth_vis_max = 5.0f, depth_vis_min = 0.0f, alpha_vis_max = 5.0f;
     float large_scale_thres = 0.1f, small_scale_thres = 0.003f, low_opac_thres = 0.005f;
     float scene_scale = 1.1f * 3.0f;
+    float ssim_weight = 0.0f, depth_weight = 0.0f;  // both 0 in every shipped config -> the fused L1 trainStep
 
     struct Stats { int64_t frames = 0, opt_iters = 0, raycasts = 0, added = 0, pruned = 0; } stats;
 

@@ -136,6 +136,25 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
                           float *v_opacities, int accumulate, gps_stream stream);
 
 /* ------------------------------------------------------------------ */
+/* Splat: fused SSIM map (the `ssim_weight > 0` loss option)            */
+/* ------------------------------------------------------------------ */
+
+/* replaces fusedssim (gsplat/rasterizer/ssim.cu:385-421 launcher, :209-303 kernel): per-channel SSIM map of img1 vs img2
+ * with the 11-tap Gaussian window (sigma 1.5), zero padding.  C1 = 0.01^2, C2 = 0.03^2 in raw_gs_model.cpp:388-389.
+ * channels_last = 0: [B,CH,H,W] planar, the reference's layout; 1: [B,H,W,CH] interleaved (how renders and camera images are
+ * held -- no permute copy).  All maps use the same layout as the images.  dm_* (all three or none, NULL when not
+ * training) receive the partial derivatives the backward needs. */
+GPS_API int gps_ssim_fwd(int B, int CH, int H, int W, int channels_last, float C1, float C2, const float *img1,
+                         const float *img2, float *ssim_map, float *dm_dmu1, float *dm_dsigma1_sq, float *dm_dsigma12,
+                         gps_stream stream);
+
+/* replaces fusedssim_backward (ssim.cu:423-460, :305-383): dL_dimg1 from dL_dmap and the saved maps (every element is
+ * written; the reference's `padding == "valid"` crop is the caller's zero border in dL_dmap, gsplat_wapper.hpp:664-669). */
+GPS_API int gps_ssim_bwd(int B, int CH, int H, int W, int channels_last, const float *img1, const float *img2,
+                         const float *dL_dmap, const float *dm_dmu1, const float *dm_dsigma1_sq, const float *dm_dsigma12,
+                         float *dL_dimg1, gps_stream stream);
+
+/* ------------------------------------------------------------------ */
 /* Splat: `raw` render method (front-to-back alpha compositing)         */
 /* ------------------------------------------------------------------ */
 

@@ -813,3 +813,79 @@ ORC_API void orc_raster_raw_bwd(int W, int H, int tile_size, int tw, int th, int
         }
     }
 }
+
+/* ---------------- fused SSIM: gsplat/rasterizer/ssim.cu:35-383 ----------------
+ * Planar [B,CH,H,W] images like the reference.  The reference's five (three) separable convolutions per channel go through
+ * LDS tiles; per output pixel that is: x-pass over the 11 taps for each of the 11 rows of the window, then the y-pass over
+ * those 11 row sums, zero padding outside the image, `val += G_k * p` in tap order 0..10 (nvcc contracts it to an fma;
+ * restated with fmaf so that the tap sums round the same way). */
+static const float SSIM_G[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f, 0.10936068743467331f,
+                                 0.21300552785396576f,  0.26601171493530273f,   0.21300552785396576f,  0.10936068743467331f,
+                                 0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
+
+static float ssim_pix(const float *img, int y, int x, int H, int W) { /* get_pix_value, ssim.cu:35-45 */
+    return (x >= W || y >= H || x < 0 || y < 0) ? 0.0f : img[(size_t)y * W + x];
+}
+
+/* separable window at (y, x) of f(p1, p2): mode 0 p1, 1 p1*p1, 2 p2, 3 p2*p2, 4 p1*p2 (the product is rounded first, like
+ * do_sq / multiply_shared_mem) */
+static float ssim_window(const float *i1, const float *i2, int mode, int y, int x, int H, int W) {
+    float col[11];
+    for (int r = 0; r < 11; r++) {
+        float val = 0.0f;
+        for (int k = 0; k < 11; k++) {
+            const float p = ssim_pix(i1, y + r - 5, x + k - 5, H, W), q = i2 ? ssim_pix(i2, y + r - 5, x + k - 5, H, W) : 0.0f;
+            const float v = mode == 0 ? p : mode == 1 ? p * p : mode == 2 ? q : mode == 3 ? q * q : p * q;
+            val = fmaf(SSIM_G[k], v, val);
+        }
+        col[r] = val;
+    }
+    float val = 0.0f;
+    for (int r = 0; r < 11; r++) val = fmaf(SSIM_G[r], col[r], val);
+    return val;
+}
+
+ORC_API void orc_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const float *img1, const float *img2, float *ssim_map,
+                          float *dm_dmu1, float *dm_dsigma1_sq, float *dm_dsigma12 /* all three or NULL */) {
+    for (int bc = 0; bc < B * CH; bc++) {
+        const float *a = img1 + (size_t)bc * H * W, *b = img2 + (size_t)bc * H * W;
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+            const float mu1 = ssim_window(a, b, 0, y, x, H, W);
+            const float sigma1_sq = ssim_window(a, b, 1, y, x, H, W) - mu1 * mu1;
+            const float mu2 = ssim_window(a, b, 2, y, x, H, W);
+            const float sigma2_sq = ssim_window(a, b, 3, y, x, H, W) - mu2 * mu2;
+            const float sigma12 = ssim_window(a, b, 4, y, x, H, W) - mu1 * mu2;
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+            const float C = 2.0f * mu1_mu2 + C1, D = 2.0f * sigma12 + C2, A = mu1_sq + mu2_sq + C1, Bq = sigma1_sq + sigma2_sq + C2;
+            const size_t o = (size_t)bc * H * W + (size_t)y * W + x;
+            ssim_map[o] = (C * D) / (A * Bq);
+            if (dm_dmu1) {
+                dm_dmu1[o] = (mu2 * 2.0f * D) / (A * Bq) - (mu2 * 2.0f * C) / (A * Bq) - (mu1 * 2.0f * C * D) / (A * A * Bq) +
+                             (mu1 * 2.0f * C * D) / (A * Bq * Bq);
+                dm_dsigma1_sq[o] = (-C * D) / (A * Bq * Bq);
+                dm_dsigma12[o] = (2 * C) / (A * Bq);
+            }
+        }
+    }
+}
+
+ORC_API void orc_ssim_bwd(int B, int CH, int H, int W, const float *img1, const float *img2, const float *dL_dmap,
+                          const float *dm_dmu1, const float *dm_dsigma1_sq, const float *dm_dsigma12, float *dL_dimg1) {
+    const size_t P = (size_t)H * W;
+    float *prod = (float *)malloc(P * sizeof(float));
+    for (int bc = 0; bc < B * CH; bc++) {
+        const float *g = dL_dmap + bc * P, *maps[3] = {dm_dmu1 + bc * P, dm_dsigma1_sq + bc * P, dm_dsigma12 + bc * P};
+        float *out = dL_dimg1 + bc * P;
+        for (size_t i = 0; i < P; i++) out[i] = 0.0f;
+        for (int m = 0; m < 3; m++) {
+            for (size_t i = 0; i < P; i++) prod[i] = maps[m][i] * g[i]; /* multiply_shared_mem(buf2, buf1) */
+            for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+                const size_t i = (size_t)y * W + x;
+                const float conv = ssim_window(prod, NULL, 0, y, x, H, W);
+                const float tmp = m == 0 ? conv : m == 1 ? img1[bc * P + i] * 2.0f * conv : img2[bc * P + i] * conv;
+                out[i] += tmp;
+            }
+        }
+    }
+    free(prod);
+}

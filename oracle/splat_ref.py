@@ -209,3 +209,24 @@ def raster_raw_bwd(means2d, conics, colors, opacities, W, H, tile_size, offsets,
                               _p(bg) if bg is not None else None, _p(offsets), _p(flatten_ids), _p(ra), _p(last), _p(v_rc),
                               _p(v_ra), _p(v_abs) if absgrad else None, _p(v_m), _p(v_c), _p(v_col), _p(v_o))
     return (v_m, v_c, v_col, v_o, v_abs) if absgrad else (v_m, v_c, v_col, v_o)
+
+
+# ----------------------------------------------------------------------------- fused SSIM (ssim.cu)
+def ssim_fwd(img1, img2, C1=0.01 ** 2, C2=0.03 ** 2, train=True):
+    """img [B,CH,H,W] -> ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 (None x3 if not train)"""
+    img1, img2 = _f32(img1), _f32(img2)
+    B, CH, H, W = img1.shape
+    m = np.zeros_like(img1)
+    d = [np.zeros_like(img1) for _ in range(3)] if train else [None] * 3
+    _lib().orc_ssim_fwd(C.c_int(B), C.c_int(CH), C.c_int(H), C.c_int(W), C.c_float(C1), C.c_float(C2), _p(img1), _p(img2), _p(m),
+                        *[_p(x) if x is not None else None for x in d])
+    return (m, *d)
+
+
+def ssim_bwd(img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12):
+    img1, img2, dL_dmap = _f32(img1), _f32(img2), _f32(dL_dmap)
+    B, CH, H, W = img1.shape
+    g = np.zeros_like(img1)
+    _lib().orc_ssim_bwd(C.c_int(B), C.c_int(CH), C.c_int(H), C.c_int(W), _p(img1), _p(img2), _p(dL_dmap), _p(_f32(dm_dmu1)),
+                        _p(_f32(dm_dsigma1_sq)), _p(_f32(dm_dsigma12)), _p(g))
+    return g

@@ -386,3 +386,45 @@ def test_raw_forward_and_backward_match_dense_compositing(with_bg):
         bad = np.abs(got - ref) > (5e-3 * np.abs(ref) + 2e-3 * scale)
         assert bad.mean() < 0.02, (name, bad.mean(), scale)
     assert np.all(out[4] >= np.abs(out[0]) - 1e-6)  # absgrad dominates |grad|
+
+
+# ----------------------------------------------------------------------------- fused SSIM (ssim.cu) vs float64 conv2d + autograd
+def _ssim_torch64(img1, img2, C1, C2):
+    import torch.nn.functional as F
+    g = torch.tensor([0.001028380123898387, 0.0075987582094967365, 0.036000773310661316, 0.10936068743467331, 0.21300552785396576,
+                      0.26601171493530273, 0.21300552785396576, 0.10936068743467331, 0.036000773310661316, 0.0075987582094967365,
+                      0.001028380123898387], dtype=torch.float64)
+    CH = img1.shape[1]
+    win = (g[:, None] * g[None, :]).expand(CH, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t, win, padding=5, groups=CH)
+    mu1, mu2 = conv(img1), conv(img2)
+    s1, s2, s12 = conv(img1 * img1) - mu1 * mu1, conv(img2 * img2) - mu2 * mu2, conv(img1 * img2) - mu1 * mu2
+    return ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))
+
+
+def test_ssim_restatement_matches_float64_conv_and_autograd():
+    """orc_ssim_fwd / orc_ssim_bwd vs the textbook definition (zero-padded 11x11 Gaussian window) in float64 with autograd,
+    for the full map and for the reference's `padding = "valid"` loss 1 - mean(map[5:-5, 5:-5]) (raw_gs_model.cpp:386-397)."""
+    rng = np.random.default_rng(2)
+    B, CH, Hs, Ws = 1, 3, 37, 50  # not multiples of any tile
+    img2 = rng.uniform(0, 1, (B, CH, Hs, Ws)).astype(np.float32)
+    img1 = np.clip(img2 + rng.normal(0, 0.15, img2.shape), 0, 1).astype(np.float32)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m, d1, d2, d3 = orc.ssim_fwd(img1, img2, C1, C2)
+    t1 = torch.tensor(img1, dtype=torch.float64, requires_grad=True)
+    ref = _ssim_torch64(t1, torch.tensor(img2, dtype=torch.float64), C1, C2)
+    np.testing.assert_allclose(m, ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    assert 0.05 < m.mean() < 0.95
+    loss = 1.0 - ref[:, :, 5:-5, 5:-5].mean()
+    loss.backward()
+    dL = np.zeros_like(img1)
+    dL[:, :, 5:-5, 5:-5] = -1.0 / (B * CH * (Hs - 10) * (Ws - 10))
+    g = orc.ssim_bwd(img1, img2, dL, d1, d2, d3)
+    want = t1.grad.numpy()
+    np.testing.assert_allclose(g, want, rtol=2e-3, atol=2e-4 * np.abs(want).max())
+    # not training: same map, no derivative maps
+    m2, n1, n2, n3 = orc.ssim_fwd(img1, img2, C1, C2, train=False)
+    assert n1 is None and np.array_equal(m, m2)
+    # identical images -> SSIM = 1 everywhere the window is inside; gradient of the map w.r.t. img1 vanishes there
+    m3, e1, e2, e3 = orc.ssim_fwd(img2, img2, C1, C2)
+    np.testing.assert_allclose(m3, 1.0, atol=1e-5)

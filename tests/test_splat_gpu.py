@@ -480,3 +480,60 @@ def test_hip_chain_matches_committed_splat_golden():
         got = N_(got).reshape(ref.shape)
         bad = np.abs(got - ref) > (2e-3 * np.abs(ref) + 5e-4 * np.abs(ref).max())
         assert bad.mean() < 2e-3, (name, bad.mean())
+
+
+@pytest.mark.parametrize("B,CH,H,W", [(1, 3, 37, 50), (2, 3, 64, 96), (1, 1, 33, 31)])
+def test_fused_ssim_fwd_bwd_vs_oracle_in_both_layouts(B, CH, H, W):
+    """gps_ssim_fwd / gps_ssim_bwd vs the restatement of ssim.cu (itself pinned against float64 conv2d + autograd): planar
+    (the reference's NCHW) and channels-last (HWC, read in place) give the same numbers."""
+    from gps_slam_amd import gsplat_ops as ops
+    from oracle import splat_ref as orc
+    rng = np.random.default_rng(B * 100 + H)
+    img2 = rng.uniform(0, 1, (B, CH, H, W)).astype(np.float32)
+    img1 = np.clip(img2 + rng.normal(0, 0.15, img2.shape), 0, 1).astype(np.float32)
+    C1, C2 = float(np.float32(0.01 * 0.01)), float(np.float32(0.03 * 0.03))
+    e_m, e1, e2, e3 = orc.ssim_fwd(img1, img2, C1, C2)
+    m, d1, d2, d3 = ops.fusedssim(C1, C2, T(img1), T(img2), train=True)
+    for got, ref, name in ((m, e_m, "map"), (d1, e1, "dm_dmu1"), (d2, e2, "dm_dsigma1_sq"), (d3, e3, "dm_dsigma12")):
+        np.testing.assert_allclose(N_(got), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=name)
+    dL = rng.normal(size=img1.shape).astype(np.float32)
+    e_g = orc.ssim_bwd(img1, img2, dL, e1, e2, e3)
+    g = ops.fusedssim_backward(C1, C2, T(img1), T(img2), T(dL), T(e1), T(e2), T(e3))
+    _grad_close(N_(g), e_g, "dL_dimg1", rtol=1e-3, atol_rel=1e-4)
+    # channels-last: bit-identical values at transposed positions
+    cl = lambda a: T(np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1))))
+    m_cl, c1, c2, c3 = ops.fusedssim(C1, C2, cl(img1), cl(img2), train=True, channels_last=True)
+    assert torch.equal(m_cl.permute(0, 3, 1, 2), m) and torch.equal(c2.permute(0, 3, 1, 2), d2)
+    g_cl = ops.fusedssim_backward(C1, C2, cl(img1), cl(img2), cl(dL), cl(e1), cl(e2), cl(e3), channels_last=True)
+    assert torch.equal(g_cl.permute(0, 3, 1, 2), g)
+    # not training: the map only
+    m2, n1, _, _ = ops.fusedssim(C1, C2, T(img1), T(img2), train=False)
+    assert n1 is None and torch.equal(m2, m)
+
+
+def test_fused_ssim_loss_autograd_matches_conv2d_autograd_at_full_size():
+    """FusedSSIMMap through compute_loss (raw_gs_model.cpp:369-417, ssim_weight 0.2, padding "valid") at 640x480 vs the same loss
+    written with torch conv2d in float64 and differentiated by autograd."""
+    import torch.nn.functional as F
+    from gps_slam_amd import gsplat_wapper as gw
+    H, W = 480, 640
+    gen = torch.Generator().manual_seed(4)
+    gt = torch.rand((H, W, 3), generator=gen).to(_dev())
+    rgb = (gt + 0.1 * torch.randn((H, W, 3), generator=gen).to(_dev())).clamp(0, 1).requires_grad_(True)
+    loss = gw.compute_loss(dict(rgb=rgb), gt, ssim_weight=0.2)
+    loss["total"].backward()
+    g = torch.tensor([0.001028380123898387, 0.0075987582094967365, 0.036000773310661316, 0.10936068743467331, 0.21300552785396576,
+                      0.26601171493530273, 0.21300552785396576, 0.10936068743467331, 0.036000773310661316, 0.0075987582094967365,
+                      0.001028380123898387], dtype=torch.float64, device=_dev())
+    win = (g[:, None] * g[None, :]).expand(3, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t, win, padding=5, groups=3)
+    r64 = rgb.detach().double().requires_grad_(True)
+    a, b = r64.permute(2, 0, 1)[None], gt.double().permute(2, 0, 1)[None]
+    mu1, mu2 = conv(a), conv(b)
+    s1, s2, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))
+    want = 0.8 * (b - a).abs().mean() + 0.2 * (1.0 - ssim[:, :, 5:-5, 5:-5].mean())
+    want.backward()
+    torch.testing.assert_close(loss["total"].double(), want, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rgb.grad.double(), r64.grad, rtol=2e-3, atol=2e-4 * float(r64.grad.abs().max()))
