@@ -162,9 +162,12 @@ __device__ __forceinline__ void final_sum(const float* __restrict__ partial, int
 }
 
 __global__ __launch_bounds__(256) void track_sum_kernel(const float* __restrict__ partial, int rows, float* __restrict__ result,
-                                                       volatile float* mailbox, int seq) {
+                                                       volatile float* mailbox, int seq, const int* __restrict__ valid_count) {
     final_sum(partial, rows, result, mailbox);
     if (mailbox) {
+        // the frame's valid-pixel count (count_valid_kernel finished long ago on this stream) rides along, so that the pose
+        // quality score at the end of the frame needs no read-back of its own
+        if (threadIdx.x == 0) mailbox[GH_SLOTS + 1] = __int_as_float(*valid_count);
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) { mailbox[GH_SLOTS] = __int_as_float(seq); __threadfence_system(); }
@@ -357,6 +360,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     for (int k = 0; k < 16; k++) ts->diag[k] = 0;
     const int use_weights = ts->frames_processed >= 100;
     static int mail_seq = 0;  // sequence numbers are process-wide so a stale mailbox value can never match
+    int mailbox_iterations = 0;
 
     for (int level = c->n_levels - 1; level >= 0; level--) {
         const int it = c->iter_type[level];
@@ -384,7 +388,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             if (it == TRK_ROTATION) track_gh_kernel<TRK_ROTATION><<<n_wgs, 256, 0, st>>>(a, w.partial);
             else if (it == TRK_TRANSLATION) track_gh_kernel<TRK_TRANSLATION><<<n_wgs, 256, 0, st>>>(a, w.partial);
             else track_gh_kernel<TRK_BOTH><<<n_wgs, 256, 0, st>>>(a, w.partial);
-            track_sum_kernel<<<1, 256, 0, st>>>(w.partial, n_wgs, w.result, mailbox, seq);
+            track_sum_kernel<<<1, 256, 0, st>>>(w.partial, n_wgs, w.result, mailbox, seq, w.count);
             GPS_LAUNCH_CHECK();
             float host[GH_SLOTS];
             if (mailbox) {
@@ -395,6 +399,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
                 }
                 if (!got && hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
                 for (int k = 0; k < GH_SLOTS; k++) host[k] = mailbox[k];
+                mailbox_iterations++;
             } else {
                 // the reference's GPU tracker reads its 32 accumulators back every iteration as well
                 if (hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
@@ -464,8 +469,12 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     // UpdatePoseQuality: the residual score (the SVM verdict only feeds failure modes that are off by default,
     // ITMLibSettings.cpp:42 behaviourOnFailure = FAILUREMODE_IGNORE)
     int n_max = 0;
-    if (hipMemcpyAsync(&n_max, w.count, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
-    if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+    if (ts->host_mailbox && mailbox_iterations > 0) {
+        n_max = float_bits(reinterpret_cast<volatile float*>(ts->host_mailbox)[GH_SLOTS + 1]);  // delivered with the last iteration
+    } else {
+        if (hipMemcpyAsync(&n_max, w.count, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+        if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+    }
     ts->diag[8] = (float)nvalid_depth_good; ts->diag[9] = f_depth_good;
     ts->diag[10] = n_max > 0 ? sqrtf(((float)nvalid_depth_good * f_depth_good + (float)(n_max - nvalid_depth_good) * c->space_thresh[0]) /
                                     (float)n_max) : 0.0f;
