@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-overlap", action="store_true", help="C++ host: run the keyframe map update to completion before the "
+                    "next frame (the reference's schedule) instead of overlapping it with tracking/fusion on a second stream")
     ap.add_argument("--gaussians", type=int, default=200000)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -150,6 +152,10 @@ def main():
         cmodel.loadConfig(dict(capacity=1 << 19, isect_capacity=8 << 20))
         cmodel.getGaussianParms().add([t.clone() for t in model.opt_gs_params.tensors()])
         cpipe = H_.SLAMPipeline(ceng, cmodel, scene_seed(rank), args.gt_pose)
+        # tracking / mapping overlap (host/slam_pipeline.hpp): the keyframe's map update runs on a second stream while the next
+        # frames are tracked and fused; same results as the sequential schedule.  flush() below closes the timed region, so every
+        # frame's work (incl. the deferred prune) is inside it.
+        cpipe.overlap_mapping = not args.no_overlap
         ccams = []
         for k in range(n_frames):
             c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k].astype(np.float32)))
@@ -159,6 +165,7 @@ def main():
         def run(lo, hi):
             for i in range(lo, hi):
                 cpipe.processFrame(i, ccams[i], rgb_dev[i], depth_dev[i])
+            cpipe.flush()
     else:
         def run(lo, hi):
             for i in range(lo, hi):
@@ -259,7 +266,7 @@ def main():
                                    % (W, H, "given poses (use_gt_pose=true, as every shipped config)" if args.gt_pose else
                                       "depth ICP tracking (ExtendedTracker, use_gt_pose=false)", N // 1000),
                        "gaussians": N, "local_opt_interval": 10, "local_opt_iters": 20,
-                       "frames_per_step": 1, "stats": stats, "host": args.host, "use_gt_pose": bool(args.gt_pose), "quality": quality, "split": split},
+                       "frames_per_step": 1, "stats": stats, "host": args.host, "overlap_mapping": bool(args.host == "cpp" and not args.no_overlap), "use_gt_pose": bool(args.gt_pose), "quality": quality, "split": split},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,5 +1,8 @@
 #include "slam_pipeline.hpp"
 
+#include <c10/hip/HIPGuard.h>
+#include <hip/hip_runtime_api.h>
+
 #include <cmath>
 
 using namespace gpsh;
@@ -181,7 +184,7 @@ void SLAMPipeline::removeRedundantGs() {
 }
 
 // ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
-void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
+void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     curr_frame_id = i;
     if (!main_engine->trackingActive && (int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed)
         main_engine->gtC2wPoses.push_back(cam.c2w);
@@ -199,15 +202,98 @@ void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8,
     stats.frames++;
     if (work_mode == "recon") return;
     if (i % local_opt_interval == 0 && i > 0) {
+        if (overlap_mapping) keyframeStepOverlapped(); else keyframeStep();
+    }
+}
+
+// ------------------------------------------------------------------ tracking / mapping overlap (see slam_pipeline.hpp)
+namespace {
+inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
+struct MapStream { c10::hip::HIPStream s; };
+}  // namespace
+
+void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
+    if (!overlap_mapping) { processFrameImpl(i, cam, rgb_u8, depth_mm_i16); return; }
+    // overlap: frames run on a HIGH-priority stream of their own, so that the short, latency-bound tracker kernels are
+    // dispatched ahead of the map stream's long rasterizer kernels; ordered after the caller's stream (inputs), and the
+    // caller's stream is re-joined in flush()
+    ensureStreams();
+    const hipStream_t caller = c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPStream& fs = static_cast<MapStream*>(frame_stream_)->s;
+    if (caller != fs.stream()) {
+        hip_ok(hipEventRecord((hipEvent_t)ev_caller_, caller), "hipEventRecord");
+        hip_ok(hipStreamWaitEvent(fs.stream(), (hipEvent_t)ev_caller_, 0), "hipStreamWaitEvent");
+    }
+    c10::hip::HIPStreamGuard guard(fs);
+    processFrameImpl(i, cam, rgb_u8, depth_mm_i16);
+}
+
+void SLAMPipeline::ensureStreams() {
+    if (map_stream_) return;
+    map_stream_ = new MapStream{c10::hip::getStreamFromPool(/*isHighPriority=*/false, c10::hip::current_device())};
+    frame_stream_ = new MapStream{c10::hip::getStreamFromPool(/*isHighPriority=*/true, c10::hip::current_device())};
+    for (void** e : {&ev_frame_, &ev_raycasts_, &ev_map_, &ev_caller_}) {
+        hipEvent_t ev;
+        hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        *e = ev;
+    }
+}
+
+void SLAMPipeline::keyframeStep() {
+    localFrameRaycast();
+    keyFrameRaycast();
+    initNewGaussians(localframe_raycast_window.back());
+    localOptimize();
+    removeRedundantGs();
+}
+
+void SLAMPipeline::keyframeStepOverlapped() {
+    ensureStreams();
+    const hipStream_t frames = c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPStream& ms = static_cast<MapStream*>(map_stream_)->s;
+    // the previous update must be complete before its camera / raycast lists are replaced (host wait: B is idle afterwards)
+    if (map_in_flight_) { hip_ok(hipEventSynchronize((hipEvent_t)ev_map_), "hipEventSynchronize"); map_in_flight_ = false; }
+    hip_ok(hipEventRecord((hipEvent_t)ev_frame_, frames), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
+    {
+        c10::hip::HIPStreamGuard guard(ms);
+        if (prune_pending_) { removeRedundantGs(); prune_pending_ = false; }  // update k's prune, before update k+1 reads the model
         localFrameRaycast();
         keyFrameRaycast();
+        hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
         initNewGaussians(localframe_raycast_window.back());
         localOptimize();
+        hip_ok(hipEventRecord((hipEvent_t)ev_map_, ms.stream()), "hipEventRecord");
+        map_in_flight_ = true;
+        prune_pending_ = true;
+    }
+    // the next frames' fusion must not modify the volume (or reuse the engine's free-view scratch) before the raycasts read it
+    hip_ok(hipStreamWaitEvent(frames, (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+}
+
+void SLAMPipeline::flush() {
+    if (frame_stream_) hip_ok(hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream()), "hipStreamSynchronize");
+    if (map_in_flight_) { hip_ok(hipEventSynchronize((hipEvent_t)ev_map_), "hipEventSynchronize"); map_in_flight_ = false; }
+    if (prune_pending_) {
+        c10::hip::HIPStreamGuard guard(static_cast<MapStream*>(map_stream_)->s);
         removeRedundantGs();
+        prune_pending_ = false;
+        hip_ok(hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream()), "hipStreamSynchronize");
+    }
+}
+
+SLAMPipeline::~SLAMPipeline() {
+    if (map_stream_) {
+        (void)hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream());
+        (void)hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream());
+        for (void* e : {ev_frame_, ev_raycasts_, ev_map_, ev_caller_}) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        delete static_cast<MapStream*>(map_stream_);
+        delete static_cast<MapStream*>(frame_stream_);
     }
 }
 
 void SLAMPipeline::SLAMTrainCams(std::vector<Camera>& cams, const std::vector<torch::Tensor>& rgb_u8,
                                  const std::vector<torch::Tensor>& depth_mm_i16) {
     for (size_t i = 0; i < cams.size(); i++) processFrame((int)i, cams[i], rgb_u8[i], depth_mm_i16[i]);
+    flush();
 }
