@@ -162,10 +162,20 @@ def main():
             c.id, c.image, c.depth = k, cams[k].image, cams[k].depth
             ccams.append(c)
 
+        frame_times = [] if os.environ.get("GPS_BENCH_FRAME_TIMES") else None
+
         def run(lo, hi):
             for i in range(lo, hi):
+                if frame_times is not None:
+                    t = time.perf_counter()
                 cpipe.processFrame(i, ccams[i], rgb_dev[i], depth_dev[i])
+                if frame_times is not None:
+                    frame_times.append((i, time.perf_counter() - t))
+            if frame_times is not None:
+                t = time.perf_counter()
             cpipe.flush()
+            if frame_times is not None:
+                frame_times.append((-1, time.perf_counter() - t))
     else:
         def run(lo, hi):
             for i in range(lo, hi):
@@ -192,6 +202,13 @@ def main():
     grp.barrier()
     torch.cuda.synchronize()
     dt = grp.max_over_ranks(time.perf_counter() - t0)
+    if args.host == "cpp" and frame_times is not None and rank == 0:  # host-side duration of every processFrame call (debug aid)
+        timed = [(i, d) for i, d in frame_times if i >= Wm or i == -1][-(K + 1):]
+        key = [d for i, d in timed if i > 0 and i % 10 == 0]
+        rest = [d for i, d in timed if i > 0 and i % 10 != 0]
+        sys.stderr.write("processFrame host time: keyframes mean %.3f ms, other frames mean %.3f ms (min %.3f max %.3f), final flush %.3f ms\n"
+                         % (1e3 * sum(key) / max(1, len(key)), 1e3 * sum(rest) / max(1, len(rest)), 1e3 * min(rest), 1e3 * max(rest),
+                            1e3 * timed[-1][1]))
 
     out = None
     if rank == 0:

@@ -179,6 +179,8 @@ PYBIND11_MODULE(_host, m) {
         .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams, py::call_guard<py::gil_scoped_release>())
         .def("runRaycastByCam", &SLAMPipeline::runRaycastByCam, py::arg("cam"), py::arg("use_cam_depth") = true)
         .def_readwrite("overlap_mapping", &SLAMPipeline::overlap_mapping)
+        .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)
+        .def_readwrite("pump_iters_per_frame", &SLAMPipeline::pump_iters_per_frame)
         .def("flush", &SLAMPipeline::flush, py::call_guard<py::gil_scoped_release>())
         .def("stats", [](SLAMPipeline& p) {
             p.flush();

@@ -146,11 +146,22 @@ void SLAMPipeline::initNewGaussians(TensorDict& rm) {
 
 // ------------------------------------------------------------------ localOptimize :195-289
 void SLAMPipeline::localOptimize() {
+    localOptimizeBegin();
+    optimizeIterations(opt_pending_);
+}
+
+void SLAMPipeline::localOptimizeBegin() {
+    opt_pending_ = 0;
     if (model->getGaussianNum() == 0) return;
     model->initOptimizers(-1, scene_scale);
-    RandomSelector<Camera> loader(opt_cam_list, rng_);
-    for (int it = 0; it < local_opt_iters; it++) {
-        auto pick = loader.getNext();
+    opt_loader_.reset(new RandomSelector<Camera>(opt_cam_list, rng_));
+    opt_pending_ = local_opt_iters;
+}
+
+// the next `count` iterations of the current localOptimize (cameras drawn in the same order as the all-at-once loop)
+void SLAMPipeline::optimizeIterations(int count) {
+    for (; count > 0 && opt_pending_ > 0; count--, opt_pending_--) {
+        auto pick = opt_loader_->getNext();
         const Camera& cam = *pick.second;
         TensorDict& rc = opt_raycast_list[pick.first];
         if (ssim_weight > 0 || depth_weight > 0) {
@@ -224,6 +235,7 @@ void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8,
         hip_ok(hipEventRecord((hipEvent_t)ev_caller_, caller), "hipEventRecord");
         hip_ok(hipStreamWaitEvent(fs.stream(), (hipEvent_t)ev_caller_, 0), "hipStreamWaitEvent");
     }
+    pumpMapping(pump_iters_per_frame);  // keep the map stream fed before this thread starts spinning on the tracker
     c10::hip::HIPStreamGuard guard(fs);
     processFrameImpl(i, cam, rgb_u8, depth_mm_i16);
 }
@@ -252,6 +264,7 @@ void SLAMPipeline::keyframeStepOverlapped() {
     const hipStream_t frames = c10::hip::getCurrentHIPStream().stream();
     c10::hip::HIPStream& ms = static_cast<MapStream*>(map_stream_)->s;
     // the previous update must be complete before its camera / raycast lists are replaced (host wait: B is idle afterwards)
+    pumpMapping(opt_pending_);
     if (map_in_flight_) { hip_ok(hipEventSynchronize((hipEvent_t)ev_map_), "hipEventSynchronize"); map_in_flight_ = false; }
     hip_ok(hipEventRecord((hipEvent_t)ev_frame_, frames), "hipEventRecord");
     hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
@@ -262,16 +275,32 @@ void SLAMPipeline::keyframeStepOverlapped() {
         keyFrameRaycast();
         hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
         initNewGaussians(localframe_raycast_window.back());
-        localOptimize();
-        hip_ok(hipEventRecord((hipEvent_t)ev_map_, ms.stream()), "hipEventRecord");
-        map_in_flight_ = true;
-        prune_pending_ = true;
+        localOptimizeBegin();
+        map_update_open_ = true;
     }
+    // a few iterations now, the rest a few at a time from the following processFrame calls: enqueueing all 20 at once keeps the
+    // host (and with it the frame stream) busy for ~1 ms while the map stream only needs to stay ahead of the GPU
+    pumpMapping(pump_iters_first);
     // the next frames' fusion must not modify the volume (or reuse the engine's free-view scratch) before the raycasts read it
     hip_ok(hipStreamWaitEvent(frames, (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
 }
 
+// enqueue up to `count` pending optimise iterations on the map stream; closing the update records its completion event
+void SLAMPipeline::pumpMapping(int count) {
+    if (!map_update_open_) return;
+    c10::hip::HIPStream& ms = static_cast<MapStream*>(map_stream_)->s;
+    c10::hip::HIPStreamGuard guard(ms);
+    optimizeIterations(count);
+    if (opt_pending_ == 0) {
+        hip_ok(hipEventRecord((hipEvent_t)ev_map_, ms.stream()), "hipEventRecord");
+        map_update_open_ = false;
+        map_in_flight_ = true;
+        prune_pending_ = true;
+    }
+}
+
 void SLAMPipeline::flush() {
+    pumpMapping(opt_pending_);
     if (frame_stream_) hip_ok(hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream()), "hipStreamSynchronize");
     if (map_in_flight_) { hip_ok(hipEventSynchronize((hipEvent_t)ev_map_), "hipEventSynchronize"); map_in_flight_ = false; }
     if (prune_pending_) {

@@ -11,6 +11,7 @@
 // reference seeds from std::random_device (dataset_reader.h:39) are seeded here so that runs are reproducible.
 #pragma once
 #include <deque>
+#include <memory>
 #include <random>
 
 #include "raw_gs_model.hpp"
@@ -103,6 +104,7 @@ public:
     // Results are those of the sequential schedule.  Off by default: with it on, processFrame() returns while the update is
     // still in flight and the model may only be read after flush() (SLAMTrainCams and the accessors below call it).
     bool overlap_mapping = false;
+    int pump_iters_first = 4, pump_iters_per_frame = 3;  // optimise iterations enqueued at the keyframe / per following frame
     void flush();
     ~SLAMPipeline();
 
@@ -111,6 +113,12 @@ private:
     void ensureStreams();
     void keyframeStep();
     void keyframeStepOverlapped();
+    void localOptimizeBegin();
+    void optimizeIterations(int count);
+    void pumpMapping(int count);
+    std::unique_ptr<RandomSelector<Camera>> opt_loader_;
+    int opt_pending_ = 0;
+    bool map_update_open_ = false;
     std::mt19937_64 rng_;
     at::Generator gen_;
     void *map_stream_ = nullptr, *frame_stream_ = nullptr;  // c10 stream handle storage (see .cpp)
