@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o bench -- $CMD > gpurun_ou
   python scratch/prof_summary.py "$(find /tmp/prof_stats -name '*.db' | head -1)" 48
   echo
   echo "bench line of the profiled run:"
-  tail -1 gpurun_out/bench_prof.log | cut -c1-400
+  grep '^{"metric"' gpurun_out/bench_prof.log | tail -1 | cut -c1-400
 } > gpurun_out/r01_bench_kernel_stats.md
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/prof_$c -o a -- python scratch/raster_bench.py > gpurun_out/pmc_$c.log 2>&1
