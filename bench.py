@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-map-thread", action="store_true", help="C++ host, with overlap: interleave the map update's host work "
+                    "with the frames on one thread instead of giving it a worker thread")
     ap.add_argument("--no-overlap", action="store_true", help="C++ host: run the keyframe map update to completion before the "
                     "next frame (the reference's schedule) instead of overlapping it with tracking/fusion on a second stream")
     ap.add_argument("--gaussians", type=int, default=200000)
@@ -156,6 +158,7 @@ def main():
         # frames are tracked and fused; same results as the sequential schedule.  flush() below closes the timed region, so every
         # frame's work (incl. the deferred prune) is inside it.
         cpipe.overlap_mapping = not args.no_overlap
+        cpipe.mapping_thread = not args.no_map_thread
         ccams = []
         for k in range(n_frames):
             c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k].astype(np.float32)))
@@ -283,7 +286,7 @@ def main():
                                    % (W, H, "given poses (use_gt_pose=true, as every shipped config)" if args.gt_pose else
                                       "depth ICP tracking (ExtendedTracker, use_gt_pose=false)", N // 1000),
                        "gaussians": N, "local_opt_interval": 10, "local_opt_iters": 20,
-                       "frames_per_step": 1, "stats": stats, "host": args.host, "overlap_mapping": bool(args.host == "cpp" and not args.no_overlap), "use_gt_pose": bool(args.gt_pose), "quality": quality, "split": split},
+                       "frames_per_step": 1, "stats": stats, "host": args.host, "overlap_mapping": bool(args.host == "cpp" and not args.no_overlap), "mapping_thread": bool(args.host == "cpp" and not args.no_overlap and not args.no_map_thread), "use_gt_pose": bool(args.gt_pose), "quality": quality, "split": split},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -179,18 +179,19 @@ PYBIND11_MODULE(_host, m) {
         .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams, py::call_guard<py::gil_scoped_release>())
         .def("runRaycastByCam", &SLAMPipeline::runRaycastByCam, py::arg("cam"), py::arg("use_cam_depth") = true)
         .def_readwrite("overlap_mapping", &SLAMPipeline::overlap_mapping)
+        .def_readwrite("mapping_thread", &SLAMPipeline::mapping_thread)
         .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)
         .def_readwrite("pump_iters_per_frame", &SLAMPipeline::pump_iters_per_frame)
         .def("flush", &SLAMPipeline::flush, py::call_guard<py::gil_scoped_release>())
         .def("stats", [](SLAMPipeline& p) {
-            p.flush();
+            { py::gil_scoped_release nogil; p.flush(); }
             py::dict d;
             d["frames"] = p.stats.frames; d["opt_iters"] = p.stats.opt_iters; d["raycasts"] = p.stats.raycasts;
             d["added"] = p.stats.added; d["pruned"] = p.stats.pruned;
             return d;
         })
-        .def("optCams", [](SLAMPipeline& p) { p.flush(); return p.opt_cam_list; })
-        .def("optRaycasts", [](SLAMPipeline& p) { p.flush(); return p.opt_raycast_list; })
+        .def("optCams", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return p.opt_cam_list; })
+        .def("optRaycasts", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return p.opt_raycast_list; })
         .def_readwrite("workspace_dir", &SLAMPipeline::workspace_dir)
         .def_readwrite("saved_mesh", &SLAMPipeline::saved_mesh)
         .def_readwrite("saved_engine", &SLAMPipeline::saved_engine)

@@ -49,10 +49,14 @@ void SLAMPipeline::loadConfig(const Config& c) {
 // ------------------------------------------------------------------ raycast -> tensors (runRaycastByCam :362-415)
 TensorDict SLAMPipeline::runRaycastByCam(const Camera& cam, bool use_cam_depth) {
     (void)use_cam_depth;
+    return raycastCam(cam, main_engine->camPoses);
+}
+
+TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses) {
     ITMBasicEngine* eng = main_engine;
     ORUtils::SE3Pose pose;
-    if (cam.id >= 0 && cam.id < (int)eng->camPoses.size()) {
-        pose = eng->camPoses[cam.id];
+    if (cam.id >= 0 && cam.id < (int)poses.size()) {
+        pose = poses[cam.id];
     } else {
         auto c = cam.c2w.to(torch::kCPU, torch::kFloat32).contiguous();
         pose.SetInvM(c.data_ptr<float>());
@@ -105,27 +109,31 @@ void SLAMPipeline::updateFrameList() {
     if (is_key) keyframe_cam_list.push_back(curr_cam);
 }
 
-void SLAMPipeline::localFrameRaycast() {
+void SLAMPipeline::localFrameRaycast() { raycastWindow(localframe_cam_window, main_engine->camPoses); }
+void SLAMPipeline::keyFrameRaycast() { raycastKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses); }
+void SLAMPipeline::initNewGaussians(TensorDict& rm) { initNewGaussiansFor(rm, curr_cam); }
+
+void SLAMPipeline::raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses) {
     localframe_raycast_window.clear();
-    for (const Camera& cam : localframe_cam_window) localframe_raycast_window.push_back(runRaycastByCam(cam));
+    for (const Camera& cam : window) localframe_raycast_window.push_back(raycastCam(cam, poses));
 }
 
-void SLAMPipeline::keyFrameRaycast() {
-    opt_cam_list.assign(localframe_cam_window.begin(), localframe_cam_window.end());
+void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
+                                    const std::vector<ORUtils::SE3Pose>& poses) {
+    opt_cam_list.assign(window.begin(), window.end());
     opt_raycast_list.assign(localframe_raycast_window.begin(), localframe_raycast_window.end());
-    const int n = std::min<int>(keyframe_select_max, (int)keyframe_cam_list.size());
-    RandomSelector<Camera> sel(keyframe_cam_list, rng_);
+    const int n = std::min<int>(keyframe_select_max, (int)keyframes.size());
+    RandomSelector<Camera> sel(keyframes, rng_);
     for (int k = 0; k < n; k++) {
         const Camera* cam = sel.getNext().second;
         opt_cam_list.push_back(*cam);
-        opt_raycast_list.push_back(runRaycastByCam(*cam));
+        opt_raycast_list.push_back(raycastCam(*cam, poses));
     }
 }
 
 // ------------------------------------------------------------------ initNewGaussians :450-526
-void SLAMPipeline::initNewGaussians(TensorDict& rm) {
+void SLAMPipeline::initNewGaussiansFor(TensorDict& rm, const Camera& cam) {
     torch::NoGradGuard no_grad;
-    Camera& cam = curr_cam;
     const auto &depth = rm.at("depth_map"), &color = rm.at("color_map"), &vertex = rm.at("vertex_map");
     int frame_num = local_opt_interval;
     auto valid = (depth > depth_vis_min) & (depth < depth_vis_max);
@@ -213,7 +221,9 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     stats.frames++;
     if (work_mode == "recon") return;
     if (i % local_opt_interval == 0 && i > 0) {
-        if (overlap_mapping) keyframeStepOverlapped(); else keyframeStep();
+        if (overlap_mapping && mapping_thread) keyframeStepThreaded();
+        else if (overlap_mapping) keyframeStepOverlapped();
+        else keyframeStep();
     }
 }
 
@@ -235,6 +245,7 @@ void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8,
         hip_ok(hipEventRecord((hipEvent_t)ev_caller_, caller), "hipEventRecord");
         hip_ok(hipStreamWaitEvent(fs.stream(), (hipEvent_t)ev_caller_, 0), "hipStreamWaitEvent");
     }
+    rethrowWorkerError();
     pumpMapping(pump_iters_per_frame);  // keep the map stream fed before this thread starts spinning on the tracker
     c10::hip::HIPStreamGuard guard(fs);
     processFrameImpl(i, cam, rgb_u8, depth_mm_i16);
@@ -285,6 +296,71 @@ void SLAMPipeline::keyframeStepOverlapped() {
     hip_ok(hipStreamWaitEvent(frames, (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
 }
 
+// ------------------------------------------------------------------ mapping thread
+// The classic SLAM split: this (the caller's) thread tracks and fuses, a worker thread owns the Gaussian model and runs each
+// keyframe's map update start to finish on the map stream -- its host-side waits (mask counts in addGaussians / prune, 240
+// kernel launches) no longer stall the frame stream at all.  Hand-over at keyframe i: wait for update i-10, record "frame i
+// fused", snapshot the camera lists / poses the update reads (the frame thread keeps appending to the originals), wake the
+// worker, wait (~0.3 ms) until it has enqueued the raycasts and recorded their event, make the frame stream wait for it.
+void SLAMPipeline::keyframeStepThreaded() {
+    ensureStreams();
+    const hipStream_t frames = c10::hip::getCurrentHIPStream().stream();
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!worker_.joinable()) worker_ = std::thread([this, dev = (int)c10::hip::current_device()] { mapWorker(dev); });
+    cv_.wait(lk, [&] { return done_seq_ == job_seq_ || worker_error_; });
+    if (worker_error_) { lk.unlock(); rethrowWorkerError(); }
+    hip_ok(hipEventRecord((hipEvent_t)ev_frame_, frames), "hipEventRecord");
+    job_.curr_cam = curr_cam;
+    job_.window = localframe_cam_window;
+    job_.keyframes = keyframe_cam_list;
+    job_.poses = main_engine->camPoses;
+    job_seq_++;
+    cv_.notify_all();
+    cv_.wait(lk, [&] { return raycasts_seq_ == job_seq_ || worker_error_; });
+    if (worker_error_) { lk.unlock(); rethrowWorkerError(); }
+    hip_ok(hipStreamWaitEvent(frames, (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+}
+
+void SLAMPipeline::mapWorker(int device_index) {
+    try {
+        c10::hip::set_device((c10::DeviceIndex)device_index);
+        c10::hip::HIPStream& ms = static_cast<MapStream*>(map_stream_)->s;
+        c10::hip::HIPStreamGuard guard(ms);
+        int64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || job_seq_ > seen; });
+                if (stop_) return;
+                seen = job_seq_;
+            }
+            // job_ is stable until done_seq_ catches up (the frame thread waits for that before it writes the next one)
+            hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
+            raycastWindow(job_.window, job_.poses);
+            raycastKeyframes(job_.window, job_.keyframes, job_.poses);
+            hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
+            { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
+            cv_.notify_all();
+            initNewGaussiansFor(localframe_raycast_window.back(), job_.curr_cam);
+            localOptimize();
+            removeRedundantGs();
+            hip_ok(hipStreamSynchronize(ms.stream()), "hipStreamSynchronize");
+            { std::lock_guard<std::mutex> lk(mu_); done_seq_ = seen; }
+            cv_.notify_all();
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(mu_);
+        worker_error_ = std::current_exception();
+        cv_.notify_all();
+    }
+}
+
+void SLAMPipeline::rethrowWorkerError() {
+    std::exception_ptr e;
+    { std::lock_guard<std::mutex> lk(mu_); e = worker_error_; worker_error_ = nullptr; }
+    if (e) std::rethrow_exception(e);
+}
+
 // enqueue up to `count` pending optimise iterations on the map stream; closing the update records its completion event
 void SLAMPipeline::pumpMapping(int count) {
     if (!map_update_open_) return;
@@ -300,6 +376,12 @@ void SLAMPipeline::pumpMapping(int count) {
 }
 
 void SLAMPipeline::flush() {
+    if (worker_.joinable()) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return done_seq_ == job_seq_ || worker_error_; });
+        lk.unlock();
+        rethrowWorkerError();
+    }
     pumpMapping(opt_pending_);
     if (frame_stream_) hip_ok(hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream()), "hipStreamSynchronize");
     if (map_in_flight_) { hip_ok(hipEventSynchronize((hipEvent_t)ev_map_), "hipEventSynchronize"); map_in_flight_ = false; }
@@ -312,6 +394,11 @@ void SLAMPipeline::flush() {
 }
 
 SLAMPipeline::~SLAMPipeline() {
+    if (worker_.joinable()) {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        worker_.join();
+    }
     if (map_stream_) {
         (void)hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream());
         (void)hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream());

@@ -10,8 +10,12 @@
 // All compute goes through the C-ABI (RawGaussianModel, ITMBasicEngine); this file is bookkeeping.  Random choices the
 // reference seeds from std::random_device (dataset_reader.h:39) are seeded here so that runs are reproducible.
 #pragma once
+#include <condition_variable>
 #include <deque>
+#include <exception>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <random>
 
 #include "raw_gs_model.hpp"
@@ -104,6 +108,9 @@ public:
     // Results are those of the sequential schedule.  Off by default: with it on, processFrame() returns while the update is
     // still in flight and the model may only be read after flush() (SLAMTrainCams and the accessors below call it).
     bool overlap_mapping = false;
+    // with overlap_mapping: run the map update on a worker thread of its own (tracking thread + mapping thread) instead of
+    // interleaving its host work with the frames on the caller's thread
+    bool mapping_thread = false;
     int pump_iters_first = 4, pump_iters_per_frame = 3;  // optimise iterations enqueued at the keyframe / per following frame
     void flush();
     ~SLAMPipeline();
@@ -111,8 +118,24 @@ public:
 private:
     void processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16);
     void ensureStreams();
+    TensorDict raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses);
+    void raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses);
+    void raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
+                          const std::vector<ORUtils::SE3Pose>& poses);
+    void initNewGaussiansFor(TensorDict& raycast_maps, const Camera& cam);
     void keyframeStep();
     void keyframeStepOverlapped();
+    void keyframeStepThreaded();
+    void mapWorker(int device_index);
+    void rethrowWorkerError();
+    struct MapJob { Camera curr_cam; std::deque<Camera> window; std::vector<Camera> keyframes; std::vector<ORUtils::SE3Pose> poses; };
+    MapJob job_;
+    std::thread worker_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int64_t job_seq_ = 0, raycasts_seq_ = 0, done_seq_ = 0;
+    bool stop_ = false;
+    std::exception_ptr worker_error_;
     void localOptimizeBegin();
     void optimizeIterations(int count);
     void pumpMapping(int count);

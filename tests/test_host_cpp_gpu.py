@@ -468,12 +468,13 @@ def test_overlapped_mapping_equals_sequential_schedule():
     rgb = torch.as_tensor(rgba).to(DEV)
     dep = torch.as_tensor(seq["depth"].astype(np.int16)).to(DEV)
 
-    def run(overlap):
+    def run(overlap, thread=False):
         eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
         model = h.SLAMGaussianModel()
         model.loadConfig(dict(capacity=1 << 16))
         pipe = h.SLAMPipeline(eng, model, 11, False)  # tracking on: the latency-bound part that overlaps
         pipe.overlap_mapping = overlap
+        pipe.mapping_thread = thread
         for i in range(n):
             c = h.Camera(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
             c.id = i
@@ -487,11 +488,12 @@ def test_overlapped_mapping_equals_sequential_schedule():
                 [t.clone() for t in (p.getMeans(), p.getScales(), p.getQuats(), p.getFeaturesDc(), p.getFeaturesRest(), p.getOpacities())])
 
     st_s, cnt_s, live_s, par_s = run(False)
-    st_o, cnt_o, live_o, par_o = run(True)
-    assert st_s == st_o and st_s["opt_iters"] == 60 and st_s["added"] > 100
-    assert torch.equal(cnt_s[:4], cnt_o[:4]) and torch.equal(live_s, live_o)
-    for a, b in zip(par_s, par_o):
-        assert a.shape == b.shape
-        # same kernels on the same inputs; float atomics in the rasterizer backward make the order of additions (not the
-        # schedule) the only source of difference, amplified a little by Adam's normalisation over 60 iterations
-        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+    for mode in ((True, False), (True, True)):  # streams on one host thread; tracking thread + mapping thread
+        st_o, cnt_o, live_o, par_o = run(*mode)
+        assert st_s == st_o and st_s["opt_iters"] == 60 and st_s["added"] > 100
+        assert torch.equal(cnt_s[:4], cnt_o[:4]) and torch.equal(live_s, live_o)
+        for a, b in zip(par_s, par_o):
+            assert a.shape == b.shape
+            # same kernels on the same inputs; float atomics in the rasterizer backward make the order of additions (not the
+            # schedule) the only source of difference, amplified a little by Adam's normalisation over 60 iterations
+            torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
