@@ -195,6 +195,8 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("workspace_dir", &SLAMPipeline::workspace_dir)
         .def_readwrite("saved_mesh", &SLAMPipeline::saved_mesh)
         .def_readwrite("saved_engine", &SLAMPipeline::saved_engine)
+        .def("renderEvalImgs", &SLAMPipeline::renderEvalImgs, py::arg("cams"), py::arg("names") = std::vector<std::string>{"rgb"},
+             py::call_guard<py::gil_scoped_release>())
         .def("saveMesh", &SLAMPipeline::saveMesh)
         .def("saveEngine", &SLAMPipeline::saveEngine)
         .def("loadEngine", &SLAMPipeline::loadEngine)

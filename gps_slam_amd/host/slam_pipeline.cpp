@@ -202,6 +202,37 @@ void SLAMPipeline::removeRedundantGs() {
     }
 }
 
+// ------------------------------------------------------------------ renderEvalImgs :588-695 (tensors instead of image files)
+std::vector<TensorDict> SLAMPipeline::renderEvalImgs(const std::vector<Camera>& cams, const std::vector<std::string>& names) {
+    torch::NoGradGuard no_grad;
+    flush();
+    std::vector<TensorDict> out;
+    for (const Camera& cam : cams) {
+        TensorDict r;
+        TORCH_CHECK(cam.on_device(), "Camera::toGPU() must run before the camera is rendered");
+        auto rc = runRaycastByCam(cam, false);
+        r["raycast_color"] = rc.at("color_map");
+        r["raycast_depth"] = rc.at("depth_map");
+        if (model->getGaussianNum() > 0) {
+            auto res = model->forward(cam, rc.at("depth_map"), rc.at("color_map"));
+            for (const std::string& name : names) {
+                if (name == "rgb") {
+                    r["rgb"] = torch::clamp(res.at("rgb"), 0, 1);
+                    if (cam.image.defined()) {
+                        auto mse = torch::mean(torch::square(r["rgb"] - cam.image.to(device)));
+                        r["psnr"] = -10.0 * torch::log10(mse);
+                    }
+                } else if (name == "alpha" || name == "depth") {
+                    r[name] = res.at(name).clone();
+                }
+            }
+            if (r.count("rgb")) r["rgb"] = r["rgb"].clone();  // forward() returns views of buffers the next camera overwrites
+        }
+        out.push_back(r);
+    }
+    return out;
+}
+
 // ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
 void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     curr_frame_id = i;

@@ -67,6 +67,12 @@ public:
     void localOptimize();
     void removeRedundantGs();
 
+    // renderEvalImgs (slam_pipeline.cpp:588-695), the compute half: for every camera the free-view raycast with the stored pose
+    // and, if the model is not empty, forward() under NoGradGuard.  Returns per camera the tensors the reference turns into
+    // image files with OpenCV ("raycast_color", "raycast_depth" and, per requested name, "rgb" clamped to [0,1], "alpha",
+    // "depth") plus "psnr" (run/read_results.py's metric) -- the JPEG/PNG writing itself is I/O outside this library.
+    std::vector<TensorDict> renderEvalImgs(const std::vector<Camera>& cams, const std::vector<std::string>& names = {"rgb"});
+
     // slam_pipeline.h:32-49: mesh / engine state files under workspace_dir (empty names are skipped like the reference)
     std::string workspace_dir = ".", saved_mesh, saved_engine;
     void saveMesh() { if (!saved_mesh.empty()) main_engine->SaveSceneToMesh((workspace_dir + "/" + saved_mesh).c_str()); }

@@ -273,6 +273,13 @@ def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():
     err_render = (res["rgb"] - cams[0].image).abs().mean().item()
     err_tsdf = (rcs[0]["color_map"] - cams[0].image).abs().mean().item()
     assert err_render <= err_tsdf * 1.02, (err_render, err_tsdf)
+    # renderEvalImgs (slam_pipeline.cpp:588-695, tensors instead of image files): raycast + no-grad forward per camera
+    res = {k: v.clone() for k, v in res.items()}  # forward() returns views of buffers the next render overwrites
+    ev = pipe_c.renderEvalImgs(cams[:2], ["rgb", "alpha", "depth"])
+    assert len(ev) == 2 and set(ev[0]) >= {"raycast_color", "raycast_depth", "rgb", "alpha", "depth", "psnr"}
+    assert float(ev[0]["rgb"].min()) >= 0.0 and float(ev[0]["rgb"].max()) <= 1.0
+    torch.testing.assert_close(ev[0]["rgb"], res["rgb"].clamp(0, 1), rtol=1e-5, atol=1e-6)
+    assert 10.0 < float(ev[0]["psnr"]) < 60.0 and not torch.equal(ev[0]["rgb"], ev[1]["rgb"])
 
 
 def test_full_loop_at_1280x720_cpp_host():
