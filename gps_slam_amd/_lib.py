@@ -65,6 +65,7 @@ PROTOTYPES = {
     "gps_isect_tiles_no_depth": (i32, [i32, vp, vp, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "gps_ssim_fwd": (i32, [i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_ssim_bwd": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_upload_floats": (i32, [vp, vp, i32, vp]),
     "gps_isect_tiles": (i32, [i32, vp, vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, i64, vp]),
     "gps_raster_raw_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_raster_raw_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,

@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256) void normal_map_kernel(int W, int H, const flo
 
 }  // namespace
 
+namespace {
+struct SmallFloats { float v[64]; };
+__global__ __launch_bounds__(64) void upload_floats_kernel(SmallFloats v, int n, float* __restrict__ dst) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
+}
+}  // namespace
+
 extern "C" {
 
 int gps_knn_mean_dist2(int P, const float* points, float* mean_dist2, gps_stream stream) {
@@ -101,6 +108,16 @@ int gps_normal_map(int width, int height, const float* vertex_map, float* normal
     GPS_REQUIRE(width > 0 && height > 0 && vertex_map && normal_map);
     dim3 grid(gps_div_up(width, 16), gps_div_up(height, 16));
     normal_map_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(width, height, vertex_map, normal_map);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_upload_floats(float* dst, const float* host_values, int n, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(dst && host_values && n > 0 && n <= 64);
+    SmallFloats v;
+    for (int k = 0; k < 64; k++) v.v[k] = k < n ? host_values[k] : 0.0f;
+    upload_floats_kernel<<<1, 64, 0, (hipStream_t)stream>>>(v, n, dst);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -25,8 +25,7 @@ torch::Tensor poseInv(const torch::Tensor& c2w) {
 void Camera::toGPU(const torch::Device& device) {
     if (!pack_.defined()) {
         auto c = c2w_slam.to(torch::kCPU, torch::kFloat32).contiguous();
-        auto host = torch::empty({28}, torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
-        float* h = host.data_ptr<float>();
+        float h[28];
         const float* m = c.data_ptr<float>();
         // viewmat = [R^T | -R^T t] row-major
         for (int r = 0; r < 3; r++) {
@@ -37,7 +36,9 @@ void Camera::toGPU(const torch::Device& device) {
         auto Kc = K.to(torch::kCPU, torch::kFloat32).contiguous();
         for (int k = 0; k < 9; k++) h[16 + k] = Kc.data_ptr<float>()[k];
         h[25] = m[3]; h[26] = m[7]; h[27] = m[11];
-        pack_ = host.to(device, /*non_blocking=*/true);
+        // through the kernel argument buffer: no pinned staging tensor, no copy-engine latency on the frame stream
+        pack_ = torch::empty({28}, f32(device));
+        check(gps_upload_floats(fptr(pack_), h, 28, current_stream()), "gps_upload_floats");
     }
     if (image.defined() && !image.is_cuda()) image = image.to(device);
     if (depth.defined() && !depth.is_cuda()) depth = depth.to(device);

@@ -284,6 +284,12 @@ GPS_API int gps_knn_mean_dist2(int P, const float *points, float *mean_dist2, gp
  * normal_map[H,W,3] (Sobel, replicate padding, cross(dy,dx) normalised, 0 where vertex z <= 0). */
 GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float *normal_map, gps_stream stream);
 
+/* Uploads up to 64 floats from host memory into device memory THROUGH THE KERNEL ARGUMENT BUFFER (values are read on the host at
+ * call time; no pinned staging, no copy-engine transfer, ordered on `stream` like any kernel).  Camera::toGPU() uses it for the
+ * 28-float viewmat | K | camera position pack of every frame: a hipMemcpyAsync of that size costs ~15 us of copy-engine latency
+ * on the frame stream's dependent chain. */
+GPS_API int gps_upload_floats(float *dst, const float *host_values, int n, gps_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* Splat: one optimise iteration / one render as a single call         */
 /* ------------------------------------------------------------------ */
