@@ -63,15 +63,22 @@ def dominant_kernel_roofline(model, pipe, eng, cams, device, hbm_peak_gbs):
     alg_bwd = 52.0 * ng + 24.0 * P + 40.0 * ng
     alg_fwd = 44.0 * ni + 4.0 * P + 20.0 * P
     ach = alg_bwd / t_bwd / 1e9
-    traffic = None
+    traffic, valu = None, None
     pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_raster_bwd.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            traffic = rec.get("hbm_bytes_per_launch")
+            insts = (rec.get("wave_instructions_per_launch") or {}).get("SQ_INSTS_VALU")
+            if insts:
+                # issue-side yardstick for a VALU-bound kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles;
+                # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md) -> fraction of the chip's VALU issue slots this launch used
+                valu = {"wave_instructions": insts, "issue_frac": insts * 4.0 / (1024 * 2.4e9 * t_bwd),
+                        "note": "SQ_INSTS_VALU (own --pmc pass, profiles/pmc_raster_bwd.json) x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)"}
         except (OSError, ValueError):
             traffic = None
     return {"bound": "hbm", "kernel": "raster_ges_bwd_gs_kernel", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
-            "frac": ach / hbm_peak_gbs, "traffic": traffic, "avg_launch_us": t_bwd * 1e6,
+            "frac": ach / hbm_peak_gbs, "traffic": traffic, "valu": valu, "avg_launch_us": t_bwd * 1e6,
             "algorithmic_bytes": alg_bwd, "units": {"n_groups": ng, "pixels": P, "n_isects": ni, "gaussians": N,
                                                     "n_visible": nvis},
             "note": "rasterization is ALU/LDS-issue bound (exp + ~40 flop per pixel-Gaussian pair), not a stream; "
