@@ -92,6 +92,8 @@ PROTOTYPES = {
     "gps_tsdf_track_camera": (i32, [C.POINTER(TsdfState), C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64, vp]),
     "gps_tsdf_process_frame_tracked": (i32, [C.POINTER(TsdfState), vp, C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64,
                                              vp]),
+    "gps_tsdf_process_frame_tracked_gated": (i32, [C.POINTER(TsdfState), vp, C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64,
+                                                   vp, vp, vp]),
     "gps_tsdf_convert_depth": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_allocate": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
     "gps_tsdf_integrate": (i32, [C.POINTER(TsdfState), vp, vp]),

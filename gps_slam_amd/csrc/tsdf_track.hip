@@ -486,6 +486,12 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
 
 int gps_tsdf_process_frame_tracked(const gps_tsdf_state* s, const int16_t* depth_mm, const gps_track_config* cfg,
                                    gps_track_state* ts, void* scratch, int64_t scratch_bytes, gps_stream stream) {
+    return gps_tsdf_process_frame_tracked_gated(s, depth_mm, cfg, ts, scratch, scratch_bytes, stream, nullptr, nullptr);
+}
+
+int gps_tsdf_process_frame_tracked_gated(const gps_tsdf_state* s, const int16_t* depth_mm, const gps_track_config* cfg,
+                                         gps_track_state* ts, void* scratch, int64_t scratch_bytes, gps_stream stream,
+                                         void (*before_fusion)(void*), void* user) {
     GPS_REQUIRE(s && depth_mm && cfg && ts);
     int r;
     if ((r = gps_tsdf_convert_depth(s, depth_mm, stream)) != GPS_OK) return r;
@@ -493,6 +499,7 @@ int gps_tsdf_process_frame_tracked(const gps_tsdf_state* s, const int16_t* depth
         if (ts->age_point_cloud >= 0) ts->frames_processed++; else ts->frames_processed = 0;
         if ((r = gps_tsdf_track_camera(s, cfg, ts, scratch, scratch_bytes, stream)) != GPS_OK) return r;
     }
+    if (before_fusion) before_fusion(user);  // everything above only READ the volume; what follows modifies it
     if ((r = gps_tsdf_allocate(s, ts->pose_M, ts->pose_invM, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_integrate(s, ts->pose_M, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_expected_depths(s, ts->pose_M, 0, stream)) != GPS_OK) return r;

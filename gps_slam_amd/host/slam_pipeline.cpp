@@ -323,8 +323,12 @@ void SLAMPipeline::keyframeStepOverlapped() {
     // a few iterations now, the rest a few at a time from the following processFrame calls: enqueueing all 20 at once keeps the
     // host (and with it the frame stream) busy for ~1 ms while the map stream only needs to stay ahead of the GPU
     pumpMapping(pump_iters_first);
-    // the next frames' fusion must not modify the volume (or reuse the engine's free-view scratch) before the raycasts read it
-    hip_ok(hipStreamWaitEvent(frames, (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+    // the next frame's fusion must not modify the volume (or reuse the engine's free-view scratch) before the raycasts read it;
+    // its tracking may overlap them: the wait sits in the engine's before-fusion hook
+    (void)frames;
+    main_engine->beforeNextFusion = [this] {
+        hip_ok(hipStreamWaitEvent(c10::hip::getCurrentHIPStream().stream(), (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+    };
 }
 
 // ------------------------------------------------------------------ mapping thread
@@ -347,9 +351,19 @@ void SLAMPipeline::keyframeStepThreaded() {
     job_.poses = main_engine->camPoses;
     job_seq_++;
     cv_.notify_all();
-    cv_.wait(lk, [&] { return raycasts_seq_ == job_seq_ || worker_error_; });
-    if (worker_error_) { lk.unlock(); rethrowWorkerError(); }
-    hip_ok(hipStreamWaitEvent(frames, (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+    // The next frame's fusion must not modify the volume (or reuse the engine's free-view scratch) before the update's raycasts
+    // have read it -- but its TRACKING may run meanwhile: the wait (for the worker to have recorded the event, then the
+    // stream-side wait on it) is deferred to the engine's before-fusion hook of the next ProcessFrame.
+    const int64_t want = job_seq_;
+    (void)frames;
+    main_engine->beforeNextFusion = [this, want] {
+        {
+            std::unique_lock<std::mutex> lk2(mu_);
+            cv_.wait(lk2, [&] { return raycasts_seq_ >= want || worker_error_; });
+        }
+        rethrowWorkerError();
+        hip_ok(hipStreamWaitEvent(c10::hip::getCurrentHIPStream().stream(), (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+    };
 }
 
 void SLAMPipeline::mapWorker(int device_index) {
@@ -407,6 +421,7 @@ void SLAMPipeline::pumpMapping(int count) {
 }
 
 void SLAMPipeline::flush() {
+    main_engine->beforeNextFusion = nullptr;  // no further frame: everything is joined below anyway
     if (worker_.joinable()) {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return done_seq_ == job_seq_ || worker_error_; });

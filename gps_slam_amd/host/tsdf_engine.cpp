@@ -96,8 +96,12 @@ ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, cons
     state_.rgb = ptr<uint8_t>(rgb_u8);
     if (trackingActive) {
         if (!track_scratch_.defined()) turnOnTracking();  // ITMLibSettings defaults
-        check(gps_tsdf_process_frame_tracked(&state_, ptr<int16_t>(depth_mm_i16), &track_cfg_, &track_state_,
-                                             track_scratch_.data_ptr(), track_scratch_.numel(), current_stream()),
+        std::function<void()> gate;
+        gate.swap(beforeNextFusion);
+        check(gps_tsdf_process_frame_tracked_gated(&state_, ptr<int16_t>(depth_mm_i16), &track_cfg_, &track_state_,
+                                                   track_scratch_.data_ptr(), track_scratch_.numel(), current_stream(),
+                                                   gate ? +[](void* f) { (*static_cast<std::function<void()>*>(f))(); } : nullptr,
+                                                   gate ? &gate : nullptr),
               "gps_tsdf_process_frame_tracked");
         pose_d_.SetBoth(track_state_.pose_M, track_state_.pose_invM);
     } else {
@@ -105,6 +109,7 @@ ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, cons
         auto c2w = gtC2wPoses[framesProcessed].to(torch::kCPU, torch::kFloat32).contiguous();
         pose_d_.SetInvM(c2w.data_ptr<float>());
         pose_d_.Coerce();
+        if (beforeNextFusion) { std::function<void()> gate; gate.swap(beforeNextFusion); gate(); }
         check(gps_tsdf_process_frame(&state_, ptr<int16_t>(depth_mm_i16), pose_d_.GetM(), pose_d_.GetInvM(),
                                      current_stream()), "gps_tsdf_process_frame");
     }

@@ -7,6 +7,8 @@
 // slam_pipeline-style code reads the same: ProcessFrame, runRaycast, GetFreeImage, GetFreeVertex, getVoxelSize,
 // GetTrackingState()->pose_d->GetInvM(), camPoses, gtC2wPoses.
 #pragma once
+#include <functional>
+
 #include "gps_host_common.hpp"
 
 enum MemoryDeviceType { MEMORYDEVICE_CPU, MEMORYDEVICE_CUDA };
@@ -93,6 +95,10 @@ public:
                         float outlierSpaceF = 0.004f, float minstep = 1e-4f, float tukeyCutOff = 8.0f, int framesToSkip = 20,
                         int framesToWeight = 50);
     const gps_track_state& trackState() const { return track_state_; }
+
+    // One-shot hook for the next ProcessFrame: called on the calling thread after the frame's tracking and before its fusion
+    // (gps_tsdf_process_frame_tracked_gated); with given poses it runs right before the fusion kernels are enqueued.
+    std::function<void()> beforeNextFusion;
 
     std::vector<ORUtils::SE3Pose> camPoses;       // pose used for every processed frame
     std::vector<torch::Tensor> gtC2wPoses;         // dataset poses, [4,4] float CPU tensors (push before ProcessFrame)

@@ -540,6 +540,14 @@ GPS_API int gps_tsdf_track_camera(const gps_tsdf_state *s, const gps_track_confi
 GPS_API int gps_tsdf_process_frame_tracked(const gps_tsdf_state *s, const int16_t *depth_mm, const gps_track_config *cfg,
                                            gps_track_state *ts, void *scratch, int64_t scratch_bytes, gps_stream stream);
 
+/* Same, with a hook between the part of the frame that only READS the voxel volume (depth conversion, tracking) and the part
+ * that modifies it (allocate, integrate, ...): before_fusion(user), if not NULL, is called on the calling thread at that point.
+ * A pipeline that renders free views of the volume on another stream passes a callback that makes `stream` wait for them
+ * (hipStreamWaitEvent), so that the next frame's tracking overlaps those raycasts instead of queueing behind them. */
+GPS_API int gps_tsdf_process_frame_tracked_gated(const gps_tsdf_state *s, const int16_t *depth_mm, const gps_track_config *cfg,
+                                                 gps_track_state *ts, void *scratch, int64_t scratch_bytes, gps_stream stream,
+                                                 void (*before_fusion)(void *user), void *user);
+
 #ifdef __cplusplus
 }
 #endif
