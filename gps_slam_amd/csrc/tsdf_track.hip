@@ -63,11 +63,44 @@ __device__ __forceinline__ float4 bilinear_with_holes(const float4* __restrict__
     return r;
 }
 
+// The scene side as the tracker reads it: point and normal of a pixel in ONE 32-byte record (pn[2i], pn[2i+1]).  The two maps
+// are separate arrays in gps_tsdf_state (ICP maps, API-visible); gathering a bilinear footprint from both touches 4 + 4 cache
+// lines in two dependent phases (normals only after the distance test).  Interleaved, the footprint is 2 x 64 contiguous bytes
+// fetched in one phase -- half the lines to keep in (or re-fetch into) an L2 the map stream's rasterizer kernels keep sweeping.
+__global__ __launch_bounds__(256) void interleave_maps_kernel(const float4* __restrict__ points, const float4* __restrict__ normals,
+                                                             int n, float4* __restrict__ pn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pn[2 * i] = points[i];
+    pn[2 * i + 1] = normals[i];
+}
+
+__device__ __forceinline__ float4 bilerp4(const float4 a, const float4 b, const float4 c, const float4 d, float dx, float dy) {
+    if (a.w < 0 || b.w < 0 || c.w < 0 || d.w < 0) return make_float4(0.f, 0.f, 0.f, -1.0f);
+    float4 r;
+    r.x = (a.x * (1.0f - dx) * (1.0f - dy) + b.x * dx * (1.0f - dy) + c.x * (1.0f - dx) * dy + d.x * dx * dy);
+    r.y = (a.y * (1.0f - dx) * (1.0f - dy) + b.y * dx * (1.0f - dy) + c.y * (1.0f - dx) * dy + d.y * dx * dy);
+    r.z = (a.z * (1.0f - dx) * (1.0f - dy) + b.z * dx * (1.0f - dy) + c.z * (1.0f - dx) * dy + d.z * dx * dy);
+    r.w = (a.w * (1.0f - dx) * (1.0f - dy) + b.w * dx * (1.0f - dy) + c.w * (1.0f - dx) * dy + d.w * dx * dy);
+    return r;
+}
+
+// interpolateBilinear_withHoles of the point map and of the normal map at the same position (each with its own hole rule)
+__device__ __forceinline__ void bilinear_pair_with_holes(const float4* __restrict__ pn, float px, float py, int W, float4& cp, float4& n) {
+    const short ix = (short)floorf(px), iy = (short)floorf(py);
+    const float dx = px - (float)ix, dy = py - (float)iy;
+    const float4* r0 = pn + 2 * (ix + iy * W);
+    const float4* r1 = pn + 2 * (ix + (iy + 1) * W);
+    const float4 pa = r0[0], na = r0[1], pb = r0[2], nb = r0[3], pc = r1[0], nc = r1[1], pd = r1[2], nd = r1[3];
+    cp = bilerp4(pa, pb, pc, pd, dx, dy);
+    n = bilerp4(na, nb, nc, nd, dx, dy);
+}
+
 struct GhArgs {
     const float* depth;
     int vw, vh;
     float4 view_intr;
-    const float4 *points, *normals;
+    const float4* pn;  // interleaved point | normal records (interleave_maps_kernel)
     int sw, sh;
     float4 scene_intr;
     Mat4 approxInvPose, scenePose;
@@ -91,12 +124,12 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
     const float u = a.scene_intr.x * qx / qz + a.scene_intr.z;
     const float v = a.scene_intr.y * qy / qz + a.scene_intr.w;
     if (!((u >= 0.0f) && (u <= a.sw - 2) && (v >= 0.0f) && (v <= a.sh - 2))) return;
-    const float4 cp = bilinear_with_holes(a.points, u, v, a.sw);
+    float4 cp, n;
+    bilinear_pair_with_holes(a.pn, u, v, a.sw, cp, n);
     if (cp.w < 0.0f) return;
     const float dx = cp.x - tx, dy = cp.y - ty, dz = cp.z - tz;
     const float dist = dx * dx + dy * dy + dz * dz;
     if (dist > a.tukey_cutoff * a.space_thresh) return;
-    const float4 n = bilinear_with_holes(a.normals, u, v, a.sw);
     float w = fmaxf(0.0f, 1.0f - (depth - a.vf_min) / (a.vf_max - a.vf_min));
     w *= w;
     if (a.use_weights) {
@@ -264,6 +297,7 @@ struct Scratch {
     float* level[GPS_TRACK_MAX_LEVELS];  // [0] unused (= s.depth)
     float *partial, *result;
     int* count;
+    float4* pn;
 };
 
 size_t carve(Scratch* w, char* base, int W, int H) {
@@ -278,6 +312,7 @@ size_t carve(Scratch* w, char* base, int W, int H) {
     char* p = take((size_t)GH_MAX_WGS * GH_SLOTS * sizeof(float)); if (w) w->partial = (float*)p;
     p = take(GH_SLOTS * sizeof(float)); if (w) w->result = (float*)p;
     p = take(sizeof(int)); if (w) w->count = (int*)p;
+    p = take((size_t)W * H * 2 * sizeof(float4)); if (w) w->pn = (float4*)p;
     return off;
 }
 
@@ -349,6 +384,8 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     }
     if (hipMemsetAsync(w.count, 0, sizeof(int), st) != hipSuccess) return GPS_ERR_LAUNCH;
     count_valid_kernel<<<128, 256, 0, st>>>(s.depth, W * H, w.count);
+    interleave_maps_kernel<<<gps_div_up(W * H, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(s.icp_points),
+                                                                    reinterpret_cast<const float4*>(s.icp_normals), W * H, w.pn);
     GPS_LAUNCH_CHECK();
 
     float hessian_good[36] = {0}, nabla_good[6] = {0}, hessian_depth_good[36] = {0}, f_depth_good = 0;
@@ -375,7 +412,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             GhArgs a;
             a.depth = dl[level]; a.vw = lw[level]; a.vh = lh[level];
             a.view_intr = make_float4(lintr[level][0], lintr[level][1], lintr[level][2], lintr[level][3]);
-            a.points = reinterpret_cast<const float4*>(s.icp_points); a.normals = reinterpret_cast<const float4*>(s.icp_normals);
+            a.pn = w.pn;
             a.sw = W; a.sh = H;
             a.scene_intr = make_float4(lintr[0][0], lintr[0][1], lintr[0][2], lintr[0][3]);
             a.approxInvPose = load_mat(approxInvPose); a.scenePose = load_mat(ts->pose_pc_M);
