@@ -107,10 +107,11 @@ public:
     // Tracking / mapping overlap.  The reference runs a keyframe's map update (raycasts, new Gaussians, 20 optimise iterations,
     // prune) to completion before it looks at the next frame.  Nothing in frames i+1 .. i+9 reads the Gaussian model, and the
     // model update reads the TSDF volume only through the free-view raycasts at its start -- so with overlap_mapping the
-    // update runs on a second HIP stream while the caller's stream tracks and fuses the following frames (the latency-bound
+    // update runs on a second HIP stream while a high-priority stream tracks and fuses the following frames (the latency-bound
     // LM loop of the tracker fits into the shadow of the throughput-bound rasterizer kernels).  Ordering is kept with events:
-    // map stream waits for frame i's fusion; the caller's stream waits for the raycasts before it fuses frame i+1; the next
-    // keyframe waits for the previous update; the prune of update k runs at the start of update k+1 (or in flush()).
+    // map stream waits for frame i's fusion; frame i+1 may TRACK at once but waits for the raycasts before it fuses
+    // (ITMBasicEngine::beforeNextFusion); the next keyframe waits for the previous update; without a mapping thread the prune
+    // of update k runs at the start of update k+1 (or in flush()).
     // Results are those of the sequential schedule.  Off by default: with it on, processFrame() returns while the update is
     // still in flight and the model may only be read after flush() (SLAMTrainCams and the accessors below call it).
     bool overlap_mapping = false;
