@@ -299,9 +299,13 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
             ad.sstep[k] = small_step[k];
         }
     }
-    const int threads = fuse ? GPS_FUSED_ADAM_THREADS : 256;
+    // parameter (+ gradient) rows of the workgroup's Gaussians live in LDS: halve the workgroup until they fit 64 KB
+    // (K = 16: 256 / 128 threads; K = 25, SH degree 4: 128 / 64 threads).  rows * threads stays a multiple of 4 floats.
+    int threads = fuse ? GPS_FUSED_ADAM_THREADS : 256;
+    auto lds_bytes = [&](int t) { return (size_t)t * (K - 1) * 3 * sizeof(float) * (fuse ? 2 : 1); };
+    while (threads > 64 && lds_bytes(threads) > 65536) threads >>= 1;
     dim3 g(gps_div_up(N, threads)), b(threads);
-    const size_t lds = (size_t)threads * (K - 1) * 3 * sizeof(float) * (fuse ? 2 : 1);  // parameter (+ gradient) rows
+    const size_t lds = lds_bytes(threads);
     GPS_REQUIRE(lds <= 65536);
     hipStream_t s = (hipStream_t)stream;
 #define GPS_BWD(D)                                                                                                 \

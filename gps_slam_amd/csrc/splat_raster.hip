@@ -20,8 +20,6 @@
 // reduces (within the 32-lane half) + atomically adds when the Gaussian changes:
 // ~N_visible x 10 atomics instead of n_groups x 10.  Pixel/box semantics
 // (int() truncation, +1 offsets, i > y_max guard) are the reference's.
-#include <stdlib.h>
-
 #include "common.hpp"
 
 namespace {
@@ -95,166 +93,9 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_ges_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Forward, record-streaming variant used by the fused model path.
-//
-// Every lane of a wave needs the SAME Gaussian record, so the record does not have to go through LDS or VGPRs at
-// all: it is fetched with SCALAR loads (s_load_dwordx4 through the per-CU scalar cache) into SGPRs and the per-pixel
-// VALU ops take the SGPRs as operands.  Each wave64 (a 16x4 pixel strip) walks the tile's sorted list on its own:
-//   * 64 Gaussian ids per coalesced vector load, broadcast one at a time with v_readlane;
-//   * the 48-byte packed record {xy, conic, opac, depth, rgb, extent} of the NEXT Gaussian is requested while the
-//     current one is evaluated (1-deep software prefetch of the dependent id -> record chain);
-//   * wave-uniform culling: the record carries the half-extents of the region where opac*exp(-sigma) >= 1/255
-//     (inflated by 1 % + 0.01 px); if that box misses the wave's strip the whole pair evaluation is skipped with a
-//     scalar branch.  The test is conservative, so the result equals the un-culled loop.
-// No LDS, no __syncthreads: the 4 waves of a tile never wait for each other.
-// record = 3 x float4: a = {mx, my, ca, cb}  b = {cc, opac, depth, r}  c = {g, b, xbounds, ybounds}, the bounds being
-// two int16 pixel indices each (lo | hi << 16), see pack_record() in splat_math.hpp
-
-__global__ __launch_bounds__(256) void raster_ges_fwd_rec_kernel(const float4* __restrict__ recs,
-                                                                const float* __restrict__ ref_depth, int W, int H,
-                                                                int tw, int th,
-                                                                const int32_t* __restrict__ tile_offsets,
-                                                                const int32_t* __restrict__ flatten_ids,
-                                                                const int64_t* __restrict__ counts, float delta_depth,
-                                                                float4* __restrict__ render_colors,
-                                                                float* __restrict__ render_alphas) {
-    const int tile_id = blockIdx.x;
-    const int ty = tile_id / tw, tx = tile_id - ty * tw;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = ty * 16 + wave * 4 + (lane >> 4), j = tx * 16 + (lane & 15);
-    const bool inside = (i < H) && (j < W);
-    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-    const int pix = i * W + j;
-    // first pixel column / row of this wave's 16x4 strip (wave uniform, kept in SGPRs)
-    const int col0 = tx * 16, row0 = __builtin_amdgcn_readfirstlane(ty * 16 + wave * 4);
-
-    const int n_isects = (int)counts[0];
-    const int range_start = tile_offsets[tile_id];
-    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
-    const float cut = inside ? ref_depth[pix] + delta_depth : -3.0e38f;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, wsum = 0.f;
-
-    for (int base = range_start; base < range_end; base += 64) {
-        const int cnt = min(64, range_end - base);
-        const int my_id = (lane < cnt) ? flatten_ids[base + lane] : 0;
-        int g = __builtin_amdgcn_readlane(my_id, 0);
-        float4 ra = recs[3 * (size_t)g], rb = recs[3 * (size_t)g + 1], rc = recs[3 * (size_t)g + 2];
-        for (int t = 0; t < cnt; ++t) {
-            const float4 a = ra, b = rb, c = rc;
-            float4 na = a, nb = b, nc = c;
-            if (t + 1 < cnt) {  // request the next record now (uniform id -> scalar loads) ...
-                g = __builtin_amdgcn_readlane(my_id, (t + 1) & 63);
-                na = recs[3 * (size_t)g]; nb = recs[3 * (size_t)g + 1]; nc = recs[3 * (size_t)g + 2];
-            }
-            __builtin_amdgcn_sched_barrier(0);  // ... and do not let the register hand-over below move up to it
-            // conservative wave-level cull: integer pixel bounds of the alpha >= 1/255 box, scalar compares
-            const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
-            const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16;
-            const int y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
-            if (!(x_hi < col0 || x_lo > col0 + 15 || y_hi < row0 || y_lo > row0 + 3)) {
-                const float dx = a.x - px, dy = a.y - py;
-                const float sigma = 0.5f * (a.z * dx * dx + b.x * dy * dy) + a.w * dx * dy;
-                const float alpha = fminf(0.999f, b.y * __expf(-sigma));
-                const bool hit = !(b.z > cut) && !(sigma < 0.f) && !(alpha < 1.f / 255.f);
-                if (hit) {
-                    o0 += b.w * alpha; o1 += c.x * alpha; o2 += c.y * alpha; o3 += b.z * alpha;
-                    wsum += alpha;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ra = na; rb = nb; rc = nc;
-        }
-    }
-    if (inside) {
-        render_colors[pix] = make_float4(o0, o1, o2, o3);
-        render_alphas[pix] = wsum;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Forward, LDS-staged records + wave-level culling + PPT pixels per lane (fused model path, experimental variants).
-// records = the packed 48-byte per-Gaussian records of gps_gauss_preprocess_fwd (incl. int16 pixel bounds of the
-// alpha >= 1/255 box).  A wave covers a 16 x (4*PPT) pixel region: lane -> column (lane & 15), rows
-// (lane >> 4) * PPT + k.  The bounds test is wave-uniform (all lanes read the same LDS word), so a skipped Gaussian
-// costs one ds_read_b64 + ~6 VALU instead of the ~25-instruction pair evaluation per pixel.
-template <int PPT, bool CULL>
-__global__ __launch_bounds__(256 / PPT) void raster_ges_fwd_v2_kernel(
-    const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
-    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
-    float* __restrict__ render_alphas) {
-    constexpr int THREADS = 256 / PPT;
-    constexpr int BATCH = 256;
-    __shared__ float4 r0[BATCH + 1];
-    __shared__ float4 r1[BATCH + 1];
-    __shared__ float4 r2[BATCH + 1];
-    const int tile_id = blockIdx.x;
-    const int ty = tile_id / tw, tx = tile_id - ty * tw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = tx * 16 + (lane & 15);
-    const int row_base = ty * 16 + wave * (4 * PPT) + (lane >> 4) * PPT;  // first of this lane's PPT rows
-    const int wrow0 = ty * 16 + wave * (4 * PPT), wrow1 = wrow0 + 4 * PPT - 1, col0 = tx * 16;
-    const float px = (float)j + 0.5f;
-    float py[PPT], cut[PPT], o0[PPT], o1[PPT], o2[PPT], o3[PPT], ws[PPT];
-    bool inside[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        const int i = row_base + k;
-        inside[k] = (i < H) && (j < W);
-        py[k] = (float)i + 0.5f;
-        cut[k] = inside[k] ? ref_depth[i * W + j] + delta_depth : -3.0e38f;
-        o0[k] = o1[k] = o2[k] = o3[k] = ws[k] = 0.f;
-    }
-    const int n_isects = (int)counts[0];
-    const int range_start = tile_offsets[tile_id];
-    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
-
-    for (int batch_start = range_start; batch_start < range_end; batch_start += BATCH) {
-        __syncthreads();
-        for (int q = tid; q < BATCH; q += THREADS) {
-            const int idx = batch_start + q;
-            if (idx < range_end) {
-                const int g = flatten_ids[idx];
-                r0[q] = recs[3 * (size_t)g]; r1[q] = recs[3 * (size_t)g + 1]; r2[q] = recs[3 * (size_t)g + 2];
-            }
-        }
-        __syncthreads();
-        const int batch_size = min(BATCH, range_end - batch_start);
-        // software pipeline: record t+1 is read from LDS while record t is evaluated (the arrays have one spare slot)
-        float4 a = r0[0], b = r1[0], c = r2[0];
-        for (int t = 0; t < batch_size; ++t) {
-            const float4 na = r0[t + 1], nb = r1[t + 1], nc = r2[t + 1];
-            const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
-            const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16;
-            const int y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
-            const bool skip = CULL && (x_hi < col0 || x_lo > col0 + 15 || y_hi < wrow0 || y_lo > wrow1);  // wave uniform
-            if (!skip) {
-                const float dx = a.x - px;
-                const float adx2 = a.z * dx * dx, bdx = a.w * dx;
-#pragma unroll
-                for (int k = 0; k < PPT; k++) {
-                    const float dy = a.y - py[k];
-                    const float sigma = 0.5f * (adx2 + b.x * dy * dy) + bdx * dy;
-                    const float alpha = fminf(0.999f, b.y * __expf(-sigma));
-                    const bool hit = !(b.z > cut[k]) && !(sigma < 0.f) && !(alpha < 1.f / 255.f);
-                    const float al = hit ? alpha : 0.f;
-                    o0[k] += b.w * al; o1[k] += c.x * al; o2[k] += c.y * al; o3[k] += b.z * al; ws[k] += al;
-                }
-            }
-            a = na; b = nb; c = nc;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < PPT; k++)
-        if (inside[k]) {
-            const int pix = (row_base + k) * W + j;
-            render_colors[pix] = make_float4(o0[k], o1[k], o2[k], o3[k]);
-            render_alphas[pix] = ws[k];
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Forward, packed-math variant (the fused path's default).  The pair evaluation is VALU bound (PMC: ~23 wave
+// Forward from the packed per-Gaussian records of gps_gauss_preprocess_fwd (the fused model path), packed math.
+// record = 3 x float4: a = {mx, my, ca, cb}  b = {cc, opac, depth, r}  c = {g, b, xbounds, ybounds}, see pack_record() in
+// splat_math.hpp.  The pair evaluation is VALU bound (PMC: ~23 wave
 // instructions per Gaussian x 64-pixel strip), so the lever is instructions per pixel:
 //   * each lane owns TWO horizontally adjacent pixels and evaluates them with v_pk_{add,mul,fma}_f32 -- dy, c*dy^2 and
 //     b*dy are shared by the pair, everything in dx and the five accumulators are 2-wide: ~25 VALU per Gaussian for
@@ -449,13 +290,9 @@ __device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, 
     const int i = R.y0 + q;
     if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw))) return;
     const int pix = i * W + j;
-#ifdef GPS_EXP_NO_GATHER
-    const float rd = 1000.f; o.vc = make_float4(0.1f, 0.2f, 0.3f, (float)pix * 1e-9f); o.va = 0.5f;
-#else
     const float rd = ref_depth[pix];
     o.vc = v_render_colors[pix];
     o.va = v_render_alphas[pix];
-#endif
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     o.dx = R.x - px; o.dy = R.y - py;
     const float sigma = 0.5f * (R.ca * o.dx * o.dx + R.cc * o.dy * o.dy) + R.cb * o.dx * o.dy;
@@ -581,19 +418,9 @@ int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_m
     GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
     GPS_REQUIRE(N == 0 || records);
     const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
-    static const int variant = getenv("GPS_RASTER_FWD_VARIANT") ? atoi(getenv("GPS_RASTER_FWD_VARIANT")) : 5;
-    hipStream_t st = (hipStream_t)stream;
-#define GPS_V2ARGS (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, \
-                   delta_depth, (float4*)render_colors, render_alphas
-    switch (variant) {
-        case 0: raster_ges_fwd_rec_kernel<<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;   // scalar-load streaming
-        case 1: raster_ges_fwd_v2_kernel<1, true><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;   // LDS + cull, 1 px/lane
-        case 4: raster_ges_fwd_v2_kernel<4, false><<<tw * th, 64, 0, st>>>(GPS_V2ARGS); break;   // 4 px/lane, 1 wave/tile
-        case 2: raster_ges_fwd_v2_kernel<2, true><<<tw * th, 128, 0, st>>>(GPS_V2ARGS); break;   // LDS + cull, 2 px/lane
-        case 3: raster_ges_fwd_v2_kernel<1, false><<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;  // LDS, no cull
-        default: raster_ges_fwd_pk_kernel<<<tw * th, 256, 0, st>>>(GPS_V2ARGS); break;           // packed math, 2 px/lane
-    }
-#undef GPS_V2ARGS
+    raster_ges_fwd_pk_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>(
+        (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
+        (float4*)render_colors, render_alphas);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -613,7 +440,7 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
     if (!accumulate)
         zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
                                                                                      v_opacities);
-    static const int bwd_blocks = getenv("GPS_BWD_BLOCKS") ? atoi(getenv("GPS_BWD_BLOCKS")) : 4096;
+    constexpr int bwd_blocks = 4096;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
     raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
                                                   (const float4*)colors, opacities, radii, ref_depth_map, counts,
                                                   delta_depth, width, height, (const float4*)v_render_colors,

@@ -224,6 +224,9 @@ class RawGaussianModel:
         self.opt_gs_params = RawGaussianParams(device, capacity=cfg.get("capacity", 1 << 19),
                                                sh_k=numShBases(self.maxSH))
         self.isect_capacity = cfg.get("isect_capacity", None)
+        # gps_splat_step.fuse_sh_rest_adam: 0 = gradients are written and a separate Adam kernel steps (grads() is valid),
+        # 2 = what the C++ host runs (host/raw_gs_model.cpp): every tensor stepped inside the backward kernel
+        self.fuse_adam = int(cfg.get("fuse_sh_rest_adam", 0))
         self._opt = None       # Adam state: capacity-sized m / v / g buffers + step count
         self._step = None      # persistent gps_splat_step
         self._step_key = None
@@ -271,6 +274,7 @@ class RawGaussianModel:
                     setattr(st, name, t.data_ptr())
             st.isect_capacity, st.group_capacity, st.workspace_bytes = icap, gcap, B["workspace"].numel()
             st.beta1, st.beta2, st.adam_eps = 0.9, 0.999, 1e-15
+            st.fuse_sh_rest_adam = self.fuse_adam
             self._step, self._step_key, self._B = st, key, B
         st = self._step
         st.N = p.N

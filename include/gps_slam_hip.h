@@ -116,9 +116,10 @@ GPS_API int gps_raster_ges_fwd(int N, const float *means2d, const float *conics,
                        float delta_depth, float *render_colors, float *render_alphas, int32_t *last_ids,
                        gps_stream stream);
 
-/* Same result as gps_raster_ges_fwd from the packed records written by gps_gauss_preprocess_fwd: every wave64 streams
- * the tile's list with scalar loads (no LDS, no barriers) and skips, with a conservative wave-uniform test, Gaussians
- * whose alpha >= 1/255 box misses its 16x4 pixel strip. */
+/* Same operator (rasterize_to_pixels_fwd_ges.cu:223-407) fed by the packed 48-byte records gps_gauss_preprocess_fwd writes
+ * instead of the four per-Gaussian arrays: the forward the fused model path (gps_splat_render / gps_splat_train_step) runs.
+ * 256-record LDS batches, two pixels per lane with packed fp32 math, alpha = exp2 of a pre-scaled exponent; agrees with
+ * gps_raster_ges_fwd to float rounding (tests/test_splat_gpu.py). */
 GPS_API int gps_raster_ges_fwd_rec(int N, const float *records, const float *ref_depth_map, int width, int height,
                                    const int32_t *tile_offsets, const int32_t *flatten_ids, const int64_t *counts,
                                    float delta_depth, float *render_colors, float *render_alphas, gps_stream stream);

@@ -615,6 +615,132 @@ ORC_API void orc_raster_ges_bwd_gs(int W, int H, int64_t n_groups, float delta_d
 }
 
 /*
+ * Decision-margin accounting for the two kernels above (test infrastructure only; not a restatement of reference code).
+ * A (pixel, Gaussian) pair is accepted iff !(depth > ref + delta) && !(sigma < 0) && !(alpha < 1/255).  An implementation
+ * that evaluates exp() with different rounding (__expf, exp2 with folded constants) can decide a pair differently from
+ * expf only when opac*exp(-sigma) lies within `rel_band` (relative) of 1/255, or the Gaussian's depth within `rel_band`
+ * (relative) of the cut.  These functions list what such flips could change:
+ *   forward : budget[H,W,5] = sum over the pixel's borderline pairs of |c_q| * alpha (q = 0..3) and alpha (q = 4);
+ *             n_pairs[0] = number of borderline pairs, n_pairs[1] = number of pixels that have one.
+ *   backward: budget[N,10] = sum over the Gaussian's borderline pixel slots of the absolute value of the slot's
+ *             contribution to {v_colors[4], v_conics[3], v_means2d[2], v_opacities}; n_pairs as above (per Gaussian).
+ * rel_band < 0 selects a second mode: the same sums over the ACCEPTED pairs instead of the borderline ones, i.e.
+ * sum |term| of every output -- the scale a summation-order / exp-rounding tolerance is relative to.
+ */
+static int borderline(float opac, float vis, float depth, float cut, float rel_band) {
+    const float t = 1.f / 255.f;
+    float a = opac * vis;
+    if (fabsf(a - t) <= rel_band * t) return 1;
+    if (fabsf(depth - cut) <= rel_band * fabsf(cut)) return 1;
+    return 0;
+}
+
+ORC_API void orc_raster_ges_fwd_flip_budget(int W, int H, int tile_size, int tw, int th, int64_t n_isects,
+                                            float delta_depth, const float *means2d, const float *conics,
+                                            const float *colors, const float *opacities, const float *ref_depth,
+                                            const int32_t *tile_offsets, const int32_t *flatten_ids, float rel_band,
+                                            float *budget, int64_t *n_pairs) {
+    n_pairs[0] = n_pairs[1] = 0;
+    for (int ty = 0; ty < th; ty++)
+        for (int tx = 0; tx < tw; tx++) {
+            int tile_id = ty * tw + tx;
+            int32_t rs = tile_offsets[tile_id];
+            int32_t re = (tile_id == tw * th - 1) ? (int32_t)n_isects : tile_offsets[tile_id + 1];
+            for (int ly = 0; ly < tile_size; ly++)
+                for (int lx = 0; lx < tile_size; lx++) {
+                    int i = ty * tile_size + ly, j = tx * tile_size + lx;
+                    if (i >= H || j >= W) continue;
+                    float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                    int pix = i * W + j;
+                    float cut = ref_depth[pix] + delta_depth;
+                    float *b = budget + 5 * (size_t)pix;
+                    int any = 0;
+                    for (int q = 0; q < 5; q++) b[q] = 0.f;
+                    for (int32_t k = rs; k < re; k++) {
+                        int32_t g = flatten_ids[k];
+                        const float *c = colors + 4 * (size_t)g;
+                        float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                        float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                        float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                        if (sigma < 0.f) continue;
+                        float vis = expf(-sigma);
+                        float alpha = fminf(0.999f, opacities[g] * vis);
+                        if (rel_band < 0.f) {
+                            if (c[3] > cut || alpha < 1.f / 255.f) continue;
+                        } else {
+                            if (!borderline(opacities[g], vis, c[3], cut, rel_band)) continue;
+                            /* a depth-borderline pair only matters if it would pass the alpha test (and vice versa) */
+                            if (alpha < (1.f - rel_band) / 255.f || c[3] > cut + rel_band * fabsf(cut)) continue;
+                        }
+                        for (int q = 0; q < 4; q++) b[q] += fabsf(c[q]) * alpha;
+                        b[4] += alpha;
+                        any = 1;
+                        n_pairs[0]++;
+                    }
+                    n_pairs[1] += any;
+                }
+        }
+}
+
+ORC_API void orc_raster_ges_bwd_gs_flip_budget(int W, int H, int N, int64_t n_groups, float delta_depth,
+                                               const int32_t *group_gs_ids, const int32_t *group_starts,
+                                               const float *means2d, const float *conics, const float *colors,
+                                               const float *opacities, const int32_t *radiis, const float *ref_depth,
+                                               const float *v_render_colors, const float *v_render_alphas,
+                                               float rel_band, float *budget, int64_t *n_pairs) {
+    memset(budget, 0, sizeof(float) * 10 * (size_t)N);
+    n_pairs[0] = n_pairs[1] = 0;
+    int32_t last_counted = -1;
+    for (int64_t gid = 0; gid < n_groups; gid++) {
+        int32_t g = group_gs_ids[gid];
+        int32_t r = radiis[g];
+        float x = means2d[2 * g], y = means2d[2 * g + 1];
+        float opac = opacities[g];
+        float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+        const float *rgb = colors + 4 * (size_t)g;
+        int32_t x_min = (int32_t)x - r, x_max = (int32_t)x + r;
+        int32_t y_min = (int32_t)y - r, y_max = (int32_t)y + r;
+        uint32_t gstart = (uint32_t)group_starts[gid];
+        float *b = budget + 10 * (size_t)g;
+        for (uint32_t lane = 0; lane < 32; lane++) {
+            uint32_t pid = ((uint32_t)gid - gstart) * 32u + lane;
+            int32_t j = x_min + 1 + (int32_t)(pid % (uint32_t)(x_max - x_min));
+            int32_t i = y_min + 1 + (int32_t)(pid / (uint32_t)(x_max - x_min));
+            if (!(i < H && j < W && i >= 0 && j >= 0) || i > y_max) continue;
+            int pix = i * W + j;
+            float cut = ref_depth[pix] + delta_depth;
+            float dx = x - ((float)j + 0.5f), dy = y - ((float)i + 0.5f);
+            float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+            if (sigma < 0.f) continue;
+            float vis = expf(-sigma);
+            float alpha = fminf(0.999f, opac * vis);
+            if (rel_band < 0.f) {
+                if (rgb[3] > cut || alpha < 1.f / 255.f) continue;
+            } else {
+                if (!borderline(opac, vis, rgb[3], cut, rel_band)) continue;
+                if (alpha < (1.f - rel_band) / 255.f || rgb[3] > cut + rel_band * fabsf(cut)) continue;
+            }
+            float v_alpha = v_render_alphas[pix];
+            v_alpha = fabsf(v_alpha);
+            for (int q = 0; q < 4; q++) {
+                float vc = v_render_colors[4 * pix + q];
+                b[q] += fabsf(alpha * vc);
+                v_alpha += fabsf(rgb[q] * vc);   /* sum |term|: also bounds the cancellation inside v_alpha */
+            }
+            float v_sigma = -opac * vis * v_alpha;
+            b[4] += fabsf(0.5f * v_sigma * dx * dx);
+            b[5] += fabsf(v_sigma * dx * dy);
+            b[6] += fabsf(0.5f * v_sigma * dy * dy);
+            b[7] += fabsf(v_sigma * (ca * dx + cb * dy));
+            b[8] += fabsf(v_sigma * (cb * dx + cc * dy));
+            b[9] += fabsf(vis * v_alpha);
+            n_pairs[0]++;
+            if (g != last_counted) { n_pairs[1]++; last_counted = g; }
+        }
+    }
+}
+
+/*
  * Exact tile-parallel adjoint of the ges forward
  * (gsplat/rasterizer/rasterize_to_pixels_bwd_ges.cu:164-291; unused by the
  * shipped configs, kept as the mathematical reference for gradient tests).

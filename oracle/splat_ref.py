@@ -139,6 +139,40 @@ def raster_ges_bwd_gs(means2d, conics, colors, opacities, radiis, ref_depth, W, 
     return v_m, v_c, v_col, v_o
 
 
+def raster_ges_fwd_flip_budget(means2d, conics, colors, opacities, ref_depth, W, H, tile_size, offsets, flatten_ids,
+                               delta_depth, rel_band=1e-5):
+    """Per pixel: what a flip of every borderline accept/reject decision could change -> (budget[H,W,5], n_pairs,
+    n_pixels).  See orc_raster_ges_fwd_flip_budget."""
+    means2d, conics, colors, opacities, ref_depth = map(_f32, (means2d, conics, colors, opacities, ref_depth))
+    offsets, flatten_ids = _i32(offsets), _i32(flatten_ids)
+    th, tw = offsets.shape
+    budget = np.zeros((H, W, 5), np.float32)
+    n = np.zeros(2, np.int64)
+    _lib().orc_raster_ges_fwd_flip_budget(C.c_int(W), C.c_int(H), C.c_int(tile_size), C.c_int(tw), C.c_int(th),
+                                          C.c_int64(flatten_ids.shape[0]), C.c_float(delta_depth), _p(means2d),
+                                          _p(conics), _p(colors), _p(opacities), _p(ref_depth), _p(offsets),
+                                          _p(flatten_ids), C.c_float(rel_band), _p(budget), _p(n))
+    return budget, int(n[0]), int(n[1])
+
+
+def raster_ges_bwd_gs_flip_budget(means2d, conics, colors, opacities, radiis, ref_depth, W, H, group_gs_ids,
+                                  group_starts, delta_depth, v_render_colors, v_render_alphas, rel_band=1e-5):
+    """Per Gaussian: |contribution| of every borderline pixel slot to the 10 gradient entries, ordered
+    {v_colors[4], v_conics[3], v_means2d[2], v_opacities} -> (budget[N,10], n_pairs, n_gaussians)."""
+    means2d, conics, colors, opacities, ref_depth = map(_f32, (means2d, conics, colors, opacities, ref_depth))
+    v_render_colors, v_render_alphas = _f32(v_render_colors), _f32(v_render_alphas)
+    radiis, group_gs_ids, group_starts = map(_i32, (radiis, group_gs_ids, group_starts))
+    N = radiis.shape[0]
+    budget = np.zeros((N, 10), np.float32)
+    n = np.zeros(2, np.int64)
+    _lib().orc_raster_ges_bwd_gs_flip_budget(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int64(group_gs_ids.shape[0]),
+                                             C.c_float(delta_depth), _p(group_gs_ids), _p(group_starts), _p(means2d),
+                                             _p(conics), _p(colors), _p(opacities), _p(radiis), _p(ref_depth),
+                                             _p(v_render_colors), _p(v_render_alphas), C.c_float(rel_band), _p(budget),
+                                             _p(n))
+    return budget, int(n[0]), int(n[1])
+
+
 def raster_ges_bwd_exact(means2d, conics, colors, opacities, ref_depth, W, H, tile_size, offsets, flatten_ids,
                          delta_depth, v_render_colors, v_render_alphas):
     means2d, conics, colors, opacities, ref_depth = map(_f32, (means2d, conics, colors, opacities, ref_depth))

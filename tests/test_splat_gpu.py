@@ -351,8 +351,8 @@ def test_adam_matches_libtorch_sequence():
 
 @pytest.mark.parametrize("N,W,H", [(3000, 96, 64), (150000, 640, 480)])
 def test_record_streaming_forward_equals_lds_forward(N, W, H):
-    """gps_raster_ges_fwd_rec (scalar-load records + conservative wave culling) must reproduce gps_raster_ges_fwd: the
-    culling may only skip (pixel, Gaussian) pairs that fail alpha >= 1/255 anyway."""
+    """gps_raster_ges_fwd_rec (packed records, 2 px/lane packed math, exp2 with the opacity folded into the exponent -- the
+    forward the fused path times) must reproduce the operator-level gps_raster_ges_fwd."""
     from gps_slam_amd import gsplat_ops as ops
     TS, delta = 16, 0.1
     tw, th = (W + TS - 1) // TS, (H + TS - 1) // TS
