@@ -73,6 +73,7 @@ PROTOTYPES = {
     "gps_raster_ges_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
     "gps_raster_ges_bwd_gs": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp,
                                     i32, vp]),
+    "gps_raster_ges_bwd_exact": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_compose_l1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_adam_step": (i32, [C.POINTER(AdamSegment), i32, f64, f64, f64, i32, vp]),
     "gps_gauss_preprocess_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32,

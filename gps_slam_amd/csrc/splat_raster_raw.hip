@@ -269,9 +269,120 @@ __global__ __launch_bounds__(256) void raster_raw_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Exact tile-parallel adjoint of the `ges` forward (rasterize_to_pixels_bwd_ges.cu:18-291): what the reference's
+// RasterizeToPixelsGes autograd Function runs (gsplat_wapper.hpp:355-487; the shipped models use the Gaussian-parallel
+// box backward of splat_raster.hip instead).  Same tile / patch geometry and the same swap-based wave reduction + LDS
+// gradient tile as raster_raw_bwd_kernel above; the order-independent sum has no transmittance recurrence, so the tile's
+// list is walked front to back and a pixel's terms depend on that Gaussian alone.
+__global__ __launch_bounds__(256) void raster_ges_bwd_exact_kernel(
+    const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ ref_depth, float delta_depth, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids, const int64_t* __restrict__ counts,
+    const float4* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d,
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    constexpr int NG = 12;
+    __shared__ RawRec recs[RAW_BATCH];
+    __shared__ float grad[RAW_BATCH][NG];
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tw, tx = tile_id - ty * tw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int row_slot = ((lane >> 4) & 1) * 2 + (lane >> 5);
+    const int i = ty * 16 + ((tid >> 7) << 3) + ((tid >> 3) & 7), j = tx * 16 + (((tid >> 6) & 1) << 3) + (tid & 7);
+    const bool inside = (i < H) && (j < W);
+    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+    const int pix = inside ? i * W + j : 0;
+    const int n_isects = (int)counts[0];
+    const int range_start = tile_offsets[tile_id];
+    const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
+    if (range_end <= range_start) return;
+    const float cut = inside ? ref_depth[pix] + delta_depth : -3.0e38f;
+    const float4 vc = inside ? v_render_colors[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float va = inside ? v_render_alphas[pix] : 0.f;
+    for (int batch_start = range_start; batch_start < range_end; batch_start += RAW_BATCH) {
+        __syncthreads();
+        const int n = min(RAW_BATCH, range_end - batch_start);
+        if (tid < n) recs[tid] = load_rec(flatten_ids[batch_start + tid], means2d, conics, colors, opacities);
+        for (int k = tid; k < RAW_BATCH * NG; k += 256) (&grad[0][0])[k] = 0.f;
+        __syncthreads();
+        for (int t = 0; t < n; ++t) {
+            const RawRec r = recs[t];
+            const float dx = r.x - px, dy = r.y - py;
+            const float sigma = 0.5f * (r.ca * dx * dx + r.cc * dy * dy) + r.cb * dx * dy;
+            const float vis_raw = __expf(-sigma);
+            const float alpha_raw = fminf(0.999f, r.opac * vis_raw);
+            const bool valid = inside && !(r.c3 > cut) && sigma >= 0.f && alpha_raw >= 1.f / 255.f;
+            if (!__any(valid)) continue;  // wave uniform
+            const float alpha = valid ? alpha_raw : 0.f;
+            const float vis = valid ? vis_raw : 0.f;
+            const float g0 = alpha * vc.x, g1 = alpha * vc.y, g2 = alpha * vc.z, g3 = alpha * vc.w;
+            const float v_alpha = r.c0 * vc.x + r.c1 * vc.y + r.c2 * vc.z + r.c3 * vc.w + va;
+            const float ov = r.opac * vis;
+            const bool unclamped = ov <= 0.999f;
+            const float v_sigma = unclamped ? -ov * v_alpha : 0.f;
+            const float g4 = 0.5f * v_sigma * dx * dx;
+            const float g5 = v_sigma * dx * dy;
+            const float g6 = 0.5f * v_sigma * dy * dy;
+            const float g7 = v_sigma * (r.ca * dx + r.cb * dy);
+            const float g8 = v_sigma * (r.cb * dx + r.cc * dy);
+            const float g9 = unclamped ? vis * v_alpha : 0.f;
+            const float z0 = reduce4(g0, g1, g2, g3);
+            const float z1 = reduce4(g4, g5, g6, g7);
+            if ((lane & 15) == 15) {
+                float* gt = &grad[t][row_slot];
+                atomicAdd(gt, z0);
+                atomicAdd(gt + 4, z1);
+            }
+            const float z2 = dpp_add_masked<0x142, 0xA>(row_sum_to_lane15(sum_halves(g8, g9)));
+            if ((lane & 31) == 31) atomicAdd(&grad[t][8 + (lane >> 5)], z2);
+        }
+        __syncthreads();
+        if (tid < n) {
+            const int gid = recs[tid].id;
+            const float* gt = grad[tid];
+            float* vcol = v_colors + 4 * (size_t)gid;
+            float* vk = v_conics + 3 * (size_t)gid;
+            float* vm = v_means2d + 2 * (size_t)gid;
+            if (gt[0] != 0.f) atomicAdd(vcol + 0, gt[0]);
+            if (gt[1] != 0.f) atomicAdd(vcol + 1, gt[1]);
+            if (gt[2] != 0.f) atomicAdd(vcol + 2, gt[2]);
+            if (gt[3] != 0.f) atomicAdd(vcol + 3, gt[3]);
+            if (gt[4] != 0.f) atomicAdd(vk + 0, gt[4]);
+            if (gt[5] != 0.f) atomicAdd(vk + 1, gt[5]);
+            if (gt[6] != 0.f) atomicAdd(vk + 2, gt[6]);
+            if (gt[7] != 0.f) atomicAdd(vm + 0, gt[7]);
+            if (gt[8] != 0.f) atomicAdd(vm + 1, gt[8]);
+            if (gt[9] != 0.f) atomicAdd(v_opacities + gid, gt[9]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int gps_raster_ges_bwd_exact(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                             const float* ref_depth_map, int width, int height, int tile_size, const int32_t* tile_offsets,
+                             const int32_t* flatten_ids, const int64_t* counts, float delta_depth, const float* v_render_colors,
+                             const float* v_render_alphas, float* v_means2d, float* v_conics, float* v_colors,
+                             float* v_opacities, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    GPS_REQUIRE(tile_size == 16);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means2d && conics && colors && opacities && ref_depth_map && tile_offsets && flatten_ids && counts &&
+                v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities);
+    const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
+    hipStream_t s = (hipStream_t)stream;
+    zero_raw_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors, v_opacities,
+                                                                                    nullptr);
+    raster_ges_bwd_exact_kernel<<<tw * th, 256, 0, s>>>((const float2*)means2d, conics, (const float4*)colors, opacities,
+                                                       ref_depth_map, delta_depth, width, height, tw, th, tile_offsets,
+                                                       flatten_ids, counts, (const float4*)v_render_colors, v_render_alphas,
+                                                       v_means2d, v_conics, v_colors, v_opacities);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
 
 int gps_raster_raw_fwd(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
                        const float* backgrounds, int width, int height, int tile_size, const int32_t* tile_offsets,

@@ -4,6 +4,9 @@
 // non-pinhole cameras, backgrounds, masks, absgrad) throw, like the reference's AT_ERROR paths.
 #pragma once
 #include "gps_host_common.hpp"
+#include "hip_bindings.hpp"  // the launcher level (rasterizer/bindings.h, ssim.h, simple_knn.h signatures) + distCUDA2
+
+double getDuration(struct timespec start, struct timespec end);  // gsplat_wapper.hpp:12, gsplat_wapper.cpp:3-13 (ms)
 
 // gsplat_wapper.hpp:16-95: apply(sh_degree, dirs[...,3], coeffs[...,K,3], masks[...]) -> colors[...,3]
 struct SphericalHarmonicsNew : public torch::autograd::Function<SphericalHarmonicsNew> {
@@ -37,6 +40,21 @@ struct RasterizeToPixelsGes_NewParallel : public torch::autograd::Function<Raste
                                                 c10::optional<torch::Tensor> masks, int width, int height,
                                                 int tile_size, torch::Tensor isect_offsets, torch::Tensor flatten_ids,
                                                 torch::Tensor group_gs_ids, torch::Tensor group_starts, bool absgrad,
+                                                float delta_depth);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
+// gsplat_wapper.hpp:355-487: apply(means2d, conics, colors, opacities, ref_depth_map, base_color_map, backgrounds, masks,
+// width, height, tile_size, isect_offsets, flatten_ids, absgrad, delta_depth) -> {render_colors, weight_sum}; the backward is
+// the EXACT tile-parallel adjoint (rasterize_to_pixels_bwd_ges.cu).  Unused by raw_gs_model.cpp (:291 picks _NewParallel).
+struct RasterizeToPixelsGes : public torch::autograd::Function<RasterizeToPixelsGes> {
+    static torch::autograd::tensor_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor means2d,
+                                                torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities,
+                                                torch::Tensor ref_depth_map, torch::Tensor base_color_map,
+                                                c10::optional<torch::Tensor> backgrounds,
+                                                c10::optional<torch::Tensor> masks, int width, int height, int tile_size,
+                                                torch::Tensor isect_offsets, torch::Tensor flatten_ids, bool absgrad,
                                                 float delta_depth);
     static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx,
                                                  torch::autograd::tensor_list grad_outputs);
@@ -84,8 +102,7 @@ variable_list isectTiles(torch::Tensor means2d, torch::Tensor radii, torch::Tens
                          int tile_height, bool sort = true);
 torch::Tensor isectOffsetEncode(torch::Tensor isect_ids, int n_cameras, int tile_width, int tile_height);
 
-// gsplat_wapper.cpp:50-53 -> distCUDA2 (simple_knn.h:21): mean squared distance to the 3 nearest neighbours
-torch::Tensor distCUDA2(const torch::Tensor& points);
+// gsplat_wapper.cpp:50-53 -> distCUDA2 (simple_knn.h:21, hip_bindings.hpp): mean squared distance to the 3 nearest neighbours
 torch::Tensor simpleKNN(torch::Tensor points);
 
 // gsplat_wapper.cpp:105-139

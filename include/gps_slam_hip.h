@@ -136,6 +136,17 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
                           const float *v_render_alphas, float *v_means2d, float *v_conics, float *v_colors,
                           float *v_opacities, int accumulate, gps_stream stream);
 
+/* replaces gsplat::rasterize_to_pixels_bwd_ges_tensor (rasterize_to_pixels_bwd_ges.cu:18-291): the exact tile-parallel
+ * adjoint of gps_raster_ges_fwd, what the reference's RasterizeToPixelsGes autograd Function runs (gsplat_wapper.hpp:355-487;
+ * the shipped models use the Gaussian-parallel box backward above).  n_isects is read from counts[0].
+ * Out (zero-filled by this call, then accumulated): v_means2d[N,2] v_conics[N,3] v_colors[N,4] v_opacities[N]. */
+GPS_API int gps_raster_ges_bwd_exact(int N, const float *means2d, const float *conics, const float *colors,
+                                     const float *opacities, const float *ref_depth_map, int width, int height,
+                                     int tile_size, const int32_t *tile_offsets, const int32_t *flatten_ids,
+                                     const int64_t *counts, float delta_depth, const float *v_render_colors,
+                                     const float *v_render_alphas, float *v_means2d, float *v_conics, float *v_colors,
+                                     float *v_opacities, gps_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* Splat: fused SSIM map (the `ssim_weight > 0` loss option)            */
 /* ------------------------------------------------------------------ */

@@ -624,6 +624,8 @@ ORC_API void orc_raster_ges_bwd_gs(int W, int H, int64_t n_groups, float delta_d
  *             n_pairs[0] = number of borderline pairs, n_pairs[1] = number of pixels that have one.
  *   backward: budget[N,10] = sum over the Gaussian's borderline pixel slots of the absolute value of the slot's
  *             contribution to {v_colors[4], v_conics[3], v_means2d[2], v_opacities}; n_pairs as above (per Gaussian).
+ * The backward has a third decision, `opac * vis <= 0.999f` (whether the conic / xy / opacity terms exist at all): pairs
+ * within rel_band of it count towards entries 4..9 of their Gaussian.
  * rel_band < 0 selects a second mode: the same sums over the ACCEPTED pairs instead of the borderline ones, i.e.
  * sum |term| of every output -- the scale a summation-order / exp-rounding tolerance is relative to.
  */
@@ -714,17 +716,21 @@ ORC_API void orc_raster_ges_bwd_gs_flip_budget(int W, int H, int N, int64_t n_gr
             if (sigma < 0.f) continue;
             float vis = expf(-sigma);
             float alpha = fminf(0.999f, opac * vis);
+            int clamp_only = 0;  /* accepted either way; only the `opac * vis <= 0.999f` branch is borderline */
             if (rel_band < 0.f) {
                 if (rgb[3] > cut || alpha < 1.f / 255.f) continue;
             } else {
-                if (!borderline(opac, vis, rgb[3], cut, rel_band)) continue;
                 if (alpha < (1.f - rel_band) / 255.f || rgb[3] > cut + rel_band * fabsf(cut)) continue;
+                if (!borderline(opac, vis, rgb[3], cut, rel_band)) {
+                    if (fabsf(opac * vis - 0.999f) > rel_band * 0.999f) continue;
+                    clamp_only = 1;
+                }
             }
             float v_alpha = v_render_alphas[pix];
             v_alpha = fabsf(v_alpha);
             for (int q = 0; q < 4; q++) {
                 float vc = v_render_colors[4 * pix + q];
-                b[q] += fabsf(alpha * vc);
+                if (!clamp_only) b[q] += fabsf(alpha * vc);
                 v_alpha += fabsf(rgb[q] * vc);   /* sum |term|: also bounds the cancellation inside v_alpha */
             }
             float v_sigma = -opac * vis * v_alpha;
