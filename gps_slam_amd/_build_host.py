@@ -8,7 +8,7 @@ import sysconfig
 HERE = os.path.dirname(os.path.abspath(__file__))
 HOST = os.path.join(HERE, "host")
 CXX = os.environ.get("CXX", "g++")
-SRCS = ["hip_bindings.cpp", "gsplat_wapper.cpp", "raw_gs_param.cpp", "raw_gs_model.cpp", "tsdf_engine.cpp", "slam_pipeline.cpp", "bindings.cpp"]
+SRCS = ["hip_bindings.cpp", "gsplat_wapper.cpp", "raw_gs_param.cpp", "raw_gs_model.cpp", "tsdf_engine.cpp", "infinitam_tools.cpp", "slam_pipeline.cpp", "bindings.cpp"]
 
 
 def _stale(target, deps):

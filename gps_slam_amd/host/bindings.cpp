@@ -39,6 +39,13 @@ PYBIND11_MODULE(_host, m) {
                                                              isect_offsets, flatten_ids, group_gs_ids, group_starts,
                                                              false, delta_depth);
           });
+    m.def("RasterizeToPixelsGes",
+          [](torch::Tensor means2d, torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities,
+             torch::Tensor ref_depth_map, torch::Tensor base_color_map, int w, int h, int tile_size,
+             torch::Tensor isect_offsets, torch::Tensor flatten_ids, float delta_depth) {
+              return RasterizeToPixelsGes::apply(means2d, conics, colors, opacities, ref_depth_map, base_color_map, c10::nullopt,
+                                                 c10::nullopt, w, h, tile_size, isect_offsets, flatten_ids, false, delta_depth);
+          });
     m.def("RasterizeToPixels",
           [](torch::Tensor means2d, torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities,
              c10::optional<torch::Tensor> backgrounds, int w, int h, int tile_size, torch::Tensor isect_offsets,
@@ -128,55 +135,107 @@ PYBIND11_MODULE(_host, m) {
                                 float ratio, int frame_num) { return s.addGaussians(cam, maps, mask, ratio, frame_num); });
 
     // ---- TSDF engine
-    py::class_<ITMBasicEngine>(m, "ITMBasicEngine")
+    py::class_<TsdfEngine>(m, "ITMBasicEngine")
         .def(py::init([](int w, int h, float fx, float fy, float cx, float cy, float voxel_size, float mu, float vmin,
-                         float vmax) { return new ITMBasicEngine(w, h, fx, fy, cx, cy, voxel_size, mu, vmin, vmax); }),
+                         float vmax) { return new TsdfEngine(w, h, fx, fy, cx, cy, voxel_size, mu, vmin, vmax); }),
              py::arg("width"), py::arg("height"), py::arg("fx"), py::arg("fy"), py::arg("cx"), py::arg("cy"),
              py::arg("voxel_size") = 0.005f, py::arg("mu") = 0.02f, py::arg("view_frustum_min") = 0.2f,
              py::arg("view_frustum_max") = 10.0f)
-        .def("pushGtPose", [](ITMBasicEngine& e, const torch::Tensor& c2w) { e.gtC2wPoses.push_back(c2w); })
-        .def("turnOffTracking", &ITMBasicEngine::turnOffTracking)
-        .def("turnOnTracking", [](ITMBasicEngine& e) { e.turnOnTracking(); })
-        .def("lastPose", [](ITMBasicEngine& e) {
+        .def("pushGtPose", [](TsdfEngine& e, const torch::Tensor& c2w) { e.gtC2wPoses.push_back(c2w); })
+        .def("turnOffTracking", &TsdfEngine::turnOffTracking)
+        .def("turnOnTracking", [](TsdfEngine& e) { e.turnOnTracking(); })
+        .def("lastPose", [](TsdfEngine& e) {
             auto t = torch::empty({2, 16}, torch::kFloat32);
             const ORUtils::SE3Pose& p = e.camPoses.back();
             for (int i = 0; i < 16; i++) { t[0][i] = p.GetM()[i]; t[1][i] = p.GetInvM()[i]; }
             return t;
         })
-        .def("trackDiag", [](ITMBasicEngine& e) {
+        .def("trackDiag", [](TsdfEngine& e) {
             auto t = torch::empty({16}, torch::kFloat32);
             for (int i = 0; i < 16; i++) t[i] = e.trackState().diag[i];
             return t;
         })
-        .def("ProcessFrame", [](ITMBasicEngine& e, const torch::Tensor& rgb, const torch::Tensor& depth) {
+        .def("ProcessFrame", [](TsdfEngine& e, const torch::Tensor& rgb, const torch::Tensor& depth) {
             e.ProcessFrame(rgb, depth);
         })
-        .def("runRaycastC2w", [](ITMBasicEngine& e, const torch::Tensor& c2w) {
+        .def("runRaycastC2w", [](TsdfEngine& e, const torch::Tensor& c2w) {
             ORUtils::SE3Pose pose;
             auto c = c2w.to(torch::kCPU, torch::kFloat32).contiguous();
             pose.SetInvM(c.data_ptr<float>());
             e.runRaycast(&pose);
         })
-        .def("GetFreeImage", [](ITMBasicEngine& e) { return e.GetFreeImage()->tensor(); })
-        .def("GetFreeVertex", [](ITMBasicEngine& e) { return e.GetFreeVertex()->tensor(); })
-        .def("GetLiveVertex", [](ITMBasicEngine& e) { return e.GetLiveVertex()->tensor(); })
-        .def("getVoxelSize", &ITMBasicEngine::getVoxelSize)
-        .def("counters", &ITMBasicEngine::counters)
-        .def("MeshScene", &ITMBasicEngine::MeshScene, py::arg("maxTriangles") = (int64_t)1 << 24)
-        .def("SaveSceneToMesh", [](ITMBasicEngine& e, const std::string& f, int64_t m) { return e.SaveSceneToMesh(f.c_str(), m); },
+        .def("GetFreeImage", [](TsdfEngine& e) { return e.GetFreeImage()->tensor(); })
+        .def("GetFreeVertex", [](TsdfEngine& e) { return e.GetFreeVertex()->tensor(); })
+        .def("GetLiveVertex", [](TsdfEngine& e) { return e.GetLiveVertex()->tensor(); })
+        .def("getVoxelSize", &TsdfEngine::getVoxelSize)
+        .def("counters", &TsdfEngine::counters)
+        .def("MeshScene", &TsdfEngine::MeshScene, py::arg("maxTriangles") = (int64_t)1 << 24)
+        .def("SaveSceneToMesh", [](TsdfEngine& e, const std::string& f, int64_t m) { return e.SaveSceneToMesh(f.c_str(), m); },
              py::arg("fileName"), py::arg("maxTriangles") = (int64_t)1 << 24)
-        .def("SaveToFile", &ITMBasicEngine::SaveToFile)
-        .def("LoadFromFile", &ITMBasicEngine::LoadFromFile)
-        .def_readonly("framesProcessed", &ITMBasicEngine::framesProcessed);
+        .def("SaveToFile", &TsdfEngine::SaveToFile)
+        .def("LoadFromFile", &TsdfEngine::LoadFromFile)
+        .def("runRaycastIntrinsics", [](TsdfEngine& e, const torch::Tensor& c2w, float fx, float fy, float cx, float cy) {
+            // ITMBasicEngine::runRaycast(pose, intrinsics) with an explicit ITMIntrinsics (slam_pipeline.cpp:367-376)
+            ORUtils::SE3Pose pose;
+            auto c = c2w.to(torch::kCPU, torch::kFloat32).contiguous();
+            pose.SetInvM(c.data_ptr<float>());
+            ITMLib::ITMIntrinsics in;
+            in.SetFrom(e.state().width, e.state().height, fx, fy, cx, cy);
+            e.runRaycast(&pose, &in);
+        })
+        .def("camIntrincs", [](TsdfEngine& e) {
+            auto t = torch::empty({(int64_t)e.camIntrincs.size(), 4}, torch::kFloat32);
+            for (size_t i = 0; i < e.camIntrincs.size(); i++) {
+                const auto& p = e.camIntrincs[i].projectionParamsSimple;
+                t[i][0] = p.fx; t[i][1] = p.fy; t[i][2] = p.px; t[i][3] = p.py;
+            }
+            return t;
+        })
+        .def_readonly("framesProcessed", &TsdfEngine::framesProcessed);
+
+    // ---- the reference's construction path: DatasetReader -> createTsdfEngine -> CLIEngine (slam_trainer.cpp:20-33)
+    py::class_<DatasetReader>(m, "DatasetReader")
+        .def(py::init([](int w, int h, float fx, float fy, float cx, float cy) {
+            auto* r = new DatasetReader();
+            r->width = w; r->height = h; r->fx = fx; r->fy = fy; r->cx = cx; r->cy = cy;
+            return r;
+        }))
+        .def("addTrainCamera", [](DatasetReader& r, const Camera& c) { r.train_vec.push_back(c); })
+        .def("size", [](DatasetReader& r) { return r.train_vec.size(); });
+    py::class_<InfiniTAM::Engine::CLIEngine, std::unique_ptr<InfiniTAM::Engine::CLIEngine, py::nodelete>>(m, "CLIEngine")
+        .def("ProcessFrame", &InfiniTAM::Engine::CLIEngine::ProcessFrame)
+        .def("Shutdown", &InfiniTAM::Engine::CLIEngine::Shutdown)
+        .def("GetDepthSize", [](InfiniTAM::Engine::CLIEngine& e) { auto d = e.GetDepthSize(); return std::make_pair(d.x, d.y); })
+        .def("GetRGBSize", [](InfiniTAM::Engine::CLIEngine& e) { auto d = e.GetRGBSize(); return std::make_pair(d.x, d.y); })
+        .def("getMainEngine", [](InfiniTAM::Engine::CLIEngine& e) {
+            return static_cast<TsdfEngine*>(dynamic_cast<ITMLib::ITMBasicEngine<ITMVoxel, ITMVoxelIndex>*>(e.getMainEngine()));
+        }, py::return_value_policy::reference)
+        .def_readwrite("prefetch", &InfiniTAM::Engine::CLIEngine::prefetch)
+        .def_readonly("uploadedBytes", &InfiniTAM::Engine::CLIEngine::uploadedBytes)
+        .def_readonly("currentFrameNo", &InfiniTAM::Engine::CLIEngine::currentFrameNo);
+    m.def("createTsdfEngine", [](const DatasetReader& r, const py::dict& cfg) { return createTsdfEngine(r, config_from_dict(cfg)); },
+          py::return_value_policy::reference);
 
     // ---- pipeline
     py::class_<SLAMPipeline>(m, "SLAMPipeline")
-        .def(py::init<ITMBasicEngine*, SLAMGaussianModel*, uint64_t, bool>(), py::arg("engine"), py::arg("model"),
+        .def(py::init<TsdfEngine*, SLAMGaussianModel*, uint64_t, bool>(), py::arg("engine"), py::arg("model"),
              py::arg("seed") = 1234, py::arg("use_gt_pose") = true, py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
+        .def(py::init<uint64_t>(), py::arg("seed") = 1234)
+        .def("setTsdfEngine", &SLAMPipeline::setTsdfEngine)
+        .def("setModel", [](SLAMPipeline& p, SLAMGaussianModel* m) { p.model = m; p.device = m->device; }, py::keep_alive<1, 2>())
+        .def("SLAMTrainCamsModel", [](SLAMPipeline& p, SLAMGaussianModel& m, std::vector<Camera>& cams) {
+            p.SLAMTrainCams(m, cams);
+            return cams;  // with c2w_slam filled in
+        }, py::call_guard<py::gil_scoped_release>())
+        .def("processFrameCLI", [](SLAMPipeline& p, int i, Camera& cam) { p.processFrame(i, cam); },
+             py::call_guard<py::gil_scoped_release>())
         .def("loadConfig", [](SLAMPipeline& p, const py::dict& d) { p.loadConfig(config_from_dict(d)); })
         // the optimise loop may run the autograd engine (losses beyond L1): it must not hold the GIL
-        .def("processFrame", &SLAMPipeline::processFrame, py::call_guard<py::gil_scoped_release>())
-        .def("SLAMTrainCams", &SLAMPipeline::SLAMTrainCams, py::call_guard<py::gil_scoped_release>())
+        .def("processFrame", py::overload_cast<int, Camera&, const torch::Tensor&, const torch::Tensor&>(&SLAMPipeline::processFrame),
+             py::call_guard<py::gil_scoped_release>())
+        .def("SLAMTrainCams", py::overload_cast<std::vector<Camera>&, const std::vector<torch::Tensor>&,
+                                                const std::vector<torch::Tensor>&>(&SLAMPipeline::SLAMTrainCams),
+             py::call_guard<py::gil_scoped_release>())
         .def("runRaycastByCam", &SLAMPipeline::runRaycastByCam, py::arg("cam"), py::arg("use_cam_depth") = true)
         .def_readwrite("overlap_mapping", &SLAMPipeline::overlap_mapping)
         .def_readwrite("mapping_thread", &SLAMPipeline::mapping_thread)

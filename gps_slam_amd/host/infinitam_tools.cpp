@@ -1,0 +1,164 @@
+#include "infinitam_tools.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstring>
+
+using namespace gpsh;
+using namespace InfiniTAM::Engine;
+using namespace ITMLib;
+
+CLIEngine* CLIEngine::instance = NULL;
+
+namespace {
+inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
+}  // namespace
+
+// Three device slots: frame n is read by its kernels from slot n % 3 while frame n + 1 is uploaded into the next one; a slot
+// is overwritten two frames later, after the event recorded behind its last reader.
+struct CLIEngine::Staging {
+    hipStream_t copy = nullptr;
+    std::unique_ptr<ITMUChar4Image> rgb[3];
+    std::unique_ptr<ITMShortImage> depth[3];
+    hipEvent_t uploaded[3] = {nullptr, nullptr, nullptr}, consumed[3] = {nullptr, nullptr, nullptr};
+    int frame_in_slot[3] = {-1, -1, -1};
+    bool used[3] = {false, false, false};
+    ~Staging() {
+        if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+        for (int k = 0; k < 3; k++) {
+            if (uploaded[k]) (void)hipEventDestroy(uploaded[k]);
+            if (consumed[k]) (void)hipEventDestroy(consumed[k]);
+        }
+    }
+};
+
+void CLIEngine::Initialise(std::vector<ITMUChar4Image*> rgb_images_, std::vector<ITMShortImage*> depth_images_,
+                           ITMMainEngine* mainEngine_) {
+    TORCH_CHECK(!rgb_images_.empty() && rgb_images_.size() == depth_images_.size() && mainEngine_, "CLIEngine::Initialise");
+    rgb_images = rgb_images_;
+    depth_images = depth_images_;
+    mainEngine = mainEngine_;
+    currentFrameNo = 0;
+    uploadedBytes = 0;
+    staging_.reset(new Staging());
+    hip_ok(hipStreamCreateWithFlags(&staging_->copy, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < 3; k++) {
+        staging_->rgb[k].reset(new ITMUChar4Image(GetRGBSize(), false, true));
+        staging_->depth[k].reset(new ITMShortImage(GetDepthSize(), false, true));
+        hip_ok(hipEventCreateWithFlags(&staging_->uploaded[k], hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&staging_->consumed[k], hipEventDisableTiming), "hipEventCreate");
+    }
+}
+
+void CLIEngine::upload(int frame) {
+    Staging& st = *staging_;
+    const int slot = frame % 3;
+    if (st.frame_in_slot[slot] == frame) return;
+    ITMUChar4Image* rgb = rgb_images[frame];
+    ITMShortImage* dep = depth_images[frame];
+    TORCH_CHECK(rgb->isAllocated_CPU() && dep->isAllocated_CPU(), "CLIEngine: input images live in host memory");
+    if (st.used[slot]) hip_ok(hipStreamWaitEvent(st.copy, st.consumed[slot], 0), "hipStreamWaitEvent");
+    const size_t nb_rgb = rgb->dataSize() * sizeof(Vector4u), nb_d = dep->dataSize() * sizeof(short);
+    hip_ok(hipMemcpyAsync(st.rgb[slot]->GetData(MEMORYDEVICE_CUDA), rgb->GetData(MEMORYDEVICE_CPU), nb_rgb, hipMemcpyHostToDevice,
+                          st.copy), "UpdateView: rgb upload");
+    hip_ok(hipMemcpyAsync(st.depth[slot]->GetData(MEMORYDEVICE_CUDA), dep->GetData(MEMORYDEVICE_CPU), nb_d, hipMemcpyHostToDevice,
+                          st.copy), "UpdateView: depth upload");
+    hip_ok(hipEventRecord(st.uploaded[slot], st.copy), "hipEventRecord");
+    st.frame_in_slot[slot] = frame;
+    uploadedBytes += (int64_t)(nb_rgb + nb_d);
+}
+
+bool CLIEngine::ProcessFrame() {
+    if (currentFrameNo >= (int)rgb_images.size()) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (prefetch) {
+        Staging& st = *staging_;
+        const hipStream_t frames = (hipStream_t)current_stream();
+        const int slot = currentFrameNo % 3;
+        upload(currentFrameNo);                                                   // no-op when the previous call prefetched it
+        hip_ok(hipStreamWaitEvent(frames, st.uploaded[slot], 0), "hipStreamWaitEvent");
+        if (currentFrameNo + 1 < (int)rgb_images.size()) upload(currentFrameNo + 1);  // overlaps this frame's kernels
+        mainEngine->ProcessFrame(st.rgb[slot].get(), st.depth[slot].get());
+        hip_ok(hipEventRecord(st.consumed[slot], frames), "hipEventRecord");
+        st.used[slot] = true;
+    } else {
+        mainEngine->ProcessFrame(rgb_images[currentFrameNo], depth_images[currentFrameNo]);  // engine uploads on its stream
+        uploadedBytes += (int64_t)(rgb_images[currentFrameNo]->dataSize() * 6);
+    }
+    processedTime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    currentFrameNo++;
+    return true;
+}
+
+void CLIEngine::Run() {
+    while (ProcessFrame()) {}
+}
+
+void CLIEngine::Shutdown() {
+    staging_.reset();
+    rgb_images.clear();
+    depth_images.clear();
+    mainEngine = nullptr;
+    delete instance;
+    instance = NULL;
+}
+
+CLIEngine* createTsdfEngine(const DatasetReader& data_reader, const Config& config) {
+    // 1. calibration (InfiniTAM_tools.cpp:5-10)
+    ITMRGBDCalib rgbd_calib;
+    rgbd_calib.intrinsics_rgb.SetFrom(data_reader.width, data_reader.height, data_reader.fx, data_reader.fy, data_reader.cx,
+                                      data_reader.cy);
+    rgbd_calib.intrinsics_d = rgbd_calib.intrinsics_rgb;
+    rgbd_calib.disparityCalib.SetStandard();
+    // 2. InfiniTAM images, host memory (:12-46)
+    const int image_num = (int)data_reader.train_vec.size();
+    TORCH_CHECK(image_num > 0, "createTsdfEngine: empty dataset");
+    std::vector<ITMUChar4Image*> rgb_images(image_num);
+    std::vector<ITMShortImage*> depth_images(image_num);
+    std::vector<torch::Tensor> gt_c2w_poses(image_num);
+    const Vector2i dims(data_reader.width, data_reader.height);
+    const int64_t P = (int64_t)dims.x * dims.y;
+    for (int i = 0; i < image_num; i++) {
+        const Camera& cam = data_reader.train_vec[i];
+        TORCH_CHECK(cam.image.defined() && cam.depth.defined(), "createTsdfEngine: camera ", i, " has no image / depth");
+        auto img = cam.image.detach().to(torch::kCPU, torch::kFloat32);
+        TORCH_CHECK(img.dim() == 3 && img.size(0) == dims.y && img.size(1) == dims.x && img.size(2) == 3,
+                    "Only images with 3 channels are supported");
+        auto u8img = (img * 255.0).toType(torch::kUInt8).contiguous();  // tensorToImage: truncation, not rounding
+        rgb_images[i] = new ITMUChar4Image(dims, true, false);
+        {
+            const uint8_t* src = u8img.data_ptr<uint8_t>();
+            Vector4u* dst = rgb_images[i]->GetData(MEMORYDEVICE_CPU);
+            for (int64_t k = 0; k < P; k++) dst[k] = Vector4u{src[3 * k], src[3 * k + 1], src[3 * k + 2], 255};
+        }
+        auto d = cam.depth.detach().to(torch::kCPU, torch::kFloat32);
+        TORCH_CHECK(d.numel() == P, "Only images with 1 channels are supported");
+        // cv::Mat::convertTo(CV_16UC1, 1000): saturate_cast<ushort>(cvRound(v * 1000)), round half to even
+        auto mm = torch::round(d * 1000.0f).clamp(0.0, 65535.0).to(torch::kInt32).contiguous();
+        depth_images[i] = new ITMShortImage(dims, true, false);
+        {
+            const int32_t* src = mm.data_ptr<int32_t>();
+            short* dst = depth_images[i]->GetData(MEMORYDEVICE_CPU);
+            for (int64_t k = 0; k < P; k++) dst[k] = (short)(unsigned short)src[k];
+        }
+        gt_c2w_poses[i] = cam.c2w.to(torch::kCPU, torch::kFloat32).contiguous();
+    }
+    // 3. main engine (:48-63)
+    ITMLibSettings* internalSettings = new ITMLibSettings();
+    internalSettings->sceneParams.voxelSize = (float)config.get("voxel_size", 0.005);
+    internalSettings->sceneParams.mu = (float)config.get("trunc_dist", 0.02);
+    internalSettings->sceneParams.viewFrustum_min = (float)config.get("viewFrustum_min", 0.2);
+    internalSettings->sceneParams.viewFrustum_max = (float)config.get("viewFrustum_max", 10.0);
+    ITMMainEngine* mainEngine =
+        new ITMBasicEngine<ITMVoxel, ITMVoxelIndex>(internalSettings, rgbd_calib, rgb_images[0]->noDims, depth_images[0]->noDims);
+    if (config.get("use_gt_pose", 1.0) != 0.0) {
+        auto* be = dynamic_cast<ITMBasicEngine<ITMVoxel, ITMVoxelIndex>*>(mainEngine);
+        be->turnOffTracking();
+        be->gtC2wPoses = gt_c2w_poses;
+    }
+    // 4. CLI engine (:64-67)
+    CLIEngine* tsdf_engine = CLIEngine::Instance();
+    tsdf_engine->Initialise(rgb_images, depth_images, mainEngine);
+    return tsdf_engine;
+}

