@@ -129,7 +129,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_blocks_kernel(int nblk, int
         int64_t ovf = 0;
         if (ni > isect_cap) { ni = isect_cap; ovf = 1; }
         if (ng > group_cap) { ng = group_cap; ovf = 1; }
-        counts[0] = ni; counts[1] = ng; counts[2] = ovf; counts[3] = vis_total;
+        // the overflow word is STICKY (only ever raised here): a host that looks at it once per keyframe still sees an
+        // overflow of any launch in between; the caller zeroes it
+        counts[0] = ni; counts[1] = ng; if (ovf) counts[2] = 1; counts[3] = vis_total;
     }
 }
 

@@ -69,6 +69,8 @@ PYBIND11_MODULE(_host, m) {
     m.def("rgb2sh", &rgb2sh);
     m.def("sh2rgb", &sh2rgb);
     m.def("poseInv", &poseInv);
+    m.def("RawGaussianParamsMake", &RawGaussianParams::make, py::arg("xyz"), py::arg("rgb"), py::arg("normals"),
+          py::arg("max_sh_degree") = 3, py::arg("init_opacs") = 0.5f, py::arg("max_scale") = 0.01f, py::arg("min_scale") = -1.0f);
     m.def("computeNormalMap", &computeNormalMap);
 
     // ---- Camera
@@ -120,6 +122,8 @@ PYBIND11_MODULE(_host, m) {
             s.trainStep(cam, ref_depth, base_color, clamped.has_value() ? *clamped : torch::Tensor());
         }, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"), py::arg("ref_depth_clamped") = py::none())
         .def("reserveWorkspace", &SLAMGaussianModel::reserveWorkspace)
+        .def("checkBinningCapacity", &SLAMGaussianModel::checkBinningCapacity)
+        .def("adamState", [](SLAMGaussianModel& s) { return s.adamState(); })
         .def("lossSum", &SLAMGaussianModel::lossSum)
         .def("initOptimizers", &SLAMGaussianModel::initOptimizers, py::arg("max_iterations") = -1,
              py::arg("scene_scale") = 1.0f)
@@ -242,6 +246,10 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)
         .def_readwrite("pump_iters_per_frame", &SLAMPipeline::pump_iters_per_frame)
         .def("flush", &SLAMPipeline::flush, py::call_guard<py::gil_scoped_release>())
+        .def("removeRedundantGs", &SLAMPipeline::removeRedundantGs)
+        .def_readwrite("large_scale_thres", &SLAMPipeline::large_scale_thres)
+        .def_readwrite("small_scale_thres", &SLAMPipeline::small_scale_thres)
+        .def_readwrite("low_opac_thres", &SLAMPipeline::low_opac_thres)
         .def("stats", [](SLAMPipeline& p) {
             { py::gil_scoped_release nogil; p.flush(); }
             py::dict d;

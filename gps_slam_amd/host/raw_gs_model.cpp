@@ -100,6 +100,28 @@ gps_splat_step& RawGaussianModel::stepStruct(int W, int H) {
     return s;
 }
 
+std::pair<int64_t, int64_t> RawGaussianModel::checkBinningCapacity() {
+    if (!B_.counts.defined()) return {0, 0};
+    auto c = B_.counts.cpu();  // blocking 32-byte read-back
+    const int64_t* h = c.data_ptr<int64_t>();
+    const int64_t ni = h[0], ng = h[1];
+    const bool overflow = h[2] != 0;
+    const int64_t icap = step_.isect_capacity, gcap = step_.group_capacity;
+    // grow ahead of need (group capacity is 2 x the intersection capacity): the next stepStruct() re-creates the
+    // capacity-sized buffers, and the sticky flag with them
+    int64_t want = icap;
+    const int64_t need = std::max(ni, (ng + 1) / 2);
+    while (want < 2 * need) want *= 2;
+    if (overflow) want = std::max(want, 2 * icap);
+    if (want != icap) { isect_capacity = want; step_cap_ = -1; }
+    (void)gcap;
+    TORCH_CHECK(!overflow, "tile-intersection buffers overflowed (capacity ", icap, " intersections / ", gcap,
+                " groups): Gaussians were dropped from a render or a backward pass since the last check.  The capacity has been "
+                "raised to ", isect_capacity, " for the following iterations; set isect_capacity in the model configuration "
+                "to start there.");
+    return {ni, ng};
+}
+
 void RawGaussianModel::bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
                                   const torch::Tensor& base_color, const torch::Tensor& gt_rgb) {
     TORCH_CHECK(cam.on_device(), "Camera::toGPU() must run before the camera is rendered (slam_pipeline.cpp:84)");

@@ -36,6 +36,12 @@ public:
     // Allocate everything an iteration at this image size needs (intermediates, Adam state) now instead of lazily on the
     // first forward / initOptimizers -- keeps one-off hipMalloc + memset time out of the frame loop.
     void reserveWorkspace(int width, int height);
+    // Capacity check of the binning buffers, meant for a point where the host synchronises anyway (once per keyframe:
+    // SLAMPipeline::removeRedundantGs).  The kernels clamp n_isects / n_groups to the buffer capacities and raise a sticky
+    // device flag where the reference would have allocated exact sizes (isect_tiles_no_depth.cu:238-262); this reads it back.
+    // Overflow since the last check -> throws (Gaussians were dropped from a render / backward); more than half of a
+    // capacity in use -> the buffers are doubled before the next iteration.  Returns {n_isects, n_groups} of the last launch.
+    std::pair<int64_t, int64_t> checkBinningCapacity();
     void initOptimizers(int max_iterations = -1, float scene_scale = 1);  // raw_gs_model.cpp:654-675
     void optimizersZeroGrad();
     void optimizersStep();
@@ -56,6 +62,14 @@ public:
     int getGaussianNum() { return opt_gs_params.getGaussianNum(); }
     std::string getRenderMethod() const { return render_method; }
     std::vector<torch::Tensor> grads();  // gradients of the last iteration, reference parameter order
+    // Adam state as [:N] views: {exp_avg x 6, exp_avg_sq x 6} in reference parameter order (empty before initOptimizers)
+    std::vector<torch::Tensor> adamState() {
+        std::vector<torch::Tensor> out;
+        if (!have_opt_) return out;
+        const int64_t N = opt_gs_params.getGaussianNum();
+        for (auto* vec : {&adam_m_, &adam_v_}) for (auto& t : *vec) out.push_back(t.slice(0, 0, N));
+        return out;
+    }
 
     static torch::Tensor clampRefDepth(const torch::Tensor& ref_depth);  // raw_gs_model.cpp:205-207
 

@@ -70,8 +70,13 @@ void SLAMPipeline::loadConfig(const Config& c) {
 
 // ------------------------------------------------------------------ raycast -> tensors (runRaycastByCam :362-415)
 TensorDict SLAMPipeline::runRaycastByCam(const Camera& cam, bool use_cam_depth) {
-    (void)use_cam_depth;
-    return raycastCam(cam, main_engine->camPoses);
+    TensorDict m = raycastCam(cam, main_engine->camPoses);
+    if (use_cam_depth) {  // slam_pipeline.cpp:405-408: the sensor depth instead of the raycast's (no call site of the loop uses it)
+        TORCH_CHECK(cam.depth.defined(), "runRaycastByCam(use_cam_depth = true): the camera has no depth image");
+        m["depth_map"] = cam.depth.contiguous().to(device);
+        m["depth_map_clamped"] = RawGaussianModel::clampRefDepth(m["depth_map"]);
+    }
+    return m;
 }
 
 TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses) {
@@ -218,6 +223,9 @@ void SLAMPipeline::removeRedundantGs() {
     auto mask = (smax < small_scale_thres) | (smax > large_scale_thres) |
                 (model->getRealOpacities().squeeze(-1) < low_opac_thres);
     const int64_t n = mask.sum().item<int64_t>();  // the reference syncs 5 times here for its printf; once is enough
+    // the host is synchronised with the map stream right here: look at the capacity flags the kernels cannot raise as exceptions
+    model->checkBinningCapacity();
+    main_engine->checkRenderingBlocks();
     if (n > 0) {
         model->prunePoints(mask);
         stats.pruned += n;

@@ -156,6 +156,17 @@ void TsdfEngine::runRaycast(ORUtils::SE3Pose* pose, ITMLib::ITMIntrinsics* intri
     check(gps_tsdf_free_raycast(&s, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
 }
 
+bool TsdfEngine::checkRenderingBlocks() {
+    auto c = counters_.cpu();
+    const bool over = c.data_ptr<int32_t>()[GPS_TSDF_OVERFLOW] != 0;
+    if (over && !warned_rendering_blocks_) {
+        fprintf(stderr, "gps_slam_amd: more than 262144 rendering blocks in a CreateExpectedDepths call: the ray z-ranges of "
+                        "that view were computed from a truncated block list (as the reference does, silently)\n");
+        warned_rendering_blocks_ = true;
+    }
+    return over;
+}
+
 // ------------------------------------------------------------------------------------------------ meshing
 std::pair<torch::Tensor, torch::Tensor> TsdfEngine::MeshScene(int64_t maxTriangles) {
     auto tri = torch::empty({maxTriangles, 7, 3}, f32(device_));

@@ -166,6 +166,10 @@ public:
     // hash.dat, excess.dat, last.txt} in the reference's MemoryBlockPersister format (size_t count + raw elements)
     void SaveToFile(const std::string& saveOutputDirectory);
     void LoadFromFile(const std::string& saveInputDirectory);
+    // MAX_RENDERING_BLOCKS (262144) exceeded in some CreateExpectedDepths since the last check?  The reference drops the excess
+    // blocks silently (ITMVisualisationEngine_CUDA.tcu:150-163); here the kernel raises counters[GPS_TSDF_OVERFLOW] and this
+    // (blocking) read-back turns it into one warning on stderr per engine.  Returns the flag.
+    bool checkRenderingBlocks();
     const gps_tsdf_state& state() const { return state_; }
     torch::Tensor currentRgb() const { return frame_inputs_.empty() ? torch::Tensor() : frame_inputs_[0]; }  // view->rgb, [H,W,4] u8
     torch::Tensor counters() const { return counters_; }
@@ -188,6 +192,7 @@ public:
     ITMLib::ITMIntrinsics intrinsics_d;            // view->calib.intrinsics_d
     std::vector<torch::Tensor> gtC2wPoses;         // dataset poses, [4,4] float CPU tensors (push before ProcessFrame)
     bool trackingActive = true;
+    bool warned_rendering_blocks_ = false;
     int framesProcessed = 0;
 
 private:

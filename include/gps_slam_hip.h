@@ -95,7 +95,9 @@ GPS_API int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity);
  *      tile_offsets[tile_h*tile_w];
  *      counts[4] (device int64): {n_isects, n_groups, overflow_flag, n_visible}.
  * If n_isects > isect_capacity or n_groups > group_capacity the excess is dropped, counts[2] is
- * set non-zero and counts[0]/[1] hold the clamped values. */
+ * set non-zero and counts[0]/[1] hold the clamped values.  counts[2] is sticky: the library only ever raises it (the
+ * caller zeroes counts before the first call and after handling an overflow), so a host that reads it once per
+ * keyframe still learns of an overflow in any launch in between. */
 GPS_API int gps_isect_tiles_no_depth(int N, const float *means2d, const int32_t *radii, int tile_size, int tile_width,
                              int tile_height, int64_t isect_capacity, int64_t group_capacity,
                              int32_t *tiles_per_gauss, int64_t *isect_ids, int32_t *flatten_ids,

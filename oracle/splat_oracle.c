@@ -737,8 +737,8 @@ ORC_API void orc_raster_ges_bwd_gs_flip_budget(int W, int H, int N, int64_t n_gr
             b[4] += fabsf(0.5f * v_sigma * dx * dx);
             b[5] += fabsf(v_sigma * dx * dy);
             b[6] += fabsf(0.5f * v_sigma * dy * dy);
-            b[7] += fabsf(v_sigma * (ca * dx + cb * dy));
-            b[8] += fabsf(v_sigma * (cb * dx + cc * dy));
+            b[7] += fabsf(v_sigma) * (fabsf(ca * dx) + fabsf(cb * dy));   /* |terms|: the inner sum cancels as well */
+            b[8] += fabsf(v_sigma) * (fabsf(cb * dx) + fabsf(cc * dy));
             b[9] += fabsf(vis * v_alpha);
             n_pairs[0]++;
             if (g != last_counted) { n_pairs[1]++; last_counted = g; }
