@@ -509,7 +509,10 @@ __global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* 
     if (i >= P) return;
     const float4 r = rays[i];
     const uchar4 c = colour[i];
-    color_map[3 * i] = (float)c.x / 255.0f; color_map[3 * i + 1] = (float)c.y / 255.0f; color_map[3 * i + 2] = (float)c.z / 255.0f;
+    // .to(kFloat).div(255.0) (cv_utils.cpp:327): ATen divides a tensor by a host scalar as a multiplication with the float
+    // reciprocal (BinaryDivTrueKernel: inv_b = 1 / b), which is NOT the IEEE quotient for every byte value -- reproduced
+    const float inv255 = 1.0f / 255.0f;
+    color_map[3 * i] = (float)c.x * inv255; color_map[3 * i + 1] = (float)c.y * inv255; color_map[3 * i + 2] = (float)c.z * inv255;
     const float keep = r.w > 0 ? 1.0f : 0.0f;
     const float vx = (r.x * keep) * voxel_size, vy = (r.y * keep) * voxel_size, vz = (r.z * keep) * voxel_size;
     vertex_map[3 * i] = vx; vertex_map[3 * i + 1] = vy; vertex_map[3 * i + 2] = vz;

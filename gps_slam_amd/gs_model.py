@@ -358,6 +358,28 @@ class RawGaussianModel:
     def loss_sum(self):
         return self._B["loss"]
 
+    def check_binning_capacity(self):
+        """RawGaussianModel::checkBinningCapacity (host/raw_gs_model.cpp): blocking read-back of the binning counts.  The
+        kernels clamp n_isects / n_groups to the buffer capacities and raise a sticky flag where the reference would have
+        allocated exact sizes; an overflow since the last check raises, more than half of a capacity in use doubles the
+        buffers before the next iteration.  -> (n_isects, n_groups) of the last launch."""
+        if self._B is None:
+            return 0, 0
+        ni, ng, overflow, _ = self._B["counts"].cpu().tolist()
+        icap = int(self._step.isect_capacity)
+        want, need = icap, max(ni, (ng + 1) // 2)
+        while want < 2 * need:
+            want *= 2
+        if overflow:
+            want = max(want, 2 * icap)
+        if want != icap:
+            self.isect_capacity = want
+            self._step = None  # re-created (with zeroed counts) by the next _step_struct
+        if overflow:
+            raise RuntimeError("tile-intersection buffers overflowed (capacity %d): Gaussians were dropped from a render or a "
+                               "backward pass; capacity raised to %d for the following iterations" % (icap, want))
+        return ni, ng
+
     # ------------------------------------------------------------------ structure edits (every 10 frames)
     def prunePoints(self, delete_mask):
         """raw_gs_model.cpp:635-644 (+ removeFromOptimizer): stable compaction of params and Adam state"""

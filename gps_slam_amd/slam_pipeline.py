@@ -193,6 +193,7 @@ class SLAMPipeline:
         mask = (smax < c["small_scale_thres"]) | (smax > c["large_scale_thres"]) | \
                (model.getRealOpacities().squeeze(-1) < c["low_opac_thres"])
         n = int(mask.sum())  # the reference syncs 5 times here for its printf; once is enough
+        model.check_binning_capacity()  # the host is synchronised here anyway: read the kernels' sticky overflow flag
         if n > 0:
             model.prunePoints(mask)
             self.stats["pruned"] += n
