@@ -21,29 +21,69 @@ def _time_launches(fn, n, stream):
     return start.elapsed_time(end) * 1e-3 / n
 
 
-def dominant_kernel_roofline(model, pipe, eng, cams, device, hbm_peak_gbs):
-    """Dominant kernel of the step = the Gaussian-parallel ges backward (raster_ges_bwd_gs_kernel): it has the
-    largest share of GPU time per SLAM frame (2 launches/frame; see profiles/).  Measured live with events on the
-    stream the C-ABI launches on (torch's current stream), on the last optimisation camera of the run, through the
-    same C-ABI entry point with accumulate=1 (exactly one kernel per call).  `others` lists the forward rasterizer."""
+def iteration_bytes(N, Nv, I, G, P, T):
+    """Algorithmic (compulsory) HBM bytes of one optimise iteration, SURVEY.md 8(d), term by term."""
+    terms = {
+        "proj_fwd": 68 * N, "sh_fwd": 217 * Nv, "binning": 24 * N + 44 * I + 8 * G + 4 * T, "raster_fwd": 44 * I + 28 * P,
+        "compose_l1": 40 * P, "raster_bwd": 52 * G + 24 * P + 40 * G, "sh_bwd": 408 * Nv, "proj_bwd": 116 * Nv + 40 * N,
+        "adam": 28 * 59 * N,
+    }
+    return float(sum(terms.values())), {k: float(v) for k, v in terms.items()}
+
+
+def fusion_bytes(P, V, S):
+    """Algorithmic HBM bytes of one TSDF frame, SURVEY.md 8(d), WITHOUT the ray term (hash / voxel gathers of neighbouring
+    rays are largely L2 resident; S-bar, the mean steps per ray, is not logged by the kernel): upload + convert + allocate (depth
+    + 2 probes x 16 B) + two table sweeps + integrate R/W + visible list + min/max image + raycast outputs."""
+    return float(6 * P + 6 * P + 4 * P + 32 * P + 2 * S * 17 + V * 8192 + V * 16 + 8 * P / 64.0 + 20 * P)
+
+
+def _python_twin(scene, device):
+    """The C++ model's state in the Python mirror (same C-ABI, same buffer layout) for the per-kernel measurements below;
+    the timed region never touched it."""
+    from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
+    cp = scene.model.getGaussianParms()
+    model = SLAMGaussianModel(dict(capacity=1 << 19, isect_capacity=8 << 20), device=device)
+    model.add_params(dict(means=cp.getMeans().clone(), scales=cp.getScales().clone(), quats=cp.getQuats().clone(),
+                          featuresDc=cp.getFeaturesDc().clone(), featuresRest=cp.getFeaturesRest().clone(),
+                          opacities=cp.getOpacities().clone()))
+    oc, orc = scene.pipe.optCams(), scene.pipe.optRaycasts()
+    c, rc = oc[-1], orc[-1]
+    cam = Camera(c.id, c.width, c.height, c.fx, c.fy, c.cx, c.cy, c.c2w.cpu().numpy(), image=c.image, device=device)
+    cam.c2w_slam = c.c2w_slam.cpu()
+    cam.invalidate()
+    return model, cam, rc
+
+
+def iteration_roofline(scene, seq, result, hbm_peak_gbs, K):
+    """`roofline` of the bench line, all of it measured on the state the timed run ended in (no stored constants are divided
+    by live times):
+
+    * dominant kernel = the Gaussian-parallel ges backward (largest share of GPU time per SLAM frame): `achieved` =
+      algorithmic bytes (SURVEY 8(d) raster-bwd row x the G, P of this launch) / average launch duration, HIP events on the
+      launch stream, accumulate = 1 so exactly one kernel per call;
+    * `iteration`: B_iter of SURVEY 8(d) evaluated with the logged N, Nv, I, G / the measured duration of one whole optimise
+      iteration (gps_splat_train_step, 20 back-to-back) -> fraction of HBM peak;
+    * `frame`: (2 B_iter + B_fuse) / the measured ms_per_step (20 iterations per 10 frames; B_fuse without the ray term);
+    * `traffic` (HBM bytes per launch from --pmc passes) only if profiles/pmc_raster_bwd.json was collected on a scene whose
+      (N, G) match this one within 1 %; otherwise null.  tools/profile.sh regenerates the file.
+    """
     import json
     from gps_slam_amd._lib import lib
+    device = "cuda:%d" % torch.cuda.current_device()
+    model, cam, rc = _python_twin(scene, device)
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
-    cam = pipe.opt_cam_list[-1] if pipe.opt_cam_list else cams[-1]
-    rc = pipe.opt_raycast_list[-1] if pipe.opt_raycast_list else pipe.runRaycastByCam(cam)
-    if model._opt is None:
-        model.initOptimizers(-1, 1.0)
+    model.initOptimizers(-1, 1.0)
     model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
     torch.cuda.synchronize()
     B, st = model._B, model._step
     counts = B["counts"].cpu().tolist()
     ni, ng, nvis = int(counts[0]), int(counts[1]), int(counts[3])
     W, H, N = st.width, st.height, st.N
-    P = W * H
+    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     ref = rc["depth_map_clamped"]
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    pp = model.opt_gs_params
 
     def fwd():  # the forward the fused step launches (packed-math kernel over the preprocess records)
         lib.gps_raster_ges_fwd_rec(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]),
@@ -56,35 +96,107 @@ def dominant_kernel_roofline(model, pipe, eng, cams, device, hbm_peak_gbs):
                                   ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]),
                                   ptr(B["v_opacities"]), 1, sp)
 
+    def step():
+        model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+
     t_bwd = _time_launches(bwd, 50, stream)
     t_fwd = _time_launches(fwd, 50, stream)
-    # algorithmic bytes, SURVEY 8(d) raster-bwd row: 52 B Gaussian record per 32-px group + gradient image once
-    # (24 B/px) + 40 B of accumulations per group
+    t_iter = _time_launches(step, 20, stream)
     alg_bwd = 52.0 * ng + 24.0 * P + 40.0 * ng
     alg_fwd = 44.0 * ni + 4.0 * P + 20.0 * P
     ach = alg_bwd / t_bwd / 1e9
-    traffic, valu = None, None
+    b_iter, terms = iteration_bytes(N, nvis, ni, ng, P, T)
+    V = int(scene.engine.counters().cpu()[2])  # GPS_TSDF_N_VISIBLE of the last fused frame
+    S = 0x100000 + 0x20000
+    b_fuse = fusion_bytes(P, V, S)
+    t_frame = result["ms_per_step"] * 1e-3
+    b_frame = 2.0 * b_iter + b_fuse
+    traffic, traffic_note, valu = None, "no PMC file for this scene", None
     pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_raster_bwd.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            traffic = rec.get("hbm_bytes_per_launch")
-            insts = (rec.get("wave_instructions_per_launch") or {}).get("SQ_INSTS_VALU")
-            if insts:
-                # issue-side yardstick for a VALU-bound kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles;
-                # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md) -> fraction of the chip's VALU issue slots this launch used
-                valu = {"wave_instructions": insts, "issue_frac": insts * 4.0 / (1024 * 2.4e9 * t_bwd),
-                        "note": "SQ_INSTS_VALU (own --pmc pass, profiles/pmc_raster_bwd.json) x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)"}
+            u = rec.get("units") or {}
+            if u and abs(u.get("n_groups", 0) - ng) <= 0.01 * ng and abs(u.get("gaussians", 0) - N) <= 0.01 * N:
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_note = "profiles/pmc_raster_bwd.json (same scene: N and G within 1 %): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
+                valu = rec.get("valu")
+            else:
+                traffic_note = "profiles/pmc_raster_bwd.json was collected on a different scene (its N, G: %s, %s) -- not reported" % (
+                    u.get("gaussians"), u.get("n_groups"))
         except (OSError, ValueError):
-            traffic = None
+            pass
     return {"bound": "hbm", "kernel": "raster_ges_bwd_gs_kernel", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
-            "frac": ach / hbm_peak_gbs, "traffic": traffic, "valu": valu, "avg_launch_us": t_bwd * 1e6,
-            "algorithmic_bytes": alg_bwd, "units": {"n_groups": ng, "pixels": P, "n_isects": ni, "gaussians": N,
-                                                    "n_visible": nvis},
-            "note": "rasterization is ALU/LDS-issue bound (exp + ~40 flop per pixel-Gaussian pair), not a stream; "
-                    "the HBM fraction is reported because it is the contract's yardstick",
+            "frac": ach / hbm_peak_gbs, "traffic": traffic, "traffic_note": traffic_note, "valu": valu,
+            "avg_launch_us": t_bwd * 1e6, "algorithmic_bytes": alg_bwd,
+            "units": {"n_groups": ng, "pixels": P, "n_isects": ni, "gaussians": N, "n_visible": nvis, "tiles": T,
+                      "visible_blocks": V},
+            "iteration": {"algorithmic_bytes": b_iter, "terms": terms, "avg_us": t_iter * 1e6,
+                          "achieved_GBs": b_iter / t_iter / 1e9, "frac": b_iter / t_iter / 1e9 / hbm_peak_gbs},
+            "frame": {"algorithmic_bytes": b_frame, "fusion_bytes_without_ray_term": b_fuse, "ms": t_frame * 1e3,
+                      "achieved_GBs": b_frame / t_frame / 1e9, "frac": b_frame / t_frame / 1e9 / hbm_peak_gbs},
+            "note": "rasterization is ALU/LDS-issue bound (exp + ~40 flop per pixel-Gaussian pair), not a stream; the HBM "
+                    "fraction is reported because it is the contract's yardstick",
             "others": {"raster_ges_fwd_pk_kernel": {"avg_launch_us": t_fwd * 1e6, "algorithmic_bytes": alg_fwd,
                                                  "achieved_GBs": alg_fwd / t_fwd / 1e9}}}
+
+
+def render_psnr_vs_oracle(model, cam, rc, seq):
+    """PSNR (scripts/utils/image_utils.py:19-21) of the HIP render of the final state against the CPU
+    restatement's render of the same state (same parameters, pose, raycast maps), both clamped to [0,1], full image."""
+    from oracle import splat_ref as orc
+    cp = model.getGaussianParms()
+    n = lambda t: t.detach().cpu().numpy()
+    K = np.array([[seq["fx"], 0, seq["cx"]], [0, seq["fy"], seq["cy"]], [0, 0, 1]], np.float32)
+    W, H = seq["W"], seq["H"]
+    t0 = time.perf_counter()
+    e_rgb, _ = orc.ges_render(n(cp.getMeans()), n(cp.getScales()), n(cp.getQuats()), n(cp.getFeaturesDc()), n(cp.getFeaturesRest()),
+                              n(cp.getOpacities()), n(cam.c2w_slam), K, W, H, n(rc["depth_map"])[..., 0], n(rc["color_map"]),
+                              delta_depth=0.1)
+    oracle_s = time.perf_counter() - t0
+    with torch.no_grad():
+        got = model.forward(cam, rc["depth_map"], rc["color_map"])["rgb"].clamp(0, 1).double()
+    exp = torch.as_tensor(e_rgb).to(got.device).clamp(0, 1).double()
+    mse = float(((got - exp) ** 2).mean())
+    return {"render_psnr_db_vs_oracle": (-10.0 * float(np.log10(mse))) if mse > 0 else float("inf"),
+            "render_max_abs_diff_vs_oracle": float((got - exp).abs().max()), "oracle_render_seconds": oracle_s}
+
+
+def fusion_split(seq, first, K, gt_pose, dt_total):
+    """Fusion-FPS / Gaussian-FPS split as the reference reports it (run/read_results.py:38-39): the TSDF-only `recon` loop over
+    the same timed frames (upload + tracking + fuse + raycast, no Gaussians) on a fresh engine gives the fusion share, the
+    rest of the step time is the Gaussian share."""
+    import gps_slam_amd._host as H_
+    W, H = seq["W"], seq["H"]
+    reader = H_.DatasetReader(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    cams = []
+    for k in range(first + K):
+        c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k]))
+        c.id = k
+        c.image = torch.as_tensor(seq["rgb"][k].astype(np.float32) / 255.0)
+        c.depth = torch.as_tensor(seq["depth"][k].astype(np.float32) / 1000.0)[..., None]
+        reader.addTrainCamera(c)
+        pc = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k]))
+        pc.id = k
+        cams.append(pc)
+    cli = H_.createTsdfEngine(reader, dict(voxel_size=0.005, trunc_dist=0.02, viewFrustum_min=0.2, viewFrustum_max=10.0,
+                                           use_gt_pose=1 if gt_pose else 0))
+    model = H_.SLAMGaussianModel()
+    pipe = H_.SLAMPipeline(1)
+    pipe.setTsdfEngine(cli)
+    pipe.setModel(model)
+    pipe.work_mode = "recon"
+    for i in range(first):
+        pipe.processFrameCLI(i, cams[i])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(first, first + K):
+        pipe.processFrameCLI(i, cams[i])
+    torch.cuda.synchronize()
+    fusion_ms = 1000.0 * (time.perf_counter() - t1) / K
+    total_ms = 1000.0 * dt_total / K
+    return {"fusion_ms_per_frame": fusion_ms, "gaussian_ms_per_frame": max(0.0, total_ms - fusion_ms),
+            "fusion_fps": 1000.0 / fusion_ms, "gaussian_fps": 1000.0 / max(1e-9, total_ms - fusion_ms)}
 
 
 def cpu_baseline(seq, W, H, max_seconds=20.0):

@@ -79,6 +79,10 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("id", &Camera::id)
         .def_readwrite("width", &Camera::width)
         .def_readwrite("height", &Camera::height)
+        .def_readwrite("fx", &Camera::fx)
+        .def_readwrite("fy", &Camera::fy)
+        .def_readwrite("cx", &Camera::cx)
+        .def_readwrite("cy", &Camera::cy)
         .def_readwrite("image", &Camera::image)
         .def_readwrite("depth", &Camera::depth)
         .def_readwrite("c2w", &Camera::c2w)

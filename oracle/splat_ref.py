@@ -264,3 +264,32 @@ def ssim_bwd(img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12):
     _lib().orc_ssim_bwd(C.c_int(B), C.c_int(CH), C.c_int(H), C.c_int(W), _p(img1), _p(img2), _p(dL_dmap), _p(_f32(dm_dmu1)),
                         _p(_f32(dm_dsigma1_sq)), _p(_f32(dm_dsigma12)), _p(g))
     return g
+
+
+# ----------------------------------------------------------------------------- gesForward as a whole
+def ges_render(means, log_scales, quats, sh_dc, sh_rest, opac_logit, c2w, K, W, H, ref_depth, base_color, delta_depth=0.1,
+               sh_degree=3, max_gs_radii=100, tile_size=16):
+    """RawGaussianModel::gesForward under NoGradGuard (src/raw_gs_model.cpp:188-367) with the oracle operators:
+    exp / projection / radii clamp / SH / clamp_min / sigmoid -> binning -> ges rasterizer -> compose with the TSDF layer.
+    ref_depth [H,W] is the RAW raycast depth (0 = miss; clamped to 1000 below 0.01 as raw_gs_model.cpp:205-207),
+    base_color [H,W,3].  -> rgb [H,W,3] float32, weight_sum [H,W]."""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    means, log_scales, quats, sh_dc, sh_rest, opac_logit = map(f, (means, log_scales, quats, sh_dc, sh_rest, opac_logit))
+    c2w = np.asarray(c2w, np.float32)
+    R, t = c2w[:3, :3], c2w[:3, 3]
+    vm = np.eye(4, dtype=np.float32)
+    vm[:3, :3] = R.T
+    vm[:3, 3] = -R.T @ t
+    radii, m2, depths, conics = proj_fwd(means, quats, np.exp(log_scales), vm, np.asarray(K, np.float32), W, H)
+    radii = np.minimum(radii, max_gs_radii)
+    sh = np.concatenate([sh_dc[:, None], sh_rest], 1)
+    rgb = np.maximum(sh_fwd(sh_degree, means - t[None], sh, radii > 0) + np.float32(0.5), np.float32(0.0))
+    colors = np.concatenate([rgb, depths[:, None]], 1).astype(np.float32)
+    opac = (np.float32(1.0) / (np.float32(1.0) + np.exp(-opac_logit.reshape(-1)))).astype(np.float32)
+    tw, th = (W + tile_size - 1) // tile_size, (H + tile_size - 1) // tile_size
+    _, _, flat, _, _, offs = isect_tiles(m2, radii, tile_size, tw, th)
+    ref = f(ref_depth).reshape(H, W)
+    ref_c = np.where(ref < 0.01, np.float32(1000.0), ref).astype(np.float32)
+    rc, ws, _ = raster_ges_fwd(m2, conics, colors, opac, ref_c, W, H, tile_size, offs, flat, delta_depth)
+    out = (rc[..., :3] + f(base_color)) / (ws[..., None] + np.float32(1.0))
+    return out.astype(np.float32), ws

@@ -1,0 +1,69 @@
+"""BASELINE configs[3] at full size, as bench.py runs it: 1280x720 RGB-D, 5 mm voxels, ~400k pre-seeded Gaussians, depth-ICP
+tracking ON, the whole SLAM loop through the reference's construction path (createTsdfEngine -> CLIEngine -> SLAMPipeline,
+per-frame upload) for three keyframe periods -- and the same for configs[2]'s 640x480 / 200k.  Checked against the oracle:
+
+  * the TSDF volume the HIP loop built along its TRACKED trajectory is bit-identical to what the CPU restatement of the ITMLib
+    engine (oracle/tsdf_oracle.c, pinned bit-for-bit by the reference's own CPU engine) builds from the same frames and poses;
+  * the tracked poses stay on the ground-truth orbit;
+  * the optimised model's render equals the CPU restatement's render of the same state (PSNR > 60 dB), and it is closer to
+    the input image than the TSDF colour alone.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("W,H,n_gauss,oracle_frames", [(1280, 720, 400000, 12), (640, 480, 200000, 31)], ids=["720p-400k", "480p-200k"])
+def test_full_pipeline_tracking_on_at_baseline_size(W, H, n_gauss, oracle_frames):
+    import bench
+    from bench_kernels import render_psnr_vs_oracle
+    from oracle import tsdf_ref as R
+    n, seed = 31, 1234
+    seq = bench.synthetic_sequence(W, H, n, seed)
+    seeds = bench.seed_gaussians(seq, n_gauss, seed, DEV)
+    scene = bench.Scene(seq, seeds, seed, use_gt_pose=False, overlap=False, n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02)
+    eng = scene.engine
+    # the CPU restatement follows frame by frame with the pose the HIP tracker produced (the first `oracle_frames` frames at
+    # 720p: the single-threaded oracle needs ~1.5 s per 5 mm frame of that size)
+    o = R.TsdfOracle(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0)
+    for i in range(n):
+        scene.pipe.processFrameCLI(i, scene.cams[i])
+        if i < oracle_frames:
+            torch.cuda.synchronize()
+            pose = eng.lastPose().numpy()
+            # the frame as createTsdfEngine converted it (cv_utils.cpp:57-101): truncating * 255, rounding * 1000
+            rgb = (seq["rgb"][i].astype(np.float32) / np.float32(255.0) * np.float32(255.0)).astype(np.uint8)
+            o.process_frame(rgb, seq["depth"][i], pose[0].copy(), pose[1].copy())
+            c = eng.counters().cpu().numpy()
+            assert [int(c[2]), int(c[0]), int(c[1])] == [o.n_visible, o.last_free_block, o.last_free_excess], i
+            live = eng.GetLiveVertex().cpu().numpy().reshape(H, W, 4)
+            assert live.tobytes() == o.image("raycast").tobytes(), "live raycast of frame %d differs from the oracle" % i
+    scene.pipe.flush()
+    torch.cuda.synchronize()
+    o.close()
+    st = dict(scene.pipe.stats())
+    assert st["frames"] == n and st["opt_iters"] == 60 and st["raycasts"] >= 12, st
+    N = scene.model.getGaussianNum()
+    assert 0.9 * n_gauss < N < 1.25 * n_gauss, N
+    # tracked trajectory vs ground truth (world = first camera in both)
+    for i in (5, 15, 30):
+        est, gt = scene.cams[i].c2w_slam.cpu().numpy(), seq["c2w"][i]
+        assert np.linalg.norm(est[:3, 3] - gt[:3, 3]) < 5e-3, (i, est[:3, 3], gt[:3, 3])
+        cos = (np.trace(est[:3, :3].T @ gt[:3, :3]) - 1.0) / 2.0
+        assert np.degrees(np.arccos(np.clip(cos, -1, 1))) < 0.2, i
+    assert float(eng.trackDiag()[8]) > 0.3 * W * H  # inliers of the last accepted evaluation
+    # the optimised model: HIP render == CPU restatement's render of the same state; better than the TSDF colour alone
+    cams, rcs = scene.pipe.optCams(), scene.pipe.optRaycasts()
+    q = render_psnr_vs_oracle(scene.model, cams[-1], rcs[-1], seq)
+    print("N=%d, render PSNR HIP vs oracle %.1f dB (max |diff| %.2e), oracle render %.1f s" %
+          (N, q["render_psnr_db_vs_oracle"], q["render_max_abs_diff_vs_oracle"], q["oracle_render_seconds"]))
+    assert q["render_psnr_db_vs_oracle"] > 60.0
+    with torch.no_grad():
+        res = scene.model.forward(cams[-1], rcs[-1]["depth_map"], rcs[-1]["color_map"])
+    err_render = (res["rgb"] - cams[-1].image).abs().mean().item()
+    err_tsdf = (rcs[-1]["color_map"] - cams[-1].image).abs().mean().item()
+    assert err_render <= err_tsdf * 1.02, (err_render, err_tsdf)
+    scene.close()
