@@ -7,17 +7,27 @@
 //   (per-iteration reduction + 32-float read-back); Engines/LowLevel/Shared/ITMLowLevelEngine_Shared.h:48-69;
 //   ORUtils/Cholesky.h, ORUtils/SE3Pose.cpp (tsdf_pose.hpp).
 //
-// The reference's GPU tracker is a host loop: per Levenberg-Marquardt iteration one evaluation kernel, a 32-float read-back,
-// the 6x6 solve + SE3 update on the host, the next launch -- ~18 dependent host round trips per frame, which on this path
-// was the frame stream's critical chain (round 1: 0.37 of 0.70 ms per frame).  Here the WHOLE of TrackCamera is one
-// persistent launch (track_lm_kernel): pyramid, then per level a device-side loop
-//     evaluate all pixels -> one row of partial sums per workgroup -> grid rendezvous -> every workgroup adds the rows in a
-//     fixed order and runs the LM bookkeeping (Cholesky, damping, ApplyDelta, SetInvM + Coerce, convergence test) on its own
-//     LDS copy of the state
-// and ONE read-back per frame (pose + diagnostics, written straight into a pinned host mailbox).  The reduction is a fixed
-// tree (per-thread register sums -> wave -> workgroup -> 16 row groups added in order), so results are reproducible run to
-// run; they differ from the CPU engine's scan-order sums only by float re-association (poses agree to ~1e-5,
-// tests/test_tsdf_gpu.py).
+// Split like the reference's GPU tracker -- the per-pixel residual / Jacobian evaluation and its reduction are kernels, the
+// 6x6 Levenberg-Marquardt bookkeeping (Cholesky, step, SE3 coercion, accept / reject) is host code fed by 32 floats per
+// iteration -- with the launch train around it cut down:
+//
+//   track_prepare_kernel      depth pyramid (all levels) + valid-pixel count + interleaved ICP maps: ONE launch per frame
+//                             (the reference: one subsample kernel per level; round 1 here: 5 launches)
+//   track_eval_kernel<ITER>   one LM iteration: every workgroup evaluates its pixels and stores one row of partial sums; the
+//                             LAST workgroup to arrive adds the rows in a fixed order and writes the 32 totals straight into a
+//                             pinned host mailbox the host spins on (no summing kernel, no memcpy, no stream synchronise)
+//
+// What was tried in round 2 and measured slower (kept out of the tree): (1) the whole LM loop in ONE persistent launch with a
+// grid-wide rendezvous per iteration -- correct, but all its workgroups must be resident at once, and next to the map stream's
+// rasterizer kernels the big spinning workgroups starved behind a steady supply of small ones (800 -> 120 frames/s with the
+// mapping overlap on); (2) a device-side state machine, one ordinary launch per iteration, the host only topping the queue up
+// ahead of a progress counter -- no host round trip at all, yet 0.90 instead of 0.71 ms per tracked frame: the 6x6 Cholesky +
+// two 4x4 inverses + SE3 log / exp run as ONE dependent instruction chain in one lane (~10 us; the host does it in < 1 us,
+// i.e. less than the PCIe round trip it saves), and carrying that code raised the evaluation's register allocation to 164
+// VGPRs (3 waves per SIMD), tripling the gather-latency-bound evaluation time.
+// The reduction is a fixed tree (per-thread register sums -> wave -> workgroup -> 8 row groups added in order), so results
+// are reproducible run to run; they differ from the CPU engine's scan-order sums only by float re-association (poses agree
+// to ~1e-5, tests/test_tsdf_gpu.py).
 #include <math.h>
 #include <sched.h>
 #include <stdlib.h>
@@ -125,79 +135,11 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
     }
 }
 
-// ---------------------------------------------------------------- the Levenberg-Marquardt loop, on the device
-// ORUtils::Cholesky (ORUtils/Cholesky.h) for the 3x3 / 6x6 normal equations.  The size is a template parameter so that every
-// loop unrolls and the factor lives in registers (with a run-time size the arrays go to scratch memory -- allocated for every
-// lane of every resident wave although one thread per workgroup solves).
-template <int N>
-struct Chol {
-    float ch[N * N];
-    __device__ __forceinline__ explicit Chol(const float* mat) {
-#pragma unroll
-        for (int i = 0; i < N * N; i++) ch[i] = mat[i];
-#pragma unroll
-        for (int c = 0; c < N; c++) {
-            float inv_diag = 1;
-#pragma unroll
-            for (int r = c; r < N; r++) {
-                float val = ch[c + r * N];
-#pragma unroll
-                for (int c2 = 0; c2 < c; c2++) val -= ch[c + c2 * N] * ch[c2 + r * N];
-                if (r == c) { ch[c + r * N] = val; inv_diag = 1.0f / val; }
-                else { ch[r + c * N] = val; ch[c + r * N] = val * inv_diag; }
-            }
-        }
-    }
-    __device__ __forceinline__ void backsub(float* result, const float* v) const {
-        float y[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            float val = v[i];
-#pragma unroll
-            for (int j = 0; j < i; j++) val -= ch[j + i * N] * y[j];
-            y[i] = val;
-        }
-#pragma unroll
-        for (int i = 0; i < N; i++) y[i] /= ch[i + i * N];
-#pragma unroll
-        for (int i = N - 1; i >= 0; i--) {
-            float val = y[i];
-#pragma unroll
-            for (int j = i + 1; j < N; j++) val -= ch[i + j * N] * result[j];
-            result[i] = val;
-        }
-    }
-    __device__ __forceinline__ float determinant() const {
-        float ret = 1.0f;
-#pragma unroll
-        for (int i = 0; i < N; ++i) ret *= ch[i + i * N];
-        return ret * ret;
-    }
-};
+constexpr int EV_THREADS = 256;
+constexpr int EV_MAX_WGS = 512;           // rows of the partial table
+constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 
-__device__ __forceinline__ void m4_mul(const float* a, const float* b, float* out) {  // ORUtils Matrix4 operator*
-    float r[16];
-#pragma unroll
-    for (int col = 0; col < 4; col++)
-#pragma unroll
-        for (int row = 0; row < 4; row++) {
-            float acc = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc += a[k * 4 + row] * b[col * 4 + k];
-            r[col * 4 + row] = acc;
-        }
-#pragma unroll
-    for (int i = 0; i < 16; i++) out[i] = r[i];
-}
-
-constexpr int LM_THREADS = 512;         // 8 waves with a 256-VGPR budget each: the 29 accumulators + 8 gathered float4 of the
-                                        // 6-parameter evaluation fit without spilling (a 1024-thread group spilled 50+ registers)
-constexpr int LM_MAX_WGS = 256;         // rows of the partial table; <= one workgroup per CU: co-resident by construction
-constexpr int LM_ROW_GROUPS = LM_THREADS / 32;
-constexpr int RES_FLOATS = 64;          // result block: M[16] | invM[16] | diag[16] | status, valid-pixel count | seq
-constexpr uint32_t LM_SPIN_LIMIT = 1u << 22;
-
-struct LmArgs {
+struct PrepArgs {
     gps_track_config cfg;
     const float* depth0;                // full-resolution depth (s.depth)
     float* level[GPS_TRACK_MAX_LEVELS]; // [0] unused
@@ -205,68 +147,26 @@ struct LmArgs {
     const float4* normals;
     float4* pn;
     int W, H;
-    float4 intr;                        // fx fy cx cy of level 0
-    float vf_min, vf_max;
-    int use_weights;
-    Mat4 pose_M, pose_invM, pose_pc_M;
-    uint32_t* partial;                  // [2][LM_MAX_WGS][GH_SLOTS] float bits
-    uint32_t* sync;                     // [0] rendezvous arrivals, [1] valid-pixel count (both zeroed before the launch)
-    float* result;                      // device [RES_FLOATS]
-    volatile float* mailbox;            // pinned host copy of `result` with the sequence number last, or nullptr
-    int seq;
+    uint32_t* sync;                     // [0] the evaluation's ticket, [1] valid-pixel count (both zeroed before the launch)
 };
 
-// The state the host loop of ITMExtendedTracker::TrackCamera keeps between iterations (ITMExtendedTracker.cpp:470-665).
-// Every workgroup holds an identical copy in LDS and updates it with identical arithmetic from identical totals, so the new
-// pose needs no broadcast: ONE grid-wide rendezvous per iteration.
-struct LmState {
-    float M[16], invM[16], approxInvPose[16], lastGoodM[16], lastGoodInvM[16];
-    float hessian_good[36], nabla_good[6], hessian_depth_good[36];
-    float f_old, lambda, f_depth_good;
-    int nvalid_depth_good, last_type, iters[GPS_TRACK_MAX_LEVELS];
-    int converged, failed;
-};
-
-// Grid-wide rendezvous without L2 flushes.  The XCDs' L2s are not coherent with each other: an agent-scope release / acquire
-// pair means buffer_wbl2 + buffer_inv of the WHOLE L2 -- per workgroup, per iteration, with the map stream's rasterizer
-// sharing that L2 (measured in round 1 on a last-block-done ticket: 758 -> 600 frames/s).  Everything exchanged between
-// workgroups inside the iteration loop therefore goes through agent-scope RELAXED atomics (sc1 stores / loads: write-through
-// to, and read from, the memory-side coherence point), ordered by program order + s_waitcnt: the partial row is stored,
-// vmcnt(0) waits for the stores' acknowledgements, then the arrival counter is incremented; a workgroup that has seen the
-// count reads the rows with sc1 loads.  No cache line of anything else is written back or invalidated.  The spin is bounded:
-// a workgroup that never sees the count reports failure instead of hanging the queue.
-__device__ __forceinline__ bool grid_rendezvous(uint32_t* counter, uint32_t target) {
-    __shared__ int ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): this wave's sc1 stores are acknowledged
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < LM_SPIN_LIMIT)
-            __builtin_amdgcn_s_sleep(2);
-        ok = spins < LM_SPIN_LIMIT;
-    }
-    __syncthreads();
-    return ok != 0;
-}
-
-// PrepareForEvaluation (ITMExtendedTracker.cpp:216-268) in one pass: a work item is one 2^(L-1) x 2^(L-1) block of
-// full-resolution pixels = one pixel of the coarsest level; it produces every pyramid pixel above that block locally
-// (filterSubsampleWithHoles is hierarchical: a level-l pixel is the mean of the VALID pixels among its four level-(l-1)
-// children, ITMLowLevelEngine_Shared.h:48-69), counts the valid full-resolution pixels and interleaves the ICP maps.
-__device__ __forceinline__ void build_pyramid(const LmArgs& a, int n_wgs) {
+// PrepareForEvaluation (ITMExtendedTracker.cpp:216-268) in one pass.  A work item is one
+// 2^(L-1) x 2^(L-1) block of full-resolution pixels = one pixel of the coarsest level; it produces every pyramid pixel above
+// that block locally (filterSubsampleWithHoles is hierarchical: a level-l pixel is the mean of the VALID pixels among its
+// four level-(l-1) children, ITMLowLevelEngine_Shared.h:48-69), counts the valid full-resolution pixels and interleaves the
+// ICP maps.
+__global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
     const int L = a.cfg.n_levels;
     const int B = 1 << (L - 1);  // block edge in level-0 pixels
     const int bw = (a.W + B - 1) / B, bh = (a.H + B - 1) / B;
-    // level sizes: repeated floor halving == a right shift
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < bw * bh; item += n_wgs * blockDim.x) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < bw * bh; item += stride) {
         const int by = item / bw, bx = item - by * bw;
-        // bottom-up: level l reads the level below from memory THIS thread wrote (level 0: the input); no other thread
-        // touches the block
+        // bottom-up: level l reads the level below from memory THIS thread wrote (level 0: the input)
         for (int l = 1; l < L; l++) {
             const int e = B >> l;  // edge of the block at level l
             const float* src = l == 1 ? a.depth0 : a.level[l - 1];
-            const int w_in = a.W >> (l - 1), lwl = a.W >> l, lhl = a.H >> l;
+            const int w_in = a.W >> (l - 1), lwl = a.W >> l, lhl = a.H >> l;  // repeated floor halving == a right shift
             for (int yy = 0; yy < e; yy++)
                 for (int xx = 0; xx < e; xx++) {
                     const int x = bx * e + xx, y = by * e + yy;
@@ -283,28 +183,39 @@ __device__ __forceinline__ void build_pyramid(const LmArgs& a, int n_wgs) {
     }
     int valid = 0;
     const int n = a.W * a.H;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_wgs * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         valid += a.depth0[i] > 0.0f ? 1 : 0;
         a.pn[2 * i] = a.points[i];
         a.pn[2 * i + 1] = a.normals[i];
     }
     for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o, 64);
-    if ((threadIdx.x & 63) == 0 && valid) __hip_atomic_fetch_add(&a.sync[1], (uint32_t)valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.sync[1], (uint32_t)valid);  // zeroed by the caller's memset
 }
 
+// One LM iteration's evaluation + reduction.  Cross-workgroup traffic inside the launch avoids L2 flushes: the XCDs' L2s are
+// not coherent with each other, and an agent-scope release / acquire pair means buffer_wbl2 + buffer_inv of the WHOLE L2 per
+// workgroup (round 1 measured a fenced last-block-done ticket 20 % slower than a second launch, with the map stream's
+// rasterizer sharing that L2).  The rows therefore travel as agent-scope RELAXED atomic stores / loads (sc1: write-through to /
+// read from the memory-side coherence point), ordered by program order + s_waitcnt: rows stored, vmcnt(0) waits for their
+// acknowledgement, THEN the ticket is taken; the workgroup that draws the last ticket reads the rows with sc1 loads and resets
+// the ticket.  Nothing else is written back or invalidated.  Totals + the frame's valid-pixel count go to the pinned host
+// mailbox, sequence number last.
 template <int ITER>
-__device__ __forceinline__ void eval_level(const GhArgs& g, int n_wgs, float* row /* LDS [GH_SLOTS] */) {
+__global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
+                                                              float* __restrict__ result, volatile float* mailbox, int seq) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ;
-    __shared__ float red[LM_THREADS / 64][GH_SLOTS];
+    __shared__ float red[EV_THREADS / 64][GH_SLOTS];
+    __shared__ float group[EV_ROW_GROUPS][GH_SLOTS];
+    __shared__ int is_last;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0f;
-    const int n = g.vw * g.vh;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_wgs * blockDim.x) {
-        const int y = i / g.vw, x = i - y * g.vw;
-        gh_point<ITER>(g, x, y, acc[0], acc[1], acc + 2, acc + 2 + NP);
+    const int n = a.vw * a.vh;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / a.vw, x = i - y * a.vw;
+        gh_point<ITER>(a, x, y, acc[0], acc[1], acc + 2, acc + 2 + NP);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         float v = acc[k];
@@ -313,228 +224,113 @@ __device__ __forceinline__ void eval_level(const GhArgs& g, int n_wgs, float* ro
         if (lane == 0) red[wave][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < GH_SLOTS) {
-        float t = 0.0f;
-        if (threadIdx.x < NV)
-            for (int w = 0; w < LM_THREADS / 64; w++) t += red[w][threadIdx.x];  // fixed order
-        row[threadIdx.x] = t;
+    if (tid < GH_SLOTS) {
+        const float t = tid < NV ? ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) : 0.0f;
+        __hip_atomic_store(partial + (size_t)blockIdx.x * GH_SLOTS + tid, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): wave 0's sc1 stores are acknowledged
+        const uint32_t old = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old + 1u == gridDim.x;
     }
     __syncthreads();
-}
-
-// One LM iteration's bookkeeping from the 32 totals (ITMExtendedTracker.cpp:560-640: normalise, accept / reject, damped
-// solve, ApplyDelta, SetInvM + Coerce, HasConverged) -- what thread 0 of every workgroup runs on its own LDS copy.
-// IT (the level's iteration type) is a template parameter: with compile-time sizes every small array below is registers.
-template <int IT>
-__device__ __noinline__ void lm_update(LmState& S, float term_thresh, int level, const float* tot) {
-    constexpr int noPara = IT == TRK_BOTH ? 6 : 3;
-    float hessian_depth[36], nabla_depth[6];
-#pragma unroll
-    for (int i = 0; i < 36; i++) hessian_depth[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 6; i++) nabla_depth[i] = 0.0f;
-    const int nvalid = (int)tot[0];
-    float f_depth = tot[1];
-#pragma unroll
-    for (int r = 0; r < noPara; r++) nabla_depth[r] = tot[2 + r];
+    if (!is_last) return;
+    // ---- the last workgroup: slot k of rows r, r + 8, ... by thread (r, k), then the 8 row groups in order
     {
-        int counter = 0;
+        const int k = tid & (GH_SLOTS - 1), r = tid >> 5;
+        float s = 0.0f;
+        const int rows = (int)gridDim.x;
+        constexpr int INFLIGHT = 32;  // a 512-row table is 64 loads per thread: two memory-side round trips, not eight
+        for (int rr = r; rr < rows; rr += INFLIGHT * EV_ROW_GROUPS) {
+            uint32_t v[INFLIGHT];  // independent loads in flight, added in row order afterwards
 #pragma unroll
-        for (int r = 0; r < noPara; r++)
+            for (int u = 0; u < INFLIGHT; u++) {
+                const int row = rr + u * EV_ROW_GROUPS;
+                v[u] = row < rows ? __hip_atomic_load(partial + (size_t)row * GH_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            }
 #pragma unroll
-            for (int cc = 0; cc <= r; cc++, counter++) hessian_depth[r + cc * 6] = tot[2 + noPara + counter];
+            for (int u = 0; u < INFLIGHT; u++) s += __uint_as_float(v[u]);
+        }
+        group[r][k] = s;
     }
+    __syncthreads();
+    if (tid < GH_SLOTS) {
+        float t = 0.0f;
 #pragma unroll
-    for (int r = 0; r < noPara; ++r)
-#pragma unroll
-        for (int cc = r + 1; cc < noPara; cc++) hessian_depth[r + cc * 6] = hessian_depth[cc + r * 6];
-    if (nvalid > 100) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) hessian_depth[i] /= nvalid;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) nabla_depth[i] /= nvalid;
-        f_depth /= nvalid;
-    } else {
-        f_depth = 3.402823466e+38f;
+        for (int r = 0; r < EV_ROW_GROUPS; r++) t += group[r][tid];
+        result[tid] = t;
+        if (mailbox) mailbox[tid] = t;
     }
-    S.iters[level] += 1;
-    if ((nvalid <= 0) || (f_depth >= S.f_old)) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) { S.M[i] = S.lastGoodM[i]; S.invM[i] = S.lastGoodInvM[i]; S.approxInvPose[i] = S.invM[i]; }
-        S.lambda *= 10.0f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) { S.lastGoodM[i] = S.M[i]; S.lastGoodInvM[i] = S.invM[i]; }
-        S.f_old = f_depth;
-#pragma unroll
-        for (int i = 0; i < 36; i++) { S.hessian_good[i] = hessian_depth[i]; S.hessian_depth_good[i] = hessian_depth[i]; }
-#pragma unroll
-        for (int i = 0; i < 6; i++) S.nabla_good[i] = nabla_depth[i];
-        S.lambda /= 10.0f;
-        S.nvalid_depth_good = nvalid; S.f_depth_good = f_depth;
+    if (tid == 0) {
+        __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every workgroup has arrived: next launch starts at 0
+        const uint32_t n_valid = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        result[GH_SLOTS + 1] = __uint_as_float(n_valid);
+        if (mailbox) mailbox[GH_SLOTS + 1] = __uint_as_float(n_valid);
     }
-    float A[36], nabla[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = S.hessian_good[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { A[i + i * 6] *= 1.0f + S.lambda; nabla[i] = S.nabla_good[i]; }
-    float step[6] = {0, 0, 0, 0, 0, 0};
-    if (IT != TRK_BOTH) {
-        float small[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int cc = 0; cc < 3; cc++) small[r + cc * 3] = A[r + cc * 6];
-        Chol<3>(small).backsub(step, nabla);
-    } else {
-        Chol<6>(A).backsub(step, nabla);
+    if (mailbox) {
+        // The mailbox words are system-scope write-through stores (volatile host memory: flat_store sc0 sc1).  Waiting for
+        // their acknowledgement (vmcnt(0)) before the sequence number is stored orders them for the host; a
+        // __threadfence_system() here would ALSO write back and invalidate this XCD's entire L2 (buffer_wbl2 + buffer_inv),
+        // which is full of the map stream's rasterizer data -- once per LM iteration.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) mailbox[GH_SLOTS] = __int_as_float(seq);
     }
-    float s6[6] = {0, 0, 0, 0, 0, 0};
-    if (IT == TRK_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
-    else if (IT == TRK_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
-    else {
-#pragma unroll
-        for (int i = 0; i < 6; i++) s6[i] = step[i];
-    }
-    float Tinc[16];
-    Tinc[0 * 4 + 0] = 1.0f;   Tinc[1 * 4 + 0] = s6[2];  Tinc[2 * 4 + 0] = -s6[1]; Tinc[3 * 4 + 0] = s6[3];
-    Tinc[0 * 4 + 1] = -s6[2]; Tinc[1 * 4 + 1] = 1.0f;   Tinc[2 * 4 + 1] = s6[0];  Tinc[3 * 4 + 1] = s6[4];
-    Tinc[0 * 4 + 2] = s6[1];  Tinc[1 * 4 + 2] = -s6[0]; Tinc[2 * 4 + 2] = 1.0f;   Tinc[3 * 4 + 2] = s6[5];
-    Tinc[0 * 4 + 3] = 0.0f;   Tinc[1 * 4 + 3] = 0.0f;   Tinc[2 * 4 + 3] = 0.0f;   Tinc[3 * 4 + 3] = 1.0f;
-    float cur[16], next[16], M[16], invM[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) cur[i] = S.approxInvPose[i];
-    m4_mul(Tinc, cur, next);
-    // pose_d->SetInvM(approxInvPose); pose_d->Coerce(); approxInvPose = pose_d->GetInvM()
-    if (!pose_set_invM_coerce(next, M, invM)) { S.failed = 1; return; }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { S.M[i] = M[i]; S.invM[i] = invM[i]; S.approxInvPose[i] = invM[i]; }
-    bool converged = true;
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-        if (fabsf(step[i]) > term_thresh) converged = false;
-    S.converged = converged ? 1 : 0;
 }
 
-// ITMExtendedTracker::TrackCamera as ONE launch.
-__global__ __launch_bounds__(LM_THREADS) void track_lm_kernel(LmArgs a) {
-    __shared__ LmState S;
-    __shared__ float row[GH_SLOTS];
-    __shared__ float group[LM_ROW_GROUPS][GH_SLOTS];
-    __shared__ float tot[GH_SLOTS];
-    const int n_wgs = gridDim.x;
-    const int tid = threadIdx.x;
-    uint32_t target = 0;
-    bool alive = true;
+// ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
+struct Chol {
+    float ch[36];
+    int size;
+    Chol(const float* mat, int n) : size(n) {
+        for (int i = 0; i < n * n; i++) ch[i] = mat[i];
+        for (int c = 0; c < n; c++) {
+            float inv_diag = 1;
+            for (int r = c; r < n; r++) {
+                float val = ch[c + r * n];
+                for (int c2 = 0; c2 < c; c2++) val -= ch[c + c2 * n] * ch[c2 + r * n];
+                if (r == c) { ch[c + r * n] = val; inv_diag = 1.0f / val; }
+                else { ch[r + c * n] = val; ch[c + r * n] = val * inv_diag; }
+            }
+        }
+    }
+    void backsub(float* result, const float* v) const {
+        float y[6];
+        for (int i = 0; i < size; i++) {
+            float val = v[i];
+            for (int j = 0; j < i; j++) val -= ch[j + i * size] * y[j];
+            y[i] = val;
+        }
+        for (int i = 0; i < size; i++) y[i] /= ch[i + i * size];
+        for (int i = size - 1; i >= 0; i--) {
+            float val = y[i];
+            for (int j = i + 1; j < size; j++) val -= ch[i + j * size] * result[j];
+            result[i] = val;
+        }
+    }
+    float determinant() const {
+        float ret = 1.0f;
+        for (int i = 0; i < size; ++i) ret *= ch[i + i * size];
+        return ret * ret;
+    }
+};
 
-    build_pyramid(a, n_wgs);
-    if (tid == 0) {
-        for (int i = 0; i < 16; i++) { S.M[i] = a.pose_M.m[i]; S.invM[i] = a.pose_invM.m[i]; }
-        for (int i = 0; i < 36; i++) { S.hessian_good[i] = 0.0f; S.hessian_depth_good[i] = 0.0f; }
-        for (int i = 0; i < 6; i++) S.nabla_good[i] = 0.0f;
-        for (int i = 0; i < GPS_TRACK_MAX_LEVELS; i++) S.iters[i] = 0;
-        S.f_depth_good = 0.0f; S.nvalid_depth_good = 0; S.last_type = TRK_NONE; S.failed = 0; S.converged = 0;
-    }
-    // The pyramid and the interleaved maps are plain stores that OTHER workgroups (other XCDs) read afterwards: write them
-    // back and drop stale lines ONCE per frame (agent-scope release before / acquire after the first rendezvous).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    target += n_wgs;
-    alive = grid_rendezvous(&a.sync[0], target);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+void m4_mul(const float* a, const float* b, float* out) {  // ORUtils Matrix4 operator*
+    float r[16];
+    for (int col = 0; col < 4; col++)
+        for (int row = 0; row < 4; row++) {
+            float acc = 0;
+            for (int k = 0; k < 4; k++) acc += a[k * 4 + row] * b[col * 4 + k];
+            r[col * 4 + row] = acc;
+        }
+    memcpy(out, r, sizeof(r));
+}
 
-    int parity = 0;
-    for (int level = a.cfg.n_levels - 1; level >= 0 && alive; level--) {
-        const int it = a.cfg.iter_type[level];
-        if (it == TRK_NONE) continue;
-        if (tid == 0) {
-            S.last_type = it;
-            for (int i = 0; i < 16; i++) { S.approxInvPose[i] = S.invM[i]; S.lastGoodM[i] = S.M[i]; S.lastGoodInvM[i] = S.invM[i]; }
-            S.f_old = 3.402823466e+38f; S.lambda = 1.0f; S.converged = 0;
-        }
-        __syncthreads();
-        GhArgs g;
-        g.depth = level == 0 ? a.depth0 : a.level[level];
-        g.vw = a.W >> level; g.vh = a.H >> level;
-        // the reference halves the intrinsics level by level (ITMExtendedTracker.cpp:230-233): repeated * 0.5f is exact
-        float4 vi = a.intr;
-        for (int l = 0; l < level; l++) { vi.x *= 0.5f; vi.y *= 0.5f; vi.z *= 0.5f; vi.w *= 0.5f; }
-        g.view_intr = vi;
-        g.pn = a.pn; g.sw = a.W; g.sh = a.H;
-        g.scene_intr = a.intr;
-        g.scenePose = a.pose_pc_M;
-        g.space_thresh = a.cfg.space_thresh[level]; g.tukey_cutoff = a.cfg.tukey_cutoff;
-        g.vf_min = a.vf_min; g.vf_max = a.vf_max; g.use_weights = a.use_weights;
-        g.frames_to_skip = a.cfg.frames_to_skip; g.frames_to_weight = a.cfg.frames_to_weight;
-        for (int iter = 0; iter < a.cfg.n_iter[level] && alive; iter++) {
-            // wave-uniform values read from LDS: pin them to SGPRs (16 VGPRs less in a loop that needs every one)
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                g.approxInvPose.m[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(S.approxInvPose[i])));
-            if (it == TRK_ROTATION) eval_level<TRK_ROTATION>(g, n_wgs, row);
-            else if (it == TRK_TRANSLATION) eval_level<TRK_TRANSLATION>(g, n_wgs, row);
-            else eval_level<TRK_BOTH>(g, n_wgs, row);
-            uint32_t* mine = a.partial + ((size_t)parity * LM_MAX_WGS + blockIdx.x) * GH_SLOTS;
-            if (tid < GH_SLOTS) __hip_atomic_store(mine + tid, __float_as_uint(row[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            target += n_wgs;
-            alive = grid_rendezvous(&a.sync[0], target);
-            // every workgroup adds all rows: slot k of rows r, r + 16, ... by thread (r, k), then the row groups in order
-            {
-                const int k = tid & (GH_SLOTS - 1), r = tid >> 5;  // LM_ROW_GROUPS row groups x 32 slots
-                const uint32_t* tab = a.partial + (size_t)parity * LM_MAX_WGS * GH_SLOTS;
-                float s = 0.0f;
-                for (int rr = r; rr < n_wgs; rr += LM_ROW_GROUPS)
-                    s += __uint_as_float(__hip_atomic_load(tab + rr * GH_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                group[r][k] = s;
-            }
-            __syncthreads();
-            if (tid < GH_SLOTS) {
-                float t = 0.0f;
-#pragma unroll
-                for (int r = 0; r < LM_ROW_GROUPS; r++) t += group[r][tid];
-                tot[tid] = t;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                if (it == TRK_ROTATION) lm_update<TRK_ROTATION>(S, a.cfg.term_thresh, level, tot);
-                else if (it == TRK_TRANSLATION) lm_update<TRK_TRANSLATION>(S, a.cfg.term_thresh, level, tot);
-                else lm_update<TRK_BOTH>(S, a.cfg.term_thresh, level, tot);
-            }
-            __syncthreads();
-            parity ^= 1;
-            if (S.failed) alive = false;
-            if (S.converged) break;
-        }
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        float* res = a.result;
-        for (int i = 0; i < 16; i++) { res[i] = S.M[i]; res[16 + i] = S.invM[i]; }
-        for (int i = 0; i < 8; i++) res[32 + i] = (float)S.iters[i];
-        const int n_max = (int)__hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res[40] = (float)S.nvalid_depth_good;
-        res[41] = S.f_depth_good;
-        // UpdatePoseQuality: the residual score (the SVM verdict only feeds failure modes that are off by default,
-        // ITMLibSettings.cpp:42 behaviourOnFailure = FAILUREMODE_IGNORE)
-        res[42] = n_max > 0 ? sqrtf(((float)S.nvalid_depth_good * S.f_depth_good +
-                                     (float)(n_max - S.nvalid_depth_good) * a.cfg.space_thresh[0]) / (float)n_max) : 0.0f;
-        float det = 0.0f;
-        if (S.last_type == TRK_BOTH) {
-            float hg[36];
-#pragma unroll
-            for (int i = 0; i < 36; i++) hg[i] = S.hessian_depth_good[i];
-            det = Chol<6>(hg).determinant();
-            if (isnan(det)) det = 0.0f;
-        }
-        res[43] = det;
-        for (int i = 44; i < 48; i++) res[i] = 0.0f;
-        res[48] = alive ? 1.0f : -1.0f;  // status: -1 = a rendezvous timed out or a singular pose
-        res[49] = __int_as_float(n_max);
-        if (a.mailbox) {
-            for (int i = 0; i < 50; i++) a.mailbox[i] = res[i];
-            __threadfence_system();
-            a.mailbox[50] = __int_as_float(a.seq);
-            __threadfence_system();
-        }
-    }
+bool set_invM_coerce(const float* invM_in, float* M, float* invM) {  // pose_d->SetInvM(m); Coerce()
+    float rm[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) rm[r * 4 + c] = invM_in[c * 4 + r];
+    return gps_pose_from_c2w(rm, M, invM) == GPS_OK;
 }
 
 inline int float_bits(float f) { int i; memcpy(&i, &f, 4); return i; }
@@ -555,8 +351,8 @@ size_t carve(Scratch* w, char* base, int W, int H) {
         char* p = take((size_t)(lw > 0 && lh > 0 ? lw * lh : 1) * sizeof(float));
         if (w) w->level[l] = (float*)p;
     }
-    char* p = take((size_t)2 * LM_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;
-    p = take(RES_FLOATS * sizeof(float)); if (w) w->result = (float*)p;
+    char* p = take((size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;
+    p = take(64 * sizeof(float)); if (w) w->result = (float*)p;
     p = take(64); if (w) w->sync = (uint32_t*)p;
     p = take((size_t)W * H * 2 * sizeof(float4)); if (w) w->pn = (float4*)p;
     return off;
@@ -592,7 +388,7 @@ int gps_track_config_init(gps_track_config* c, const char* levels, int num_iter_
 
 int gps_track_state_reset(gps_track_state* ts) {
     if (!ts) return GPS_ERR_ARG;
-    void* mailbox = ts->host_mailbox;
+    void* mailbox = ts->host_mailbox;  // the mailbox and the sequence counter belong to the state's owner / the library
     const int32_t seq = ts->mail_seq;
     memset(ts, 0, sizeof(*ts));
     ts->host_mailbox = mailbox;
@@ -621,54 +417,161 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     carve(&w, (char*)scratch, W, H);
     hipStream_t st = (hipStream_t)stream;
 
-    LmArgs a;
-    a.cfg = *c;
-    a.depth0 = s.depth;
-    for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++) a.level[l] = l == 0 ? nullptr : w.level[l];
-    a.points = reinterpret_cast<const float4*>(s.icp_points);
-    a.normals = reinterpret_cast<const float4*>(s.icp_normals);
-    a.pn = w.pn;
-    a.W = W; a.H = H;
-    a.intr = make_float4(s.fx, s.fy, s.cx, s.cy);
-    a.vf_min = s.view_frustum_min; a.vf_max = s.view_frustum_max;
-    a.use_weights = ts->frames_processed >= 100;
-    a.pose_M = load_mat(ts->pose_M);
-    a.pose_invM = load_mat(ts->pose_invM);  // kept consistent with pose_M by every writer of the state
-    a.pose_pc_M = load_mat(ts->pose_pc_M);
-    a.partial = w.partial; a.sync = w.sync; a.result = w.result;
-    volatile float* mailbox = reinterpret_cast<volatile float*>(ts->host_mailbox);
-    a.mailbox = mailbox;
-    // the sequence number the kernel writes last: unique per call on this state (a stale mailbox value can never match)
-    const int seq = (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1);  // >= 1
-    a.seq = seq;
-    if (mailbox) mailbox[50] = 0.0f;  // 0 is never a sequence number: nothing stale can match
+    // PrepareForEvaluation: depth pyramid; the scene side (ICP maps) always stays at full resolution
+    const float* dl[GPS_TRACK_MAX_LEVELS];
+    int lw[GPS_TRACK_MAX_LEVELS], lh[GPS_TRACK_MAX_LEVELS];
+    float lintr[GPS_TRACK_MAX_LEVELS][4] = {{s.fx, s.fy, s.cx, s.cy}};
+    dl[0] = s.depth; lw[0] = W; lh[0] = H;
+    PrepArgs pa;
+    pa.cfg = *c;
+    pa.depth0 = s.depth;
+    pa.level[0] = nullptr;
+    for (int l = 1; l < GPS_TRACK_MAX_LEVELS; l++) pa.level[l] = w.level[l];
+    for (int l = 1; l < c->n_levels; l++) {
+        lw[l] = lw[l - 1] / 2; lh[l] = lh[l - 1] / 2;
+        dl[l] = w.level[l];
+        for (int k = 0; k < 4; k++) lintr[l][k] = lintr[l - 1][k] * 0.5f;
+    }
+    pa.points = reinterpret_cast<const float4*>(s.icp_points);
+    pa.normals = reinterpret_cast<const float4*>(s.icp_normals);
+    pa.pn = w.pn; pa.W = W; pa.H = H; pa.sync = w.sync;
     if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) return GPS_ERR_LAUNCH;
-    // enough workgroups to give every thread ~2 pixels of the finest level, never more rows than the partial table holds
-    const int n_wgs = max(1, min(LM_MAX_WGS, gps_div_up((int64_t)W * H, 2 * LM_THREADS)));
-    track_lm_kernel<<<n_wgs, LM_THREADS, 0, st>>>(a);
+    track_prepare_kernel<<<gps_div_up((int64_t)W * H, 4 * 256), 256, 0, st>>>(pa);
     GPS_LAUNCH_CHECK();
 
-    float host[RES_FLOATS];
-    if (mailbox) {
-        // ONE wait per frame: spin on the sequence number, bounded (fall back to a stream synchronise); yield now and then so
-        // that an oversubscribed host (8 ranks x 2 threads) does not burn a core per rank for nothing
-        bool got = false;
-        for (long spin = 0; spin < 400000000L; spin++) {
-            if (float_bits(mailbox[50]) == seq) { got = true; break; }
-            if ((spin & 0x3FFF) == 0x3FFF) sched_yield();
+    float hessian_good[36] = {0}, nabla_good[6] = {0}, hessian_depth_good[36] = {0}, f_depth_good = 0;
+    int nvalid_depth_good = 0;
+    float M[16], invM[16];
+    memcpy(M, ts->pose_M, 64);
+    memcpy(invM, ts->pose_invM, 64);  // kept consistent with pose_M by every writer of the state
+    int last_type = TRK_NONE;
+    for (int k = 0; k < 16; k++) ts->diag[k] = 0;
+    const int use_weights = ts->frames_processed >= 100;
+    int mailbox_iterations = 0;
+
+    for (int level = c->n_levels - 1; level >= 0; level--) {
+        const int it = c->iter_type[level];
+        if (it == TRK_NONE) continue;
+        last_type = it;
+        float approxInvPose[16], lastGoodM[16], lastGoodInvM[16];
+        memcpy(approxInvPose, invM, 64);
+        memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
+        float f_old = 3.402823466e+38f, lambda = 1.0f;
+        const int noPara = it == TRK_BOTH ? 6 : 3;
+        for (int iter = 0; iter < c->n_iter[level]; iter++) {
+            GhArgs a;
+            a.depth = dl[level]; a.vw = lw[level]; a.vh = lh[level];
+            a.view_intr = make_float4(lintr[level][0], lintr[level][1], lintr[level][2], lintr[level][3]);
+            a.pn = w.pn;
+            a.sw = W; a.sh = H;
+            a.scene_intr = make_float4(lintr[0][0], lintr[0][1], lintr[0][2], lintr[0][3]);
+            a.approxInvPose = load_mat(approxInvPose); a.scenePose = load_mat(ts->pose_pc_M);
+            a.space_thresh = c->space_thresh[level]; a.tukey_cutoff = c->tukey_cutoff; a.vf_min = s.view_frustum_min;
+            a.vf_max = s.view_frustum_max; a.use_weights = use_weights; a.frames_to_skip = c->frames_to_skip;
+            a.frames_to_weight = c->frames_to_weight;
+            const int n_wgs = min(EV_MAX_WGS, gps_div_up(a.vw * a.vh, EV_THREADS));
+            volatile float* mailbox = reinterpret_cast<volatile float*>(ts->host_mailbox);
+            // per-state sequence number (>= 1; the slot is cleared first, so nothing stale can match)
+            const int seq = (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1);
+            if (mailbox) mailbox[GH_SLOTS] = 0.0f;
+            if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq);
+            else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq);
+            else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq);
+            GPS_LAUNCH_CHECK();
+            float host[GH_SLOTS];
+            if (mailbox) {
+                // spin on the sequence number the kernel writes last (bounded: fall back to a stream synchronise)
+                bool got = false;
+                for (long spin = 0; spin < 200000000L; spin++) {
+                    if (float_bits(mailbox[GH_SLOTS]) == seq) { got = true; break; }
+                    // a result normally lands within ~20 us (a few thousand polls); a host that is still spinning far beyond
+                    // that is oversubscribed or the GPU is busy elsewhere: stop burning the core between polls
+                    if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+                }
+                if (!got && hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+                for (int k = 0; k < GH_SLOTS; k++) host[k] = mailbox[k];
+                mailbox_iterations++;
+            } else {
+                // the reference's GPU tracker reads its 32 accumulators back every iteration as well
+                if (hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+                if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+            }
+
+            float hessian_depth[36] = {0}, nabla_depth[6] = {0};
+            const int nvalid = (int)host[0];
+            float f_depth = host[1];
+            for (int r = 0; r < noPara; r++) nabla_depth[r] = host[2 + r];
+            for (int r = 0, counter = 0; r < noPara; r++)
+                for (int cc = 0; cc <= r; cc++, counter++) hessian_depth[r + cc * 6] = host[2 + noPara + counter];
+            for (int r = 0; r < noPara; ++r)
+                for (int cc = r + 1; cc < noPara; cc++) hessian_depth[r + cc * 6] = hessian_depth[cc + r * 6];
+            if (nvalid > 100) {
+                for (int i = 0; i < 36; ++i) hessian_depth[i] /= nvalid;
+                for (int i = 0; i < 6; ++i) nabla_depth[i] /= nvalid;
+                f_depth /= nvalid;
+            } else {
+                f_depth = 3.402823466e+38f;
+            }
+            ts->diag[level] += 1;
+            if ((nvalid <= 0) || (f_depth >= f_old)) {
+                memcpy(M, lastGoodM, 64); memcpy(invM, lastGoodInvM, 64);
+                memcpy(approxInvPose, invM, 64);
+                lambda *= 10.0f;
+            } else {
+                memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
+                f_old = f_depth;
+                memcpy(hessian_good, hessian_depth, sizeof(hessian_good));
+                memcpy(nabla_good, nabla_depth, sizeof(nabla_good));
+                lambda /= 10.0f;
+                nvalid_depth_good = nvalid; f_depth_good = f_depth;
+                memcpy(hessian_depth_good, hessian_depth, sizeof(hessian_depth));
+            }
+            float A[36];
+            for (int i = 0; i < 36; ++i) A[i] = hessian_good[i];
+            for (int i = 0; i < 6; ++i) A[i + i * 6] *= 1.0f + lambda;
+            float step[6] = {0, 0, 0, 0, 0, 0};
+            if (it != TRK_BOTH) {
+                float small[9];
+                for (int r = 0; r < 3; r++)
+                    for (int cc = 0; cc < 3; cc++) small[r + cc * 3] = A[r + cc * 6];
+                Chol(small, 3).backsub(step, nabla_good);
+            } else {
+                Chol(A, 6).backsub(step, nabla_good);
+            }
+            float s6[6] = {0, 0, 0, 0, 0, 0};
+            if (it == TRK_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
+            else if (it == TRK_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
+            else { for (int i = 0; i < 6; i++) s6[i] = step[i]; }
+            float Tinc[16];
+            Tinc[0 * 4 + 0] = 1.0f;   Tinc[1 * 4 + 0] = s6[2];  Tinc[2 * 4 + 0] = -s6[1]; Tinc[3 * 4 + 0] = s6[3];
+            Tinc[0 * 4 + 1] = -s6[2]; Tinc[1 * 4 + 1] = 1.0f;   Tinc[2 * 4 + 1] = s6[0];  Tinc[3 * 4 + 1] = s6[4];
+            Tinc[0 * 4 + 2] = s6[1];  Tinc[1 * 4 + 2] = -s6[0]; Tinc[2 * 4 + 2] = 1.0f;   Tinc[3 * 4 + 2] = s6[5];
+            Tinc[0 * 4 + 3] = 0.0f;   Tinc[1 * 4 + 3] = 0.0f;   Tinc[2 * 4 + 3] = 0.0f;   Tinc[3 * 4 + 3] = 1.0f;
+            m4_mul(Tinc, approxInvPose, approxInvPose);
+            if (!set_invM_coerce(approxInvPose, M, invM)) return GPS_ERR_ARG;
+            memcpy(approxInvPose, invM, 64);
+            bool converged = true;
+            for (int i = 0; i < 6; i++)
+                if (fabs(step[i]) > c->term_thresh) { converged = false; break; }
+            if (converged) break;
         }
-        if (!got && hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
-        for (int k = 0; k < 50; k++) host[k] = mailbox[k];
+    }
+    memcpy(ts->pose_M, M, 64); memcpy(ts->pose_invM, invM, 64);
+    // UpdatePoseQuality: the residual score (the SVM verdict only feeds failure modes that are off by default,
+    // ITMLibSettings.cpp:42 behaviourOnFailure = FAILUREMODE_IGNORE)
+    int n_max = 0;
+    if (ts->host_mailbox && mailbox_iterations > 0) {
+        n_max = float_bits(reinterpret_cast<volatile float*>(ts->host_mailbox)[GH_SLOTS + 1]);  // delivered with the last iteration
     } else {
-        if (hipMemcpyAsync(host, w.result, 50 * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+        if (hipMemcpyAsync(&n_max, w.sync + 1, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
         if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
     }
-    if (!(host[48] > 0.0f)) return GPS_ERR_LAUNCH;  // rendezvous time-out / singular pose: reported, never silent
-    memcpy(ts->pose_M, host, 64);
-    memcpy(ts->pose_invM, host + 16, 64);
-    for (int k = 0; k < 16; k++) ts->diag[k] = 0;
-    for (int k = 0; k < 8; k++) ts->diag[k] = host[32 + k];
-    ts->diag[8] = host[40]; ts->diag[9] = host[41]; ts->diag[10] = host[42]; ts->diag[11] = host[43];
+    ts->diag[8] = (float)nvalid_depth_good; ts->diag[9] = f_depth_good;
+    ts->diag[10] = n_max > 0 ? sqrtf(((float)nvalid_depth_good * f_depth_good + (float)(n_max - nvalid_depth_good) * c->space_thresh[0]) /
+                                    (float)n_max) : 0.0f;
+    float det = 0.0f;
+    if (last_type == TRK_BOTH) { det = Chol(hessian_depth_good, 6).determinant(); if (isnan(det)) det = 0.0f; }
+    ts->diag[11] = det;
     return GPS_OK;
 }
 
