@@ -202,52 +202,74 @@ __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restric
     }
 }
 
-// Sum over the 32 lanes of a half-wave with DPP adds (no LDS crossbar traffic): row_shr 1/2/4/8 leave each 16-lane
-// row's total in its lane 15, row_bcast15 restricted to rows 1 and 3 adds the lower row's total into the upper row.
-// The half's total ends up in lane 31 of the half (hl == 31) ONLY.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+// ---------------------------------------------------------------------------------------------------------
+// Backward.  One wave64 task = 32 consecutive 32-pixel groups, as two contiguous runs of 16 (one per half-wave).
+// Phase A: lanes 0..15 of each half fetch their step's group header and Gaussian record and park them in LDS --
+//          ONE global round trip per task instead of one dependent chain per step.
+// Phase B: 16 steps; every lane of a half reads its step's record from LDS, evaluates its pixel of the 2r x 2r box and
+//          accumulates in registers; several steps are in flight at a time so that their pixel gathers overlap.  A half
+//          reduces and writes its 10 sums only when the Gaussian changes.
+//
+// Per-pixel inputs: three gathers per pixel slot (ref_depth 4 B, v_render_colors 16 B, v_render_alphas 4 B).  Packing them into
+// one 32-byte record per pixel (written by the compose kernel; 2 x dwordx4 from one sector) was built and measured SLOWER
+// (84 vs 79 us at G = 668 k): the record array is 9.8 MB against 7.3 MB for the three arrays, and what limits the gathers is
+// how much of the gradient image each XCD's 4 MB L2 holds, not the number of load instructions.
+//
+// LDS layout.  A step's two records (one per half-wave) are read by the same instruction: lanes 0-31 one address, lanes 32-63
+// another.  Stored 16 records apart (round 1) the two addresses were 1024 bytes = a multiple of the bank cycle apart -> a 2-way
+// conflict on every read (PMC: SQ_LDS_BANK_CONFLICT 3.07e6 vs SQ_ACTIVE_INST_LDS 3.71e6).  Interleaved per step they are 64
+// bytes apart: different banks.
+//
+// Flush.  Ten values x 32 lanes -> ten totals.  v_permlane16_swap exchanges the odd rows of one register with the even rows of
+// another, so "swap, add" halves the lane span of TWO values at once: five swaps + five adds leave five registers whose two
+// 16-lane rows hold one value each; four DPP row_shr adds per register finish the sums (lane 15 of a row); four DPP row_shl
+// moves line the ten totals up in ten lanes so that ONE memory instruction writes them: ~45 VALU instead of 85 for ten full
+// half-wave DPP reductions.
+typedef float bwd_v4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_add(float v) {  // v + (v moved by a row-local DPP shift; lanes without a source add 0)
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
     return v + __int_as_float(moved);
 }
-__device__ __forceinline__ float half_sum_to_lane31(float v) {
-    v = dpp_add<0x111, 0xF>(v);  // row_shr:1
-    v = dpp_add<0x112, 0xF>(v);  // row_shr:2
-    v = dpp_add<0x114, 0xF>(v);  // row_shr:4
-    v = dpp_add<0x118, 0xF>(v);  // row_shr:8
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+__device__ __forceinline__ float row_total_to_lane15(float v) {
+    v = dpp_row_add<0x111>(v);  // row_shr:1
+    v = dpp_row_add<0x112>(v);  // row_shr:2
+    v = dpp_row_add<0x114>(v);  // row_shr:4
+    v = dpp_row_add<0x118>(v);  // row_shr:8
     return v;
+}
+// rows of the result: {a over rows 0+1, b over rows 0+1, a over rows 2+3, b over rows 2+3} -- per half-wave: row 0 = a, row 1 = b
+__device__ __forceinline__ float pair_rows(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lane 15 of each row -> lane 15 - K of the same row (row_shl:K), merged into `packed` there
+template <int K>
+__device__ __forceinline__ float place(float packed, float v, int lane16) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + K, 0xF, 0xF, true);
+    return lane16 == 15 - K ? __int_as_float(moved) : packed;
 }
 
 struct Acc { float c0, c1, c2, c3, ka, kb, kc, mx, my, op; };
 
-// s_k (valid in lane 31 of the half) -> lane 31 - k of the half: row_shl:k moves lane 31's value down k lanes
-template <int K>
-__device__ __forceinline__ float spread(float packed, float sk, int hl) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(sk), 0x100 + K, 0xF, 0xF, true);
-    return hl == 31 - K ? __int_as_float(moved) : packed;
-}
-
-// Reduce the half-wave's 10 partial sums and add them to Gaussian g's gradient rows.  The ten totals are spread over
-// lanes 31..22 of the half (lane 31 - k holds total k) so that ONE memory instruction writes all of them.
+// Reduce the half-wave's 10 partial sums and add them to Gaussian g's gradient rows.
 //   exclusive = this half-wave saw every pixel group of g (the segment neither touches the start nor the end of the
 //   half's 16-group run) and the arrays were zeroed by this launch: a plain store, no read-modify-write at the L2.
 //   otherwise: float atomics (another half-wave may hold the rest of g, or the caller accumulates across launches).
 __device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, bool exclusive, float* __restrict__ v_means2d,
                                           float* __restrict__ v_conics, float* __restrict__ v_colors,
                                           float* __restrict__ v_opacities) {
-    float v = half_sum_to_lane31(a.c0);
-    v = spread<1>(v, half_sum_to_lane31(a.c1), hl);
-    v = spread<2>(v, half_sum_to_lane31(a.c2), hl);
-    v = spread<3>(v, half_sum_to_lane31(a.c3), hl);
-    v = spread<4>(v, half_sum_to_lane31(a.ka), hl);
-    v = spread<5>(v, half_sum_to_lane31(a.kb), hl);
-    v = spread<6>(v, half_sum_to_lane31(a.kc), hl);
-    v = spread<7>(v, half_sum_to_lane31(a.mx), hl);
-    v = spread<8>(v, half_sum_to_lane31(a.my), hl);
-    v = spread<9>(v, half_sum_to_lane31(a.op), hl);
-    const int k = 31 - hl;  // which total this lane holds
-    if (g >= 0 && k < 10) {
+    const int lane16 = hl & 15, row = hl >> 4;
+    // value index 2 j + row sits in register j: (c0,c1) (c2,c3) (ka,kb) (kc,mx) (my,op)
+    float v = row_total_to_lane15(pair_rows(a.c0, a.c1));
+    v = place<1>(v, row_total_to_lane15(pair_rows(a.c2, a.c3)), lane16);
+    v = place<2>(v, row_total_to_lane15(pair_rows(a.ka, a.kb)), lane16);
+    v = place<3>(v, row_total_to_lane15(pair_rows(a.kc, a.mx)), lane16);
+    v = place<4>(v, row_total_to_lane15(pair_rows(a.my, a.op)), lane16);
+    const int j = 15 - lane16;
+    if (g >= 0 && j < 5) {
+        const int k = 2 * j + row;  // which total this lane holds
         float* dst = k < 4 ? v_colors + 4 * (size_t)g + k
                    : k < 7 ? v_conics + 3 * (size_t)g + (k - 4)
                    : k < 9 ? v_means2d + 2 * (size_t)g + (k - 7)
@@ -258,13 +280,6 @@ __device__ __forceinline__ void flush_acc(Acc& a, int g, int hl, bool exclusive,
     a.c0 = a.c1 = a.c2 = a.c3 = a.ka = a.kb = a.kc = a.mx = a.my = a.op = 0.f;
 }
 
-// One wave64 task = 32 consecutive 32-pixel groups, as two contiguous runs of 16 (one per half-wave).
-// Phase A: lanes 0..15 of each half fetch their step's group header and Gaussian record and park them in LDS --
-//          ONE global round trip per task instead of one dependent chain per step.
-// Phase B: 16 steps; every lane of a half reads its step's record from LDS (2 distinct addresses per access:
-//          broadcast, conflict free), evaluates its pixel of the 2r x 2r box and accumulates in registers; two steps
-//          are in flight at a time so that their 3+3 pixel gathers overlap.  A half reduces with shuffles and issues
-//          its 10 atomics only when the Gaussian changes.
 struct __attribute__((aligned(16))) BwdRec {
     float x, y, ca, cb;      // xy, conic a, b
     float cc, opac, r, g;    // conic c, opacity, colour r, g
@@ -274,14 +289,17 @@ struct __attribute__((aligned(16))) BwdRec {
     float inv_bw;            // 1 / bw: (pid + 0.5) * inv_bw truncates to pid / bw exactly for pid < 2^16
 };
 
-#ifndef BWD_INFLIGHT
-#define BWD_INFLIGHT 2
-#endif
+constexpr int BWD_INFLIGHT = 2;
 struct BwdPix { bool on; float alpha, vis, dx, dy; float4 vc; float va; };
 
-__device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, const float* __restrict__ ref_depth,
-                                         float delta_depth, const float4* __restrict__ v_render_colors,
-                                         const float* __restrict__ v_render_alphas, BwdPix& o) {
+struct BwdPixSrc {
+    const float* ref_depth;
+    const float4* v_render_colors;
+    const float* v_render_alphas;
+    float delta_depth;
+};
+
+__device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, const BwdPixSrc& src, BwdPix& o) {
     o.on = false;
     if (R.gs_id < 0) return;
     const uint32_t pid = (uint32_t)R.pid0 + (uint32_t)hl;
@@ -290,15 +308,15 @@ __device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, 
     const int i = R.y0 + q;
     if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw))) return;
     const int pix = i * W + j;
-    const float rd = ref_depth[pix];
-    o.vc = v_render_colors[pix];
-    o.va = v_render_alphas[pix];
+    const float cut = src.ref_depth[pix] + src.delta_depth;
+    o.vc = src.v_render_colors[pix];
+    o.va = src.v_render_alphas[pix];
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     o.dx = R.x - px; o.dy = R.y - py;
     const float sigma = 0.5f * (R.ca * o.dx * o.dx + R.cc * o.dy * o.dy) + R.cb * o.dx * o.dy;
     o.vis = __expf(-sigma);
     o.alpha = fminf(0.999f, R.opac * o.vis);
-    o.on = !(sigma < 0.f) && !(o.alpha < 1.f / 255.f) && !(R.depth > rd + delta_depth);
+    o.on = !(sigma < 0.f) && !(o.alpha < 1.f / 255.f) && !(R.depth > cut);
 }
 
 __device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, Acc& acc) {
@@ -319,11 +337,10 @@ __device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, Acc&
 __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int32_t* __restrict__ group_gs_ids, const int32_t* __restrict__ group_starts,
     const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
-    const float* __restrict__ opacities, const int32_t* __restrict__ radiis, const float* __restrict__ ref_depth,
-    const int64_t* __restrict__ counts, float delta_depth, int W, int H, const float4* __restrict__ v_render_colors,
-    const float* __restrict__ v_render_alphas, float* __restrict__ v_means2d, float* __restrict__ v_conics,
+    const float* __restrict__ opacities, const int32_t* __restrict__ radiis, BwdPixSrc src,
+    const int64_t* __restrict__ counts, int W, int H, float* __restrict__ v_means2d, float* __restrict__ v_conics,
     float* __restrict__ v_colors, float* __restrict__ v_opacities, int plain_ok) {
-    __shared__ BwdRec recs[4][2][16];
+    __shared__ BwdRec recs[4][16][2];  // [wave][step][half]: the two records one read instruction touches are 64 B apart
     const int n_groups = (int)counts[1];
     const int n_tasks = (n_groups + 31) >> 5;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int per_xcd = (n_tasks + 7) >> 3;
     const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tasks, xcd_lo + per_xcd);
     const int wave_in_xcd = slot * 4 + wave_in_wg, waves_per_xcd = wgs_per_xcd * 4;
-    BwdRec* my = recs[wave_in_wg][half];
+    BwdRec* my = &recs[wave_in_wg][0][half];  // step s: my[2 * s]
 
     for (int task = xcd_lo + wave_in_xcd; task < xcd_hi; task += waves_per_xcd) {
         // ---- phase A: one record per step, fetched by lanes 0..15 of each half
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
                 R.pid0 = (gid - gstart) * 32;
                 R.x0 = (int)xy.x - r + 1; R.y0 = (int)xy.y - r + 1; R.bw = 2 * r; R.inv_bw = 1.0f / (float)(2 * r);
             }
-            my[hl] = R;
+            my[2 * hl] = R;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -369,11 +386,10 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
         for (int s = 0; s < 16; s += BWD_INFLIGHT) {
             BwdPix p[BWD_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < BWD_INFLIGHT; ++u)
-                bwd_eval(my[s + u], hl, W, H, ref_depth, delta_depth, v_render_colors, v_render_alphas, p[u]);
+            for (int u = 0; u < BWD_INFLIGHT; ++u) bwd_eval(my[2 * (s + u)], hl, W, H, src, p[u]);
 #pragma unroll
             for (int u = 0; u < BWD_INFLIGHT; ++u) {
-                const BwdRec R = my[s + u];
+                const BwdRec R = my[2 * (s + u)];
                 if (R.gs_id != cur_g) {
                     // the segment that ends here started after step 0 and ends before the run does
                     if (cur_g >= 0)
@@ -441,10 +457,10 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
         zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
                                                                                      v_opacities);
     constexpr int bwd_blocks = 4096;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
+    BwdPixSrc src = {ref_depth_map, (const float4*)v_render_colors, v_render_alphas, delta_depth};
     raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
-                                                  (const float4*)colors, opacities, radii, ref_depth_map, counts,
-                                                  delta_depth, width, height, (const float4*)v_render_colors,
-                                                  v_render_alphas, v_means2d, v_conics, v_colors, v_opacities, accumulate ? 0 : 1);
+                                                        (const float4*)colors, opacities, radii, src, counts, width, height,
+                                                        v_means2d, v_conics, v_colors, v_opacities, accumulate ? 0 : 1);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -1,0 +1,49 @@
+"""Per-kernel times of one optimise iteration on the bench scene after its settle frames (HIP events, 50 launches each).
+usage: python tools/raster_bench.py [width height gaussians]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from bench_kernels import _python_twin, _time_launches
+from gps_slam_amd._lib import lib
+
+W, H, NG = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (640, 480, 200000)
+seq = bench.synthetic_sequence(W, H, 31, 1234)
+seeds = bench.seed_gaussians(seq, NG, 1234, "cuda:0")
+scene = bench.Scene(seq, seeds, 1234, True, False, 31, 1.0, 0.02)
+scene.run(0, 31)
+model, cam, rc = _python_twin(scene, "cuda:0")
+model.initOptimizers(-1, 1.0)
+step = lambda: model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+step()
+torch.cuda.synchronize()
+B, st = model._B, model._step
+counts = B["counts"].cpu().tolist()
+print("N %d  n_isects %d  n_groups %d  visible %d" % (st.N, counts[0], counts[1], counts[3]))
+# how much of the 2r x 2r boxes the backward walks can contribute at all: area of {alpha >= 1/255} = 2 pi T / sqrt(det Q),
+# T = ln(255 opac), against the box area 4 r^2 (visible Gaussians)
+r_ = B["radii"][:st.N].float()
+con = B["conics"][:st.N]
+T_ = torch.log(255.0 * B["opacities"][:st.N]).clamp_min(0)
+det = (con[:, 0] * con[:, 2] - con[:, 1] ** 2).clamp_min(1e-12)
+ell = 2 * 3.14159265 * T_ / det.sqrt()
+vis = r_ > 0
+print("sum ellipse area / sum box area = %.3f   (mean radius %.1f px, mean T %.2f)" % (float(ell[vis].sum() / (4 * r_[vis] ** 2).sum()),
+                                                                                      float(r_[vis].mean()), float(T_[vis].mean())))
+stream = torch.cuda.current_stream()
+sp = C.c_void_p(stream.cuda_stream)
+p = lambda t: C.c_void_p(t.data_ptr())
+ref, N = rc["depth_map_clamped"], st.N
+fwd = lambda: lib.gps_raster_ges_fwd_rec(N, p(B["records"]), p(ref), W, H, p(B["tile_offsets"]), p(B["flatten_ids"]), p(B["counts"]),
+                                         model.delta_depth, p(B["render_colors"]), p(B["weight_sum"]), sp)
+bwd = lambda: lib.gps_raster_ges_bwd_gs(N, p(B["means2d"]), p(B["conics"]), p(B["colors"]), p(B["opacities"]), p(B["radii"]), p(ref), W, H,
+                                        p(B["group_gs_ids"]), p(B["group_starts"]), p(B["counts"]), model.delta_depth,
+                                        p(B["v_render_colors"]), p(B["v_render_alphas"]), p(B["v_means2d"]), p(B["v_conics"]),
+                                        p(B["v_colors"]), p(B["v_opacities"]), 1, sp)
+for name, fn, n in (("raster fwd (records)", fwd, 50), ("raster bwd (operator entry: 3 gathers)", bwd, 50), ("whole train step", step, 20)):
+    print("%-42s %.1f us" % (name, 1e6 * _time_launches(fn, n, stream)))
+scene.close()
