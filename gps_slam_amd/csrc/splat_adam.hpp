@@ -22,7 +22,7 @@ static inline AdamScalars adam_scalars(double lr, double beta1, double beta2, do
     return a;
 }
 
-// Rounding sequence measured against ATen on gfx950 (scratch/adam_probe.py, 2^20 samples, 100% bitwise):
+// Rounding sequence measured against ATen on gfx950 (tools/adam_probe.py, 2^20 samples, 100% bitwise):
 //   add_(g, alpha)        -> fma(alpha, g, m*b1)
 //   addcmul_(g, g, value) -> fma(value, g*g, v*b2)
 //   sqrt()/c              -> sqrt * float(1/c)   ; add_(eps) unfused

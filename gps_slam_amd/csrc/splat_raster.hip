@@ -215,10 +215,10 @@ __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restric
 // (84 vs 79 us at G = 668 k): the record array is 9.8 MB against 7.3 MB for the three arrays, and what limits the gathers is
 // how much of the gradient image each XCD's 4 MB L2 holds, not the number of load instructions.
 //
-// LDS layout.  A step's two records (one per half-wave) are read by the same instruction: lanes 0-31 one address, lanes 32-63
-// another.  Stored 16 records apart (round 1) the two addresses were 1024 bytes = a multiple of the bank cycle apart -> a 2-way
-// conflict on every read (PMC: SQ_LDS_BANK_CONFLICT 3.07e6 vs SQ_ACTIVE_INST_LDS 3.71e6).  Interleaved per step they are 64
-// bytes apart: different banks.
+// LDS layout.  Reads are broadcasts (all 32 lanes of a half read one record: conflict free whatever the layout); the bank
+// conflicts the counters show (SQ_LDS_BANK_CONFLICT) come from phase A's STORES -- 16 lanes each writing a 64-byte record.
+// Records of a half are contiguous (stride 16 dwords: 8-way on a ds_write_b128); interleaving the halves per step (stride 32
+// dwords) was measured worse (conflict cycles 3.1e6 -> 7.2e6 per launch), and either way they are < 3 % of the wave cycles.
 //
 // Flush.  Ten values x 32 lanes -> ten totals.  v_permlane16_swap exchanges the odd rows of one register with the even rows of
 // another, so "swap, add" halves the lane span of TWO values at once: five swaps + five adds leave five registers whose two
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const float* __restrict__ opacities, const int32_t* __restrict__ radiis, BwdPixSrc src,
     const int64_t* __restrict__ counts, int W, int H, float* __restrict__ v_means2d, float* __restrict__ v_conics,
     float* __restrict__ v_colors, float* __restrict__ v_opacities, int plain_ok) {
-    __shared__ BwdRec recs[4][16][2];  // [wave][step][half]: the two records one read instruction touches are 64 B apart
+    __shared__ BwdRec recs[4][2][16];  // [wave][half][step]
     const int n_groups = (int)counts[1];
     const int n_tasks = (n_groups + 31) >> 5;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int per_xcd = (n_tasks + 7) >> 3;
     const int xcd_lo = xcd * per_xcd, xcd_hi = min(n_tasks, xcd_lo + per_xcd);
     const int wave_in_xcd = slot * 4 + wave_in_wg, waves_per_xcd = wgs_per_xcd * 4;
-    BwdRec* my = &recs[wave_in_wg][0][half];  // step s: my[2 * s]
+    BwdRec* my = recs[wave_in_wg][half];
 
     for (int task = xcd_lo + wave_in_xcd; task < xcd_hi; task += waves_per_xcd) {
         // ---- phase A: one record per step, fetched by lanes 0..15 of each half
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
                 R.pid0 = (gid - gstart) * 32;
                 R.x0 = (int)xy.x - r + 1; R.y0 = (int)xy.y - r + 1; R.bw = 2 * r; R.inv_bw = 1.0f / (float)(2 * r);
             }
-            my[2 * hl] = R;
+            my[hl] = R;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -386,10 +386,10 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
         for (int s = 0; s < 16; s += BWD_INFLIGHT) {
             BwdPix p[BWD_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < BWD_INFLIGHT; ++u) bwd_eval(my[2 * (s + u)], hl, W, H, src, p[u]);
+            for (int u = 0; u < BWD_INFLIGHT; ++u) bwd_eval(my[s + u], hl, W, H, src, p[u]);
 #pragma unroll
             for (int u = 0; u < BWD_INFLIGHT; ++u) {
-                const BwdRec R = my[2 * (s + u)];
+                const BwdRec R = my[s + u];
                 if (R.gs_id != cur_g) {
                     // the segment that ends here started after step 0 and ends before the run does
                     if (cur_g >= 0)

@@ -150,13 +150,16 @@ struct GesRenderFunction : public torch::autograd::Function<GesRenderFunction> {
         gps_splat_step& st = model->stepStruct(cam->width, cam->height);
         model->bindCamera(st, *cam, ref_clamped, base_color, torch::Tensor());
         check(gps_splat_render(&st, current_stream()), "gps_splat_render");
+        ctx->saved_data["launch_id"] = model->nextLaunchId();
         auto& B = model->buffers();
         check(gps_compose_l1(cam->width, cam->height, fptr(B.render_colors), fptr(B.weight_sum), fptr(base_color),
                              fptr(ref_depth), nullptr, fptr(B.rgb), fptr(B.depth), nullptr, nullptr, nullptr,
                              current_stream()), "gps_compose_l1");
         ctx->saved_data["model"] = model_ptr;
-        ctx->saved_data["cam"] = cam_ptr;
-        ctx->save_for_backward({ref_depth, ref_clamped, base_color});
+        ctx->saved_data["width"] = (int64_t)cam->width;
+        ctx->saved_data["height"] = (int64_t)cam->height;
+        // the camera's device pack travels with the node (the Camera object may be gone by the time backward runs)
+        ctx->save_for_backward({ref_depth, ref_clamped, base_color, cam->pack_tensor()});
         (void)means; (void)scales; (void)quats; (void)dc; (void)rest; (void)opac;
         // fresh tensors: autograd owns its outputs, the model buffers are reused by the next launch
         return {B.rgb.clone(), B.depth.clone(), B.weight_sum.index({0}).clone()};
@@ -164,12 +167,18 @@ struct GesRenderFunction : public torch::autograd::Function<GesRenderFunction> {
 
     static tensor_list backward(AutogradContext* ctx, tensor_list g) {
         auto* model = reinterpret_cast<RawGaussianModel*>(ctx->saved_data["model"].toInt());
-        const auto* cam = reinterpret_cast<const Camera*>(ctx->saved_data["cam"].toInt());
         auto saved = ctx->get_saved_variables();
-        const torch::Tensor &ref_depth = saved[0], &ref_clamped = saved[1], &base_color = saved[2];
+        const torch::Tensor &ref_depth = saved[0], &ref_clamped = saved[1], &base_color = saved[2], &cam_pack = saved[3];
+        const int H = (int)ctx->saved_data["height"].toInt(), W = (int)ctx->saved_data["width"].toInt();
+        // The per-launch intermediates live in the model's buffers, not in this node (they are capacity sized: cloning them per
+        // forward would cost more than the forward).  They are only valid until the next launch: refuse, loudly, to
+        // differentiate a stale graph (two grad-mode forwards before one backward, an eval forward in between, ...).
+        TORCH_CHECK(model->launchId() == ctx->saved_data["launch_id"].toInt(),
+                    "gesForward: backward() of a render whose intermediates were overwritten by a later forward() / trainStep() "
+                    "of the same model; call backward() before the next launch (one camera per backward, as "
+                    "slam_pipeline.cpp:247-254 does)");
         auto& B = model->buffers();
-        gps_splat_step& st = model->stepStruct(cam->width, cam->height);
-        const int H = cam->height, W = cam->width;
+        gps_splat_step& st = model->stepStruct(W, H);
         // compose: rgb = (raw_rgb + base)/(Ws + 1); depth = (raw_d + ref*b)/(Ws + b), b = [ref > 0]; alpha = Ws
         auto Ws = B.weight_sum.index({0});                                   // [H,W,1]
         auto v_rc = torch::zeros({1, H, W, 4}, Ws.options());
@@ -188,7 +197,8 @@ struct GesRenderFunction : public torch::autograd::Function<GesRenderFunction> {
         }
         if (g[2].defined()) v_ra += g[2];
         v_ra = v_ra.unsqueeze(0).contiguous();
-        model->bindCamera(st, *cam, ref_clamped, base_color, torch::Tensor());
+        st.viewmat = fptr(cam_pack); st.Kmat = fptr(cam_pack) + 16; st.cam_pos = fptr(cam_pack) + 25;
+        st.ref_depth_clamped = fptr(ref_clamped);
         check(gps_raster_ges_bwd_gs(st.N, st.means2d, st.conics, st.colors, st.opacities, st.radii, st.ref_depth_clamped,
                                     W, H, st.group_gs_ids, st.group_starts, st.counts, st.delta_depth, fptr(v_rc),
                                     fptr(v_ra), st.v_means2d, st.v_conics, st.v_colors, st.v_opacities, 0,
@@ -272,6 +282,7 @@ TensorDict RawGaussianModel::gesForward(const Camera& cam, const torch::Tensor& 
         gps_splat_step& st = stepStruct(cam.width, cam.height);
         bindCamera(st, cam, ref_clamped, base_color, torch::Tensor());
         check(gps_splat_render(&st, current_stream()), "gps_splat_render");
+        nextLaunchId();
         check(gps_compose_l1(cam.width, cam.height, fptr(B_.render_colors), fptr(B_.weight_sum), fptr(base_color),
                              fptr(ref_depth), nullptr, fptr(B_.rgb), fptr(B_.depth), nullptr, nullptr, nullptr,
                              current_stream()), "gps_compose_l1");
@@ -391,6 +402,7 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
     st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 2 : 0;  // all six tensors stepped inside the backward kernel
     adam_step_ += 1;
     check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");
+    nextLaunchId();
 }
 
 std::vector<torch::Tensor> RawGaussianModel::grads() {

@@ -101,11 +101,17 @@ public:
     void bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
                     const torch::Tensor& base_color, const torch::Tensor& gt_rgb);
     Buffers& buffers() { return B_; }
+    // Every launch that overwrites the per-launch intermediates (radii, means2d, conics, colors, the tile / group tables, the
+    // render) gets a new id.  The grad-mode forward stamps it into its autograd node; its backward reads those intermediates
+    // and refuses to run if another launch has replaced them in between.
+    int64_t launchId() const { return launch_id_; }
+    int64_t nextLaunchId() { return ++launch_id_; }
 
 protected:
     Buffers B_;
     gps_splat_step step_{};
     int64_t step_cap_ = -1;
+    int64_t launch_id_ = 0;
     int step_w_ = 0, step_h_ = 0;
     // Adam state: capacity-sized exp_avg / exp_avg_sq / grad buffers in reference parameter order + step count
     std::vector<torch::Tensor> adam_m_, adam_v_, adam_g_;

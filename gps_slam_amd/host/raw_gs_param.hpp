@@ -33,6 +33,7 @@ struct Camera {
     torch::Tensor viewmat_tensor() const { return pack_.slice(0, 0, 16).view({4, 4}); }
     torch::Tensor K_tensor() const { return pack_.slice(0, 16, 25).view({3, 3}); }
     torch::Tensor cam_pos_tensor() const { return pack_.slice(0, 25, 28); }
+    const torch::Tensor& pack_tensor() const { return pack_; }  // device float[28] = viewmat | K | cam_pos
 
 private:
     torch::Tensor pack_;  // device float[28] = viewmat(16) | K(9) | cam_pos(3)
