@@ -136,7 +136,11 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
 }
 
 constexpr int EV_THREADS = 256;
-constexpr int EV_MAX_WGS = 512;           // rows of the partial table
+constexpr int EV_MAX_WGS = 256;           // rows of the partial table.  Measured on the 640x480 loop (ms per tracked frame): 128 rows
+                                          // 0.750, 256 rows 0.725, 512 rows 0.735, 1280 rows (one pixel per thread) 0.818 -- the last
+                                          // workgroup's fixed-order sum costs what the evaluation's extra parallelism buys.  (Two
+                                          // pixels in flight per thread -- both depth loads, then both bilinear footprints -- changed
+                                          // nothing either, 0.721: launch + tail + the host round trip dominate an iteration.)
 constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 
 struct PrepArgs {

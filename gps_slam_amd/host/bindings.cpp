@@ -257,8 +257,8 @@ PYBIND11_MODULE(_host, m) {
         .def("stats", [](SLAMPipeline& p) {
             { py::gil_scoped_release nogil; p.flush(); }
             py::dict d;
-            d["frames"] = p.stats.frames; d["opt_iters"] = p.stats.opt_iters; d["raycasts"] = p.stats.raycasts;
-            d["added"] = p.stats.added; d["pruned"] = p.stats.pruned;
+            d["frames"] = p.stats.frames.load(); d["opt_iters"] = p.stats.opt_iters.load(); d["raycasts"] = p.stats.raycasts.load();
+            d["added"] = p.stats.added.load(); d["pruned"] = p.stats.pruned.load();
             return d;
         })
         .def("optCams", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return p.opt_cam_list; })

@@ -10,6 +10,7 @@
 // All compute goes through the C-ABI (RawGaussianModel, TsdfEngine); this file is bookkeeping.  Random choices the
 // reference seeds from std::random_device (dataset_reader.h:39) are seeded here so that runs are reproducible.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <exception>
@@ -111,7 +112,8 @@ public:
     float scene_scale = 1.1f * 3.0f;
     float ssim_weight = 0.0f, depth_weight = 0.0f;  // both 0 in every shipped config -> the fused L1 trainStep
 
-    struct Stats { int64_t frames = 0, opt_iters = 0, raycasts = 0, added = 0, pruned = 0; } stats;
+    // counters are bumped by the frame thread AND (mapping_thread) by the map worker: atomics
+    struct Stats { std::atomic<int64_t> frames{0}, opt_iters{0}, raycasts{0}, added{0}, pruned{0}; } stats;
 
     // Tracking / mapping overlap.  The reference runs a keyframe's map update (raycasts, new Gaussians, 20 optimise iterations,
     // prune) to completion before it looks at the next frame.  Nothing in frames i+1 .. i+9 reads the Gaussian model, and the

@@ -95,8 +95,11 @@ ITMTrackingState* TsdfEngine::ProcessFrame(const torch::Tensor& rgb_u8, const to
                     rgb_u8.size(-1) == 4, "rgb must be a contiguous uint8 [H,W,4] device tensor (uchar4)");
     TORCH_CHECK(depth_mm_i16.is_cuda() && depth_mm_i16.scalar_type() == torch::kInt16 && depth_mm_i16.is_contiguous(),
                 "depth must be a contiguous int16 [H,W] device tensor (millimetres)");
-    frame_inputs_ = {rgb_u8, depth_mm_i16};  // keep alive while kernels may read them
-    state_.rgb = ptr<uint8_t>(rgb_u8);
+    {
+        std::lock_guard<std::mutex> lk(state_mu_);
+        frame_inputs_ = {rgb_u8, depth_mm_i16};  // keep alive while kernels may read them
+        state_.rgb = ptr<uint8_t>(rgb_u8);
+    }
     if (trackingActive) {
         if (!track_scratch_.defined()) turnOnTracking();  // ITMLibSettings defaults
         std::function<void()> gate;
@@ -146,7 +149,8 @@ ITMTrackingState* TsdfEngine::ProcessFrame(ITMUChar4Image* rgbImage, ITMShortIma
 void TsdfEngine::runRaycast(ORUtils::SE3Pose* pose, ITMLib::ITMIntrinsics* intrinsics) {
     TORCH_CHECK(pose != nullptr, "runRaycast(NULL, NULL) (re-render of the live view, ITMBasicEngine.tpp:503-518) is not on "
                 "SLAMPipeline's path and is not implemented; pass the pose of the view");
-    gps_tsdf_state s = state_;
+    gps_tsdf_state s;
+    { std::lock_guard<std::mutex> lk(state_mu_); s = state_; }
     if (intrinsics) {
         TORCH_CHECK(intrinsics->imgSize.x == s.width && intrinsics->imgSize.y == s.height,
                     "runRaycast: the free-view render state has the depth camera's image size");

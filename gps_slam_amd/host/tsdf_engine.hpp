@@ -15,6 +15,7 @@
 // SaveSceneToMesh.
 #pragma once
 #include <functional>
+#include <mutex>
 
 #include "gps_host_common.hpp"
 
@@ -197,6 +198,9 @@ public:
 
 private:
     gps_tsdf_state state_{};
+    // state_.rgb / frame_inputs_ change per frame (frame thread) while a mapping worker may snapshot state_ for a free-view
+    // raycast: the snapshot and the per-frame update take this lock (device-side ordering is the caller's events)
+    mutable std::mutex state_mu_;
     torch::Device device_;
     torch::Tensor vba_, vba_alloc_list_, hash_, excess_list_, counters_, alloc_prio_, scan_scratch_, visible_type_,
         visible_ids_, depth_, minmax_, raycast_, icp_points_, icp_normals_, fv_visible_ids_, fv_minmax_, fv_raycast_,
