@@ -522,9 +522,9 @@ typedef struct {
     float pose_M[16], pose_invM[16], pose_pc_M[16];
     int32_t age_point_cloud, frames_processed;
     float diag[16];
-    /* optional: >= 256 bytes of PINNED, device-visible host memory (hipHostMalloc / torch pinned tensor).  If set, the
-     * tracking kernel writes the frame's result (pose + diagnostics, sequence number last) straight into it and the host
-     * spins on the sequence number instead of paying hipMemcpy + stream synchronise; NULL = the memcpy path. */
+    /* optional: >= 256 bytes of PINNED, device-visible host memory (hipHostMalloc / torch pinned tensor).  If set, every
+     * evaluation kernel writes its reduced sums (sequence number last) straight into it and the host spins on the sequence
+     * number instead of paying hipMemcpy + stream synchronise per iteration; NULL = the memcpy path. */
     void *host_mailbox;
     /* sequence number of the last tracking call on this state (owned by the library; kept by gps_track_state_reset) */
     int32_t mail_seq, pad_;
@@ -544,11 +544,13 @@ GPS_API int gps_track_state_reset(gps_track_state *ts);
 GPS_API int64_t gps_track_scratch_bytes(int width, int height);
 
 /* ITMExtendedTracker::TrackCamera (useDepth, !useColour): refines ts->pose_M / pose_invM against the ICP maps of the last
- * raycast (s->icp_points / s->icp_normals, rendered from ts->pose_pc_M) using s->depth.  ONE launch: depth pyramid and the
- * whole Levenberg-Marquardt loop of every level (evaluation, fixed-order reduction, 6x6 Cholesky solve, damping, SE3 update,
- * convergence test -- ITMExtendedTracker_CUDA.cu + ITMExtendedTracker.cpp:470-665) run on the device.  HOST-SYNCHRONOUS
- * once, at the end: the call returns when the refined pose is in ts (the caller needs it to enqueue the fusion).
- * GPS_ERR_LAUNCH also reports a device-side failure (grid rendezvous time-out, singular pose). */
+ * raycast (s->icp_points / s->icp_normals, rendered from ts->pose_pc_M) using s->depth.
+ * One launch builds the depth pyramid levels and the valid-pixel count; every Levenberg-Marquardt iteration is then ONE
+ * launch (ITMExtendedTracker_CUDA.cu's depthTrackerOneLevel_g_rt_device evaluation + a fixed-order reduction by the last
+ * workgroup to finish, written straight into ts->host_mailbox) followed by the 6x6 Cholesky solve, damping, SE3 update and
+ * convergence test on the host (ITMExtendedTracker.cpp:470-665) -- the next iteration's kernel arguments depend on that
+ * decision.  HOST-SYNCHRONOUS: the call returns when the refined pose is in ts (the caller needs it to enqueue the fusion).
+ * GPS_ERR_LAUNCH also reports a kernel that never delivered its result (bounded wait on the mailbox). */
 GPS_API int gps_tsdf_track_camera(const gps_tsdf_state *s, const gps_track_config *cfg, gps_track_state *ts, void *scratch,
                                   int64_t scratch_bytes, gps_stream stream);
 

@@ -628,6 +628,9 @@ ORC_API void orc_raster_ges_bwd_gs(int W, int H, int64_t n_groups, float delta_d
  * within rel_band of it count towards entries 4..9 of their Gaussian.
  * rel_band < 0 selects a second mode: the same sums over the ACCEPTED pairs instead of the borderline ones, i.e.
  * sum |term| of every output -- the scale a summation-order / exp-rounding tolerance is relative to.
+ * rel_band <= -2: as above with every term weighted by sum |terms of sigma| = 0.5 (|a| dx^2 + |c| dy^2) + |b dx dy|:
+ * sigma's own rounding (a few float ulps of ITS largest term) becomes a RELATIVE error of exp(-sigma), so narrow Gaussians
+ * hit far from their centre (large, cancelling terms) need a tolerance proportional to this sum, not to the output alone.
  */
 static int borderline(float opac, float vis, float depth, float cut, float rel_band) {
     const float t = 1.f / 255.f;
@@ -674,8 +677,12 @@ ORC_API void orc_raster_ges_fwd_flip_budget(int W, int H, int tile_size, int tw,
                             /* a depth-borderline pair only matters if it would pass the alpha test (and vice versa) */
                             if (alpha < (1.f - rel_band) / 255.f || c[3] > cut + rel_band * fabsf(cut)) continue;
                         }
-                        for (int q = 0; q < 4; q++) b[q] += fabsf(c[q]) * alpha;
-                        b[4] += alpha;
+                        /* rel_band <= -2: every term weighted by sum |terms of sigma| -- the condition number of
+                         * exp(-sigma) with respect to the rounding of sigma's own sum */
+                        float wgt = (rel_band <= -2.f)
+                                        ? 0.5f * (fabsf(ca) * dx * dx + fabsf(cc) * dy * dy) + fabsf(cb * dx * dy) : 1.f;
+                        for (int q = 0; q < 4; q++) b[q] += fabsf(c[q]) * alpha * wgt;
+                        b[4] += alpha * wgt;
                         any = 1;
                         n_pairs[0]++;
                     }
@@ -733,13 +740,16 @@ ORC_API void orc_raster_ges_bwd_gs_flip_budget(int W, int H, int N, int64_t n_gr
                 if (!clamp_only) b[q] += fabsf(alpha * vc);
                 v_alpha += fabsf(rgb[q] * vc);   /* sum |term|: also bounds the cancellation inside v_alpha */
             }
-            float v_sigma = -opac * vis * v_alpha;
+            float wgt = (rel_band <= -2.f) ? 0.5f * (fabsf(ca) * dx * dx + fabsf(cc) * dy * dy) + fabsf(cb * dx * dy) : 1.f;
+            if (rel_band <= -2.f)
+                for (int q = 0; q < 4; q++) b[q] += fabsf(alpha * v_render_colors[4 * pix + q]) * (wgt - 1.f);
+            float v_sigma = -opac * vis * v_alpha * wgt;
             b[4] += fabsf(0.5f * v_sigma * dx * dx);
             b[5] += fabsf(v_sigma * dx * dy);
             b[6] += fabsf(0.5f * v_sigma * dy * dy);
             b[7] += fabsf(v_sigma) * (fabsf(ca * dx) + fabsf(cb * dy));   /* |terms|: the inner sum cancels as well */
             b[8] += fabsf(v_sigma) * (fabsf(cb * dx) + fabsf(cc * dy));
-            b[9] += fabsf(vis * v_alpha);
+            b[9] += fabsf(vis * v_alpha) * wgt;
             n_pairs[0]++;
             if (g != last_counted) { n_pairs[1]++; last_counted = g; }
         }

@@ -35,6 +35,14 @@ rc, ra, last = orc.raster_ges_fwd(m2, conics, colors, opac, ref_depth, W, H, TS,
 v_rc = rng.normal(size=(H, W, 4)).astype(np.float32)
 v_ra = rng.normal(size=(H, W)).astype(np.float32)
 v_m2, v_con, v_col, v_op = orc.raster_ges_bwd_gs(m2, conics, colors, opac, radii, ref_depth, W, H, ggs, gst, 0.1, v_rc, v_ra)
+# rounding scale (sum |terms|: rel_band -1; the same weighted by sum |terms of sigma|: rel_band -2) and borderline-pair budgets
+# (rel_band = 1e-5) of both rasterizer stages: what a consumer of this fixture may tolerate per element instead of a generic
+# outlier budget
+fb = {}
+for tag, band in (("scale", -1.0), ("sig", -2.0), ("flip", 1e-5)):
+    fb["fwd_" + tag], _, _ = orc.raster_ges_fwd_flip_budget(m2, conics, colors, opac, ref_depth, W, H, TS, offs, flat, 0.1, rel_band=band)
+    fb["bwd_" + tag], _, _ = orc.raster_ges_bwd_gs_flip_budget(m2, conics, colors, opac, radii, ref_depth, W, H, ggs, gst, 0.1, v_rc, v_ra,
+                                                            rel_band=band)
 v_means, v_quats, v_scales = orc.proj_bwd(g["means"], g["quats"], scales, vm, K, W, H, radii, conics, v_m2,
                                           np.ascontiguousarray(v_col[:, 3]), v_con)
 v_coeffs, v_dirs = orc.sh_bwd(3, dirs, g["sh"], radii > 0, np.ascontiguousarray(v_col[:, :3]))
@@ -44,5 +52,5 @@ np.savez_compressed(out, W=W, H=H, TS=TS, means=g["means"], quats=g["quats"], lo
                     radii=radii, means2d=m2, depths=depths, conics=conics, colors=colors, opac=opac, tiles_per_gauss=tpg,
                     isect_ids=ids, flatten_ids=flat, group_gs_ids=ggs, group_starts=gst, offsets=offs, render_colors=rc,
                     weight_sum=ra, v_means2d=v_m2, v_conics=v_con, v_colors=v_col, v_opacities=v_op, v_means=v_means,
-                    v_quats=v_quats, v_scales=v_scales, v_coeffs=v_coeffs)
+                    v_quats=v_quats, v_scales=v_scales, v_coeffs=v_coeffs, **fb)
 print("wrote", out, os.path.getsize(out), "bytes; n_isects", len(flat), "n_groups", len(ggs), "visible", int((radii > 0).sum()))
