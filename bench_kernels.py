@@ -121,6 +121,11 @@ def iteration_roofline(scene, seq, result, hbm_peak_gbs, K):
                 traffic = rec.get("hbm_bytes_per_launch")
                 traffic_note = "profiles/pmc_raster_bwd.json (same scene: N and G within 1 %): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
                 valu = rec.get("valu")
+                if valu and valu.get("wave_instructions_per_launch", {}).get("SQ_INSTS_VALU"):
+                    # counter collection serialises and slows the launches (launch_us_same_run); the instruction COUNT is
+                    # what carries over -- priced here against this run's live launch time
+                    valu = dict(valu, issue_frac_live=valu["wave_instructions_per_launch"]["SQ_INSTS_VALU"] * 4.0 /
+                                (1024 * 2.4e9 * t_bwd), launch_us_live=t_bwd * 1e6)
             else:
                 traffic_note = "profiles/pmc_raster_bwd.json was collected on a different scene (its N, G: %s, %s) -- not reported" % (
                     u.get("gaussians"), u.get("n_groups"))
