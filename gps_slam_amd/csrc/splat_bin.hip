@@ -10,37 +10,25 @@
 // caller-chosen capacity, and the pipeline is
 //   count (+ per-256 block sums) -> single-workgroup scan of block sums ->
 //   expand (balanced, coalesced: one thread per OUTPUT element, binary search
-//   in the block's LDS prefix) -> stable LSD radix sort on the tile id only
-//   (1 or 2 passes of <= 8 bits: 1,200 tiles = 11 bits, 3,600 tiles = 12 bits)
-//   -> tile offsets.
+//   in the block's LDS prefix) -> ONE stable counting-sort pass on the whole tile id
+//   (up to 4,096 tiles: a per-(tile, 2048-item block) count table, one workgroup per
+//   tile scans its row, the scatter ranks 11/12-bit digits with wave ballots; the tile
+//   offsets are the exclusive scan of the tile totals, so no pass over the sorted keys
+//   is needed).  More tiles than that: 2 LSD passes of <= 8 bits + an offsets pass.
 // Sort keys are u32 tile ids; the int64 isect_ids of the reference API are
 // materialised only if the caller asks for them.  The sort is stable, so inside
 // a tile Gaussians stay in ascending index order exactly like cub's LSD sort.
-#include "common.hpp"
+#include "splat_bin.hpp"
 
 namespace {
 
-constexpr int BIN_BLOCK = 256;          // Gaussians per count/expand workgroup
+using gps::BIN_BLOCK;                   // Gaussians per count/expand workgroup
+using gps::TileBox;
+using gps::tile_bbox;
 constexpr int SORT_THREADS = 256;       // 4 waves
 constexpr int SORT_ITEMS = 8;           // items per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 2048 items per workgroup
 constexpr int SCAN_THREADS = 1024;
-
-struct TileBox { uint32_t x0, y0, x1, y1; };
-
-// isect_tiles_no_depth.cu:68-80: bbox in tile units; float->uint conversion saturates at 0.
-__device__ __forceinline__ TileBox tile_bbox(float mx, float my, int radius_i, int tile_size, int tw, int th) {
-    float radius = (float)radius_i;
-    float ts = (float)tile_size;
-    float tr = radius / ts, tx = mx / ts, ty = my / ts;
-    TileBox b;
-    float fx0 = floorf(tx - tr), fy0 = floorf(ty - tr), fx1 = ceilf(tx + tr), fy1 = ceilf(ty + tr);
-    b.x0 = (uint32_t)fminf(fmaxf(fx0, 0.f), (float)tw);
-    b.y0 = (uint32_t)fminf(fmaxf(fy0, 0.f), (float)th);
-    b.x1 = (uint32_t)fminf(fmaxf(fx1, 0.f), (float)tw);
-    b.y1 = (uint32_t)fminf(fmaxf(fy1, 0.f), (float)th);
-    return b;
-}
 
 // ---- workgroup-wide exclusive scan of one int per thread (blockDim multiple of 64, <= 1024) ----
 __device__ __forceinline__ int block_excl_scan(int v, int* lds_wave_sums /*[17]*/, int& total) {
@@ -73,7 +61,6 @@ __global__ __launch_bounds__(BIN_BLOCK) void count_kernel(int N, const float* __
                                                          int32_t* __restrict__ tiles_by_rank) {
     // order != NULL (depth-keyed binning of the `raw` method): thread i handles the Gaussian of depth rank i; its tile
     // count also goes to tiles_by_rank[i], which is what the expansion scans; no pixel groups are produced
-    __shared__ int red[3][BIN_BLOCK / 64];
     int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
     int t = 0, g = 0, vis = 0;
     if (i < N) {
@@ -81,24 +68,16 @@ __global__ __launch_bounds__(BIN_BLOCK) void count_kernel(int N, const float* __
         int r = radii[gi];
         if (r > 0) {
             float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)gi);
-            TileBox b = tile_bbox(m.x, m.y, r, tile_size, tw, th);
-            t = (int)((b.y1 - b.y0) * (b.x1 - b.x0));
-            float rf = (float)r;
-            if (!order) g = (int)((4 * rf * rf + 32 - 1) / 32);  // fp32 expression of isect_tiles_no_depth.cu:87
+            gps::tile_group_count(m.x, m.y, r, tile_size, tw, th, t, g);
+            if (order) g = 0;
             vis = 1;
         }
         tiles_per_gauss[gi] = t;
         if (order) tiles_by_rank[i] = t;
         groups_per_gauss[i] = g;
     }
-    int ts = wave_sum_i(t), gs = wave_sum_i(g), vs = wave_sum_i(vis);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ts; red[1][threadIdx.x >> 6] = gs; red[2][threadIdx.x >> 6] = vs; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int a = 0, b = 0, c = 0;
-        for (int w = 0; w < BIN_BLOCK / 64; w++) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
-        blk_tiles[blockIdx.x] = a; blk_groups[blockIdx.x] = b; blk_vis[blockIdx.x] = c;
-    }
+    gps::BinCountOut o = {tiles_per_gauss, groups_per_gauss, blk_tiles, blk_groups, blk_vis, tile_size, tw, th};
+    gps::bin_block_sums(o, t, g, vis);
 }
 
 // ---------------- single workgroup: exclusive scan of the block sums, totals -> counts ----------------
@@ -301,6 +280,105 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     }
 }
 
+// ---------------- one-pass stable counting sort on the whole tile id (n_tiles <= WIDE_MAX_BINS) ----------------
+// The binning of an optimise iteration is launch-latency bound (10 launches of 5-12 us for 4 MB of keys), so the two 8-bit
+// LSD passes + the offsets pass (7 launches) are replaced by 3: count table, row scan, scatter.  Same output order: a
+// counting sort on the full key is the stable sort.
+constexpr int WIDE_MAX_BINS = 4096;
+
+__global__ __launch_bounds__(SORT_THREADS) void wide_hist_kernel(const uint32_t* __restrict__ keys,
+                                                                const int64_t* __restrict__ counts, int bins,
+                                                                int nblk_cap, uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t wh[];  // [bins]
+    const int n = (int)counts[0];
+    const int base = blockIdx.x * SORT_TILE;
+    if (base >= n) return;
+    for (int b = threadIdx.x; b < bins; b += SORT_THREADS) wh[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        int idx = base + k * SORT_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&wh[keys[idx]], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += SORT_THREADS) hist[(size_t)b * nblk_cap + blockIdx.x] = wh[b];
+}
+
+// Ranking as in radix_scatter_kernel with `bits`-wide digits; per-wave running counts are 16-bit (a wave owns 512 items).
+// Workgroup 0 also writes the tile offsets = exclusive scan of the tile totals (isect_tiles_no_depth.cu:373-425: first
+// index of each tile, n for the tiles behind the last one).
+__global__ __launch_bounds__(SORT_THREADS) void wide_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in,
+                                                                   const int64_t* __restrict__ counts, int bins, int bits,
+                                                                   int nblk_cap, const uint32_t* __restrict__ hist,
+                                                                   const uint32_t* __restrict__ digit_total,
+                                                                   uint32_t* __restrict__ keys_out /* may be NULL */,
+                                                                   uint32_t* __restrict__ vals_out,
+                                                                   int32_t* __restrict__ tile_offsets) {
+    extern __shared__ uint32_t wlds[];
+    uint32_t* digitbase = wlds;                                               // [bins]
+    uint16_t* wavecnt = reinterpret_cast<uint16_t*>(wlds + bins);             // [4][bins]
+    __shared__ int dws[17];
+    const int n = (int)counts[0];
+    const int base = blockIdx.x * SORT_TILE;
+    if (base >= n && blockIdx.x != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // exclusive scan of the tile totals: thread t owns `per` consecutive tiles
+    const int per = (bins + SORT_THREADS - 1) / SORT_THREADS;
+    const int lo = min(bins, (int)threadIdx.x * per), hi = min(bins, lo + per);
+    int sum = 0;
+    if (n > 0)
+        for (int b = lo; b < hi; b++) sum += (int)digit_total[b];
+    int dtot;
+    int run = block_excl_scan(sum, dws, dtot);
+    for (int b = lo; b < hi; b++) {
+        digitbase[b] = (uint32_t)run;
+        if (blockIdx.x == 0) tile_offsets[b] = run;
+        if (n > 0) run += (int)digit_total[b];
+    }
+    if (base >= n) return;  // (workgroup 0 of an empty launch: offsets only)
+    for (int k = threadIdx.x; k < (SORT_THREADS / 64) * bins; k += SORT_THREADS) wavecnt[k] = 0;
+    __syncthreads();
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    const int wbase = base + wave * (64 * SORT_ITEMS);
+    const unsigned long long lt = lanemask_lt();
+    uint16_t* mycnt = wavecnt + wave * bins;
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        int idx = wbase + k * 64 + lane;
+        bool valid = idx < n;
+        key[k] = valid ? keys_in[idx] : 0u;
+        val[k] = valid ? vals_in[idx] : 0u;
+        const uint32_t d = key[k];
+        unsigned long long same = __ballot(valid);
+        for (int b = 0; b < bits; b++) {
+            unsigned long long bal = __ballot(valid && ((d >> b) & 1u));
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t prev = mycnt[d];
+        rank[k] = prev + (uint32_t)__popcll(same & lt);
+        if (valid && (same >> lane) == 1ull) mycnt[d] = (uint16_t)(prev + (uint32_t)__popcll(same));
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += SORT_THREADS) {
+        digitbase[b] += hist[(size_t)b * nblk_cap + blockIdx.x];
+        uint32_t acc = 0;
+        for (int w = 0; w < SORT_THREADS / 64; w++) { uint32_t c = wavecnt[w * bins + b]; wavecnt[w * bins + b] = (uint16_t)acc; acc += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        int idx = wbase + k * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = key[k];
+            uint32_t pos = digitbase[d] + mycnt[d] + rank[k];
+            if (keys_out) keys_out[pos] = key[k];
+            vals_out[pos] = val[k];
+        }
+    }
+}
+
 // ---------------- tile offsets (+ optional int64 copy of the sorted keys) ----------------
 // isect_tiles_no_depth.cu:373-425
 __global__ __launch_bounds__(256) void offsets_kernel(const uint32_t* __restrict__ keys,
@@ -372,8 +450,8 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
     p = take((size_t)cap * 4); if (w) w->vals_a = (uint32_t*)p;
     p = take((size_t)cap * 4); if (w) w->keys_b = (uint32_t*)p;
     p = take((size_t)cap * 4); if (w) w->vals_b = (uint32_t*)p;
-    p = take((size_t)256 * nblkI * 4); if (w) w->hist = (uint32_t*)p;
-    p = take((size_t)256 * 4); if (w) w->digit_total = (uint32_t*)p;
+    p = take((size_t)WIDE_MAX_BINS * nblkI * 4); if (w) w->hist = (uint32_t*)p;   // [tile][2048-item block] count table
+    p = take((size_t)WIDE_MAX_BINS * 4); if (w) w->digit_total = (uint32_t*)p;
     p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->order = (uint32_t*)p;
     p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->tiles_by_rank = (int32_t*)p;
     p = take(4 * sizeof(int64_t)); if (w) w->count_n = (int64_t*)p;
@@ -384,6 +462,36 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
 
 }  // namespace
 
+static int isect_impl(int N, const float* means2d, const int32_t* radii, const float* depths, int tile_size, int tile_width,
+                      int tile_height, int64_t isect_capacity, int64_t group_capacity, int32_t* tiles_per_gauss,
+                      int64_t* isect_ids, int32_t* flatten_ids, int32_t* group_gs_ids, int32_t* group_starts,
+                      int32_t* tile_offsets, int64_t* counts, void* workspace, int64_t workspace_bytes, gps_stream stream,
+                      bool counted);
+
+namespace gps {
+
+int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss, int tile_size, int tile_width, int tile_height,
+                        void* workspace, int64_t workspace_bytes, BinCountOut* out) {
+    GPS_REQUIRE(N >= 0 && isect_capacity > 0 && workspace && out && tiles_per_gauss);
+    if (workspace_bytes < (int64_t)carve(nullptr, nullptr, N, isect_capacity)) return GPS_ERR_CAPACITY;
+    Workspace w;
+    carve(&w, (char*)workspace, N, isect_capacity);
+    *out = {tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups, w.blk_vis, tile_size, tile_width, tile_height};
+    return GPS_OK;
+}
+
+int isect_tiles_no_depth_counted(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
+                                 int tile_height, int64_t isect_capacity, int64_t group_capacity, int32_t* tiles_per_gauss,
+                                 int32_t* flatten_ids, int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets,
+                                 int64_t* counts, void* workspace, int64_t workspace_bytes, gps_stream stream) {
+    GPS_REQUIRE(group_gs_ids && group_starts);
+    return isect_impl(N, means2d, radii, nullptr, tile_size, tile_width, tile_height, isect_capacity, group_capacity,
+                      tiles_per_gauss, nullptr, flatten_ids, group_gs_ids, group_starts, tile_offsets, counts, workspace,
+                      workspace_bytes, stream, true);
+}
+
+}  // namespace gps
+
 extern "C" {
 
 int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity) {
@@ -391,11 +499,13 @@ int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity) {
     return (int64_t)carve(nullptr, nullptr, N, isect_capacity);
 }
 
+}  // extern "C"
+
 static int isect_impl(int N, const float* means2d, const int32_t* radii, const float* depths /* NULL: no-depth variant */,
                       int tile_size, int tile_width, int tile_height, int64_t isect_capacity, int64_t group_capacity,
                       int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* group_gs_ids,
                       int32_t* group_starts, int32_t* tile_offsets, int64_t* counts, void* workspace, int64_t workspace_bytes,
-                      gps_stream stream) {
+                      gps_stream stream, bool counted /* first pass already written (gps::isect_count_targets) */) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0);
     GPS_REQUIRE(isect_capacity > 0 && isect_capacity < (1ll << 31) && group_capacity > 0 && group_capacity < (1ll << 31));
@@ -428,7 +538,7 @@ static int isect_impl(int N, const float* means2d, const int32_t* radii, const f
     int32_t* tpg_scan = order ? w.tiles_by_rank : tiles_per_gauss;
     if (!group_gs_ids) { group_gs_ids = w.dummy_groups; group_starts = w.dummy_groups; }
 
-    if (N > 0)
+    if (N > 0 && !counted)
         count_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
                                                    tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
                                                    w.blk_vis, order, w.tiles_by_rank);
@@ -441,13 +551,16 @@ static int isect_impl(int N, const float* means2d, const int32_t* radii, const f
                                                     group_starts, order);
     int bits_total = 1;
     while ((1 << bits_total) < n_tiles) bits_total++;
-    const uint32_t* sorted_keys;
-    if (bits_total <= 8) {
-        radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, counts, 0, bits_total, w.nblkI, w.hist);
-        radix_scan_kernel<<<1 << bits_total, 256, 0, s>>>(counts, w.nblkI, w.hist, w.digit_total);
-        radix_scatter_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, w.vals_a, counts, 0, bits_total, w.nblkI,
-                                                                    w.hist, w.digit_total, w.keys_b, (uint32_t*)flatten_ids);
-        sorted_keys = w.keys_b;
+    const uint32_t* sorted_keys = nullptr;
+    if (n_tiles <= WIDE_MAX_BINS) {
+        // one counting-sort pass on the whole tile id; the offsets come out of the scatter
+        uint32_t* keys_out = isect_ids ? w.keys_b : nullptr;
+        wide_hist_kernel<<<w.nblkI, SORT_THREADS, (size_t)n_tiles * 4, s>>>(w.keys_a, counts, n_tiles, w.nblkI, w.hist);
+        radix_scan_kernel<<<n_tiles, 256, 0, s>>>(counts, w.nblkI, w.hist, w.digit_total);
+        wide_scatter_kernel<<<w.nblkI, SORT_THREADS, (size_t)n_tiles * (4 + 2 * (SORT_THREADS / 64)), s>>>(
+            w.keys_a, w.vals_a, counts, n_tiles, bits_total, w.nblkI, w.hist, w.digit_total, keys_out, (uint32_t*)flatten_ids,
+            tile_offsets);
+        sorted_keys = keys_out;
     } else {
         int b1 = (bits_total + 1) / 2, b2 = bits_total - b1;
         radix_hist_kernel<<<w.nblkI, SORT_THREADS, 0, s>>>(w.keys_a, counts, 0, b1, w.nblkI, w.hist);
@@ -460,10 +573,15 @@ static int isect_impl(int N, const float* means2d, const int32_t* radii, const f
                                                                     w.hist, w.digit_total, w.keys_a, (uint32_t*)flatten_ids);
         sorted_keys = w.keys_a;
     }
-    offsets_kernel<<<512, 256, 0, s>>>(sorted_keys, counts, n_tiles, tile_offsets, isect_ids, depths, flatten_ids);
+    // the pass over the sorted keys is only needed for the int64 isect_ids of the operator API (and for the offsets of the
+    // two-pass path)
+    if (sorted_keys)
+        offsets_kernel<<<512, 256, 0, s>>>(sorted_keys, counts, n_tiles, tile_offsets, isect_ids, depths, flatten_ids);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
+
+extern "C" {
 
 int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
                              int tile_height, int64_t isect_capacity, int64_t group_capacity,
@@ -473,7 +591,7 @@ int gps_isect_tiles_no_depth(int N, const float* means2d, const int32_t* radii, 
     GPS_REQUIRE(group_gs_ids && group_starts);
     return isect_impl(N, means2d, radii, nullptr, tile_size, tile_width, tile_height, isect_capacity, group_capacity,
                       tiles_per_gauss, isect_ids, flatten_ids, group_gs_ids, group_starts, tile_offsets, counts, workspace,
-                      workspace_bytes, stream);
+                      workspace_bytes, stream, false);
 }
 
 int gps_isect_tiles(int N, const float* means2d, const int32_t* radii, const float* depths, int tile_size, int tile_width,
@@ -484,7 +602,7 @@ int gps_isect_tiles(int N, const float* means2d, const int32_t* radii, const flo
     static const float dummy_depth = 1.0f;
     return isect_impl(N, means2d, radii, depths ? depths : &dummy_depth, tile_size, tile_width, tile_height, isect_capacity,
                       1 << 20, tiles_per_gauss, isect_ids, flatten_ids, nullptr, nullptr, tile_offsets, counts, workspace,
-                      workspace_bytes, stream);
+                      workspace_bytes, stream, false);
 }
 
 }  // extern "C"

@@ -1,0 +1,70 @@
+// Shared between splat_bin.hip (tile binning) and splat_fused.hip / splat_step.hip: the fused preprocessing kernel of the
+// model path can produce the binning's first pass (tiles / 32-pixel groups per Gaussian + per-256 block sums) itself, so an
+// optimise iteration does not launch count_kernel over the arrays it has just written.
+#pragma once
+#include "common.hpp"
+
+namespace gps {
+
+constexpr int BIN_BLOCK = 256;  // Gaussians per count / expand workgroup == threads of the preprocessing kernel
+
+struct TileBox { uint32_t x0, y0, x1, y1; };
+
+// isect_tiles_no_depth.cu:68-80: bbox in tile units; float->uint conversion saturates at 0.
+__device__ __forceinline__ TileBox tile_bbox(float mx, float my, int radius_i, int tile_size, int tw, int th) {
+    float radius = (float)radius_i;
+    float ts = (float)tile_size;
+    float tr = radius / ts, tx = mx / ts, ty = my / ts;
+    TileBox b;
+    float fx0 = floorf(tx - tr), fy0 = floorf(ty - tr), fx1 = ceilf(tx + tr), fy1 = ceilf(ty + tr);
+    b.x0 = (uint32_t)fminf(fmaxf(fx0, 0.f), (float)tw);
+    b.y0 = (uint32_t)fminf(fmaxf(fy0, 0.f), (float)th);
+    b.x1 = (uint32_t)fminf(fmaxf(fx1, 0.f), (float)tw);
+    b.y1 = (uint32_t)fminf(fmaxf(fy1, 0.f), (float)th);
+    return b;
+}
+
+// tiles and 32-pixel groups of one Gaussian (isect_tiles_no_depth.cu:82-90)
+__device__ __forceinline__ void tile_group_count(float mx, float my, int r, int tile_size, int tw, int th, int& tiles, int& groups) {
+    TileBox b = tile_bbox(mx, my, r, tile_size, tw, th);
+    tiles = (int)((b.y1 - b.y0) * (b.x1 - b.x0));
+    float rf = (float)r;
+    groups = (int)((4 * rf * rf + 32 - 1) / 32);  // fp32 expression of isect_tiles_no_depth.cu:87
+}
+
+// where the first pass's results live (pointers into the caller's binning workspace); tiles_per_gauss == nullptr: off
+struct BinCountOut {
+    int32_t *tiles_per_gauss, *groups_per_gauss, *blk_tiles, *blk_groups, *blk_vis;
+    int tile_size, tw, th;
+};
+
+// one value triple per thread -> the three per-workgroup sums (all BIN_BLOCK threads must call)
+__device__ __forceinline__ void bin_block_sums(const BinCountOut& o, int t, int g, int vis) {
+    __shared__ int red[3][BIN_BLOCK / 64];
+    int ts = wave_sum_i(t), gs = wave_sum_i(g), vs = wave_sum_i(vis);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ts; red[1][threadIdx.x >> 6] = gs; red[2][threadIdx.x >> 6] = vs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0, c = 0;
+        for (int w = 0; w < BIN_BLOCK / 64; w++) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+        o.blk_tiles[blockIdx.x] = a; o.blk_groups[blockIdx.x] = b; o.blk_vis[blockIdx.x] = c;
+    }
+}
+
+// splat_bin.hip: the count targets inside `workspace` for (N, isect_capacity); GPS_OK or an error
+int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss, int tile_size, int tile_width, int tile_height,
+                        void* workspace, int64_t workspace_bytes, BinCountOut* out);
+// splat_bin.hip: gps_isect_tiles_no_depth whose first pass has already been written to isect_count_targets()'s pointers
+int isect_tiles_no_depth_counted(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
+                                 int tile_height, int64_t isect_capacity, int64_t group_capacity, int32_t* tiles_per_gauss,
+                                 int32_t* flatten_ids, int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets,
+                                 int64_t* counts, void* workspace, int64_t workspace_bytes, gps_stream stream);
+// splat_fused.hip: gps_gauss_preprocess_fwd that also writes the binning's first pass
+int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const float* log_scales, const float* quats,
+                          const float* opac_logit, const float* sh_dc, const float* sh_rest, const float* viewmat,
+                          const float* Kmat, const float* cam_pos, int width, int height, float eps2d, float near_plane,
+                          float far_plane, float radius_clip, int max_gs_radii, int32_t* radii, float* means2d, float* depths,
+                          float* conics, float* colors, float* opacities, float* records, const BinCountOut* count,
+                          gps_stream stream);
+
+}  // namespace gps

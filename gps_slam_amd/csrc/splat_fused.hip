@@ -12,6 +12,7 @@
 // the 59 parameter gradients (plain stores, no memsets, no atomics).
 // The per-Gaussian math is splat_math.hpp, shared with the op-level kernels the parity tests pin.
 #include "splat_adam.hpp"
+#include "splat_bin.hpp"
 #include "splat_math.hpp"
 
 using namespace gps;
@@ -43,11 +44,23 @@ struct FusedIn {
 // coalesced.
 __device__ __forceinline__ void stage_rows_in(float* __restrict__ lds, const float* __restrict__ g, int64_t first_float,
                                               int n_floats) {
-    // first_float is a multiple of 4 (256 rows per workgroup); n_floats may have a tail at the last workgroup
+    // first_float is a multiple of 4 (256 rows per workgroup); n_floats may have a tail at the last workgroup.
+    // A thread copies ~12 float4 (45 floats per row / 4): issued in batches of STAGE_BATCH loads BEFORE the first LDS store --
+    // as a plain loop the compiler emitted load, s_waitcnt vmcnt(0), store per trip, i.e. 12 dependent memory round trips.
+    constexpr int STAGE_BATCH = 6;
     const float4* g4 = reinterpret_cast<const float4*>(g + first_float);
     float4* l4 = reinterpret_cast<float4*>(lds);
     const int n4 = n_floats >> 2;
-    for (int e = threadIdx.x; e < n4; e += blockDim.x) l4[e] = g4[e];
+    const int T = blockDim.x;
+    for (int e0 = threadIdx.x; e0 < n4; e0 += STAGE_BATCH * T) {
+        float4 a[STAGE_BATCH];
+#pragma unroll
+        // clamped, unconditional loads AND stores (a trip past the end re-copies the last float4: same value, same place):
+        // with a bounds test on the store the compiler sinks each load into its branch and the clause is gone again
+        for (int u = 0; u < STAGE_BATCH; u++) a[u] = g4[min(e0 + u * T, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < STAGE_BATCH; u++) l4[min(e0 + u * T, n4 - 1)] = a[u];
+    }
     for (int e = (n4 << 2) + threadIdx.x; e < n_floats; e += blockDim.x) lds[e] = g[first_float + e];
 }
 __device__ __forceinline__ void stage_rows_out(const float* __restrict__ lds, float* __restrict__ g, int64_t first_float,
@@ -63,41 +76,51 @@ template <int DEG>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t* __restrict__ radii,
                                                              float* __restrict__ means2d, float* __restrict__ depths,
                                                              float* __restrict__ conics, float* __restrict__ colors,
-                                                             float* __restrict__ opac, float4* __restrict__ recs) {
+                                                             float* __restrict__ opac, float4* __restrict__ recs,
+                                                             BinCountOut cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= in.N) return;
-    constexpr int NB = (DEG + 1) * (DEG + 1);
-    Cam cam;
-    cam_from_arrays(in.viewmat, in.Kmat, in.W, in.H, cam);
-    const float p[3] = {in.means[3 * i], in.means[3 * i + 1], in.means[3 * i + 2]};
-    const float4 q4 = *reinterpret_cast<const float4*>(in.quats + 4 * (size_t)i);
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    const float s[3] = {expf(in.log_scales[3 * i]), expf(in.log_scales[3 * i + 1]), expf(in.log_scales[3 * i + 2])};
-    Proj o = project_gaussian(cam, p, q, s, in.eps2d, in.near_plane, in.far_plane, in.radius_clip);
-    if (in.max_radii > 0) o.radius = min(o.radius, in.max_radii);
-    radii[i] = o.radius;
-    *reinterpret_cast<float2*>(means2d + 2 * (size_t)i) = make_float2(o.mx, o.my);
-    depths[i] = o.z;
-    conics[3 * i] = o.ca; conics[3 * i + 1] = o.cb; conics[3 * i + 2] = o.cc;
-    float r = 0.f, g = 0.f, b = 0.f;
-    if (o.radius > 0) {
-        const float dx = p[0] - in.cam_pos[0], dy = p[1] - in.cam_pos[1], dz = p[2] - in.cam_pos[2];
-        const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
-        float Y[NB];
-        sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
-        r = Y[0] * in.sh_dc[3 * i]; g = Y[0] * in.sh_dc[3 * i + 1]; b = Y[0] * in.sh_dc[3 * i + 2];
-        // (direct reads: only visible Gaussians need their row here, staging all 256 through LDS measured slower)
-        const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
+    int n_tiles = 0, n_groups = 0, vis = 0;
+    if (i < in.N) {
+        constexpr int NB = (DEG + 1) * (DEG + 1);
+        Cam cam;
+        cam_from_arrays(in.viewmat, in.Kmat, in.W, in.H, cam);
+        const float p[3] = {in.means[3 * i], in.means[3 * i + 1], in.means[3 * i + 2]};
+        const float4 q4 = *reinterpret_cast<const float4*>(in.quats + 4 * (size_t)i);
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float s[3] = {expf(in.log_scales[3 * i]), expf(in.log_scales[3 * i + 1]), expf(in.log_scales[3 * i + 2])};
+        Proj o = project_gaussian(cam, p, q, s, in.eps2d, in.near_plane, in.far_plane, in.radius_clip);
+        if (in.max_radii > 0) o.radius = min(o.radius, in.max_radii);
+        radii[i] = o.radius;
+        *reinterpret_cast<float2*>(means2d + 2 * (size_t)i) = make_float2(o.mx, o.my);
+        depths[i] = o.z;
+        conics[3 * i] = o.ca; conics[3 * i + 1] = o.cb; conics[3 * i + 2] = o.cc;
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (o.radius > 0) {
+            const float dx = p[0] - in.cam_pos[0], dy = p[1] - in.cam_pos[1], dz = p[2] - in.cam_pos[2];
+            const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+            float Y[NB];
+            sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
+            r = Y[0] * in.sh_dc[3 * i]; g = Y[0] * in.sh_dc[3 * i + 1]; b = Y[0] * in.sh_dc[3 * i + 2];
+            // (direct reads: only visible Gaussians need their row here, staging all 256 through LDS measured slower)
+            const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
 #pragma unroll
-        for (int k = 1; k < NB; k++) {
-            r += Y[k] * cf[3 * (k - 1)]; g += Y[k] * cf[3 * (k - 1) + 1]; b += Y[k] * cf[3 * (k - 1) + 2];
+            for (int k = 1; k < NB; k++) {
+                r += Y[k] * cf[3 * (k - 1)]; g += Y[k] * cf[3 * (k - 1) + 1]; b += Y[k] * cf[3 * (k - 1) + 2];
+            }
+            r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
         }
-        r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
+        *reinterpret_cast<float4*>(colors + 4 * (size_t)i) = make_float4(r, g, b, o.z);
+        const float op = 1.f / (1.f + expf(-in.opac_logit[i]));
+        opac[i] = op;
+        if (recs) pack_record(o, r, g, b, op, recs + 3 * (size_t)i);
+        if (cnt.tiles_per_gauss) {
+            // first pass of the tile binning (count_kernel of splat_bin.hip) on the values still in registers
+            if (o.radius > 0) { tile_group_count(o.mx, o.my, o.radius, cnt.tile_size, cnt.tw, cnt.th, n_tiles, n_groups); vis = 1; }
+            cnt.tiles_per_gauss[i] = n_tiles;
+            cnt.groups_per_gauss[i] = n_groups;
+        }
     }
-    *reinterpret_cast<float4*>(colors + 4 * (size_t)i) = make_float4(r, g, b, o.z);
-    const float op = 1.f / (1.f + expf(-in.opac_logit[i]));
-    opac[i] = op;
-    if (recs) pack_record(o, r, g, b, op, recs + 3 * (size_t)i);
+    if (cnt.tiles_per_gauss) bin_block_sums(cnt, n_tiles, n_groups, vis);  // (uniform branch: every thread arrives)
 }
 
 // FUSE_ADAM: the Adam step of the sh_rest tensor (45 of the 59 parameters) happens here, on the LDS tiles, instead of in
@@ -117,18 +140,37 @@ struct FusedAdam {
     float sstep[5];     // lr_k / (1 - beta1^t)
 };
 
-template <int L>
-__device__ __forceinline__ void adam_row(const FusedAdam& ad, int k, int i, const float* g) {
-    AdamScalars sc = ad.sc;
-    sc.step_size = ad.sstep[k];
-    float* p = ad.sp[k] + (size_t)i * L;
-    float* m = ad.sm[k] + (size_t)i * L;
-    float* v = ad.sv[k] + (size_t)i * L;
+// The five small tensors (3 + 3 + 4 + 3 + 1 = 14 floats per Gaussian), stepped by the thread that owns the Gaussian: all 42
+// loads (parameter, both moments) are issued before the first update -- row by row with the stores in between, every
+// component was its own memory round trip (the compiler cannot move a load of m[c+1] above the store of p[c]).
+__device__ __forceinline__ void adam_small_rows(const FusedAdam& ad, int i, const float* const g[5]) {
+    constexpr int L[5] = {3, 3, 4, 3, 1};
+    float P[14], M[14], V[14];
+    int o = 0;
 #pragma unroll
-    for (int c = 0; c < L; c++) {
-        float pc = p[c], mc = m[c], vc = v[c];
-        adam_update(sc, g[c], mc, vc, pc);
-        p[c] = pc; m[c] = mc; v[c] = vc;
+    for (int k = 0; k < 5; k++) {
+        const float* p = ad.sp[k] + (size_t)i * L[k];
+        const float* m = ad.sm[k] + (size_t)i * L[k];
+        const float* v = ad.sv[k] + (size_t)i * L[k];
+#pragma unroll
+        for (int c = 0; c < L[k]; c++, o++) { P[o] = p[c]; M[o] = m[c]; V[o] = v[c]; }
+    }
+    o = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        AdamScalars sc = ad.sc;
+        sc.step_size = ad.sstep[k];
+#pragma unroll
+        for (int c = 0; c < L[k]; c++, o++) adam_update(sc, g[k][c], M[o], V[o], P[o]);
+    }
+    o = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float* p = ad.sp[k] + (size_t)i * L[k];
+        float* m = ad.sm[k] + (size_t)i * L[k];
+        float* v = ad.sv[k] + (size_t)i * L[k];
+#pragma unroll
+        for (int c = 0; c < L[k]; c++, o++) { p[c] = P[o]; m[c] = M[o]; v[c] = V[o]; }
     }
 }
 
@@ -229,12 +271,28 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
             float4* gp = reinterpret_cast<float4*>(ad.param + tile_first);
             float4* gm = reinterpret_cast<float4*>(ad.exp_avg + tile_first);
             float4* gv = reinterpret_cast<float4*>(ad.exp_avg_sq + tile_first);
-            for (int e = threadIdx.x; e < n4; e += blockDim.x) {
-                float4 p = p4[e], m = gm[e], v = gv[e];
-                const float4 g = g4[e];
-                adam_update(ad.sc, g.x, m.x, v.x, p.x); adam_update(ad.sc, g.y, m.y, v.y, p.y);
-                adam_update(ad.sc, g.z, m.z, v.z, p.z); adam_update(ad.sc, g.w, m.w, v.w, p.w);
-                gm[e] = m; gv[e] = v; gp[e] = p;
+            // ADAM_BATCH trips' worth of moment loads in flight before the first dependent use (as a plain loop every trip
+            // was load, load, s_waitcnt vmcnt(0), update, 3 stores: ~12 dependent round trips per workgroup)
+            constexpr int ADAM_BATCH = 4;
+            const int T = blockDim.x;
+            for (int e0 = threadIdx.x; e0 < n4; e0 += ADAM_BATCH * T) {
+                float4 m[ADAM_BATCH], v[ADAM_BATCH];
+#pragma unroll
+                for (int u = 0; u < ADAM_BATCH; u++) {
+                    const int e = min(e0 + u * T, n4 - 1);  // unconditional loads: one clause
+                    m[u] = gm[e]; v[u] = gv[e];
+                }
+#pragma unroll
+                for (int u = 0; u < ADAM_BATCH; u++) {
+                    const int e = e0 + u * T;
+                    if (e < n4) {
+                        float4 p = p4[e];
+                        const float4 g = g4[e];
+                        adam_update(ad.sc, g.x, m[u].x, v[u].x, p.x); adam_update(ad.sc, g.y, m[u].y, v[u].y, p.y);
+                        adam_update(ad.sc, g.z, m[u].z, v[u].z, p.z); adam_update(ad.sc, g.w, m[u].w, v[u].w, p.w);
+                        gm[e] = m[u]; gv[e] = v[u]; gp[e] = p;
+                    }
+                }
             }
             for (int e = (n4 << 2) + threadIdx.x; e < n; e += blockDim.x) {
                 float p = sh_tile[e], m = ad.exp_avg[tile_first + e], v = ad.exp_avg_sq[tile_first + e];
@@ -255,8 +313,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
         v_opac_logit[i] = vo;
     }
     if (ad.small) {  // every read of this Gaussian's parameters is done: step them in place
-        adam_row<3>(ad, 0, i, vp); adam_row<3>(ad, 1, i, vs); adam_row<4>(ad, 2, i, vq); adam_row<3>(ad, 3, i, vdc);
-        adam_row<1>(ad, 4, i, &vo);
+        const float* const gs[5] = {vp, vs, vq, vdc, &vo};
+        adam_small_rows(ad, i, gs);
     }
 }
 
@@ -323,6 +381,36 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
     return GPS_OK;
 }
 
+int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const float* log_scales, const float* quats,
+                          const float* opac_logit, const float* sh_dc, const float* sh_rest, const float* viewmat,
+                          const float* Kmat, const float* cam_pos, int width, int height, float eps2d, float near_plane,
+                          float far_plane, float radius_clip, int max_gs_radii, int32_t* radii, float* means2d, float* depths,
+                          float* conics, float* colors, float* opacities, float* records, const BinCountOut* count,
+                          gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
+    GPS_REQUIRE(radii && means2d && depths && conics && colors && opacities);
+    float4* recs = reinterpret_cast<float4*>(records);
+    FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
+                  max_gs_radii, eps2d, near_plane, far_plane, radius_clip};
+    BinCountOut cnt = {};
+    if (count) cnt = *count;
+    static_assert(BIN_BLOCK == 256, "the binning's per-block sums are per preprocessing workgroup");
+    dim3 g(gps_div_up(N, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (sh_degree) {
+        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
+        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
+        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
+        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
+        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
+    }
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
 }  // namespace gps
 
 extern "C" {
@@ -333,25 +421,9 @@ int gps_gauss_preprocess_fwd(int N, int K, int sh_degree, const float* means, co
                              float eps2d, float near_plane, float far_plane, float radius_clip, int max_gs_radii,
                              int32_t* radii, float* means2d, float* depths, float* conics, float* colors,
                              float* opacities, float* records, gps_stream stream) {
-    GPS_ENTER();
-    GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
-    if (N == 0) return GPS_OK;
-    GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
-    GPS_REQUIRE(radii && means2d && depths && conics && colors && opacities);
-    float4* recs = reinterpret_cast<float4*>(records);
-    FusedIn in = {means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat, cam_pos, N, K, width, height,
-                  max_gs_radii, eps2d, near_plane, far_plane, radius_clip};
-    dim3 g(gps_div_up(N, 256)), b(256);
-    hipStream_t s = (hipStream_t)stream;
-    switch (sh_degree) {
-        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
-        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
-        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
-        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
-        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs); break;
-    }
-    GPS_LAUNCH_CHECK();
-    return GPS_OK;
+    return gps::preprocess_fwd_launch(N, K, sh_degree, means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat,
+                                      cam_pos, width, height, eps2d, near_plane, far_plane, radius_clip, max_gs_radii, radii,
+                                      means2d, depths, conics, colors, opacities, records, nullptr, stream);
 }
 
 int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float* means, const float* log_scales,

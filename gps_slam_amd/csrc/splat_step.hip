@@ -6,6 +6,7 @@
 // captured into a hipGraph by the caller (nothing here allocates or synchronises).
 #include "common.hpp"
 #include "splat_adam.hpp"
+#include "splat_bin.hpp"
 
 extern "C" {
 
@@ -13,14 +14,18 @@ int gps_splat_render(const gps_splat_step* a, gps_stream stream) {
     GPS_REQUIRE(a != nullptr);
     const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
     int r;
-    r = gps_gauss_preprocess_fwd(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
-                                 a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
-                                 a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
-                                 a->depths, a->conics, a->colors, a->opacities, a->records, stream);
+    // the preprocessing kernel also writes the first pass of the tile binning (tiles / groups per Gaussian + block sums)
+    gps::BinCountOut cnt;
+    r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, &cnt);
     if (r != GPS_OK) return r;
-    r = gps_isect_tiles_no_depth(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
-                                 a->tiles_per_gauss, nullptr, a->flatten_ids, a->group_gs_ids, a->group_starts,
-                                 a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
+    r = gps::preprocess_fwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
+                                   a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
+                                   a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
+                                   a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, stream);
+    if (r != GPS_OK) return r;
+    r = gps::isect_tiles_no_depth_counted(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
+                                          a->tiles_per_gauss, a->flatten_ids, a->group_gs_ids, a->group_starts,
+                                          a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
     if (r != GPS_OK) return r;
     if (a->records)
         r = gps_raster_ges_fwd_rec(a->N, a->records, a->ref_depth_clamped, a->width, a->height, a->tile_offsets,

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void reset_kernel(TsdfState s) {
     }
     for (int64_t i = tid; i < s.n_blocks; i += stride) s.vba_alloc_list[i] = (int32_t)i;
     for (int64_t i = tid; i < s.n_excess; i += stride) s.excess_list[i] = (int32_t)i;
+    // min/max images: everything outside the 1/8-resolution window CreateExpectedDepths rewrites stays at this value
+    const float2 mm_init = make_float2(FAR_AWAY, VERY_CLOSE);
+    float2* mm = reinterpret_cast<float2*>(s.minmax);
+    float2* fmm = reinterpret_cast<float2*>(s.fv_minmax);
+    for (int64_t i = tid; i < (int64_t)s.width * s.height; i += stride) { mm[i] = mm_init; fmm[i] = mm_init; }
     if (tid < 16) {
         int v0 = 0;
         if (tid == GPS_TSDF_LAST_FREE_BLOCK) v0 = s.n_blocks - 1;

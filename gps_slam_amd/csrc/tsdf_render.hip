@@ -26,11 +26,15 @@ namespace {
 //     = 39 KB), strides over the visible list, projects the 8 block corners (ProjectSingleBlock, Shared.h:36-91) and
 //     min/max-es the bounding box with LDS integer atomics (positive floats order like their bit patterns), then
 //     writes its image to a partial buffer with plain coalesced stores;
-//  B) one thread per pixel reduces the partials and writes the full-resolution-stride image the raycaster indexes
-//     (x/8 + (y/8)*W), initialising every other pixel to (FAR_AWAY, VERY_CLOSE) like the reference's memset kernel.
+//  B) one thread per cell of that window reduces the partials into the full-resolution-stride image the raycaster indexes
+//     (x/8 + (y/8)*W).  Every other pixel of that image holds (FAR_AWAY, VERY_CLOSE) -- the reference's memset kernel
+//     rewrites them every call; here gps_tsdf_reset writes them once and nothing ever touches them again.
+// The rendering-block count accumulates in a scratch counter that pass B publishes and clears, so no memset launch
+// precedes pass A.
 constexpr int ED_GROUPS = 64;
+constexpr int ED_THREADS = 1024;  // ~45k visible blocks over 64 x 1024 threads: one block per thread, no dependent second trip
 
-__global__ __launch_bounds__(256) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
+__global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
                                                                      const int32_t* __restrict__ vis_ids, int count_slot,
                                                                      int sw, int sh, uint2* __restrict__ partial) {
     extern __shared__ uint2 img[];  // [sw*sh] {min bits, max bits}
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void expected_depths_partial_kernel(TsdfState 
     }
     const int tot = wave_sum_i(my_blocks);
     if ((threadIdx.x & 63) == 0 && tot) {
-        const int before = atomicAdd(&s.counters[GPS_TSDF_RENDER_BLOCKS], tot);
+        const int before = atomicAdd(&s.counters[GPS_TSDF_SCRATCH2], tot);
         if (before + tot >= MAX_RENDERING_BLOCKS) s.counters[GPS_TSDF_OVERFLOW] = 1;
     }
     __syncthreads();
@@ -90,22 +94,24 @@ __global__ __launch_bounds__(256) void expected_depths_partial_kernel(TsdfState 
     for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) out[i] = img[i];
 }
 
-__global__ __launch_bounds__(256) void expected_depths_reduce_kernel(int W, int H, int sw, int sh, int groups,
+__global__ __launch_bounds__(256) void expected_depths_reduce_kernel(TsdfState s, int sw, int sh, int groups,
                                                                     const uint2* __restrict__ partial,
                                                                     float2* __restrict__ mm) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * H) return;
-    const int y = i / W, x = i - y * W;
-    float2 r = make_float2(FAR_AWAY, VERY_CLOSE);
-    if (x < sw && y < sh) {
-        uint32_t lo = __float_as_uint(FAR_AWAY), hi = __float_as_uint(VERY_CLOSE);
-        for (int g = 0; g < groups; g++) {
-            const uint2 p = partial[(size_t)g * sw * sh + x + y * sw];
-            lo = min(lo, p.x); hi = max(hi, p.y);
-        }
-        r = make_float2(__uint_as_float(lo), __uint_as_float(hi));
+    if (i == 0) {  // pass A of this call is complete (stream order): publish its rendering-block count, clear the scratch
+        s.counters[GPS_TSDF_RENDER_BLOCKS] = s.counters[GPS_TSDF_SCRATCH2];
+        s.counters[GPS_TSDF_SCRATCH2] = 0;
     }
-    mm[i] = r;
+    if (i >= sw * sh) return;
+    const int y = i / sw, x = i - y * sw;
+    if (x >= s.width || y >= s.height) return;
+    uint32_t lo = __float_as_uint(FAR_AWAY), hi = __float_as_uint(VERY_CLOSE);
+#pragma unroll 16
+    for (int g = 0; g < groups; g++) {
+        const uint2 p = partial[(size_t)g * sw * sh + i];
+        lo = min(lo, p.x); hi = max(hi, p.y);
+    }
+    mm[x + y * s.width] = make_float2(__uint_as_float(lo), __uint_as_float(hi));
 }
 
 // ---------------------------------------------------------------- voxel access (ITMRepresentationAccess.h)
@@ -547,11 +553,10 @@ int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_
     // partial images live behind the sweep scratch (3*nblk + 16 ints + n_total flag bytes), see gps_tsdf_scratch_bytes
     uint2* partial = reinterpret_cast<uint2*>(s.scan_scratch + 3 * nblk + 16 + (n_total + 3) / 4 + 2);
     float2* mm = reinterpret_cast<float2*>(free_view ? s.fv_minmax : s.minmax);
-    hipMemsetAsync(&s.counters[GPS_TSDF_RENDER_BLOCKS], 0, sizeof(int32_t), st);
-    expected_depths_partial_kernel<<<ED_GROUPS, 256, lds, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
+    expected_depths_partial_kernel<<<ED_GROUPS, ED_THREADS, lds, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
                                                                 free_view ? GPS_TSDF_N_VISIBLE_FREE : GPS_TSDF_N_VISIBLE,
                                                                 sw, sh, partial);
-    expected_depths_reduce_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(s.width, s.height, sw, sh, ED_GROUPS, partial, mm);
+    expected_depths_reduce_kernel<<<gps_div_up(sw * sh, 256), 256, 0, st>>>(s, sw, sh, ED_GROUPS, partial, mm);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

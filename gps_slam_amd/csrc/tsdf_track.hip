@@ -151,7 +151,8 @@ struct PrepArgs {
     const float4* normals;
     float4* pn;
     int W, H;
-    uint32_t* sync;                     // [0] the evaluation's ticket, [1] valid-pixel count (both zeroed before the launch)
+    uint32_t* sync;                     // [0] the evaluation's ticket, [1 + parity] valid-pixel count of this frame (zero on entry)
+    int parity;
 };
 
 // PrepareForEvaluation (ITMExtendedTracker.cpp:216-268) in one pass.  A work item is one
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
         a.pn[2 * i + 1] = a.normals[i];
     }
     for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o, 64);
-    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.sync[1], (uint32_t)valid);  // zeroed by the caller's memset
+    // zero on entry: the evaluation launches of the PREVIOUS frame cleared this slot (they read the other one)
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.sync[1 + a.parity], (uint32_t)valid);
 }
 
 // One LM iteration's evaluation + reduction.  Cross-workgroup traffic inside the launch avoids L2 flushes: the XCDs' L2s are
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
 // mailbox, sequence number last.
 template <int ITER>
 __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
-                                                              float* __restrict__ result, volatile float* mailbox, int seq) {
+                                                              float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ;
     __shared__ float red[EV_THREADS / 64][GH_SLOTS];
     __shared__ float group[EV_ROW_GROUPS][GH_SLOTS];
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32
     }
     if (tid == 0) {
         __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every workgroup has arrived: next launch starts at 0
-        const uint32_t n_valid = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n_valid = __hip_atomic_load(&sync[1 + parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[2 - parity], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next frame's count slot
         result[GH_SLOTS + 1] = __uint_as_float(n_valid);
         if (mailbox) mailbox[GH_SLOTS + 1] = __uint_as_float(n_valid);
     }
@@ -439,12 +442,22 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     pa.points = reinterpret_cast<const float4*>(s.icp_points);
     pa.normals = reinterpret_cast<const float4*>(s.icp_normals);
     pa.pn = w.pn; pa.W = W; pa.H = H; pa.sync = w.sync;
-    if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) return GPS_ERR_LAUNCH;
+    // ts->scratch_epoch: 0 = the scratch words have to be zeroed (first call on this state / the last call failed), else
+    // 1 + parity of the valid-count slot this frame uses.  The ticket resets itself and every evaluation launch clears the
+    // other frame's count slot, so the steady state needs no memset launch in front of the frame.
+    int parity = 0;
+    if (ts->scratch_epoch == 0) {
+        if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) return GPS_ERR_LAUNCH;
+    } else {
+        parity = ts->scratch_epoch - 1;
+    }
+    ts->scratch_epoch = 0;  // restored on success
+    pa.parity = parity;
     track_prepare_kernel<<<gps_div_up((int64_t)W * H, 4 * 256), 256, 0, st>>>(pa);
     GPS_LAUNCH_CHECK();
 
     float hessian_good[36] = {0}, nabla_good[6] = {0}, hessian_depth_good[36] = {0}, f_depth_good = 0;
-    int nvalid_depth_good = 0;
+    int nvalid_depth_good = 0, eval_launches = 0;
     float M[16], invM[16];
     memcpy(M, ts->pose_M, 64);
     memcpy(invM, ts->pose_invM, 64);  // kept consistent with pose_M by every writer of the state
@@ -478,10 +491,11 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             // per-state sequence number (>= 1; the slot is cleared first, so nothing stale can match)
             const int seq = (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1);
             if (mailbox) mailbox[GH_SLOTS] = 0.0f;
-            if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq);
-            else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq);
-            else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq);
+            if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq, parity);
+            else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq, parity);
+            else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq, parity);
             GPS_LAUNCH_CHECK();
+            eval_launches++;
             float host[GH_SLOTS];
             if (mailbox) {
                 // spin on the sequence number the kernel writes last (bounded: fall back to a stream synchronise)
@@ -567,7 +581,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     if (ts->host_mailbox && mailbox_iterations > 0) {
         n_max = float_bits(reinterpret_cast<volatile float*>(ts->host_mailbox)[GH_SLOTS + 1]);  // delivered with the last iteration
     } else {
-        if (hipMemcpyAsync(&n_max, w.sync + 1, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+        if (hipMemcpyAsync(&n_max, w.sync + 1 + parity, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
         if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
     }
     ts->diag[8] = (float)nvalid_depth_good; ts->diag[9] = f_depth_good;
@@ -576,6 +590,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     float det = 0.0f;
     if (last_type == TRK_BOTH) { det = Chol(hessian_depth_good, 6).determinant(); if (isnan(det)) det = 0.0f; }
     ts->diag[11] = det;
+    if (eval_launches > 0) ts->scratch_epoch = 2 - parity;  // 1 + the other parity (its slot was cleared by those launches)
     return GPS_OK;
 }
 

@@ -381,7 +381,8 @@ enum {
     GPS_TSDF_RENDER_BLOCKS = 4,    /* rendering blocks requested by the last CreateExpectedDepths */
     GPS_TSDF_OVERFLOW = 5,         /* non-zero: MAX_RENDERING_BLOCKS (262144) exceeded -> min/max image not reference-exact */
     GPS_TSDF_SCRATCH0 = 6,
-    GPS_TSDF_SCRATCH1 = 7
+    GPS_TSDF_SCRATCH1 = 7,
+    GPS_TSDF_SCRATCH2 = 8          /* rendering blocks of the CreateExpectedDepths in flight (published to [4], then cleared) */
 };
 
 /* All pointers are device memory owned by the caller (the reference owns the same buffers through
@@ -421,7 +422,9 @@ typedef struct {
 /* Size in bytes of gps_tsdf_state.scan_scratch (sweep counts + flags + per-workgroup min/max partial images). */
 GPS_API int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_excess);
 
-/* ITMSceneReconstructionEngine::ResetScene (Reconstruction/CUDA/ITMSceneReconstructionEngine_CUDA.tcu:52-80) */
+/* ITMSceneReconstructionEngine::ResetScene (Reconstruction/CUDA/ITMSceneReconstructionEngine_CUDA.tcu:52-80).  Also fills
+ * minmax / fv_minmax with (FAR_AWAY, VERY_CLOSE): CreateExpectedDepths only ever rewrites the 1/8-resolution window of those
+ * images, so the reference's per-call memset of the rest happens once, here.  Must precede every other call on a state. */
 GPS_API int gps_tsdf_reset(const gps_tsdf_state *s, gps_stream stream);
 
 /* ITMViewBuilder::UpdateView depth conversion (ViewBuilding/Shared/ITMViewBuilder_Shared.h:27-36):
@@ -527,7 +530,10 @@ typedef struct {
      * number instead of paying hipMemcpy + stream synchronise per iteration; NULL = the memcpy path. */
     void *host_mailbox;
     /* sequence number of the last tracking call on this state (owned by the library; kept by gps_track_state_reset) */
-    int32_t mail_seq, pad_;
+    int32_t mail_seq;
+    /* 0: the next tracking call zeroes its scratch words first (set by gps_track_state_reset and after a failed call; set it
+     * to 0 yourself when you hand the state a DIFFERENT scratch buffer); otherwise owned by the library */
+    int32_t scratch_epoch;
 } gps_track_state;
 
 /* Builds the configuration from the reference's tracker string parameters (ITMLibSettings.cpp:54-57 default:
