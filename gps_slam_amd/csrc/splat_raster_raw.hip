@@ -11,10 +11,14 @@
 // totals to global memory -- 10 global atomics per (tile, Gaussian) pair instead of the reference's 10 per (warp, Gaussian)
 // (8 warps per tile).
 #include "common.hpp"
-
-
+#include "wave_reduce.hpp"
 
 namespace {
+
+using gps::reduce4;
+using gps::sum_halves;
+using gps::row_sum_to_lane15;
+using gps::dpp_add_masked;
 
 constexpr int RAW_BATCH = 256;
 
@@ -102,35 +106,7 @@ __global__ __launch_bounds__(256) void raster_raw_fwd_kernel(
 // per half-wave) -> 3 registers (four values each, one per row) in 9 swaps + 9 adds; the remaining sum inside each 16-lane
 // row is 4 DPP row_shr adds per register.  30 VALU ops per Gaussian instead of 72 for twelve full DPP reductions, and the
 // totals come out in lane 15 of each row: 3 ds_add_f32 (4 lanes each) instead of 12.
-__device__ __forceinline__ float sum_halves(float a, float b) {  // lanes 0-31: a summed over halves; lanes 32-63: b
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float sum_row_pairs(float a, float b) {  // rows: {a01, b01, a23, b23}
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_add_raw(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-    return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float row_sum_to_lane15(float v) {
-    v = dpp_add_raw<0x111>(v);  // row_shr:1
-    v = dpp_add_raw<0x112>(v);  // row_shr:2
-    v = dpp_add_raw<0x114>(v);  // row_shr:4
-    v = dpp_add_raw<0x118>(v);  // row_shr:8
-    return v;
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add_masked(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
-    return v + __int_as_float(moved);
-}
-// values (a, b, c, d) -> one register whose rows 0..3 end up holding the wave totals of (a, c, b, d) in lane 15
-__device__ __forceinline__ float reduce4(float a, float b, float c, float d) {
-    return row_sum_to_lane15(sum_row_pairs(sum_halves(a, b), sum_halves(c, d)));
-}
+// (helpers: wave_reduce.hpp)
 
 __global__ __launch_bounds__(256) void zero_raw_grads_kernel(int N, float* __restrict__ v_means2d, float* __restrict__ v_conics,
                                                             float* __restrict__ v_colors, float* __restrict__ v_opacities,

@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include "tsdf_common.hpp"
+#include "wave_reduce.hpp"
 #include "tsdf_pose.hpp"
 
 using namespace gpst;
@@ -143,8 +144,13 @@ constexpr int EV_MAX_WGS = 256;           // rows of the partial table.  Measure
                                           // nothing either, 0.721: launch + tail + the host round trip dominate an iteration.)
 constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 
+// per-level constants of the evaluation, read by the pre-launched kernel (track_eval_poll_kernel) from device memory
+struct LevelTab { const float* depth; int vw, vh; float ix, iy, iz, iw; float space_thresh; int n_wgs; };
+
 struct PrepArgs {
     gps_track_config cfg;
+    LevelTab tab_vals[GPS_TRACK_MAX_LEVELS];
+    LevelTab* tab_out;
     const float* depth0;                // full-resolution depth (s.depth)
     float* level[GPS_TRACK_MAX_LEVELS]; // [0] unused
     const float4* points;               // ICP maps of the last raycast
@@ -186,6 +192,11 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
                 }
         }
     }
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++)  // (static indices: a dynamically indexed kernel argument array goes to scratch)
+            if ((int)threadIdx.x == l && l < L) a.tab_out[l] = a.tab_vals[l];
+    }
     int valid = 0;
     const int n = a.W * a.H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -206,28 +217,29 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
 // acknowledgement, THEN the ticket is taken; the workgroup that draws the last ticket reads the rows with sc1 loads and resets
 // the ticket.  Nothing else is written back or invalidated.  Totals + the frame's valid-pixel count go to the pinned host
 // mailbox, sequence number last.
+// One evaluation by the workgroups [0, n_rows) of a launch (shared by the two kernels below).
 template <int ITER>
-__global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
-                                                              float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
-    constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ;
+__device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
+                                          float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
+    constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ, NQ = (NV + 3) / 4;
     __shared__ float red[EV_THREADS / 64][GH_SLOTS];
     __shared__ float group[EV_ROW_GROUPS][GH_SLOTS];
     __shared__ int is_last;
-    float acc[NV];
+    float acc[4 * NQ];
 #pragma unroll
-    for (int k = 0; k < NV; k++) acc[k] = 0.0f;
+    for (int k = 0; k < 4 * NQ; k++) acc[k] = 0.0f;
     const int n = a.vw * a.vh;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_rows * blockDim.x) {
         const int y = i / a.vw, x = i - y * a.vw;
         gh_point<ITER>(a, x, y, acc[0], acc[1], acc + 2, acc + 2 + NP);
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave totals, four values per register (wave_reduce.hpp): 10 VALU ops per quad instead of 24 ds_bpermute round trips
+    const int row_slot = ((lane >> 4) & 1) * 2 + (lane >> 5);  // reduce4 leaves (a, c, b, d) in rows 0..3
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        float v = acc[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) red[wave][k] = v;
+    for (int q = 0; q < NQ; q++) {
+        const float z = gps::reduce4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if ((lane & 15) == 15) red[wave][4 * q + row_slot] = z;
     }
     __syncthreads();
     if (tid < GH_SLOTS) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): wave 0's sc1 stores are acknowledged
         const uint32_t old = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = old + 1u == gridDim.x;
+        is_last = old + 1u == (uint32_t)n_rows;
     }
     __syncthreads();
     if (!is_last) return;
@@ -245,8 +257,8 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32
     {
         const int k = tid & (GH_SLOTS - 1), r = tid >> 5;
         float s = 0.0f;
-        const int rows = (int)gridDim.x;
-        constexpr int INFLIGHT = 32;  // a 512-row table is 64 loads per thread: two memory-side round trips, not eight
+        const int rows = n_rows;
+        constexpr int INFLIGHT = 32;  // a 256-row table is 32 loads per thread: one memory-side round trip
         for (int rr = r; rr < rows; rr += INFLIGHT * EV_ROW_GROUPS) {
             uint32_t v[INFLIGHT];  // independent loads in flight, added in row order afterwards
 #pragma unroll
@@ -283,6 +295,97 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32
         __syncthreads();
         if (tid == 0) mailbox[GH_SLOTS] = __int_as_float(seq);
     }
+}
+
+// (1) one launch per LM iteration with its arguments as kernel arguments: the host_mailbox == NULL path
+template <int ITER>
+__global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
+                                                              float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
+    eval_body<ITER>(a, (int)gridDim.x, partial, sync, result, mailbox, seq, parity);
+}
+
+// (2) PRE-LAUNCHED evaluation (mailbox path).  What an LM iteration evaluates -- level, kind, pose -- is decided by the host
+// from the previous evaluation's sums, so with (1) every iteration pays hipLaunchKernel + the dispatch latency (~8 us) AFTER
+// the host has decided.  This kernel is enqueued BEFORE that: its workgroups start as soon as the previous evaluation has
+// drained, read one 64-byte argument line from pinned host memory until it carries this launch's sequence number, and then
+// run the same evaluation.  The host's decision travels as one cache-line write instead of a launch:
+//     word 0 sequence number | 1 command, kind, level | 2..13 approxInvPose (3 rows x 4 columns) | 14 0 | 15 xor of 0..14
+// The line is written payload first, sequence number last, and read by ONE load instruction of 16 lanes (one 64-byte
+// request); the xor word rejects a torn line anyway.  ARG_SKIP retires a launch the LM loop did not need (the iteration
+// count is data dependent); a launch whose line never arrives gives up after ARG_TIMEOUT (host error paths), so a stream
+// can never be wedged by it.  Per-level constants come from a small device table written by track_prepare_kernel.
+struct PollArgs {
+    const float4* pn; int sw, sh;
+    float4 scene_intr;
+    Mat4 scenePose;
+    float tukey_cutoff, vf_min, vf_max;
+    int use_weights, frames_to_skip, frames_to_weight;
+    const LevelTab* tab;
+    const uint32_t* arg_line;  // pinned host memory, 64-byte aligned
+    uint32_t* dev_line;        // device copy of the line (relayed by workgroup 0)
+};
+constexpr uint32_t ARG_RUN = 1, ARG_SKIP = 2;
+constexpr long long ARG_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
+
+__global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa, uint32_t* __restrict__ partial,
+                                                                   uint32_t* __restrict__ sync, float* __restrict__ result,
+                                                                   volatile float* mailbox, int seq, int parity) {
+    __shared__ uint32_t line[16];
+    if (threadIdx.x < 16) {
+        // Workgroup 0 polls the host line and relays it through a device-memory copy the other workgroups poll: with all 256
+        // workgroups reading the host line across PCIe, the CPU's store waited ~20 us for ownership of its own cache line
+        // (measured: 33 us per iteration instead of ~20; one poller: 1.7 us host -> GPU -> host round trip).
+        const bool relay = blockIdx.x == 0;
+        const uint32_t* src = relay ? pa.arg_line : pa.dev_line;
+        const long long t0 = wall_clock64();
+        uint32_t v;
+        for (;;) {
+            v = relay ? __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                      : __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t x = threadIdx.x < 15 ? v : 0u;  // xor of words 0..14 over the 16 active lanes (row 0 of the wave)
+            x ^= __shfl_xor(x, 1, 16); x ^= __shfl_xor(x, 2, 16); x ^= __shfl_xor(x, 4, 16); x ^= __shfl_xor(x, 8, 16);
+            const uint32_t w0 = __shfl(v, 0, 16), w15 = __shfl(v, 15, 16);
+            if (w0 == (uint32_t)seq && w15 == x) break;
+            if (wall_clock64() - t0 > ARG_TIMEOUT) {  // give up: behave like ARG_SKIP (and relay that)
+                v = threadIdx.x == 0 ? (uint32_t)seq : threadIdx.x == 1 ? ARG_SKIP : 0u;
+                uint32_t y = threadIdx.x < 15 ? v : 0u;
+                y ^= __shfl_xor(y, 1, 16); y ^= __shfl_xor(y, 2, 16); y ^= __shfl_xor(y, 4, 16); y ^= __shfl_xor(y, 8, 16);
+                if (threadIdx.x == 15) v = y;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        line[threadIdx.x] = v;
+        if (relay) {  // payload, wait for the acknowledgement (sc1 stores), then the sequence number
+            if (threadIdx.x != 0) __hip_atomic_store(pa.dev_line + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (threadIdx.x == 0) __hip_atomic_store(pa.dev_line, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    const uint32_t ctl = __builtin_amdgcn_readfirstlane(line[1]);
+    if ((ctl & 0xFF) != ARG_RUN) return;
+    const int kind = (int)((ctl >> 8) & 0xFF), level = (int)((ctl >> 16) & 0xFF);
+    const LevelTab lt = pa.tab[level];
+    if ((int)blockIdx.x >= lt.n_wgs) return;
+    GhArgs a;
+    a.depth = lt.depth; a.vw = lt.vw; a.vh = lt.vh;
+    a.view_intr = make_float4(lt.ix, lt.iy, lt.iz, lt.iw);
+    a.pn = pa.pn; a.sw = pa.sw; a.sh = pa.sh; a.scene_intr = pa.scene_intr;
+    // approxInvPose, ORUtils layout m[col * 4 + row]: rows 0..2 travel, row 3 is (0, 0, 0, 1)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            a.approxInvPose.m[c * 4 + r] = __uint_as_float(__builtin_amdgcn_readfirstlane(line[2 + c * 3 + r]));
+        a.approxInvPose.m[c * 4 + 3] = c == 3 ? 1.0f : 0.0f;
+    }
+    a.scenePose = pa.scenePose;
+    a.space_thresh = lt.space_thresh; a.tukey_cutoff = pa.tukey_cutoff; a.vf_min = pa.vf_min; a.vf_max = pa.vf_max;
+    a.use_weights = pa.use_weights; a.frames_to_skip = pa.frames_to_skip; a.frames_to_weight = pa.frames_to_weight;
+    if (kind == TRK_ROTATION) eval_body<TRK_ROTATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity);
+    else if (kind == TRK_TRANSLATION) eval_body<TRK_TRANSLATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity);
+    else eval_body<TRK_BOTH>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity);
 }
 
 // ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
@@ -347,6 +450,8 @@ struct Scratch {
     uint32_t *partial, *sync;
     float* result;
     float4* pn;
+    LevelTab* tab;
+    uint32_t* dev_line;
 };
 
 size_t carve(Scratch* w, char* base, int W, int H) {
@@ -361,6 +466,8 @@ size_t carve(Scratch* w, char* base, int W, int H) {
     char* p = take((size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;
     p = take(64 * sizeof(float)); if (w) w->result = (float*)p;
     p = take(64); if (w) w->sync = (uint32_t*)p;
+    p = take(GPS_TRACK_MAX_LEVELS * sizeof(LevelTab)); if (w) w->tab = (LevelTab*)p;
+    p = take(64); if (w) w->dev_line = (uint32_t*)p;
     p = take((size_t)W * H * 2 * sizeof(float4)); if (w) w->pn = (float4*)p;
     return off;
 }
@@ -453,8 +560,58 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     }
     ts->scratch_epoch = 0;  // restored on success
     pa.parity = parity;
+    for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++) pa.tab_vals[l] = LevelTab{};
+    for (int l = 0; l < c->n_levels; l++)
+        pa.tab_vals[l] = LevelTab{dl[l], lw[l], lh[l], lintr[l][0], lintr[l][1], lintr[l][2], lintr[l][3], c->space_thresh[l],
+                                  min(EV_MAX_WGS, gps_div_up(lw[l] * lh[l], EV_THREADS))};
+    pa.tab_out = w.tab;
     track_prepare_kernel<<<gps_div_up((int64_t)W * H, 4 * 256), 256, 0, st>>>(pa);
     GPS_LAUNCH_CHECK();
+
+    // Mailbox path: evaluations are PRE-LAUNCHED (track_eval_poll_kernel); the host's per-iteration decision is one
+    // cache-line write into the argument line (words 48..63 of the mailbox block).
+    volatile float* const mailbox = reinterpret_cast<volatile float*>(ts->host_mailbox);
+    volatile uint32_t* const arg_line = mailbox ? reinterpret_cast<volatile uint32_t*>(ts->host_mailbox) + 48 : nullptr;
+    GPS_REQUIRE(!mailbox || (reinterpret_cast<uintptr_t>(ts->host_mailbox) & 63) == 0);
+    PollArgs pl = {};
+    if (mailbox) {
+        pl.pn = w.pn; pl.sw = W; pl.sh = H;
+        pl.scene_intr = make_float4(lintr[0][0], lintr[0][1], lintr[0][2], lintr[0][3]);
+        pl.scenePose = load_mat(ts->pose_pc_M);
+        pl.tukey_cutoff = c->tukey_cutoff; pl.vf_min = s.view_frustum_min; pl.vf_max = s.view_frustum_max;
+        pl.use_weights = ts->frames_processed >= 100; pl.frames_to_skip = c->frames_to_skip; pl.frames_to_weight = c->frames_to_weight;
+        pl.tab = w.tab;
+        pl.arg_line = const_cast<const uint32_t*>(arg_line);
+        pl.dev_line = w.dev_line;
+    }
+    auto next_seq = [&]() { return (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1); };
+    // payload first, sequence number last (x86 stores are not reordered with each other; the compiler barrier keeps the order)
+    auto publish = [&](int seq, uint32_t cmd, int kind, int level, const float* pose) {
+        uint32_t wds[16] = {0};
+        wds[1] = cmd | ((uint32_t)kind << 8) | ((uint32_t)level << 16);
+        if (pose)
+            for (int col = 0; col < 4; col++)
+                for (int r = 0; r < 3; r++) memcpy(&wds[2 + col * 3 + r], &pose[col * 4 + r], 4);
+        wds[0] = (uint32_t)seq;
+        uint32_t x = 0;
+        for (int k = 0; k < 15; k++) x ^= wds[k];
+        wds[15] = x;
+        for (int k = 1; k < 16; k++) arg_line[k] = wds[k];
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        arg_line[0] = wds[0];
+    };
+    // a pre-launched evaluation that has not been given its arguments yet; retired with ARG_SKIP on every way out
+    struct Pending {
+        int seq = 0;
+        decltype(publish)* pub;
+        ~Pending() { if (seq) (*pub)(seq, ARG_SKIP, 0, 0, nullptr); }
+    } pending;
+    pending.pub = &publish;
+    auto prelaunch = [&]() -> int {
+        pending.seq = next_seq();
+        track_eval_poll_kernel<<<EV_MAX_WGS, EV_THREADS, 0, st>>>(pl, w.partial, w.sync, w.result, mailbox, pending.seq, parity);
+        return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+    };
 
     float hessian_good[36] = {0}, nabla_good[6] = {0}, hessian_depth_good[36] = {0}, f_depth_good = 0;
     int nvalid_depth_good = 0, eval_launches = 0;
@@ -487,18 +644,18 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             a.vf_max = s.view_frustum_max; a.use_weights = use_weights; a.frames_to_skip = c->frames_to_skip;
             a.frames_to_weight = c->frames_to_weight;
             const int n_wgs = min(EV_MAX_WGS, gps_div_up(a.vw * a.vh, EV_THREADS));
-            volatile float* mailbox = reinterpret_cast<volatile float*>(ts->host_mailbox);
-            // per-state sequence number (>= 1; the slot is cleared first, so nothing stale can match)
-            const int seq = (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1);
-            if (mailbox) mailbox[GH_SLOTS] = 0.0f;
-            if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq, parity);
-            else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq, parity);
-            else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq, parity);
-            GPS_LAUNCH_CHECK();
-            eval_launches++;
             float host[GH_SLOTS];
             if (mailbox) {
-                // spin on the sequence number the kernel writes last (bounded: fall back to a stream synchronise)
+                // this evaluation is the pre-launched kernel (or the frame's first launch): hand it its arguments, then put
+                // the NEXT evaluation on the stream before waiting -- its launch cost overlaps this evaluation
+                if (!pending.seq && prelaunch() != GPS_OK) return GPS_ERR_LAUNCH;
+                const int seq = pending.seq;
+                pending.seq = 0;
+                mailbox[GH_SLOTS] = 0.0f;  // per-state sequence numbers (>= 1): nothing stale can match
+                publish(seq, ARG_RUN, it, level, approxInvPose);
+                eval_launches++;
+                if (prelaunch() != GPS_OK) return GPS_ERR_LAUNCH;
+                // spin on the sequence number the kernel writes last (bounded)
                 bool got = false;
                 for (long spin = 0; spin < 200000000L; spin++) {
                     if (float_bits(mailbox[GH_SLOTS]) == seq) { got = true; break; }
@@ -506,10 +663,27 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
                     // that is oversubscribed or the GPU is busy elsewhere: stop burning the core between polls
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                 }
-                if (!got && hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+                if (!got) {
+                    // the pre-launched kernel gave up before its line arrived (this thread was descheduled for longer than
+                    // ARG_TIMEOUT between the launch and the publish): retire what is queued and evaluate with a plain launch
+                    publish(pending.seq, ARG_SKIP, 0, 0, nullptr);
+                    pending.seq = 0;
+                    const int seq2 = next_seq();
+                    if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
+                    else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
+                    else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
+                    GPS_LAUNCH_CHECK();
+                    if (hipStreamSynchronize(st) != hipSuccess || float_bits(mailbox[GH_SLOTS]) != seq2) return GPS_ERR_LAUNCH;
+                }
                 for (int k = 0; k < GH_SLOTS; k++) host[k] = mailbox[k];
                 mailbox_iterations++;
             } else {
+                const int seq = next_seq();
+                if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+                else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+                else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+                GPS_LAUNCH_CHECK();
+                eval_launches++;
                 // the reference's GPU tracker reads its 32 accumulators back every iteration as well
                 if (hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
                 if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
