@@ -85,6 +85,7 @@ PROTOTYPES = {
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, vp, f64, f64, f64, i32, vp]),
     "gps_tsdf_scratch_bytes": (i64, [i32, i32, i32, i32]),
     "gps_tsdf_reset": (i32, [C.POINTER(TsdfState), vp]),
+    "gps_tsdf_rebuild_index": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_mesh_workspace_bytes": (i64, [C.POINTER(TsdfState)]),
     "gps_tsdf_mesh_scene": (i32, [C.POINTER(TsdfState), i64, vp, vp, vp, i64, vp]),
     "gps_track_config_init": (i32, [C.POINTER(TrackConfig), C.c_char_p, i32, i32, f32, f32, f32, f32, i32, i32]),

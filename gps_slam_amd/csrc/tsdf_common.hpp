@@ -17,6 +17,26 @@ constexpr float FAR_AWAY = 999999.9f;
 constexpr float VERY_CLOSE = 0.05f;
 constexpr int MINMAX_SUB = 8;
 constexpr int MAX_RENDERING_BLOCKS = 65536 * 4;
+constexpr int ED_GROUPS = 64;  // per-workgroup partial min/max images of CreateExpectedDepths
+
+// Layout of gps_tsdf_state.scan_scratch (int32 words; sized by gps_tsdf_scratch_bytes):
+//   [3 * nblk + 16]             per-1024-slot counts of the ordered sweeps + totals
+//   [(n_total + 3) / 4 + 2]     one flag byte per hash slot (visible-list compaction)
+//   [ED_GROUPS * sw * sh * 2]   partial min/max images
+//   [16]                        pad
+//   [n_buckets / 32]            PERSISTENT: one bit per bucket, set iff its head entry is non-empty (ptr != -2).  Blocks are
+//                               never freed, so alloc_apply only ever sets bits; gps_tsdf_reset clears them,
+//                               gps_tsdf_rebuild_index recomputes them from the table (after a scene was loaded into it).
+//                               The raycaster's free-space march asks this 128 KB bitmap instead of the 16 MB table.
+static inline int64_t scratch_words_before_bits(const gps_tsdf_state& s) {
+    const int64_t n_total = (int64_t)s.n_buckets + s.n_excess;
+    const int64_t nblk = (n_total + 1023) / 1024;
+    const int64_t sw = s.width / MINMAX_SUB + 2, sh = s.height / MINMAX_SUB + 2;
+    return 3 * nblk + 16 + (n_total + 3) / 4 + 2 + (int64_t)ED_GROUPS * sw * sh * 2 + 16;
+}
+static inline uint32_t* bucket_bits(const gps_tsdf_state& s) {
+    return reinterpret_cast<uint32_t*>(s.scan_scratch) + scratch_words_before_bits(s);
+}
 
 struct Mat4 { float m[16]; };  // ORUtils layout m[col*4 + row]
 

@@ -27,7 +27,7 @@ using namespace gpst;
 namespace {
 
 // ---------------------------------------------------------------- reset
-__global__ __launch_bounds__(256) void reset_kernel(TsdfState s) {
+__global__ __launch_bounds__(256) void reset_kernel(TsdfState s, uint32_t* __restrict__ bits) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nvox = (int64_t)s.n_blocks * BLK3;
@@ -49,12 +49,23 @@ __global__ __launch_bounds__(256) void reset_kernel(TsdfState s) {
     float2* mm = reinterpret_cast<float2*>(s.minmax);
     float2* fmm = reinterpret_cast<float2*>(s.fv_minmax);
     for (int64_t i = tid; i < (int64_t)s.width * s.height; i += stride) { mm[i] = mm_init; fmm[i] = mm_init; }
+    for (int64_t i = tid; i < (s.n_buckets + 31) / 32; i += stride) bits[i] = 0u;
     if (tid < 16) {
         int v0 = 0;
         if (tid == GPS_TSDF_LAST_FREE_BLOCK) v0 = s.n_blocks - 1;
         if (tid == GPS_TSDF_LAST_FREE_EXCESS) v0 = s.n_excess - 1;
         s.counters[tid] = v0;
     }
+}
+
+// bucket-occupancy bitmap from the table (gps_tsdf_rebuild_index)
+__global__ __launch_bounds__(256) void rebuild_bits_kernel(TsdfState s, uint32_t* __restrict__ bits) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool occ = idx < s.n_buckets && s.hash[idx].ptr != -2;
+    const unsigned long long b = __ballot(occ);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && idx < s.n_buckets) bits[idx >> 5] = (uint32_t)b;
+    if (lane == 32 && idx < s.n_buckets) bits[idx >> 5] = (uint32_t)(b >> 32);
 }
 
 // ---------------------------------------------------------------- view building
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __
 }
 
 __global__ __launch_bounds__(SWEEP) void alloc_apply_kernel(TsdfState s, Mat4 invM, const int32_t* __restrict__ blk1,
-                                                           const int32_t* __restrict__ blk2) {
+                                                           const int32_t* __restrict__ blk2, uint32_t* __restrict__ bits) {
     __shared__ int ws[17];
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
     const int n_total = s.n_buckets + s.n_excess;
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(SWEEP) void alloc_apply_kernel(TsdfState s, Mat4 in
         if (vbaIdx >= 0) {
             ne.ptr = s.vba_alloc_list[vbaIdx];
             s.hash[idx] = ne;
+            atomicOr(&bits[idx >> 5], 1u << (idx & 31));  // bucket head now non-empty (idx < n_buckets for type-1 requests)
             s.visible_type[idx] = 1;  // "new entry is visible" (Shared.h:311)
             atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
         } else {
@@ -409,7 +421,17 @@ int gps_tsdf_reset(const gps_tsdf_state* sp, gps_stream stream) {
     GPS_REQUIRE(sp != nullptr);
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
-    reset_kernel<<<4096, 256, 0, (hipStream_t)stream>>>(s);
+    reset_kernel<<<4096, 256, 0, (hipStream_t)stream>>>(s, bucket_bits(s));
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_rebuild_index(const gps_tsdf_state* sp, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    rebuild_bits_kernel<<<gps_div_up(s.n_buckets, 256), 256, 0, (hipStream_t)stream>>>(s, bucket_bits(s));
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -448,7 +470,7 @@ int gps_tsdf_allocate(const gps_tsdf_state* sp, const float* M, const float* inv
     alloc_request_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(s, im);
     alloc_count_kernel<<<nblk, SWEEP, 0, st>>>(s, blk1, blk2);
     scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blk1, blk2, tot);
-    alloc_apply_kernel<<<nblk, SWEEP, 0, st>>>(s, im, blk1, blk2);
+    alloc_apply_kernel<<<nblk, SWEEP, 0, st>>>(s, im, blk1, blk2, bucket_bits(s));
     // ordered visible list (byte flags live behind the per-block counts in scan_scratch)
     uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
     visible_count_kernel<VIS_LIVE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags);

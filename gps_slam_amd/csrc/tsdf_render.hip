@@ -31,7 +31,6 @@ namespace {
 //     rewrites them every call; here gps_tsdf_reset writes them once and nothing ever touches them again.
 // The rendering-block count accumulates in a scratch counter that pass B publishes and clears, so no memset launch
 // precedes pass A.
-constexpr int ED_GROUPS = 64;
 constexpr int ED_THREADS = 1024;  // ~45k visible blocks over 64 x 1024 threads: one block per thread, no dependent second trip
 
 __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
@@ -117,11 +116,11 @@ __global__ __launch_bounds__(256) void expected_depths_reduce_kernel(TsdfState s
 // ---------------------------------------------------------------- voxel access (ITMRepresentationAccess.h)
 struct BlockCache { int bx, by, bz, ptr; };
 #ifndef GPS_RAYCAST_SKIP
-#define GPS_RAYCAST_SKIP 4
+#define GPS_RAYCAST_SKIP 5
 #endif
-constexpr int SKIP = GPS_RAYCAST_SKIP;  // free-space look-ahead of the raycaster (0 = off)
+constexpr int SKIP = GPS_RAYCAST_SKIP;  // free-space look-ahead of the raycaster, 1..31
 
-__device__ __forceinline__ int floor_div_blk(int v) { return ((v < 0) ? v - BLK + 1 : v) / BLK; }
+__device__ __forceinline__ int floor_div_blk(int v) { return v >> 3; }  // floor(v / 8): arithmetic shift (BLK == 8)
 
 // findVoxel (ITMRepresentationAccess.h:81-113) split into "which block" and "which voxel".  resolve_with_head returns
 // the first voxel index of block (bx,by,bz) or -1 with the reference's cache and vmIndex side effects (cache hit ->
@@ -243,7 +242,7 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
 // castRay (Shared.h:122-221); 16x16 pixel workgroups of four 8x8 wave patches
 template <bool MODIFY_VISIBLE>
 __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
-                                                     float4* __restrict__ rays) {
+                                                     float4* __restrict__ rays, const uint32_t* __restrict__ bits) {
     // one wave64 = one 8x8 pixel patch = exactly one cell of the 1/8-resolution min/max image: all 64 rays share their
     // [min, max] range, so their free-space runs and step counts stay close (a 16x4 strip straddles two cells)
     const int wave_in_wg = threadIdx.x >> 6, lane_ = threadIdx.x & 63;
@@ -277,11 +276,17 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     float sdfValue = 1.0f, confidence = 0.f, stepLength;
     int vmIndex = 0;
 #ifdef GPS_RAYCAST_STATS
-    int n_un = 0, n_co = 0, n_in = 0;
+    int n_un = 0, n_co = 0, n_in = 0, adv_sum = 0;
+    const float range0 = totalLengthMax - totalLength;
     const uint64_t t_start = wall_clock64();
     uint64_t tk_heads = 0, tk_vox = 0, tk_interp = 0, tk_tail = 0, tk0;
+#ifdef GPS_RAYCAST_STATS_TICKS  // (s_memrealtime costs ~1 us per call: off unless the per-section sums are wanted)
 #define TICK0() (tk0 = wall_clock64())
 #define TICK(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tk0; tk0 = now_; } while (0)
+#else
+#define TICK0() ((void)tk0)
+#define TICK(acc) ((void)acc)
+#endif
 #else
 #define TICK0()
 #define TICK(acc)
@@ -293,39 +298,44 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
         // float additions in the same order as the one-lookup-per-step loop.  A lane whose sample is in its cached
         // block needs no bucket at all; the others fetch all 1+SKIP bucket heads in one batch.
         TICK0();
-        float qx[SKIP + 1], qy[SKIP + 1], qz[SKIP + 1], ql[SKIP + 1];
-        int kx[SKIP + 1], ky[SKIP + 1], kz[SKIP + 1], hidx[SKIP + 1];
-        uint4 hraw[SKIP + 1] = {};
-        HashEntry head[SKIP + 1];
-        qx[0] = px; qy[0] = py; qz[0] = pz; ql[0] = totalLength;
-#pragma unroll
-        for (int j = 1; j <= SKIP; j++) {
-            qx[j] = qx[j - 1] + (float)BLK * rx; qy[j] = qy[j - 1] + (float)BLK * ry; qz[j] = qz[j - 1] + (float)BLK * rz;
-            ql[j] = ql[j - 1] + (float)BLK;
-        }
         const int vx = (int)roundf_ref(px), vy = (int)roundf_ref(py), vz = (int)roundf_ref(pz);
-        kx[0] = floor_div_blk(vx); ky[0] = floor_div_blk(vy); kz[0] = floor_div_blk(vz);
-        const int lin = vx + (vy - kx[0]) * BLK + (vz - ky[0]) * BLK * BLK - kz[0] * BLK3;
-        const bool cached = kx[0] == cache.bx && ky[0] == cache.by && kz[0] == cache.bz;
+        const int kx0 = floor_div_blk(vx), ky0 = floor_div_blk(vy), kz0 = floor_div_blk(vz);
+        const int lin = vx + (vy - kx0) * BLK + (vz - ky0) * BLK * BLK - kz0 * BLK3;
+        const bool cached = kx0 == cache.bx && ky0 == cache.by && kz0 == cache.bz;
+        int hidx0 = 0;
+        uint4 hraw0 = {};
+        uint32_t occupied = ~0u;  // bit j: the bucket of candidate j has a non-empty head (or was not looked at)
         if (!cached) {
+            hidx0 = hash_index(kx0, ky0, kz0, s.n_buckets - 1);
+            hraw0 = load_raw(s.hash, hidx0);
+            // candidates 1..SKIP: where the next steps land IF this and the following lookups fail (a failed lookup always
+            // advances by one block edge) -- the same float additions in the same order as the one-lookup-per-step loop.
+            // Only the occupancy BIT of their buckets is fetched (one batch of dword loads from a 128 KB bitmap, see
+            // tsdf_common.hpp); an empty head is a certain miss (ITMRepresentationAccess.h:95-110: no entry, no chain).
+            // Round 1 fetched the 16-byte heads of 4 candidates; measured on the bench scene (tools/probe/raycast_time.py,
+            // live raycast): heads x 4: 137.5 us; bits x 1 / 2 / 3 / 5 / 7 / 9 / 15: 123.6 / 115.4 / 116.5 / 112.5 / 116.1 /
+            // 122.2 / 141.1 us -- past ~7 the per-candidate index arithmetic (round, shift, hash: ~25 VALU ops) outweighs
+            // the saved round trips (on a scene of 10 m free-space runs: 926 -> 673 us with ONE candidate, slower again
+            // with more).
+            uint32_t word[SKIP], shift[SKIP];
+            float cx_ = px, cy_ = py, cz_ = pz;
 #pragma unroll
-            for (int j = 0; j <= SKIP; j++) {
-                if (j > 0) {
-                    kx[j] = floor_div_blk((int)roundf_ref(qx[j])); ky[j] = floor_div_blk((int)roundf_ref(qy[j]));
-                    kz[j] = floor_div_blk((int)roundf_ref(qz[j]));
-                }
-                hidx[j] = hash_index(kx[j], ky[j], kz[j], s.n_buckets - 1);
-                hraw[j] = load_raw(s.hash, hidx[j]);
+            for (int j = 0; j < SKIP; j++) {
+                cx_ += (float)BLK * rx; cy_ += (float)BLK * ry; cz_ += (float)BLK * rz;
+                const int h = hash_index(floor_div_blk((int)roundf_ref(cx_)), floor_div_blk((int)roundf_ref(cy_)),
+                                         floor_div_blk((int)roundf_ref(cz_)), s.n_buckets - 1);
+                word[j] = bits[h >> 5];
+                shift[j] = (uint32_t)h & 31u;
             }
+            pin(hraw0);
+            occupied = 1u;
 #pragma unroll
-            for (int j = 0; j + 1 <= SKIP; j += 2) pin(hraw[j], hraw[j + 1]);
-            if ((SKIP & 1) == 0) pin(hraw[SKIP]);
+            for (int j = 0; j < SKIP; j++) occupied |= ((word[j] >> shift[j]) & 1u) << (j + 1);
         }
-#pragma unroll
-        for (int j = 0; j <= SKIP; j++) head[j] = decode_entry(hraw[j]);
+        const HashEntry head0 = decode_entry(hraw0);
         int base;
         if (cached) { vmIndex = 1; base = cache.ptr; }
-        else base = resolve_with_head(s, kx[0], ky[0], kz[0], head[0], hidx[0], vmIndex, cache);
+        else base = resolve_with_head(s, kx0, ky0, kz0, head0, hidx0, vmIndex, cache);
 #ifdef GPS_RAYCAST_STATS
         asm volatile("" : "+v"(base));
         TICK(tk_heads);
@@ -359,20 +369,20 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
 #endif
         if (!vmIndex) {
             stepLength = BLK;
-            // advance over the candidates that are plainly unallocated steps inside the range (not the cached block,
-            // head entry is another block or free, no excess chain); the first one that is anything else is sampled by
-            // the next iteration.  (One batch per iteration: an inner run-to-completion loop would serialise the lanes.)
+            // advance over the candidates that are certainly unallocated steps inside the range (empty bucket head); the
+            // first one that is anything else is sampled by the next iteration.  (One batch per iteration: an inner
+            // run-to-completion loop would serialise the lanes.)
             int adv = 0;
+            float cx_ = px, cy_ = py, cz_ = pz, cl_ = totalLength;
 #pragma unroll
             for (int j = 1; j <= SKIP; j++) {
-                const bool plain = ql[j] < totalLengthMax &&
-                                   !(kx[j] == cache.bx && ky[j] == cache.by && kz[j] == cache.bz) &&
-                                   !(entry_is(head[j], kx[j], ky[j], kz[j]) & (head[j].ptr >= 0)) && head[j].offset < 1;
-                if (adv == j - 1 && plain) adv = j;
+                cx_ += (float)BLK * rx; cy_ += (float)BLK * ry; cz_ += (float)BLK * rz; cl_ += (float)BLK;
+                const bool plain = cl_ < totalLengthMax && !((occupied >> j) & 1u);
+                if (adv == j - 1 && plain) { adv = j; px = cx_; py = cy_; pz = cz_; totalLength = cl_; }
             }
-#pragma unroll
-            for (int j = 1; j <= SKIP; j++)
-                if (adv == j) { px = qx[j]; py = qy[j]; pz = qz[j]; totalLength = ql[j]; }
+#ifdef GPS_RAYCAST_STATS
+            adv_sum += adv;
+#endif
         } else {
             if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
                 float dummy;
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
 #ifdef GPS_RAYCAST_STATS
     const uint64_t t_end = wall_clock64();
 #ifdef GPS_RAYCAST_STATS_SECTIONS
-    rays[x + y * W] = make_float4((float)(tk_tail), (float)tk_heads, (float)tk_vox, (float)(wall_clock64() - t_start));
+    rays[x + y * W] = make_float4((float)n_un, (float)adv_sum, (float)(n_co + n_in), range0);
 #else
     rays[x + y * W] = make_float4((float)(n_un + n_co + n_in), (float)n_un, __uint_as_float((uint32_t)t_start),
                                   __uint_as_float((uint32_t)t_end));
@@ -566,7 +576,10 @@ int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_exces
     const int64_t n_total = (int64_t)n_buckets + n_excess;
     const int64_t nblk = (n_total + 1023) / 1024;
     const int64_t sw = width / MINMAX_SUB + 2, sh = height / MINMAX_SUB + 2;
-    return 4 * (3 * nblk + 16 + (n_total + 3) / 4 + 2) + (int64_t)ED_GROUPS * sw * sh * 8 + 64;
+    (void)nblk; (void)sw; (void)sh;
+    gps_tsdf_state t = {};
+    t.width = width; t.height = height; t.n_buckets = n_buckets; t.n_excess = n_excess;
+    return 4 * (scratch_words_before_bits(t) + (n_buckets + 31) / 32 + 16);
 }
 
 int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, gps_stream stream) {
@@ -578,9 +591,9 @@ int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view,
     const float2* mm = reinterpret_cast<const float2*>(free_view ? s.fv_minmax : s.minmax);
     float4* rays = reinterpret_cast<float4*>(free_view ? s.fv_raycast : s.raycast);
     if (update_visible)
-        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays);
+        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s));
     else
-        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays);
+        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s));
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

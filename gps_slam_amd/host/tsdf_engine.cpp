@@ -258,4 +258,5 @@ void TsdfEngine::LoadFromFile(const std::string& saveInputDirectory) {
     c.data_ptr<int32_t>()[GPS_TSDF_LAST_FREE_BLOCK] = last_block;
     c.data_ptr<int32_t>()[GPS_TSDF_LAST_FREE_EXCESS] = last_excess;
     counters_.copy_(c);
+    check(gps_tsdf_rebuild_index(&state_, current_stream()), "gps_tsdf_rebuild_index");  // the table was written from outside
 }

@@ -206,6 +206,7 @@ class TsdfEngine:
         c = self.counters.cpu()
         c[0], c[1] = sc["last_free_block"], sc["last_free_excess"]
         self.counters.copy_(c)
+        check(lib.gps_tsdf_rebuild_index(C.byref(self.state), self._stream()), "gps_tsdf_rebuild_index")
 
     # ---- host views for tests / persistence (sync)
     def counters_host(self):

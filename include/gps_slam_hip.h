@@ -419,13 +419,19 @@ typedef struct {
     uint8_t *fv_colour;              /* [H*W*4] uchar4 */
 } gps_tsdf_state;
 
-/* Size in bytes of gps_tsdf_state.scan_scratch (sweep counts + flags + per-workgroup min/max partial images). */
+/* Size in bytes of gps_tsdf_state.scan_scratch (sweep counts + flags + per-workgroup min/max partial images + the persistent
+ * bucket-occupancy bitmap: the buffer belongs to the state for its whole life, not to a call). */
 GPS_API int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_excess);
 
 /* ITMSceneReconstructionEngine::ResetScene (Reconstruction/CUDA/ITMSceneReconstructionEngine_CUDA.tcu:52-80).  Also fills
  * minmax / fv_minmax with (FAR_AWAY, VERY_CLOSE): CreateExpectedDepths only ever rewrites the 1/8-resolution window of those
  * images, so the reference's per-call memset of the rest happens once, here.  Must precede every other call on a state. */
 GPS_API int gps_tsdf_reset(const gps_tsdf_state *s, gps_stream stream);
+
+/* Recomputes the library's private index over the hash table (a bucket-occupancy bitmap kept in scan_scratch, which the
+ * raycaster's free-space march reads instead of the table).  The fusion keeps it current by itself; call this after writing
+ * the table from OUTSIDE the library (ITMScene::LoadFromDirectory: hash.dat / excess.dat copied into s->hash). */
+GPS_API int gps_tsdf_rebuild_index(const gps_tsdf_state *s, gps_stream stream);
 
 /* ITMViewBuilder::UpdateView depth conversion (ViewBuilding/Shared/ITMViewBuilder_Shared.h:27-36):
  * depth_mm int16[H*W] -> s->depth (d <= 0 ? -1 : d * 0.001f). */
