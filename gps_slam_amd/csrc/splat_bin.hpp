@@ -51,6 +51,32 @@ __device__ __forceinline__ void bin_block_sums(const BinCountOut& o, int t, int 
     }
 }
 
+// gradient buffers of the backward rasterizer the preprocessing kernel may zero on the way (v_colors == nullptr: off):
+// the backward then starts from pre-zeroed buffers and needs no zero-fill launch
+struct ZeroGrads { float *v_means2d, *v_conics, *v_colors, *v_opacities; };
+
+// compose + L1 (gps_compose_l1) as the epilogue of the forward rasterizer (base_color == nullptr: off): a tile's finished
+// pixels go straight from registers into rgb / loss / the two image gradients -- no launch, no re-read of the render
+struct FwdCompose {
+    const float* base_color;  // [P,3]
+    const float* gt_rgb;      // [P,3]
+    float* rgb;               // [P,3]
+    float* loss;              // scalar accumulator
+    float* v_render_colors;   // [P,4]
+    float* v_render_alphas;   // [P]
+    float inv_count;          // 1 / (3 P)
+};
+// splat_raster.hip
+int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_depth_map, int width, int height,
+                              const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts, float delta_depth,
+                              float* render_colors, float* render_alphas, const FwdCompose* compose, gps_stream stream);
+// gps_raster_ges_bwd_gs with zero_mode: 0 zero-fill here, 1 accumulate onto the buffers, 2 the buffers are already zero
+int raster_ges_bwd_gs_launch(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                             const int32_t* radii, const float* ref_depth_map, int width, int height,
+                             const int32_t* group_gs_ids, const int32_t* group_starts, const int64_t* counts, float delta_depth,
+                             const float* v_render_colors, const float* v_render_alphas, float* v_means2d, float* v_conics,
+                             float* v_colors, float* v_opacities, int zero_mode, gps_stream stream);
+
 // splat_bin.hip: the count targets inside `workspace` for (N, isect_capacity); GPS_OK or an error
 int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss, int tile_size, int tile_width, int tile_height,
                         void* workspace, int64_t workspace_bytes, BinCountOut* out);
@@ -65,6 +91,6 @@ int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const
                           const float* Kmat, const float* cam_pos, int width, int height, float eps2d, float near_plane,
                           float far_plane, float radius_clip, int max_gs_radii, int32_t* radii, float* means2d, float* depths,
                           float* conics, float* colors, float* opacities, float* records, const BinCountOut* count,
-                          gps_stream stream);
+                          const ZeroGrads* zero, gps_stream stream);
 
 }  // namespace gps

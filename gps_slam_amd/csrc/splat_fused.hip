@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
                                                              float* __restrict__ means2d, float* __restrict__ depths,
                                                              float* __restrict__ conics, float* __restrict__ colors,
                                                              float* __restrict__ opac, float4* __restrict__ recs,
-                                                             BinCountOut cnt) {
+                                                             BinCountOut cnt, ZeroGrads zg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int n_tiles = 0, n_groups = 0, vis = 0;
     if (i < in.N) {
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
         const float op = 1.f / (1.f + expf(-in.opac_logit[i]));
         opac[i] = op;
         if (recs) pack_record(o, r, g, b, op, recs + 3 * (size_t)i);
+        if (zg.v_colors) {  // the backward rasterizer's accumulators of this Gaussian (its zero-fill launch, folded in)
+            *reinterpret_cast<float4*>(zg.v_colors + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            zg.v_conics[3 * i] = 0.f; zg.v_conics[3 * i + 1] = 0.f; zg.v_conics[3 * i + 2] = 0.f;
+            *reinterpret_cast<float2*>(zg.v_means2d + 2 * (size_t)i) = make_float2(0.f, 0.f);
+            zg.v_opacities[i] = 0.f;
+        }
         if (cnt.tiles_per_gauss) {
             // first pass of the tile binning (count_kernel of splat_bin.hip) on the values still in registers
             if (o.radius > 0) { tile_group_count(o.mx, o.my, o.radius, cnt.tile_size, cnt.tw, cnt.th, n_tiles, n_groups); vis = 1; }
@@ -386,7 +392,7 @@ int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const
                           const float* Kmat, const float* cam_pos, int width, int height, float eps2d, float near_plane,
                           float far_plane, float radius_clip, int max_gs_radii, int32_t* radii, float* means2d, float* depths,
                           float* conics, float* colors, float* opacities, float* records, const BinCountOut* count,
-                          gps_stream stream) {
+                          const ZeroGrads* zero, gps_stream stream) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
     if (N == 0) return GPS_OK;
@@ -397,15 +403,17 @@ int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const
                   max_gs_radii, eps2d, near_plane, far_plane, radius_clip};
     BinCountOut cnt = {};
     if (count) cnt = *count;
+    ZeroGrads zg = {};
+    if (zero) { zg = *zero; GPS_REQUIRE(zg.v_means2d && zg.v_conics && zg.v_colors && zg.v_opacities); }
     static_assert(BIN_BLOCK == 256, "the binning's per-block sums are per preprocessing workgroup");
     dim3 g(gps_div_up(N, 256)), b(256);
     hipStream_t s = (hipStream_t)stream;
     switch (sh_degree) {
-        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
-        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
-        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
-        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
-        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt); break;
+        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
+        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
+        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
+        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
+        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
     }
     GPS_LAUNCH_CHECK();
     return GPS_OK;
@@ -423,7 +431,7 @@ int gps_gauss_preprocess_fwd(int N, int K, int sh_degree, const float* means, co
                              float* opacities, float* records, gps_stream stream) {
     return gps::preprocess_fwd_launch(N, K, sh_degree, means, log_scales, quats, opac_logit, sh_dc, sh_rest, viewmat, Kmat,
                                       cam_pos, width, height, eps2d, near_plane, far_plane, radius_clip, max_gs_radii, radii,
-                                      means2d, depths, conics, colors, opacities, records, nullptr, stream);
+                                      means2d, depths, conics, colors, opacities, records, nullptr, nullptr, stream);
 }
 
 int gps_gauss_preprocess_bwd(int N, int K, int sh_degree, const float* means, const float* log_scales,

@@ -21,6 +21,7 @@
 // ~N_visible x 10 atomics instead of n_groups x 10.  Pixel/box semantics
 // (int() truncation, +1 offsets, i > y_max guard) are the reference's.
 #include "common.hpp"
+#include "splat_bin.hpp"
 
 namespace {
 
@@ -107,11 +108,29 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_ges_fwd_kernel(
 //     through LDS at the end in a fixed order (deterministic; the sum is order independent in exact arithmetic).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// one pixel of gps_compose_l1 (splat_optim.hip: compose_l1_kernel) on a render that is still in registers; returns the
+// pixel's |gt - rgb| sum
+__device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int p, float4 rc, float w) {
+    const float den = w + 1.0f;  // base colour weight is always 1 (raw_gs_model.cpp:321-323)
+    const float n0 = rc.x + fc.base_color[3 * p], n1 = rc.y + fc.base_color[3 * p + 1], n2 = rc.z + fc.base_color[3 * p + 2];
+    const float c0 = n0 / den, c1 = n1 / den, c2 = n2 / den;
+    fc.rgb[3 * p] = c0; fc.rgb[3 * p + 1] = c1; fc.rgb[3 * p + 2] = c2;
+    const float d0 = fc.gt_rgb[3 * p] - c0, d1 = fc.gt_rgb[3 * p + 1] - c1, d2 = fc.gt_rgb[3 * p + 2] - c2;
+    const float ic = fc.inv_count;
+    const float g0 = d0 > 0.f ? -ic : (d0 < 0.f ? ic : 0.f);
+    const float g1 = d1 > 0.f ? -ic : (d1 < 0.f ? ic : 0.f);
+    const float g2 = d2 > 0.f ? -ic : (d2 < 0.f ? ic : 0.f);
+    reinterpret_cast<float4*>(fc.v_render_colors)[p] = make_float4(g0 / den, g1 / den, g2 / den, 0.f);
+    const float dd = den * den;
+    fc.v_render_alphas[p] = -(g0 * n0) / dd - (g1 * n1) / dd - (g2 * n2) / dd;
+    return fabsf(d0) + fabsf(d1) + fabsf(d2);
+}
+
 __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
-    float* __restrict__ render_alphas) {
+    float* __restrict__ render_alphas, gps::FwdCompose fc) {
     constexpr int BATCH = 256;
     __shared__ float4 r0[BATCH];   // {mx, my, 0.5*ca*log2e, cb*log2e}
     __shared__ float4 r1[BATCH];   // {0.5*cc*log2e, -log2(opac), depth, r}
@@ -177,15 +196,18 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
     __syncthreads();
     if (!list_half) {
         const int pix = row * W + col;
-        if (in0) {
-            render_colors[pix] = make_float4(o0.x + part[slot + 0], o1.x + part[slot + 1], o2.x + part[slot + 2],
-                                             o3.x + part[slot + 3]);
-            render_alphas[pix] = ws.x + part[slot + 4];
-        }
-        if (in1) {
-            render_colors[pix + 1] = make_float4(o0.y + part[slot + 5], o1.y + part[slot + 6], o2.y + part[slot + 7],
-                                                 o3.y + part[slot + 8]);
-            render_alphas[pix + 1] = ws.y + part[slot + 9];
+        const float4 c0 = make_float4(o0.x + part[slot + 0], o1.x + part[slot + 1], o2.x + part[slot + 2], o3.x + part[slot + 3]);
+        const float4 c1 = make_float4(o0.y + part[slot + 5], o1.y + part[slot + 6], o2.y + part[slot + 7], o3.y + part[slot + 8]);
+        const float w0 = ws.x + part[slot + 4], w1 = ws.y + part[slot + 9];
+        if (in0) { render_colors[pix] = c0; render_alphas[pix] = w0; }
+        if (in1) { render_colors[pix + 1] = c1; render_alphas[pix + 1] = w1; }
+        if (fc.base_color) {
+            // compose + L1 + image gradients of the two pixels, operation for operation what compose_l1_kernel does
+            float lsum = 0.f;
+            if (in0) lsum += compose_l1_pixel(fc, pix, c0, w0);
+            if (in1) lsum += compose_l1_pixel(fc, pix + 1, c1, w1);
+            lsum = wave_sum(lsum);
+            if (lane == 0) atomicAdd(fc.loss, lsum * fc.inv_count);
         }
     }
 }
@@ -407,6 +429,54 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
 
 }  // namespace
 
+namespace gps {
+
+int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_depth_map, int width, int height,
+                              const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts, float delta_depth,
+                              float* render_colors, float* render_alphas, const FwdCompose* compose, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
+    GPS_REQUIRE(N == 0 || records);
+    FwdCompose fc = {};
+    if (compose) {
+        fc = *compose;
+        GPS_REQUIRE(fc.base_color && fc.gt_rgb && fc.rgb && fc.loss && fc.v_render_colors && fc.v_render_alphas);
+    }
+    const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
+    raster_ges_fwd_pk_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>(
+        (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
+        (float4*)render_colors, render_alphas, fc);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int raster_ges_bwd_gs_launch(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                             const int32_t* radii, const float* ref_depth_map, int width, int height,
+                             const int32_t* group_gs_ids, const int32_t* group_starts, const int64_t* counts, float delta_depth,
+                             const float* v_render_colors, const float* v_render_alphas, float* v_means2d, float* v_conics,
+                             float* v_colors, float* v_opacities, int zero_mode, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means2d && conics && colors && opacities && radii && ref_depth_map && group_gs_ids && group_starts &&
+                counts && v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities);
+    hipStream_t s = (hipStream_t)stream;
+    if (zero_mode == 0)
+        zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
+                                                                                     v_opacities);
+    constexpr int bwd_blocks = 4096;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
+    BwdPixSrc src = {ref_depth_map, (const float4*)v_render_colors, v_render_alphas, delta_depth};
+    // plain stores where a half-wave owns a Gaussian: only if the buffers are known to be zero (filled here or by the caller)
+    raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
+                                                        (const float4*)colors, opacities, radii, src, counts, width, height,
+                                                        v_means2d, v_conics, v_colors, v_opacities, zero_mode == 1 ? 0 : 1);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // namespace gps
+
 extern "C" {
 
 int gps_raster_ges_fwd(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
@@ -429,16 +499,8 @@ int gps_raster_ges_fwd(int N, const float* means2d, const float* conics, const f
 int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_map, int width, int height,
                            const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts,
                            float delta_depth, float* render_colors, float* render_alphas, gps_stream stream) {
-    GPS_ENTER();
-    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
-    GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
-    GPS_REQUIRE(N == 0 || records);
-    const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
-    raster_ges_fwd_pk_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>(
-        (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
-        (float4*)render_colors, render_alphas);
-    GPS_LAUNCH_CHECK();
-    return GPS_OK;
+    return gps::raster_ges_fwd_rec_launch(N, records, ref_depth_map, width, height, tile_offsets, flatten_ids, counts,
+                                          delta_depth, render_colors, render_alphas, nullptr, stream);
 }
 
 int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, const float* colors,
@@ -447,22 +509,9 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
                           float delta_depth, const float* v_render_colors, const float* v_render_alphas,
                           float* v_means2d, float* v_conics, float* v_colors, float* v_opacities, int accumulate,
                           gps_stream stream) {
-    GPS_ENTER();
-    GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
-    if (N == 0) return GPS_OK;
-    GPS_REQUIRE(means2d && conics && colors && opacities && radii && ref_depth_map && group_gs_ids && group_starts &&
-                counts && v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities);
-    hipStream_t s = (hipStream_t)stream;
-    if (!accumulate)
-        zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
-                                                                                     v_opacities);
-    constexpr int bwd_blocks = 4096;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
-    BwdPixSrc src = {ref_depth_map, (const float4*)v_render_colors, v_render_alphas, delta_depth};
-    raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
-                                                        (const float4*)colors, opacities, radii, src, counts, width, height,
-                                                        v_means2d, v_conics, v_colors, v_opacities, accumulate ? 0 : 1);
-    GPS_LAUNCH_CHECK();
-    return GPS_OK;
+    return gps::raster_ges_bwd_gs_launch(N, means2d, conics, colors, opacities, radii, ref_depth_map, width, height,
+                                         group_gs_ids, group_starts, counts, delta_depth, v_render_colors, v_render_alphas,
+                                         v_means2d, v_conics, v_colors, v_opacities, accumulate ? 1 : 0, stream);
 }
 
 }  // extern "C"

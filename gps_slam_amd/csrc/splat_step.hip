@@ -10,7 +10,9 @@
 
 extern "C" {
 
-int gps_splat_render(const gps_splat_step* a, gps_stream stream) {
+// projection + binning + forward rasterizer; `compose` / `zero`: the train step's compose + L1 and gradient zero-fill riding
+// along in those kernels (nullptr: the plain render)
+static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose, const gps::ZeroGrads* zero, gps_stream stream) {
     GPS_REQUIRE(a != nullptr);
     const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
     int r;
@@ -21,15 +23,16 @@ int gps_splat_render(const gps_splat_step* a, gps_stream stream) {
     r = gps::preprocess_fwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
                                    a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
                                    a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
-                                   a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, stream);
+                                   a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, zero, stream);
     if (r != GPS_OK) return r;
     r = gps::isect_tiles_no_depth_counted(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
                                           a->tiles_per_gauss, a->flatten_ids, a->group_gs_ids, a->group_starts,
                                           a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
     if (r != GPS_OK) return r;
     if (a->records)
-        r = gps_raster_ges_fwd_rec(a->N, a->records, a->ref_depth_clamped, a->width, a->height, a->tile_offsets,
-                                   a->flatten_ids, a->counts, a->delta_depth, a->render_colors, a->weight_sum, stream);
+        r = gps::raster_ges_fwd_rec_launch(a->N, a->records, a->ref_depth_clamped, a->width, a->height, a->tile_offsets,
+                                           a->flatten_ids, a->counts, a->delta_depth, a->render_colors, a->weight_sum,
+                                           compose, stream);
     else
         r = gps_raster_ges_fwd(a->N, a->means2d, a->conics, a->colors, a->opacities, a->ref_depth_clamped, a->width,
                                a->height, 16, a->tile_offsets, a->flatten_ids, a->counts, a->delta_depth,
@@ -37,18 +40,30 @@ int gps_splat_render(const gps_splat_step* a, gps_stream stream) {
     return r;
 }
 
+int gps_splat_render(const gps_splat_step* a, gps_stream stream) { return render_chain(a, nullptr, nullptr, stream); }
+
 int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stream) {
     GPS_REQUIRE(a != nullptr && adam_step >= 1);
     GPS_REQUIRE(a->gt_rgb && a->loss && a->v_render_colors && a->v_render_alphas);
-    int r = gps_splat_render(a, stream);
+    // Launch sites of one iteration: preprocess (+ binning count pass + zero-fill of the rasterizer gradients), scan, expand,
+    // count table, row scan, scatter, forward rasterizer (+ compose + L1 + image gradients in its epilogue), backward
+    // rasterizer, preprocess backward (+ Adam).
+    GPS_REQUIRE(a->base_color != nullptr);
+    const bool fused_fwd = a->records != nullptr;  // the record rasterizer carries the compose epilogue
+    gps::FwdCompose fc = {a->base_color, a->gt_rgb, a->rgb, a->loss, a->v_render_colors, a->v_render_alphas,
+                          1.0f / (3.0f * (float)(a->width * a->height))};
+    gps::ZeroGrads zg = {a->v_means2d, a->v_conics, a->v_colors, a->v_opacities};
+    int r = render_chain(a, fused_fwd ? &fc : nullptr, &zg, stream);
     if (r != GPS_OK) return r;
-    r = gps_compose_l1(a->width, a->height, a->render_colors, a->weight_sum, a->base_color, nullptr, a->gt_rgb, a->rgb,
-                       nullptr, a->loss, a->v_render_colors, a->v_render_alphas, stream);
-    if (r != GPS_OK) return r;
-    r = gps_raster_ges_bwd_gs(a->N, a->means2d, a->conics, a->colors, a->opacities, a->radii, a->ref_depth_clamped,
-                              a->width, a->height, a->group_gs_ids, a->group_starts, a->counts, a->delta_depth,
-                              a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
-                              a->v_opacities, 0, stream);
+    if (!fused_fwd) {
+        r = gps_compose_l1(a->width, a->height, a->render_colors, a->weight_sum, a->base_color, nullptr, a->gt_rgb, a->rgb,
+                           nullptr, a->loss, a->v_render_colors, a->v_render_alphas, stream);
+        if (r != GPS_OK) return r;
+    }
+    r = gps::raster_ges_bwd_gs_launch(a->N, a->means2d, a->conics, a->colors, a->opacities, a->radii, a->ref_depth_clamped,
+                                      a->width, a->height, a->group_gs_ids, a->group_starts, a->counts, a->delta_depth,
+                                      a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
+                                      a->v_opacities, a->N > 0 ? 2 : 0, stream);
     if (r != GPS_OK) return r;
     const int mode = a->K > 1 ? a->fuse_sh_rest_adam : 0;
     const bool fuse = mode >= 1, all = mode >= 2;

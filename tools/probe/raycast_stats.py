@@ -29,6 +29,16 @@ if mode == "stats":
         ps.mean(), np.percentile(ps, 90), ps.max(), pd.mean(), np.percentile(pd, 90), pd.max(), (pd / np.maximum(ps, 1)).mean()))
     span = (t1.max() - t0.min()) * 0.01
     print("kernel span by the tick counters: %.1f us; waves %d" % (span, ps.size))
+    st = ((t0 - t0.min()) * 0.01).reshape(H // 8, 8, W // 8, 8).min(axis=(1, 3)).reshape(-1)
+    en = ((t1 - t0.min()) * 0.01).reshape(H // 8, 8, W // 8, 8).max(axis=(1, 3)).reshape(-1)
+    print("wave start times: p50 %.1f p90 %.1f max %.1f us; end times p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
+        np.percentile(st, 50), np.percentile(st, 90), st.max(), np.percentile(en, 50), np.percentile(en, 90), np.percentile(en, 99), en.max()))
+    for lo, hi in ((0, 5), (5, 10), (10, 15), (15, 20), (20, 40)):
+        m = (ps.reshape(-1) >= lo) & (ps.reshape(-1) < hi)
+        if m.any():
+            print("   waves with %2d..%2d iterations: %5d, duration mean %.1f us (%.2f us/iteration)" % (lo, hi, m.sum(), pd.reshape(-1)[m].mean(), (pd.reshape(-1)[m] / np.maximum(ps.reshape(-1)[m], 1)).mean()))
+    running = [(int(((st <= t) & (en > t)).sum())) for t in np.arange(0, en.max(), en.max() / 12)]
+    print("   waves in flight over time:", running)
     order = np.argsort(pd.reshape(-1))[::-1][:5]
     for o in order:
         print("  slow wave %d: %d iterations, %.1f us" % (o, ps.reshape(-1)[o], pd.reshape(-1)[o]))
