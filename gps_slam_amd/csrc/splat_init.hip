@@ -86,6 +86,114 @@ __global__ __launch_bounds__(256) void normal_map_kernel(int W, int H, const flo
 
 namespace {
 struct SmallFloats { float v[64]; };
+// ---------------------------------------------------------------- new-Gaussian sampling (initNewGaussians / addGaussians)
+// slam_pipeline.cpp:450-526 builds the sample mask with ~12 elementwise / reduce tensor ops; one thread per pixel here, with
+// ATen's float sequence: mean over the 3 channels = ((a + b) + c) * RN(1/3), sum = (x + y) + z.
+__global__ __launch_bounds__(256) void new_gaussian_mask_kernel(int P, const float* __restrict__ depth, const float* __restrict__ src,
+                                                               const float* __restrict__ image, const float* __restrict__ vertex,
+                                                               const float* __restrict__ alpha, float dmin, float dmax,
+                                                               float err_thres, float alpha_max, uint8_t* __restrict__ mask) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float d = depth[p];
+    bool valid = (d > dmin) && (d < dmax);
+    const float vs = (vertex[3 * p] + vertex[3 * p + 1]) + vertex[3 * p + 2];
+    valid = valid && !(vs == 0.0f);
+    const float e0 = fabsf(src[3 * p] - image[3 * p]), e1 = fabsf(src[3 * p + 1] - image[3 * p + 1]),
+                e2 = fabsf(src[3 * p + 2] - image[3 * p + 2]);
+    const float err = ((e0 + e1) + e2) * (1.0f / 3.0f);
+    bool m = (err > err_thres) && valid;
+    if (alpha) m = m && (alpha[p] < alpha_max);
+    mask[p] = m ? 1 : 0;
+}
+
+// masked_select's ORDER (row-major) without its host round trips, in two launches over 4096-byte blocks (16 consecutive
+// bytes per thread, one coalesced dwordx4 each): (1) set bytes per block; (2) every block sums the counts in front of it (a
+// few hundred adds by one wave), scans its own threads and writes the ids; block 0 also publishes the total to a device
+// word and (optionally) a pinned host word.
+constexpr int CM_THREADS = 256, CM_PER = 16, CM_BLOCK = CM_THREADS * CM_PER;
+
+__device__ __forceinline__ int load_mask16(int n, const uint8_t* __restrict__ mask, int first, uint32_t (&w)[4]) {
+    // bytes [first, first + 16) as four words (zero past n); returns the number of non-zero bytes
+    if (first + CM_PER <= n && (reinterpret_cast<uintptr_t>(mask + first) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(mask + first);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            w[q] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p = first + 4 * q + k;
+                if (p < n) w[q] |= (uint32_t)mask[p] << (8 * k);
+            }
+        }
+    }
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) c += ((w[q] >> (8 * k)) & 0xFFu) ? 1 : 0;
+    return c;
+}
+
+__global__ __launch_bounds__(CM_THREADS) void mask_count_kernel(int n, const uint8_t* __restrict__ mask, int32_t* __restrict__ blk) {
+    __shared__ int red[CM_THREADS / 64];
+    uint32_t w[4];
+    int c = load_mask16(n, mask, blockIdx.x * CM_BLOCK + threadIdx.x * CM_PER, w);
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(CM_THREADS) void mask_write_kernel(int n, const uint8_t* __restrict__ mask, const int32_t* __restrict__ blk,
+                                                               int nblk, int32_t* __restrict__ ids, int32_t* __restrict__ count,
+                                                               volatile int32_t* host_count) {
+    __shared__ int ws[CM_THREADS / 64 + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {  // ids in front of this block, and (block 0) the grand total
+        int before = 0, total = 0;
+        for (int b = lane; b < nblk; b += 64) { const int v = blk[b]; total += v; if (b < (int)blockIdx.x) before += v; }
+        before = wave_sum_i(before); total = wave_sum_i(total);
+        if (lane == 0) {
+            ws[CM_THREADS / 64] = before;
+            if (blockIdx.x == 0) { count[0] = total; if (host_count) host_count[0] = total; }
+        }
+    }
+    uint32_t w[4];
+    const int first = blockIdx.x * CM_BLOCK + threadIdx.x * CM_PER;
+    const int c = load_mask16(n, mask, first, w);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    int run = ws[CM_THREADS / 64] + incl - c;
+    for (int k = 0; k < wave; k++) run += ws[k];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((w[q] >> (8 * k)) & 0xFFu) ids[run++] = first + 4 * q + k;
+}
+
+// rows subset[j] of the masked pixels: vertex, image colour, normal -> three [k,3] arrays
+__global__ __launch_bounds__(256) void gather_pixels_kernel(int k, const int32_t* __restrict__ ids, const int32_t* __restrict__ subset,
+                                                           const float* __restrict__ vertex, const float* __restrict__ image,
+                                                           const float* __restrict__ normal, float* __restrict__ verts,
+                                                           float* __restrict__ cols, float* __restrict__ norms) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const int p = ids[subset[j]];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        verts[3 * j + c] = vertex[3 * p + c];
+        cols[3 * j + c] = image[3 * p + c];
+        norms[3 * j + c] = normal[3 * p + c];
+    }
+}
+
 __global__ __launch_bounds__(64) void upload_floats_kernel(SmallFloats v, int n, float* __restrict__ dst) {
     if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
 }
@@ -108,6 +216,47 @@ int gps_normal_map(int width, int height, const float* vertex_map, float* normal
     GPS_REQUIRE(width > 0 && height > 0 && vertex_map && normal_map);
     dim3 grid(gps_div_up(width, 16), gps_div_up(height, 16));
     normal_map_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(width, height, vertex_map, normal_map);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_new_gaussian_mask(int width, int height, const float* depth_map, const float* src_rgb, const float* image,
+                          const float* vertex_map, const float* alpha, float depth_vis_min, float depth_vis_max,
+                          float color_error_thres, float alpha_vis_max, uint8_t* mask, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(width > 0 && height > 0 && depth_map && src_rgb && image && vertex_map && mask);
+    const int P = width * height;
+    new_gaussian_mask_kernel<<<gps_div_up(P, 256), 256, 0, (hipStream_t)stream>>>(P, depth_map, src_rgb, image, vertex_map, alpha,
+                                                                                 depth_vis_min, depth_vis_max, color_error_thres,
+                                                                                 alpha_vis_max, mask);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int64_t gps_compact_mask_workspace_bytes(int n) { return n < 0 ? GPS_ERR_ARG : (int64_t)sizeof(int32_t) * (gps_div_up(n, CM_BLOCK) + 1); }
+
+int gps_compact_mask(int n, const uint8_t* mask, int32_t* ids, int32_t* count, int32_t* host_count, void* workspace,
+                     int64_t workspace_bytes, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(n >= 0 && count && workspace && (n == 0 || (mask && ids)));
+    if (workspace_bytes < gps_compact_mask_workspace_bytes(n)) return GPS_ERR_CAPACITY;
+    const int nblk = gps_div_up(n, CM_BLOCK);
+    int32_t* blk = (int32_t*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    if (nblk > 0) mask_count_kernel<<<nblk, CM_THREADS, 0, s>>>(n, mask, blk);
+    mask_write_kernel<<<nblk > 0 ? nblk : 1, CM_THREADS, 0, s>>>(n, mask, blk, nblk, ids, count, host_count);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_gather_pixels(int k, const int32_t* ids, const int32_t* subset, const float* vertex_map, const float* image,
+                      const float* normal_map, float* verts, float* cols, float* norms, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(k >= 0);
+    if (k == 0) return GPS_OK;
+    GPS_REQUIRE(ids && subset && vertex_map && image && normal_map && verts && cols && norms);
+    gather_pixels_kernel<<<gps_div_up(k, 256), 256, 0, (hipStream_t)stream>>>(k, ids, subset, vertex_map, image, normal_map, verts,
+                                                                             cols, norms);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

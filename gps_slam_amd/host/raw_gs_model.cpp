@@ -434,22 +434,48 @@ void RawGaussianModel::prunePoints(const torch::Tensor& deleteMask) {
 int SLAMGaussianModel::addGaussians(const Camera& cam, const TensorDict& frame_maps, const torch::Tensor& sample_mask,
                                     float new_gs_sample_ratio, int frame_num, c10::optional<at::Generator> gen) {
     (void)frame_num;
-    const int64_t H = cam.image.size(0), W = cam.image.size(1);
-    auto m = sample_mask.expand({H, W, 3});
-    auto verts = torch::masked_select(frame_maps.at("vertex_map"), m).reshape({-1, 3});
-    auto cols = torch::masked_select(cam.image, m).reshape({-1, 3});
-    auto norms = torch::masked_select(frame_maps.at("normal_map"), m).reshape({-1, 3});
-    const int64_t n = verts.size(0);
+    const int64_t H = cam.image.size(0), W = cam.image.size(1), P = H * W;
+    const auto dev = cam.image.device();
+    // The reference materialises three masked_select results (each a nonzero + gather with its own host round trip) and then
+    // keeps a random tenth of the rows.  Here: ONE ordered compaction of the mask into pixel ids (same selection order),
+    // one read of their number, and a gather of only the sampled rows.
+    TORCH_CHECK(sample_mask.scalar_type() == torch::kBool && sample_mask.numel() == P, "sample_mask: bool [H,W,1]");
+    auto mask = sample_mask.contiguous();
+    auto image = cam.image.contiguous();
+    auto vertex = frame_maps.at("vertex_map").contiguous(), normal = frame_maps.at("normal_map").contiguous();
+    gpsh::check_f32_dev(image, "cam.image"); gpsh::check_f32_dev(vertex, "vertex_map"); gpsh::check_f32_dev(normal, "normal_map");
+    auto ids = torch::empty({P}, gpsh::i32(dev));
+    auto count = torch::empty({1}, gpsh::i32(dev));
+    if (!host_count_.defined()) host_count_ = torch::zeros({16}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    auto stream = c10::hip::getCurrentHIPStream();
+    auto cws = torch::empty({gps_compact_mask_workspace_bytes((int)P)}, gpsh::u8(dev));
+    gpsh::check(gps_compact_mask((int)P, reinterpret_cast<const uint8_t*>(mask.data_ptr<bool>()), gpsh::iptr(ids), gpsh::iptr(count),
+                                 host_count_.data_ptr<int32_t>(), cws.data_ptr(), cws.numel(), (gps_stream)stream.stream()),
+                "gps_compact_mask");
+    stream.synchronize();
+    const int64_t n = host_count_.data_ptr<int32_t>()[0];
     const int64_t num_select = (int64_t)(n * new_gs_sample_ratio);
     if (num_select <= 0) return 0;
     // uniformly random subset (the reference: torch::randperm(n)[:num_select]); drawn on the host, n is known here
     // The subset is the reference's; the ORDER is pixel order, not permutation order: Gaussians with neighbouring ids then
     // splat onto neighbouring pixels, which keeps the gradient-image gathers of the Gaussian-parallel backward inside each
     // XCD's L2 (with random ids every XCD sweeps the whole 7 MB image: rocprofv3 FETCH_SIZE 190 MB per launch).
-    auto perm = std::get<0>(torch::randperm(n, gen, torch::TensorOptions().dtype(torch::kInt64)).slice(0, 0, num_select).sort())
-                    .to(verts.device());
-    auto t = RawGaussianParams::make(verts.index_select(0, perm).contiguous(), cols.index_select(0, perm),
-                                     norms.index_select(0, perm), maxSH, defaultOpacities, maxInitScale, minInitScale);
+    auto perm = std::get<0>(torch::randperm(n, gen, torch::TensorOptions().dtype(torch::kInt64)).slice(0, 0, num_select).sort());
+    // pinned staging buffer, allocated once (hipHostMalloc costs milliseconds and synchronises the device); the stream
+    // synchronise above guarantees the previous call's copy out of it has completed
+    if (!host_subset_.defined() || host_subset_.numel() < num_select)
+        host_subset_ = torch::empty({std::max<int64_t>(P, num_select)}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    auto perm32 = host_subset_.slice(0, 0, num_select);
+    perm32.copy_(perm);
+    auto subset = torch::empty({num_select}, gpsh::i32(dev));
+    TORCH_CHECK(hipMemcpyAsync(subset.data_ptr(), perm32.data_ptr(), (size_t)num_select * 4, hipMemcpyHostToDevice, stream.stream()) ==
+                    hipSuccess, "hipMemcpyAsync(subset)");
+    auto verts = torch::empty({num_select, 3}, gpsh::f32(dev)), cols = torch::empty({num_select, 3}, gpsh::f32(dev)),
+         norms = torch::empty({num_select, 3}, gpsh::f32(dev));
+    gpsh::check(gps_gather_pixels((int)num_select, gpsh::iptr(ids), gpsh::iptr(subset), gpsh::fptr(vertex), gpsh::fptr(image),
+                                  gpsh::fptr(normal), gpsh::fptr(verts), gpsh::fptr(cols), gpsh::fptr(norms),
+                                  (gps_stream)stream.stream()), "gps_gather_pixels");
+    auto t = RawGaussianParams::make(verts, cols, norms, maxSH, defaultOpacities, maxInitScale, minInitScale);
     if (!opt_gs_params.buffer(0).defined()) opt_gs_params.reserve(1 << 19, numShBases(maxSH), verts.device());
     opt_gs_params.add(t);
     if (!leaf_.empty()) setParamsRequireGrad();

@@ -121,6 +121,8 @@ protected:
     bool have_opt_ = false;
     std::vector<torch::Tensor> leaf_;  // parameter leaves handed to autograd by the last grad-mode forward
     std::vector<torch::Tensor> keep_;  // inputs of the last launch, kept alive until the next one
+    torch::Tensor host_count_;         // pinned word the mask compaction reports its count in (addGaussians)
+    torch::Tensor host_subset_;        // pinned staging buffer of the sampled subset
 };
 
 class SLAMGaussianModel : public RawGaussianModel {

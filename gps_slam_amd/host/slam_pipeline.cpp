@@ -163,18 +163,22 @@ void SLAMPipeline::initNewGaussiansFor(TensorDict& rm, const Camera& cam) {
     torch::NoGradGuard no_grad;
     const auto &depth = rm.at("depth_map"), &color = rm.at("color_map"), &vertex = rm.at("vertex_map");
     int frame_num = local_opt_interval;
-    auto valid = (depth > depth_vis_min) & (depth < depth_vis_max);
-    valid = valid & ~((vertex.sum(2) == 0).unsqueeze(-1));
-    torch::Tensor mask;
+    // valid = depth in (min, max) & vertex.sum(2) != 0;  mask = mean|src - image| > thres & valid [& alpha < max]: one launch
+    // (gps_new_gaussian_mask) instead of the reference's ~12 tensor ops (:455-480)
+    const int64_t H = cam.image.size(0), W = cam.image.size(1);
+    auto image = cam.image.contiguous(), depth_c = depth.contiguous(), vertex_c = vertex.contiguous();
+    auto mask = torch::empty({H, W, 1}, torch::TensorOptions().dtype(torch::kBool).device(depth.device()));
+    torch::Tensor src = color.contiguous(), alpha;
     if (model->getGaussianNum() == 0) {
-        auto err = torch::mean(torch::abs(color - cam.image), -1, true);
-        mask = (err > color_error_thres) & valid;
         frame_num += 1;
     } else {
         auto res = model->forward(cam, depth, color);
-        auto err = torch::mean(torch::abs(res.at("rgb") - cam.image), -1, true);
-        mask = (err > color_error_thres) & valid & (res.at("alpha") < alpha_vis_max);
+        src = res.at("rgb").contiguous();
+        alpha = res.at("alpha").contiguous();
     }
+    check(gps_new_gaussian_mask((int)W, (int)H, fptr(depth_c), fptr(src), fptr(image), fptr(vertex_c), fptr(alpha), depth_vis_min,
+                                depth_vis_max, color_error_thres, alpha_vis_max, reinterpret_cast<uint8_t*>(mask.data_ptr<bool>()),
+                                current_stream()), "gps_new_gaussian_mask");
     rm["normal_map"] = computeNormalMap(vertex);
     stats.added += model->addGaussians(cam, rm, mask, new_gs_sample_ratio, frame_num, gen_);
 }

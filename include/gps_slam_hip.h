@@ -294,6 +294,28 @@ GPS_API int gps_gauss_preprocess_bwd_adam(int N, int K, int sh_degree, const flo
  * P < 4, as in the reference).  Exact, no scratch memory, no host sync. */
 GPS_API int gps_knn_mean_dist2(int P, const float *points, float *mean_dist2, gps_stream stream);
 
+/* The sample mask of SLAMPipeline::initNewGaussians (slam/slam_pipeline.cpp:450-526) in one launch instead of ~12 tensor ops:
+ *   valid = depth in (depth_vis_min, depth_vis_max) and vertex.sum(-1) != 0
+ *   mask  = mean(|src_rgb - image|, -1) > color_error_thres  and  valid  [and alpha < alpha_vis_max, if alpha != NULL]
+ * src_rgb: what the colour error is measured on -- the raycast colour for an empty model, the render otherwise.  All maps
+ * [H,W,c] float32 device; mask [H,W] bytes (a torch bool tensor).  Float sequence as ATen's (mean = ((a+b)+c) * RN(1/3)). */
+GPS_API int gps_new_gaussian_mask(int width, int height, const float *depth_map, const float *src_rgb, const float *image,
+                                  const float *vertex_map, const float *alpha, float depth_vis_min, float depth_vis_max,
+                                  float color_error_thres, float alpha_vis_max, uint8_t *mask, gps_stream stream);
+
+/* torch::masked_select's selection order (slam/slam_gs_model.cpp:14-19) as indices: ids[0..count) = positions of the
+ * non-zero bytes of mask[0..n) in ascending order; count[0] (device) and, if host_count != NULL (pinned, device-visible
+ * host memory), host_count[0] receive the number.  Two launches over 4096-byte blocks (workspace: one int per block), no host
+ * synchronisation inside. */
+GPS_API int64_t gps_compact_mask_workspace_bytes(int n);
+GPS_API int gps_compact_mask(int n, const uint8_t *mask, int32_t *ids, int32_t *count, int32_t *host_count, void *workspace,
+                             int64_t workspace_bytes, gps_stream stream);
+
+/* Rows ids[subset[j]], j < k, of three [P,3] maps -> three [k,3] arrays (the index_select of the sampled subset,
+ * slam_gs_model.cpp:27-33, without materialising the three masked_select results first). */
+GPS_API int gps_gather_pixels(int k, const int32_t *ids, const int32_t *subset, const float *vertex_map, const float *image,
+                              const float *normal_map, float *verts, float *cols, float *norms, gps_stream stream);
+
 /* replaces computeNormalMap (src/tensor_math.cpp:278-300 + featureGradient :217-248): vertex_map[H,W,3] ->
  * normal_map[H,W,3] (Sobel, replicate padding, cross(dy,dx) normalised, 0 where vertex z <= 0). */
 GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float *normal_map, gps_stream stream);
