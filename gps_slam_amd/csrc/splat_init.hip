@@ -88,7 +88,8 @@ namespace {
 struct SmallFloats { float v[64]; };
 // ---------------------------------------------------------------- new-Gaussian sampling (initNewGaussians / addGaussians)
 // slam_pipeline.cpp:450-526 builds the sample mask with ~12 elementwise / reduce tensor ops; one thread per pixel here, with
-// ATen's float sequence: mean over the 3 channels = ((a + b) + c) * RN(1/3), sum = (x + y) + z.
+// ATen's float sequence on this stack (tools/probe/aten_mean_probe.py: a 3-element reduction runs two accumulators, even and
+// odd elements): sum = (x + z) + y, mean = ((a + c) + b) * RN(1/3).
 __global__ __launch_bounds__(256) void new_gaussian_mask_kernel(int P, const float* __restrict__ depth, const float* __restrict__ src,
                                                                const float* __restrict__ image, const float* __restrict__ vertex,
                                                                const float* __restrict__ alpha, float dmin, float dmax,
@@ -97,11 +98,11 @@ __global__ __launch_bounds__(256) void new_gaussian_mask_kernel(int P, const flo
     if (p >= P) return;
     const float d = depth[p];
     bool valid = (d > dmin) && (d < dmax);
-    const float vs = (vertex[3 * p] + vertex[3 * p + 1]) + vertex[3 * p + 2];
+    const float vs = (vertex[3 * p] + vertex[3 * p + 2]) + vertex[3 * p + 1];
     valid = valid && !(vs == 0.0f);
     const float e0 = fabsf(src[3 * p] - image[3 * p]), e1 = fabsf(src[3 * p + 1] - image[3 * p + 1]),
                 e2 = fabsf(src[3 * p + 2] - image[3 * p + 2]);
-    const float err = ((e0 + e1) + e2) * (1.0f / 3.0f);
+    const float err = ((e0 + e2) + e1) * (1.0f / 3.0f);
     bool m = (err > err_thres) && valid;
     if (alpha) m = m && (alpha[p] < alpha_max);
     mask[p] = m ? 1 : 0;

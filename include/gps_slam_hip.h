@@ -298,7 +298,8 @@ GPS_API int gps_knn_mean_dist2(int P, const float *points, float *mean_dist2, gp
  *   valid = depth in (depth_vis_min, depth_vis_max) and vertex.sum(-1) != 0
  *   mask  = mean(|src_rgb - image|, -1) > color_error_thres  and  valid  [and alpha < alpha_vis_max, if alpha != NULL]
  * src_rgb: what the colour error is measured on -- the raycast colour for an empty model, the render otherwise.  All maps
- * [H,W,c] float32 device; mask [H,W] bytes (a torch bool tensor).  Float sequence as ATen's (mean = ((a+b)+c) * RN(1/3)). */
+ * [H,W,c] float32 device; mask [H,W] bytes (a torch bool tensor).  Float sequence as ATen's 3-element reductions
+ * (sum = (x+z)+y, mean = ((a+c)+b) * RN(1/3)), so that pixels whose error lands on the threshold decide as the tensor ops do. */
 GPS_API int gps_new_gaussian_mask(int width, int height, const float *depth_map, const float *src_rgb, const float *image,
                                   const float *vertex_map, const float *alpha, float depth_vis_min, float depth_vis_max,
                                   float color_error_thres, float alpha_vis_max, uint8_t *mask, gps_stream stream);

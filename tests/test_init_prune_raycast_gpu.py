@@ -307,3 +307,66 @@ def test_remove_redundant_gs_thresholds_order_and_adam_state(which):
         assert torch.equal(a, b[keep])                                            # stable order, every tensor
     for t in got_state:
         assert torch.equal(t.reshape(M, -1)[:, 0], tag[keep] + 0.25)              # Adam rows followed their Gaussians
+
+
+# ------------------------------------------------------------------------------------------------ sampling kernels
+@pytest.mark.parametrize("W,H,with_alpha", [(640, 480, True), (50, 37, False), (1280, 720, True)])
+def test_new_gaussian_mask_compaction_and_gather_match_the_tensor_sequence(W, H, with_alpha):
+    """gps_new_gaussian_mask == the reference's mask expression (slam_pipeline.cpp:455-480) evaluated with torch ops on the
+    GPU (bit for bit: same float sequence); gps_compact_mask == masked_select's row-major order; gps_gather_pixels == the
+    index_select of a subset of those rows (slam_gs_model.cpp:14-33)."""
+    from gps_slam_amd._lib import lib
+    g = torch.Generator(device=DEV).manual_seed(W + H)
+    P = W * H
+    R = lambda *s: torch.rand(*s, device=DEV, generator=g)
+    depth = R(H, W, 1) * 8.0
+    src, image = R(H, W, 3), R(H, W, 3)
+    # values that make the error land ON the threshold for some pixels, and exact zeros in the vertex sum
+    image[::7, ::5] = src[::7, ::5] + 0.1
+    vertex = R(H, W, 3) - 0.5
+    vertex[::3, ::4] = 0.0
+    vertex[1::9, 2::6, 2] = -(vertex[1::9, 2::6, 0] + vertex[1::9, 2::6, 1])
+    alpha = R(H, W, 1) if with_alpha else None
+    dmin, dmax, thr, amax = 0.5, 6.0, 0.1, 0.7
+    valid = (depth > dmin) & (depth < dmax)
+    valid = valid & ~((vertex.sum(2) == 0).unsqueeze(-1))
+    err = torch.mean(torch.abs(src - image), -1, True)
+    ref_mask = (err > thr) & valid
+    if with_alpha:
+        ref_mask = ref_mask & (alpha < amax)
+    mask = torch.empty(H, W, 1, dtype=torch.bool, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.gps_new_gaussian_mask(W, H, depth.data_ptr(), src.data_ptr(), image.data_ptr(), vertex.data_ptr(),
+                                     alpha.data_ptr() if with_alpha else None, dmin, dmax, thr, amax, mask.data_ptr(), st) == 0
+    assert torch.equal(mask, ref_mask)
+    assert 0.05 < ref_mask.float().mean() < 0.95
+
+    ids = torch.full((P,), -1, dtype=torch.int32, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    host_count = torch.zeros(16, dtype=torch.int32).pin_memory()
+    ws = torch.empty(int(lib.gps_compact_mask_workspace_bytes(P)), dtype=torch.uint8, device=DEV)
+    assert lib.gps_compact_mask(P, mask.data_ptr(), ids.data_ptr(), count.data_ptr(), host_count.data_ptr(), ws.data_ptr(),
+                                ws.numel(), st) == 0
+    torch.cuda.synchronize()
+    ref_ids = torch.nonzero(ref_mask.reshape(-1)).squeeze(1).to(torch.int32)
+    n = int(ref_ids.numel())
+    assert int(count) == n and int(host_count[0]) == n
+    assert torch.equal(ids[:n], ref_ids) and bool((ids[n:] == -1).all())
+    # ragged length: not a multiple of the 4096-byte blocks, unaligned start
+    for off, m in ((3, P - 5), (0, 1), (1, 0)):
+        sub = mask.reshape(-1)[off:off + m]
+        cnt2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ids2 = torch.full((max(m, 1),), -1, dtype=torch.int32, device=DEV)
+        assert lib.gps_compact_mask(m, sub.data_ptr(), ids2.data_ptr(), cnt2.data_ptr(), None, ws.data_ptr(), ws.numel(), st) == 0
+        r2 = torch.nonzero(sub).squeeze(1).to(torch.int32)
+        assert int(cnt2) == r2.numel() and torch.equal(ids2[:r2.numel()], r2)
+
+    k = max(1, n // 10)
+    subset = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:k].sort().values.to(torch.int32).to(DEV)
+    normal = R(H, W, 3)
+    outs = [torch.empty(k, 3, device=DEV) for _ in range(3)]
+    assert lib.gps_gather_pixels(k, ids.data_ptr(), subset.data_ptr(), vertex.data_ptr(), image.data_ptr(), normal.data_ptr(),
+                                 outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), st) == 0
+    m3 = ref_mask.expand(H, W, 3)
+    for o, src_map in zip(outs, (vertex, image, normal)):
+        assert torch.equal(o, torch.masked_select(src_map, m3).reshape(-1, 3)[subset.long()])
