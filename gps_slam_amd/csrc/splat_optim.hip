@@ -55,6 +55,23 @@ __global__ __launch_bounds__(256) void compose_l1_kernel(int P, const float4* __
     if (threadIdx.x == 0 && loss != nullptr) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
 }
 
+// torch::optim::Adam's fresh state (zeros_like per parameter) for up to 16 tensors in one launch
+struct ZeroArgs { float* p[16]; int64_t end4[16]; int n; };
+__global__ __launch_bounds__(256) void zero_many_kernel(ZeroArgs a) {
+    const int64_t total4 = a.end4[a.n - 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += stride) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 15; k++) s += (k < a.n - 1 && e >= a.end4[k]) ? 1 : 0;
+        float* base = a.p[0];
+        int64_t first = 0;
+#pragma unroll
+        for (int k = 1; k < 16; k++) if (s == k) { base = a.p[k]; first = a.end4[k - 1]; }   // (static indices: no scratch copy)
+        reinterpret_cast<float4*>(base)[e - first] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 struct AdamArgs {
     gps_adam_segment seg[GPS_ADAM_MAX_SEGMENTS];
     float step_size[GPS_ADAM_MAX_SEGMENTS];  // lr / (1 - b1^t), computed in double on the host like libtorch
@@ -120,6 +137,26 @@ int gps_compose_l1(int width, int height, const float* render_colors, const floa
                                                                     base_color, ref_depth_raw, gt_rgb, rgb, depth,
                                                                     loss, (float4*)v_render_colors, v_render_alphas,
                                                                     1.0f / (3.0f * (float)P));
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_zero_floats(int n, float* const* ptrs, const int64_t* numels, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(n >= 1 && n <= 16 && ptrs && numels);
+    ZeroArgs a = {};
+    int64_t run = 0;
+    for (int k = 0; k < n; k++) {
+        // float4 stores: 16-byte aligned buffers whose length is a multiple of 4 floats (or padded to one by the owner)
+        GPS_REQUIRE(numels[k] >= 0 && (numels[k] == 0 || ptrs[k]) && (((uintptr_t)ptrs[k]) & 15) == 0 && (numels[k] & 3) == 0);
+        a.p[k] = ptrs[k];
+        run += numels[k] / 4;
+        a.end4[k] = run;
+    }
+    for (int k = n; k < 16; k++) { a.p[k] = ptrs[0]; a.end4[k] = run; }
+    a.n = n;
+    if (run == 0) return GPS_OK;
+    zero_many_kernel<<<(int)min((int64_t)4096, (int64_t)gps_div_up(run, 256)), 256, 0, (hipStream_t)stream>>>(a);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

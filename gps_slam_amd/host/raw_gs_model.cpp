@@ -350,9 +350,20 @@ void RawGaussianModel::initOptimizers(int max_iterations, float scene_scale) {
         }
         adam_cap_ = cap;
     } else {
+        // fresh state for the live rows: one launch for the 12 tensors (lengths rounded up to whole float4s inside the
+        // capacity-sized buffers)
         const int64_t N = getGaussianNum();
-        for (int k = 0; k < 6; k++) { adam_m_[k].slice(0, 0, N).zero_(); adam_v_[k].slice(0, 0, N).zero_(); }
+        float* ptrs[12];
+        int64_t numels[12];
+        for (int k = 0; k < 6; k++) {
+            const int64_t row = adam_m_[k].numel() / std::max<int64_t>(1, adam_m_[k].size(0));
+            const int64_t n = std::min<int64_t>(adam_m_[k].numel(), (N * row + 3) / 4 * 4);
+            ptrs[2 * k] = fptr(adam_m_[k]); ptrs[2 * k + 1] = fptr(adam_v_[k]);
+            numels[2 * k] = numels[2 * k + 1] = n;
+        }
+        if (N > 0) check(gps_zero_floats(12, ptrs, numels, current_stream()), "gps_zero_floats");
     }
+    pending_prunes_.clear();  // the state those would have compacted has just been replaced
     lrs_[0] = means_lr * scene_scale; lrs_[1] = scales_lr; lrs_[2] = quats_lr; lrs_[3] = featuresDc_lr;
     lrs_[4] = featuresRest_lr; lrs_[5] = opacities_lr;
     adam_step_ = 0;
@@ -376,6 +387,7 @@ void RawGaussianModel::optimizersZeroGrad() {
 void RawGaussianModel::optimizersStep() {
     // the autograd route: gradients sit in the leaves' .grad(); one fused multi-tensor Adam launch
     TORCH_CHECK(have_opt_, "initOptimizers() first");
+    applyPendingPrunes();
     gps_adam_segment seg[6];
     const int64_t N = getGaussianNum();
     std::vector<torch::Tensor> hold;
@@ -396,6 +408,7 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
                                  const torch::Tensor& ref_depth_clamped) {
     TORCH_CHECK(have_opt_ && adam_cap_ == opt_gs_params.capacity(), "initOptimizers() first");
     TORCH_CHECK(cam.image.defined() && cam.image.is_cuda(), "camera image must be on the device");
+    applyPendingPrunes();
     auto clamped = ref_depth_clamped.defined() ? ref_depth_clamped : clampRefDepth(ref_depth);
     gps_splat_step& st = stepStruct(cam.width, cam.height);
     bindCamera(st, cam, clamped, base_color, cam.image);
@@ -417,17 +430,29 @@ void RawGaussianModel::prunePoints(const torch::Tensor& deleteMask) {
     p.remove(deleteMask);
     auto keep = p.keep_index();
     const int64_t m = keep.size(0);
-    if (have_opt_ && adam_cap_ == p.capacity()) {
+    (void)m;
+    // removeFromOptimizer (raw_gs_model.cpp:640-644): the Adam state follows the parameters -- LAZILY.  The pipeline builds
+    // fresh optimizers before the next step (initOptimizers at every localOptimize), which makes compacting 2 x 59 floats per
+    // Gaussian here dead work; the compaction is recorded and carried out only if a step / state read comes first.
+    if (have_opt_ && adam_cap_ == p.capacity()) pending_prunes_.push_back({keep, N});
+    if (!leaf_.empty()) setParamsRequireGrad();
+}
+
+void RawGaussianModel::applyPendingPrunes() {
+    if (pending_prunes_.empty()) return;
+    RawGaussianParams& p = opt_gs_params;
+    for (auto& pr : pending_prunes_) {
+        const int64_t m = pr.keep.size(0);
         for (int k = 0; k < 6; k++) {
             for (auto* vec : {&adam_m_, &adam_v_}) {
                 auto& t = (*vec)[k];
-                auto tmp = p.alt_[k].slice(0, 0, m);  // the alternate parameter buffer is free scratch right now
-                torch::index_select_out(tmp, t.slice(0, 0, N), 0, keep);
+                auto tmp = p.alt_[k].slice(0, 0, m);  // the alternate parameter buffer is free scratch between remove() calls
+                torch::index_select_out(tmp, t.slice(0, 0, pr.n_before), 0, pr.keep);
                 t.slice(0, 0, m).copy_(tmp);
             }
         }
     }
-    if (!leaf_.empty()) setParamsRequireGrad();
+    pending_prunes_.clear();
 }
 
 // ------------------------------------------------------------------------------------------------ addGaussians

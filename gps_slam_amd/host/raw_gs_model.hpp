@@ -66,6 +66,7 @@ public:
     std::vector<torch::Tensor> adamState() {
         std::vector<torch::Tensor> out;
         if (!have_opt_) return out;
+        applyPendingPrunes();
         const int64_t N = opt_gs_params.getGaussianNum();
         for (auto* vec : {&adam_m_, &adam_v_}) for (auto& t : *vec) out.push_back(t.slice(0, 0, N));
         return out;
@@ -121,6 +122,9 @@ protected:
     bool have_opt_ = false;
     std::vector<torch::Tensor> leaf_;  // parameter leaves handed to autograd by the last grad-mode forward
     std::vector<torch::Tensor> keep_;  // inputs of the last launch, kept alive until the next one
+    struct PendingPrune { torch::Tensor keep; int64_t n_before; };
+    std::vector<PendingPrune> pending_prunes_;  // prunePoints' Adam-state compactions not carried out yet
+    void applyPendingPrunes();
     torch::Tensor host_count_;         // pinned word the mask compaction reports its count in (addGaussians)
     torch::Tensor host_subset_;        // pinned staging buffer of the sampled subset
 };

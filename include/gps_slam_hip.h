@@ -231,6 +231,11 @@ typedef struct {
     double lr; /* libtorch keeps lr/betas/eps as double and rounds once per use */
 } gps_adam_segment;
 
+/* Zero-fills n (<= 16) float buffers in one launch -- a fresh torch::optim::Adam's exp_avg / exp_avg_sq for every parameter
+ * (raw_gs_model.cpp:654-675 builds new optimizers at every localOptimize).  ptrs / numels are HOST arrays; each buffer is
+ * 16-byte aligned and numels[k] is a multiple of 4 (round the length up inside a capacity-sized buffer). */
+GPS_API int gps_zero_floats(int n, float *const *ptrs, const int64_t *numels, gps_stream stream);
+
 /* One optimiser step over up to 8 parameter tensors, bit-compatible update order with libtorch's
  * torch::optim::Adam (raw_gs_model.cpp:654-705; eps 1e-15, betas (0.9,0.999), no weight decay):
  *   m = m*b1 + g*(1-b1); v = v*b2 + g*g*(1-b2);
