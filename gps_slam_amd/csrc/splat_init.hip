@@ -195,6 +195,48 @@ __global__ __launch_bounds__(256) void gather_pixels_kernel(int k, const int32_t
     }
 }
 
+// RawGaussianParams::init (src/raw_gs_param.cpp:11-74) for k new Gaussians in one launch: KNN scale (clamped, z x 0.1 when a
+// normal is given), normal -> quaternion (computeQuat / quaternionFromAxisAngle, src/tensor_math.cpp:184-201), colour -> SH
+// DC, zero higher bands, logit(opacity).  Written straight into the rows the caller points at (the tail of the model's
+// capacity buffers), in the reference's float sequence (3-element reductions as ATen runs them: (x0 + x2) + x1).
+__global__ __launch_bounds__(256) void init_gaussians_kernel(int k, const float* __restrict__ xyz, const float* __restrict__ rgb,
+                                                            const float* __restrict__ normals, const float* __restrict__ knn,
+                                                            int K, float init_opac, float max_scale, float min_scale,
+                                                            float* __restrict__ means, float* __restrict__ log_scales,
+                                                            float* __restrict__ quats, float* __restrict__ sh_dc,
+                                                            float* __restrict__ sh_rest, float* __restrict__ opac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    means[3 * i] = xyz[3 * i]; means[3 * i + 1] = xyz[3 * i + 1]; means[3 * i + 2] = xyz[3 * i + 2];
+    const float raw = fminf(fmaxf(sqrtf(knn[i]), min_scale), max_scale);  // torch::clamp(sqrt(distCUDA2), min, max)
+    float q0 = 1.0f, q1 = 1.0f, q2 = 1.0f, q3 = 1.0f;                       // torch::ones without normals
+    float sz = raw;
+    if (normals) {
+        sz = raw * 0.1f;
+        const float nx = normals[3 * i], ny = normals[3 * i + 1], nz = normals[3 * i + 2];
+        // axis = cross((0,0,1), n); axis / (|axis| + 1e-8), twice; angle = acos(dot((0,0,1), n))
+        float ax = 0.0f * nz - 1.0f * ny, ay = 1.0f * nx - 0.0f * nz, az = 0.0f * ny - 0.0f * nx;
+        float nrm = sqrtf((ax * ax + az * az) + ay * ay) + 1e-8f;
+        ax = ax / nrm; ay = ay / nrm; az = az / nrm;
+        const float angle = acosf((0.0f * nx + 1.0f * nz) + 0.0f * ny);
+        nrm = sqrtf((ax * ax + az * az) + ay * ay) + 1e-8f;
+        ax = ax / nrm; ay = ay / nrm; az = az / nrm;
+        const float half = angle * 0.5f;
+        const float sn = sinf(half);
+        q0 = cosf(half); q1 = ax * sn; q2 = ay * sn; q3 = az * sn;
+    }
+    log_scales[3 * i] = logf(raw); log_scales[3 * i + 1] = logf(raw); log_scales[3 * i + 2] = logf(sz);
+    *reinterpret_cast<float4*>(quats + 4 * (size_t)i) = make_float4(q0, q1, q2, q3);
+    // (rgb - 0.5) / SH_C0 with a host scalar: ATen multiplies by the reciprocal, taken in DOUBLE and then rounded
+    // (tools/probe/aten_div_probe.py: f32(1 / C0) = 3.5449078, not 1 / f32(C0) = 3.5449076)
+    const float inv_c0 = (float)(1.0 / 0.28209479177387814);
+    sh_dc[3 * i] = (rgb[3 * i] - 0.5f) * inv_c0; sh_dc[3 * i + 1] = (rgb[3 * i + 1] - 0.5f) * inv_c0;
+    sh_dc[3 * i + 2] = (rgb[3 * i + 2] - 0.5f) * inv_c0;
+    float* r = sh_rest + (size_t)i * (K - 1) * 3;
+    for (int c = 0; c < (K - 1) * 3; c++) r[c] = 0.0f;
+    opac[i] = logf(init_opac / (1.0f - init_opac));  // torch::logit
+}
+
 __global__ __launch_bounds__(64) void upload_floats_kernel(SmallFloats v, int n, float* __restrict__ dst) {
     if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
 }
@@ -258,6 +300,21 @@ int gps_gather_pixels(int k, const int32_t* ids, const int32_t* subset, const fl
     GPS_REQUIRE(ids && subset && vertex_map && image && normal_map && verts && cols && norms);
     gather_pixels_kernel<<<gps_div_up(k, 256), 256, 0, (hipStream_t)stream>>>(k, ids, subset, vertex_map, image, normal_map, verts,
                                                                              cols, norms);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_init_gaussians(int k, const float* xyz, const float* rgb, const float* normals, const float* knn_mean_dist2, int K,
+                       float init_opacity, float max_scale, float min_scale, float* means, float* log_scales, float* quats,
+                       float* sh_dc, float* sh_rest, float* opac_logit, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(k >= 0 && K >= 1);
+    if (k == 0) return GPS_OK;
+    GPS_REQUIRE(xyz && rgb && knn_mean_dist2 && means && log_scales && quats && sh_dc && opac_logit && (K == 1 || sh_rest));
+    GPS_REQUIRE((((uintptr_t)quats) & 15) == 0);
+    init_gaussians_kernel<<<gps_div_up(k, 256), 256, 0, (hipStream_t)stream>>>(k, xyz, rgb, normals, knn_mean_dist2, K, init_opacity,
+                                                                              max_scale, min_scale, means, log_scales, quats,
+                                                                              sh_dc, sh_rest, opac_logit);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -500,9 +500,8 @@ int SLAMGaussianModel::addGaussians(const Camera& cam, const TensorDict& frame_m
     gpsh::check(gps_gather_pixels((int)num_select, gpsh::iptr(ids), gpsh::iptr(subset), gpsh::fptr(vertex), gpsh::fptr(image),
                                   gpsh::fptr(normal), gpsh::fptr(verts), gpsh::fptr(cols), gpsh::fptr(norms),
                                   (gps_stream)stream.stream()), "gps_gather_pixels");
-    auto t = RawGaussianParams::make(verts, cols, norms, maxSH, defaultOpacities, maxInitScale, minInitScale);
     if (!opt_gs_params.buffer(0).defined()) opt_gs_params.reserve(1 << 19, numShBases(maxSH), verts.device());
-    opt_gs_params.add(t);
+    opt_gs_params.appendInit(verts, cols, norms, maxSH, defaultOpacities, maxInitScale, minInitScale);
     if (!leaf_.empty()) setParamsRequireGrad();
     return (int)num_select;
 }

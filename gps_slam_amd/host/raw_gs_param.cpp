@@ -48,39 +48,53 @@ void Camera::toGPU(const torch::Device& device) {
 namespace {
 
 // tensor_math.cpp:184-201 computeQuat + quaternionFromAxisAngle
-torch::Tensor compute_quat(const torch::Tensor& init_vec, const torch::Tensor& target_vec) {
-    auto axis = torch::cross(init_vec, target_vec, 1);
-    axis = axis / (torch::norm(axis, 2, {-1}, true) + 1e-8);
-    auto angle = torch::acos(torch::sum(init_vec * target_vec, 1)).unsqueeze(-1);
-    auto naxis = axis / (torch::norm(axis, 2, {-1}, true) + 1e-8);
-    auto half = angle / 2;
-    return torch::cat({torch::cos(half), naxis * torch::sin(half)}, 1);
-}
-
 const int64_t TAIL[RawGaussianParams::NUM][2] = {{3, 0}, {3, 0}, {4, 0}, {3, 0}, {15, 3}, {1, 0}};
 
 }  // namespace
 
+namespace {
+// gps_init_gaussians on k points into the rows the six pointers name
+void init_rows(const torch::Tensor& xyz, const torch::Tensor& rgb, const torch::Tensor& normals, int K, float init_opacs,
+               float max_scale, float min_scale, float* const out[6]) {
+    const int64_t P = xyz.size(0);
+    auto x = xyz.contiguous(), c = rgb.contiguous();
+    auto n = normals.defined() ? normals.contiguous() : torch::Tensor();
+    check_f32_dev(x, "xyz"); check_f32_dev(c, "rgb");
+    auto knn = distCUDA2(x);
+    check(gps_init_gaussians((int)P, fptr(x), fptr(c), fptr(n), fptr(knn), K, init_opacs, max_scale, min_scale, out[0], out[1],
+                             out[2], out[3], out[4], out[5], current_stream()), "gps_init_gaussians");
+}
+}  // namespace
+
+// One launch (gps_init_gaussians) + the KNN kernel instead of the reference's ~35 tensor ops (raw_gs_param.cpp:24-62); the
+// op-for-op torch sequence this replaces is what tests/test_init_prune_raycast_gpu.py::_ref_init restates.
 std::vector<torch::Tensor> RawGaussianParams::make(const torch::Tensor& xyz, const torch::Tensor& rgb,
                                                    const torch::Tensor& normals, int max_sh_degree, float init_opacs,
                                                    float max_scale, float min_scale) {
     const int64_t P = xyz.size(0);
     const auto opt = xyz.options();
-    auto raw_scales = torch::sqrt(distCUDA2(xyz));
-    raw_scales = torch::clamp(raw_scales, min_scale, max_scale).unsqueeze(1).repeat({1, 3});
-    auto quats = torch::ones({P, 4}, opt);
-    if (normals.defined()) {
-        raw_scales.index_put_({Slice(), 2}, raw_scales.index({Slice(), 2}) * 0.1);
-        auto z_axis = torch::zeros_like(raw_scales);
-        z_axis.index_put_({Slice(), 2}, 1.0);
-        quats = compute_quat(z_axis, normals);
-    }
     const int K = numShBases(max_sh_degree);
-    auto shs = torch::zeros({P, K, 3}, opt);
-    shs.index_put_({Slice(), 0, Slice(0, 3)}, rgb2sh(rgb));
-    auto opac = torch::logit(init_opacs * torch::ones({P, 1}, opt));
-    return {xyz, raw_scales.log(), quats, shs.index({Slice(), 0, Slice()}).contiguous(),
-            shs.index({Slice(), Slice(1, K), Slice()}).contiguous(), opac};
+    std::vector<torch::Tensor> t = {torch::empty({P, 3}, opt), torch::empty({P, 3}, opt), torch::empty({P, 4}, opt),
+                                    torch::empty({P, 3}, opt), torch::empty({P, K - 1, 3}, opt), torch::empty({P, 1}, opt)};
+    float* out[6];
+    for (int k = 0; k < 6; k++) out[k] = fptr(t[k]);
+    if (P > 0) init_rows(xyz, rgb, normals, K, init_opacs, max_scale, min_scale, out);
+    return t;
+}
+
+// init() of `xyz.size(0)` new Gaussians written straight behind the existing ones (make() + add() without the six copies)
+void RawGaussianParams::appendInit(const torch::Tensor& xyz, const torch::Tensor& rgb, const torch::Tensor& normals,
+                                   int max_sh_degree, float init_opacs, float max_scale, float min_scale) {
+    const int64_t n = xyz.size(0);
+    const int K = numShBases(max_sh_degree);
+    if (!buf_[0].defined() || N_ + n > cap_ || K != K_)
+        reserve(std::max<int64_t>(2 * cap_, std::max<int64_t>(1 << 19, N_ + n)), K, xyz.device());
+    if (n == 0) return;
+    float* out[6];
+    for (int k = 0; k < 6; k++) out[k] = fptr(buf_[k]) + N_ * (buf_[k].numel() / buf_[k].size(0));
+    // quats rows are 16 bytes: any row offset keeps the float4 store aligned
+    init_rows(xyz, rgb, normals, K, init_opacs, max_scale, min_scale, out);
+    N_ += n;
 }
 
 void RawGaussianParams::reserve(int64_t capacity, int sh_k, const torch::Device& device) {

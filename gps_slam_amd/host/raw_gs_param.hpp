@@ -59,6 +59,9 @@ public:
     bool isDefined() const { return N_ > 0; }
     int getGaussianNum() const { return (int)N_; }
     void reserve(int64_t capacity, int sh_k, const torch::Device& device);
+    // make() + add() in place: the new rows are initialised directly behind the existing ones
+    void appendInit(const torch::Tensor& xyz, const torch::Tensor& rgb, const torch::Tensor& normals, int max_sh_degree,
+                    float init_opacs, float max_scale = -1, float min_scale = -1);
     void add(const RawGaussianParams& other);            // raw_gs_param.cpp:123-145
     void add(const std::vector<torch::Tensor>& tensors);  // same, from loose tensors (NUM entries, reference order)
     void remove(const torch::Tensor& mask);               // raw_gs_param.cpp:148-157: mask = rows to delete

@@ -322,6 +322,16 @@ GPS_API int gps_compact_mask(int n, const uint8_t *mask, int32_t *ids, int32_t *
 GPS_API int gps_gather_pixels(int k, const int32_t *ids, const int32_t *subset, const float *vertex_map, const float *image,
                               const float *normal_map, float *verts, float *cols, float *norms, gps_stream stream);
 
+/* RawGaussianParams::init (src/raw_gs_param.cpp:11-74) for k points in one launch instead of ~35 tensor ops: from points,
+ * colours, optional normals (NULL: identity-like quaternion of ones, isotropic scale) and the KNN mean squared distances
+ * (gps_knn_mean_dist2) to the six parameter tensors, written to the rows the output pointers name (e.g. the tail of
+ * capacity-sized buffers): means[k,3], log_scales[k,3] = log(clamp(sqrt(knn), min_scale, max_scale)) (z x 0.1 with normals),
+ * quats[k,4] = rotation of (0,0,1) onto the normal (tensor_math.cpp:184-201), sh_dc[k,3] = (rgb - 0.5) / C0,
+ * sh_rest[k,K-1,3] = 0, opac_logit[k] = logit(init_opacity). */
+GPS_API int gps_init_gaussians(int k, const float *xyz, const float *rgb, const float *normals, const float *knn_mean_dist2,
+                               int K, float init_opacity, float max_scale, float min_scale, float *means, float *log_scales,
+                               float *quats, float *sh_dc, float *sh_rest, float *opac_logit, gps_stream stream);
+
 /* replaces computeNormalMap (src/tensor_math.cpp:278-300 + featureGradient :217-248): vertex_map[H,W,3] ->
  * normal_map[H,W,3] (Sobel, replicate padding, cross(dy,dx) normalised, 0 where vertex z <= 0). */
 GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float *normal_map, gps_stream stream);
