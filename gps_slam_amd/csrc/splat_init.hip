@@ -237,6 +237,39 @@ __global__ __launch_bounds__(256) void init_gaussians_kernel(int k, const float*
     opac[i] = logf(init_opac / (1.0f - init_opac));  // torch::logit
 }
 
+// removeRedundantGs' delete mask (slam/slam_pipeline.cpp:564-586): max real scale < small or > large, or real opacity < low;
+// keep = !delete.  exp / sigmoid as the tensor ops evaluate them (expf; 1 / (1 + expf(-x))).
+__global__ __launch_bounds__(256) void prune_mask_kernel(int N, const float* __restrict__ log_scales, const float* __restrict__ opac_logit,
+                                                        float small_thres, float large_thres, float low_opac,
+                                                        uint8_t* __restrict__ del, uint8_t* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float s0 = expf(log_scales[3 * i]), s1 = expf(log_scales[3 * i + 1]), s2 = expf(log_scales[3 * i + 2]);
+    const float smax = fmaxf(fmaxf(s0, s1), s2);
+    const float op = 1.0f / (1.0f + expf(-opac_logit[i]));
+    const bool d = (smax < small_thres) || (smax > large_thres) || (op < low_opac);
+    del[i] = d ? 1 : 0;
+    keep[i] = d ? 0 : 1;
+}
+
+// index_select of rows ids[0..m) for up to 8 row-major float tensors in one launch (prunePoints: the six parameter tensors)
+struct GatherArgs { const float* src[8]; float* dst[8]; int row[8]; int64_t end[8]; int n; };
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a, const int32_t* __restrict__ ids) {
+    const int64_t total = a.end[a.n - 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += (k < a.n - 1 && e >= a.end[k]) ? 1 : 0;
+        const float* src = a.src[0]; float* dst = a.dst[0]; int row = a.row[0]; int64_t first = 0;
+#pragma unroll
+        for (int k = 1; k < 8; k++) if (s == k) { src = a.src[k]; dst = a.dst[k]; row = a.row[k]; first = a.end[k - 1]; }
+        const int64_t le = e - first;
+        const int r = (int)(le / row), c = (int)(le - (int64_t)r * row);
+        dst[le] = src[(int64_t)ids[r] * row + c];
+    }
+}
+
 __global__ __launch_bounds__(64) void upload_floats_kernel(SmallFloats v, int n, float* __restrict__ dst) {
     if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
 }
@@ -315,6 +348,39 @@ int gps_init_gaussians(int k, const float* xyz, const float* rgb, const float* n
     init_gaussians_kernel<<<gps_div_up(k, 256), 256, 0, (hipStream_t)stream>>>(k, xyz, rgb, normals, knn_mean_dist2, K, init_opacity,
                                                                               max_scale, min_scale, means, log_scales, quats,
                                                                               sh_dc, sh_rest, opac_logit);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_prune_mask(int N, const float* log_scales, const float* opac_logit, float small_scale_thres, float large_scale_thres,
+                   float low_opac_thres, uint8_t* delete_mask, uint8_t* keep_mask, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(log_scales && opac_logit && delete_mask && keep_mask);
+    prune_mask_kernel<<<gps_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(N, log_scales, opac_logit, small_scale_thres,
+                                                                          large_scale_thres, low_opac_thres, delete_mask, keep_mask);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_gather_rows(int m, const int32_t* ids, int n_tensors, const float* const* srcs, float* const* dsts, const int32_t* row_floats,
+                    gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(m >= 0 && n_tensors >= 1 && n_tensors <= 8 && srcs && dsts && row_floats);
+    if (m == 0) return GPS_OK;
+    GPS_REQUIRE(ids != nullptr);
+    GatherArgs a = {};
+    int64_t run = 0;
+    for (int k = 0; k < n_tensors; k++) {
+        GPS_REQUIRE(srcs[k] && dsts[k] && row_floats[k] >= 1);
+        a.src[k] = srcs[k]; a.dst[k] = dsts[k]; a.row[k] = row_floats[k];
+        run += (int64_t)m * row_floats[k];
+        a.end[k] = run;
+    }
+    for (int k = n_tensors; k < 8; k++) { a.src[k] = srcs[0]; a.dst[k] = dsts[0]; a.row[k] = 1; a.end[k] = run; }
+    a.n = n_tensors;
+    gather_rows_kernel<<<(int)min((int64_t)8192, (int64_t)gps_div_up(run, 256)), 256, 0, (hipStream_t)stream>>>(a, ids);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -424,18 +424,18 @@ std::vector<torch::Tensor> RawGaussianModel::grads() {
     return out;
 }
 
-void RawGaussianModel::prunePoints(const torch::Tensor& deleteMask) {
+void RawGaussianModel::prunePoints(const torch::Tensor& deleteMask) { pruneKeep(~deleteMask); }
+
+int64_t RawGaussianModel::pruneKeep(const torch::Tensor& keepMask) {
     RawGaussianParams& p = opt_gs_params;
     const int64_t N = p.getGaussianNum();
-    p.remove(deleteMask);
-    auto keep = p.keep_index();
-    const int64_t m = keep.size(0);
-    (void)m;
+    const int64_t m = p.removeKeep(keepMask);
     // removeFromOptimizer (raw_gs_model.cpp:640-644): the Adam state follows the parameters -- LAZILY.  The pipeline builds
     // fresh optimizers before the next step (initOptimizers at every localOptimize), which makes compacting 2 x 59 floats per
     // Gaussian here dead work; the compaction is recorded and carried out only if a step / state read comes first.
-    if (have_opt_ && adam_cap_ == p.capacity()) pending_prunes_.push_back({keep, N});
+    if (m != N && have_opt_ && adam_cap_ == p.capacity()) pending_prunes_.push_back({p.keep_index(), N});
     if (!leaf_.empty()) setParamsRequireGrad();
+    return m;
 }
 
 void RawGaussianModel::applyPendingPrunes() {

@@ -46,6 +46,7 @@ public:
     void optimizersZeroGrad();
     void optimizersStep();
     void prunePoints(const torch::Tensor& deleteMask);  // raw_gs_model.cpp:635-644 (+ removeFromOptimizer)
+    int64_t pruneKeep(const torch::Tensor& keepMask);   // prunePoints(~keepMask); returns the number of Gaussians kept
     void setParamsRequireGrad();
 
     RawGaussianParams& getGaussianParms() { return opt_gs_params; }

@@ -139,15 +139,40 @@ void RawGaussianParams::add(const RawGaussianParams& other) {
     add(t);
 }
 
-void RawGaussianParams::remove(const torch::Tensor& mask) {
-    keep_idx_ = torch::nonzero(~mask).squeeze(1);
-    const int64_t m = keep_idx_.size(0);
+void RawGaussianParams::remove(const torch::Tensor& mask) { removeKeep(~mask); }
+
+// Keeps the rows whose byte in keep_mask is set: ordered compaction of the mask into row ids (gps_compact_mask: nonzero()
+// without its launches), one read of their number, ONE gather launch for the six tensors into the alternate buffers.
+int64_t RawGaussianParams::removeKeep(const torch::Tensor& keep_mask) {
+    TORCH_CHECK(keep_mask.scalar_type() == torch::kBool && keep_mask.numel() == N_, "keep mask: bool [N]");
+    auto km = keep_mask.contiguous();
+    const auto dev = buf_[0].device();
+    auto ids = torch::empty({std::max<int64_t>(N_, 1)}, i32(dev));
+    auto count = torch::empty({1}, i32(dev));
+    if (!host_count_.defined()) host_count_ = torch::zeros({16}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    auto ws = torch::empty({gps_compact_mask_workspace_bytes((int)N_)}, u8(dev));
+    auto stream = c10::hip::getCurrentHIPStream();
+    check(gps_compact_mask((int)N_, reinterpret_cast<const uint8_t*>(km.data_ptr<bool>()), iptr(ids), iptr(count),
+                           host_count_.data_ptr<int32_t>(), ws.data_ptr(), ws.numel(), (gps_stream)stream.stream()), "gps_compact_mask");
+    stream.synchronize();
+    const int64_t m = host_count_.data_ptr<int32_t>()[0];
+    keep_ids32_ = ids.slice(0, 0, m);
+    keep_idx_ = torch::Tensor();  // int64 copy made on demand (keep_index())
+    if (m == N_) return m;
+    const float* srcs[NUM]; float* dsts[NUM]; int32_t rows[NUM];
     for (int k = 0; k < NUM; k++) {
-        auto dst = alt_[k].slice(0, 0, m);
-        torch::index_select_out(dst, buf_[k].slice(0, 0, N_), 0, keep_idx_);
-        std::swap(buf_[k], alt_[k]);
+        srcs[k] = fptr(buf_[k]); dsts[k] = fptr(alt_[k]);
+        rows[k] = (int32_t)(buf_[k].numel() / buf_[k].size(0));
     }
+    check(gps_gather_rows((int)m, iptr(ids), NUM, srcs, dsts, rows, (gps_stream)stream.stream()), "gps_gather_rows");
+    for (int k = 0; k < NUM; k++) std::swap(buf_[k], alt_[k]);
     N_ = m;
+    return m;
+}
+
+torch::Tensor RawGaussianParams::keep_index() const {
+    if (!keep_idx_.defined() && keep_ids32_.defined()) keep_idx_ = keep_ids32_.to(torch::kInt64);
+    return keep_idx_;
 }
 
 // ------------------------------------------------------------------------------------------------ persistence

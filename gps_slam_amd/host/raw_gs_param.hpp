@@ -87,12 +87,15 @@ public:
     int64_t capacity() const { return cap_; }
     int shK() const { return K_; }
     torch::Tensor buffer(int k) const { return buf_[k]; }  // capacity-sized storage of tensor k
-    torch::Tensor keep_index() const { return keep_idx_; } // indices kept by the last remove()
+    torch::Tensor keep_index() const;                      // int64 indices kept by the last remove()
+    int64_t removeKeep(const torch::Tensor& keep_mask);    // remove(~keep_mask); returns the number of rows kept
 
 protected:
     torch::Tensor view(int k) const { return buf_[k].defined() ? buf_[k].slice(0, 0, N_) : torch::Tensor(); }
     torch::Tensor buf_[NUM], alt_[NUM];
-    torch::Tensor exposure, keep_idx_;
+    torch::Tensor exposure;
+    mutable torch::Tensor keep_idx_;
+    torch::Tensor keep_ids32_, host_count_;
     int64_t N_ = 0, cap_ = 0;
     int K_ = 16;
     torch::Device device_ = torch::kCUDA;

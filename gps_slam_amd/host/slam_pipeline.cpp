@@ -223,17 +223,20 @@ void SLAMPipeline::optimizeIterations(int count) {
 void SLAMPipeline::removeRedundantGs() {
     torch::NoGradGuard no_grad;
     if (model->getGaussianNum() == 0) return;
-    auto smax = std::get<0>(model->getRealScales().max(-1));
-    auto mask = (smax < small_scale_thres) | (smax > large_scale_thres) |
-                (model->getRealOpacities().squeeze(-1) < low_opac_thres);
-    const int64_t n = mask.sum().item<int64_t>();  // the reference syncs 5 times here for its printf; once is enough
+    // delete = max real scale < small or > large, or real opacity < low (:566-575): one launch; the compaction of the keep
+    // mask synchronises with the map stream once (the reference syncs 5 times here for its printf)
+    const int64_t N = model->getGaussianNum();
+    const auto dev = model->getMeans().device();
+    auto del = torch::empty({N}, torch::TensorOptions().dtype(torch::kBool).device(dev));
+    auto keep = torch::empty({N}, torch::TensorOptions().dtype(torch::kBool).device(dev));
+    check(gps_prune_mask((int)N, fptr(model->getScales()), fptr(model->getOpacities()), small_scale_thres, large_scale_thres,
+                         low_opac_thres, reinterpret_cast<uint8_t*>(del.data_ptr<bool>()),
+                         reinterpret_cast<uint8_t*>(keep.data_ptr<bool>()), current_stream()), "gps_prune_mask");
+    const int64_t kept = model->pruneKeep(keep);
     // the host is synchronised with the map stream right here: look at the capacity flags the kernels cannot raise as exceptions
     model->checkBinningCapacity();
     main_engine->checkRenderingBlocks();
-    if (n > 0) {
-        model->prunePoints(mask);
-        stats.pruned += n;
-    }
+    stats.pruned += N - kept;
 }
 
 // ------------------------------------------------------------------ renderEvalImgs :588-695 (tensors instead of image files)

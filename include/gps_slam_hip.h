@@ -332,6 +332,18 @@ GPS_API int gps_init_gaussians(int k, const float *xyz, const float *rgb, const 
                                int K, float init_opacity, float max_scale, float min_scale, float *means, float *log_scales,
                                float *quats, float *sh_dc, float *sh_rest, float *opac_logit, gps_stream stream);
 
+/* The delete mask of SLAMPipeline::removeRedundantGs (slam/slam_pipeline.cpp:564-586) in one launch:
+ * delete = max(exp(log_scales)) < small or > large, or sigmoid(opac_logit) < low_opac; keep = !delete (both [N] bytes). */
+GPS_API int gps_prune_mask(int N, const float *log_scales, const float *opac_logit, float small_scale_thres,
+                           float large_scale_thres, float low_opac_thres, uint8_t *delete_mask, uint8_t *keep_mask,
+                           gps_stream stream);
+
+/* prunePoints' index_select (src/raw_gs_model.cpp:635-644) for up to 8 row-major float tensors in ONE launch:
+ * dsts[t][j, :] = srcs[t][ids[j], :], j < m, rows of row_floats[t] floats.  srcs / dsts / row_floats are HOST arrays;
+ * dsts must not alias srcs. */
+GPS_API int gps_gather_rows(int m, const int32_t *ids, int n_tensors, const float *const *srcs, float *const *dsts,
+                            const int32_t *row_floats, gps_stream stream);
+
 /* replaces computeNormalMap (src/tensor_math.cpp:278-300 + featureGradient :217-248): vertex_map[H,W,3] ->
  * normal_map[H,W,3] (Sobel, replicate padding, cross(dy,dx) normalised, 0 where vertex z <= 0). */
 GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float *normal_map, gps_stream stream);

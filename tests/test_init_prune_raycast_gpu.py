@@ -370,3 +370,34 @@ def test_new_gaussian_mask_compaction_and_gather_match_the_tensor_sequence(W, H,
     m3 = ref_mask.expand(H, W, 3)
     for o, src_map in zip(outs, (vertex, image, normal)):
         assert torch.equal(o, torch.masked_select(src_map, m3).reshape(-1, 3)[subset.long()])
+
+
+def test_prune_mask_and_row_gather_match_the_tensor_sequence():
+    """gps_prune_mask == slam_pipeline.cpp:566-575 evaluated with torch ops (bit for bit, thresholds ON the values for some rows);
+    gps_gather_rows == index_select of the six parameter tensors (raw_gs_param.cpp:148-157) in one launch."""
+    from gps_slam_amd._lib import lib
+    g = torch.Generator(device=DEV).manual_seed(5)
+    N = 100003
+    ls = torch.randn(N, 3, device=DEV, generator=g) * 1.5 - 4.0
+    ol = torch.randn(N, 1, device=DEV, generator=g) * 3.0
+    small, large, low = 0.004, 0.08, 0.05
+    ls[::11, 0] = float(np.log(np.float32(large)))  # max scale lands on / next to the threshold
+    ls[::11, 1:] = -9.0
+    smax = torch.exp(ls).max(-1).values
+    ref = (smax < small) | (smax > large) | (torch.sigmoid(ol).squeeze(-1) < low)
+    dele = torch.empty(N, dtype=torch.bool, device=DEV)
+    keep = torch.empty(N, dtype=torch.bool, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.gps_prune_mask(N, ls.data_ptr(), ol.data_ptr(), small, large, low, dele.data_ptr(), keep.data_ptr(), st) == 0
+    assert torch.equal(dele, ref) and torch.equal(keep, ~ref)
+    assert 0.05 < ref.float().mean() < 0.95
+    ids = torch.nonzero(keep).squeeze(1).to(torch.int32)
+    m = int(ids.numel())
+    rows = [3, 3, 4, 3, 45, 1]
+    srcs = [torch.randn(N, r, device=DEV, generator=g) for r in rows]
+    dsts = [torch.full((N, r), float("nan"), device=DEV) for r in rows]
+    P6 = C.c_void_p * 6
+    assert lib.gps_gather_rows(m, ids.data_ptr(), 6, P6(*[t.data_ptr() for t in srcs]), P6(*[t.data_ptr() for t in dsts]),
+                               (C.c_int32 * 6)(*rows), st) == 0
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_[:m], s_[ids.long()]) and bool(torch.isnan(d_[m:]).all())
