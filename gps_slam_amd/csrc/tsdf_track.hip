@@ -136,7 +136,10 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
     }
 }
 
-constexpr int EV_THREADS = 256;
+#ifndef GPS_TRACK_EV_THREADS
+#define GPS_TRACK_EV_THREADS 256
+#endif
+constexpr int EV_THREADS = GPS_TRACK_EV_THREADS;
 constexpr int EV_MAX_WGS = 256;           // rows of the partial table.  Measured on the 640x480 loop (ms per tracked frame): 128 rows
                                           // 0.750, 256 rows 0.725, 512 rows 0.735, 1280 rows (one pixel per thread) 0.818 -- the last
                                           // workgroup's fixed-order sum costs what the evaluation's extra parallelism buys.  (Two
@@ -243,7 +246,11 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
     }
     __syncthreads();
     if (tid < GH_SLOTS) {
-        const float t = tid < NV ? ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) : 0.0f;
+        float t = 0.0f;
+        if (tid < NV) {
+#pragma unroll
+            for (int w2 = 0; w2 < EV_THREADS / 64; w2 += 2) t += red[w2][tid] + red[w2 + 1][tid];  // fixed order
+        }
         __hip_atomic_store(partial + (size_t)blockIdx.x * GH_SLOTS + tid, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) {
