@@ -221,13 +221,26 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
 // the ticket.  Nothing else is written back or invalidated.  Totals + the frame's valid-pixel count go to the pinned host
 // mailbox, sequence number last.
 // One evaluation by the workgroups [0, n_rows) of a launch (shared by the two kernels below).
+//
+// Row hand-over WITHOUT acknowledgements or a ticket (round 2, second step).  A row of the table is two 64-byte chunks, each
+// 15 sums + the launch's sequence number in its last word (sum d lives in word d + d / 15).  A workgroup stores its row with
+// one sc1 store instruction (two 64-byte write transactions) and is DONE: no wait for the acknowledgement, no ticket.
+// Workgroup 0 is the summer: after its own row it reads all rows (sc1 loads) until both tags of every row carry this
+// launch's number -- stale rows carry older ones, so nothing is ever reset -- and adds them in fixed order.  The totals go to
+// the pinned mailbox in the same chunked format (the host waits for both tags), again without an acknowledgement wait.
+// Against the ticket version this takes three memory-side round trips out of every iteration's dependent chain (row
+// acknowledgement, ticket, mailbox acknowledgement); under the map stream's memory traffic each of them was ~2-3 us.
+__device__ __forceinline__ int chunk_word(int d) { return d + d / 15; }
+constexpr long long ROW_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
+
 template <int ITER>
 __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
                                           float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ, NQ = (NV + 3) / 4;
+    static_assert(NV <= 29, "29 sums + the valid-pixel count fill the two 15-word chunks");
     __shared__ float red[EV_THREADS / 64][GH_SLOTS];
     __shared__ float group[EV_ROW_GROUPS][GH_SLOTS];
-    __shared__ int is_last;
+    __shared__ int all_ok;
     float acc[4 * NQ];
 #pragma unroll
     for (int k = 0; k < 4 * NQ; k++) acc[k] = 0.0f;
@@ -245,62 +258,71 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
         if ((lane & 15) == 15) red[wave][4 * q + row_slot] = z;
     }
     __syncthreads();
-    if (tid < GH_SLOTS) {
-        float t = 0.0f;
-        if (tid < NV) {
+    if (tid < GH_SLOTS) {  // word tid of this workgroup's row: sums in words d + d / 15, the sequence number in words 15 and 31
+        const int d = tid - (tid >> 4);  // inverse of chunk_word for non-tag words
+        uint32_t wv = (uint32_t)seq;
+        if ((tid & 15) != 15) {
+            float t = 0.0f;
+            if (d < NV) {
 #pragma unroll
-            for (int w2 = 0; w2 < EV_THREADS / 64; w2 += 2) t += red[w2][tid] + red[w2 + 1][tid];  // fixed order
+                for (int w2 = 0; w2 < EV_THREADS / 64; w2 += 2) t += red[w2][d] + red[w2 + 1][d];  // fixed order
+            }
+            wv = __float_as_uint(t);
         }
-        __hip_atomic_store(partial + (size_t)blockIdx.x * GH_SLOTS + tid, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partial + (size_t)blockIdx.x * GH_SLOTS + tid, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): wave 0's sc1 stores are acknowledged
-        const uint32_t old = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = old + 1u == (uint32_t)n_rows;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    // ---- the last workgroup: slot k of rows r, r + 8, ... by thread (r, k), then the 8 row groups in order
-    {
-        const int k = tid & (GH_SLOTS - 1), r = tid >> 5;
-        float s = 0.0f;
-        const int rows = n_rows;
-        constexpr int INFLIGHT = 32;  // a 256-row table is 32 loads per thread: one memory-side round trip
+    if (blockIdx.x != 0) return;
+    // ---- workgroup 0, the summer: word k of rows r, r + 8, ... by thread (r, k); a round is ONE batch of loads
+    const int k = tid & (GH_SLOTS - 1), r = tid >> 5;
+    const int rows = n_rows;
+    float s = 0.0f;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+        s = 0.0f;
+        constexpr int INFLIGHT = 32;  // a 256-row table is 32 loads per thread: one memory-side round trip per round
         for (int rr = r; rr < rows; rr += INFLIGHT * EV_ROW_GROUPS) {
-            uint32_t v[INFLIGHT];  // independent loads in flight, added in row order afterwards
+            uint32_t v[INFLIGHT];
 #pragma unroll
             for (int u = 0; u < INFLIGHT; u++) {
                 const int row = rr + u * EV_ROW_GROUPS;
-                v[u] = row < rows ? __hip_atomic_load(partial + (size_t)row * GH_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v[u] = row < rows ? __hip_atomic_load(partial + (size_t)row * GH_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : (uint32_t)seq;
             }
 #pragma unroll
-            for (int u = 0; u < INFLIGHT; u++) s += __uint_as_float(v[u]);
+            for (int u = 0; u < INFLIGHT; u++) {
+                if ((k & 15) == 15) ok = ok && v[u] == (uint32_t)seq;  // this lane holds a tag word of the row
+                else s += __uint_as_float(v[u]);                       // rows added in row order
+            }
         }
-        group[r][k] = s;
-    }
-    __syncthreads();
-    if (tid < GH_SLOTS) {
-        float t = 0.0f;
-#pragma unroll
-        for (int r = 0; r < EV_ROW_GROUPS; r++) t += group[r][tid];
-        result[tid] = t;
-        if (mailbox) mailbox[tid] = t;
-    }
-    if (tid == 0) {
-        __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every workgroup has arrived: next launch starts at 0
-        const uint32_t n_valid = __hip_atomic_load(&sync[1 + parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&sync[2 - parity], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next frame's count slot
-        result[GH_SLOTS + 1] = __uint_as_float(n_valid);
-        if (mailbox) mailbox[GH_SLOTS + 1] = __uint_as_float(n_valid);
-    }
-    if (mailbox) {
-        // The mailbox words are system-scope write-through stores (volatile host memory: flat_store sc0 sc1).  Waiting for
-        // their acknowledgement (vmcnt(0)) before the sequence number is stored orders them for the host; a
-        // __threadfence_system() here would ALSO write back and invalidate this XCD's entire L2 (buffer_wbl2 + buffer_inv),
-        // which is full of the map stream's rasterizer data -- once per LM iteration.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (tid == 0) all_ok = 1;
         __syncthreads();
-        if (tid == 0) mailbox[GH_SLOTS] = __int_as_float(seq);
+        if (!ok) all_ok = 0;
+        __syncthreads();
+        const int done = all_ok;
+        __syncthreads();
+        if (done) break;
+        if (wall_clock64() - t0 > ROW_TIMEOUT) return;  // a row never arrived: no result (the host's bounded wait reports it)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    group[r][k] = s;
+    __syncthreads();
+    if (tid < GH_SLOTS) {  // word tid of the result, chunked like a row: sums, then the valid-pixel count as payload 29
+        const int d = tid - (tid >> 4);
+        uint32_t wv = (uint32_t)seq;
+        float t = 0.0f;
+        if ((tid & 15) != 15) {
+            if (d < 29) {
+#pragma unroll
+                for (int g2 = 0; g2 < EV_ROW_GROUPS; g2++) t += group[g2][tid];
+                wv = __float_as_uint(t);
+            } else {  // d == 29: the frame's valid-pixel count
+                wv = __hip_atomic_load(&sync[1 + parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sync[2 - parity], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next frame's count slot
+            }
+        }
+        result[tid] = __uint_as_float(wv);  // (device copy, same layout: the host_mailbox == NULL path reads it back)
+        if (mailbox) reinterpret_cast<volatile uint32_t*>(mailbox)[tid] = wv;  // one store instruction: two 64-byte chunks
     }
 }
 
@@ -562,6 +584,8 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     int parity = 0;
     if (ts->scratch_epoch == 0) {
         if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) return GPS_ERR_LAUNCH;
+        // row tags: sequence numbers are >= 1, so a zeroed table can never look like a delivered row
+        if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) return GPS_ERR_LAUNCH;
     } else {
         parity = ts->scratch_epoch - 1;
     }
@@ -628,7 +652,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     int last_type = TRK_NONE;
     for (int k = 0; k < 16; k++) ts->diag[k] = 0;
     const int use_weights = ts->frames_processed >= 100;
-    int mailbox_iterations = 0;
+    int mailbox_iterations = 0, n_valid_bits = 0;
 
     for (int level = c->n_levels - 1; level >= 0; level--) {
         const int it = c->iter_type[level];
@@ -651,21 +675,21 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
             a.vf_max = s.view_frustum_max; a.use_weights = use_weights; a.frames_to_skip = c->frames_to_skip;
             a.frames_to_weight = c->frames_to_weight;
             const int n_wgs = min(EV_MAX_WGS, gps_div_up(a.vw * a.vh, EV_THREADS));
-            float host[GH_SLOTS];
+            float raw[GH_SLOTS];  // two 64-byte chunks: 15 payload words + the sequence number each (eval_body)
             if (mailbox) {
                 // this evaluation is the pre-launched kernel (or the frame's first launch): hand it its arguments, then put
                 // the NEXT evaluation on the stream before waiting -- its launch cost overlaps this evaluation
                 if (!pending.seq && prelaunch() != GPS_OK) return GPS_ERR_LAUNCH;
                 const int seq = pending.seq;
                 pending.seq = 0;
-                mailbox[GH_SLOTS] = 0.0f;  // per-state sequence numbers (>= 1): nothing stale can match
+                mailbox[15] = 0.0f; mailbox[31] = 0.0f;  // per-state sequence numbers (>= 1): nothing stale can match
                 publish(seq, ARG_RUN, it, level, approxInvPose);
                 eval_launches++;
                 if (prelaunch() != GPS_OK) return GPS_ERR_LAUNCH;
                 // spin on the sequence number the kernel writes last (bounded)
                 bool got = false;
                 for (long spin = 0; spin < 200000000L; spin++) {
-                    if (float_bits(mailbox[GH_SLOTS]) == seq) { got = true; break; }
+                    if (float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq) { got = true; break; }
                     // a result normally lands within ~20 us (a few thousand polls); a host that is still spinning far beyond
                     // that is oversubscribed or the GPU is busy elsewhere: stop burning the core between polls
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
@@ -680,9 +704,10 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
                     else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                     else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                     GPS_LAUNCH_CHECK();
-                    if (hipStreamSynchronize(st) != hipSuccess || float_bits(mailbox[GH_SLOTS]) != seq2) return GPS_ERR_LAUNCH;
+                    if (hipStreamSynchronize(st) != hipSuccess || float_bits(mailbox[15]) != seq2 || float_bits(mailbox[31]) != seq2)
+                        return GPS_ERR_LAUNCH;
                 }
-                for (int k = 0; k < GH_SLOTS; k++) host[k] = mailbox[k];
+                for (int k = 0; k < GH_SLOTS; k++) raw[k] = mailbox[k];
                 mailbox_iterations++;
             } else {
                 const int seq = next_seq();
@@ -692,9 +717,13 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
                 GPS_LAUNCH_CHECK();
                 eval_launches++;
                 // the reference's GPU tracker reads its 32 accumulators back every iteration as well
-                if (hipMemcpyAsync(host, w.result, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+                if (hipMemcpyAsync(raw, w.result, sizeof(raw), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
                 if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+                if (float_bits(raw[15]) != seq || float_bits(raw[31]) != seq) return GPS_ERR_LAUNCH;  // the summer gave up
             }
+            float host[GH_SLOTS];
+            for (int d = 0; d < 30; d++) host[d] = raw[d + d / 15];  // payload d lives in word d + d / 15
+            n_valid_bits = float_bits(host[29]);
 
             float hessian_depth[36] = {0}, nabla_depth[6] = {0};
             const int nvalid = (int)host[0];
@@ -759,8 +788,8 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     // UpdatePoseQuality: the residual score (the SVM verdict only feeds failure modes that are off by default,
     // ITMLibSettings.cpp:42 behaviourOnFailure = FAILUREMODE_IGNORE)
     int n_max = 0;
-    if (ts->host_mailbox && mailbox_iterations > 0) {
-        n_max = float_bits(reinterpret_cast<volatile float*>(ts->host_mailbox)[GH_SLOTS + 1]);  // delivered with the last iteration
+    if (eval_launches > 0) {
+        n_max = n_valid_bits;  // delivered with every evaluation's sums
     } else {
         if (hipMemcpyAsync(&n_max, w.sync + 1 + parity, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
         if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
