@@ -84,9 +84,8 @@ struct GhArgs {
 
 // computePerPointGH_exDepth for one pixel, accumulated into the caller's registers.  ITER: 0 rotation, 1 translation, 2 both.
 template <int ITER>
-__device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& cnt, float& f, float* nabla, float* hess) {
+__device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float depth, float& cnt, float& f, float* nabla, float* hess) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3;
-    const float depth = a.depth[x + y * a.vw];
     if (depth <= 1e-8f) return;
     float px = depth * (((float)x - a.view_intr.z) / a.view_intr.x);
     float py = depth * (((float)y - a.view_intr.w) / a.view_intr.y);
@@ -140,7 +139,10 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float& c
 #define GPS_TRACK_EV_THREADS 256
 #endif
 constexpr int EV_THREADS = GPS_TRACK_EV_THREADS;
-constexpr int EV_MAX_WGS = 256;           // rows of the partial table.  Measured on the 640x480 loop (ms per tracked frame): 128 rows
+#ifndef GPS_TRACK_EV_MAX_WGS
+#define GPS_TRACK_EV_MAX_WGS 256
+#endif
+constexpr int EV_MAX_WGS = GPS_TRACK_EV_MAX_WGS;           // rows of the partial table.  Measured on the 640x480 loop (ms per tracked frame): 128 rows
                                           // 0.750, 256 rows 0.725, 512 rows 0.735, 1280 rows (one pixel per thread) 0.818 -- the last
                                           // workgroup's fixed-order sum costs what the evaluation's extra parallelism buys.  (Two
                                           // pixels in flight per thread -- both depth loads, then both bilinear footprints -- changed
@@ -245,9 +247,12 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
 #pragma unroll
     for (int k = 0; k < 4 * NQ; k++) acc[k] = 0.0f;
     const int n = a.vw * a.vh;
+    // (prefetching the next pixel's depth ahead of this pixel's bilinear gather -- one dependent round trip per trip instead of
+    // two -- and two pixels in flight were both measured: no change; launch-to-launch overhead and the hand-over chain set
+    // an iteration's length, not this loop)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_rows * blockDim.x) {
         const int y = i / a.vw, x = i - y * a.vw;
-        gh_point<ITER>(a, x, y, acc[0], acc[1], acc + 2, acc + 2 + NP);
+        gh_point<ITER>(a, x, y, a.depth[i], acc[0], acc[1], acc + 2, acc + 2 + NP);
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // wave totals, four values per register (wave_reduce.hpp): 10 VALU ops per quad instead of 24 ds_bpermute round trips
@@ -349,7 +354,7 @@ struct PollArgs {
     Mat4 scenePose;
     float tukey_cutoff, vf_min, vf_max;
     int use_weights, frames_to_skip, frames_to_weight;
-    const LevelTab* tab;
+    LevelTab tab[GPS_TRACK_MAX_LEVELS];  // per-level constants (kernel arguments: selected with static indices, no memory round trip)
     const uint32_t* arg_line;  // pinned host memory, 64-byte aligned
     uint32_t* dev_line;        // device copy of the line (relayed by workgroup 0)
 };
@@ -395,7 +400,10 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
     const uint32_t ctl = __builtin_amdgcn_readfirstlane(line[1]);
     if ((ctl & 0xFF) != ARG_RUN) return;
     const int kind = (int)((ctl >> 8) & 0xFF), level = (int)((ctl >> 16) & 0xFF);
-    const LevelTab lt = pa.tab[level];
+    LevelTab lt = pa.tab[0];
+#pragma unroll
+    for (int l = 1; l < GPS_TRACK_MAX_LEVELS; l++)  // (a dynamically indexed kernel-argument array would be copied to scratch)
+        if (level == l) lt = pa.tab[l];
     if ((int)blockIdx.x >= lt.n_wgs) return;
     GhArgs a;
     a.depth = lt.depth; a.vw = lt.vw; a.vh = lt.vh;
@@ -611,7 +619,7 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
         pl.scenePose = load_mat(ts->pose_pc_M);
         pl.tukey_cutoff = c->tukey_cutoff; pl.vf_min = s.view_frustum_min; pl.vf_max = s.view_frustum_max;
         pl.use_weights = ts->frames_processed >= 100; pl.frames_to_skip = c->frames_to_skip; pl.frames_to_weight = c->frames_to_weight;
-        pl.tab = w.tab;
+        for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++) pl.tab[l] = pa.tab_vals[l];
         pl.arg_line = const_cast<const uint32_t*>(arg_line);
         pl.dev_line = w.dev_line;
     }
