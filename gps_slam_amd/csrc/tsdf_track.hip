@@ -347,7 +347,11 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32
 // The line is written payload first, sequence number last, and read by ONE load instruction of 16 lanes (one 64-byte
 // request); the xor word rejects a torn line anyway.  ARG_SKIP retires a launch the LM loop did not need (the iteration
 // count is data dependent); a launch whose line never arrives gives up after ARG_TIMEOUT (host error paths), so a stream
-// can never be wedged by it.  Per-level constants come from a small device table written by track_prepare_kernel.
+// can never be wedged by it.  Per-level constants are kernel arguments.
+// Measured after this: keeping ONE launch resident for all evaluations of a frame (workgroups wait for the next line instead
+// of exiting; late workgroups join at the current evaluation) -- no faster (0.571 vs 0.560 ms per tracked frame, overlap
+// schedule 934 vs 960 frames/s): with the next launch already queued, launch-to-launch overhead is off the critical path;
+// an iteration is the host <-> device loop itself (sums -> PCIe -> solve -> line -> PCIe -> relay -> rows -> sums).
 struct PollArgs {
     const float4* pn; int sw, sh;
     float4 scene_intr;
