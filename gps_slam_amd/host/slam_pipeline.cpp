@@ -6,6 +6,11 @@
 #include <cmath>
 
 using namespace gpsh;
+
+namespace {
+inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
+struct MapStream { c10::hip::HIPStream s; };
+}  // namespace
 using torch::indexing::Slice;
 
 torch::Tensor computeNormalMap(const torch::Tensor& vertex_map_in) {
@@ -79,7 +84,7 @@ TensorDict SLAMPipeline::runRaycastByCam(const Camera& cam, bool use_cam_depth) 
     return m;
 }
 
-TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses) {
+TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses, void** ev_out) {
     TsdfEngine* eng = main_engine;
     ORUtils::SE3Pose pose;
     if (cam.id >= 0 && cam.id < (int)poses.size()) {
@@ -89,9 +94,10 @@ TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils
         pose.SetInvM(c.data_ptr<float>());
         pose.Coerce();
     }
-    eng->runRaycast(&pose);
     const int H = cam.height, W = cam.width;
     const auto F = f32(device);
+    // (the result tensors are allocated on the CONSUMER's stream, before the guard below: the caching allocator ties a block
+    // to the stream that was current at allocation)
     TensorDict m;
     m["color_map"] = torch::empty({H, W, 3}, F);
     m["vertex_map"] = torch::empty({H, W, 3}, F);
@@ -99,13 +105,49 @@ TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils
     m["depth_map"] = torch::empty({H, W, 1}, F);
     m["depth_map_clamped"] = torch::empty({H, W, 1}, F);
     auto w2c = poseInv(cam.c2w.to(torch::kCPU, torch::kFloat32)).contiguous();  // poseInv(cam.c2w): dataset pose (:398)
+    c10::optional<c10::hip::HIPStreamGuard> on_rc;
+    if (ev_out) on_rc.emplace(static_cast<MapStream*>(rc_stream_)->s);
+    eng->runRaycast(&pose);
     check(gps_raycast_to_maps(W, H, reinterpret_cast<const float*>(eng->GetFreeVertex()->GetData(MEMORYDEVICE_CUDA)),
                               reinterpret_cast<const uint8_t*>(eng->GetFreeImage()->GetData(MEMORYDEVICE_CUDA)),
                               eng->getVoxelSize(), w2c.data_ptr<float>(), fptr(m["color_map"]), fptr(m["vertex_map"]),
                               fptr(m["confidence_map"]), fptr(m["depth_map"]), fptr(m["depth_map_clamped"]),
                               current_stream()), "gps_raycast_to_maps");
+    if (ev_out) {
+        if (rc_event_next_ == rc_events_.size()) {
+            hipEvent_t ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            rc_events_.push_back(ev);
+        }
+        *ev_out = rc_events_[rc_event_next_++];
+        hip_ok(hipEventRecord((hipEvent_t)*ev_out, c10::hip::getCurrentHIPStream().stream()), "hipEventRecord");
+    }
     stats.raycasts++;
     return m;
+}
+
+void SLAMPipeline::beginAsyncRaycasts() {
+    window_raycast_events_.clear(); opt_raycast_events_.clear();
+    rc_event_next_ = 0;
+    if (!async_raycasts) return;
+    if (!rc_stream_) {
+        rc_stream_ = new MapStream{c10::hip::getStreamFromPool(/*isHighPriority=*/true, c10::hip::current_device())};
+        hipEvent_t ev;
+        hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        ev_rc_begin_ = ev;
+    }
+    // the raycast stream starts behind everything the current stream holds (the fusion of the keyframe; the previous
+    // update's last readers of the engine's free-view scratch)
+    hip_ok(hipEventRecord((hipEvent_t)ev_rc_begin_, c10::hip::getCurrentHIPStream().stream()), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(static_cast<MapStream*>(rc_stream_)->s.stream(), (hipEvent_t)ev_rc_begin_, 0), "hipStreamWaitEvent");
+}
+
+void SLAMPipeline::waitRaycast(void* ev) {
+    if (ev) hip_ok(hipStreamWaitEvent(c10::hip::getCurrentHIPStream().stream(), (hipEvent_t)ev, 0), "hipStreamWaitEvent");
+}
+
+void SLAMPipeline::waitAllRaycasts() {
+    if (rc_event_next_ > 0) waitRaycast(rc_events_[rc_event_next_ - 1]);  // one stream: the last event covers all
 }
 
 // ------------------------------------------------------------------ frame bookkeeping (updateFrameList :319-360)
@@ -142,25 +184,34 @@ void SLAMPipeline::initNewGaussians(TensorDict& rm) { initNewGaussiansFor(rm, cu
 
 void SLAMPipeline::raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses) {
     localframe_raycast_window.clear();
-    for (const Camera& cam : window) localframe_raycast_window.push_back(raycastCam(cam, poses));
+    beginAsyncRaycasts();
+    for (const Camera& cam : window) {
+        void* ev = nullptr;
+        localframe_raycast_window.push_back(raycastCam(cam, poses, async_raycasts ? &ev : nullptr));
+        window_raycast_events_.push_back(ev);
+    }
 }
 
 void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
                                     const std::vector<ORUtils::SE3Pose>& poses) {
     opt_cam_list.assign(window.begin(), window.end());
     opt_raycast_list.assign(localframe_raycast_window.begin(), localframe_raycast_window.end());
+    opt_raycast_events_ = window_raycast_events_;
     const int n = std::min<int>(keyframe_select_max, (int)keyframes.size());
     RandomSelector<Camera> sel(keyframes, rng_);
     for (int k = 0; k < n; k++) {
         const Camera* cam = sel.getNext().second;
         opt_cam_list.push_back(*cam);
-        opt_raycast_list.push_back(raycastCam(*cam, poses));
+        void* ev = nullptr;
+        opt_raycast_list.push_back(raycastCam(*cam, poses, async_raycasts ? &ev : nullptr));
+        opt_raycast_events_.push_back(ev);
     }
 }
 
 // ------------------------------------------------------------------ initNewGaussians :450-526
 void SLAMPipeline::initNewGaussiansFor(TensorDict& rm, const Camera& cam) {
     torch::NoGradGuard no_grad;
+    if (!window_raycast_events_.empty()) waitRaycast(window_raycast_events_.back());  // rm is the newest window camera's result
     const auto &depth = rm.at("depth_map"), &color = rm.at("color_map"), &vertex = rm.at("vertex_map");
     int frame_num = local_opt_interval;
     // valid = depth in (min, max) & vertex.sum(2) != 0;  mask = mean|src - image| > thres & valid [& alpha < max]: one launch
@@ -203,6 +254,7 @@ void SLAMPipeline::optimizeIterations(int count) {
         auto pick = opt_loader_->getNext();
         const Camera& cam = *pick.second;
         TensorDict& rc = opt_raycast_list[pick.first];
+        if (pick.first < (int)opt_raycast_events_.size()) waitRaycast(opt_raycast_events_[pick.first]);
         if (ssim_weight > 0 || depth_weight > 0) {
             // losses beyond L1: the reference's own sequence (slam_pipeline.cpp:247-254) through the autograd route
             Config wc;
@@ -309,10 +361,6 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
 }
 
 // ------------------------------------------------------------------ tracking / mapping overlap (see slam_pipeline.hpp)
-namespace {
-inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
-struct MapStream { c10::hip::HIPStream s; };
-}  // namespace
 
 void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     if (!overlap_mapping) { processFrameImpl(i, cam, rgb_u8, depth_mm_i16); return; }
@@ -349,6 +397,7 @@ void SLAMPipeline::keyframeStep() {
     initNewGaussians(localframe_raycast_window.back());
     localOptimize();
     removeRedundantGs();
+    waitAllRaycasts();  // the next frame's fusion modifies the volume (results no iteration drew would still be in flight)
 }
 
 void SLAMPipeline::keyframeStepOverlapped() {
@@ -365,6 +414,7 @@ void SLAMPipeline::keyframeStepOverlapped() {
         if (prune_pending_) { removeRedundantGs(); prune_pending_ = false; }  // update k's prune, before update k+1 reads the model
         localFrameRaycast();
         keyFrameRaycast();
+        if (async_raycasts) waitAllRaycasts();  // (this arrangement keeps its single map stream: the gate below covers them)
         hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
         initNewGaussians(localframe_raycast_window.back());
         localOptimizeBegin();
@@ -433,12 +483,15 @@ void SLAMPipeline::mapWorker(int device_index) {
             hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
             raycastWindow(job_.window, job_.poses);
             raycastKeyframes(job_.window, job_.keyframes, job_.poses);
-            hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
+            // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)
+            hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, async_raycasts && rc_stream_ ? static_cast<MapStream*>(rc_stream_)->s.stream()
+                                                                                         : ms.stream()), "hipEventRecord");
             { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
             cv_.notify_all();
             initNewGaussiansFor(localframe_raycast_window.back(), job_.curr_cam);
             localOptimize();
             removeRedundantGs();
+            waitAllRaycasts();
             hip_ok(hipStreamSynchronize(ms.stream()), "hipStreamSynchronize");
             { std::lock_guard<std::mutex> lk(mu_); done_seq_ = seen; }
             cv_.notify_all();

@@ -126,6 +126,7 @@ public:
     // Results are those of the sequential schedule.  Off by default: with it on, processFrame() returns while the update is
     // still in flight and the model may only be read after flush() (SLAMTrainCams and the accessors below call it).
     bool overlap_mapping = false;
+    bool async_raycasts = true;   // the update's free-view raycasts run beside its optimise iterations (same results)
     // with overlap_mapping: run the map update on a worker thread of its own (tracking thread + mapping thread) instead of
     // interleaving its host work with the frames on the caller's thread
     bool mapping_thread = false;
@@ -136,7 +137,8 @@ public:
 private:
     void processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16);
     void ensureStreams();
-    TensorDict raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses);
+    // `ev_out` != nullptr: run on the raycast stream and hand back the event that marks the result complete
+    TensorDict raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses, void** ev_out = nullptr);
     void raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses);
     void raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
                           const std::vector<ORUtils::SE3Pose>& poses);
@@ -163,6 +165,17 @@ private:
     std::mt19937_64 rng_;
     at::Generator gen_;
     void *map_stream_ = nullptr, *frame_stream_ = nullptr;  // c10 stream handle storage (see .cpp)
+    // A keyframe's free-view raycasts on a stream of their own, next to the optimise iterations (they only read the volume; the
+    // rasterizer kernels fill the GPU their latency-bound tails leave idle): every result carries an event, and whoever reads
+    // a result (initNewGaussians, an optimise iteration) makes its stream wait for it.
+    void* rc_stream_ = nullptr;
+    void* ev_rc_begin_ = nullptr;                 // "the volume the raycasts read is complete" (recorded on the issuing stream)
+    std::vector<void*> rc_events_;                // hipEvent_t pool, one per raycast of the current update
+    size_t rc_event_next_ = 0;
+    std::vector<void*> window_raycast_events_, opt_raycast_events_;  // parallel to localframe_raycast_window / opt_raycast_list
+    void beginAsyncRaycasts();                    // call once per update, on the stream that is ordered after the volume
+    void waitRaycast(void* ev);                   // current stream waits for one result (no-op for nullptr)
+    void waitAllRaycasts();                       // ... for all of this update's
     void *ev_frame_ = nullptr, *ev_raycasts_ = nullptr, *ev_map_ = nullptr, *ev_caller_ = nullptr;  // hipEvent_t
     bool map_in_flight_ = false, prune_pending_ = false;
 };
