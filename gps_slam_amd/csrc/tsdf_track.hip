@@ -214,6 +214,62 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
     if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.sync[1 + a.parity], (uint32_t)valid);
 }
 
+// The same for pyramids of up to 5 levels (coarsest pixel <= 16 x 16 full-resolution pixels; the default "rrbb" has 4): one
+// workgroup per 16 x 16 tile, thread = pixel.  Level 0 goes through LDS once (row-coalesced loads), every level above is
+// computed from the LDS copy of the level below by the first (16 >> l)^2 threads -- the first version gave each THREAD a whole
+// coarsest-level block and walked it with strided loads (25 us; this one: see DESIGN.md).
+__global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
+    __shared__ float lv[2][16 * 16];
+    __shared__ int wv[4];
+    const int L = a.cfg.n_levels;
+    const int tiles_x = (a.W + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = tx * 16 + lx, y = ty * 16 + ly;
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++)  // (static indices: a dynamically indexed kernel argument array goes to scratch)
+            if ((int)threadIdx.x == l && l < L) a.tab_out[l] = a.tab_vals[l];
+    }
+    float d = 0.0f;
+    const bool in = x < a.W && y < a.H;
+    if (in) {
+        const int i = x + y * a.W;
+        d = a.depth0[i];
+        a.pn[2 * i] = a.points[i];
+        a.pn[2 * i + 1] = a.normals[i];
+    }
+    lv[0][threadIdx.x] = d;
+    int valid = (in && d > 0.0f) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o, 64);
+    if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = valid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int v = (wv[0] + wv[1]) + (wv[2] + wv[3]);
+        // zero on entry: the evaluation launches of the PREVIOUS frame cleared this slot (they read the other one)
+        if (v) atomicAdd(&a.sync[1 + a.parity], (uint32_t)v);
+    }
+    // level l from level l - 1: filterSubsampleWithHoles (mean of the valid children, ITMLowLevelEngine_Shared.h:48-69)
+    for (int l = 1; l < L; l++) {
+        const int e = 16 >> l, e_in = 16 >> (l - 1);  // tile edge at level l / l - 1
+        const float* src = lv[(l - 1) & 1];
+        float* dst = lv[l & 1];
+        if ((int)threadIdx.x < e * e) {
+            const int px = threadIdx.x % e, py = threadIdx.x / e;
+            float acc = 0.0f, good = 0.0f, v;
+            v = src[(2 * px + 0) + (2 * py + 0) * e_in]; if (v > 0.0f) { acc += v; good++; }
+            v = src[(2 * px + 1) + (2 * py + 0) * e_in]; if (v > 0.0f) { acc += v; good++; }
+            v = src[(2 * px + 0) + (2 * py + 1) * e_in]; if (v > 0.0f) { acc += v; good++; }
+            v = src[(2 * px + 1) + (2 * py + 1) * e_in]; if (v > 0.0f) { acc += v; good++; }
+            if (good > 0) acc /= good;
+            dst[px + py * e] = acc;
+            const int gx = tx * e + px, gy = ty * e + py, lwl = a.W >> l, lhl = a.H >> l;
+            if (gx < lwl && gy < lhl) a.level[l][gx + gy * lwl] = acc;
+        }
+        __syncthreads();
+    }
+}
+
 // One LM iteration's evaluation + reduction.  Cross-workgroup traffic inside the launch avoids L2 flushes: the XCDs' L2s are
 // not coherent with each other, and an agent-scope release / acquire pair means buffer_wbl2 + buffer_inv of the WHOLE L2 per
 // workgroup (round 1 measured a fenced last-block-done ticket 20 % slower than a second launch, with the map stream's
@@ -608,7 +664,8 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
         pa.tab_vals[l] = LevelTab{dl[l], lw[l], lh[l], lintr[l][0], lintr[l][1], lintr[l][2], lintr[l][3], c->space_thresh[l],
                                   min(EV_MAX_WGS, gps_div_up(lw[l] * lh[l], EV_THREADS))};
     pa.tab_out = w.tab;
-    track_prepare_kernel<<<gps_div_up((int64_t)W * H, 4 * 256), 256, 0, st>>>(pa);
+    if (c->n_levels <= 5) track_prepare_tile_kernel<<<((W + 15) >> 4) * ((H + 15) >> 4), 256, 0, st>>>(pa);
+    else track_prepare_kernel<<<gps_div_up((int64_t)W * H, 4 * 256), 256, 0, st>>>(pa);
     GPS_LAUNCH_CHECK();
 
     // Mailbox path: evaluations are PRE-LAUNCHED (track_eval_poll_kernel); the host's per-iteration decision is one
