@@ -247,6 +247,7 @@ PYBIND11_MODULE(_host, m) {
         .def("runRaycastByCam", &SLAMPipeline::runRaycastByCam, py::arg("cam"), py::arg("use_cam_depth") = true)
         .def_readwrite("overlap_mapping", &SLAMPipeline::overlap_mapping)
         .def_readwrite("mapping_thread", &SLAMPipeline::mapping_thread)
+        .def_readwrite("async_raycasts", &SLAMPipeline::async_raycasts)
         .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)
         .def_readwrite("pump_iters_per_frame", &SLAMPipeline::pump_iters_per_frame)
         .def("flush", &SLAMPipeline::flush, py::call_guard<py::gil_scoped_release>())
