@@ -106,8 +106,10 @@ def _bin_inputs(N, W, H, seed, rmax=40):
     return m2, radii
 
 
+# 96x64: 24 tiles; 640x480: 1,200; 1280x720: 3,600 (the one-pass counting sort on the whole tile id, <= 4,096 tiles);
+# 2048x1200: 9,600 tiles (two LSD passes + offsets pass)
 @pytest.mark.parametrize("N,W,H", [(0, 96, 64), (1, 96, 64), (3000, 96, 64), (100000, 640, 480), (60000, 1280, 720),
-                                   (777, 50, 37)])
+                                   (777, 50, 37), (50000, 2048, 1200)])
 def test_binning_bit_exact(N, W, H):
     from gps_slam_amd import gsplat_ops as ops
     from oracle import splat_ref as orc
@@ -127,6 +129,25 @@ def test_binning_bit_exact(N, W, H):
     np.testing.assert_array_equal(N_(g_gst), gst)
     np.testing.assert_array_equal(N_(g_offs)[0], offs)
     assert int(N_(r.counts)[3]) == int((radii > 0).sum())
+
+
+@pytest.mark.parametrize("N,W,H", [(100000, 640, 480), (0, 96, 64), (50000, 2048, 1200)])
+def test_binning_without_isect_ids_writes_the_same_lists_and_offsets(N, W, H):
+    """The model path asks for no int64 isect_ids: the tile offsets then come out of the scatter (exclusive scan of the tile
+    totals) instead of a pass over the sorted keys."""
+    from gps_slam_amd import gsplat_ops as ops
+    from oracle import splat_ref as orc
+    TS = 16
+    tw, th = (W + TS - 1) // TS, (H + TS - 1) // TS
+    m2, radii = _bin_inputs(max(N, 3), W, H, seed=N + W + 1)
+    m2, radii = m2[:N], radii[:N]
+    tpg, ids, flat, ggs, gst, offs = orc.isect_tiles(m2, radii, TS, tw, th)
+    r = ops.isect_tiles_no_depth(T(m2).reshape(1, N, 2), T(radii).reshape(1, N), TS, tw, th, want_isect_ids=False)
+    ni, ng = r.sizes()
+    assert ni == flat.shape[0] and ng == ggs.shape[0]
+    np.testing.assert_array_equal(N_(r.flatten_ids)[:ni], flat)
+    np.testing.assert_array_equal(N_(r.isect_offsets).reshape(-1), offs.reshape(-1))
+    np.testing.assert_array_equal(N_(r.group_gs_ids)[:ng], ggs)
 
 
 def test_binning_capacity_overflow_is_reported():
