@@ -179,6 +179,12 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
             const v2f w = a.z * dx + bdy;
             const v2f sig = w * dx + cdy2;          // sigma * log2(e)
             const v2f e = sig + b.y;                // sigma' - log2(opacity)
+            // Wave-uniform skip: if e > 8 for both pixels of every lane, no pixel of this wave's 16 x 8 half tile can reach
+            // alpha >= 1/255 (v_exp_f32 is within 1 ulp: exp2(-e) <= 2^-8 (1 + 2^-22) < 1/255), so the Gaussian adds exact
+            // zeros here -- and the two quarter-rate exponentials, the tests and the five packed accumulations are most of the
+            // body.  45 % of a tile's list entries do not reach a given half (radius-4.5 footprints on 16-pixel tiles):
+            // 81.6 -> 69.5 us, bit-identical output.
+            if (__builtin_amdgcn_ballot_w64(!(e.x > 8.0f) || !(e.y > 8.0f)) == 0) continue;
             const float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.x));
             const float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.y));
             const bool hit0 = !(b.z > cut0) && !(sig.x < 0.f) && !(al0 < 1.f / 255.f);

@@ -44,6 +44,17 @@ bwd = lambda: lib.gps_raster_ges_bwd_gs(N, p(B["means2d"]), p(B["conics"]), p(B[
                                         p(B["group_gs_ids"]), p(B["group_starts"]), p(B["counts"]), model.delta_depth,
                                         p(B["v_render_colors"]), p(B["v_render_alphas"]), p(B["v_means2d"]), p(B["v_conics"]),
                                         p(B["v_colors"]), p(B["v_opacities"]), 1, sp)
+alt = os.environ.get("GPS_ALT_LIB")  # a second build of the library: same inputs through both, outputs compared bit for bit
+if alt:
+    from gps_slam_amd._lib import load_library
+    lib2 = load_library(alt)
+    fwd(); torch.cuda.synchronize()
+    a_rc, a_ws = B["render_colors"].clone(), B["weight_sum"].clone()
+    lib2.gps_raster_ges_fwd_rec(N, p(B["records"]), p(ref), W, H, p(B["tile_offsets"]), p(B["flatten_ids"]), p(B["counts"]),
+                                model.delta_depth, p(B["render_colors"]), p(B["weight_sum"]), sp)
+    torch.cuda.synchronize()
+    print("forward: %s == %s bit for bit: %s" % (os.environ.get("GPS_SLAM_HIP_LIB", "default"), alt,
+                                                 bool(torch.equal(a_rc, B["render_colors"]) and torch.equal(a_ws, B["weight_sum"]))))
 for name, fn, n in (("raster fwd (records)", fwd, 50), ("raster bwd (operator entry: 3 gathers)", bwd, 50), ("whole train step", step, 20)):
     print("%-42s %.1f us" % (name, 1e6 * _time_launches(fn, n, stream)))
 scene.close()
