@@ -336,15 +336,18 @@ __device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, 
     const int i = R.y0 + q;
     if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw))) return;
     const int pix = i * W + j;
-    const float cut = src.ref_depth[pix] + src.delta_depth;
-    o.vc = src.v_render_colors[pix];
-    o.va = src.v_render_alphas[pix];
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     o.dx = R.x - px; o.dy = R.y - py;
     const float sigma = 0.5f * (R.ca * o.dx * o.dx + R.cc * o.dy * o.dy) + R.cb * o.dx * o.dy;
     o.vis = __expf(-sigma);
     o.alpha = fminf(0.999f, R.opac * o.vis);
-    o.on = !(sigma < 0.f) && !(o.alpha < 1.f / 255.f) && !(R.depth > cut);
+    // the three per-pixel gathers (24 bytes from three arrays) only for slots that pass the alpha test: the {alpha >= 1/255}
+    // ellipse fills 45 % of the 2r x 2r box the groups enumerate (tools/raster_bench.py), the rest would fetch and discard
+    if ((sigma < 0.f) || (o.alpha < 1.f / 255.f)) return;
+    const float cut = src.ref_depth[pix] + src.delta_depth;
+    o.vc = src.v_render_colors[pix];
+    o.va = src.v_render_alphas[pix];
+    o.on = !(R.depth > cut);
 }
 
 __device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, Acc& acc) {
