@@ -198,6 +198,32 @@ def test_tracker_follows_ground_truth_at_full_size():
     assert np.array_equal(runs[0], runs[1])
 
 
+def test_tracker_without_mailbox_gives_the_same_poses():
+    """gps_track_state.host_mailbox == NULL: every evaluation is a plain launch and the sums come back by memcpy -- the same
+    kernels' body, the same fixed-order sums, so the poses are bit-identical to the pre-launched / mailbox path; a state that is
+    handed a fresh scratch buffer (scratch_epoch = 0) keeps working."""
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    W, H, n = 320, 240, 8
+    seq = synth.make_sequence(W, H, n, step_deg=0.4)
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
+    runs = []
+    for mode in ("mailbox", "memcpy", "new-scratch"):
+        eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.01, mu=0.04, device="cuda:0")
+        eng.turnOnTracking()
+        if mode == "memcpy":
+            eng.track_state.host_mailbox = None
+        poses = []
+        for f in range(n):
+            if mode == "new-scratch" and f == 4:
+                eng.track_scratch = torch.full_like(eng.track_scratch, 0x5A)  # garbage, not zeros
+                eng.track_state.scratch_epoch = 0
+            M, invM = eng.ProcessFrameTracked(_dev(rgba[f]), _dev(seq["depth"][f].astype(np.int16)))
+            poses.append(invM.copy())
+        runs.append(np.stack(poses))
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    assert np.abs(runs[0][-1] - runs[0][0]).max() > 1e-3  # the camera actually moved
+
+
 # ----------------------------------------------------------------------------- meshing + persistence (SURVEY 8(f) rank 3)
 def _fused_pair(W, H, voxel, mu, frames, **kw):
     from gps_slam_amd.tsdf_engine import TsdfEngine
