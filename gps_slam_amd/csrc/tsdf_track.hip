@@ -11,11 +11,14 @@
 // 6x6 Levenberg-Marquardt bookkeeping (Cholesky, step, SE3 coercion, accept / reject) is host code fed by 32 floats per
 // iteration -- with the launch train around it cut down:
 //
-//   track_prepare_kernel      depth pyramid (all levels) + valid-pixel count + interleaved ICP maps: ONE launch per frame
+//   track_prepare_tile_kernel depth pyramid (all levels) + valid-pixel count + interleaved ICP maps: ONE launch per frame
 //                             (the reference: one subsample kernel per level; round 1 here: 5 launches)
-//   track_eval_kernel<ITER>   one LM iteration: every workgroup evaluates its pixels and stores one row of partial sums; the
-//                             LAST workgroup to arrive adds the rows in a fixed order and writes the 32 totals straight into a
-//                             pinned host mailbox the host spins on (no summing kernel, no memcpy, no stream synchronise)
+//   track_eval_poll_kernel    one LM iteration, PRE-LAUNCHED: its workgroups wait for a 64-byte argument line (level, kind,
+//                             pose) the host writes once it has decided; every workgroup evaluates its pixels and stores one
+//                             sequence-tagged row of partial sums; workgroup 0 re-reads the rows until all are this launch's,
+//                             adds them in a fixed order and writes the totals into a pinned host mailbox the host spins on
+//                             (no summing kernel, no memcpy, no stream synchronise, no acknowledgement waits, no ticket)
+//   track_eval_kernel<ITER>   the same body as a plain launch with kernel arguments (host_mailbox == NULL, or the fall-back)
 //
 // What was tried in round 2 and measured slower (kept out of the tree): (1) the whole LM loop in ONE persistent launch with a
 // grid-wide rendezvous per iteration -- correct, but all its workgroups must be resident at once, and next to the map stream's
@@ -149,13 +152,12 @@ constexpr int EV_MAX_WGS = GPS_TRACK_EV_MAX_WGS;           // rows of the partia
                                           // nothing either, 0.721: launch + tail + the host round trip dominate an iteration.)
 constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 
-// per-level constants of the evaluation, read by the pre-launched kernel (track_eval_poll_kernel) from device memory
+// per-level constants of the evaluation (kernel arguments of track_eval_poll_kernel)
 struct LevelTab { const float* depth; int vw, vh; float ix, iy, iz, iw; float space_thresh; int n_wgs; };
 
 struct PrepArgs {
     gps_track_config cfg;
-    LevelTab tab_vals[GPS_TRACK_MAX_LEVELS];
-    LevelTab* tab_out;
+    LevelTab tab_vals[GPS_TRACK_MAX_LEVELS];  // (host-side staging of the per-level constants; the kernels do not read it)
     const float* depth0;                // full-resolution depth (s.depth)
     float* level[GPS_TRACK_MAX_LEVELS]; // [0] unused
     const float4* points;               // ICP maps of the last raycast
@@ -197,11 +199,6 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
                 }
         }
     }
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++)  // (static indices: a dynamically indexed kernel argument array goes to scratch)
-            if ((int)threadIdx.x == l && l < L) a.tab_out[l] = a.tab_vals[l];
-    }
     int valid = 0;
     const int n = a.W * a.H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -226,11 +223,6 @@ __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int x = tx * 16 + lx, y = ty * 16 + ly;
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++)  // (static indices: a dynamically indexed kernel argument array goes to scratch)
-            if ((int)threadIdx.x == l && l < L) a.tab_out[l] = a.tab_vals[l];
-    }
     float d = 0.0f;
     const bool in = x < a.W && y < a.H;
     if (in) {
@@ -547,7 +539,6 @@ struct Scratch {
     uint32_t *partial, *sync;
     float* result;
     float4* pn;
-    LevelTab* tab;
     uint32_t* dev_line;
 };
 
@@ -563,7 +554,6 @@ size_t carve(Scratch* w, char* base, int W, int H) {
     char* p = take((size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;
     p = take(64 * sizeof(float)); if (w) w->result = (float*)p;
     p = take(64); if (w) w->sync = (uint32_t*)p;
-    p = take(GPS_TRACK_MAX_LEVELS * sizeof(LevelTab)); if (w) w->tab = (LevelTab*)p;
     p = take(64); if (w) w->dev_line = (uint32_t*)p;
     p = take((size_t)W * H * 2 * sizeof(float4)); if (w) w->pn = (float4*)p;
     return off;
@@ -663,7 +653,6 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     for (int l = 0; l < c->n_levels; l++)
         pa.tab_vals[l] = LevelTab{dl[l], lw[l], lh[l], lintr[l][0], lintr[l][1], lintr[l][2], lintr[l][3], c->space_thresh[l],
                                   min(EV_MAX_WGS, gps_div_up(lw[l] * lh[l], EV_THREADS))};
-    pa.tab_out = w.tab;
     if (c->n_levels <= 5) track_prepare_tile_kernel<<<((W + 15) >> 4) * ((H + 15) >> 4), 256, 0, st>>>(pa);
     else track_prepare_kernel<<<gps_div_up((int64_t)W * H, 4 * 256), 256, 0, st>>>(pa);
     GPS_LAUNCH_CHECK();
