@@ -318,13 +318,39 @@ __global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const
 // coalesced 512-byte access and the per-block header chain (visible_ids -> hash entry) is paid once per 512 voxels
 // while 8 waves per SIMD keep ~8k independent blocks in flight chip-wide (the per-block dependent-load latency, not
 // bandwidth, bounded the earlier one-workgroup-per-block layout).
+// Divergence.  The colour update (4 bilinear taps x 3 channels + exact divisions: ~100 VALU ops) applies only to voxels within
+// a quarter of the band (~20 % of an allocated block), but with lane = voxel of a slice nearly every slice has SOME such
+// voxel, so all 64 lanes sat through it 8 times per block (66 M wave instructions per launch, 180 per slice).  The colour
+// work is therefore split off: phase 1 updates depth / weight for every slice and pushes the (slice, lane) pairs that need
+// colour into a per-wave LDS queue (ballot + prefix); phase 2 drains the queue 64 tasks at a time with all lanes busy,
+// re-deriving the projection with the same operations (bit-identical) and re-reading the voxel phase 1 just wrote.
+template <bool FAST_DIV>
+__device__ __forceinline__ bool project_voxel(const TsdfState& s, const Mat4& M, float pmx, float pmy, float pmz, int W, int H,
+                                              float& cz, float& ix, float& iy) {
+    float cx, cy;
+    mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
+    if (cz <= 0) return false;
+    if (FAST_DIV && cz >= 1e-4f) {  // (wave-uniform in practice; tiny cz would overflow the unscaled sequence)
+        const float rz = refined_rcp(cz);
+        ix = div_shared(s.fx * cx, cz, rz) + s.cx;
+        iy = div_shared(s.fy * cy, cz, rz) + s.cy;
+    } else {
+        ix = s.fx * cx / cz + s.cx;
+        iy = s.fy * cy / cz + s.cy;
+    }
+    return !((ix < 1) || (ix > W - 2) || (iy < 1) || (iy > H - 2));
+}
+
 template <bool FAST_DIV>
 __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
+    __shared__ uint16_t queue[4][BLK3];  // per wave: (slice << 6 | lane) of the voxels that take the colour update
     const int n_visible = s.counters[GPS_TSDF_N_VISIBLE];
     const int lane = threadIdx.x & 63;
     const int lx = lane & 7, ly = lane >> 3;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint16_t* q = queue[threadIdx.x >> 6];
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int W = s.width, H = s.height;
     const float mu = s.mu;
     const float inv_mu = 1.0f / mu;                       // RN(1/mu), RN(1/255), RN(1/32767) for div_known
@@ -336,79 +362,91 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
         uint64_t* blk = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + lane;
         const float pmx = (float)(he.x * BLK + lx) * s.voxel_size;
         const float pmy = (float)(he.y * BLK + ly) * s.voxel_size;
+        int n_tasks = 0;
+        // ---- phase 1: depth / weight of every voxel
 #pragma unroll 2
         for (int lz = 0; lz < BLK; lz++) {
             uint64_t* slot = blk + lz * 64;
             const float pmz = (float)(he.z * BLK + lz) * s.voxel_size;
-            float cx, cy, cz;
-            mul_point(M, pmx, pmy, pmz, 1.0f, cx, cy, cz);
-            if (cz <= 0) continue;
-            float ix, iy;
-            if (FAST_DIV && cz >= 1e-4f) {  // (wave-uniform in practice; tiny cz would overflow the unscaled sequence)
-                const float rz = refined_rcp(cz);
-                ix = div_shared(s.fx * cx, cz, rz) + s.cx;
-                iy = div_shared(s.fy * cy, cz, rz) + s.cy;
-            } else {
-                ix = s.fx * cx / cz + s.cx;
-                iy = s.fy * cy / cz + s.cy;
-            }
-            if ((ix < 1) || (ix > W - 2) || (iy < 1) || (iy > H - 2)) continue;
-            const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
-            if (dm <= 0.0f) continue;
-            const float eta = dm - cz;
-            if (eta < -mu) continue;
-            uint64_t raw = *slot;
-            // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
-            const int16_t sdf = (int16_t)(raw & 0xFFFF);
-            const int oldW = (int)((raw >> 16) & 0xFF);
-            float oldF = FAST_DIV ? div_known((float)sdf, 32767.0f, inv_32767) : (float)sdf / 32767.0f;
-            const float eta_mu = FAST_DIV ? div_known(eta, mu, inv_mu) : eta / mu;
-            float newF = (1.0f < eta_mu) ? 1.0f : eta_mu;
-            int newW = 1;
-            newF = oldW * oldF + newW * newF;
-            newW = oldW + newW;
-            if (FAST_DIV) { const float fw = (float)newW; newF = div_shared(newF, fw, refined_rcp(fw)); }
-            else newF /= newW;
-            newW = (newW < s.max_w) ? newW : s.max_w;
-            raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
-            if (!((eta > mu) || (fabsf(eta_mu) > 0.25f))) {
-                // colour: rgb camera == depth camera (trafo_rgb_to_depth is identity, InfiniTAM_tools.cpp:6-10), so the
-                // colour projection repeats the depth projection's rounding sequence exactly
-                const int px = (int)floorf(ix), py = (int)floorf(iy);
-                const float dx = ix - (float)px, dy = iy - (float)py;
-                const uchar4 a = img[px + py * W];
-                uchar4 b = make_uchar4(0, 0, 0, 0), c = b, d = b;
-                if (dx != 0) b = img[(px + 1) + py * W];
-                if (dy != 0) c = img[px + (py + 1) * W];
-                if (dx != 0 && dy != 0) d = img[(px + 1) + (py + 1) * W];
-                const float oldWc = (float)((raw >> 48) & 0xFF);
-                const float sumW = oldWc + 1.0f;
-                const float maxWf = (float)(uint8_t)s.max_w;
-                const float cw = (sumW < maxWf) ? sumW : maxWf;
-                const float rsum = FAST_DIV ? refined_rcp(sumW) : 0.f;
-                uint64_t packed = 0;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float fa = k == 0 ? a.x : k == 1 ? a.y : a.z, fb = k == 0 ? b.x : k == 1 ? b.y : b.z;
-                    const float fc = k == 0 ? c.x : k == 1 ? c.y : c.z, fd = k == 0 ? d.x : k == 1 ? d.y : d.z;
-                    // ((a*(1-dx))*(1-dy) + (b*dx)*(1-dy)) + (c*(1-dx))*dy) + (d*dx)*dy  (ITMPixelUtils.h:25-26)
-                    const float m = ((fa * (1.0f - dx) * (1.0f - dy) + fb * dx * (1.0f - dy)) + fc * (1.0f - dx) * dy) +
-                                    fd * dx * dy;
-                    const float oldByte = (float)((raw >> (24 + 8 * k)) & 0xFF);
-                    const float meas = FAST_DIV ? div_known(m, 255.0f, inv_255) : m / 255.0f;
-                    const float oldC = FAST_DIV ? div_known(oldByte, 255.0f, inv_255) : oldByte / 255.0f;
-                    float newC = oldC * oldWc + meas * 1.0f;
-                    if (FAST_DIV) newC = div_shared(newC, sumW, rsum);
-                    else newC /= sumW;
-                    const float sc = newC * 255.0f;
-                    int vi = (int)((sc < 0) ? (sc - 0.5f) : (sc + 0.5f));
-                    vi = max(0, min(255, vi));
-                    packed |= (uint64_t)vi << (24 + 8 * k);
+            bool colour = false;
+            float cz, ix, iy;
+            if (project_voxel<FAST_DIV>(s, M, pmx, pmy, pmz, W, H, cz, ix, iy)) {
+                const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
+                const float eta = dm - cz;
+                if (dm > 0.0f && !(eta < -mu)) {
+                    uint64_t raw = *slot;
+                    // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
+                    const int16_t sdf = (int16_t)(raw & 0xFFFF);
+                    const int oldW = (int)((raw >> 16) & 0xFF);
+                    float oldF = FAST_DIV ? div_known((float)sdf, 32767.0f, inv_32767) : (float)sdf / 32767.0f;
+                    const float eta_mu = FAST_DIV ? div_known(eta, mu, inv_mu) : eta / mu;
+                    float newF = (1.0f < eta_mu) ? 1.0f : eta_mu;
+                    int newW = 1;
+                    newF = oldW * oldF + newW * newF;
+                    newW = oldW + newW;
+                    if (FAST_DIV) { const float fw = (float)newW; newF = div_shared(newF, fw, refined_rcp(fw)); }
+                    else newF /= newW;
+                    newW = (newW < s.max_w) ? newW : s.max_w;
+                    raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
+                    *slot = raw;
+                    colour = !((eta > mu) || (fabsf(eta_mu) > 0.25f));
                 }
-                raw = (raw & ~0x00FFFFFFFF000000ull) | packed | ((uint64_t)(uint8_t)cw << 48);
             }
+            const unsigned long long need = __ballot(colour);
+            if (colour) q[n_tasks + __popcll(need & lt)] = (uint16_t)((lz << 6) | lane);
+            n_tasks += __popcll(need);
+        }
+        // ---- phase 2: colour of the queued voxels, 64 at a time (one wave's own LDS queue: a wave-level fence, no barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < n_tasks; t0 += 64) {
+            if (t0 + lane >= n_tasks) continue;
+            const int id = q[t0 + lane];
+            const int lz = id >> 6, l2 = id & 63;
+            uint64_t* slot = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + l2 + lz * 64;
+            const float vx = (float)(he.x * BLK + (l2 & 7)) * s.voxel_size;
+            const float vy = (float)(he.y * BLK + (l2 >> 3)) * s.voxel_size;
+            const float vz = (float)(he.z * BLK + lz) * s.voxel_size;
+            float cz, ix, iy;
+            project_voxel<FAST_DIV>(s, M, vx, vy, vz, W, H, cz, ix, iy);  // passed in phase 1: same operations, same values
+            uint64_t raw = *slot;
+            // colour: rgb camera == depth camera (trafo_rgb_to_depth is identity, InfiniTAM_tools.cpp:6-10), so the
+            // colour projection repeats the depth projection's rounding sequence exactly
+            const int px = (int)floorf(ix), py = (int)floorf(iy);
+            const float dx = ix - (float)px, dy = iy - (float)py;
+            const uchar4 a = img[px + py * W];
+            uchar4 b = make_uchar4(0, 0, 0, 0), c = b, d = b;
+            if (dx != 0) b = img[(px + 1) + py * W];
+            if (dy != 0) c = img[px + (py + 1) * W];
+            if (dx != 0 && dy != 0) d = img[(px + 1) + (py + 1) * W];
+            const float oldWc = (float)((raw >> 48) & 0xFF);
+            const float sumW = oldWc + 1.0f;
+            const float maxWf = (float)(uint8_t)s.max_w;
+            const float cw = (sumW < maxWf) ? sumW : maxWf;
+            const float rsum = FAST_DIV ? refined_rcp(sumW) : 0.f;
+            uint64_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float fa = k == 0 ? a.x : k == 1 ? a.y : a.z, fb = k == 0 ? b.x : k == 1 ? b.y : b.z;
+                const float fc = k == 0 ? c.x : k == 1 ? c.y : c.z, fd = k == 0 ? d.x : k == 1 ? d.y : d.z;
+                // ((a*(1-dx))*(1-dy) + (b*dx)*(1-dy)) + (c*(1-dx))*dy) + (d*dx)*dy  (ITMPixelUtils.h:25-26)
+                const float m = ((fa * (1.0f - dx) * (1.0f - dy) + fb * dx * (1.0f - dy)) + fc * (1.0f - dx) * dy) +
+                                fd * dx * dy;
+                const float oldByte = (float)((raw >> (24 + 8 * k)) & 0xFF);
+                const float meas = FAST_DIV ? div_known(m, 255.0f, inv_255) : m / 255.0f;
+                const float oldC = FAST_DIV ? div_known(oldByte, 255.0f, inv_255) : oldByte / 255.0f;
+                float newC = oldC * oldWc + meas * 1.0f;
+                if (FAST_DIV) newC = div_shared(newC, sumW, rsum);
+                else newC /= sumW;
+                const float sc = newC * 255.0f;
+                int vi = (int)((sc < 0) ? (sc - 0.5f) : (sc + 0.5f));
+                vi = max(0, min(255, vi));
+                packed |= (uint64_t)vi << (24 + 8 * k);
+            }
+            raw = (raw & ~0x00FFFFFFFF000000ull) | packed | ((uint64_t)(uint8_t)cw << 48);
             *slot = raw;
         }
+        __builtin_amdgcn_wave_barrier();  // the queue is reused by the wave's next block
     }
 }
 
