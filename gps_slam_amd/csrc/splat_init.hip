@@ -270,6 +270,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a, const in
     }
 }
 
+// uchar4 frame -> float3 image in [0, 1]: tensor.slice(2, 0, 3).to(float).div_(255) (x * RN(1/255)) in one launch
+__global__ __launch_bounds__(256) void rgba8_to_rgbf_kernel(int P, const uchar4* __restrict__ src, float* __restrict__ dst) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uchar4 c = src[p];
+    const float k = (float)(1.0 / 255.0);
+    dst[3 * p] = (float)c.x * k; dst[3 * p + 1] = (float)c.y * k; dst[3 * p + 2] = (float)c.z * k;
+}
+
 __global__ __launch_bounds__(64) void upload_floats_kernel(SmallFloats v, int n, float* __restrict__ dst) {
     if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
 }
@@ -381,6 +390,16 @@ int gps_gather_rows(int m, const int32_t* ids, int n_tensors, const float* const
     for (int k = n_tensors; k < 8; k++) { a.src[k] = srcs[0]; a.dst[k] = dsts[0]; a.row[k] = 1; a.end[k] = run; }
     a.n = n_tensors;
     gather_rows_kernel<<<(int)min((int64_t)8192, (int64_t)gps_div_up(run, 256)), 256, 0, (hipStream_t)stream>>>(a, ids);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_rgba8_to_rgbf(int n_pixels, const uint8_t* rgba, float* rgb, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(n_pixels >= 0);
+    if (n_pixels == 0) return GPS_OK;
+    GPS_REQUIRE(rgba && rgb && (((uintptr_t)rgba) & 3) == 0);
+    rgba8_to_rgbf_kernel<<<gps_div_up(n_pixels, 256), 256, 0, (hipStream_t)stream>>>(n_pixels, reinterpret_cast<const uchar4*>(rgba), rgb);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

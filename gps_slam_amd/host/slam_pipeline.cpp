@@ -338,7 +338,10 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
         if (!cam.image.defined()) {
             // no float copy of the image was kept for this camera: derive it from the uchar4 frame UpdateView just put into HBM
             // (3 of its 4 bytes per pixel) instead of uploading 12 more bytes per pixel as Camera::toGPU would
-            cam.image = main_engine->currentRgb().slice(2, 0, 3).to(torch::kFloat32).div_(255.0f);
+            auto rgba = main_engine->currentRgb();  // [H,W,4] u8, contiguous
+            cam.image = torch::empty({rgba.size(0), rgba.size(1), 3}, f32(rgba.device()));
+            check(gps_rgba8_to_rgbf((int)(rgba.size(0) * rgba.size(1)), ptr<uint8_t>(rgba), fptr(cam.image), current_stream()),
+                  "gps_rgba8_to_rgbf");
         }
     }
     // est_pose = pose_d->GetInvM() (:81-82): ORUtils column-major -> row-major tensor

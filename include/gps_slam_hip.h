@@ -348,6 +348,11 @@ GPS_API int gps_gather_rows(int m, const int32_t *ids, int n_tensors, const floa
  * normal_map[H,W,3] (Sobel, replicate padding, cross(dy,dx) normalised, 0 where vertex z <= 0). */
 GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float *normal_map, gps_stream stream);
 
+/* uchar4 frame -> float image: rgb[p, c] = rgba[p, c] * (1/255), c < 3 (what Camera::toGPU's image / 255 amounts to when
+ * the frame is already in HBM as the uchar4 image UpdateView uploaded: 3 of its 4 bytes per pixel instead of a second
+ * 12-byte-per-pixel upload). */
+GPS_API int gps_rgba8_to_rgbf(int n_pixels, const uint8_t *rgba, float *rgb, gps_stream stream);
+
 /* Uploads up to 64 floats from host memory into device memory THROUGH THE KERNEL ARGUMENT BUFFER (values are read on the host at
  * call time; no pinned staging, no copy-engine transfer, ordered on `stream` like any kernel).  Camera::toGPU() uses it for the
  * 28-float viewmat | K | camera position pack of every frame: a hipMemcpyAsync of that size costs ~15 us of copy-engine latency
