@@ -401,3 +401,16 @@ def test_prune_mask_and_row_gather_match_the_tensor_sequence():
                                (C.c_int32 * 6)(*rows), st) == 0
     for s_, d_ in zip(srcs, dsts):
         assert torch.equal(d_[:m], s_[ids.long()]) and bool(torch.isnan(d_[m:]).all())
+
+
+def test_rgba8_to_rgbf_equals_the_tensor_sequence():
+    """gps_rgba8_to_rgbf == frame[..., :3].to(float32).div_(255) bit for bit (all 256 byte values)."""
+    from gps_slam_amd._lib import lib
+    H, W = 37, 50
+    g = torch.Generator().manual_seed(2)
+    rgba = torch.randint(0, 256, (H, W, 4), generator=g, dtype=torch.uint8)
+    rgba.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
+    rgba = rgba.to(DEV)
+    out = torch.empty(H, W, 3, device=DEV)
+    assert lib.gps_rgba8_to_rgbf(H * W, rgba.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(out, rgba[..., :3].to(torch.float32).div_(255.0))
