@@ -26,8 +26,11 @@ def timed(fn, reps=30):
     return e0.elapsed_time(e1) / reps * 1e3
 t_live = timed(lambda: lib.gps_tsdf_raycast(C.byref(eng.state), invM.ctypes.data, 0, 0, None))
 same = torch.equal(eng.GetLiveVertex(), ref)
+import hashlib
+digest = hashlib.sha1(eng.GetLiveVertex().cpu().numpy().tobytes()).hexdigest()[:12]
 M2, invM2 = pose_from_c2w(seq["c2w"][n - 15])
 t_free = timed(lambda: lib.gps_tsdf_free_raycast(C.byref(eng.state), M2.ctypes.data, invM2.ctypes.data, None))
 mm = eng.minmax.view(H, W, 2)[:H // 8, :W // 8].cpu().numpy()
 print("   minmax window: zmin mean %.2f zmax mean %.2f; visible blocks %d" % (mm[..., 0].mean(), mm[..., 1].mean(), int(eng.counters.cpu()[2])))
+print("   live vertex map sha1 %s" % digest)
 print("%s: live raycast %.1f us (output unchanged: %s), free-view raycast call %.1f us" % (os.environ.get("GPS_SLAM_HIP_LIB", "default"), t_live, same, t_free))
