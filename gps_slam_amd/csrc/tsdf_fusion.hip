@@ -356,41 +356,67 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
     const float inv_mu = 1.0f / mu;                       // RN(1/mu), RN(1/255), RN(1/32767) for div_known
     const float inv_255 = 1.0f / 255.0f, inv_32767 = 1.0f / 32767.0f;
     const uchar4* img = reinterpret_cast<const uchar4*>(s.rgb);
+    // the entry of the wave's next block and the list word of the one after it are fetched under the current block's loads
+    // (clamped indices: the loads stay unconditional)
+    HashEntry he_next = {};
+    int id_after = 0;
+    if (wave < n_visible) {
+        he_next = load_entry(s.hash, s.visible_ids[wave]);
+        id_after = s.visible_ids[min(wave + n_waves, n_visible - 1)];
+    }
     for (int e = wave; e < n_visible; e += n_waves) {
-        const HashEntry he = load_entry(s.hash, s.visible_ids[e]);
-        if (he.ptr < 0) continue;  // uniform across the wave
+        const HashEntry he = he_next;
+        if (he.ptr < 0) {  // uniform across the wave
+            he_next = load_entry(s.hash, id_after);
+            id_after = s.visible_ids[min(e + 2 * n_waves, n_visible - 1)];
+            continue;
+        }
         uint64_t* blk = reinterpret_cast<uint64_t*>(s.vba + (size_t)he.ptr * BLK3) + lane;
         const float pmx = (float)(he.x * BLK + lx) * s.voxel_size;
         const float pmy = (float)(he.y * BLK + ly) * s.voxel_size;
         int n_tasks = 0;
-        // ---- phase 1: depth / weight of every voxel
-#pragma unroll 2
+        // ---- phase 1: depth / weight of every voxel.  The block's 4 KB are read unconditionally (coalesced, 8 loads) while
+        // the eight projections run, and the eight depth gathers go out as one batch: three dependent round trips per block
+        // (entry, voxels + depths, stores) instead of two per slice -- the kernel is bound by that chain, not by bytes
+        uint64_t raw8[BLK];
+        float cz8[BLK], dm8[BLK];
+        int at8[BLK];
+        bool ok8[BLK];
+#pragma unroll
+        for (int lz = 0; lz < BLK; lz++) raw8[lz] = blk[lz * 64];
+#pragma unroll
         for (int lz = 0; lz < BLK; lz++) {
-            uint64_t* slot = blk + lz * 64;
             const float pmz = (float)(he.z * BLK + lz) * s.voxel_size;
+            float ix = 0.f, iy = 0.f;
+            ok8[lz] = project_voxel<FAST_DIV>(s, M, pmx, pmy, pmz, W, H, cz8[lz], ix, iy);
+            at8[lz] = ok8[lz] ? (int)(ix + 0.5f) + (int)(iy + 0.5f) * W : 0;
+        }
+#pragma unroll
+        for (int lz = 0; lz < BLK; lz++) dm8[lz] = s.depth[at8[lz]];
+        he_next = load_entry(s.hash, id_after);
+        id_after = s.visible_ids[min(e + 2 * n_waves, n_visible - 1)];
+#pragma unroll
+        for (int lz = 0; lz < BLK; lz++) {
             bool colour = false;
-            float cz, ix, iy;
-            if (project_voxel<FAST_DIV>(s, M, pmx, pmy, pmz, W, H, cz, ix, iy)) {
-                const float dm = s.depth[(int)(ix + 0.5f) + (int)(iy + 0.5f) * W];
-                const float eta = dm - cz;
-                if (dm > 0.0f && !(eta < -mu)) {
-                    uint64_t raw = *slot;
-                    // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
-                    const int16_t sdf = (int16_t)(raw & 0xFFFF);
-                    const int oldW = (int)((raw >> 16) & 0xFF);
-                    float oldF = FAST_DIV ? div_known((float)sdf, 32767.0f, inv_32767) : (float)sdf / 32767.0f;
-                    const float eta_mu = FAST_DIV ? div_known(eta, mu, inv_mu) : eta / mu;
-                    float newF = (1.0f < eta_mu) ? 1.0f : eta_mu;
-                    int newW = 1;
-                    newF = oldW * oldF + newW * newF;
-                    newW = oldW + newW;
-                    if (FAST_DIV) { const float fw = (float)newW; newF = div_shared(newF, fw, refined_rcp(fw)); }
-                    else newF /= newW;
-                    newW = (newW < s.max_w) ? newW : s.max_w;
-                    raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
-                    *slot = raw;
-                    colour = !((eta > mu) || (fabsf(eta_mu) > 0.25f));
-                }
+            const float dm = dm8[lz];
+            const float eta = dm - cz8[lz];
+            if (ok8[lz] && dm > 0.0f && !(eta < -mu)) {
+                uint64_t raw = raw8[lz];
+                // unpack {short sdf; uchar w_depth; uchar clr[3]; uchar w_color; pad}
+                const int16_t sdf = (int16_t)(raw & 0xFFFF);
+                const int oldW = (int)((raw >> 16) & 0xFF);
+                float oldF = FAST_DIV ? div_known((float)sdf, 32767.0f, inv_32767) : (float)sdf / 32767.0f;
+                const float eta_mu = FAST_DIV ? div_known(eta, mu, inv_mu) : eta / mu;
+                float newF = (1.0f < eta_mu) ? 1.0f : eta_mu;
+                int newW = 1;
+                newF = oldW * oldF + newW * newF;
+                newW = oldW + newW;
+                if (FAST_DIV) { const float fw = (float)newW; newF = div_shared(newF, fw, refined_rcp(fw)); }
+                else newF /= newW;
+                newW = (newW < s.max_w) ? newW : s.max_w;
+                raw = (raw & ~0xFFFFFFull) | (uint64_t)(uint16_t)(int16_t)(newF * 32767.0f) | ((uint64_t)(uint8_t)newW << 16);
+                blk[lz * 64] = raw;
+                colour = !((eta > mu) || (fabsf(eta_mu) > 0.25f));
             }
             const unsigned long long need = __ballot(colour);
             if (colour) q[n_tasks + __popcll(need & lt)] = (uint16_t)((lz << 6) | lane);
@@ -414,11 +440,14 @@ __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
             // colour projection repeats the depth projection's rounding sequence exactly
             const int px = (int)floorf(ix), py = (int)floorf(iy);
             const float dx = ix - (float)px, dy = iy - (float)py;
+            // the four taps go out together (1 <= ix <= W-2: all in the image); the reference reads b, c, d only when their
+            // weight is non-zero and uses 0 otherwise
             const uchar4 a = img[px + py * W];
-            uchar4 b = make_uchar4(0, 0, 0, 0), c = b, d = b;
-            if (dx != 0) b = img[(px + 1) + py * W];
-            if (dy != 0) c = img[px + (py + 1) * W];
-            if (dx != 0 && dy != 0) d = img[(px + 1) + (py + 1) * W];
+            uchar4 b = img[(px + 1) + py * W], c = img[px + (py + 1) * W], d = img[(px + 1) + (py + 1) * W];
+            const uchar4 zero4 = make_uchar4(0, 0, 0, 0);
+            if (!(dx != 0)) b = zero4;
+            if (!(dy != 0)) c = zero4;
+            if (!(dx != 0 && dy != 0)) d = zero4;
             const float oldWc = (float)((raw >> 48) & 0xFF);
             const float sumW = oldWc + 1.0f;
             const float maxWf = (float)(uint8_t)s.max_w;
@@ -543,8 +572,11 @@ int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stre
     TsdfState s = *sp;
     // persistent grid of 8192 waves (one block per wave at a time), strides over the visible list
     // the fast exact divisions need mu's significand not to be all ones (div_known_safe); any other mu takes the generic path
-    if (div_known_safe(s.mu)) integrate_kernel<true><<<2048, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
-    else integrate_kernel<false><<<2048, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
+#ifndef GPS_INTEGRATE_WGS
+#define GPS_INTEGRATE_WGS 4096
+#endif
+    if (div_known_safe(s.mu)) integrate_kernel<true><<<GPS_INTEGRATE_WGS, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
+    else integrate_kernel<false><<<GPS_INTEGRATE_WGS, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

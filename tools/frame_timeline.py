@@ -1,17 +1,18 @@
-"""Kernel timeline of ONE frame (convert_depth .. next convert_depth) inside the first timed region of a bench.py
-kernel trace (rocprofv3 --kernel-trace rocpd database).  usage: frame_timeline.py <db> [frame index in the region]"""
-import glob, sqlite3, sys
+"""Timeline of ONE tracked frame from a rocprofv3 --kernel-trace rocpd database: every kernel between two consecutive
+track_prepare launches near the end of the run, with its start offset, duration and the idle gap in front of it.
+usage: frame_timeline.py <db> [frames from the end, default 5]"""
+import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1])
-k = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-rows = db.execute("select name,start,end from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if "spin_kernel" in r[0]]
-sel = rows[marks[0]:marks[1]]
-idx = [i for i, r in enumerate(sel) if "convert_depth" in r[0]]
-i0, i1 = idx[k], idx[k + 1]
-t0 = sel[i0][1]
-prev_end = t0
-for r in sel[i0:i1]:
-    n = r[0].replace("(anonymous namespace)::", "").split("(")[0][:44]
-    print("%-46s start %8.1f us  dur %6.1f  gap %5.1f" % (n, (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[1] - prev_end) / 1e3))
-    prev_end = r[2]
-print("frame: %.1f us" % ((sel[i1][1] - t0) / 1e3))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+rows = list(db.execute("select name,start,end,stream_id from kernels order by start")) if any(
+    r[1] == "stream_id" for r in db.execute("pragma table_info(kernels)")) else [
+    (n, s, e, 0) for n, s, e in db.execute("select name,start,end from kernels order by start")]
+prep = [i for i, r in enumerate(rows) if "track_prepare" in r[0]]
+a, b = prep[-back - 1], prep[-back]
+t0, last_end = rows[a][1], rows[a][1]
+busy = 0
+for n, s, e, st in rows[a:b]:
+    k = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("void ", ""))[:44]
+    print("%8.1f us  +%6.1f gap  %7.1f us  s%-3s %s" % ((s - t0) / 1e3, (s - last_end) / 1e3, (e - s) / 1e3, st, k))
+    last_end = max(last_end, e); busy += e - s
+print("frame %.1f us, kernels %.1f us" % ((rows[b][1] - t0) / 1e3, busy / 1e3))
