@@ -317,41 +317,59 @@ struct __attribute__((aligned(16))) BwdRec {
     float inv_bw;            // 1 / bw: (pid + 0.5) * inv_bw truncates to pid / bw exactly for pid < 2^16
 };
 
-constexpr int BWD_INFLIGHT = 2;
-struct BwdPix { bool on; float alpha, vis, dx, dy; float4 vc; float va; };
+#ifndef GPS_BWD_INFLIGHT
+#define GPS_BWD_INFLIGHT 2
+#endif
+constexpr int BWD_INFLIGHT = GPS_BWD_INFLIGHT;
+struct BwdPix { bool on; float alpha, vis, dx, dy, cut; float4 vc; float va; };
 
-struct BwdPixSrc {
+struct BwdPixArgs {  // kernel arguments
     const float* ref_depth;
     const float4* v_render_colors;
     const float* v_render_alphas;
     float delta_depth;
 };
+struct BwdPixSrc {  // the three per-pixel arrays as buffer resources (W * H elements each)
+    __amdgpu_buffer_rsrc_t ref_depth, v_render_colors, v_render_alphas;
+    float delta_depth;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pixel_buffer(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);  // raw dword buffer, stride 0
+}
 
+// Straight-line on purpose.  With the gathers under the alpha-test branch and their use under bwd_accum's branch, the
+// compiler cannot tell at the loop's back edge whether a gather is still pending and guards the next step's address
+// registers with s_waitcnt vmcnt(0) -- which (vmcnt counts in order) also waits for the gathers the previous step has just
+// issued: one full memory round trip per step, SQ_WAIT_ANY 55 %.  Here every lane always loads (slots that fail the test
+// read pixel 0: one extra address per wave), and bwd_landed() makes the arrival of a step's three values an unconditional
+// point of the loop, so two steps' gathers are really in flight together.
 __device__ __forceinline__ void bwd_eval(const BwdRec& R, int hl, int W, int H, const BwdPixSrc& src, BwdPix& o) {
-    o.on = false;
-    if (R.gs_id < 0) return;
     const uint32_t pid = (uint32_t)R.pid0 + (uint32_t)hl;
     const int q = (int)(((float)pid + 0.5f) * R.inv_bw);  // pid / bw
     const int j = R.x0 + ((int)pid - q * R.bw);
     const int i = R.y0 + q;
-    if (!((i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw))) return;
-    const int pix = i * W + j;
+    const bool inside = (R.gs_id >= 0) && (i < H) && (j < W) && (i >= 0) && (j >= 0) && (q < R.bw);
     const float px = (float)j + 0.5f, py = (float)i + 0.5f;
     o.dx = R.x - px; o.dy = R.y - py;
     const float sigma = 0.5f * (R.ca * o.dx * o.dx + R.cc * o.dy * o.dy) + R.cb * o.dx * o.dy;
     o.vis = __expf(-sigma);
     o.alpha = fminf(0.999f, R.opac * o.vis);
-    // the three per-pixel gathers (24 bytes from three arrays) only for slots that pass the alpha test: the {alpha >= 1/255}
-    // ellipse fills 45 % of the 2r x 2r box the groups enumerate (tools/raster_bench.py), the rest would fetch and discard
-    if ((sigma < 0.f) || (o.alpha < 1.f / 255.f)) return;
-    const float cut = src.ref_depth[pix] + src.delta_depth;
-    o.vc = src.v_render_colors[pix];
-    o.va = src.v_render_alphas[pix];
-    o.on = !(R.depth > cut);
+    // the {alpha >= 1/255} ellipse fills 45 % of the 2r x 2r box the groups enumerate (tools/raster_bench.py)
+    o.on = inside && !((sigma < 0.f) || (o.alpha < 1.f / 255.f));
+    // raw buffer loads: a 32-bit byte offset per lane instead of three 64-bit addresses, and a slot that fails the test
+    // passes an out-of-range offset -- the load returns 0 without touching memory
+    const uint32_t pix = o.on ? (uint32_t)(i * W + j) : 0x0FFFFFFFu;
+    o.cut = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src.ref_depth, pix * 4u, 0, 0));  // (tested in bwd_accum)
+    o.vc = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(src.v_render_colors, pix * 16u, 0, 0));
+    o.va = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src.v_render_alphas, pix * 4u, 0, 0));
 }
 
-__device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, Acc& acc) {
-    if (!p.on) return;
+__device__ __forceinline__ void bwd_landed(BwdPix& p) {
+    asm volatile("" : "+v"(p.cut), "+v"(p.va), "+v"(p.vc.x), "+v"(p.vc.y), "+v"(p.vc.z), "+v"(p.vc.w));
+}
+
+__device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, float delta_depth, Acc& acc) {
+    if (!p.on || R.depth > p.cut + delta_depth) return;
     acc.c0 += p.alpha * p.vc.x; acc.c1 += p.alpha * p.vc.y; acc.c2 += p.alpha * p.vc.z; acc.c3 += p.alpha * p.vc.w;
     const float v_alpha = R.r * p.vc.x + R.g * p.vc.y + R.b * p.vc.z + R.depth * p.vc.w + p.va;
     if (R.opac * p.vis <= 0.999f) {
@@ -368,10 +386,13 @@ __device__ __forceinline__ void bwd_accum(const BwdRec& R, const BwdPix& p, Acc&
 __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
     const int32_t* __restrict__ group_gs_ids, const int32_t* __restrict__ group_starts,
     const float2* __restrict__ means2d, const float* __restrict__ conics, const float4* __restrict__ colors,
-    const float* __restrict__ opacities, const int32_t* __restrict__ radiis, BwdPixSrc src,
+    const float* __restrict__ opacities, const int32_t* __restrict__ radiis, BwdPixArgs pix_args,
     const int64_t* __restrict__ counts, int W, int H, float* __restrict__ v_means2d, float* __restrict__ v_conics,
     float* __restrict__ v_colors, float* __restrict__ v_opacities, int plain_ok) {
     __shared__ BwdRec recs[4][2][16];  // [wave][half][step]
+    const uint32_t n_px = (uint32_t)(W * H);
+    const BwdPixSrc src = {pixel_buffer(pix_args.ref_depth, n_px * 4u), pixel_buffer(pix_args.v_render_colors, n_px * 16u),
+                           pixel_buffer(pix_args.v_render_alphas, n_px * 4u), pix_args.delta_depth};
     const int n_groups = (int)counts[1];
     const int n_tasks = (n_groups + 31) >> 5;
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
@@ -428,7 +449,8 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
                     first_seg = cur_g < 0;  // still no Gaussian seen (cannot happen after a real segment)
                     cur_g = R.gs_id;
                 }
-                bwd_accum(R, p[u], acc);
+                bwd_landed(p[u]);
+                bwd_accum(R, p[u], src.delta_depth, acc);
             }
         }
         if (cur_g >= 0) flush_acc(acc, cur_g, hl, false, v_means2d, v_conics, v_colors, v_opacities);
@@ -475,7 +497,7 @@ int raster_ges_bwd_gs_launch(int N, const float* means2d, const float* conics, c
         zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
                                                                                      v_opacities);
     constexpr int bwd_blocks = 4096;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
-    BwdPixSrc src = {ref_depth_map, (const float4*)v_render_colors, v_render_alphas, delta_depth};
+    BwdPixArgs src = {ref_depth_map, (const float4*)v_render_colors, v_render_alphas, delta_depth};
     // plain stores where a half-wave owns a Gaussian: only if the buffers are known to be zero (filled here or by the caller)
     raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
                                                         (const float4*)colors, opacities, radii, src, counts, width, height,

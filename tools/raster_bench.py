@@ -40,10 +40,11 @@ p = lambda t: C.c_void_p(t.data_ptr())
 ref, N = rc["depth_map_clamped"], st.N
 fwd = lambda: lib.gps_raster_ges_fwd_rec(N, p(B["records"]), p(ref), W, H, p(B["tile_offsets"]), p(B["flatten_ids"]), p(B["counts"]),
                                          model.delta_depth, p(B["render_colors"]), p(B["weight_sum"]), sp)
-bwd = lambda: lib.gps_raster_ges_bwd_gs(N, p(B["means2d"]), p(B["conics"]), p(B["colors"]), p(B["opacities"]), p(B["radii"]), p(ref), W, H,
+bwd_of = lambda L: lambda: L.gps_raster_ges_bwd_gs(N, p(B["means2d"]), p(B["conics"]), p(B["colors"]), p(B["opacities"]), p(B["radii"]), p(ref), W, H,
                                         p(B["group_gs_ids"]), p(B["group_starts"]), p(B["counts"]), model.delta_depth,
                                         p(B["v_render_colors"]), p(B["v_render_alphas"]), p(B["v_means2d"]), p(B["v_conics"]),
                                         p(B["v_colors"]), p(B["v_opacities"]), 1, sp)
+bwd = bwd_of(lib)
 alt = os.environ.get("GPS_ALT_LIB")  # a second build of the library: same inputs through both, outputs compared bit for bit
 if alt:
     from gps_slam_amd._lib import load_library
@@ -55,6 +56,14 @@ if alt:
     torch.cuda.synchronize()
     print("forward: %s == %s bit for bit: %s" % (os.environ.get("GPS_SLAM_HIP_LIB", "default"), alt,
                                                  bool(torch.equal(a_rc, B["render_colors"]) and torch.equal(a_ws, B["weight_sum"]))))
+    grads = lambda: [B[k][:st.N].clone() for k in ("v_means2d", "v_conics", "v_colors", "v_opacities")]
+    def zero():
+        for k in ("v_means2d", "v_conics", "v_colors", "v_opacities"): B[k].zero_()
+    zero(); bwd(); torch.cuda.synchronize(); ga = grads()
+    zero(); bwd_of(lib2)(); torch.cuda.synchronize(); gb = grads()
+    print("backward: max |difference| per array (float atomics: order-dependent last bits) %s" %
+          ["%.2e / %.2e" % (float((x - y).abs().max()), float(x.abs().max())) for x, y in zip(ga, gb)])
+    print("%-42s %.1f us" % ("raster bwd, " + os.path.basename(alt), 1e6 * _time_launches(bwd_of(lib2), 50, stream)))
 for name, fn, n in (("raster fwd (records)", fwd, 50), ("raster bwd (operator entry: 3 gathers)", bwd, 50), ("whole train step", step, 20)):
     print("%-42s %.1f us" % (name, 1e6 * _time_launches(fn, n, stream)))
 scene.close()
