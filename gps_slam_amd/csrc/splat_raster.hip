@@ -169,28 +169,44 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
         // wave-uniform bounds -> scalar loop counter
         const int lo = __builtin_amdgcn_readfirstlane(list_half ? (n >> 1) : 0);
         const int hi = __builtin_amdgcn_readfirstlane(list_half ? n : (n >> 1));
-#pragma unroll 2
-        for (int t = lo; t < hi; ++t) {
-            const float4 a = r0[t], b = r1[t];
-            const float2 c = r2[t];
-            const float dy = a.y - py;
-            const v2f dx = a.x - px;
-            const float cdy2 = b.x * dy * dy, bdy = a.w * dy;
-            const v2f w = a.z * dx + bdy;
-            const v2f sig = w * dx + cdy2;          // sigma * log2(e)
-            const v2f e = sig + b.y;                // sigma' - log2(opacity)
-            // Wave-uniform skip: if e > 8 for both pixels of every lane, no pixel of this wave's 16 x 8 half tile can reach
-            // alpha >= 1/255 (v_exp_f32 is within 1 ulp: exp2(-e) <= 2^-8 (1 + 2^-22) < 1/255), so the Gaussian adds exact
-            // zeros here -- and the two quarter-rate exponentials, the tests and the five packed accumulations are most of the
-            // body.  45 % of a tile's list entries do not reach a given half (radius-4.5 footprints on 16-pixel tiles):
-            // 81.6 -> 69.5 us, bit-identical output.
-            if (__builtin_amdgcn_ballot_w64(!(e.x > 8.0f) || !(e.y > 8.0f)) == 0) continue;
-            const float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.x));
-            const float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.y));
-            const bool hit0 = !(b.z > cut0) && !(sig.x < 0.f) && !(al0 < 1.f / 255.f);
-            const bool hit1 = !(b.z > cut1) && !(sig.y < 0.f) && !(al1 < 1.f / 255.f);
+        // Wave-uniform skip (test()): if e > 8 for both pixels of every lane, no pixel of this wave's 16 x 8 half tile can reach
+        // alpha >= 1/255 (v_exp_f32 is within 1 ulp: exp2(-e) <= 2^-8 (1 + 2^-22) < 1/255), so the Gaussian adds exact zeros
+        // here -- and the two quarter-rate exponentials, the tests and the five packed accumulations are most of the body.
+        // 45 % of a tile's list entries do not reach a given half (radius-4.5 footprints on 16-pixel tiles): 81.6 -> 69.5 us,
+        // bit-identical output.
+        // Two entries per trip, written out by hand (the skip keeps the compiler from unrolling): both records' LDS reads leave
+        // together and the two independent test chains fill each other's packed-FP32 dependency slots (4 s_nop per entry in
+        // the one-at-a-time loop); entries still accumulate in list order, so the sums are bit-identical.
+        struct Entry { float4 a, b; v2f sig, e; };
+        auto test = [&](Entry& g) -> bool {
+            const float dy = g.a.y - py;
+            const v2f dx = g.a.x - px;
+            const float cdy2 = g.b.x * dy * dy, bdy = g.a.w * dy;
+            const v2f w = g.a.z * dx + bdy;
+            g.sig = w * dx + cdy2;        // sigma * log2(e)
+            g.e = g.sig + g.b.y;          // sigma' - log2(opacity)
+            return __builtin_amdgcn_ballot_w64(!(g.e.x > 8.0f) || !(g.e.y > 8.0f)) != 0;
+        };
+        auto blend = [&](const Entry& g, const float2 c) {
+            const float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-g.e.x));
+            const float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-g.e.y));
+            const bool hit0 = !(g.b.z > cut0) && !(g.sig.x < 0.f) && !(al0 < 1.f / 255.f);
+            const bool hit1 = !(g.b.z > cut1) && !(g.sig.y < 0.f) && !(al1 < 1.f / 255.f);
             const v2f al = {hit0 ? al0 : 0.f, hit1 ? al1 : 0.f};
-            o0 += b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += b.z * al; ws += al;
+            o0 += g.b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += g.b.z * al; ws += al;
+        };
+        int t = lo;
+        for (; t + 1 < hi; t += 2) {
+            Entry g0, g1;
+            g0.a = r0[t]; g0.b = r1[t]; g1.a = r0[t + 1]; g1.b = r1[t + 1];
+            const bool k0 = test(g0), k1 = test(g1);
+            if (k0) blend(g0, r2[t]);
+            if (k1) blend(g1, r2[t + 1]);
+        }
+        if (t < hi) {
+            Entry g0;
+            g0.a = r0[t]; g0.b = r1[t];
+            if (test(g0)) blend(g0, r2[t]);
         }
     }
     // second list half -> LDS -> first list half adds and stores

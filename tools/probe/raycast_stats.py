@@ -1,4 +1,4 @@
-"""Raycaster step / time statistics on the bench scene (instrumented library variants of tools/probe/build_stats_lib.sh).
+"""Raycaster step / time statistics on the bench scene (instrumented library variants: tools/probe/variant.py stats tsdf_render.hip -DGPS_RAYCAST_STATS ...).
 usage (GPU box):  GPS_SLAM_HIP_LIB=tools/probe/libgps_stats.so python tools/probe/raycast_stats.py
                   GPS_SLAM_HIP_LIB=tools/probe/libgps_sections.so python tools/probe/raycast_stats.py sections"""
 import os, sys

@@ -63,7 +63,14 @@ if alt:
     zero(); bwd_of(lib2)(); torch.cuda.synchronize(); gb = grads()
     print("backward: max |difference| per array (float atomics: order-dependent last bits) %s" %
           ["%.2e / %.2e" % (float((x - y).abs().max()), float(x.abs().max())) for x, y in zip(ga, gb)])
-    print("%-42s %.1f us" % ("raster bwd, " + os.path.basename(alt), 1e6 * _time_launches(bwd_of(lib2), 50, stream)))
+    fwd2 = lambda: lib2.gps_raster_ges_fwd_rec(N, p(B["records"]), p(ref), W, H, p(B["tile_offsets"]), p(B["flatten_ids"]), p(B["counts"]),
+                                               model.delta_depth, p(B["render_colors"]), p(B["weight_sum"]), sp)
+    # alternate the two builds (whichever is timed first after a pause reads ~10 % slow): best of three rounds each
+    for what, f_a, f_b in (("raster bwd", bwd_of(lib2), bwd), ("raster fwd", fwd2, fwd)):
+        ta, tb = [], []
+        for _ in range(3):
+            ta.append(1e6 * _time_launches(f_a, 50, stream)); tb.append(1e6 * _time_launches(f_b, 50, stream))
+        print("%-12s %s %.1f us | default %.1f us" % (what, os.path.basename(alt), min(ta), min(tb)))
 for name, fn, n in (("raster fwd (records)", fwd, 50), ("raster bwd (operator entry: 3 gathers)", bwd, 50), ("whole train step", step, 20)):
     print("%-42s %.1f us" % (name, 1e6 * _time_launches(fn, n, stream)))
 scene.close()
