@@ -126,7 +126,12 @@ __device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int
     return fabsf(d0) + fabsf(d1) + fabsf(d2);
 }
 
-__global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
+#ifndef GPS_FWD_LIST_SPLIT
+#define GPS_FWD_LIST_SPLIT 4
+#endif
+constexpr int FWD_SPLIT = GPS_FWD_LIST_SPLIT;  // waves per pixel half: the tile's list is added in this many parts
+constexpr int FWD_THREADS = 128 * FWD_SPLIT;
+__global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
@@ -135,11 +140,11 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
     __shared__ float4 r0[BATCH];   // {mx, my, 0.5*ca*log2e, cb*log2e}
     __shared__ float4 r1[BATCH];   // {0.5*cc*log2e, -log2(opac), depth, r}
     __shared__ float2 r2[BATCH];   // {g, b}
-    __shared__ float part[128 * 10];
+    __shared__ float part[(FWD_SPLIT - 1) * 128 * 10];
     const int tile_id = blockIdx.x;
     const int ty = tile_id / tw, tx = tile_id - ty * tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int list_half = wave >> 1, pix_half = wave & 1;
+    const int list_part = wave >> 1, pix_half = wave & 1;
     const int row = ty * 16 + pix_half * 8 + (lane >> 3), col = tx * 16 + 2 * (lane & 7);
     const bool in0 = (row < H) && (col < W), in1 = (row < H) && (col + 1 < W);
     const v2f px = {(float)col + 0.5f, (float)col + 1.5f};
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
         __syncthreads();
         {
             const int idx = batch_start + tid;
-            if (idx < range_end) {
+            if (tid < BATCH && idx < range_end) {
                 const size_t g = (size_t)flatten_ids[idx];
                 const float4 a = recs[3 * g], b = recs[3 * g + 1], c = recs[3 * g + 2];
                 r0[tid] = make_float4(a.x, a.y, 0.5f * LOG2E * a.z, LOG2E * a.w);
@@ -167,8 +172,8 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
         __syncthreads();
         const int n = min(BATCH, range_end - batch_start);
         // wave-uniform bounds -> scalar loop counter
-        const int lo = __builtin_amdgcn_readfirstlane(list_half ? (n >> 1) : 0);
-        const int hi = __builtin_amdgcn_readfirstlane(list_half ? n : (n >> 1));
+        const int lo = __builtin_amdgcn_readfirstlane(list_part * n / FWD_SPLIT);
+        const int hi = __builtin_amdgcn_readfirstlane((list_part + 1) * n / FWD_SPLIT);
         // Wave-uniform skip (test()): if e > 8 for both pixels of every lane, no pixel of this wave's 16 x 8 half tile can reach
         // alpha >= 1/255 (v_exp_f32 is within 1 ulp: exp2(-e) <= 2^-8 (1 + 2^-22) < 1/255), so the Gaussian adds exact zeros
         // here -- and the two quarter-rate exponentials, the tests and the five packed accumulations are most of the body.
@@ -209,18 +214,25 @@ __global__ __launch_bounds__(256) void raster_ges_fwd_pk_kernel(
             if (test(g0)) blend(g0, r2[t]);
         }
     }
-    // second list half -> LDS -> first list half adds and stores
+    // list parts 1.. -> LDS -> part 0 adds them in order and stores
     const int slot = (pix_half * 64 + lane) * 10;
-    if (list_half) {
-        part[slot + 0] = o0.x; part[slot + 1] = o1.x; part[slot + 2] = o2.x; part[slot + 3] = o3.x; part[slot + 4] = ws.x;
-        part[slot + 5] = o0.y; part[slot + 6] = o1.y; part[slot + 7] = o2.y; part[slot + 8] = o3.y; part[slot + 9] = ws.y;
+    if (list_part) {
+        float* q = part + (list_part - 1) * 1280 + slot;
+        q[0] = o0.x; q[1] = o1.x; q[2] = o2.x; q[3] = o3.x; q[4] = ws.x;
+        q[5] = o0.y; q[6] = o1.y; q[7] = o2.y; q[8] = o3.y; q[9] = ws.y;
     }
     __syncthreads();
-    if (!list_half) {
+    if (!list_part) {
         const int pix = row * W + col;
-        const float4 c0 = make_float4(o0.x + part[slot + 0], o1.x + part[slot + 1], o2.x + part[slot + 2], o3.x + part[slot + 3]);
-        const float4 c1 = make_float4(o0.y + part[slot + 5], o1.y + part[slot + 6], o2.y + part[slot + 7], o3.y + part[slot + 8]);
-        const float w0 = ws.x + part[slot + 4], w1 = ws.y + part[slot + 9];
+#pragma unroll
+        for (int k = 0; k < FWD_SPLIT - 1; k++) {
+            const float* q = part + k * 1280 + slot;
+            o0.x += q[0]; o1.x += q[1]; o2.x += q[2]; o3.x += q[3]; ws.x += q[4];
+            o0.y += q[5]; o1.y += q[6]; o2.y += q[7]; o3.y += q[8]; ws.y += q[9];
+        }
+        const float4 c0 = make_float4(o0.x, o1.x, o2.x, o3.x);
+        const float4 c1 = make_float4(o0.y, o1.y, o2.y, o3.y);
+        const float w0 = ws.x, w1 = ws.y;
         if (in0) { render_colors[pix] = c0; render_alphas[pix] = w0; }
         if (in1) { render_colors[pix + 1] = c1; render_alphas[pix + 1] = w1; }
         if (fc.base_color) {
@@ -491,7 +503,7 @@ int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_dept
         GPS_REQUIRE(fc.base_color && fc.gt_rgb && fc.rgb && fc.loss && fc.v_render_colors && fc.v_render_alphas);
     }
     const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
-    raster_ges_fwd_pk_kernel<<<tw * th, 256, 0, (hipStream_t)stream>>>(
+    raster_ges_fwd_pk_kernel<<<tw * th, FWD_THREADS, 0, (hipStream_t)stream>>>(
         (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
         (float4*)render_colors, render_alphas, fc);
     GPS_LAUNCH_CHECK();

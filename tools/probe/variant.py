@@ -15,6 +15,7 @@ from gps_slam_amd import _build as B
 name, src = sys.argv[1], sys.argv[2]
 base = os.path.basename(src)
 path = src if os.path.sep in src else os.path.join(B.CSRC, src)
+assert base in B.sources(), "a replacement source keeps the name of the file it replaces (e.g. /tmp/x/splat_raster.hip)"
 flags = list(B.COMMON) + [f for pre, fl in B.PER_FILE.items() if base.startswith(pre) for f in fl] + sys.argv[3:]
 obj = "/tmp/variant_%s.o" % name
 subprocess.check_call([B.HIPCC] + flags + ["-I" + os.path.join(ROOT, "include"), "-I" + B.CSRC, "-c", path, "-o", obj])
