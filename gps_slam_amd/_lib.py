@@ -21,6 +21,12 @@ class TsdfState(C.Structure):
                 ("fv_visible_ids", vp), ("fv_minmax", vp), ("fv_raycast", vp), ("fv_colour", vp)]
 
 
+class TsdfView(C.Structure):
+    """gps_tsdf_view: one free view of gps_tsdf_free_raycast_batch"""
+    _fields_ = [("M", f32 * 16), ("invM", f32 * 16), ("fx", f32), ("fy", f32), ("cx", f32), ("cy", f32),
+                ("visible_ids", vp), ("minmax", vp), ("raycast", vp), ("colour", vp), ("scratch", vp), ("counters", vp)]
+
+
 class TrackConfig(C.Structure):
     """gps_track_config"""
     _fields_ = [("n_levels", i32), ("iter_type", i32 * 8), ("n_iter", i32 * 8), ("space_thresh", f32 * 8),
@@ -106,6 +112,9 @@ PROTOTYPES = {
     "gps_tsdf_render_colour": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_process_frame": (i32, [C.POINTER(TsdfState), vp, vp, vp, vp]),
     "gps_tsdf_free_raycast": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
+    "gps_tsdf_view_table_bytes": (i64, [i32]),
+    "gps_tsdf_view_init": (i32, [C.POINTER(TsdfState), C.POINTER(TsdfView), vp]),
+    "gps_tsdf_free_raycast_batch": (i32, [C.POINTER(TsdfState), i32, C.POINTER(TsdfView), vp, vp]),
     "gps_pose_from_c2w": (i32, [vp, vp, vp]),
     "gps_raycast_to_maps": (i32, [i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_knn_mean_dist2": (i32, [i32, vp, vp, vp]),

@@ -42,6 +42,37 @@ struct Mat4 { float m[16]; };  // ORUtils layout m[col*4 + row]
 
 static inline Mat4 load_mat(const float* p) { Mat4 r; for (int i = 0; i < 16; i++) r.m[i] = p[i]; return r; }
 
+// One free view of a batch (gps_tsdf_free_raycast_batch): the table the batch kernels read with blockIdx.z.  Every kernel of
+// the free-view chain takes the scene by value as before plus an optional table; with a table, apply_view() swaps in the view's
+// own render-state buffers, scratch, counters, intrinsics and pose -- the kernel body is the single-view code.
+struct ViewRec {
+    Mat4 M, invM;
+    float fx, fy, cx, cy;
+    int32_t* visible_ids;
+    float* minmax;
+    float* raycast;
+    uint8_t* colour;
+    int32_t* scratch;
+    int32_t* counters;
+};
+constexpr int MAX_BATCH_VIEWS = 16;
+struct ViewTable { ViewRec v[MAX_BATCH_VIEWS]; };
+
+__device__ __forceinline__ void apply_view(TsdfState& s, const ViewRec& v) {
+    s.fv_visible_ids = v.visible_ids; s.fv_minmax = v.minmax; s.fv_raycast = v.raycast; s.fv_colour = v.colour;
+    s.scan_scratch = v.scratch; s.counters = v.counters;
+    s.fx = v.fx; s.fy = v.fy; s.cx = v.cx; s.cy = v.cy;
+}
+// regions of scan_scratch the ordered visible-list sweep and the expected-depth pass use (see the layout above)
+__host__ __device__ __forceinline__ int sweep_blocks(const TsdfState& s) { return (s.n_buckets + s.n_excess + 1023) / 1024; }
+__host__ __device__ __forceinline__ int32_t* sweep_counts(const TsdfState& s) { return s.scan_scratch + 2 * sweep_blocks(s); }
+__host__ __device__ __forceinline__ uint8_t* sweep_flags(const TsdfState& s) {
+    return reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * sweep_blocks(s) + 16);
+}
+__host__ __device__ __forceinline__ uint2* minmax_partials(const TsdfState& s) {
+    return reinterpret_cast<uint2*>(s.scan_scratch + 3 * sweep_blocks(s) + 16 + (s.n_buckets + s.n_excess + 3) / 4 + 2);
+}
+
 static inline bool state_valid(const gps_tsdf_state& s) {
     if (s.width <= 0 || s.height <= 0 || s.n_blocks <= 0 || s.n_buckets <= 0 || s.n_excess <= 0) return false;
     if ((s.n_buckets & (s.n_buckets - 1)) != 0 || s.n_buckets < 32) return false;  // hash mask = n_buckets - 1

@@ -194,8 +194,11 @@ __global__ __launch_bounds__(SWEEP) void alloc_count_kernel(TsdfState s, int32_t
 
 // single workgroup: exclusive scan of up to two arrays of per-block counts, totals to out_tot[0..1]
 __global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __restrict__ a, int32_t* __restrict__ b,
-                                                          int32_t* __restrict__ out_tot) {
+                                                          int32_t* __restrict__ out_tot, const ViewRec* __restrict__ views) {
     __shared__ int ws[17];
+    if (views) {  // free-view batch: the sweep counts and the list length of view blockIdx.z
+        a = views[blockIdx.z].scratch + 2 * nblk; b = nullptr; out_tot = views[blockIdx.z].counters + GPS_TSDF_N_VISIBLE_FREE;
+    }
     const int per = (nblk + 1023) / 1024;
     const int lo = min(nblk, (int)threadIdx.x * per), hi = min(nblk, lo + per);
     for (int which = 0; which < 2; which++) {
@@ -283,8 +286,9 @@ __device__ __forceinline__ bool slot_visible(const TsdfState& s, const Mat4& M, 
 
 template <int MODE>
 __global__ __launch_bounds__(SWEEP) void visible_count_kernel(TsdfState s, Mat4 M, int32_t* __restrict__ blk,
-                                                             uint8_t* __restrict__ flags) {
+                                                             uint8_t* __restrict__ flags, const ViewRec* __restrict__ views) {
     __shared__ int ws[17];
+    if (views) { apply_view(s, views[blockIdx.z]); M = views[blockIdx.z].M; blk = sweep_counts(s); flags = sweep_flags(s); }
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
     const int n_total = s.n_buckets + s.n_excess;
     if (MODE == VIS_LIVE && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -303,8 +307,10 @@ __global__ __launch_bounds__(SWEEP) void visible_count_kernel(TsdfState s, Mat4 
 
 __global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const int32_t* __restrict__ blk,
                                                              const uint8_t* __restrict__ flags,
-                                                             int32_t* __restrict__ out_ids, int cap) {
+                                                             int32_t* __restrict__ out_ids, int cap,
+                                                             const ViewRec* __restrict__ views) {
     __shared__ int ws[17];
+    if (views) { apply_view(s, views[blockIdx.z]); blk = sweep_counts(s); flags = sweep_flags(s); out_ids = s.fv_visible_ids; }
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
     const int n_total = s.n_buckets + s.n_excess;
     const bool v = idx < n_total ? flags[idx] != 0 : false;
@@ -536,13 +542,13 @@ int gps_tsdf_allocate(const gps_tsdf_state* sp, const float* M, const float* inv
     mark_previous_visible_kernel<<<256, 256, 0, st>>>(s);
     alloc_request_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(s, im);
     alloc_count_kernel<<<nblk, SWEEP, 0, st>>>(s, blk1, blk2);
-    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blk1, blk2, tot);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blk1, blk2, tot, nullptr);
     alloc_apply_kernel<<<nblk, SWEEP, 0, st>>>(s, im, blk1, blk2, bucket_bits(s));
     // ordered visible list (byte flags live behind the per-block counts in scan_scratch)
     uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
-    visible_count_kernel<VIS_LIVE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags);
-    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE]);
-    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.visible_ids, s.n_blocks);
+    visible_count_kernel<VIS_LIVE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags, nullptr);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE], nullptr);
+    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.visible_ids, s.n_blocks, nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -558,12 +564,28 @@ int gps_tsdf_find_visible(const gps_tsdf_state* sp, const float* M, gps_stream s
     const int nblk = gps_div_up(n_total, SWEEP);
     int32_t* blkv = s.scan_scratch + 2 * nblk;
     uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
-    visible_count_kernel<VIS_FREE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags);
-    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE_FREE]);
-    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.fv_visible_ids, s.n_blocks);
+    visible_count_kernel<VIS_FREE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags, nullptr);
+    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE_FREE], nullptr);
+    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.fv_visible_ids, s.n_blocks, nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
+
+}  // extern "C"
+
+namespace gpst {
+// ordered visible lists of n free views in three launches (grid.z = view)
+int find_visible_batch(const TsdfState& s, int n, const ViewRec* table, hipStream_t st) {
+    const int nblk = sweep_blocks(s);
+    const Mat4 none = {};
+    visible_count_kernel<VIS_FREE><<<dim3(nblk, 1, n), SWEEP, 0, st>>>(s, none, nullptr, nullptr, table);
+    scan_counts_kernel<<<dim3(1, 1, n), 1024, 0, st>>>(nblk, nullptr, nullptr, nullptr, table);
+    visible_write_kernel<<<dim3(nblk, 1, n), SWEEP, 0, st>>>(s, nullptr, nullptr, nullptr, s.n_blocks, table);
+    return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+}  // namespace gpst
+
+extern "C" {
 
 int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stream) {
     GPS_ENTER();

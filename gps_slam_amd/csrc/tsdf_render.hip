@@ -35,8 +35,11 @@ constexpr int ED_THREADS = 1024;  // ~45k visible blocks over 64 x 1024 threads:
 
 __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
                                                                      const int32_t* __restrict__ vis_ids, int count_slot,
-                                                                     int sw, int sh, uint2* __restrict__ partial) {
+                                                                     int sw, int sh, uint2* __restrict__ partial,
+                                                                     const ViewRec* __restrict__ views) {
     extern __shared__ uint2 img[];  // [sw*sh] {min bits, max bits}
+    int32_t* const overflow_word = s.counters + GPS_TSDF_OVERFLOW;  // (of the scene, also for a view of a batch)
+    if (views) { apply_view(s, views[blockIdx.z]); M = views[blockIdx.z].M; vis_ids = s.fv_visible_ids; partial = minmax_partials(s); }
     const int n = s.counters[count_slot];
     const int W = s.width, H = s.height;
     const uint2 init = make_uint2(__float_as_uint(FAR_AWAY), __float_as_uint(VERY_CLOSE));
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(Tsd
     const int tot = wave_sum_i(my_blocks);
     if ((threadIdx.x & 63) == 0 && tot) {
         const int before = atomicAdd(&s.counters[GPS_TSDF_SCRATCH2], tot);
-        if (before + tot >= MAX_RENDERING_BLOCKS) s.counters[GPS_TSDF_OVERFLOW] = 1;
+        if (before + tot >= MAX_RENDERING_BLOCKS) *overflow_word = 1;
     }
     __syncthreads();
     uint2* out = partial + (size_t)blockIdx.x * sw * sh;
@@ -95,7 +98,8 @@ __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(Tsd
 
 __global__ __launch_bounds__(256) void expected_depths_reduce_kernel(TsdfState s, int sw, int sh, int groups,
                                                                     const uint2* __restrict__ partial,
-                                                                    float2* __restrict__ mm) {
+                                                                    float2* __restrict__ mm, const ViewRec* __restrict__ views) {
+    if (views) { apply_view(s, views[blockIdx.z]); partial = minmax_partials(s); mm = reinterpret_cast<float2*>(s.fv_minmax); }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {  // pass A of this call is complete (stream order): publish its rendering-block count, clear the scratch
         s.counters[GPS_TSDF_RENDER_BLOCKS] = s.counters[GPS_TSDF_SCRATCH2];
@@ -242,7 +246,12 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
 // castRay (Shared.h:122-221); 16x16 pixel workgroups of four 8x8 wave patches
 template <bool MODIFY_VISIBLE>
 __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
-                                                     float4* __restrict__ rays, const uint32_t* __restrict__ bits) {
+                                                     float4* __restrict__ rays, const uint32_t* __restrict__ bits,
+                                                     const ViewRec* __restrict__ views) {
+    if (views) {
+        apply_view(s, views[blockIdx.z]); invM = views[blockIdx.z].invM;
+        minmax = reinterpret_cast<const float2*>(s.fv_minmax); rays = reinterpret_cast<float4*>(s.fv_raycast);
+    }
     // one wave64 = one 8x8 pixel patch = exactly one cell of the 1/8-resolution min/max image: all 64 rays share their
     // [min, max] range, so their free-space runs and step counts stay close (a 16x4 strip straddles two cells)
     const int wave_in_wg = threadIdx.x >> 6, lane_ = threadIdx.x & 63;
@@ -483,7 +492,12 @@ __global__ __launch_bounds__(256) void icp_kernel(TsdfState s, Mat4 invM, const 
 
 // readFromSDF_color4u_interpolated, GPS-SLAM variant renormalised over w_color >= 1
 // (ITMRepresentationAccess.h:344-423) + drawPixelColour (Shared.h:384-394)
-__global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* __restrict__ rays, uchar4* __restrict__ out) {
+__global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* __restrict__ rays, uchar4* __restrict__ out,
+                                                    const ViewRec* __restrict__ views) {
+    if (views) {
+        apply_view(s, views[blockIdx.z]);
+        rays = reinterpret_cast<const float4*>(s.fv_raycast); out = reinterpret_cast<uchar4*>(s.fv_colour);
+    }
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= s.width || y >= s.height) return;
     const int loc = x + y * s.width;
@@ -542,9 +556,75 @@ __global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* 
     if (depth_clamped) depth_clamped[i] = dz < 0.01f ? 1000.0f : dz;
 }
 
+// the table of a batch travels as a kernel argument (no staging buffer, no copy engine) into device memory
+__global__ void upload_views_kernel(ViewTable t, int n, ViewRec* __restrict__ dst) {
+    const int words = n * (int)(sizeof(ViewRec) / 4);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&t);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<uint32_t*>(dst)[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void view_init_kernel(int P, float2* __restrict__ mm, int32_t* __restrict__ counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) mm[i] = make_float2(FAR_AWAY, VERY_CLOSE);
+    if (i < GPS_TSDF_N_COUNTERS) counters[i] = 0;
+}
+
 }  // namespace
 
+namespace gpst { int find_visible_batch(const TsdfState& s, int n, const ViewRec* table, hipStream_t st); }
+
 extern "C" {
+
+int64_t gps_tsdf_view_table_bytes(int n_views) {
+    return n_views > 0 && n_views <= MAX_BATCH_VIEWS ? (int64_t)n_views * (int64_t)sizeof(ViewRec) : GPS_ERR_ARG;
+}
+
+int gps_tsdf_view_init(const gps_tsdf_state* sp, const gps_tsdf_view* v, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && v != nullptr && v->minmax && v->counters);
+    const int P = sp->width * sp->height;
+    view_init_kernel<<<gps_div_up(max(P, (int)GPS_TSDF_N_COUNTERS), 256), 256, 0, (hipStream_t)stream>>>(
+        P, reinterpret_cast<float2*>(v->minmax), v->counters);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_tsdf_free_raycast_batch(const gps_tsdf_state* sp, int n_views, const gps_tsdf_view* views, void* table,
+                                gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && views != nullptr && table != nullptr && n_views > 0 && n_views <= MAX_BATCH_VIEWS);
+    GPS_REQUIRE(state_valid(*sp));
+    TsdfState s = *sp;
+    hipStream_t st = (hipStream_t)stream;
+    static_assert(sizeof(ViewTable) <= 3584, "the table is a kernel argument");
+    ViewTable t = {};
+    for (int k = 0; k < n_views; k++) {
+        const gps_tsdf_view& v = views[k];
+        GPS_REQUIRE(v.visible_ids && v.minmax && v.raycast && v.colour && v.scratch && v.counters);
+        ViewRec& r = t.v[k];
+        r.M = load_mat(v.M); r.invM = load_mat(v.invM);
+        r.fx = v.fx; r.fy = v.fy; r.cx = v.cx; r.cy = v.cy;
+        r.visible_ids = v.visible_ids; r.minmax = v.minmax; r.raycast = v.raycast; r.colour = v.colour;
+        r.scratch = v.scratch; r.counters = v.counters;
+    }
+    ViewRec* tab = reinterpret_cast<ViewRec*>(table);
+    upload_views_kernel<<<1, 256, 0, st>>>(t, n_views, tab);
+    int r;
+    if ((r = gpst::find_visible_batch(s, n_views, tab, st)) != GPS_OK) return r;
+    const int sw = s.width / MINMAX_SUB + 2, sh = s.height / MINMAX_SUB + 2;
+    const size_t lds = (size_t)sw * sh * sizeof(uint2);
+    GPS_REQUIRE(lds <= 160 * 1024);
+    const Mat4 none = {};
+    expected_depths_partial_kernel<<<dim3(ED_GROUPS, 1, n_views), ED_THREADS, lds, st>>>(s, none, nullptr, GPS_TSDF_N_VISIBLE_FREE, sw,
+                                                                                     sh, nullptr, tab);
+    expected_depths_reduce_kernel<<<dim3(gps_div_up(sw * sh, 256), 1, n_views), 256, 0, st>>>(s, sw, sh, ED_GROUPS, nullptr, nullptr,
+                                                                                          tab);
+    const dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16), n_views);
+    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab);
+    colour_kernel<<<grid, 256, 0, st>>>(s, nullptr, nullptr, tab);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
 
 int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_view, gps_stream stream) {
     GPS_ENTER();
@@ -565,8 +645,8 @@ int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_
     float2* mm = reinterpret_cast<float2*>(free_view ? s.fv_minmax : s.minmax);
     expected_depths_partial_kernel<<<ED_GROUPS, ED_THREADS, lds, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
                                                                 free_view ? GPS_TSDF_N_VISIBLE_FREE : GPS_TSDF_N_VISIBLE,
-                                                                sw, sh, partial);
-    expected_depths_reduce_kernel<<<gps_div_up(sw * sh, 256), 256, 0, st>>>(s, sw, sh, ED_GROUPS, partial, mm);
+                                                                sw, sh, partial, nullptr);
+    expected_depths_reduce_kernel<<<gps_div_up(sw * sh, 256), 256, 0, st>>>(s, sw, sh, ED_GROUPS, partial, mm, nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -591,9 +671,9 @@ int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view,
     const float2* mm = reinterpret_cast<const float2*>(free_view ? s.fv_minmax : s.minmax);
     float4* rays = reinterpret_cast<float4*>(free_view ? s.fv_raycast : s.raycast);
     if (update_visible)
-        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s));
+        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr);
     else
-        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s));
+        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -618,7 +698,7 @@ int gps_tsdf_render_colour(const gps_tsdf_state* sp, gps_stream stream) {
     TsdfState s = *sp;
     dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16));
     colour_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(s, reinterpret_cast<const float4*>(s.fv_raycast),
-                                                        reinterpret_cast<uchar4*>(s.fv_colour));
+                                                        reinterpret_cast<uchar4*>(s.fv_colour), nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

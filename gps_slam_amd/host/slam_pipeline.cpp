@@ -182,12 +182,68 @@ void SLAMPipeline::localFrameRaycast() { raycastWindow(localframe_cam_window, ma
 void SLAMPipeline::keyFrameRaycast() { raycastKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses); }
 void SLAMPipeline::initNewGaussians(TensorDict& rm) { initNewGaussiansFor(rm, curr_cam); }
 
+// runRaycastByCam for several cameras of ONE volume state: one batched free-view chain (TsdfEngine::runRaycastBatch) instead
+// of one chain per camera, then each view's tensor glue.  Same tensors as raycastCam per camera; one event covers them all.
+std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera*>& cams,
+                                                  const std::vector<ORUtils::SE3Pose>& poses, void** ev_out) {
+    std::vector<TensorDict> out;
+    if (cams.empty()) return out;
+    TsdfEngine* eng = main_engine;
+    const auto F = f32(device);
+    std::vector<ORUtils::SE3Pose> view_poses(cams.size());
+    std::vector<torch::Tensor> w2c(cams.size());
+    for (size_t k = 0; k < cams.size(); k++) {
+        const Camera& cam = *cams[k];
+        if (cam.id >= 0 && cam.id < (int)poses.size()) {
+            view_poses[k] = poses[cam.id];
+        } else {
+            auto c = cam.c2w.to(torch::kCPU, torch::kFloat32).contiguous();
+            view_poses[k].SetInvM(c.data_ptr<float>());
+            view_poses[k].Coerce();
+        }
+        // (result tensors on the CONSUMER's stream, before the guard below, as in raycastCam)
+        TensorDict m;
+        m["color_map"] = torch::empty({cam.height, cam.width, 3}, F);
+        m["vertex_map"] = torch::empty({cam.height, cam.width, 3}, F);
+        m["confidence_map"] = torch::empty({cam.height, cam.width, 1}, F);
+        m["depth_map"] = torch::empty({cam.height, cam.width, 1}, F);
+        m["depth_map_clamped"] = torch::empty({cam.height, cam.width, 1}, F);
+        out.push_back(m);
+        w2c[k] = poseInv(cam.c2w.to(torch::kCPU, torch::kFloat32)).contiguous();  // poseInv(cam.c2w): dataset pose (:398)
+    }
+    c10::optional<c10::hip::HIPStreamGuard> on_rc;
+    if (ev_out) on_rc.emplace(static_cast<MapStream*>(rc_stream_)->s);
+    eng->runRaycastBatch(view_poses);
+    for (size_t k = 0; k < cams.size(); k++) {
+        TensorDict& m = out[k];
+        check(gps_raycast_to_maps(cams[k]->width, cams[k]->height,
+                                  reinterpret_cast<const float*>(eng->GetFreeVertex((int)k)->GetData(MEMORYDEVICE_CUDA)),
+                                  reinterpret_cast<const uint8_t*>(eng->GetFreeImage((int)k)->GetData(MEMORYDEVICE_CUDA)),
+                                  eng->getVoxelSize(), w2c[k].data_ptr<float>(), fptr(m["color_map"]), fptr(m["vertex_map"]),
+                                  fptr(m["confidence_map"]), fptr(m["depth_map"]), fptr(m["depth_map_clamped"]),
+                                  current_stream()), "gps_raycast_to_maps");
+    }
+    if (ev_out) {
+        if (rc_event_next_ == rc_events_.size()) {
+            hipEvent_t ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            rc_events_.push_back(ev);
+        }
+        *ev_out = rc_events_[rc_event_next_++];
+        hip_ok(hipEventRecord((hipEvent_t)*ev_out, c10::hip::getCurrentHIPStream().stream()), "hipEventRecord");
+    }
+    stats.raycasts += (int64_t)cams.size();
+    return out;
+}
+
 void SLAMPipeline::raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses) {
     localframe_raycast_window.clear();
     beginAsyncRaycasts();
-    for (const Camera& cam : window) {
-        void* ev = nullptr;
-        localframe_raycast_window.push_back(raycastCam(cam, poses, async_raycasts ? &ev : nullptr));
+    std::vector<const Camera*> cams;
+    for (const Camera& cam : window) cams.push_back(&cam);
+    void* ev = nullptr;
+    for (TensorDict& m : raycastCams(cams, poses, async_raycasts ? &ev : nullptr)) {
+        localframe_raycast_window.push_back(m);
         window_raycast_events_.push_back(ev);
     }
 }
@@ -199,11 +255,15 @@ void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std:
     opt_raycast_events_ = window_raycast_events_;
     const int n = std::min<int>(keyframe_select_max, (int)keyframes.size());
     RandomSelector<Camera> sel(keyframes, rng_);
+    std::vector<const Camera*> cams;
     for (int k = 0; k < n; k++) {
         const Camera* cam = sel.getNext().second;
         opt_cam_list.push_back(*cam);
-        void* ev = nullptr;
-        opt_raycast_list.push_back(raycastCam(*cam, poses, async_raycasts ? &ev : nullptr));
+        cams.push_back(cam);
+    }
+    void* ev = nullptr;
+    for (TensorDict& m : raycastCams(cams, poses, async_raycasts ? &ev : nullptr)) {
+        opt_raycast_list.push_back(m);
         opt_raycast_events_.push_back(ev);
     }
 }

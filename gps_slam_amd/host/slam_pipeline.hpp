@@ -139,6 +139,9 @@ private:
     void ensureStreams();
     // `ev_out` != nullptr: run on the raycast stream and hand back the event that marks the result complete
     TensorDict raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses, void** ev_out = nullptr);
+    // the same for several cameras of one volume state in ONE batched free-view chain; one event for all results
+    std::vector<TensorDict> raycastCams(const std::vector<const Camera*>& cams, const std::vector<ORUtils::SE3Pose>& poses,
+                                        void** ev_out = nullptr);
     void raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses);
     void raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
                           const std::vector<ORUtils::SE3Pose>& poses);

@@ -160,6 +160,50 @@ void TsdfEngine::runRaycast(ORUtils::SE3Pose* pose, ITMLib::ITMIntrinsics* intri
     check(gps_tsdf_free_raycast(&s, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
 }
 
+void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics) {
+    const int n = (int)poses.size();
+    if (n == 0) return;
+    TORCH_CHECK(n <= 16, "runRaycastBatch: at most 16 views per call");
+    gps_tsdf_state s;
+    { std::lock_guard<std::mutex> lk(state_mu_); s = state_; }
+    float fx = s.fx, fy = s.fy, cx = s.cx, cy = s.cy;
+    if (intrinsics) {
+        TORCH_CHECK(intrinsics->imgSize.x == s.width && intrinsics->imgSize.y == s.height,
+                    "runRaycastBatch: the free-view render states have the depth camera's image size");
+        fx = intrinsics->projectionParamsSimple.fx; fy = intrinsics->projectionParamsSimple.fy;
+        cx = intrinsics->projectionParamsSimple.px; cy = intrinsics->projectionParamsSimple.py;
+    }
+    const int64_t P = (int64_t)s.width * s.height;
+    const auto I = torch::TensorOptions().dtype(torch::kInt32).device(device_);
+    const auto F = torch::TensorOptions().dtype(torch::kFloat32).device(device_);
+    std::vector<gps_tsdf_view> recs(n);
+    for (int k = 0; k < n; k++) {
+        const bool fresh = k >= (int)views_.size();
+        if (fresh) {
+            std::unique_ptr<FreeView> v(new FreeView());
+            v->visible_ids = torch::zeros({s.n_blocks}, I);
+            v->minmax = torch::zeros({P * 2}, F);
+            v->raycast = torch::zeros({P * 4}, F);
+            v->colour = zeros_bytes(P * 4, device_);
+            v->scratch = zeros_bytes(gps_tsdf_scratch_bytes(s.width, s.height, s.n_buckets, s.n_excess) + 16, device_);
+            v->counters = torch::zeros({GPS_TSDF_N_COUNTERS}, I);
+            v->image_p.reset(new ITMUChar4Image(s.width, s.height, v->colour));
+            v->vertex_p.reset(new ITMFloat4Image(s.width, s.height, v->raycast));
+            views_.push_back(std::move(v));
+        }
+        FreeView& v = *views_[k];
+        gps_tsdf_view& r = recs[k];
+        memcpy(r.M, poses[k].GetM(), 64);
+        memcpy(r.invM, poses[k].GetInvM(), 64);
+        r.fx = fx; r.fy = fy; r.cx = cx; r.cy = cy;
+        r.visible_ids = iptr(v.visible_ids); r.minmax = fptr(v.minmax); r.raycast = fptr(v.raycast);
+        r.colour = ptr<uint8_t>(v.colour); r.scratch = reinterpret_cast<int32_t*>(v.scratch.data_ptr()); r.counters = iptr(v.counters);
+        if (fresh) check(gps_tsdf_view_init(&s, &r, current_stream()), "gps_tsdf_view_init");
+    }
+    if (!view_table_.defined()) view_table_ = zeros_bytes(gps_tsdf_view_table_bytes(16), device_);
+    check(gps_tsdf_free_raycast_batch(&s, n, recs.data(), view_table_.data_ptr(), current_stream()), "gps_tsdf_free_raycast_batch");
+}
+
 bool TsdfEngine::checkRenderingBlocks() {
     auto c = counters_.cpu();
     const bool over = c.data_ptr<int32_t>()[GPS_TSDF_OVERFLOW] != 0;

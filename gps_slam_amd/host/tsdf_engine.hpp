@@ -152,6 +152,12 @@ public:
     // are uploaded (asynchronously, pinned -> the engine's staging buffers) on the current stream first; images with a device
     // copy are read in place.
     ITMTrackingState* ProcessFrame(ITMUChar4Image* rgbImage, ITMShortImage* rawDepthImage);
+    // runRaycast for several poses at once (gps_tsdf_free_raycast_batch): every launch of the free-view chain covers all
+    // views, each view renders into a render state of its own (kept by the engine, created on first use) -- view k's images
+    // are GetFreeImage(k) / GetFreeVertex(k).  Same images as runRaycast(pose k) would leave in GetFreeImage() / GetFreeVertex().
+    void runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics = nullptr);
+    ITMUChar4Image* GetFreeImage(int view) { return views_.at(view)->image_p.get(); }
+    ITMFloat4Image* GetFreeVertex(int view) { return views_.at(view)->vertex_p.get(); }
     ITMUChar4Image* GetFreeImage() { return &free_image_; }
     ITMFloat4Image* GetFreeVertex() { return &free_vertex_; }
     ITMFloat4Image* GetLiveVertex() { return &live_vertex_; }
@@ -205,6 +211,13 @@ private:
     torch::Tensor vba_, vba_alloc_list_, hash_, excess_list_, counters_, alloc_prio_, scan_scratch_, visible_type_,
         visible_ids_, depth_, minmax_, raycast_, icp_points_, icp_normals_, fv_visible_ids_, fv_minmax_, fv_raycast_,
         fv_colour_;
+    struct FreeView {  // one ITMRenderState_VH worth of buffers + scratch + counters (gps_tsdf_view)
+        torch::Tensor visible_ids, minmax, raycast, colour, scratch, counters;
+        std::unique_ptr<ITMUChar4Image> image_p;
+        std::unique_ptr<ITMFloat4Image> vertex_p;
+    };
+    std::vector<std::unique_ptr<FreeView>> views_;
+    torch::Tensor view_table_;
     std::vector<torch::Tensor> frame_inputs_;
     torch::Tensor stage_rgb_[2], stage_depth_[2];  // UpdateView staging (host-resident input images), alternating per frame
     gps_track_config track_cfg_{};

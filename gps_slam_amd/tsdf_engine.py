@@ -151,10 +151,42 @@ class TsdfEngine:
               "gps_tsdf_free_raycast")
         return M, invM
 
-    def GetFreeImage(self):
+    # ---- the same for several poses in one chain of launches (gps_tsdf_free_raycast_batch); view k's images:
+    #      GetFreeVertex(k) / GetFreeImage(k)
+    def runRaycastBatch(self, poses):
+        from ._lib import TsdfView
+        n = len(poses)
+        views = getattr(self, "_views", [])
+        P = self.W * self.H
+        z = lambda cnt, dt: torch.zeros(cnt, dtype=dt, device=self.device)
+        while len(views) < n:
+            v = dict(visible_ids=z(self.n_blocks, torch.int32), minmax=z(P * 2, torch.float32), raycast=z(P * 4, torch.float32),
+                     colour=z(P * 4, torch.uint8), scratch=torch.zeros_like(self.scan_scratch), counters=z(16, torch.int32))
+            rec = TsdfView()
+            for k, t in v.items():
+                setattr(rec, k, t.data_ptr())
+            check(lib.gps_tsdf_view_init(C.byref(self.state), C.byref(rec), self._stream()), "gps_tsdf_view_init")
+            views.append(v)
+        self._views = views
+        arr = (TsdfView * n)()
+        for k, (M, invM) in enumerate(poses):
+            for name, t in views[k].items():
+                setattr(arr[k], name, t.data_ptr())
+            arr[k].M[:] = M.reshape(-1).tolist(); arr[k].invM[:] = invM.reshape(-1).tolist()
+            arr[k].fx, arr[k].fy, arr[k].cx, arr[k].cy = self.state.fx, self.state.fy, self.state.cx, self.state.cy
+        if getattr(self, "_view_table", None) is None or self._view_table.numel() < int(lib.gps_tsdf_view_table_bytes(n)):
+            self._view_table = torch.zeros(int(lib.gps_tsdf_view_table_bytes(16)), dtype=torch.uint8, device=self.device)
+        check(lib.gps_tsdf_free_raycast_batch(C.byref(self.state), n, arr, self._view_table.data_ptr(), self._stream()),
+              "gps_tsdf_free_raycast_batch")
+
+    def GetFreeImage(self, view=None):
+        if view is not None:
+            return self._views[view]["colour"].view(self.H, self.W, 4)
         return self.fv_colour.view(self.H, self.W, 4)
 
-    def GetFreeVertex(self):
+    def GetFreeVertex(self, view=None):
+        if view is not None:
+            return self._views[view]["raycast"].view(self.H, self.W, 4)
         return self.fv_raycast.view(self.H, self.W, 4)
 
     def GetLiveVertex(self):

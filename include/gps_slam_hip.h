@@ -437,7 +437,8 @@ enum {
     GPS_TSDF_OVERFLOW = 5,         /* non-zero: MAX_RENDERING_BLOCKS (262144) exceeded -> min/max image not reference-exact */
     GPS_TSDF_SCRATCH0 = 6,
     GPS_TSDF_SCRATCH1 = 7,
-    GPS_TSDF_SCRATCH2 = 8          /* rendering blocks of the CreateExpectedDepths in flight (published to [4], then cleared) */
+    GPS_TSDF_SCRATCH2 = 8,         /* rendering blocks of the CreateExpectedDepths in flight (published to [4], then cleared) */
+    GPS_TSDF_N_COUNTERS = 16
 };
 
 /* All pointers are device memory owned by the caller (the reference owns the same buffers through
@@ -527,6 +528,33 @@ GPS_API int gps_tsdf_process_frame(const gps_tsdf_state *s, const int16_t *depth
 /* ITMBasicEngine::runRaycast(pose, intrinsics) (Core/ITMBasicEngine.tpp:519-525) = find_visible +
  * expected_depths(free) + raycast(free) + render_colour. */
 GPS_API int gps_tsdf_free_raycast(const gps_tsdf_state *s, const float *M, const float *invM, gps_stream stream);
+
+/* The same for SEVERAL views at once.  A keyframe update of SLAMPipeline renders up to 9 free views of one volume state
+ * (slam/slam_pipeline.cpp:416-447: localFrameRaycast + keyFrameRaycast call runRaycastByCam once per camera); one view is a
+ * chain of 6 short, latency-bound launches (~190 us), and the next frame's fusion has to wait for the last of them.  Here
+ * every launch of the chain covers all views (grid.z = view): the same kernels, the same per-view results (bit-identical to
+ * gps_tsdf_free_raycast, tests/test_tsdf_gpu.py), the views' dependent memory round trips overlap instead of queueing.
+ *
+ * Each view brings the render state one ITMRenderState_VH holds (its own visible list, min/max image, ray image, colour
+ * image), a scratch area of gps_tsdf_scratch_bytes() and a private counter block (int32[GPS_TSDF_N_COUNTERS]; the list length
+ * lands in counters[GPS_TSDF_N_VISIBLE_FREE]).  gps_tsdf_view_init prepares minmax / counters ONCE after allocation (what
+ * gps_tsdf_reset does for the state's own free view).  `table` is device memory of gps_tsdf_view_table_bytes(n_views) bytes the
+ * call overwrites; n_views <= 16.  The scene's own free-view buffers and scratch are not touched; MAX_RENDERING_BLOCKS
+ * overflow of any view is raised in the SCENE's counters[GPS_TSDF_OVERFLOW]. */
+typedef struct gps_tsdf_view {
+    float M[16], invM[16];  /* pose of the view (ORUtils layout, as gps_tsdf_free_raycast) */
+    float fx, fy, cx, cy;   /* intrinsics of the view (image size = the state's) */
+    int32_t *visible_ids;   /* [n_blocks] */
+    float *minmax;          /* [H*W*2] */
+    float *raycast;         /* [H*W*4] out: what fv_raycast receives */
+    uint8_t *colour;        /* [H*W*4] out: what fv_colour receives */
+    int32_t *scratch;       /* gps_tsdf_scratch_bytes(width, height, n_buckets, n_excess) bytes */
+    int32_t *counters;      /* [GPS_TSDF_N_COUNTERS] */
+} gps_tsdf_view;
+GPS_API int64_t gps_tsdf_view_table_bytes(int n_views);
+GPS_API int gps_tsdf_view_init(const gps_tsdf_state *s, const gps_tsdf_view *view, gps_stream stream);
+GPS_API int gps_tsdf_free_raycast_batch(const gps_tsdf_state *s, int n_views, const gps_tsdf_view *views, void *table,
+                                        gps_stream stream);
 
 /* SLAMPipeline::runRaycastByCam tensor glue (slam/slam_pipeline.cpp:386-403, src/cv_utils.cpp:322-341) fused:
  * rays float4[H*W] + colour uchar4[H*W] (device) -> color_map[H,W,3] (/255), vertex_map[H,W,3] (metres, 0 where no hit),

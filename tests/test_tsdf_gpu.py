@@ -126,6 +126,39 @@ def test_engine_matches_oracle_full_size(W, H, voxel, mu, frames):
     o.close()
 
 
+@pytest.mark.parametrize("W,H,voxel,mu,frames,n_views", [(160, 120, 0.01, 0.04, 6, 5), (640, 480, 0.005, 0.02, 12, 9)])
+def test_batched_free_views_equal_one_view_at_a_time(W, H, voxel, mu, frames, n_views):
+    """gps_tsdf_free_raycast_batch (every launch of the free-view chain covers all views, per-view render state) against
+    gps_tsdf_free_raycast called once per pose on the same volume: rays, colours, visible lists and min/max windows bit for
+    bit; the scene's own free-view buffers untouched by the batch; a second batch (other poses, reused views) still exact."""
+    from gps_slam_amd.tsdf_engine import TsdfEngine, pose_from_c2w
+    seq = synth.make_sequence(W, H, frames, step_deg=2.0)
+    eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel, mu, 0.2, 10.0)
+    for f in range(frames):
+        eng.ProcessFrame(_dev(seq["rgb"][f]), _dev(seq["depth"][f].astype(np.int16)), seq["c2w"][f])
+    for order in (lambda k: k % frames, lambda k: (frames - 1 - 2 * k) % frames):
+        poses = [pose_from_c2w(seq["c2w"][order(k)]) for k in range(n_views)]
+        want = []
+        for M, invM in poses:
+            eng.runRaycast(pose=(M, invM))
+            n = int(eng.counters.cpu()[3])
+            want.append((eng.GetFreeVertex().clone(), eng.GetFreeImage().clone(), eng.fv_visible_ids[:n].clone(),
+                         eng.fv_minmax.view(H, W, 2)[:H // 8 + 1, :W // 8 + 1].clone()))
+        keep = (eng.fv_raycast.clone(), eng.fv_colour.clone(), eng.counters.clone())
+        eng.runRaycastBatch(poses)
+        torch.cuda.synchronize()
+        for k in range(n_views):
+            rays, col, ids, mm = want[k]
+            v = eng._views[k]
+            assert torch.equal(eng.GetFreeVertex(k), rays), k
+            assert torch.equal(eng.GetFreeImage(k), col), k
+            n = int(v["counters"].cpu()[3])
+            assert n == ids.numel() and torch.equal(v["visible_ids"][:n], ids), k
+            assert torch.equal(v["minmax"].view(H, W, 2)[:H // 8 + 1, :W // 8 + 1], mm), k
+        assert (want[0][0][..., 3] > 0).float().mean() > 0.5
+        assert torch.equal(eng.fv_raycast, keep[0]) and torch.equal(eng.fv_colour, keep[1]) and torch.equal(eng.counters, keep[2])
+
+
 def test_integration_is_idempotent_in_weight_and_converges():
     """Size-independent property at full size: fusing the SAME frame twice keeps every allocated block, raises
     w_depth by exactly one where the voxel was updated, and leaves sdf unchanged up to the truncating store."""

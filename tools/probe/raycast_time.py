@@ -34,3 +34,13 @@ mm = eng.minmax.view(H, W, 2)[:H // 8, :W // 8].cpu().numpy()
 print("   minmax window: zmin mean %.2f zmax mean %.2f; visible blocks %d" % (mm[..., 0].mean(), mm[..., 1].mean(), int(eng.counters.cpu()[2])))
 print("   live vertex map sha1 %s" % digest)
 print("%s: live raycast %.1f us (output unchanged: %s), free-view raycast call %.1f us" % (os.environ.get("GPS_SLAM_HIP_LIB", "default"), t_live, same, t_free))
+
+# nine free views: one at a time vs gps_tsdf_free_raycast_batch
+poses = [pose_from_c2w(seq["c2w"][max(0, n - 1 - 4 * k)]) for k in range(9)]
+def one_by_one():
+    for M_, i_ in poses:
+        lib.gps_tsdf_free_raycast(C.byref(eng.state), M_.ctypes.data, i_.ctypes.data, None)
+eng.runRaycastBatch(poses)
+print("9 free views: one at a time %.1f us, batched %.1f us" % (timed(one_by_one, 10), timed(lambda: eng.runRaycastBatch(poses), 10)))
+for nv in (2, 4, 7):
+    print("   batch of %d: %.1f us" % (nv, timed(lambda: eng.runRaycastBatch(poses[:nv]), 10)))
