@@ -24,7 +24,9 @@ class TsdfState(C.Structure):
 class TsdfView(C.Structure):
     """gps_tsdf_view: one free view of gps_tsdf_free_raycast_batch"""
     _fields_ = [("M", f32 * 16), ("invM", f32 * 16), ("fx", f32), ("fy", f32), ("cx", f32), ("cy", f32),
-                ("visible_ids", vp), ("minmax", vp), ("raycast", vp), ("colour", vp), ("scratch", vp), ("counters", vp)]
+                ("visible_ids", vp), ("minmax", vp), ("raycast", vp), ("colour", vp), ("scratch", vp), ("counters", vp),
+                ("w2c", f32 * 16), ("color_map", vp), ("vertex_map", vp), ("confidence_map", vp), ("depth_map", vp),
+                ("depth_map_clamped", vp)]
 
 
 class TrackConfig(C.Structure):

@@ -54,8 +54,11 @@ struct ViewRec {
     uint8_t* colour;
     int32_t* scratch;
     int32_t* counters;
+    // optional runRaycastByCam glue of the view (gps_raycast_to_maps), written by the batch's last kernel; color_map == NULL: none
+    Mat4 w2c_rm;
+    float *color_map, *vertex_map, *conf_map, *depth_map, *depth_clamped;
 };
-constexpr int MAX_BATCH_VIEWS = 16;
+constexpr int MAX_BATCH_VIEWS = 12;
 struct ViewTable { ViewRec v[MAX_BATCH_VIEWS]; };
 
 __device__ __forceinline__ void apply_view(TsdfState& s, const ViewRec& v) {

@@ -490,19 +490,60 @@ __global__ __launch_bounds__(256) void icp_kernel(TsdfState s, Mat4 invM, const 
     }
 }
 
+// runRaycastByCam glue (slam/slam_pipeline.cpp:386-403 + cv_utils.cpp:322-341) in one pass:
+// colour uchar4 -> float3 / 255; vertex = xyz * [w > 0] * voxel_size; confidence = w;
+// depth = z of (w2c * [vertex, 1]) / w-row, forced to 0 where vertex.sum() == 0.
+__device__ __forceinline__ void write_view_maps(int i, const float4 r, const uchar4 c, float voxel_size, const Mat4& w2c_rm,
+                                                float* __restrict__ color_map, float* __restrict__ vertex_map,
+                                                float* __restrict__ conf_map, float* __restrict__ depth_map,
+                                                float* __restrict__ depth_clamped) {
+    // .to(kFloat).div(255.0) (cv_utils.cpp:327): ATen divides a tensor by a host scalar as a multiplication with the float
+    // reciprocal (BinaryDivTrueKernel: inv_b = 1 / b), which is NOT the IEEE quotient for every byte value -- reproduced
+    const float inv255 = 1.0f / 255.0f;
+    color_map[3 * i] = (float)c.x * inv255; color_map[3 * i + 1] = (float)c.y * inv255; color_map[3 * i + 2] = (float)c.z * inv255;
+    const float keep = r.w > 0 ? 1.0f : 0.0f;
+    const float vx = (r.x * keep) * voxel_size, vy = (r.y * keep) * voxel_size, vz = (r.z * keep) * voxel_size;
+    vertex_map[3 * i] = vx; vertex_map[3 * i + 1] = vy; vertex_map[3 * i + 2] = vz;
+    conf_map[i] = r.w;
+    const float* m = w2c_rm.m;  // row-major here
+    const float tz = m[8] * vx + m[9] * vy + m[10] * vz + m[11] * 1.0f;
+    const float tw = m[12] * vx + m[13] * vy + m[14] * vz + m[15] * 1.0f;
+    const float dz = ((vx + vy) + vz == 0.0f) ? 0.0f : tz / tw;
+    depth_map[i] = dz;
+    if (depth_clamped) depth_clamped[i] = dz < 0.01f ? 1000.0f : dz;
+}
+
+__global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* __restrict__ rays,
+                                                          const uchar4* __restrict__ colour, float voxel_size, Mat4 w2c_rm,
+                                                          float* __restrict__ color_map, float* __restrict__ vertex_map,
+                                                          float* __restrict__ conf_map, float* __restrict__ depth_map,
+                                                          float* __restrict__ depth_clamped) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    write_view_maps(i, rays[i], colour[i], voxel_size, w2c_rm, color_map, vertex_map, conf_map, depth_map, depth_clamped);
+}
+
 // readFromSDF_color4u_interpolated, GPS-SLAM variant renormalised over w_color >= 1
 // (ITMRepresentationAccess.h:344-423) + drawPixelColour (Shared.h:384-394)
 __global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* __restrict__ rays, uchar4* __restrict__ out,
                                                     const ViewRec* __restrict__ views) {
+    const ViewRec* maps = nullptr;  // the view's tensor glue rides on this kernel (it holds the ray and the colour of the pixel)
     if (views) {
         apply_view(s, views[blockIdx.z]);
         rays = reinterpret_cast<const float4*>(s.fv_raycast); out = reinterpret_cast<uchar4*>(s.fv_colour);
+        if (views[blockIdx.z].color_map) maps = views + blockIdx.z;
     }
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= s.width || y >= s.height) return;
     const int loc = x + y * s.width;
     const float4 r = rays[loc];
-    if (!(r.w > 0)) { out[loc] = make_uchar4(0, 0, 0, 0); return; }
+    if (!(r.w > 0)) {
+        const uchar4 c = make_uchar4(0, 0, 0, 0);
+        out[loc] = c;
+        if (maps) write_view_maps(loc, r, c, s.voxel_size, maps->w2c_rm, maps->color_map, maps->vertex_map, maps->conf_map,
+                                  maps->depth_map, maps->depth_clamped);
+        return;
+    }
     const float fx_ = floorf(r.x), fy_ = floorf(r.y), fz_ = floorf(r.z);
     const float cx = r.x - fx_, cy = r.y - fy_, cz = r.z - fz_;
     const int ix = (int)fx_, iy = (int)fy_, iz = (int)fz_;
@@ -524,37 +565,12 @@ __global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* 
     }
     r0 /= wsum; r1 /= wsum; r2 /= wsum;
     const float c0 = r0 / 255.0f, c1 = r1 / 255.0f, c2 = r2 / 255.0f;
-    out[loc] = make_uchar4((unsigned char)(c0 * 255.0f), (unsigned char)(c1 * 255.0f), (unsigned char)(c2 * 255.0f), 255);
+    const uchar4 px = make_uchar4((unsigned char)(c0 * 255.0f), (unsigned char)(c1 * 255.0f), (unsigned char)(c2 * 255.0f), 255);
+    out[loc] = px;
+    if (maps) write_view_maps(loc, r, px, s.voxel_size, maps->w2c_rm, maps->color_map, maps->vertex_map, maps->conf_map,
+                              maps->depth_map, maps->depth_clamped);
 }
 
-
-// runRaycastByCam glue (slam/slam_pipeline.cpp:386-403 + cv_utils.cpp:322-341) in one pass:
-// colour uchar4 -> float3 / 255; vertex = xyz * [w > 0] * voxel_size; confidence = w;
-// depth = z of (w2c * [vertex, 1]) / w-row, forced to 0 where vertex.sum() == 0.
-__global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* __restrict__ rays,
-                                                          const uchar4* __restrict__ colour, float voxel_size, Mat4 w2c_rm,
-                                                          float* __restrict__ color_map, float* __restrict__ vertex_map,
-                                                          float* __restrict__ conf_map, float* __restrict__ depth_map,
-                                                          float* __restrict__ depth_clamped) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const float4 r = rays[i];
-    const uchar4 c = colour[i];
-    // .to(kFloat).div(255.0) (cv_utils.cpp:327): ATen divides a tensor by a host scalar as a multiplication with the float
-    // reciprocal (BinaryDivTrueKernel: inv_b = 1 / b), which is NOT the IEEE quotient for every byte value -- reproduced
-    const float inv255 = 1.0f / 255.0f;
-    color_map[3 * i] = (float)c.x * inv255; color_map[3 * i + 1] = (float)c.y * inv255; color_map[3 * i + 2] = (float)c.z * inv255;
-    const float keep = r.w > 0 ? 1.0f : 0.0f;
-    const float vx = (r.x * keep) * voxel_size, vy = (r.y * keep) * voxel_size, vz = (r.z * keep) * voxel_size;
-    vertex_map[3 * i] = vx; vertex_map[3 * i + 1] = vy; vertex_map[3 * i + 2] = vz;
-    conf_map[i] = r.w;
-    const float* m = w2c_rm.m;  // row-major here
-    const float tz = m[8] * vx + m[9] * vy + m[10] * vz + m[11] * 1.0f;
-    const float tw = m[12] * vx + m[13] * vy + m[14] * vz + m[15] * 1.0f;
-    const float dz = ((vx + vy) + vz == 0.0f) ? 0.0f : tz / tw;
-    depth_map[i] = dz;
-    if (depth_clamped) depth_clamped[i] = dz < 0.01f ? 1000.0f : dz;
-}
 
 // the table of a batch travels as a kernel argument (no staging buffer, no copy engine) into device memory
 __global__ void upload_views_kernel(ViewTable t, int n, ViewRec* __restrict__ dst) {
@@ -606,6 +622,12 @@ int gps_tsdf_free_raycast_batch(const gps_tsdf_state* sp, int n_views, const gps
         r.fx = v.fx; r.fy = v.fy; r.cx = v.cx; r.cy = v.cy;
         r.visible_ids = v.visible_ids; r.minmax = v.minmax; r.raycast = v.raycast; r.colour = v.colour;
         r.scratch = v.scratch; r.counters = v.counters;
+        if (v.color_map) {
+            GPS_REQUIRE(v.vertex_map && v.confidence_map && v.depth_map);
+            r.w2c_rm = load_mat(v.w2c);
+            r.color_map = v.color_map; r.vertex_map = v.vertex_map; r.conf_map = v.confidence_map; r.depth_map = v.depth_map;
+            r.depth_clamped = v.depth_map_clamped;
+        }
     }
     ViewRec* tab = reinterpret_cast<ViewRec*>(table);
     upload_views_kernel<<<1, 256, 0, st>>>(t, n_views, tab);

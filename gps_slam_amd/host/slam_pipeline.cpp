@@ -213,15 +213,17 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
     }
     c10::optional<c10::hip::HIPStreamGuard> on_rc;
     if (ev_out) on_rc.emplace(static_cast<MapStream*>(rc_stream_)->s);
-    eng->runRaycastBatch(view_poses);
-    for (size_t k = 0; k < cams.size(); k++) {
-        TensorDict& m = out[k];
-        check(gps_raycast_to_maps(cams[k]->width, cams[k]->height,
-                                  reinterpret_cast<const float*>(eng->GetFreeVertex((int)k)->GetData(MEMORYDEVICE_CUDA)),
-                                  reinterpret_cast<const uint8_t*>(eng->GetFreeImage((int)k)->GetData(MEMORYDEVICE_CUDA)),
-                                  eng->getVoxelSize(), w2c[k].data_ptr<float>(), fptr(m["color_map"]), fptr(m["vertex_map"]),
-                                  fptr(m["confidence_map"]), fptr(m["depth_map"]), fptr(m["depth_map_clamped"]),
-                                  current_stream()), "gps_raycast_to_maps");
+    constexpr size_t kMaxBatch = 12;  // views per gps_tsdf_free_raycast_batch call; a later chunk reuses the render states in stream order
+    for (size_t base = 0; base < cams.size(); base += kMaxBatch) {
+        const size_t cnt = std::min(kMaxBatch, cams.size() - base);
+        std::vector<TsdfEngine::ViewMaps> maps(cnt);
+        for (size_t k = 0; k < cnt; k++) {
+            TensorDict& m = out[base + k];
+            maps[k] = {w2c[base + k].data_ptr<float>(), fptr(m["color_map"]), fptr(m["vertex_map"]), fptr(m["confidence_map"]),
+                       fptr(m["depth_map"]), fptr(m["depth_map_clamped"])};
+        }
+        // (the tensor glue of every view -- gps_raycast_to_maps -- is written by the batch's last kernel)
+        eng->runRaycastBatch(std::vector<ORUtils::SE3Pose>(view_poses.begin() + base, view_poses.begin() + base + cnt), nullptr, &maps);
     }
     if (ev_out) {
         if (rc_event_next_ == rc_events_.size()) {
@@ -264,6 +266,36 @@ void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std:
     void* ev = nullptr;
     for (TensorDict& m : raycastCams(cams, poses, async_raycasts ? &ev : nullptr)) {
         opt_raycast_list.push_back(m);
+        opt_raycast_events_.push_back(ev);
+    }
+}
+
+// localFrameRaycast + keyFrameRaycast of one keyframe update as ONE batch (what the keyframe-step functions call): same lists,
+// same random draws, same tensors; the window's and the keyframes' views share the launches.
+void SLAMPipeline::raycastWindowAndKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
+                                             const std::vector<ORUtils::SE3Pose>& poses) {
+    localframe_raycast_window.clear();
+    beginAsyncRaycasts();
+    std::vector<const Camera*> cams;
+    for (const Camera& cam : window) cams.push_back(&cam);
+    opt_cam_list.assign(window.begin(), window.end());
+    const int n = std::min<int>(keyframe_select_max, (int)keyframes.size());
+    RandomSelector<Camera> sel(keyframes, rng_);
+    for (int k = 0; k < n; k++) {
+        const Camera* cam = sel.getNext().second;
+        opt_cam_list.push_back(*cam);
+        cams.push_back(cam);
+    }
+    void* ev = nullptr;
+    std::vector<TensorDict> res = raycastCams(cams, poses, async_raycasts ? &ev : nullptr);
+    for (size_t k = 0; k < window.size(); k++) {
+        localframe_raycast_window.push_back(res[k]);
+        window_raycast_events_.push_back(ev);
+    }
+    opt_raycast_list.assign(localframe_raycast_window.begin(), localframe_raycast_window.end());
+    opt_raycast_events_ = window_raycast_events_;
+    for (size_t k = window.size(); k < res.size(); k++) {
+        opt_raycast_list.push_back(res[k]);
         opt_raycast_events_.push_back(ev);
     }
 }
@@ -455,6 +487,8 @@ void SLAMPipeline::ensureStreams() {
 }
 
 void SLAMPipeline::keyframeStep() {
+    // two batches here: initNewGaussians only needs the window's views and starts while the keyframes' views render (the
+    // overlapped arrangements below gate the NEXT FRAME on all views and take them as one batch)
     localFrameRaycast();
     keyFrameRaycast();
     initNewGaussians(localframe_raycast_window.back());
@@ -475,8 +509,7 @@ void SLAMPipeline::keyframeStepOverlapped() {
     {
         c10::hip::HIPStreamGuard guard(ms);
         if (prune_pending_) { removeRedundantGs(); prune_pending_ = false; }  // update k's prune, before update k+1 reads the model
-        localFrameRaycast();
-        keyFrameRaycast();
+        raycastWindowAndKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses);
         if (async_raycasts) waitAllRaycasts();  // (this arrangement keeps its single map stream: the gate below covers them)
         hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
         initNewGaussians(localframe_raycast_window.back());
@@ -544,8 +577,7 @@ void SLAMPipeline::mapWorker(int device_index) {
             }
             // job_ is stable until done_seq_ catches up (the frame thread waits for that before it writes the next one)
             hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
-            raycastWindow(job_.window, job_.poses);
-            raycastKeyframes(job_.window, job_.keyframes, job_.poses);
+            raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
             // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)
             hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, async_raycasts && rc_stream_ ? static_cast<MapStream*>(rc_stream_)->s.stream()
                                                                                          : ms.stream()), "hipEventRecord");

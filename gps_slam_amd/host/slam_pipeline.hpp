@@ -142,6 +142,8 @@ private:
     // the same for several cameras of one volume state in ONE batched free-view chain; one event for all results
     std::vector<TensorDict> raycastCams(const std::vector<const Camera*>& cams, const std::vector<ORUtils::SE3Pose>& poses,
                                         void** ev_out = nullptr);
+    void raycastWindowAndKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
+                                   const std::vector<ORUtils::SE3Pose>& poses);
     void raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses);
     void raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
                           const std::vector<ORUtils::SE3Pose>& poses);

@@ -160,10 +160,11 @@ void TsdfEngine::runRaycast(ORUtils::SE3Pose* pose, ITMLib::ITMIntrinsics* intri
     check(gps_tsdf_free_raycast(&s, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
 }
 
-void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics) {
+void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics,
+                                 const std::vector<ViewMaps>* maps) {
     const int n = (int)poses.size();
     if (n == 0) return;
-    TORCH_CHECK(n <= 16, "runRaycastBatch: at most 16 views per call");
+    TORCH_CHECK(n <= 12, "runRaycastBatch: at most 12 views per call");
     gps_tsdf_state s;
     { std::lock_guard<std::mutex> lk(state_mu_); s = state_; }
     float fx = s.fx, fy = s.fy, cx = s.cx, cy = s.cy;
@@ -176,7 +177,9 @@ void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITM
     const int64_t P = (int64_t)s.width * s.height;
     const auto I = torch::TensorOptions().dtype(torch::kInt32).device(device_);
     const auto F = torch::TensorOptions().dtype(torch::kFloat32).device(device_);
+    TORCH_CHECK(!maps || (int)maps->size() == n, "runRaycastBatch: one ViewMaps per pose");
     std::vector<gps_tsdf_view> recs(n);
+    memset(recs.data(), 0, sizeof(gps_tsdf_view) * (size_t)n);
     for (int k = 0; k < n; k++) {
         const bool fresh = k >= (int)views_.size();
         if (fresh) {
@@ -198,9 +201,15 @@ void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITM
         r.fx = fx; r.fy = fy; r.cx = cx; r.cy = cy;
         r.visible_ids = iptr(v.visible_ids); r.minmax = fptr(v.minmax); r.raycast = fptr(v.raycast);
         r.colour = ptr<uint8_t>(v.colour); r.scratch = reinterpret_cast<int32_t*>(v.scratch.data_ptr()); r.counters = iptr(v.counters);
+        if (maps) {
+            const ViewMaps& o = (*maps)[k];
+            memcpy(r.w2c, o.w2c_row_major, 64);
+            r.color_map = o.color_map; r.vertex_map = o.vertex_map; r.confidence_map = o.confidence_map;
+            r.depth_map = o.depth_map; r.depth_map_clamped = o.depth_map_clamped;
+        }
         if (fresh) check(gps_tsdf_view_init(&s, &r, current_stream()), "gps_tsdf_view_init");
     }
-    if (!view_table_.defined()) view_table_ = zeros_bytes(gps_tsdf_view_table_bytes(16), device_);
+    if (!view_table_.defined()) view_table_ = zeros_bytes(gps_tsdf_view_table_bytes(12), device_);
     check(gps_tsdf_free_raycast_batch(&s, n, recs.data(), view_table_.data_ptr(), current_stream()), "gps_tsdf_free_raycast_batch");
 }
 

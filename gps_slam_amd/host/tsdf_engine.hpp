@@ -155,7 +155,10 @@ public:
     // runRaycast for several poses at once (gps_tsdf_free_raycast_batch): every launch of the free-view chain covers all
     // views, each view renders into a render state of its own (kept by the engine, created on first use) -- view k's images
     // are GetFreeImage(k) / GetFreeVertex(k).  Same images as runRaycast(pose k) would leave in GetFreeImage() / GetFreeVertex().
-    void runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics = nullptr);
+    // `maps` (optional, one per pose): the runRaycastByCam tensor glue of the view (gps_raycast_to_maps), written by the batch.
+    struct ViewMaps { const float* w2c_row_major; float *color_map, *vertex_map, *confidence_map, *depth_map, *depth_map_clamped; };
+    void runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics = nullptr,
+                         const std::vector<ViewMaps>* maps = nullptr);
     ITMUChar4Image* GetFreeImage(int view) { return views_.at(view)->image_p.get(); }
     ITMFloat4Image* GetFreeVertex(int view) { return views_.at(view)->vertex_p.get(); }
     ITMUChar4Image* GetFreeImage() { return &free_image_; }

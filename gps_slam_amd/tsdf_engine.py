@@ -175,7 +175,7 @@ class TsdfEngine:
             arr[k].M[:] = M.reshape(-1).tolist(); arr[k].invM[:] = invM.reshape(-1).tolist()
             arr[k].fx, arr[k].fy, arr[k].cx, arr[k].cy = self.state.fx, self.state.fy, self.state.cx, self.state.cy
         if getattr(self, "_view_table", None) is None or self._view_table.numel() < int(lib.gps_tsdf_view_table_bytes(n)):
-            self._view_table = torch.zeros(int(lib.gps_tsdf_view_table_bytes(16)), dtype=torch.uint8, device=self.device)
+            self._view_table = torch.zeros(int(lib.gps_tsdf_view_table_bytes(12)), dtype=torch.uint8, device=self.device)
         check(lib.gps_tsdf_free_raycast_batch(C.byref(self.state), n, arr, self._view_table.data_ptr(), self._stream()),
               "gps_tsdf_free_raycast_batch")
 

@@ -539,7 +539,7 @@ GPS_API int gps_tsdf_free_raycast(const gps_tsdf_state *s, const float *M, const
  * image), a scratch area of gps_tsdf_scratch_bytes() and a private counter block (int32[GPS_TSDF_N_COUNTERS]; the list length
  * lands in counters[GPS_TSDF_N_VISIBLE_FREE]).  gps_tsdf_view_init prepares minmax / counters ONCE after allocation (what
  * gps_tsdf_reset does for the state's own free view).  `table` is device memory of gps_tsdf_view_table_bytes(n_views) bytes the
- * call overwrites; n_views <= 16.  The scene's own free-view buffers and scratch are not touched; MAX_RENDERING_BLOCKS
+ * call overwrites; n_views <= 12.  The scene's own free-view buffers and scratch are not touched; MAX_RENDERING_BLOCKS
  * overflow of any view is raised in the SCENE's counters[GPS_TSDF_OVERFLOW]. */
 typedef struct gps_tsdf_view {
     float M[16], invM[16];  /* pose of the view (ORUtils layout, as gps_tsdf_free_raycast) */
@@ -550,6 +550,10 @@ typedef struct gps_tsdf_view {
     uint8_t *colour;        /* [H*W*4] out: what fv_colour receives */
     int32_t *scratch;       /* gps_tsdf_scratch_bytes(width, height, n_buckets, n_excess) bytes */
     int32_t *counters;      /* [GPS_TSDF_N_COUNTERS] */
+    /* optional: the view's runRaycastByCam tensor glue (exactly gps_raycast_to_maps on this view's rays / colour, written by
+     * the batch's last kernel instead of one more launch per view).  color_map == NULL: none. */
+    float w2c[16];          /* ROW-major, as gps_raycast_to_maps */
+    float *color_map, *vertex_map, *confidence_map, *depth_map, *depth_map_clamped;  /* depth_map_clamped may be NULL */
 } gps_tsdf_view;
 GPS_API int64_t gps_tsdf_view_table_bytes(int n_views);
 GPS_API int gps_tsdf_view_init(const gps_tsdf_state *s, const gps_tsdf_view *view, gps_stream stream);
