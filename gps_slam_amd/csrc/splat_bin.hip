@@ -120,13 +120,17 @@ __global__ __launch_bounds__(BIN_BLOCK) void expand_kernel(int N, const float* _
                                                           int th, const int32_t* __restrict__ tiles_per_gauss,
                                                           const int32_t* __restrict__ groups_per_gauss,
                                                           const int32_t* __restrict__ blk_tiles,
-                                                          const int32_t* __restrict__ blk_groups, int64_t isect_cap,
-                                                          int64_t group_cap, uint32_t* __restrict__ keys,
+                                                          const int32_t* __restrict__ blk_groups,
+                                                          const int32_t* __restrict__ blk_vis, int64_t* __restrict__ counts,
+                                                          int64_t isect_cap, int64_t group_cap, uint32_t* __restrict__ keys,
                                                           uint32_t* __restrict__ vals,
                                                           int32_t* __restrict__ group_gs_ids,
                                                           int32_t* __restrict__ group_starts,
                                                           const uint32_t* __restrict__ order) {
     // order != NULL: thread i expands the Gaussian of depth rank i (tiles_per_gauss is then indexed by rank)
+    // blk_tiles / blk_groups / blk_vis hold the per-block COUNTS of the count pass: every workgroup sums the blocks in front of
+    // it itself (<= a few thousand ints, one coalesced read) instead of a single-workgroup scan launch in between, and the last
+    // workgroup publishes the totals (counts[0..3], clamped to the capacities as before)
     __shared__ int ws[17];
     __shared__ int pre_t[BIN_BLOCK + 1];
     __shared__ int pre_g[BIN_BLOCK + 1];
@@ -151,7 +155,22 @@ __global__ __launch_bounds__(BIN_BLOCK) void expand_kernel(int N, const float* _
     pre_t[tid] = et; pre_g[tid] = eg;
     if (tid == 0) { pre_t[BIN_BLOCK] = tot_t; pre_g[BIN_BLOCK] = tot_g; }
     __syncthreads();
-    const int64_t base_t = blk_tiles[blockIdx.x], base_g = blk_groups[blockIdx.x];
+    int pt = 0, pg = 0, pv = 0;
+    for (int k = tid; k < (int)blockIdx.x; k += BIN_BLOCK) { pt += blk_tiles[k]; pg += blk_groups[k]; pv += blk_vis[k]; }
+    int sum_t, sum_g, sum_v;
+    block_excl_scan(pt, ws, sum_t);
+    block_excl_scan(pg, ws, sum_g);
+    block_excl_scan(pv, ws, sum_v);
+    const int64_t base_t = sum_t, base_g = sum_g;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        int64_t ni = base_t + tot_t, ng = base_g + tot_g;
+        int64_t ovf = 0;
+        if (ni > isect_cap) { ni = isect_cap; ovf = 1; }
+        if (ng > group_cap) { ng = group_cap; ovf = 1; }
+        // the overflow word is STICKY (only ever raised here): a host that looks at it once per keyframe still sees an
+        // overflow of any launch in between; the caller zeroes it
+        counts[0] = ni; counts[1] = ng; if (ovf) counts[2] = 1; counts[3] = sum_v + blk_vis[blockIdx.x];
+    }
     // one thread per output intersection
     for (int j = tid; j < tot_t; j += BIN_BLOCK) {
         int lo = 0, hi = BIN_BLOCK;  // largest src with pre_t[src] <= j
@@ -542,13 +561,14 @@ static int isect_impl(int N, const float* means2d, const int32_t* radii, const f
         count_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
                                                    tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
                                                    w.blk_vis, order, w.tiles_by_rank);
-    scan_blocks_kernel<<<1, SCAN_THREADS, 0, s>>>(N > 0 ? w.nblkN : 0, w.blk_tiles, w.blk_groups, w.blk_vis,
-                                                  isect_capacity, group_capacity, counts);
-    if (N > 0)
+    if (N > 0)  // (prefix over the blocks + totals inside: no scan launch)
         expand_kernel<<<w.nblkN, BIN_BLOCK, 0, s>>>(N, means2d, radii, tile_size, tile_width, tile_height,
-                                                    tpg_scan, w.groups_per_gauss, w.blk_tiles, w.blk_groups,
+                                                    tpg_scan, w.groups_per_gauss, w.blk_tiles, w.blk_groups, w.blk_vis, counts,
                                                     isect_capacity, group_capacity, w.keys_a, w.vals_a, group_gs_ids,
                                                     group_starts, order);
+    else  // nothing to expand: the totals are zeros
+        scan_blocks_kernel<<<1, SCAN_THREADS, 0, s>>>(0, w.blk_tiles, w.blk_groups, w.blk_vis, isect_capacity, group_capacity,
+                                                      counts);
     int bits_total = 1;
     while ((1 << bits_total) < n_tiles) bits_total++;
     const uint32_t* sorted_keys = nullptr;
