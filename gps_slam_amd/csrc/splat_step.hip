@@ -45,8 +45,8 @@ int gps_splat_render(const gps_splat_step* a, gps_stream stream) { return render
 int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stream) {
     GPS_REQUIRE(a != nullptr && adam_step >= 1);
     GPS_REQUIRE(a->gt_rgb && a->loss && a->v_render_colors && a->v_render_alphas);
-    // Launch sites of one iteration: preprocess (+ binning count pass + zero-fill of the rasterizer gradients), scan, expand,
-    // count table, row scan, scatter, forward rasterizer (+ compose + L1 + image gradients in its epilogue), backward
+    // Launch sites of one iteration (8): preprocess (+ binning count pass + zero-fill of the rasterizer gradients), expand
+    // (+ block prefix and totals), count table, row scan, scatter, forward rasterizer (+ compose + L1 + image gradients in its epilogue), backward
     // rasterizer, preprocess backward (+ Adam).
     GPS_REQUIRE(a->base_color != nullptr);
     const bool fused_fwd = a->records != nullptr;  // the record rasterizer carries the compose epilogue
