@@ -487,8 +487,7 @@ void SLAMPipeline::ensureStreams() {
 }
 
 void SLAMPipeline::keyframeStep() {
-    // two batches here: initNewGaussians only needs the window's views and starts while the keyframes' views render (the
-    // overlapped arrangements below gate the NEXT FRAME on all views and take them as one batch)
+    // two batches: initNewGaussians only needs the window's views and starts while the keyframes' views render
     localFrameRaycast();
     keyFrameRaycast();
     initNewGaussians(localframe_raycast_window.back());
@@ -509,7 +508,8 @@ void SLAMPipeline::keyframeStepOverlapped() {
     {
         c10::hip::HIPStreamGuard guard(ms);
         if (prune_pending_) { removeRedundantGs(); prune_pending_ = false; }  // update k's prune, before update k+1 reads the model
-        raycastWindowAndKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses);
+        if (merge_keyframe_raycasts) raycastWindowAndKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses);
+        else { localFrameRaycast(); keyFrameRaycast(); }
         if (async_raycasts) waitAllRaycasts();  // (this arrangement keeps its single map stream: the gate below covers them)
         hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, ms.stream()), "hipEventRecord");
         initNewGaussians(localframe_raycast_window.back());
@@ -577,7 +577,8 @@ void SLAMPipeline::mapWorker(int device_index) {
             }
             // job_ is stable until done_seq_ catches up (the frame thread waits for that before it writes the next one)
             hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
-            raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
+            if (merge_keyframe_raycasts) raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
+            else { raycastWindow(job_.window, job_.poses); raycastKeyframes(job_.window, job_.keyframes, job_.poses); }
             // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)
             hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, async_raycasts && rc_stream_ ? static_cast<MapStream*>(rc_stream_)->s.stream()
                                                                                          : ms.stream()), "hipEventRecord");

@@ -126,6 +126,11 @@ public:
     // Results are those of the sequential schedule.  Off by default: with it on, processFrame() returns while the update is
     // still in flight and the model may only be read after flush() (SLAMTrainCams and the accessors below call it).
     bool overlap_mapping = false;
+    // overlapped arrangements: the window's and the keyframes' free views of an update as ONE batch (the next frame's fusion waits
+    // for all of them anyway: 0.68 instead of 0.23 + 0.54 ms) or as two (initNewGaussians then starts after the window's views
+    // alone).  Measured: one batch is + 1 % on some boxes of the pool and - 5 % on others at 640x480 (the map update and the ten
+    // frames it runs beside are equally long there, so which of the two waits for the other flips) and - 6 % at 1280x720: two.
+    bool merge_keyframe_raycasts = false;
     bool async_raycasts = true;   // the update's free-view raycasts run beside its optimise iterations (same results)
     // with overlap_mapping: run the map update on a worker thread of its own (tracking thread + mapping thread) instead of
     // interleaving its host work with the frames on the caller's thread
