@@ -129,7 +129,9 @@ __device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int
 #ifndef GPS_FWD_LIST_SPLIT
 #define GPS_FWD_LIST_SPLIT 4
 #endif
-constexpr int FWD_SPLIT = GPS_FWD_LIST_SPLIT;  // waves per pixel half: the tile's list is added in this many parts
+constexpr int FWD_SPLIT = GPS_FWD_LIST_SPLIT;  // waves per pixel half: the tile's list is added in this many parts.  The kernel is
+// VALU-bound with stalls (66 % of the issue slots at 2 parts): more waves per tile hide them -- 2 parts 63 us, 3: 60, 4: 55.5, 6: 57,
+// 8: 77 (bench scene, 1,200 tiles; the sums of the parts are added in order, so the split only changes the rounding of the total)
 constexpr int FWD_THREADS = 128 * FWD_SPLIT;
 __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,

@@ -592,7 +592,8 @@ int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stre
     GPS_REQUIRE(sp != nullptr && M != nullptr);
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
-    // persistent grid of 8192 waves (one block per wave at a time), strides over the visible list
+    // a fixed grid of waves strides over the visible list, one block per wave at a time; measured on the bench scene (46 k visible
+    // blocks, us per launch): 1024 workgroups 71, 2048: 67, 4096: 63, 8192: 63.5, 16384: 66
     // the fast exact divisions need mu's significand not to be all ones (div_known_safe); any other mu takes the generic path
 #ifndef GPS_INTEGRATE_WGS
 #define GPS_INTEGRATE_WGS 4096
