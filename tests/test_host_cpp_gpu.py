@@ -484,13 +484,14 @@ def test_overlapped_mapping_equals_sequential_schedule():
     rgb = torch.as_tensor(rgba).to(DEV)
     dep = torch.as_tensor(seq["depth"].astype(np.int16)).to(DEV)
 
-    def run(overlap, thread=False):
+    def run(overlap, thread=False, merge=False):
         eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
         model = h.SLAMGaussianModel()
         model.loadConfig(dict(capacity=1 << 16))
         pipe = h.SLAMPipeline(eng, model, 11, False)  # tracking on: the latency-bound part that overlaps
         pipe.overlap_mapping = overlap
         pipe.mapping_thread = thread
+        pipe.merge_keyframe_raycasts = merge  # an update's free views as one batch instead of window + keyframes
         for i in range(n):
             c = h.Camera(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
             c.id = i
@@ -504,7 +505,8 @@ def test_overlapped_mapping_equals_sequential_schedule():
                 [t.clone() for t in (p.getMeans(), p.getScales(), p.getQuats(), p.getFeaturesDc(), p.getFeaturesRest(), p.getOpacities())])
 
     st_s, cnt_s, live_s, par_s = run(False)
-    for mode in ((True, False), (True, True)):  # streams on one host thread; tracking thread + mapping thread
+    # streams on one host thread; tracking thread + mapping thread; the latter with one free-view batch per update
+    for mode in ((True, False), (True, True), (True, True, True)):
         st_o, cnt_o, live_o, par_o = run(*mode)
         assert st_s == st_o and st_s["opt_iters"] == 60 and st_s["added"] > 100
         assert torch.equal(cnt_s[:4], cnt_o[:4]) and torch.equal(live_s, live_o)
