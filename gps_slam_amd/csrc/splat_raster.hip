@@ -265,8 +265,10 @@ __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restric
 // Phase A: lanes 0..15 of each half fetch their step's group header and Gaussian record and park them in LDS --
 //          ONE global round trip per task instead of one dependent chain per step.
 // Phase B: 16 steps; every lane of a half reads its step's record from LDS, evaluates its pixel of the 2r x 2r box and
-//          accumulates in registers; several steps are in flight at a time so that their pixel gathers overlap.  A half
-//          reduces and writes its 10 sums only when the Gaussian changes.
+//          accumulates in registers.  BWD_INFLIGHT steps are evaluated before the first is accumulated; with the straight-line
+//          evaluation below ONE step at a time is fastest (68 VGPRs, 7 waves per SIMD: 62.5 us against 65.5 for two steps
+//          at 82 VGPRs / 5 waves and 70 for four): other waves cover the gather better than a second step in this one.  A
+//          half reduces and writes its 10 sums only when the Gaussian changes.
 //
 // Per-pixel inputs: three gathers per pixel slot (ref_depth 4 B, v_render_colors 16 B, v_render_alphas 4 B).  Packing them into
 // one 32-byte record per pixel (written by the compose kernel; 2 x dwordx4 from one sector) was built and measured SLOWER
@@ -348,7 +350,7 @@ struct __attribute__((aligned(16))) BwdRec {
 };
 
 #ifndef GPS_BWD_INFLIGHT
-#define GPS_BWD_INFLIGHT 2
+#define GPS_BWD_INFLIGHT 1
 #endif
 constexpr int BWD_INFLIGHT = GPS_BWD_INFLIGHT;
 struct BwdPix { bool on; float alpha, vis, dx, dy, cut; float4 vc; float va; };
@@ -526,7 +528,10 @@ int raster_ges_bwd_gs_launch(int N, const float* means2d, const float* conics, c
     if (zero_mode == 0)
         zero_grads_kernel<<<min(2048, gps_div_up(4 * (int64_t)N, 256)), 256, 0, s>>>(N, v_means2d, v_conics, v_colors,
                                                                                      v_opacities);
-    constexpr int bwd_blocks = 4096;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
+#ifndef GPS_BWD_BLOCKS
+#define GPS_BWD_BLOCKS 4096
+#endif
+    constexpr int bwd_blocks = GPS_BWD_BLOCKS;  // multiple of 8 (one contiguous task range per XCD), 16 workgroups per CU
     BwdPixArgs src = {ref_depth_map, (const float4*)v_render_colors, v_render_alphas, delta_depth};
     // plain stores where a half-wave owns a Gaussian: only if the buffers are known to be zero (filled here or by the caller)
     raster_ges_bwd_gs_kernel<<<bwd_blocks, 256, 0, s>>>(group_gs_ids, group_starts, (const float2*)means2d, conics,
