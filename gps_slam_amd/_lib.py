@@ -123,6 +123,7 @@ PROTOTYPES = {
     "gps_normal_map": (i32, [i32, i32, vp, vp, vp]),
     "gps_zero_floats": (i32, [i32, vp, vp, vp]),
     "gps_rgba8_to_rgbf": (i32, [i32, vp, vp, vp]),
+    "gps_rgba8_to_rgbf_and_floats": (i32, [i32, vp, vp, vp, vp, i32, vp]),
     "gps_prune_mask": (i32, [i32, vp, vp, f32, f32, f32, vp, vp, vp]),
     "gps_gather_rows": (i32, [i32, vp, i32, vp, vp, vp, vp]),
     "gps_init_gaussians": (i32, [i32, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a, const in
 }
 
 // uchar4 frame -> float3 image in [0, 1]: tensor.slice(2, 0, 3).to(float).div_(255) (x * RN(1/255)) in one launch
-__global__ __launch_bounds__(256) void rgba8_to_rgbf_kernel(int P, const uchar4* __restrict__ src, float* __restrict__ dst) {
+// (+ optionally up to 64 host floats through the kernel-argument buffer, as upload_floats_kernel: Camera::toGPU's pose / intrinsics
+// pack in the same launch as the frame's image)
+__global__ __launch_bounds__(256) void rgba8_to_rgbf_kernel(int P, const uchar4* __restrict__ src, float* __restrict__ dst,
+                                                           SmallFloats v, int n_floats, float* __restrict__ floats_dst) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_floats) floats_dst[threadIdx.x] = v.v[threadIdx.x];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const uchar4 c = src[p];
@@ -399,7 +403,22 @@ int gps_rgba8_to_rgbf(int n_pixels, const uint8_t* rgba, float* rgb, gps_stream 
     GPS_REQUIRE(n_pixels >= 0);
     if (n_pixels == 0) return GPS_OK;
     GPS_REQUIRE(rgba && rgb && (((uintptr_t)rgba) & 3) == 0);
-    rgba8_to_rgbf_kernel<<<gps_div_up(n_pixels, 256), 256, 0, (hipStream_t)stream>>>(n_pixels, reinterpret_cast<const uchar4*>(rgba), rgb);
+    SmallFloats none = {};
+    rgba8_to_rgbf_kernel<<<gps_div_up(n_pixels, 256), 256, 0, (hipStream_t)stream>>>(n_pixels, reinterpret_cast<const uchar4*>(rgba), rgb,
+                                                                                     none, 0, nullptr);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+int gps_rgba8_to_rgbf_and_floats(int n_pixels, const uint8_t* rgba, float* rgb, float* floats_dst, const float* host_values,
+                                 int n_floats, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(n_pixels > 0 && rgba && rgb && (((uintptr_t)rgba) & 3) == 0);
+    GPS_REQUIRE(floats_dst && host_values && n_floats > 0 && n_floats <= 64);
+    SmallFloats v;
+    for (int k = 0; k < 64; k++) v.v[k] = k < n_floats ? host_values[k] : 0.0f;
+    rgba8_to_rgbf_kernel<<<gps_div_up(n_pixels, 256), 256, 0, (hipStream_t)stream>>>(n_pixels, reinterpret_cast<const uchar4*>(rgba), rgb,
+                                                                                     v, n_floats, floats_dst);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

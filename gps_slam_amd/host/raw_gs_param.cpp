@@ -22,7 +22,12 @@ torch::Tensor poseInv(const torch::Tensor& c2w) {
     return out;
 }
 
-void Camera::toGPU(const torch::Device& device) {
+void Camera::toGPU(const torch::Device& device) { toGPU(device, torch::Tensor()); }
+
+void Camera::toGPU(const torch::Device& device, const torch::Tensor& frame_rgba_u8) {
+    const bool convert = frame_rgba_u8.defined() && !image.defined();
+    if (convert) image = torch::empty({frame_rgba_u8.size(0), frame_rgba_u8.size(1), 3}, f32(frame_rgba_u8.device()));
+    bool converted = false;
     if (!pack_.defined()) {
         auto c = c2w_slam.to(torch::kCPU, torch::kFloat32).contiguous();
         float h[28];
@@ -38,8 +43,17 @@ void Camera::toGPU(const torch::Device& device) {
         h[25] = m[3]; h[26] = m[7]; h[27] = m[11];
         // through the kernel argument buffer: no pinned staging tensor, no copy-engine latency on the frame stream
         pack_ = torch::empty({28}, f32(device));
-        check(gps_upload_floats(fptr(pack_), h, 28, current_stream()), "gps_upload_floats");
+        if (convert) {
+            check(gps_rgba8_to_rgbf_and_floats((int)(frame_rgba_u8.size(0) * frame_rgba_u8.size(1)), ptr<uint8_t>(frame_rgba_u8),
+                                               fptr(image), fptr(pack_), h, 28, current_stream()), "gps_rgba8_to_rgbf_and_floats");
+            converted = true;
+        } else {
+            check(gps_upload_floats(fptr(pack_), h, 28, current_stream()), "gps_upload_floats");
+        }
     }
+    if (convert && !converted)
+        check(gps_rgba8_to_rgbf((int)(frame_rgba_u8.size(0) * frame_rgba_u8.size(1)), ptr<uint8_t>(frame_rgba_u8), fptr(image),
+                                current_stream()), "gps_rgba8_to_rgbf");
     if (image.defined() && !image.is_cuda()) image = image.to(device);
     if (depth.defined() && !depth.is_cuda()) depth = depth.to(device);
 }

@@ -25,6 +25,9 @@ struct Camera {
     // curr_cam.toGPU() (slam_pipeline.cpp:84).  viewmat = poseInv(c2w_slam), K and the camera position are packed on
     // the host and go up in ONE 28-float copy (the reference launches ~8 tiny device kernels for poseInv).
     void toGPU(const torch::Device& device = torch::kCUDA);
+    // the same when the frame already sits in HBM as the uchar4 image UpdateView uploaded and no float image was kept for this
+    // camera: image := rgba[..., :3] / 255 and the pack in ONE launch (gps_rgba8_to_rgbf_and_floats)
+    void toGPU(const torch::Device& device, const torch::Tensor& frame_rgba_u8);
     void invalidate() { pack_ = torch::Tensor(); }
     const float* viewmat() const { return pack_.data_ptr<float>(); }
     const float* Kmat() const { return pack_.data_ptr<float>() + 16; }

@@ -420,6 +420,7 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     if (!main_engine->trackingActive && (int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed)
         main_engine->gtC2wPoses.push_back(cam.c2w);
     ITMTrackingState* ts;
+    torch::Tensor frame_rgba;
     if (rgb_u8.defined()) {
         ts = main_engine->ProcessFrame(rgb_u8, depth_mm_i16);
     } else {
@@ -427,14 +428,9 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
         TORCH_CHECK(tsdf_engine != nullptr && i == tsdf_engine->currentFrameNo, "frame ", i, " is not the CLIEngine's next frame");
         tsdf_engine->ProcessFrame();
         ts = main_engine->GetTrackingState();
-        if (!cam.image.defined()) {
-            // no float copy of the image was kept for this camera: derive it from the uchar4 frame UpdateView just put into HBM
-            // (3 of its 4 bytes per pixel) instead of uploading 12 more bytes per pixel as Camera::toGPU would
-            auto rgba = main_engine->currentRgb();  // [H,W,4] u8, contiguous
-            cam.image = torch::empty({rgba.size(0), rgba.size(1), 3}, f32(rgba.device()));
-            check(gps_rgba8_to_rgbf((int)(rgba.size(0) * rgba.size(1)), ptr<uint8_t>(rgba), fptr(cam.image), current_stream()),
-                  "gps_rgba8_to_rgbf");
-        }
+        // (no float copy of the image kept for this camera: it is derived below, with the pose pack, from the uchar4 frame
+        // UpdateView just put into HBM -- 3 of its 4 bytes per pixel instead of uploading 12 more as Camera::toGPU would)
+        if (!cam.image.defined()) frame_rgba = main_engine->currentRgb();  // [H,W,4] u8, contiguous
     }
     // est_pose = pose_d->GetInvM() (:81-82): ORUtils column-major -> row-major tensor
     auto est = torch::empty({4, 4}, torch::kFloat32);
@@ -443,7 +439,7 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
         for (int c = 0; c < 4; c++) est.data_ptr<float>()[4 * r + c] = invM[4 * c + r];
     cam.c2w_slam = est;
     cam.invalidate();
-    cam.toGPU(device);
+    cam.toGPU(device, frame_rgba);
     curr_cam = cam;
     updateFrameList();
     stats.frames++;

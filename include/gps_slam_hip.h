@@ -352,6 +352,10 @@ GPS_API int gps_normal_map(int width, int height, const float *vertex_map, float
  * the frame is already in HBM as the uchar4 image UpdateView uploaded: 3 of its 4 bytes per pixel instead of a second
  * 12-byte-per-pixel upload). */
 GPS_API int gps_rgba8_to_rgbf(int n_pixels, const uint8_t *rgba, float *rgb, gps_stream stream);
+/* ... and gps_upload_floats(floats_dst, host_values, n_floats) in the SAME launch: the two things curr_cam.toGPU()
+ * (slam/slam_pipeline.cpp:84) puts into HBM for a frame -- its image and its pose / intrinsics -- as one kernel. */
+GPS_API int gps_rgba8_to_rgbf_and_floats(int n_pixels, const uint8_t *rgba, float *rgb, float *floats_dst,
+                                         const float *host_values, int n_floats, gps_stream stream);
 
 /* Uploads up to 64 floats from host memory into device memory THROUGH THE KERNEL ARGUMENT BUFFER (values are read on the host at
  * call time; no pinned staging, no copy-engine transfer, ordered on `stream` like any kernel).  Camera::toGPU() uses it for the

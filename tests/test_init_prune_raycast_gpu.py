@@ -414,3 +414,10 @@ def test_rgba8_to_rgbf_equals_the_tensor_sequence():
     out = torch.empty(H, W, 3, device=DEV)
     assert lib.gps_rgba8_to_rgbf(H * W, rgba.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     assert torch.equal(out, rgba[..., :3].to(torch.float32).div_(255.0))
+    # the same launch also carrying Camera::toGPU's 28-float pack (gps_rgba8_to_rgbf_and_floats)
+    import numpy as np
+    vals = np.random.default_rng(3).standard_normal(28).astype(np.float32)
+    out2, pack = torch.zeros(H, W, 3, device=DEV), torch.zeros(32, device=DEV)
+    assert lib.gps_rgba8_to_rgbf_and_floats(H * W, rgba.data_ptr(), out2.data_ptr(), pack.data_ptr(), vals.ctypes.data, 28,
+                                            torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(out2, out) and np.array_equal(pack[:28].cpu().numpy(), vals) and float(pack[28:].abs().sum()) == 0.0
