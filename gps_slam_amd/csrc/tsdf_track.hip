@@ -159,6 +159,8 @@ struct PrepArgs {
     gps_track_config cfg;
     LevelTab tab_vals[GPS_TRACK_MAX_LEVELS];  // (host-side staging of the per-level constants; the kernels do not read it)
     const float* depth0;                // full-resolution depth (s.depth)
+    const int16_t* depth_mm;            // != NULL (tile kernel only): the frame's raw depth; the kernel converts it and
+    float* depth0_out;                  //   writes s.depth itself (gps_tsdf_convert_depth folded into this launch)
     float* level[GPS_TRACK_MAX_LEVELS]; // [0] unused
     const float4* points;               // ICP maps of the last raycast
     const float4* normals;
@@ -227,7 +229,13 @@ __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
     const bool in = x < a.W && y < a.H;
     if (in) {
         const int i = x + y * a.W;
-        d = a.depth0[i];
+        if (a.depth_mm) {  // convertDepthAffineToFloat with the reference's 1/1000, 0 calibration (tsdf_fusion.hip: convert_depth_kernel)
+            const int16_t mm = a.depth_mm[i];
+            d = mm <= 0 ? -1.0f : (float)mm * (1.0f / 1000.0f) + 0.0f;
+            a.depth0_out[i] = d;
+        } else {
+            d = a.depth0[i];
+        }
         a.pn[2 * i] = a.points[i];
         a.pn[2 * i + 1] = a.normals[i];
     }
@@ -604,8 +612,17 @@ int64_t gps_track_scratch_bytes(int width, int height) {
     return (int64_t)carve(nullptr, nullptr, width, height);
 }
 
+static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c, gps_track_state* ts, void* scratch,
+                             int64_t scratch_bytes, gps_stream stream, const int16_t* depth_mm);
+
 int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, gps_track_state* ts, void* scratch,
                           int64_t scratch_bytes, gps_stream stream) {
+    return track_camera_impl(sp, c, ts, scratch, scratch_bytes, stream, nullptr);
+}
+
+// depth_mm != NULL: s.depth has NOT been converted yet; the prepare launch does it (tile kernel) or it is converted first
+static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c, gps_track_state* ts, void* scratch,
+                             int64_t scratch_bytes, gps_stream stream, const int16_t* depth_mm) {
     GPS_ENTER();
     GPS_REQUIRE(sp && c && ts && scratch);
     GPS_REQUIRE(state_valid(*sp));
@@ -626,6 +643,11 @@ int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, g
     PrepArgs pa;
     pa.cfg = *c;
     pa.depth0 = s.depth;
+    pa.depth_mm = nullptr; pa.depth0_out = s.depth;
+    if (depth_mm) {
+        if (c->n_levels <= 5) pa.depth_mm = depth_mm;
+        else { int r0 = gps_tsdf_convert_depth(sp, depth_mm, stream); if (r0 != GPS_OK) return r0; }
+    }
     pa.level[0] = nullptr;
     for (int l = 1; l < GPS_TRACK_MAX_LEVELS; l++) pa.level[l] = w.level[l];
     for (int l = 1; l < c->n_levels; l++) {
@@ -872,10 +894,12 @@ int gps_tsdf_process_frame_tracked_gated(const gps_tsdf_state* s, const int16_t*
                                          void (*before_fusion)(void*), void* user) {
     GPS_REQUIRE(s && depth_mm && cfg && ts);
     int r;
-    if ((r = gps_tsdf_convert_depth(s, depth_mm, stream)) != GPS_OK) return r;
     if (ts->age_point_cloud != -1) {  // ITMTrackingState::HasValidPointCloud
         if (ts->age_point_cloud >= 0) ts->frames_processed++; else ts->frames_processed = 0;
-        if ((r = gps_tsdf_track_camera(s, cfg, ts, scratch, scratch_bytes, stream)) != GPS_OK) return r;
+        // (the depth conversion rides in the tracker's prepare launch)
+        if ((r = track_camera_impl(s, cfg, ts, scratch, scratch_bytes, stream, depth_mm)) != GPS_OK) return r;
+    } else {
+        if ((r = gps_tsdf_convert_depth(s, depth_mm, stream)) != GPS_OK) return r;
     }
     if (before_fusion) before_fusion(user);  // everything above only READ the volume; what follows modifies it
     if ((r = gps_tsdf_allocate(s, ts->pose_M, ts->pose_invM, stream)) != GPS_OK) return r;
