@@ -458,7 +458,15 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
     }
     __syncthreads();
     const uint32_t ctl = __builtin_amdgcn_readfirstlane(line[1]);
-    if ((ctl & 0xFF) != ARG_RUN) return;
+    if ((ctl & 0xFF) != ARG_RUN) {
+        // retired: tell the host its line has been consumed -- there is ONE argument line, and the host must not write the next
+        // launch's arguments into it while this launch, queued but not yet running, still has to find its own (it would then
+        // wait out ARG_TIMEOUT with the whole frame stream behind it)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && mailbox)
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(const_cast<float*>(mailbox)) + 32, (uint32_t)seq, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const int kind = (int)((ctl >> 8) & 0xFF), level = (int)((ctl >> 16) & 0xFF);
     LevelTab lt = pa.tab[0];
 #pragma unroll
@@ -711,13 +719,24 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         arg_line[0] = wds[0];
     };
-    // a pre-launched evaluation that has not been given its arguments yet; retired with ARG_SKIP on every way out
+    // Retire a pre-launched evaluation the loop did not need: ARG_SKIP, then wait until the launch has SEEN it (mailbox word
+    // 32 := its sequence number).  Usually that launch is already polling and answers within a PCIe round trip; when it is
+    // still queued behind other streams' kernels the wait is what keeps the next frame's first arguments from overwriting the
+    // line it has yet to read (measured without it: 1 overlap run in ~10 lost 50 ms -- one ARG_TIMEOUT -- in a single frame).
+    auto retire = [&](int seq) {
+        publish(seq, ARG_SKIP, 0, 0, nullptr);
+        for (long spin = 0; spin < 400000000L; spin++) {  // (bounded; the launch gives up by itself after ARG_TIMEOUT)
+            if (float_bits(mailbox[32]) == seq) break;
+            if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+        }
+    };
+    // a pre-launched evaluation that has not been given its arguments yet; retired on every way out
     struct Pending {
         int seq = 0;
-        decltype(publish)* pub;
-        ~Pending() { if (seq) (*pub)(seq, ARG_SKIP, 0, 0, nullptr); }
+        decltype(retire)* ret;
+        ~Pending() { if (seq) (*ret)(seq); }
     } pending;
-    pending.pub = &publish;
+    pending.ret = &retire;
     auto prelaunch = [&]() -> int {
         pending.seq = next_seq();
         track_eval_poll_kernel<<<EV_MAX_WGS, EV_THREADS, 0, st>>>(pl, w.partial, w.sync, w.result, mailbox, pending.seq, parity);
@@ -777,7 +796,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                 if (!got) {
                     // the pre-launched kernel gave up before its line arrived (this thread was descheduled for longer than
                     // ARG_TIMEOUT between the launch and the publish): retire what is queued and evaluate with a plain launch
-                    publish(pending.seq, ARG_SKIP, 0, 0, nullptr);
+                    retire(pending.seq);
                     pending.seq = 0;
                     const int seq2 = next_seq();
                     if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);

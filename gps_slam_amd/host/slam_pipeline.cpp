@@ -445,6 +445,10 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     stats.frames++;
     if (work_mode == "recon") return;
     if (i % local_opt_interval == 0 && i > 0) {
+        if (!views_reserved_) {  // every free-view render state an update can need, once, before the first update
+            main_engine->reserveViews(localframe_cam_window_length + keyframe_select_max);
+            views_reserved_ = true;
+        }
         if (overlap_mapping && mapping_thread) keyframeStepThreaded();
         else if (overlap_mapping) keyframeStepOverlapped();
         else keyframeStep();

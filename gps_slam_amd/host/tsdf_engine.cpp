@@ -160,6 +160,38 @@ void TsdfEngine::runRaycast(ORUtils::SE3Pose* pose, ITMLib::ITMIntrinsics* intri
     check(gps_tsdf_free_raycast(&s, pose->GetM(), pose->GetInvM(), current_stream()), "gps_tsdf_free_raycast");
 }
 
+// view k's render state, created (and initialised: gps_tsdf_view_init) on first use
+void TsdfEngine::ensureView(int k, const gps_tsdf_state& s) {
+    while ((int)views_.size() <= k) {
+        const int64_t P = (int64_t)s.width * s.height;
+        const auto I = torch::TensorOptions().dtype(torch::kInt32).device(device_);
+        const auto F = torch::TensorOptions().dtype(torch::kFloat32).device(device_);
+        std::unique_ptr<FreeView> v(new FreeView());
+        v->visible_ids = torch::zeros({s.n_blocks}, I);
+        v->minmax = torch::zeros({P * 2}, F);
+        v->raycast = torch::zeros({P * 4}, F);
+        v->colour = zeros_bytes(P * 4, device_);
+        v->scratch = zeros_bytes(gps_tsdf_scratch_bytes(s.width, s.height, s.n_buckets, s.n_excess) + 16, device_);
+        v->counters = torch::zeros({GPS_TSDF_N_COUNTERS}, I);
+        v->image_p.reset(new ITMUChar4Image(s.width, s.height, v->colour));
+        v->vertex_p.reset(new ITMFloat4Image(s.width, s.height, v->raycast));
+        gps_tsdf_view r;
+        memset(&r, 0, sizeof(r));
+        r.minmax = fptr(v->minmax); r.counters = iptr(v->counters);
+        check(gps_tsdf_view_init(&s, &r, current_stream()), "gps_tsdf_view_init");
+        views_.push_back(std::move(v));
+    }
+}
+
+void TsdfEngine::reserveViews(int n) {
+    gps_tsdf_state s;
+    { std::lock_guard<std::mutex> lk(state_mu_); s = state_; }
+    if (n <= 0) return;
+    ensureView(std::min(n, 12) - 1, s);
+    // (the views are used from whatever stream a later runRaycastBatch runs on: finish their initialisation here)
+    TORCH_CHECK(hipStreamSynchronize((hipStream_t)current_stream()) == hipSuccess, "reserveViews: hipStreamSynchronize");
+}
+
 void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics,
                                  const std::vector<ViewMaps>* maps) {
     const int n = (int)poses.size();
@@ -174,26 +206,11 @@ void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITM
         fx = intrinsics->projectionParamsSimple.fx; fy = intrinsics->projectionParamsSimple.fy;
         cx = intrinsics->projectionParamsSimple.px; cy = intrinsics->projectionParamsSimple.py;
     }
-    const int64_t P = (int64_t)s.width * s.height;
-    const auto I = torch::TensorOptions().dtype(torch::kInt32).device(device_);
-    const auto F = torch::TensorOptions().dtype(torch::kFloat32).device(device_);
     TORCH_CHECK(!maps || (int)maps->size() == n, "runRaycastBatch: one ViewMaps per pose");
     std::vector<gps_tsdf_view> recs(n);
     memset(recs.data(), 0, sizeof(gps_tsdf_view) * (size_t)n);
     for (int k = 0; k < n; k++) {
-        const bool fresh = k >= (int)views_.size();
-        if (fresh) {
-            std::unique_ptr<FreeView> v(new FreeView());
-            v->visible_ids = torch::zeros({s.n_blocks}, I);
-            v->minmax = torch::zeros({P * 2}, F);
-            v->raycast = torch::zeros({P * 4}, F);
-            v->colour = zeros_bytes(P * 4, device_);
-            v->scratch = zeros_bytes(gps_tsdf_scratch_bytes(s.width, s.height, s.n_buckets, s.n_excess) + 16, device_);
-            v->counters = torch::zeros({GPS_TSDF_N_COUNTERS}, I);
-            v->image_p.reset(new ITMUChar4Image(s.width, s.height, v->colour));
-            v->vertex_p.reset(new ITMFloat4Image(s.width, s.height, v->raycast));
-            views_.push_back(std::move(v));
-        }
+        ensureView(k, s);
         FreeView& v = *views_[k];
         gps_tsdf_view& r = recs[k];
         memcpy(r.M, poses[k].GetM(), 64);
@@ -207,7 +224,6 @@ void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITM
             r.color_map = o.color_map; r.vertex_map = o.vertex_map; r.confidence_map = o.confidence_map;
             r.depth_map = o.depth_map; r.depth_map_clamped = o.depth_map_clamped;
         }
-        if (fresh) check(gps_tsdf_view_init(&s, &r, current_stream()), "gps_tsdf_view_init");
     }
     if (!view_table_.defined()) view_table_ = zeros_bytes(gps_tsdf_view_table_bytes(12), device_);
     check(gps_tsdf_free_raycast_batch(&s, n, recs.data(), view_table_.data_ptr(), current_stream()), "gps_tsdf_free_raycast_batch");

@@ -159,6 +159,9 @@ public:
     struct ViewMaps { const float* w2c_row_major; float *color_map, *vertex_map, *confidence_map, *depth_map, *depth_map_clamped; };
     void runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics = nullptr,
                          const std::vector<ViewMaps>* maps = nullptr);
+    // creates the render states of views 0 .. n-1 now (runRaycastBatch otherwise creates them on first use: ~20 MB of device
+    // allocations per view in the middle of a keyframe update)
+    void reserveViews(int n);
     ITMUChar4Image* GetFreeImage(int view) { return views_.at(view)->image_p.get(); }
     ITMFloat4Image* GetFreeVertex(int view) { return views_.at(view)->vertex_p.get(); }
     ITMUChar4Image* GetFreeImage() { return &free_image_; }
@@ -220,6 +223,7 @@ private:
         std::unique_ptr<ITMFloat4Image> vertex_p;
     };
     std::vector<std::unique_ptr<FreeView>> views_;
+    void ensureView(int k, const gps_tsdf_state& s);
     torch::Tensor view_table_;
     std::vector<torch::Tensor> frame_inputs_;
     torch::Tensor stage_rgb_[2], stage_depth_[2];  // UpdateView staging (host-resident input images), alternating per frame

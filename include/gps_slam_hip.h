@@ -624,7 +624,9 @@ typedef struct {
     float diag[16];
     /* optional: >= 256 bytes of PINNED, device-visible host memory (hipHostMalloc / torch pinned tensor).  If set, every
      * evaluation kernel writes its reduced sums (sequence number last) straight into it and the host spins on the sequence
-     * number instead of paying hipMemcpy + stream synchronise per iteration; NULL = the memcpy path. */
+     * number instead of paying hipMemcpy + stream synchronise per iteration; NULL = the memcpy path.  Layout (32-bit words,
+     * owned by the library): 0..31 the result row (two sequence-tagged 64-byte chunks), 32 the acknowledgement of a retired
+     * pre-launched evaluation, 48..63 the argument line the pre-launched evaluation reads. */
     void *host_mailbox;
     /* sequence number of the last tracking call on this state (owned by the library; kept by gps_track_state_reset) */
     int32_t mail_seq;

@@ -1,7 +1,8 @@
-# repeated default bench runs of the tree's build: spread and outliers of the two schedules
-for i in 1 2 3 4 5 6; do python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-oracle-psnr 2>&1 | python -c "
+# repeated default bench runs of the tree's build: spread and outliers of the overlap schedule (frames > 2 ms listed)
+N=${1:-6}
+for i in $(seq 1 $N); do GPS_BENCH_FRAME_TIMES=1 python bench.py --steps 100 --warmup 20 --schedule overlap --no-cpu-baseline --no-oracle-psnr 2> gpurun_out/rep_err_$i.log | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); c = j['config']; print('overlap %.1f sequential %.1f fusion_ms %.4f' % (j['value'], c['schedules']['sequential']['frames_per_s'], c['split']['fusion_ms_per_frame']))
-"; done
+        j = json.loads(l); c = j['config']; print('overlap %.1f' % (j['value']))
+"; grep "^frame\|^flush" gpurun_out/rep_err_$i.log | tail -101 | awk '$3 > 2.0 {printf "   %s %s ms;", $2, $3} END {print ""}'; grep TRACKDBG gpurun_out/rep_err_$i.log | head -6; done
