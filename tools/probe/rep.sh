@@ -5,4 +5,4 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); c = j['config']; print('overlap %.1f' % (j['value']))
-"; grep "^frame\|^flush" gpurun_out/rep_err_$i.log | tail -101 | awk '$3 > 2.0 {printf "   %s %s ms;", $2, $3} END {print ""}'; grep TRACKDBG gpurun_out/rep_err_$i.log | head -6; done
+"; grep "^frame\|^flush" gpurun_out/rep_err_$i.log | tail -101 | awk '$3 > 2.0 {printf "   %s %s ms;", $2, $3} END {print ""}'; done
