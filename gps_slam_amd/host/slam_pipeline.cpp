@@ -190,6 +190,21 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
     if (cams.empty()) return out;
     TsdfEngine* eng = main_engine;
     const auto F = f32(device);
+    if (!raycast_pool_warm_) {
+        // The result tensors of an update (5 per view, ~11 MB per 640x480 view) are allocated on the consumer's stream and freed
+        // when the next update replaces them, so in steady state the caching allocator hands the same blocks out again -- but
+        // while the keyframe list is still filling every update has one view more than the last, i.e. a fresh hipMalloc under
+        // the allocator's lock in the middle of an update (measured: the frame thread's own 3.7 MB image allocation then waited
+        // 3-6 ms for that lock in about one run in six).  Take the full set once, up front, and give it back to the cache.
+        std::vector<torch::Tensor> warm;
+        const int64_t H = cams[0]->height, W = cams[0]->width;
+        for (int k = 0; k < localframe_cam_window_length + keyframe_select_max; k++) {
+            warm.push_back(torch::empty({H, W, 3}, F)); warm.push_back(torch::empty({H, W, 3}, F));
+            warm.push_back(torch::empty({H, W, 1}, F)); warm.push_back(torch::empty({H, W, 1}, F));
+            warm.push_back(torch::empty({H, W, 1}, F));
+        }
+        raycast_pool_warm_ = true;
+    }
     std::vector<ORUtils::SE3Pose> view_poses(cams.size());
     std::vector<torch::Tensor> w2c(cams.size());
     for (size_t k = 0; k < cams.size(); k++) {

@@ -131,7 +131,7 @@ public:
     // alone).  Measured: one batch is + 1 % on some boxes of the pool and - 5 % on others at 640x480 (the map update and the ten
     // frames it runs beside are equally long there, so which of the two waits for the other flips) and - 6 % at 1280x720: two.
     bool merge_keyframe_raycasts = false;
-    bool views_reserved_ = false;
+    bool views_reserved_ = false, raycast_pool_warm_ = false;
     bool async_raycasts = true;   // the update's free-view raycasts run beside its optimise iterations (same results)
     // with overlap_mapping: run the map update on a worker thread of its own (tracking thread + mapping thread) instead of
     // interleaving its host work with the frames on the caller's thread
