@@ -17,7 +17,8 @@
 //                             pose) the host writes once it has decided; every workgroup evaluates its pixels and stores one
 //                             sequence-tagged row of partial sums; workgroup 0 re-reads the rows until all are this launch's,
 //                             adds them in a fixed order and writes the totals into a pinned host mailbox the host spins on
-//                             (no summing kernel, no memcpy, no stream synchronise, no acknowledgement waits, no ticket)
+//                             (no summing kernel, no memcpy, no stream synchronise, no ticket; the only acknowledgement is
+//                             the one a RETIRED launch gives before the host reuses the argument line, once per frame)
 //   track_eval_kernel<ITER>   the same body as a plain launch with kernel arguments (host_mailbox == NULL, or the fall-back)
 //
 // What was tried in round 2 and measured slower (kept out of the tree): (1) the whole LM loop in ONE persistent launch with a
