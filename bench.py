@@ -163,11 +163,21 @@ def setup_ranks(backend="nccl", need_gpu=True):
     return rank, local_rank, world, grp, placement, device
 
 
-def main():
+def _no_gpu_sync():
+    pass
+
+
+def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=True):
+    """argv / scene_factory / backend / need_gpu / extras exist for tests/test_multi_rank_cpu.py, which runs this very function
+    with world_size 2 on gloo and a stub scene (no GPU in the build container): the N > 1 control flow -- ranks, seeds, barriers,
+    max-over-ranks per window, whole-job aggregation, rank-0-only JSON line, final barrier -- is then the code the driver runs."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="consecutive K-step windows timed per schedule (each bracketed by barrier + synchronize, max over ranks); "
+                         "`value` is the MEDIAN window, config.windows_ms_per_step lists all of them")
     ap.add_argument("--schedule", choices=("both", "overlap", "sequential"), default="both",
                     help="which keyframe schedule(s) to time; `value` is the overlap schedule unless only sequential is run")
     ap.add_argument("--gaussians", type=int, default=200000)
@@ -184,20 +194,26 @@ def main():
                     help="use_gt_pose: true (what every shipped config sets: the tracker is off, poses are given).  Default: the "
                          "depth-only ExtendedTracker estimates the pose of every frame, as BASELINE configs[2] "
                          "(\"full track + TSDF + Gaussian optimize\") describes")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     from gps_slam_amd.dist_util import scene_seed
-    rank, local_rank, world, grp, placement, device = setup_ranks()
-    W, H, K, Wm = args.width, args.height, args.steps, args.warmup
+    rank, local_rank, world, grp, placement, device = setup_ranks(backend=backend, need_gpu=need_gpu)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world)
+    dev_sync = torch.cuda.synchronize if need_gpu else _no_gpu_sync
+    marker = (lambda: torch.cuda._sleep(1)) if need_gpu else _no_gpu_sync  # spin_kernel: phase marker for tools/prof_summary.py
+    W, H, K, Wm, NW = args.width, args.height, args.steps, args.warmup, max(1, args.windows)
     first, prologue = timed_window(Wm)
-    n_frames = first + K
+    n_frames = first + NW * K
     seed = scene_seed(rank)
-    seq = synthetic_sequence(W, H, n_frames, seed)
-    seeds = seed_gaussians(seq, args.gaussians, seed, device)
-
-    # One-off costs that are not part of any SLAM frame -- loading the code objects of every kernel, first-touch of the
-    # allocator -- are paid here, before the warm-up frames.
-    prime(device)
+    seq = None
+    if scene_factory is None:
+        seq = synthetic_sequence(W, H, n_frames, seed)
+        seeds = seed_gaussians(seq, args.gaussians, seed, device)
+        # One-off costs that are not part of any SLAM frame -- loading the code objects of every kernel, first-touch of the
+        # allocator -- are paid here, before the warm-up frames.
+        prime(device)
+        scene_factory = lambda overlap: Scene(seq, seeds, seed, args.gt_pose, overlap=overlap, n_frames=n_frames,
+                                              keyframe_theta=args.keyframe_theta, keyframe_trans=args.keyframe_trans)
 
     schedules = ("sequential", "overlap") if args.schedule == "both" else (args.schedule,)
     results, scene = {}, None
@@ -205,70 +221,93 @@ def main():
         if scene is not None:
             scene.close()
             del scene
-            torch.cuda.empty_cache()
-        scene = Scene(seq, seeds, seed, args.gt_pose, overlap=(sched == "overlap"), n_frames=n_frames,
-                      keyframe_theta=args.keyframe_theta, keyframe_trans=args.keyframe_trans)
-        torch.cuda.synchronize()
+            if need_gpu:
+                torch.cuda.empty_cache()
+        scene = scene_factory(sched == "overlap")
+        dev_sync()
         scene.run(0, first)  # untimed: prologue + warm-up frames
-        up0, st0 = scene.cli.uploadedBytes, dict(scene.pipe.stats())
-        torch.cuda.synchronize()
-        grp.barrier()
-        torch.cuda.synchronize()
-        torch.cuda._sleep(1)  # spin_kernel: phase marker for tools/prof_summary.py (start of a timed region)
-        t0 = time.perf_counter()
-        scene.run(first, first + K)
-        torch.cuda.synchronize()
-        grp.barrier()
-        torch.cuda.synchronize()
-        dt = grp.max_over_ranks(time.perf_counter() - t0)
-        torch.cuda._sleep(1)  # phase marker: end of the timed region
-        torch.cuda.synchronize()
-        results[sched] = dict(seconds=dt, frames_per_s=world * K / dt, ms_per_step=1000.0 * dt / K,
-                              uploaded_bytes_per_frame=(scene.cli.uploadedBytes - up0) / K,
-                              stats={k: int(v) - int(st0[k]) for k, v in dict(scene.pipe.stats()).items()})  # timed window only
+        windows = []
+        for w in range(NW):
+            lo = first + w * K
+            up0, st0 = scene.cli.uploadedBytes, dict(scene.pipe.stats())
+            dev_sync()
+            grp.barrier()
+            dev_sync()
+            marker()  # start of a timed region
+            t0 = time.perf_counter()
+            scene.run(lo, lo + K)
+            dev_sync()
+            grp.barrier()
+            dev_sync()
+            dt = grp.max_over_ranks(time.perf_counter() - t0)
+            marker()  # end of the timed region
+            dev_sync()
+            windows.append(dict(seconds=dt, frames_per_s=world * K / dt, ms_per_step=1000.0 * dt / K,
+                                uploaded_bytes_per_frame=(scene.cli.uploadedBytes - up0) / K,
+                                stats={k: int(v) - int(st0[k]) for k, v in dict(scene.pipe.stats()).items()}))  # this window only
+        order = sorted(range(NW), key=lambda i: windows[i]["seconds"])
+        med = windows[order[NW // 2]]  # the median window (upper median for an even count): every reported number is of ONE window
+        ms = [w["ms_per_step"] for w in windows]
+        results[sched] = dict(med, windows_ms_per_step=ms, window_spread=(max(ms) - min(ms)) / med["ms_per_step"])
     main_sched = "overlap" if "overlap" in results else schedules[0]
     dt = results[main_sched]["seconds"]
 
-    out = None
     if rank == 0:
-        from bench_kernels import cpu_baseline, iteration_roofline, fusion_split, render_psnr_vs_oracle
-        N = scene.model.getGaussianNum()
-        views = list(zip(scene.pipe.optCams(), scene.pipe.optRaycasts()))[-5:]
-
-        def _psnr(a, b):
-            return float(-10.0 * torch.log10(((a.clamp(0, 1) - b) ** 2).mean()))
-        with torch.no_grad():
-            psnr_render = [_psnr(scene.model.forward(c, rc["depth_map"], rc["color_map"])["rgb"], c.image) for c, rc in views]
-            psnr_tsdf = [_psnr(rc["color_map"], c.image) for c, rc in views]
-        quality = {"views": len(views), "render_psnr_db_vs_input": sum(psnr_render) / max(1, len(views)),
-                   "tsdf_colour_psnr_db_vs_input": sum(psnr_tsdf) / max(1, len(views))}
-        if not args.no_oracle_psnr and views:
-            quality.update(render_psnr_vs_oracle(scene.model, views[-1][0], views[-1][1], seq))
-        torch.cuda._sleep(1)  # phase marker: everything below is measurement scaffolding, not SLAM frames
-        split = fusion_split(seq, first, K, args.gt_pose, dt)
-        roof = iteration_roofline(scene, seq, results[main_sched], HBM_PEAK_GBS, K)
         out = {
             "metric": "SLAM frames/sec @640x480, ~200k Gaussians; render PSNR vs ref",
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic room0-like RGB-D %dx%d: per-frame upload (6 B/px) + %s + TSDF fuse (5mm voxels) + ges "
-                                   "splat optimise, ~%dk Gaussians; independent scene per GPU"
-                                   % (W, H, "given poses (use_gt_pose=true, as every shipped config)" if args.gt_pose else
-                                      "depth ICP tracking (ExtendedTracker, use_gt_pose=false)", N // 1000),
-                       "gaussians": N, "local_opt_interval": PERIOD, "local_opt_iters": 20, "frames_per_step": 1,
-                       "host": "cpp (createTsdfEngine -> CLIEngine -> SLAMPipeline)", "schedule": main_sched,
+            "config": {"schedule": main_sched, "windows": NW, "windows_ms_per_step": results[main_sched]["windows_ms_per_step"],
+                       "window_spread": results[main_sched]["window_spread"],
+                       "window_note": "%d consecutive %d-step windows per schedule, each bracketed by barrier + synchronize and "
+                                      "maxed over ranks; value / ms_per_step = the MEDIAN window" % (NW, K),
+                       "local_opt_interval": PERIOD, "local_opt_iters": 20, "frames_per_step": 1,
                        "use_gt_pose": bool(args.gt_pose), "prologue_frames": prologue,
                        "keyframe_thresholds": {"theta_deg": args.keyframe_theta, "trans_m": args.keyframe_trans},
                        "schedules": {k: {kk: vv for kk, vv in v.items() if kk != "seconds"} for k, v in results.items()},
-                       "stats": results[main_sched]["stats"], "placement": placement, "quality": quality, "split": split},
-            "roofline": roof,
+                       "stats": results[main_sched]["stats"], "placement": placement},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(seq, W, H)
+        if extras:
+            out["config"].update(_describe_and_measure(args, scene, seq, results[main_sched], first, K, dt, marker))
+            out["roofline"] = out["config"].pop("roofline")
+            if not args.no_cpu_baseline and world == 1:
+                from bench_kernels import cpu_baseline
+                out["cpu_baseline"] = cpu_baseline(seq, W, H)
         print(json.dumps(out), flush=True)
+    # ranks != 0 wait here while rank 0 runs its post-window measurements and prints: no rank tears the process group down
+    # (or exits, which torch.distributed.run treats as the job ending) under another rank's feet
+    grp.barrier()
     scene.close()
     grp.close()
+
+
+def _describe_and_measure(args, scene, seq, result, first, K, dt, marker):
+    """rank 0, after the timed windows: workload description, render quality against the oracle, the Fusion / Gaussian split
+    and the roofline section (all measured on the state the timed run ended in)."""
+    from bench_kernels import roofline_section, fusion_split, render_psnr_vs_oracle
+    W, H = args.width, args.height
+    N = scene.model.getGaussianNum()
+    views = list(zip(scene.pipe.optCams(), scene.pipe.optRaycasts()))[-5:]
+
+    def _psnr(a, b):
+        return float(-10.0 * torch.log10(((a.clamp(0, 1) - b) ** 2).mean()))
+    with torch.no_grad():
+        psnr_render = [_psnr(scene.model.forward(c, rc["depth_map"], rc["color_map"])["rgb"], c.image) for c, rc in views]
+        psnr_tsdf = [_psnr(rc["color_map"], c.image) for c, rc in views]
+    quality = {"views": len(views), "render_psnr_db_vs_input": sum(psnr_render) / max(1, len(views)),
+               "tsdf_colour_psnr_db_vs_input": sum(psnr_tsdf) / max(1, len(views))}
+    if not args.no_oracle_psnr and views:
+        quality.update(render_psnr_vs_oracle(scene.model, views[-1][0], views[-1][1], seq))
+    marker()  # phase marker: everything below is measurement scaffolding, not SLAM frames
+    split = fusion_split(seq, first, K, args.gt_pose, dt)
+    roof = roofline_section(scene, seq, result, HBM_PEAK_GBS, K, gt_pose=args.gt_pose)
+    return {"workload": "synthetic room0-like RGB-D %dx%d: per-frame upload (6 B/px) + %s + TSDF fuse (5mm voxels) + ges "
+                        "splat optimise, ~%dk Gaussians; independent scene per GPU"
+                        % (W, H, "given poses (use_gt_pose=true, as every shipped config)" if args.gt_pose else
+                           "depth ICP tracking (ExtendedTracker, use_gt_pose=false)", N // 1000),
+            "gaussians": N, "host": "cpp (createTsdfEngine -> CLIEngine -> SLAMPipeline)", "quality": quality, "split": split,
+            "roofline": roof}
 
 
 if __name__ == "__main__":

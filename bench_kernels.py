@@ -146,6 +146,10 @@ def iteration_roofline(scene, seq, result, hbm_peak_gbs, K):
                                                  "achieved_GBs": alg_fwd / t_fwd / 1e9}}}
 
 
+def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
+    return iteration_roofline(scene, seq, result, hbm_peak_gbs, K)
+
+
 def render_psnr_vs_oracle(model, cam, rc, seq):
     """PSNR (scripts/utils/image_utils.py:19-21) of the HIP render of the final state against the CPU
     restatement's render of the same state (same parameters, pose, raycast maps), both clamped to [0,1], full image."""

@@ -252,6 +252,11 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)
         .def_readwrite("pump_iters_per_frame", &SLAMPipeline::pump_iters_per_frame)
         .def("flush", &SLAMPipeline::flush, py::call_guard<py::gil_scoped_release>())
+        .def_readwrite("trace_frames", &SLAMPipeline::trace_frames)
+        .def("frameTrace", [](SLAMPipeline& p) {
+            { py::gil_scoped_release nogil; p.flush(); }
+            return std::make_tuple(p.trace_live, p.trace_counters, p.trace_poses);
+        })
         .def("removeRedundantGs", &SLAMPipeline::removeRedundantGs)
         .def_readwrite("large_scale_thres", &SLAMPipeline::large_scale_thres)
         .def_readwrite("small_scale_thres", &SLAMPipeline::small_scale_thres)

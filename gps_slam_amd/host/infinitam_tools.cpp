@@ -91,6 +91,17 @@ bool CLIEngine::ProcessFrame() {
     return true;
 }
 
+// The staging slot of the frame ProcessFrame() handed to the engine has readers BEHIND the engine's own kernels: the pipeline
+// derives the camera's float image from it (Camera::toGPU -> gps_rgba8_to_rgbf_and_floats) on the frame stream.  Re-recording
+// the slot's `consumed` event here moves it behind that last reader; upload(n + 3) waits for the re-recorded event.
+void CLIEngine::markConsumed() {
+    if (!prefetch || !staging_ || currentFrameNo == 0) return;
+    Staging& st = *staging_;
+    const int slot = (currentFrameNo - 1) % 3;
+    if (!st.used[slot]) return;
+    hip_ok(hipEventRecord(st.consumed[slot], (hipStream_t)current_stream()), "hipEventRecord");
+}
+
 void CLIEngine::Run() {
     while (ProcessFrame()) {}
 }

@@ -96,6 +96,9 @@ public:
     void Shutdown();
     void Run();
     bool ProcessFrame();
+    // call on the stream of the LAST reader of the frame ProcessFrame() just consumed (e.g. after deriving the camera's float
+    // image from currentRgb()): the staging slot is not overwritten by a later upload before that reader has run
+    void markConsumed();
     Vector2i GetDepthSize() { return depth_images[0]->noDims; }
     Vector2i GetRGBSize() { return rgb_images[0]->noDims; }
     ITMLib::ITMMainEngine* getMainEngine() { return mainEngine; }

@@ -447,6 +447,14 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
         // UpdateView just put into HBM -- 3 of its 4 bytes per pixel instead of uploading 12 more as Camera::toGPU would)
         if (!cam.image.defined()) frame_rgba = main_engine->currentRgb();  // [H,W,4] u8, contiguous
     }
+    if (trace_frames) {
+        trace_live.push_back(main_engine->GetLiveVertex()->tensor().clone());
+        trace_counters.push_back(main_engine->counters().clone());
+        auto t = torch::empty({2, 16}, torch::kFloat32);
+        const ORUtils::SE3Pose& p = main_engine->camPoses.back();
+        for (int k = 0; k < 16; k++) { t[0][k] = p.GetM()[k]; t[1][k] = p.GetInvM()[k]; }
+        trace_poses.push_back(t);
+    }
     // est_pose = pose_d->GetInvM() (:81-82): ORUtils column-major -> row-major tensor
     auto est = torch::empty({4, 4}, torch::kFloat32);
     const float* invM = ts->pose_d->GetInvM();
@@ -455,6 +463,7 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     cam.c2w_slam = est;
     cam.invalidate();
     cam.toGPU(device, frame_rgba);
+    if (frame_rgba.defined()) tsdf_engine->markConsumed();  // the staging slot's last reader is the conversion toGPU just enqueued
     curr_cam = cam;
     updateFrameList();
     stats.frames++;

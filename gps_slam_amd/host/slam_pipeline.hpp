@@ -138,6 +138,11 @@ public:
     bool mapping_thread = false;
     int pump_iters_first = 4, pump_iters_per_frame = 3;  // optimise iterations enqueued at the keyframe / per following frame
     void flush();
+    // Test hook: with trace_frames every frame leaves, ENQUEUED on the stream the frame ran on (no host synchronisation, so the
+    // schedule under test is undisturbed), a copy of the live raycast image and of the engine's counters, plus the pose the
+    // frame was fused with (host values).  Read them after flush().
+    bool trace_frames = false;
+    std::vector<torch::Tensor> trace_live, trace_counters, trace_poses;
     ~SLAMPipeline();
 
 private:

@@ -156,6 +156,9 @@ class TsdfEngine:
     def runRaycastBatch(self, poses):
         from ._lib import TsdfView
         n = len(poses)
+        MAX_VIEWS = 12  # views per gps_tsdf_free_raycast_batch call (gps_tsdf_view_table_bytes rejects more)
+        if n > MAX_VIEWS:
+            raise ValueError("runRaycastBatch: at most %d views per call (got %d); call it per chunk as the C++ host does" % (MAX_VIEWS, n))
         views = getattr(self, "_views", [])
         P = self.W * self.H
         z = lambda cnt, dt: torch.zeros(cnt, dtype=dt, device=self.device)
@@ -174,8 +177,10 @@ class TsdfEngine:
                 setattr(arr[k], name, t.data_ptr())
             arr[k].M[:] = M.reshape(-1).tolist(); arr[k].invM[:] = invM.reshape(-1).tolist()
             arr[k].fx, arr[k].fy, arr[k].cx, arr[k].cy = self.state.fx, self.state.fy, self.state.cx, self.state.cy
-        if getattr(self, "_view_table", None) is None or self._view_table.numel() < int(lib.gps_tsdf_view_table_bytes(n)):
-            self._view_table = torch.zeros(int(lib.gps_tsdf_view_table_bytes(12)), dtype=torch.uint8, device=self.device)
+        if getattr(self, "_view_table", None) is None:
+            nbytes = int(lib.gps_tsdf_view_table_bytes(MAX_VIEWS))
+            assert nbytes > 0, nbytes
+            self._view_table = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         check(lib.gps_tsdf_free_raycast_batch(C.byref(self.state), n, arr, self._view_table.data_ptr(), self._stream()),
               "gps_tsdf_free_raycast_batch")
 

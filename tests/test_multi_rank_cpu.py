@@ -91,6 +91,87 @@ def test_bench_multi_gpu_entry_path_with_gloo():
         assert not (set(res[0][7]) & set(res[1][7]))
 
 
+class _StubScene:
+    """what bench.main() touches of a Scene: run(lo, hi), close(), cli.uploadedBytes, pipe.stats()"""
+
+    class _Cli:
+        uploadedBytes = 0
+
+    class _Pipe:
+        def __init__(self):
+            self.n = dict(frames=0, opt_iters=0, raycasts=0, added=0, pruned=0)
+
+        def stats(self):
+            return dict(self.n)
+
+    def __init__(self, overlap, delay):
+        self.cli, self.pipe, self.overlap, self.delay, self.log = self._Cli(), self._Pipe(), overlap, delay, []
+
+    def run(self, lo, hi):
+        import time
+        self.log.append((lo, hi))
+        time.sleep(self.delay * (hi - lo))
+        self.pipe.n["frames"] += hi - lo
+        self.pipe.n["opt_iters"] += 2 * (hi - lo)
+        self.cli.uploadedBytes += 6 * 64 * 48 * (hi - lo)
+
+    def close(self):
+        pass
+
+
+def _main_worker(rank, world, port, out_dir):
+    import contextlib
+    import io
+    import json
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import bench
+    scenes = []
+
+    def factory(overlap):
+        scenes.append(_StubScene(overlap, delay=0.002 * (1 + rank)))  # rank 1 is twice as slow per frame
+        return scenes[-1]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "10", "--warmup", "5", "--windows", "3"], scene_factory=factory, backend="gloo",
+                   need_gpu=False, extras=False)
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump({"stdout": buf.getvalue(), "log": [s.log for s in scenes], "overlap": [s.overlap for s in scenes]}, f)
+
+
+def test_bench_main_end_to_end_with_two_ranks_on_gloo(tmp_path):
+    """The WHOLE bench.main() -- argument parsing, rank set-up, per-rank seeds, both schedules, prologue + warm-up, the timed
+    windows each bracketed by barriers, max-over-ranks, whole-job aggregation, the rank-0-only JSON line, the final barrier
+    before the group is torn down -- with world_size 2 on gloo and a stub scene whose frames take 2 ms on rank 0 and 4 ms on
+    rank 1: the line must carry n_gpus = 2, value = 2 ranks x K frames / the SLOW rank's median window, and no cpu_baseline."""
+    import json
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_main_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(240)
+        assert p.exitcode == 0
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    assert res[1]["stdout"].strip() == ""                                   # only rank 0 prints
+    lines = [l for l in res[0]["stdout"].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert "cpu_baseline" not in out and out["higher_is_better"] is True and out["unit"] == "frames/s"
+    assert out["config"]["windows"] == 3 and len(out["config"]["windows_ms_per_step"]) == 3
+    # the slow rank sets the time: ~4 ms per frame (rank 0 alone needs ~2 ms) -> ~2 x 10 frames / 0.040 s for the job
+    assert 3.9 < out["ms_per_step"] < 8.0, out["ms_per_step"]
+    assert abs(out["value"] - 2 * 10 / (out["ms_per_step"] * 1e-3 * 10)) < 1e-6 * out["value"]
+    assert sorted(out["config"]["schedules"]) == ["overlap", "sequential"]
+    assert out["config"]["stats"]["frames"] == 10                           # stats of ONE window
+    # every rank ran the same frame ranges: prologue + warm-up to frame 30, then three 10-frame windows, per schedule
+    for r in res:
+        assert r["overlap"] == [False, True]
+        assert r["log"] == [[[0, 30], [30, 40], [40, 50], [50, 60]]] * 2
+
+
 def test_timed_window_is_whole_keyframe_periods():
     import bench
     for w in (0, 5, 10, 20, 25, 31, 40):

@@ -109,15 +109,26 @@ def test_engine_matches_oracle_full_size(W, H, voxel, mu, frames):
         assert minmax_equal(v.image("minmax"), o.image("minmax"), True)
         assert crc_of_blocks(v.allocated_blocks()) == crc_of_blocks(o.allocated_blocks())
 
+    # 640x480 / 5 mm is also the sequence the REFERENCE's own CPU engine was run on at BASELINE size
+    # (tests/golden/tsdf_640x480_v5mm_ref_digest.npz): the HIP state is compared with the reference engine's digests directly,
+    # not only with the restatement
+    from tests.test_oracle_tsdf import FULL, check_against_fullsize_digest, check_free_view_against_fullsize_digest
+    G = np.load(FULL) if (W, H, voxel) == (640, 480, 0.005) else None
+    if G is not None:
+        assert (int(G["n_frames"]), float(G["step_deg"]), float(G["mu"])) == (frames, 1.0, mu)
     for f in range(frames):
         M, invM = eng.ProcessFrame(_dev(seq["rgb"][f]), _dev(seq["depth"][f].astype(np.int16)), seq["c2w"][f])
         oM, oInv = R.pose_from_c2w(seq["c2w"][f])
         assert bits_equal(M, oM) and bits_equal(invM, oInv)
         o.process_frame(seq["rgb"][f], seq["depth"][f], oM, oInv)
         same_frame()
+        if G is not None:
+            check_against_fullsize_digest(v, G, f)
     assert v.n_visible > 1000 and (v.image("raycast")[..., 3] > 0).mean() > 0.8
     fM, fInv = eng.runRaycast(seq["c2w"][0])
     o.free_raycast(fM, fInv)
+    if G is not None:
+        check_free_view_against_fullsize_digest(v, G, (frames - 1) * 1000)
     assert v.fv_n_visible == o.fv_n_visible
     assert bits_equal(v.fv_visible_ids(), o.fv_visible_ids())
     for name in ("fv_raycast", "fv_colour"):
@@ -207,6 +218,27 @@ def test_tracked_process_frame_matches_reference_poses():
         # the map built along the tracked trajectory is the reference's up to a handful of blocks at the band's edge
         cnt = eng.counters_host()
         assert abs(int(cnt[2]) - int(G["n_visible"][f])) <= max(3, int(0.002 * G["n_visible"][f])), (f, cnt[2], G["n_visible"][f])
+
+
+def test_tracked_frames_match_the_reference_engine_at_baseline_size():
+    """640x480 / 5 mm, tracking ON: poses against the ones the REFERENCE's CPU engine estimated on the same frames
+    (tests/golden/tsdf_640x480_v5mm_ref_digest.npz, `trk_*`).  Tree vs scan-order float sums: 2e-5 per matrix entry; the
+    allocation counters along the HIP-tracked trajectory may differ by the handful of band-edge blocks such a pose difference
+    moves (bit-equality along the HIP poses is tests/test_pipeline_full_gpu.py's job)."""
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    from tests.test_oracle_tsdf import FULL
+    G = np.load(FULL)
+    W, H, n = int(G["W"]), int(G["H"]), int(G["n_frames"])
+    seq = synth.make_sequence(W, H, n, step_deg=float(G["step_deg"]))
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
+    eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=float(G["voxel"]), mu=float(G["mu"]), device="cuda:0")
+    eng.turnOnTracking()
+    v = EngineView(eng)
+    for f in range(n):
+        M, invM = eng.ProcessFrameTracked(_dev(rgba[f]), _dev(seq["depth"][f].astype(np.int16)))
+        assert np.abs(invM - G["trk_invM"][f]).max() < 2e-5 and np.abs(M - G["trk_M"][f]).max() < 2e-5, (f, np.abs(invM - G["trk_invM"][f]).max())
+        ref_vis, ref_free = int(G["trk_counts"][f][0]), int(G["trk_counts"][f][1])
+        assert abs(v.n_visible - ref_vis) <= 0.002 * ref_vis + 2 and abs(v.last_free_block - ref_free) <= 0.002 * ref_vis + 2, f
 
 
 def test_tracker_follows_ground_truth_at_full_size():

@@ -34,6 +34,12 @@ ell = 2 * 3.14159265 * T_ / det.sqrt()
 vis = r_ > 0
 print("sum ellipse area / sum box area = %.3f   (mean radius %.1f px, mean T %.2f)" % (float(ell[vis].sum() / (4 * r_[vis] ** 2).sum()),
                                                                                       float(r_[vis].mean()), float(T_[vis].mean())))
+rv = B["radii"][:st.N][vis].long()
+hist = torch.bincount(rv.clamp_max(40), minlength=41).tolist()
+tot = sum(hist)
+print("radius histogram (visible, clamped at 40): " + " ".join("%d:%d" % (r, c) for r, c in enumerate(hist) if c))
+slots = [(4 * r * r) * c for r, c in enumerate(hist)]
+print("share of pixel slots by radius: " + " ".join("%d:%.1f%%" % (r, 100.0 * s / max(1, sum(slots))) for r, s in enumerate(slots) if s))
 stream = torch.cuda.current_stream()
 sp = C.c_void_p(stream.cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
