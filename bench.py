@@ -163,6 +163,19 @@ def setup_ranks(backend="nccl", need_gpu=True):
     return rank, local_rank, world, grp, placement, device
 
 
+def _detrended_spread(ms):
+    """(max - min) / median of the windows' ms_per_step after removing their least-squares LINE: consecutive windows are not
+    repeats of one workload -- the orbit keeps revealing new surface, every keyframe adds Gaussians (windows_gaussians) and
+    later windows are slower for that reason; what is left after the trend is the run-to-run noise."""
+    n = len(ms)
+    if n < 3:
+        return 0.0
+    xs = np.arange(n, dtype=np.float64)
+    a, b = np.polyfit(xs, np.asarray(ms, np.float64), 1)
+    res = np.asarray(ms) - (a * xs + b)
+    return float((res.max() - res.min()) / np.median(ms))
+
+
 def _no_gpu_sync():
     pass
 
@@ -244,11 +257,13 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
             dev_sync()
             windows.append(dict(seconds=dt, frames_per_s=world * K / dt, ms_per_step=1000.0 * dt / K,
                                 uploaded_bytes_per_frame=(scene.cli.uploadedBytes - up0) / K,
-                                stats={k: int(v) - int(st0[k]) for k, v in dict(scene.pipe.stats()).items()}))  # this window only
+                                stats={k: int(v) - int(st0[k]) for k, v in dict(scene.pipe.stats()).items()},  # this window only
+                                gaussians=int(scene.model.getGaussianNum()) if hasattr(scene, "model") else 0))
         order = sorted(range(NW), key=lambda i: windows[i]["seconds"])
         med = windows[order[NW // 2]]  # the median window (upper median for an even count): every reported number is of ONE window
         ms = [w["ms_per_step"] for w in windows]
-        results[sched] = dict(med, windows_ms_per_step=ms, window_spread=(max(ms) - min(ms)) / med["ms_per_step"])
+        results[sched] = dict(med, windows_ms_per_step=ms, window_spread=(max(ms) - min(ms)) / med["ms_per_step"],
+                              window_spread_detrended=_detrended_spread(ms), windows_gaussians=[w["gaussians"] for w in windows])
     main_sched = "overlap" if "overlap" in results else schedules[0]
     dt = results[main_sched]["seconds"]
 
@@ -260,8 +275,11 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
             "dtype": "f32", "data": "synthetic",
             "config": {"schedule": main_sched, "windows": NW, "windows_ms_per_step": results[main_sched]["windows_ms_per_step"],
                        "window_spread": results[main_sched]["window_spread"],
+                       "window_spread_detrended": results[main_sched]["window_spread_detrended"],
+                       "windows_gaussians": results[main_sched]["windows_gaussians"],
                        "window_note": "%d consecutive %d-step windows per schedule, each bracketed by barrier + synchronize and "
-                                      "maxed over ranks; value / ms_per_step = the MEDIAN window" % (NW, K),
+                                      "maxed over ranks; value / ms_per_step = the MEDIAN window; the scene grows from window to window "
+                                      "(windows_gaussians), window_spread_detrended is the spread around that trend" % (NW, K),
                        "local_opt_interval": PERIOD, "local_opt_iters": 20, "frames_per_step": 1,
                        "use_gt_pose": bool(args.gt_pose), "prologue_frames": prologue,
                        "keyframe_thresholds": {"theta_deg": args.keyframe_theta, "trans_m": args.keyframe_trans},

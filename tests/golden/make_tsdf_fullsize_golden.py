@@ -1,4 +1,4 @@
-"""Generates tests/golden/tsdf_640x480_v5mm_ref_digest.npz: the REFERENCE's own ITMLib CPU engine (oracle/_ref/itm_ref, built by
+"""Generates tests/golden/refdigest_tsdf_640x480_v5mm.npz: the REFERENCE's own ITMLib CPU engine (oracle/_ref/itm_ref, built by
 oracle/ref_build.sh from /root/reference) at BASELINE size -- 640x480, 5 mm voxels, mu = 2 cm -- on the synthetic sequence
 tests/test_tsdf_gpu.py::test_engine_matches_oracle_full_size fuses (synth.make_sequence(640, 480, 3, step_deg=1.0)).
 
@@ -40,6 +40,6 @@ out["trk_M"] = np.stack([trk[("M", f)].reshape(-1) for f in range(N)])
 out["trk_invM"] = np.stack([trk[("invM", f)].reshape(-1) for f in range(N)])
 out["trk_score"] = np.stack([trk[("trk_score", f)] for f in range(N)])
 out["trk_counts"] = np.stack([trk[("counts", f)] for f in range(N)])
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tsdf_640x480_v5mm_ref_digest.npz")
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refdigest_tsdf_640x480_v5mm.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -110,7 +110,7 @@ def test_engine_matches_oracle_full_size(W, H, voxel, mu, frames):
         assert crc_of_blocks(v.allocated_blocks()) == crc_of_blocks(o.allocated_blocks())
 
     # 640x480 / 5 mm is also the sequence the REFERENCE's own CPU engine was run on at BASELINE size
-    # (tests/golden/tsdf_640x480_v5mm_ref_digest.npz): the HIP state is compared with the reference engine's digests directly,
+    # (tests/golden/refdigest_tsdf_640x480_v5mm.npz): the HIP state is compared with the reference engine's digests directly,
     # not only with the restatement
     from tests.test_oracle_tsdf import FULL, check_against_fullsize_digest, check_free_view_against_fullsize_digest
     G = np.load(FULL) if (W, H, voxel) == (640, 480, 0.005) else None
@@ -222,7 +222,7 @@ def test_tracked_process_frame_matches_reference_poses():
 
 def test_tracked_frames_match_the_reference_engine_at_baseline_size():
     """640x480 / 5 mm, tracking ON: poses against the ones the REFERENCE's CPU engine estimated on the same frames
-    (tests/golden/tsdf_640x480_v5mm_ref_digest.npz, `trk_*`).  Tree vs scan-order float sums: 2e-5 per matrix entry; the
+    (tests/golden/refdigest_tsdf_640x480_v5mm.npz, `trk_*`).  Tree vs scan-order float sums: 2e-5 per matrix entry; the
     allocation counters along the HIP-tracked trajectory may differ by the handful of band-edge blocks such a pose difference
     moves (bit-equality along the HIP poses is tests/test_pipeline_full_gpu.py's job)."""
     from gps_slam_amd.tsdf_engine import TsdfEngine
