@@ -55,7 +55,8 @@ class SplatStep(C.Structure):
                                    "v_opacities")] +
                 [(p + n, vp) for p in ("g_", "m_", "v_") for n in ("means", "log_scales", "quats", "opac_logit", "sh_dc",
                                                                    "sh_rest")] +
-                [("lr", f64 * 6), ("beta1", f64), ("beta2", f64), ("adam_eps", f64), ("fuse_sh_rest_adam", i32)])
+                [("lr", f64 * 6), ("beta1", f64), ("beta2", f64), ("adam_eps", f64), ("fuse_sh_rest_adam", i32)] +
+                [(n, vp) for n in ("v_rows", "pix2", "cls_ids", "cls_counts")] + [("cls_stride", i64)])
 
 
 class AdamSegment(C.Structure):
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "gps_sh_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),
     "gps_sh_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_isect_workspace_bytes": (i64, [i32, i64]),
+    "gps_isect_workspace_init": (i32, [vp, i64, vp]),
     "gps_isect_tiles_no_depth": (i32, [i32, vp, vp, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "gps_ssim_fwd": (i32, [i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_ssim_bwd": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -81,6 +83,8 @@ PROTOTYPES = {
     "gps_raster_ges_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
     "gps_raster_ges_bwd_gs": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp,
                                     i32, vp]),
+    "gps_raster_ges_bwd_strips": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]),
+    "gps_raster_pair_image": (i32, [i32, i32, vp, vp, f32, vp, vp]),
     "gps_raster_ges_bwd_exact": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_compose_l1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_adam_step": (i32, [C.POINTER(AdamSegment), i32, f64, f64, f64, i32, vp]),

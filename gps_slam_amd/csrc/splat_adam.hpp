@@ -42,6 +42,6 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
                           const float* v_colors, const float* v_opacities, float* v_means, float* v_log_scales,
                           float* v_quats, float* v_opac_logit, float* v_sh_dc, float* v_sh_rest, float* adam_param,
                           float* adam_m, float* adam_v, AdamScalars sc, const gps_adam_segment* small5,
-                          const float* small_step, gps_stream stream);
+                          const float* small_step, gps_stream stream, const float* v_rows = nullptr);
 
 }  // namespace gps

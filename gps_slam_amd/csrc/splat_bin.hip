@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BIN_BLOCK) void count_kernel(int N, const float* __
         if (order) tiles_by_rank[i] = t;
         groups_per_gauss[i] = g;
     }
-    gps::BinCountOut o = {tiles_per_gauss, groups_per_gauss, blk_tiles, blk_groups, blk_vis, tile_size, tw, th};
+    gps::BinCountOut o = {tiles_per_gauss, groups_per_gauss, blk_tiles, blk_groups, blk_vis, tile_size, tw, th, {}};
     gps::bin_block_sums(o, t, g, vis);
 }
 
@@ -450,6 +450,7 @@ struct Workspace {
     int32_t* tiles_by_rank;  // depth mode: tile count by depth rank
     int64_t* count_n;        // depth mode: {N, 0, 0, 0} for the radix kernels
     int32_t* dummy_groups;
+    char* sb_region;         // tables of the superblock binning (splat_bin_sb.hip)
     int nblkN, nblkI;
 };
 
@@ -475,6 +476,7 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
     p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->tiles_by_rank = (int32_t*)p;
     p = take(4 * sizeof(int64_t)); if (w) w->count_n = (int64_t*)p;
     p = take(256); if (w) w->dummy_groups = (int32_t*)p;
+    p = take(gps::sb_tables_bytes()); if (w) w->sb_region = p;
     if (w) { w->nblkN = nblkN; w->nblkI = nblkI; }
     return off;
 }
@@ -490,12 +492,17 @@ static int isect_impl(int N, const float* means2d, const int32_t* radii, const f
 namespace gps {
 
 int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss, int tile_size, int tile_width, int tile_height,
-                        void* workspace, int64_t workspace_bytes, BinCountOut* out) {
+                        void* workspace, int64_t workspace_bytes, bool superblock, BinCountOut* out) {
     GPS_REQUIRE(N >= 0 && isect_capacity > 0 && workspace && out && tiles_per_gauss);
     if (workspace_bytes < (int64_t)carve(nullptr, nullptr, N, isect_capacity)) return GPS_ERR_CAPACITY;
     Workspace w;
     carve(&w, (char*)workspace, N, isect_capacity);
-    *out = {tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups, w.blk_vis, tile_size, tile_width, tile_height};
+    *out = {tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups, w.blk_vis, tile_size, tile_width, tile_height, {}};
+    if (superblock) {
+        GPS_REQUIRE(tile_width * tile_height <= SB_MAX_TILES);
+        sb_tables_carve(w.sb_region, &out->sb);
+        out->sb.sb_shift = sb_shift_for(N);
+    }
     return GPS_OK;
 }
 
@@ -516,6 +523,11 @@ extern "C" {
 int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity) {
     if (N < 0 || isect_capacity < 0) return GPS_ERR_ARG;
     return (int64_t)carve(nullptr, nullptr, N, isect_capacity);
+}
+
+int gps_isect_workspace_init(void* workspace, int64_t workspace_bytes, gps_stream stream) {
+    GPS_REQUIRE(workspace && workspace_bytes > 0);
+    return hipMemsetAsync(workspace, 0, (size_t)workspace_bytes, (hipStream_t)stream) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
 }  // extern "C"

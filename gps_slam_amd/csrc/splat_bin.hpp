@@ -32,10 +32,40 @@ __device__ __forceinline__ void tile_group_count(float mx, float my, int r, int 
     groups = (int)((4 * rf * rf + 32 - 1) / 32);  // fp32 expression of isect_tiles_no_depth.cu:87
 }
 
+// ---- superblock binning (splat_bin_sb.hip): the fused model path's tile binning in two launches behind the preprocessing
+// kernel.  A superblock = SB_BLOCKS consecutive preprocessing workgroups (256 Gaussians each), at most SB_MAX superblocks.
+//   preprocessing kernel : per workgroup an LDS histogram of its (Gaussian, tile) pairs over the <= SB_MAX_TILES tile ids, added
+//                          to the count table C[tile][superblock]; per-class Gaussian counts into cls_count[superblock][k]
+//   scan kernel          : per tile the exclusive prefix over superblocks P[tile][sb] + the tile total; C is zeroed again
+//   scatter kernel       : one workgroup per superblock enumerates its pairs in Gaussian order and writes each Gaussian id to
+//                          tile_start[tile] + P[tile][sb] + (its stable rank inside the superblock): the order a stable sort
+//                          by tile id gives (isect_tiles_no_depth.cu:313-327), without ever materialising a key / value
+//                          array; tile_offsets = exclusive scan of the tile totals; the backward's class lists ride along.
+// Invariant: C and cls_count are ZERO between launches (zeroed by gps_isect_workspace_init, then by the scan kernel).
+constexpr int SB_MAX = 512;          // superblocks (row length of the tables)
+constexpr int SB_MAX_TILES = 4096;   // tile ids the LDS histograms cover; more tiles -> the sorted-key path of splat_bin.hip
+constexpr int BWD_CLASSES = GPS_BWD_CLASSES;
+struct SbTables {
+    uint32_t* C;           // [SB_MAX_TILES][SB_MAX] counts (zero between launches)
+    uint32_t* P;           // [SB_MAX_TILES][SB_MAX] exclusive prefixes over superblocks
+    uint32_t* tile_total;  // [SB_MAX_TILES]
+    int32_t* cls_count;    // [SB_MAX][8] Gaussians per backward class (zero between launches)
+    int32_t* cls_prefix;   // [SB_MAX][8]
+    int sb_shift;          // log2(preprocessing workgroups per superblock)
+};
+__host__ __device__ inline int sb_shift_for(int N) {  // smallest power of two of 256-Gaussian blocks with <= SB_MAX superblocks
+    int s = 0;
+    while ((((int64_t)N + 255) / 256 + ((int64_t)1 << s) - 1) >> s > SB_MAX) s++;
+    return s;
+}
+// backward class of a radius: the smallest k with 4 << k >= r, the last class takes everything wider
+__host__ __device__ inline int bwd_class(int r) { return r <= 4 ? 0 : r <= 8 ? 1 : r <= 16 ? 2 : r <= 32 ? 3 : 4; }
+
 // where the first pass's results live (pointers into the caller's binning workspace); tiles_per_gauss == nullptr: off
 struct BinCountOut {
     int32_t *tiles_per_gauss, *groups_per_gauss, *blk_tiles, *blk_groups, *blk_vis;
     int tile_size, tw, th;
+    SbTables sb;   // sb.C == nullptr: no superblock histogram (the sorted-key path follows)
 };
 
 // one value triple per thread -> the three per-workgroup sums (all BIN_BLOCK threads must call)
@@ -65,6 +95,7 @@ struct FwdCompose {
     float* v_render_colors;   // [P,4]
     float* v_render_alphas;   // [P]
     float inv_count;          // 1 / (3 P)
+    float* pix2;              // [P,2] {v_render_alpha, ref_depth + delta_depth}: what the strip backward gathers (may be NULL)
 };
 // splat_raster.hip
 int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_depth_map, int width, int height,
@@ -77,9 +108,21 @@ int raster_ges_bwd_gs_launch(int N, const float* means2d, const float* conics, c
                              const float* v_render_colors, const float* v_render_alphas, float* v_means2d, float* v_conics,
                              float* v_colors, float* v_opacities, int zero_mode, gps_stream stream);
 
-// splat_bin.hip: the count targets inside `workspace` for (N, isect_capacity); GPS_OK or an error
+// splat_bin.hip: the count targets inside `workspace` for (N, isect_capacity); GPS_OK or an error.  superblock: also the
+// tables of the superblock binning (needs tile_width * tile_height <= SB_MAX_TILES and an initialised workspace)
 int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss, int tile_size, int tile_width, int tile_height,
-                        void* workspace, int64_t workspace_bytes, BinCountOut* out);
+                        void* workspace, int64_t workspace_bytes, bool superblock, BinCountOut* out);
+// splat_bin_sb.hip: bytes of the superblock tables; scan + scatter behind a preprocessing kernel that filled `cnt.sb`.
+// cls_ids / cls_counts may be NULL (render only).  counts = {n_isects, 0, overflow (sticky), n_visible}.
+size_t sb_tables_bytes();
+void sb_tables_carve(char* base, SbTables* t);
+int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, const BinCountOut& cnt, int64_t isect_capacity,
+                           const int32_t* tiles_per_gauss, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* counts,
+                           int32_t* cls_ids, int32_t* cls_counts, int64_t cls_stride, gps_stream stream);
+// splat_raster_bwd.hip
+int raster_ges_bwd_strips_launch(int N, const float* records, const int32_t* radii, const int32_t* cls_ids,
+                                 const int32_t* cls_counts, int cls_stride, const float* v_render_colors, const float* pix2,
+                                 int width, int height, float* v_rows, gps_stream stream);
 // splat_bin.hip: gps_isect_tiles_no_depth whose first pass has already been written to isect_count_targets()'s pointers
 int isect_tiles_no_depth_counted(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
                                  int tile_height, int64_t isect_capacity, int64_t group_capacity, int32_t* tiles_per_gauss,

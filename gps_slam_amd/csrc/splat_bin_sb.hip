@@ -1,0 +1,262 @@
+// Superblock binning: the fused model path's tile binning as two launches behind the preprocessing kernel (see splat_bin.hpp).
+//
+//   <- gsplat::isect_tiles_tensor_no_depth + isect_offset_encode_tensor_no_depth
+//      (gsplat/rasterizer/isect_tiles_no_depth.cu:132-461): count, cumsum, fill keys, cub radix sort by tile id, offsets.
+//
+// Same result -- per tile the Gaussian ids in ascending order, tile start offsets -- as a counting sort keyed on the tile id
+// whose "blocks" are runs of consecutive GAUSSIANS instead of runs of intersections, so that no (key, value) array is ever
+// written or read: the histogram pass runs inside the preprocessing kernel on the bounding boxes still in registers, and the
+// scatter re-derives a superblock's pairs from the same boxes.
+#include "splat_bin.hpp"
+
+namespace {
+
+using gps::BIN_BLOCK;
+using gps::SB_MAX;
+using gps::SB_MAX_TILES;
+using gps::SbTables;
+using gps::TileBox;
+using gps::tile_bbox;
+
+constexpr int SCAT_THREADS = 256;
+constexpr int SCAT_WAVES = SCAT_THREADS / 64;
+constexpr int SCAT_ITEMS = 4;                              // pairs per thread per chunk
+constexpr int SCAT_CHUNK = SCAT_THREADS * SCAT_ITEMS;      // 1024 pairs per chunk
+
+__device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
+    const int incl = wave_incl_scan_i(v);
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+// ---- one wave per tile: exclusive prefix of the tile's row of C over the superblocks; C is left zero ----
+__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, int n_sb, int32_t* __restrict__ cls_counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    static_assert(SB_MAX == 512, "a lane owns 8 consecutive superblocks");
+    if (tile < n_tiles) {
+        uint4* crow = reinterpret_cast<uint4*>(t.C + (size_t)tile * SB_MAX) + 2 * lane;
+        const uint4 a = crow[0], b = crow[1];
+        crow[0] = make_uint4(0, 0, 0, 0); crow[1] = make_uint4(0, 0, 0, 0);
+        const int s = (int)(a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w);
+        int total;
+        uint32_t run = (uint32_t)wave_excl_scan_i(s, total);
+        uint4 pa, pb;
+        pa.x = run; run += a.x; pa.y = run; run += a.y; pa.z = run; run += a.z; pa.w = run; run += a.w;
+        pb.x = run; run += b.x; pb.y = run; run += b.y; pb.z = run; run += b.z; pb.w = run;
+        uint4* prow = reinterpret_cast<uint4*>(t.P + (size_t)tile * SB_MAX) + 2 * lane;
+        prow[0] = pa; prow[1] = pb;
+        if (lane == 0) t.tile_total[tile] = (uint32_t)total;
+    }
+    // the class counts: the last workgroup's wave k scans class k over the superblocks
+    if (blockIdx.x == gridDim.x - 1 && wave < 4) {
+        for (int k = wave; k < gps::BWD_CLASSES; k += 4) {
+            int run = 0;
+            for (int base = 0; base < n_sb; base += 64) {
+                const int sb = base + lane;
+                const int c = sb < n_sb ? t.cls_count[sb * 8 + k] : 0;
+                int tot;
+                const int e = wave_excl_scan_i(c, tot);
+                if (sb < n_sb) { t.cls_prefix[sb * 8 + k] = run + e; t.cls_count[sb * 8 + k] = 0; }
+                run += tot;
+            }
+            if (lane == 0 && cls_counts) cls_counts[k] = run;
+            if (lane == 0) t.cls_prefix[SB_MAX * 8 + k] = run;   // totals row (n_visible = their sum)
+        }
+    }
+}
+
+// ---- one workgroup per superblock: stable scatter of its (Gaussian, tile) pairs + the backward's class lists ----
+__global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
+    int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const int32_t* __restrict__ tiles_per_gauss,
+    int tile_size, int tw, int th, SbTables t, int64_t isect_cap, int32_t* __restrict__ flatten_ids,
+    int32_t* __restrict__ tile_offsets, int64_t* __restrict__ counts, int32_t* __restrict__ cls_ids, int64_t cls_stride) {
+    extern __shared__ uint32_t lds[];
+    const int n_tiles = tw * th;
+    const int sb = blockIdx.x, sb_size = BIN_BLOCK << t.sb_shift;        // Gaussians per superblock
+    uint32_t* base = lds;                                                 // [n_tiles] absolute start of this superblock's run in every tile
+    uint16_t* wavecnt = reinterpret_cast<uint16_t*>(lds + n_tiles);       // [SCAT_WAVES][n_tiles] per-wave running counts of a chunk
+    uint16_t* tot16 = wavecnt + SCAT_WAVES * n_tiles;                     // [n_tiles] a chunk's pairs per tile
+    uint32_t* pre = lds + n_tiles + ((SCAT_WAVES + 1) * n_tiles + 1) / 2; // [sb_size + 1] exclusive prefix of the tile counts
+    uint32_t* box = pre + sb_size + 1;                                    // [sb_size] x0 | y0 << 12 | width << 24
+    __shared__ int ws[17];
+    __shared__ int cls_wave[SCAT_WAVES][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g0 = sb * sb_size;
+
+    // tile starts = exclusive scan of the tile totals (every workgroup recomputes it: n_tiles adds), + this superblock's prefix
+    {
+        const int per = (n_tiles + SCAT_THREADS - 1) / SCAT_THREADS;
+        const int lo = min(n_tiles, tid * per), hi = min(n_tiles, lo + per);
+        int sum = 0;
+        for (int b = lo; b < hi; b++) sum += (int)t.tile_total[b];
+        const int incl = wave_incl_scan_i(sum);
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < SCAT_WAVES; w++) { const int v = ws[w]; if (w < wave) woff += v; total += v; }
+        int run = woff + incl - sum;
+        for (int b = lo; b < hi; b++) {
+            if (sb == 0) tile_offsets[b] = (int)min((int64_t)run, isect_cap);
+            base[b] = (uint32_t)run + t.P[(size_t)b * SB_MAX + sb];
+            run += (int)t.tile_total[b];
+        }
+        if (sb == 0 && tid == 0) {
+            int64_t ni = total;
+            if (ni > isect_cap) { ni = isect_cap; counts[2] = 1; }   // sticky overflow word, as the sorted-key path
+            counts[0] = ni; counts[1] = 0;
+            int nv = 0;
+            for (int k = 0; k < gps::BWD_CLASSES; k++) nv += t.cls_prefix[SB_MAX * 8 + k];
+            counts[3] = nv;
+        }
+    }
+    // this superblock's Gaussians: tile counts -> exclusive prefix, boxes; class lists
+    int running_cls[gps::BWD_CLASSES];
+#pragma unroll
+    for (int k = 0; k < gps::BWD_CLASSES; k++) running_cls[k] = cls_ids ? t.cls_prefix[sb * 8 + k] : 0;
+    int carry = 0;
+    for (int j0 = 0; j0 < sb_size; j0 += SCAT_THREADS) {
+        const int j = j0 + tid, g = g0 + j;
+        int tcount = 0, r = 0;
+        uint32_t bx = 0;
+        if (g < N) {
+            tcount = tiles_per_gauss[g];
+            r = radii[g];
+            if (tcount > 0) {
+                const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
+                const TileBox b = tile_bbox(m.x, m.y, r, tile_size, tw, th);
+                bx = b.x0 | (b.y0 << 12) | ((b.x1 - b.x0) << 24);
+            }
+        }
+        const int incl = wave_incl_scan_i(tcount);
+        __syncthreads();   // (ws / cls_wave of the previous trip consumed)
+        if (lane == 63) ws[wave] = incl;
+        const int cls = (g < N && r > 0) ? gps::bwd_class(r) : -1;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < gps::BWD_CLASSES; k++) {
+            const unsigned long long m = __ballot(cls == k);
+            if (lane == 0) cls_wave[wave][k] = __popcll(m);
+            if (cls == k) mine = m;
+        }
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < SCAT_WAVES; w++) { const int v = ws[w]; if (w < wave) woff += v; total += v; }
+        pre[j] = (uint32_t)(carry + woff + incl - tcount);
+        box[j] = bx;
+        carry += total;
+        if (cls_ids) {
+#pragma unroll
+            for (int k = 0; k < gps::BWD_CLASSES; k++) {
+                int before = 0, all = 0;
+                for (int w = 0; w < SCAT_WAVES; w++) { const int v = cls_wave[w][k]; if (w < wave) before += v; all += v; }
+                if (cls == k) cls_ids[k * cls_stride + running_cls[k] + before + __popcll(mine & lanemask_lt())] = g;
+                running_cls[k] += all;
+            }
+        }
+    }
+    if (tid == 0) pre[sb_size] = (uint32_t)carry;
+    __syncthreads();
+    const int n_pairs = carry;
+    // chunks of SCAT_CHUNK pairs in Gaussian order; wave w owns pairs [256 w, 256 w + 256) of a chunk, visited iteration-major,
+    // lane-minor: "earlier pair, same tile" == stable rank (as wide_scatter_kernel of splat_bin.hip)
+    int bits = 1;
+    while ((1 << bits) < n_tiles) bits++;
+    const unsigned long long lt = lanemask_lt();
+    uint16_t* mycnt = wavecnt + wave * n_tiles;
+    for (int c0 = 0; c0 < n_pairs; c0 += SCAT_CHUNK) {
+        for (int k = tid; k < SCAT_WAVES * n_tiles; k += SCAT_THREADS) wavecnt[k] = 0;
+        __syncthreads();
+        uint32_t tile[SCAT_ITEMS], gid[SCAT_ITEMS], rank[SCAT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SCAT_ITEMS; k++) {
+            const int p = c0 + wave * (64 * SCAT_ITEMS) + k * 64 + lane;
+            const bool valid = p < n_pairs;
+            uint32_t d = 0;
+            gid[k] = 0;
+            if (valid) {
+                int lo = 0, hi = sb_size;   // largest j with pre[j] <= p (pairs of Gaussians without tiles have equal prefixes: take the last)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)pre[mid] <= p) lo = mid; else hi = mid; }
+                const uint32_t b = box[lo];
+                const uint32_t w = b >> 24, q = (uint32_t)(p - (int)pre[lo]);
+                d = ((b >> 12) & 0xfffu) * (uint32_t)tw + (b & 0xfffu) + (q / w) * (uint32_t)tw + q % w;
+                gid[k] = (uint32_t)(g0 + lo);
+            }
+            tile[k] = d;
+            unsigned long long same = __ballot(valid);
+            for (int bb = 0; bb < bits; bb++) {
+                const unsigned long long bal = __ballot(valid && ((d >> bb) & 1u));
+                same &= ((d >> bb) & 1u) ? bal : ~bal;
+            }
+            const uint32_t prev = mycnt[d];
+            rank[k] = prev + (uint32_t)__popcll(same & lt);
+            if (valid && (same >> lane) == 1ull) mycnt[d] = (uint16_t)(prev + (uint32_t)__popcll(same));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // per tile: exclusive prefix over the waves, the chunk's total
+        for (int b = tid; b < n_tiles; b += SCAT_THREADS) {
+            uint32_t acc = 0;
+            for (int w = 0; w < SCAT_WAVES; w++) { const uint32_t c = wavecnt[w * n_tiles + b]; wavecnt[w * n_tiles + b] = (uint16_t)acc; acc += c; }
+            tot16[b] = (uint16_t)acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAT_ITEMS; k++) {
+            const int p = c0 + wave * (64 * SCAT_ITEMS) + k * 64 + lane;
+            if (p < n_pairs) {
+                const uint32_t d = tile[k];
+                const int64_t pos = (int64_t)base[d] + mycnt[d] + rank[k];
+                if (pos < isect_cap) flatten_ids[pos] = (int32_t)gid[k];
+            }
+        }
+        __syncthreads();
+        // the next chunk's pairs of a tile go behind this chunk's
+        for (int b = tid; b < n_tiles; b += SCAT_THREADS) base[b] += tot16[b];
+    }
+}
+
+}  // namespace
+
+namespace gps {
+
+size_t sb_tables_bytes() {
+    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * 8 * 4 * 2 + 1024;
+}
+
+void sb_tables_carve(char* base, SbTables* t) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += (bytes + 255) & ~(size_t)255; return p; };
+    t->C = (uint32_t*)take((size_t)SB_MAX_TILES * SB_MAX * 4);
+    t->P = (uint32_t*)take((size_t)SB_MAX_TILES * SB_MAX * 4);
+    t->tile_total = (uint32_t*)take((size_t)SB_MAX_TILES * 4);
+    t->cls_count = (int32_t*)take((size_t)(SB_MAX + 1) * 8 * 4);
+    t->cls_prefix = (int32_t*)take((size_t)(SB_MAX + 1) * 8 * 4);
+    t->sb_shift = 0;
+}
+
+int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, const BinCountOut& cnt, int64_t isect_capacity,
+                           const int32_t* tiles_per_gauss, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* counts,
+                           int32_t* cls_ids, int32_t* cls_counts, int64_t cls_stride, gps_stream stream) {
+    GPS_ENTER();
+    const int n_tiles = cnt.tw * cnt.th;
+    GPS_REQUIRE(N > 0 && cnt.sb.C && n_tiles <= SB_MAX_TILES && cnt.tw < 4096 && cnt.th < 4096 && isect_capacity > 0);
+    GPS_REQUIRE(means2d && radii && tiles_per_gauss && flatten_ids && tile_offsets && counts);
+    GPS_REQUIRE(!cls_ids || (cls_counts && cls_stride >= N));
+    const int nblk = gps_div_up(N, BIN_BLOCK);
+    const int n_sb = (nblk + (1 << cnt.sb.sb_shift) - 1) >> cnt.sb.sb_shift;
+    GPS_REQUIRE(n_sb <= SB_MAX);
+    hipStream_t s = (hipStream_t)stream;
+    sb_scan_kernel<<<gps_div_up(n_tiles, 4), 256, 0, s>>>(n_tiles, cnt.sb, n_sb, cls_counts);
+    const int sb_size = BIN_BLOCK << cnt.sb.sb_shift;
+    const size_t lds = ((size_t)n_tiles + ((SCAT_WAVES + 1) * (size_t)n_tiles + 1) / 2 + 2 * (size_t)sb_size + 2) * 4;
+    GPS_REQUIRE(lds <= 160 * 1024);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    sb_scatter_kernel<<<n_sb, SCAT_THREADS, lds, s>>>(N, means2d, radii, tiles_per_gauss, cnt.tile_size, cnt.tw, cnt.th, cnt.sb,
+                                                     isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_stride);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
+}
+
+}  // namespace gps

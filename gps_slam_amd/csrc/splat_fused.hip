@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
                                                              BinCountOut cnt, ZeroGrads zg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int n_tiles = 0, n_groups = 0, vis = 0;
+    float box_mx = 0.f, box_my = 0.f;   // what the superblock histogram below needs of this Gaussian
+    int box_r = 0;
     if (i < in.N) {
         constexpr int NB = (DEG + 1) * (DEG + 1);
         Cam cam;
@@ -121,12 +123,40 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
         }
         if (cnt.tiles_per_gauss) {
             // first pass of the tile binning (count_kernel of splat_bin.hip) on the values still in registers
-            if (o.radius > 0) { tile_group_count(o.mx, o.my, o.radius, cnt.tile_size, cnt.tw, cnt.th, n_tiles, n_groups); vis = 1; }
+            if (o.radius > 0) {
+                tile_group_count(o.mx, o.my, o.radius, cnt.tile_size, cnt.tw, cnt.th, n_tiles, n_groups); vis = 1;
+                box_mx = o.mx; box_my = o.my; box_r = o.radius;
+            }
             cnt.tiles_per_gauss[i] = n_tiles;
             cnt.groups_per_gauss[i] = n_groups;
         }
     }
     if (cnt.tiles_per_gauss) bin_block_sums(cnt, n_tiles, n_groups, vis);  // (uniform branch: every thread arrives)
+    if (cnt.sb.C) {
+        // Superblock binning, histogram pass (splat_bin.hpp): this workgroup's (Gaussian, tile) pairs counted per tile in LDS,
+        // the non-zero bins added to the count table of its superblock; Gaussians per backward class likewise.
+        __shared__ uint32_t hist[SB_MAX_TILES];
+        const int nt = cnt.tw * cnt.th;
+        for (int b = threadIdx.x; b < nt; b += 256) hist[b] = 0;
+        __syncthreads();
+        if (n_tiles > 0) {
+            const TileBox bx = tile_bbox(box_mx, box_my, box_r, cnt.tile_size, cnt.tw, cnt.th);
+            for (uint32_t ty = bx.y0; ty < bx.y1; ty++)
+                for (uint32_t tx = bx.x0; tx < bx.x1; tx++) atomicAdd(&hist[ty * (uint32_t)cnt.tw + tx], 1u);
+        }
+        __syncthreads();
+        const int sb = (int)blockIdx.x >> cnt.sb.sb_shift;
+        for (int b = threadIdx.x; b < nt; b += 256) {
+            const uint32_t c = hist[b];
+            if (c) atomicAdd(&cnt.sb.C[(size_t)b * SB_MAX + sb], c);
+        }
+        const int cls = box_r > 0 ? bwd_class(box_r) : -1;
+#pragma unroll
+        for (int k = 0; k < BWD_CLASSES; k++) {
+            const unsigned long long m = __ballot(cls == k);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt.sb.cls_count[sb * 8 + k], (int)__popcll(m));
+        }
+    }
 }
 
 // FUSE_ADAM: the Adam step of the sh_rest tensor (45 of the 59 parameters) happens here, on the LDS tiles, instead of in
@@ -189,6 +219,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
                                                              const float* __restrict__ v_conics,
                                                              const float* __restrict__ v_colors,
                                                              const float* __restrict__ v_opac,
+                                                             const float4* __restrict__ v_rows,
                                                              float* __restrict__ v_means,
                                                              float* __restrict__ v_log_scales,
                                                              float* __restrict__ v_quats,
@@ -214,6 +245,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
     float* g_tile = FUSE_ADAM ? sh_tile + blockDim.x * row : sh_tile;
     float* vrest = g_tile + threadIdx.x * row;
     const bool vis = live && radii[i] > 0;
+    // (strip rows: a Gaussian the rasterizer did not touch has no row -- and no opacity gradient; four arrays: every element is
+    // an input, as the operator-level entry point defines it)
+    float v_opac_i = (!v_rows && live) ? v_opac[i] : 0.f;
     int written = 0;  // number of sh_rest bands written below
     if (vis) {
         Cam cam;
@@ -223,9 +257,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
         const float q[4] = {q4.x, q4.y, q4.z, q4.w};
         const float s[3] = {expf(in.log_scales[3 * i]), expf(in.log_scales[3 * i + 1]), expf(in.log_scales[3 * i + 2])};
         const float conic[3] = {conics[3 * i], conics[3 * i + 1], conics[3 * i + 2]};
-        const float vm2[2] = {v_means2d[2 * i], v_means2d[2 * i + 1]};
-        const float vc[3] = {v_conics[3 * i], v_conics[3 * i + 1], v_conics[3 * i + 2]};
-        const float4 vcol = *reinterpret_cast<const float4*>(v_colors + 4 * (size_t)i);
+        // the rasterizer's gradients of this Gaussian: one 48-byte row {colors[4], conics[3], means2d[2], opacity} from the strip
+        // backward, or the four arrays of the operator-level entry points
+        float vm2[2], vc[3];
+        float4 vcol;
+        if (v_rows) {
+            const float4 r0 = v_rows[3 * (size_t)i], r1 = v_rows[3 * (size_t)i + 1], r2 = v_rows[3 * (size_t)i + 2];
+            vcol = r0;
+            vc[0] = r1.x; vc[1] = r1.y; vc[2] = r1.z;
+            vm2[0] = r1.w; vm2[1] = r2.x;
+            v_opac_i = r2.y;
+        } else {
+            vm2[0] = v_means2d[2 * i]; vm2[1] = v_means2d[2 * i + 1];
+            vc[0] = v_conics[3 * i]; vc[1] = v_conics[3 * i + 1]; vc[2] = v_conics[3 * i + 2];
+            vcol = *reinterpret_cast<const float4*>(v_colors + 4 * (size_t)i);
+        }
         // depth channel of `colors` is the projection's depth output (raw_gs_model.cpp:286)
         project_gaussian_vjp(cam, p, q, s, conic, vm2, vcol.w, vc, vp, vq, vs);
         // SH: recompute the un-clamped colour to evaluate clamp_min's mask (grad passes where sh + 0.5 >= 0)
@@ -310,7 +356,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
     if (!live) return;
     // opac = sigmoid(logit): receives gradient for every Gaussian the rasterizer touched (0 otherwise)
     const float o = 1.f / (1.f + expf(-in.opac_logit[i]));
-    const float vo = v_opac[i] * o * (1.f - o);
+    const float vo = v_opac_i * o * (1.f - o);
     if (v_means) {  // gradient outputs (optional when the small tensors are stepped below)
         v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
         v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
@@ -337,12 +383,12 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
                           const float* v_colors, const float* v_opacities, float* v_means, float* v_log_scales,
                           float* v_quats, float* v_opac_logit, float* v_sh_dc, float* v_sh_rest, float* adam_param,
                           float* adam_m, float* adam_v, AdamScalars sc, const gps_adam_segment* small5,
-                          const float* small_step, gps_stream stream) {
+                          const float* small_step, gps_stream stream, const float* v_rows) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
     if (N == 0) return GPS_OK;
     GPS_REQUIRE(means && log_scales && quats && opac_logit && sh_dc && (K == 1 || sh_rest) && viewmat && Kmat && cam_pos);
-    GPS_REQUIRE(radii && conics && v_means2d && v_conics && v_colors && v_opacities);
+    GPS_REQUIRE(radii && conics && (v_rows || (v_means2d && v_conics && v_colors && v_opacities)));
     const bool grads_out = v_means != nullptr;
     GPS_REQUIRE(grads_out ? (v_log_scales && v_quats && v_opac_logit && v_sh_dc) : (small5 != nullptr));
     const bool fuse = adam_param != nullptr && K > 1;
@@ -373,7 +419,8 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
     GPS_REQUIRE(lds <= 65536);
     hipStream_t s = (hipStream_t)stream;
 #define GPS_BWD(D)                                                                                                 \
-    preprocess_bwd_kernel<D><<<g, b, lds, s>>>(in, ad, radii, conics, v_means2d, v_conics, v_colors, v_opacities, v_means, \
+    preprocess_bwd_kernel<D><<<g, b, lds, s>>>(in, ad, radii, conics, v_means2d, v_conics, v_colors, v_opacities,         \
+                                               reinterpret_cast<const float4*>(v_rows), v_means,                         \
                                                v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest)
     switch (sh_degree) {
         case 0: GPS_BWD(0); break;
@@ -404,7 +451,7 @@ int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const
     BinCountOut cnt = {};
     if (count) cnt = *count;
     ZeroGrads zg = {};
-    if (zero) { zg = *zero; GPS_REQUIRE(zg.v_means2d && zg.v_conics && zg.v_colors && zg.v_opacities); }
+    if (zero && zero->v_colors) { zg = *zero; GPS_REQUIRE(zg.v_means2d && zg.v_conics && zg.v_colors && zg.v_opacities); }
     static_assert(BIN_BLOCK == 256, "the binning's per-block sums are per preprocessing workgroup");
     dim3 g(gps_div_up(N, 256)), b(256);
     hipStream_t s = (hipStream_t)stream;

@@ -110,7 +110,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // one pixel of gps_compose_l1 (splat_optim.hip: compose_l1_kernel) on a render that is still in registers; returns the
 // pixel's |gt - rgb| sum
-__device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int p, float4 rc, float w) {
+__device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int p, float4 rc, float w, float cut) {
     const float den = w + 1.0f;  // base colour weight is always 1 (raw_gs_model.cpp:321-323)
     const float n0 = rc.x + fc.base_color[3 * p], n1 = rc.y + fc.base_color[3 * p + 1], n2 = rc.z + fc.base_color[3 * p + 2];
     const float c0 = n0 / den, c1 = n1 / den, c2 = n2 / den;
@@ -122,7 +122,10 @@ __device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int
     const float g2 = d2 > 0.f ? -ic : (d2 < 0.f ? ic : 0.f);
     reinterpret_cast<float4*>(fc.v_render_colors)[p] = make_float4(g0 / den, g1 / den, g2 / den, 0.f);
     const float dd = den * den;
-    fc.v_render_alphas[p] = -(g0 * n0) / dd - (g1 * n1) / dd - (g2 * n2) / dd;
+    const float va = -(g0 * n0) / dd - (g1 * n1) / dd - (g2 * n2) / dd;
+    fc.v_render_alphas[p] = va;
+    // what the strip backward gathers per pixel: {d loss / d weight sum, the depth cut ref_depth + delta_depth}
+    if (fc.pix2) reinterpret_cast<float2*>(fc.pix2)[p] = make_float2(va, cut);
     return fabsf(d0) + fabsf(d1) + fabsf(d2);
 }
 
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
         if (fc.base_color) {
             // compose + L1 + image gradients of the two pixels, operation for operation what compose_l1_kernel does
             float lsum = 0.f;
-            if (in0) lsum += compose_l1_pixel(fc, pix, c0, w0);
-            if (in1) lsum += compose_l1_pixel(fc, pix + 1, c1, w1);
+            if (in0) lsum += compose_l1_pixel(fc, pix, c0, w0, cut0);
+            if (in1) lsum += compose_l1_pixel(fc, pix + 1, c1, w1, cut1);
             lsum = wave_sum(lsum);
             if (lane == 0) atomicAdd(fc.loss, lsum * fc.inv_count);
         }

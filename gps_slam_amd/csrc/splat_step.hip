@@ -10,24 +10,38 @@
 
 extern "C" {
 
+// the strip backward's buffers are all there and the tile ids fit the superblock binning's LDS histograms
+static bool strips_on(const gps_splat_step* a) {
+    const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
+    return a->v_rows && a->pix2 && a->cls_ids && a->cls_counts && a->cls_stride >= a->N && a->records && tw * th <= gps::SB_MAX_TILES;
+}
+
 // projection + binning + forward rasterizer; `compose` / `zero`: the train step's compose + L1 and gradient zero-fill riding
-// along in those kernels (nullptr: the plain render)
+// along in those kernels (nullptr: the plain render; zero != nullptr also marks a train step: the binning then writes the
+// backward's class lists)
 static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose, const gps::ZeroGrads* zero, gps_stream stream) {
     GPS_REQUIRE(a != nullptr);
     const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
     int r;
-    // the preprocessing kernel also writes the first pass of the tile binning (tiles / groups per Gaussian + block sums)
+    // the preprocessing kernel also writes the first pass of the tile binning: tiles (/ groups) per Gaussian + block sums, and
+    // with the strip backward's buffers present the superblock binning's histogram pass
+    const bool sb = strips_on(a) && a->N > 0;
     gps::BinCountOut cnt;
-    r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, &cnt);
+    r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, sb, &cnt);
     if (r != GPS_OK) return r;
     r = gps::preprocess_fwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
                                    a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
                                    a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
                                    a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, zero, stream);
     if (r != GPS_OK) return r;
-    r = gps::isect_tiles_no_depth_counted(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
-                                          a->tiles_per_gauss, a->flatten_ids, a->group_gs_ids, a->group_starts,
-                                          a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
+    if (sb)   // scan + scatter (+ the backward's class lists when this is a train step)
+        r = gps::isect_tiles_superblock(a->N, a->means2d, a->radii, cnt, a->isect_capacity, a->tiles_per_gauss, a->flatten_ids,
+                                        a->tile_offsets, a->counts, zero ? a->cls_ids : nullptr, zero ? a->cls_counts : nullptr,
+                                        a->cls_stride, stream);
+    else
+        r = gps::isect_tiles_no_depth_counted(a->N, a->means2d, a->radii, 16, tw, th, a->isect_capacity, a->group_capacity,
+                                              a->tiles_per_gauss, a->flatten_ids, a->group_gs_ids, a->group_starts,
+                                              a->tile_offsets, a->counts, a->workspace, a->workspace_bytes, stream);
     if (r != GPS_OK) return r;
     if (a->records)
         r = gps::raster_ges_fwd_rec_launch(a->N, a->records, a->ref_depth_clamped, a->width, a->height, a->tile_offsets,
@@ -45,25 +59,33 @@ int gps_splat_render(const gps_splat_step* a, gps_stream stream) { return render
 int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stream) {
     GPS_REQUIRE(a != nullptr && adam_step >= 1);
     GPS_REQUIRE(a->gt_rgb && a->loss && a->v_render_colors && a->v_render_alphas);
-    // Launch sites of one iteration (8): preprocess (+ binning count pass + zero-fill of the rasterizer gradients), expand
-    // (+ block prefix and totals), count table, row scan, scatter, forward rasterizer (+ compose + L1 + image gradients in its epilogue), backward
-    // rasterizer, preprocess backward (+ Adam).
+    // Launch sites of one iteration with the strip backward's buffers (6): preprocess (+ the binning's histogram pass), row scan,
+    // scatter (+ the backward's class lists), forward rasterizer (+ compose + L1 + image gradients in its epilogue), backward
+    // rasterizer, preprocess backward (+ Adam).  Without them (8): preprocess (+ count pass + zero-fill of the rasterizer
+    // gradients), expand, count table, row scan, scatter, forward, group backward, preprocess backward.
     GPS_REQUIRE(a->base_color != nullptr);
     const bool fused_fwd = a->records != nullptr;  // the record rasterizer carries the compose epilogue
+    const bool strips = strips_on(a);              // (implies fused_fwd)
     gps::FwdCompose fc = {a->base_color, a->gt_rgb, a->rgb, a->loss, a->v_render_colors, a->v_render_alphas,
-                          1.0f / (3.0f * (float)(a->width * a->height))};
+                          1.0f / (3.0f * (float)(a->width * a->height)), strips ? a->pix2 : nullptr};
+    // group kernel: its four accumulator arrays are zero-filled by the preprocessing kernel; strips: every row is a plain store
     gps::ZeroGrads zg = {a->v_means2d, a->v_conics, a->v_colors, a->v_opacities};
-    int r = render_chain(a, fused_fwd ? &fc : nullptr, &zg, stream);
+    gps::ZeroGrads no_zero = {};
+    int r = render_chain(a, fused_fwd ? &fc : nullptr, strips ? &no_zero : &zg, stream);
     if (r != GPS_OK) return r;
     if (!fused_fwd) {
         r = gps_compose_l1(a->width, a->height, a->render_colors, a->weight_sum, a->base_color, nullptr, a->gt_rgb, a->rgb,
                            nullptr, a->loss, a->v_render_colors, a->v_render_alphas, stream);
         if (r != GPS_OK) return r;
     }
-    r = gps::raster_ges_bwd_gs_launch(a->N, a->means2d, a->conics, a->colors, a->opacities, a->radii, a->ref_depth_clamped,
-                                      a->width, a->height, a->group_gs_ids, a->group_starts, a->counts, a->delta_depth,
-                                      a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
-                                      a->v_opacities, a->N > 0 ? 2 : 0, stream);
+    if (strips)
+        r = gps::raster_ges_bwd_strips_launch(a->N, a->records, a->radii, a->cls_ids, a->cls_counts, (int)a->cls_stride,
+                                              a->v_render_colors, a->pix2, a->width, a->height, a->v_rows, stream);
+    else
+        r = gps::raster_ges_bwd_gs_launch(a->N, a->means2d, a->conics, a->colors, a->opacities, a->radii, a->ref_depth_clamped,
+                                          a->width, a->height, a->group_gs_ids, a->group_starts, a->counts, a->delta_depth,
+                                          a->v_render_colors, a->v_render_alphas, a->v_means2d, a->v_conics, a->v_colors,
+                                          a->v_opacities, a->N > 0 ? 2 : 0, stream);
     if (r != GPS_OK) return r;
     const int mode = a->K > 1 ? a->fuse_sh_rest_adam : 0;
     const bool fuse = mode >= 1, all = mode >= 2;
@@ -84,7 +106,7 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
                                    fuse ? nullptr : a->g_sh_rest, fuse ? a->sh_rest : nullptr,
                                    fuse ? a->m_sh_rest : nullptr, fuse ? a->v_sh_rest : nullptr,
                                    gps::adam_scalars(a->lr[4], a->beta1, a->beta2, a->adam_eps, adam_step),
-                                   all ? seg : nullptr, all ? sstep : nullptr, stream);
+                                   all ? seg : nullptr, all ? sstep : nullptr, stream, strips ? a->v_rows : nullptr);
     if (r != GPS_OK || all) return r;
     return gps_adam_step(seg, fuse ? 5 : 6, a->beta1, a->beta2, a->adam_eps, adam_step, stream);
 }

@@ -227,6 +227,9 @@ class RawGaussianModel:
         # gps_splat_step.fuse_sh_rest_adam: 0 = gradients are written and a separate Adam kernel steps (grads() is valid),
         # 2 = what the C++ host runs (host/raw_gs_model.cpp): every tensor stepped inside the backward kernel
         self.fuse_adam = int(cfg.get("fuse_sh_rest_adam", 0))
+        # the fused iteration's binning + backward rasterizer: superblock counting sort + column strips (default) or the
+        # sorted-key binning + 32-pixel-group kernel of the operator-level entry points
+        self.strip_backward = bool(cfg.get("strip_backward", True))
         self._opt = None       # Adam state: capacity-sized m / v / g buffers + step count
         self._step = None      # persistent gps_splat_step
         self._step_key = None
@@ -260,10 +263,13 @@ class RawGaussianModel:
             B = dict(radii=i32(cap), means2d=f(cap, 2), depths=f(cap), conics=f(cap, 3), colors=f(cap, 4),
                      opacities=f(cap), records=f(cap, 12), tiles_per_gauss=i32(cap), flatten_ids=i32(icap), group_gs_ids=i32(gcap),
                      group_starts=i32(gcap), tile_offsets=i32(th * tw), counts=torch.zeros(4, dtype=torch.int64, device=d),
-                     workspace=torch.empty(int(lib.gps_isect_workspace_bytes(cap, icap)), dtype=torch.uint8, device=d),
+                     # (zero-filled: the superblock binning's count tables are kept zero between launches by the kernels)
+                     workspace=torch.zeros(int(lib.gps_isect_workspace_bytes(cap, icap)), dtype=torch.uint8, device=d),
                      render_colors=f(1, H, W, 4), weight_sum=f(1, H, W, 1), rgb=f(H, W, 3), depth=f(H, W, 1),
                      loss=torch.zeros(1, device=d), v_render_colors=f(1, H, W, 4), v_render_alphas=f(1, H, W, 1),
                      v_means2d=f(cap, 2), v_conics=f(cap, 3), v_colors=f(cap, 4), v_opacities=f(cap))
+            if self.strip_backward:  # buffers of the strip backward (gps_splat_step: all set -> superblock binning + strips)
+                B.update(v_rows=f(cap, 12), pix2=f(H * W, 2), cls_ids=i32(5, cap), cls_counts=torch.zeros(8, dtype=torch.int32, device=d))
             st = SplatStep()
             st.K, st.sh_degree, st.width, st.height = p.K, self.degreesToUse, W, H
             st.max_gs_radii = int(self.max_gs_radii)
@@ -273,6 +279,7 @@ class RawGaussianModel:
                 if hasattr(st, name):
                     setattr(st, name, t.data_ptr())
             st.isect_capacity, st.group_capacity, st.workspace_bytes = icap, gcap, B["workspace"].numel()
+            st.cls_stride = cap
             st.beta1, st.beta2, st.adam_eps = 0.9, 0.999, 1e-15
             st.fuse_sh_rest_adam = self.fuse_adam
             self._step, self._step_key, self._B = st, key, B

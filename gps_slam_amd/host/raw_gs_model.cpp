@@ -23,6 +23,7 @@ void RawGaussianModel::loadConfig(const Config& c) {
     featuresRest_lr = c.get("featuresRest_lr", featuresRest_lr); opacities_lr = c.get("opacities_lr", opacities_lr);
     isect_capacity = (int64_t)c.get("isect_capacity", (double)isect_capacity);
     fuse_sh_rest_adam = c.get("fuse_sh_rest_adam", fuse_sh_rest_adam ? 1.0 : 0.0) != 0.0;
+    strip_backward = c.get("strip_backward", strip_backward ? 1.0 : 0.0) != 0.0;
     render_method = c.gets("render_method", render_method);
     const int64_t cap = (int64_t)c.get("capacity", 1 << 19);
     opt_gs_params.reserve(cap, numShBases(maxSH), device);
@@ -58,7 +59,7 @@ gps_splat_step& RawGaussianModel::stepStruct(int W, int H) {
         B_.tile_offsets = torch::empty({th * tw}, I);
         B_.counts = torch::zeros({4}, i64(device));
         const int64_t ws = gps_isect_workspace_bytes((int)cap, icap);
-        B_.workspace = torch::empty({ws}, u8(device));
+        B_.workspace = torch::zeros({ws}, u8(device));  // (the superblock binning's count tables are zero between launches)
         B_.render_colors = torch::empty({1, H, W, 4}, F); B_.weight_sum = torch::empty({1, H, W, 1}, F);
         B_.rgb = torch::empty({H, W, 3}, F); B_.depth = torch::empty({H, W, 1}, F);
         B_.loss = torch::zeros({1}, F);
@@ -79,6 +80,12 @@ gps_splat_step& RawGaussianModel::stepStruct(int W, int H) {
         s.loss = fptr(B_.loss); s.v_render_colors = fptr(B_.v_render_colors); s.v_render_alphas = fptr(B_.v_render_alphas);
         s.v_means2d = fptr(B_.v_means2d); s.v_conics = fptr(B_.v_conics); s.v_colors = fptr(B_.v_colors);
         s.v_opacities = fptr(B_.v_opacities);
+        if (strip_backward) {
+            B_.v_rows = torch::empty({cap, 12}, F); B_.pix2 = torch::empty({(int64_t)H * W, 2}, F);
+            B_.cls_ids = torch::empty({GPS_BWD_CLASSES, cap}, I); B_.cls_counts = torch::zeros({8}, I);
+            s.v_rows = fptr(B_.v_rows); s.pix2 = fptr(B_.pix2);
+            s.cls_ids = iptr(B_.cls_ids); s.cls_counts = iptr(B_.cls_counts); s.cls_stride = cap;
+        }
         s.beta1 = 0.9; s.beta2 = 0.999; s.adam_eps = 1e-15;
         step_cap_ = cap; step_w_ = W; step_h_ = H;
     }
@@ -149,7 +156,11 @@ struct GesRenderFunction : public torch::autograd::Function<GesRenderFunction> {
         const auto* cam = reinterpret_cast<const Camera*>(cam_ptr);
         gps_splat_step& st = model->stepStruct(cam->width, cam->height);
         model->bindCamera(st, *cam, ref_clamped, base_color, torch::Tensor());
-        check(gps_splat_render(&st, current_stream()), "gps_splat_render");
+        // this node's backward runs the operator-level group kernel on the render's 32-pixel group table: the sorted-key binning
+        // writes it (the superblock binning of the strip path has no use for one)
+        gps_splat_step with_groups = st;
+        with_groups.v_rows = nullptr;
+        check(gps_splat_render(&with_groups, current_stream()), "gps_splat_render");
         ctx->saved_data["launch_id"] = model->nextLaunchId();
         auto& B = model->buffers();
         check(gps_compose_l1(cam->width, cam->height, fptr(B.render_colors), fptr(B.weight_sum), fptr(base_color),

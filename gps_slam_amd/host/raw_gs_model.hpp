@@ -89,6 +89,9 @@ public:
     // trainStep: step featuresRest inside the backward kernel (its gradient never reaches HBM; grads()[4] is then stale).
     // The parameter update is bit-identical either way.
     bool fuse_sh_rest_adam = true;
+    // trainStep's binning + backward rasterizer: superblock counting sort + column strips (gps_splat_step::v_rows .. set), or
+    // the sorted-key binning + 32-pixel-group kernel of the operator-level entry points
+    bool strip_backward = true;
     std::string render_method = "ges";
     bool abs_grad = false;       // raw_gs_model.h:293
     torch::Tensor backgrounds;   // raw_gs_model.h:295 ([1,4] device tensor; undefined = none)
@@ -97,7 +100,8 @@ public:
     struct Buffers {
         torch::Tensor radii, means2d, depths, conics, colors, opacities, records, tiles_per_gauss, flatten_ids,
             group_gs_ids, group_starts, tile_offsets, counts, workspace, render_colors, weight_sum, rgb, depth, loss,
-            v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors, v_opacities;
+            v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors, v_opacities,
+            v_rows, pix2, cls_ids, cls_counts;   // the strip backward's buffers (strip_backward)
     };
     gps_splat_step& stepStruct(int W, int H);
     void bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,

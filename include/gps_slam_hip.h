@@ -84,6 +84,9 @@ GPS_API int gps_sh_bwd(int N, int K, int degrees_to_use, const float *dirs, cons
 /* Size in bytes of the scratch buffer gps_isect_tiles_no_depth needs for N Gaussians and
  * room for isect_capacity intersections. */
 GPS_API int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity);
+/* Zero-fills a binning workspace.  Call once after allocating (or re-allocating) the blob handed to gps_splat_render /
+ * gps_splat_train_step: the fused path's count tables are kept zero BETWEEN launches by the kernels themselves. */
+GPS_API int gps_isect_workspace_init(void *workspace, int64_t workspace_bytes, gps_stream stream);
 
 /* replaces gsplat::isect_tiles_tensor_no_depth + isect_offset_encode_tensor_no_depth
  * (isect_tiles_no_depth.cu:132-461) in ONE call without host synchronisation.
@@ -137,6 +140,24 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
                           const int64_t *counts, float delta_depth, const float *v_render_colors,
                           const float *v_render_alphas, float *v_means2d, float *v_conics, float *v_colors,
                           float *v_opacities, int accumulate, gps_stream stream);
+
+/* The same operator (rasterize_to_pixels_bwd_ges_new_parallel.cu:18-201: every pixel of the 2r x 2r box, the same per-pixel
+ * arithmetic) in the decomposition the fused model path runs: a Gaussian owns 4 / 8 / 16 / 32 / 64 adjacent lanes (class k:
+ * the smallest 4 << k >= r; class 4 covers every larger radius), each lane walks two columns of the box row by row, the ten
+ * gradient totals are reduced once per Gaussian and written as ONE 48-byte row
+ *     v_rows[id] = { v_colors[4], v_conics[3], v_means2d[2], v_opacity, 0, 0 }
+ * -- a plain store per Gaussian of the class lists: no atomics, no zero-fill.  Rows of Gaussians that are in no list are not
+ * touched.  records: gps_gauss_preprocess_fwd's 48-byte records; radii: the clamped radii binning used;
+ * cls_ids[GPS_BWD_CLASSES][cls_stride]: ascending Gaussian ids per class, cls_counts[GPS_BWD_CLASSES] on the device
+ * (written by the binning of gps_splat_train_step, or by gps_raster_bwd_classes for arrays that come from elsewhere);
+ * v_render_colors[P,4]; pix2[P,2] = {d loss / d weight_sum, ref_depth + delta_depth} per pixel (gps_raster_pair_image, or the
+ * fused forward's epilogue). */
+#define GPS_BWD_CLASSES 5
+GPS_API int gps_raster_ges_bwd_strips(int N, const float *records, const int32_t *radii, const int32_t *cls_ids,
+                                      const int32_t *cls_counts, int cls_stride, const float *v_render_colors,
+                                      const float *pix2, int width, int height, float *v_rows, gps_stream stream);
+GPS_API int gps_raster_pair_image(int width, int height, const float *v_render_alphas, const float *ref_depth_map,
+                                  float delta_depth, float *pix2, gps_stream stream);
 
 /* replaces gsplat::rasterize_to_pixels_bwd_ges_tensor (rasterize_to_pixels_bwd_ges.cu:18-291): the exact tile-parallel
  * adjoint of gps_raster_ges_fwd, what the reference's RasterizeToPixelsGes autograd Function runs (gsplat_wapper.hpp:355-487;
@@ -403,6 +424,14 @@ typedef struct {
      * 2: all six tensors are stepped inside the backward kernel (no Adam launch; no g_* is written).
      * The parameter update is bit-identical in all three modes. */
     int32_t fuse_sh_rest_adam;
+    /* Strip backward (gps_raster_ges_bwd_strips).  All five set: the train step bins with the superblock counting sort (which
+     * also writes the class lists), its forward epilogue writes pix2, its backward rasterizer writes v_rows and the
+     * preprocessing backward reads them; group_gs_ids / group_starts / v_means2d.. are then not touched.  Any NULL (or more
+     * than 4096 tiles): the sorted-key binning + the group kernel.
+     * v_rows[capacity,12]  pix2[H*W,2]  cls_ids[GPS_BWD_CLASSES, cls_stride]  cls_counts[8] (int32, device) */
+    float *v_rows, *pix2;
+    int32_t *cls_ids, *cls_counts;
+    int64_t cls_stride;
 } gps_splat_step;
 
 /* gesForward up to the rasterizer (preprocess -> binning -> ges forward): fills render_colors / weight_sum. */

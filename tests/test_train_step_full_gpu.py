@@ -2,7 +2,7 @@
 
 bench.py's optimise iteration is gps_splat_train_step with every Adam step fused into the backward kernel
 (fuse_sh_rest_adam = 2): preprocess_fwd_kernel<3> -> binning -> raster_ges_fwd_pk_kernel -> compose_l1_kernel ->
-raster_ges_bwd_gs_kernel -> preprocess_bwd_kernel<3> (+ Adam).  This test runs that call for three Adam steps at
+raster_ges_bwd_strip_kernel -> preprocess_bwd_kernel<3> (+ Adam).  This test runs that call for three Adam steps at
 640x480 / 200k Gaussians (BASELINE configs[2]) and 1280x720 / 400k (configs[3]) and checks EVERY stage of every step
 against the CPU oracle (oracle/splat_oracle.c restating src/raw_gs_model.cpp:188-417 and the gsplat kernels it calls)
 on the inputs that stage actually received, plus the Adam update against ATen's op sequence:
@@ -43,13 +43,13 @@ def N_(t):
     return t.detach().cpu().numpy()
 
 
-def _build(N, W, H, scale_range, seed):
+def _build(N, W, H, scale_range, seed, strips=True):
     from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
     g = scenes.random_gaussians(N, seed=seed, scale_range=scale_range)
     c2w, K = scenes.default_camera(W, H, seed=seed)
     models = []
     for mode in (0, 2):
-        m = SLAMGaussianModel(dict(capacity=1 << 19, fuse_sh_rest_adam=mode), device=DEV)
+        m = SLAMGaussianModel(dict(capacity=1 << 19, fuse_sh_rest_adam=mode, strip_backward=strips), device=DEV)
         m.add_params(dict(means=T(g["means"]), scales=T(g["log_scales"]), quats=T(g["quats"]),
                           featuresDc=T(g["sh"][:, 0].copy()), featuresRest=T(g["sh"][:, 1:].copy()),
                           opacities=T(g["opac_logit"])))
@@ -106,11 +106,23 @@ def _row_rel(got, ref, vis):
     return num / den
 
 
-@pytest.mark.parametrize("N,W,H,scale_range", [(200000, 640, 480, (0.003, 0.02)), (400000, 1280, 720, (0.002, 0.011))],
-                         ids=["640x480-200k", "1280x720-400k"])
-def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_range):
+def _rasterizer_grads(B, N, strips):
+    """[N, 10] = v_colors[4] | v_conics[3] | v_means2d[2] | v_opacity of the backward rasterizer: the strip kernel's 48-byte
+    rows, or the group kernel's four arrays"""
+    if strips:
+        return N_(B["v_rows"][:N, :10])
+    return np.concatenate([N_(B["v_colors"][:N]), N_(B["v_conics"][:N]), N_(B["v_means2d"][:N]), N_(B["v_opacities"][:N])[:, None]], 1)
+
+
+@pytest.mark.parametrize("N,W,H,scale_range,strips", [(200000, 640, 480, (0.003, 0.02), True), (400000, 1280, 720, (0.002, 0.011), True),
+                                                      (200000, 640, 480, (0.003, 0.02), False)],
+                         ids=["640x480-200k", "1280x720-400k", "640x480-200k-group-kernel"])
+def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_range, strips):
+    """strips = True: what bench.py times -- superblock binning (histogram in the preprocessing kernel, scan, scatter + class
+    lists) and the column-strip backward; False: the sorted-key binning + 32-pixel-group backward (the operator-level kernels,
+    and the train step's path when a host does not provide the strip buffers)."""
     from oracle import splat_ref as orc
-    (mA, mB), cam, ref, base, gt, c2w, K = _build(N, W, H, scale_range, seed=N // 1000)
+    (mA, mB), cam, ref, base, gt, c2w, K = _build(N, W, H, scale_range, seed=N // 1000, strips=strips)
     TS, delta = 16, mA.delta_depth
     tw, th = math.ceil(W / TS), math.ceil(H / TS)
     vm = scenes.pose_inv(c2w)
@@ -144,6 +156,9 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
             n_sign += int(off.sum())
             assert float(d.max()) <= 2.001 * lr * step
         assert n_sign <= 1e-5 * 59 * N, n_sign
+        if strips:  # no float atomics anywhere in the strip path: the two runs are the same computation
+            assert n_sign == 0
+            assert all(torch.equal(a, b) for a, b in zip(mA.opt_gs_params.tensors(), mB.opt_gs_params.tensors()))
         assert abs(float(mA.loss_sum()[0]) - float(mB.loss_sum()[0])) <= 1e-5 * float(mA.loss_sum()[0])  # float-atomic sum order
         B = mA._B
         counts = N_(B["counts"])
@@ -165,9 +180,20 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
 
         # ---- (b) binning of the HIP state: bit-exact at full size
         tpg, ids, flat, ggs, gst, offs = orc.isect_tiles(m1, r1, TS, tw, th)
-        assert ni == flat.shape[0] and ng == ggs.shape[0]
-        assert np.array_equal(N_(B["flatten_ids"][:ni]), flat) and np.array_equal(N_(B["group_gs_ids"][:ng]), ggs)
-        assert np.array_equal(N_(B["group_starts"][:ng]), gst) and np.array_equal(N_(B["tile_offsets"]), offs.reshape(-1))
+        assert ni == flat.shape[0]
+        assert np.array_equal(N_(B["flatten_ids"][:ni]), flat) and np.array_equal(N_(B["tile_offsets"]), offs.reshape(-1))
+        assert np.array_equal(N_(B["tiles_per_gauss"][:N]), tpg)
+        if strips:
+            # the backward's work lists: ascending ids per class (smallest 4 << k >= radius; the last class takes the rest)
+            cls = np.where(r1 > 0, np.searchsorted(np.array([4, 8, 16, 32]), r1, side="left"), -1)
+            cc = N_(B["cls_counts"])
+            for k in range(5):
+                want = np.nonzero(cls == k)[0]
+                assert int(cc[k]) == want.shape[0] and np.array_equal(N_(B["cls_ids"][k, :want.shape[0]]), want), k
+            assert int(counts[3]) == int((r1 > 0).sum()) and ng == 0
+        else:
+            assert ng == ggs.shape[0]
+            assert np.array_equal(N_(B["group_gs_ids"][:ng]), ggs) and np.array_equal(N_(B["group_starts"][:ng]), gst)
 
         # ---- (c) forward rasterizer (raster_ges_fwd_pk_kernel) on the HIP state
         e_rc, e_ra, _ = orc.raster_ges_fwd(m1, c1, col1, op1, ref_np, W, H, TS, offs, flat, delta)
@@ -207,8 +233,12 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
                                                           v_ra_h[..., 0], rel_band=-1.0)
         flip_b, nb_pairs, nb_g = orc.raster_ges_bwd_gs_flip_budget(m1, c1, col1, op1, r1, ref_np, W, H, ggs, gst, delta,
                                                                    v_rc_h, v_ra_h[..., 0], rel_band=BAND)
-        got_b = np.concatenate([N_(B["v_colors"][:N]), N_(B["v_conics"][:N]), N_(B["v_means2d"][:N]),
-                                N_(B["v_opacities"][:N])[:, None]], 1)
+        got_b = _rasterizer_grads(B, N, strips)
+        if strips:  # rows of Gaussians the rasterizer never sees are not written (and not read by the preprocessing backward)
+            got_b[r1 <= 0] = 0.0
+            assert np.isfinite(got_b).all()
+            assert np.array_equal(N_(B["pix2"]).reshape(H, W, 2)[..., 0], v_ra_h[..., 0])
+            assert np.array_equal(N_(B["pix2"]).reshape(H, W, 2)[..., 1], ref_np + np.float32(delta))
         exp_b = np.concatenate([e_bwd[2], e_bwd[1], e_bwd[0], e_bwd[3][:, None]], 1)
         db = np.abs(got_b - exp_b)
         rounding_b = REL * scale_b + 1e-30
@@ -219,11 +249,12 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
                                    [(float(db[i, k]), float(scale_b[i, k]), float(flip_b[i, k]), int(r1[i])) for i, k in bad[:5]])
         assert need_b.sum() <= nb_g
         print("step %d bwd: G=%d, %d borderline slots on %d Gaussians, %d Gaussians actually flipped"
-              % (step, ng, nb_pairs, nb_g, int(need_b.sum())))
+              % (step, ggs.shape[0], nb_pairs, nb_g, int(need_b.sum())))
 
         # ---- (f) preprocessing backward (preprocess_bwd_kernel<3>) on the HIP rasterizer gradients
-        e_g = _oracle_preprocess_bwd(P_o, vm, K, cam_pos, W, H, r1, c1, N_(B["v_means2d"][:N]), N_(B["v_conics"][:N]),
-                                     N_(B["v_colors"][:N]), N_(B["v_opacities"][:N]))
+        e_g = _oracle_preprocess_bwd(P_o, vm, K, cam_pos, W, H, r1, c1, np.ascontiguousarray(got_b[:, 7:9]),
+                                     np.ascontiguousarray(got_b[:, 4:7]), np.ascontiguousarray(got_b[:, 0:4]),
+                                     np.ascontiguousarray(got_b[:, 9]))
         g_hip = [N_(t) for t in mA.grads()]                               # NAMES: means scales quats dc rest opac
         vis = r1 > 0
         for name, got_g, ref_g in zip(("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"), g_hip,
