@@ -55,99 +55,211 @@ def _python_twin(scene, device):
     return model, cam, rc
 
 
-def iteration_roofline(scene, seq, result, hbm_peak_gbs, K):
-    """`roofline` of the bench line, all of it measured on the state the timed run ended in (no stored constants are divided
-    by live times):
+VALU_CYCLES = 2.0   # a wave64 VALU instruction on CDNA4's SIMD-32 (MI355X_MICROARCH.md; tools/probe/valu_rate.hip measures 1.5-1.7
+#                     shader cycles per instruction per SIMD at 8 waves, 2.9 for v_exp / v_rcp, 3.5 for v_permlane*_swap)
+SHADER_GHZ = 2.4
 
-    * dominant kernel = the Gaussian-parallel ges backward (largest share of GPU time per SLAM frame): `achieved` =
-      algorithmic bytes (SURVEY 8(d) raster-bwd row x the G, P of this launch) / average launch duration, HIP events on the
-      launch stream, accumulate = 1 so exactly one kernel per call;
-    * `iteration`: B_iter of SURVEY 8(d) evaluated with the logged N, Nv, I, G / the measured duration of one whole optimise
-      iteration (gps_splat_train_step, 20 back-to-back) -> fraction of HBM peak;
-    * `frame`: (2 B_iter + B_fuse) / the measured ms_per_step (20 iterations per 10 frames; B_fuse without the ray term);
-    * `traffic` (HBM bytes per launch from --pmc passes) only if profiles/pmc_raster_bwd.json was collected on a scene whose
-      (N, G) match this one within 1 %; otherwise null.  tools/profile.sh regenerates the file.
-    """
+
+def _pmc(kernel, N, tol=0.02):
+    """profiles/pmc_<kernel>.json (tools/profile.sh: separate --pmc passes over THIS program's micro-benchmark loops) if it was
+    collected on a scene of the same size (its recorded Gaussian count within 2 %), else None"""
     import json
+    fn = "pmc_binning.json" if kernel.startswith("binning") else "pmc_%s.json" % kernel
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fn)
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    n = (rec.get("units") or {}).get("gaussians")
+    return rec if n and abs(n - N) <= tol * N else None
+
+
+def _kernel_row(name, calls_per_frame, t, alg_bytes, hbm_peak_gbs, N, bound, note=""):
+    row = {"kernel": name, "calls_per_frame": calls_per_frame, "avg_us": t * 1e6, "us_per_frame": calls_per_frame * t * 1e6,
+           "algorithmic_bytes": alg_bytes, "achieved_GBs": alg_bytes / t / 1e9, "frac": alg_bytes / t / 1e9 / hbm_peak_gbs,
+           "bound": bound}
+    if note:
+        row["note"] = note
+    rec = _pmc(name, N)
+    if rec:
+        if rec.get("hbm_bytes_per_launch"):
+            row["traffic"] = rec["hbm_bytes_per_launch"]
+            row["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / max(1.0, alg_bytes)
+        v = (rec.get("sq") or {}).get("SQ_INSTS_VALU")
+        if v:
+            # counter collection serialises and slows the launches; the instruction COUNT carries over and is priced against
+            # this run's live launch time
+            row["valu_wave_instructions"] = v
+            row["valu_issue_frac"] = v * VALU_CYCLES / (1024 * SHADER_GHZ * 1e9 * t)
+        for k in ("wait_any_frac", "lds_conflict_per_active_lds"):
+            if k in (rec.get("sq") or {}):
+                row[k] = rec["sq"][k]
+    return row
+
+
+def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
+    """`roofline` of the bench line.  Every duration is measured live, here, with HIP events on the launch stream over 50
+    back-to-back launches of the kernel on the state the timed run ended in (Python twins of the model and of the TSDF
+    engine: same C-ABI, same buffers; the timed region never touched them); nothing stored is divided by anything live.
+
+    `kernels`: the kernels that carry a SLAM frame -- per kernel the live average launch time, launches per frame in the settled
+    loop, algorithmic (compulsory) HBM bytes per launch (evaluated with the scene's own N, Nv, I, G, P, T, V),
+    the fraction of the 8 TB/s HBM peak, and, where a PMC file of the same scene exists (tools/profile.sh), measured HBM traffic
+    and the VALU issue fraction.  The top-level `kernel` / `achieved` / `frac` are those of the kernel with the LARGEST share of
+    a frame's GPU time (calls x average), so the headline fraction is the dominant kernel's whatever it is.
+    `iteration` / `frame`: all algorithmic bytes of one optimise iteration / one frame over their measured times."""
     from gps_slam_amd._lib import lib
     device = "cuda:%d" % torch.cuda.current_device()
     model, cam, rc = _python_twin(scene, device)
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     model.initOptimizers(-1, 1.0)
-    model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+
+    def step():
+        model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+    step()
     torch.cuda.synchronize()
     B, st = model._B, model._step
     counts = B["counts"].cpu().tolist()
-    ni, ng, nvis = int(counts[0]), int(counts[1]), int(counts[3])
+    ni, nvis = int(counts[0]), int(counts[3])
     W, H, N = st.width, st.height, st.N
     P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    r = B["radii"][:N].long()
+    ng = int(((4 * r * r + 31) // 32)[r > 0].sum())   # the reference's 32-pixel groups (isect_tiles_no_depth.cu:87)
     ref = rc["depth_map_clamped"]
     ptr = lambda t: C.c_void_p(t.data_ptr())
+    strips = "v_rows" in B
 
-    def fwd():  # the forward the fused step launches (packed-math kernel over the preprocess records)
+    def fwd():  # the forward the fused step launches (packed-math kernel over the preprocess records), without the compose epilogue
         lib.gps_raster_ges_fwd_rec(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]),
                                    ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), sp)
 
     def bwd():
-        lib.gps_raster_ges_bwd_gs(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]),
-                                  ptr(B["radii"]), ptr(ref), W, H, ptr(B["group_gs_ids"]), ptr(B["group_starts"]),
-                                  ptr(B["counts"]), model.delta_depth, ptr(B["v_render_colors"]),
-                                  ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]),
-                                  ptr(B["v_opacities"]), 1, sp)
+        if strips:
+            lib.gps_raster_ges_bwd_strips(N, ptr(B["records"]), ptr(B["radii"]), ptr(B["cls_ids"]), ptr(B["cls_counts"]), st.cls_stride,
+                                          ptr(B["v_render_colors"]), ptr(B["pix2"]), W, H, ptr(B["v_rows"]), sp)
+        else:
+            lib.gps_raster_ges_bwd_gs(N, ptr(B["means2d"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]),
+                                      ptr(B["radii"]), ptr(ref), W, H, ptr(B["group_gs_ids"]), ptr(B["group_starts"]),
+                                      ptr(B["counts"]), model.delta_depth, ptr(B["v_render_colors"]),
+                                      ptr(B["v_render_alphas"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]),
+                                      ptr(B["v_opacities"]), 1, sp)
 
-    def step():
-        model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+    pr = model.opt_gs_params
+    cg = cam.toGPU()
 
-    t_bwd = _time_launches(bwd, 50, stream)
-    t_fwd = _time_launches(fwd, 50, stream)
-    t_iter = _time_launches(step, 20, stream)
-    alg_bwd = 52.0 * ng + 24.0 * P + 40.0 * ng
-    alg_fwd = 44.0 * ni + 4.0 * P + 20.0 * P
-    ach = alg_bwd / t_bwd / 1e9
-    b_iter, terms = iteration_bytes(N, nvis, ni, ng, P, T)
-    V = int(scene.engine.counters().cpu()[2])  # GPS_TSDF_N_VISIBLE of the last fused frame
+    def pre():
+        lib.gps_gauss_preprocess_fwd(N, pr.K, model.degreesToUse, ptr(pr._buf["means"]), ptr(pr._buf["scales"]), ptr(pr._buf["quats"]),
+                                     ptr(pr._buf["opacities"]), ptr(pr._buf["featuresDc"]), ptr(pr._buf["featuresRest"]),
+                                     ptr(cg["viewmat"]), ptr(cg["K"]), ptr(cg["cam_pos"]), W, H, model.eps2d, model.near_plane,
+                                     model.far_plane, model.radius_clip, int(model.max_gs_radii), ptr(B["radii"]), ptr(B["means2d"]),
+                                     ptr(B["depths"]), ptr(B["conics"]), ptr(B["colors"]), ptr(B["opacities"]), ptr(B["records"]), sp)
+
+    def render():  # preprocess (+ histogram) + scan + scatter + forward
+        model._bind_camera(st, cam, rc["depth_map_clamped"], rc["color_map"], None)
+        lib.gps_splat_render(C.byref(st), sp)
+
+    marker = lambda: torch.cuda._sleep(1)   # (tools/profile.sh finds each loop's launches behind its marker)
+    t = {}
+    for name, fn, n in (("bwd", bwd, 50), ("fwd", fwd, 50), ("pre", pre, 50), ("render", render, 50), ("step", step, 20)):
+        marker()
+        t[name] = _time_launches(fn, n, stream)
+    t_bin = max(1e-7, t["render"] - t["pre"] - t["fwd"])          # derived: scan + scatter (+ the histogram's share of preprocess)
+    t_pbwd = max(1e-7, t["step"] - t["render"] - t["bwd"])        # derived: preprocess backward + Adam (+ the compose epilogue)
+    fus = _fusion_timings(seq, gt_pose, device)
+    V = fus["visible_blocks"]
     S = 0x100000 + 0x20000
+    b_iter, terms = iteration_bytes(N, nvis, ni, ng, P, T)
     b_fuse = fusion_bytes(P, V, S)
+    rows = [
+        _kernel_row("raster_ges_bwd_strip_kernel" if strips else "raster_ges_bwd_gs_kernel", 2.0, t["bwd"], 92.0 * ng + 24.0 * P,
+                    hbm_peak_gbs, N, "latency (pixel gathers) / valu"),
+        _kernel_row("raster_ges_fwd_pk_kernel", 2.1, t["fwd"], 44.0 * ni + 28.0 * P, hbm_peak_gbs, N, "valu issue + per-tile tail"),
+        _kernel_row("preprocess_bwd_kernel", 2.0, t_pbwd, 524.0 * nvis + 40.0 * N + 28.0 * 59 * N, hbm_peak_gbs, N, "hbm",
+                    "derived: train step - render - backward rasterizer (includes the forward's compose epilogue)"),
+        _kernel_row("preprocess_fwd_kernel", 2.1, t["pre"], 68.0 * N + 217.0 * nvis, hbm_peak_gbs, N, "hbm"),
+        _kernel_row("binning (sb_scan_kernel + sb_scatter_kernel)", 2.1, t_bin, 24.0 * N + 44.0 * ni + 8.0 * ng + 4.0 * T, hbm_peak_gbs,
+                    N, "launch latency", "derived: render - preprocess - forward rasterizer; bytes = SURVEY's figure for the reference's "
+                    "count + sort + offsets, this implementation writes no key / value arrays"),
+        _kernel_row("raycast_kernel", 1.0, fus["raycast_s"], 20.0 * P, hbm_peak_gbs, N, "latency (dependent gathers along the ray)",
+                    "bytes without the ray term (S-bar is not logged): outputs only"),
+        _kernel_row("integrate_kernel", 1.0, fus["integrate_s"], 8192.0 * V, hbm_peak_gbs, N, "hbm / valu"),
+    ]
+    if fus.get("evals_per_frame"):
+        ev = fus["evals_per_frame"]
+        rows.append(dict(_kernel_row("track_eval_poll_kernel", ev, fus["poll_eval_s"] + fus["poll_spin_s"],
+                                     36.0 * P * 0.332, hbm_peak_gbs, N, "host <-> device loop",
+                                     "avg_us = GPU residency of one pre-launched evaluation = waiting for the host's argument line + "
+                                     "evaluating; bytes assume the evaluations spread evenly over the 4 pyramid levels"),
+                         spin_us=fus["poll_spin_s"] * 1e6, eval_us=fus["poll_eval_s"] * 1e6,
+                         gpu_held_idle_us_per_frame=ev * fus["poll_spin_s"] * 1e6,
+                         tracking_ms_per_frame=fus["tracking_ms_per_frame"]))
+    rows.sort(key=lambda x: -x["us_per_frame"])
+    top = rows[0]
     t_frame = result["ms_per_step"] * 1e-3
     b_frame = 2.0 * b_iter + b_fuse
-    traffic, traffic_note, valu = None, "no PMC file for this scene", None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_raster_bwd.json")
-    if os.path.exists(pmc):
-        try:
-            rec = json.load(open(pmc))
-            u = rec.get("units") or {}
-            if u and abs(u.get("n_groups", 0) - ng) <= 0.01 * ng and abs(u.get("gaussians", 0) - N) <= 0.01 * N:
-                traffic = rec.get("hbm_bytes_per_launch")
-                traffic_note = "profiles/pmc_raster_bwd.json (same scene: N and G within 1 %): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes"
-                valu = rec.get("valu")
-                if valu and valu.get("wave_instructions_per_launch", {}).get("SQ_INSTS_VALU"):
-                    # counter collection serialises and slows the launches (launch_us_same_run); the instruction COUNT is
-                    # what carries over -- priced here against this run's live launch time
-                    valu = dict(valu, issue_frac_live=valu["wave_instructions_per_launch"]["SQ_INSTS_VALU"] * 4.0 /
-                                (1024 * 2.4e9 * t_bwd), launch_us_live=t_bwd * 1e6)
-            else:
-                traffic_note = "profiles/pmc_raster_bwd.json was collected on a different scene (its N, G: %s, %s) -- not reported" % (
-                    u.get("gaussians"), u.get("n_groups"))
-        except (OSError, ValueError):
-            pass
-    return {"bound": "hbm", "kernel": "raster_ges_bwd_gs_kernel", "achieved": ach, "peak": hbm_peak_gbs, "unit": "GB/s",
-            "frac": ach / hbm_peak_gbs, "traffic": traffic, "traffic_note": traffic_note, "valu": valu,
-            "avg_launch_us": t_bwd * 1e6, "algorithmic_bytes": alg_bwd,
-            "units": {"n_groups": ng, "pixels": P, "n_isects": ni, "gaussians": N, "n_visible": nvis, "tiles": T,
-                      "visible_blocks": V},
-            "iteration": {"algorithmic_bytes": b_iter, "terms": terms, "avg_us": t_iter * 1e6,
-                          "achieved_GBs": b_iter / t_iter / 1e9, "frac": b_iter / t_iter / 1e9 / hbm_peak_gbs},
+    return {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_GBs"], "peak": hbm_peak_gbs, "unit": "GB/s",
+            "frac": top["frac"], "traffic": top.get("traffic"), "avg_launch_us": top["avg_us"],
+            "algorithmic_bytes": top["algorithmic_bytes"],
+            "dominant_by": "calls per frame x live average launch time (kernels[] is sorted by it)",
+            "kernels": rows,
+            "units": {"gaussians": N, "n_visible": nvis, "n_isects": ni, "n_groups": ng, "pixels": P, "tiles": T, "visible_blocks": V},
+            "iteration": {"algorithmic_bytes": b_iter, "terms": terms, "avg_us": t["step"] * 1e6,
+                          "achieved_GBs": b_iter / t["step"] / 1e9, "frac": b_iter / t["step"] / 1e9 / hbm_peak_gbs},
             "frame": {"algorithmic_bytes": b_frame, "fusion_bytes_without_ray_term": b_fuse, "ms": t_frame * 1e3,
                       "achieved_GBs": b_frame / t_frame / 1e9, "frac": b_frame / t_frame / 1e9 / hbm_peak_gbs},
-            "note": "rasterization is ALU/LDS-issue bound (exp + ~40 flop per pixel-Gaussian pair), not a stream; the HBM "
-                    "fraction is reported because it is the contract's yardstick",
-            "others": {"raster_ges_fwd_pk_kernel": {"avg_launch_us": t_fwd * 1e6, "algorithmic_bytes": alg_fwd,
-                                                 "achieved_GBs": alg_fwd / t_fwd / 1e9}}}
+            "fusion": {k: v for k, v in fus.items() if k.endswith("_ms_per_frame") or k in ("visible_blocks", "evals_per_frame")},
+            "micro_order": ["bwd", "fwd", "pre", "render", "step", "integrate", "raycast"],
+            "note": "no kernel on this path is a dense contraction (no MFMA); the rasterizers are latency / VALU-issue bound, their HBM "
+                    "fraction is small by construction and is reported because it is the contract's yardstick"}
 
 
-def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
-    return iteration_roofline(scene, seq, result, hbm_peak_gbs, K)
+def _fusion_timings(seq, gt_pose, device, n_sub=12):
+    """TSDF side of the roofline section on a Python twin engine fed the LAST n_sub frames of the sequence (re-based to their
+    first camera): live durations of integrate_kernel and raycast_kernel (HIP events, 20 launches), the untracked and tracked
+    whole-frame times, and the pre-launched tracker evaluations' own profile (gps_track_poll_profile)."""
+    from gps_slam_amd._lib import lib
+    from gps_slam_amd.tsdf_engine import TsdfEngine, pose_from_c2w
+    W, H = seq["W"], seq["H"]
+    n = seq["rgb"].shape[0]
+    lo = max(0, n - n_sub)
+    c0inv = np.linalg.inv(seq["c2w"][lo].astype(np.float64))
+    c2w = [(c0inv @ seq["c2w"][k].astype(np.float64)).astype(np.float32) for k in range(lo, n)]
+    rgba = [torch.as_tensor(np.concatenate([seq["rgb"][k], np.full((H, W, 1), 255, np.uint8)], -1)).to(device) for k in range(lo, n)]
+    dmm = [torch.as_tensor(seq["depth"][k].astype(np.int16)).to(device) for k in range(lo, n)]
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0, device=device)
+    for k in range(len(c2w)):
+        M, invM = eng.ProcessFrame(rgba[k], dmm[k], c2w[k])
+    torch.cuda.synchronize()
+    V = int(eng.counters_host()[2])
+    torch.cuda._sleep(1)
+    t_int = _time_launches(lambda: lib.gps_tsdf_integrate(C.byref(eng.state), M.ctypes.data, sp), 20, stream)
+    torch.cuda._sleep(1)
+    t_ray = _time_launches(lambda: lib.gps_tsdf_raycast(C.byref(eng.state), invM.ctypes.data, 0, 1, sp), 20, stream)
+    k_last = len(c2w) - 1
+    t_frame = _time_launches(lambda: eng.ProcessFrame(rgba[k_last], dmm[k_last], c2w[k_last]), 10, stream)
+    out = {"visible_blocks": V, "integrate_s": t_int, "raycast_s": t_ray, "untracked_ms_per_frame": t_frame * 1e3}
+    if not gt_pose:
+        trk = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0, device=device)
+        trk.turnOnTracking()
+        trk.ProcessFrameTracked(rgba[0], dmm[0])
+        trk.ProcessFrameTracked(rgba[1], dmm[1])
+        torch.cuda.synchronize()
+        prof0 = trk.track_poll_profile()
+        t0 = time.perf_counter()
+        for k in range(2, len(c2w)):
+            trk.ProcessFrameTracked(rgba[k], dmm[k])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / max(1, len(c2w) - 2)
+        prof1 = trk.track_poll_profile()
+        d = [(b - a) & 0xFFFFFFFF for a, b in zip(prof0, prof1)]
+        evals = max(1, d[2])
+        out.update(tracked_ms_per_frame=dt * 1e3, tracking_ms_per_frame=max(0.0, dt - t_frame) * 1e3,
+                   evals_per_frame=d[2] / max(1, len(c2w) - 2), poll_spin_s=d[0] * 1e-8 / (evals + d[3]),
+                   poll_eval_s=d[1] * 1e-8 / evals)
+    return out
 
 
 def render_psnr_vs_oracle(model, cam, rc, seq):

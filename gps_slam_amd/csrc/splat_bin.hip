@@ -462,6 +462,9 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
     int nblkI = gps_div_up(cap > 0 ? cap : 1, SORT_TILE);
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? base + o : nullptr; };
     char* p;
+    // FIRST, at an offset that does not depend on N: the superblock binning's tables are state that lives across launches
+    // (zero between them) while N changes with every add / prune
+    p = take(gps::sb_tables_bytes()); if (w) w->sb_region = p;
     p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->groups_per_gauss = (int32_t*)p;
     p = take((size_t)nblkN * 4); if (w) w->blk_tiles = (int32_t*)p;
     p = take((size_t)nblkN * 4); if (w) w->blk_groups = (int32_t*)p;
@@ -476,7 +479,6 @@ size_t carve(Workspace* w, char* base, int N, int64_t cap) {
     p = take((size_t)(N > 0 ? N : 1) * 4); if (w) w->tiles_by_rank = (int32_t*)p;
     p = take(4 * sizeof(int64_t)); if (w) w->count_n = (int64_t*)p;
     p = take(256); if (w) w->dummy_groups = (int32_t*)p;
-    p = take(gps::sb_tables_bytes()); if (w) w->sb_region = p;
     if (w) { w->nblkN = nblkN; w->nblkI = nblkI; }
     return off;
 }

@@ -49,8 +49,8 @@ struct SbTables {
     uint32_t* C;           // [SB_MAX_TILES][SB_MAX] counts (zero between launches)
     uint32_t* P;           // [SB_MAX_TILES][SB_MAX] exclusive prefixes over superblocks
     uint32_t* tile_total;  // [SB_MAX_TILES]
-    int32_t* cls_count;    // [SB_MAX][8] Gaussians per backward class (zero between launches)
-    int32_t* cls_prefix;   // [SB_MAX][8]
+    int32_t* cls_count;    // [8][SB_MAX] Gaussians per backward class and superblock (zero between launches)
+    int32_t* cls_prefix;   // [8][SB_MAX] exclusive prefixes over superblocks, then a row of the 8 totals
     int sb_shift;          // log2(preprocessing workgroups per superblock)
 };
 __host__ __device__ inline int sb_shift_for(int N) {  // smallest power of two of 256-Gaussian blocks with <= SB_MAX superblocks

@@ -18,11 +18,21 @@ using gps::SbTables;
 using gps::TileBox;
 using gps::tile_bbox;
 
-constexpr int SCAT_THREADS = 256;
+constexpr int SCAT_THREADS = 512;
 constexpr int SCAT_WAVES = SCAT_THREADS / 64;
 constexpr int SCAT_ITEMS = 4;                              // pairs per thread per chunk
 constexpr int SCAT_CHUNK = SCAT_THREADS * SCAT_ITEMS;      // 1024 pairs per chunk
 
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
 __device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
     const int incl = wave_incl_scan_i(v);
     total = __shfl(incl, 63, 64);
@@ -30,7 +40,7 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
 }
 
 // ---- one wave per tile: exclusive prefix of the tile's row of C over the superblocks; C is left zero ----
-__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, int n_sb, int32_t* __restrict__ cls_counts) {
+__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, int32_t* __restrict__ cls_counts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
     static_assert(SB_MAX == 512, "a lane owns 8 consecutive superblocks");
@@ -48,25 +58,31 @@ __global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, i
         prow[0] = pa; prow[1] = pb;
         if (lane == 0) t.tile_total[tile] = (uint32_t)total;
     }
-    // the class counts: the last workgroup's wave k scans class k over the superblocks
-    if (blockIdx.x == gridDim.x - 1 && wave < 4) {
-        for (int k = wave; k < gps::BWD_CLASSES; k += 4) {
-            int run = 0;
-            for (int base = 0; base < n_sb; base += 64) {
-                const int sb = base + lane;
-                const int c = sb < n_sb ? t.cls_count[sb * 8 + k] : 0;
-                int tot;
-                const int e = wave_excl_scan_i(c, tot);
-                if (sb < n_sb) { t.cls_prefix[sb * 8 + k] = run + e; t.cls_count[sb * 8 + k] = 0; }
-                run += tot;
-            }
-            if (lane == 0 && cls_counts) cls_counts[k] = run;
-            if (lane == 0) t.cls_prefix[SB_MAX * 8 + k] = run;   // totals row (n_visible = their sum)
+    // the class counts (row k of cls_count = class k over the superblocks): the rows behind the last tile, one wave each
+    const int k = tile - n_tiles;
+    if (k >= 0 && k < gps::BWD_CLASSES) {
+        int4* crow = reinterpret_cast<int4*>(t.cls_count + (size_t)k * SB_MAX) + 2 * lane;
+        const int4 a = crow[0], b = crow[1];
+        crow[0] = make_int4(0, 0, 0, 0); crow[1] = make_int4(0, 0, 0, 0);
+        const int s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+        int total;
+        int run = wave_excl_scan_i(s, total);
+        int4 pa, pb;
+        pa.x = run; run += a.x; pa.y = run; run += a.y; pa.z = run; run += a.z; pa.w = run; run += a.w;
+        pb.x = run; run += b.x; pb.y = run; run += b.y; pb.z = run; run += b.z; pb.w = run;
+        int4* prow = reinterpret_cast<int4*>(t.cls_prefix + (size_t)k * SB_MAX) + 2 * lane;
+        prow[0] = pa; prow[1] = pb;
+        if (lane == 0) {
+            if (cls_counts) cls_counts[k] = total;
+            t.cls_prefix[8 * SB_MAX + k] = total;   // totals row (n_visible = their sum)
         }
     }
 }
 
 // ---- one workgroup per superblock: stable scatter of its (Gaussian, tile) pairs + the backward's class lists ----
+// Everything that is "per tile" runs over the band of tile rows the superblock's boxes touch (consecutive Gaussians cover
+// neighbouring pixels, so the band is a few rows of the tile grid, not all of it); workgroup 0 takes the whole grid because it
+// also writes tile_offsets.
 __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const int32_t* __restrict__ tiles_per_gauss,
     int tile_size, int tw, int th, SbTables t, int64_t isect_cap, int32_t* __restrict__ flatten_ids,
@@ -74,64 +90,40 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     extern __shared__ uint32_t lds[];
     const int n_tiles = tw * th;
     const int sb = blockIdx.x, sb_size = BIN_BLOCK << t.sb_shift;        // Gaussians per superblock
-    uint32_t* base = lds;                                                 // [n_tiles] absolute start of this superblock's run in every tile
+    uint32_t* base = lds;                                                 // [n_tiles] absolute start of this superblock's run in a tile
     uint16_t* wavecnt = reinterpret_cast<uint16_t*>(lds + n_tiles);       // [SCAT_WAVES][n_tiles] per-wave running counts of a chunk
     uint16_t* tot16 = wavecnt + SCAT_WAVES * n_tiles;                     // [n_tiles] a chunk's pairs per tile
     uint32_t* pre = lds + n_tiles + ((SCAT_WAVES + 1) * n_tiles + 1) / 2; // [sb_size + 1] exclusive prefix of the tile counts
     uint32_t* box = pre + sb_size + 1;                                    // [sb_size] x0 | y0 << 12 | width << 24
-    __shared__ int ws[17];
+    __shared__ int ws[SCAT_WAVES], wlo[SCAT_WAVES], whi[SCAT_WAVES];
     __shared__ int cls_wave[SCAT_WAVES][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g0 = sb * sb_size;
 
-    // tile starts = exclusive scan of the tile totals (every workgroup recomputes it: n_tiles adds), + this superblock's prefix
-    {
-        const int per = (n_tiles + SCAT_THREADS - 1) / SCAT_THREADS;
-        const int lo = min(n_tiles, tid * per), hi = min(n_tiles, lo + per);
-        int sum = 0;
-        for (int b = lo; b < hi; b++) sum += (int)t.tile_total[b];
-        const int incl = wave_incl_scan_i(sum);
-        if (lane == 63) ws[wave] = incl;
-        __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < SCAT_WAVES; w++) { const int v = ws[w]; if (w < wave) woff += v; total += v; }
-        int run = woff + incl - sum;
-        for (int b = lo; b < hi; b++) {
-            if (sb == 0) tile_offsets[b] = (int)min((int64_t)run, isect_cap);
-            base[b] = (uint32_t)run + t.P[(size_t)b * SB_MAX + sb];
-            run += (int)t.tile_total[b];
-        }
-        if (sb == 0 && tid == 0) {
-            int64_t ni = total;
-            if (ni > isect_cap) { ni = isect_cap; counts[2] = 1; }   // sticky overflow word, as the sorted-key path
-            counts[0] = ni; counts[1] = 0;
-            int nv = 0;
-            for (int k = 0; k < gps::BWD_CLASSES; k++) nv += t.cls_prefix[SB_MAX * 8 + k];
-            counts[3] = nv;
-        }
-    }
-    // this superblock's Gaussians: tile counts -> exclusive prefix, boxes; class lists
+    // ---- this superblock's Gaussians: tile counts -> exclusive prefix, boxes, the band of tile rows; class lists
     int running_cls[gps::BWD_CLASSES];
 #pragma unroll
-    for (int k = 0; k < gps::BWD_CLASSES; k++) running_cls[k] = cls_ids ? t.cls_prefix[sb * 8 + k] : 0;
-    int carry = 0;
+    for (int k = 0; k < gps::BWD_CLASSES; k++) running_cls[k] = cls_ids ? t.cls_prefix[k * SB_MAX + sb] : 0;
+    int carry = 0, row_lo = th, row_hi = 0;
     for (int j0 = 0; j0 < sb_size; j0 += SCAT_THREADS) {
         const int j = j0 + tid, g = g0 + j;
+        const bool mine_j = j < sb_size;   // (a superblock can be smaller than the workgroup)
         int tcount = 0, r = 0;
         uint32_t bx = 0;
-        if (g < N) {
+        if (mine_j && g < N) {
             tcount = tiles_per_gauss[g];
             r = radii[g];
             if (tcount > 0) {
                 const float2 m = *reinterpret_cast<const float2*>(means2d + 2 * (size_t)g);
                 const TileBox b = tile_bbox(m.x, m.y, r, tile_size, tw, th);
                 bx = b.x0 | (b.y0 << 12) | ((b.x1 - b.x0) << 24);
+                row_lo = min(row_lo, (int)b.y0); row_hi = max(row_hi, (int)b.y1);
             }
         }
         const int incl = wave_incl_scan_i(tcount);
         __syncthreads();   // (ws / cls_wave of the previous trip consumed)
         if (lane == 63) ws[wave] = incl;
-        const int cls = (g < N && r > 0) ? gps::bwd_class(r) : -1;
+        const int cls = (mine_j && g < N && r > 0) ? gps::bwd_class(r) : -1;
         unsigned long long mine = 0;
 #pragma unroll
         for (int k = 0; k < gps::BWD_CLASSES; k++) {
@@ -142,8 +134,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
         __syncthreads();
         int woff = 0, total = 0;
         for (int w = 0; w < SCAT_WAVES; w++) { const int v = ws[w]; if (w < wave) woff += v; total += v; }
-        pre[j] = (uint32_t)(carry + woff + incl - tcount);
-        box[j] = bx;
+        if (mine_j) { pre[j] = (uint32_t)(carry + woff + incl - tcount); box[j] = bx; }
         carry += total;
         if (cls_ids) {
 #pragma unroll
@@ -155,17 +146,60 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
             }
         }
     }
+    const int n_pairs = carry;
+    row_lo = wave_min_i(row_lo); row_hi = wave_max_i(row_hi);
+    __syncthreads();
+    if (lane == 0) { wlo[wave] = row_lo; whi[wave] = row_hi; }
     if (tid == 0) pre[sb_size] = (uint32_t)carry;
     __syncthreads();
-    const int n_pairs = carry;
-    // chunks of SCAT_CHUNK pairs in Gaussian order; wave w owns pairs [256 w, 256 w + 256) of a chunk, visited iteration-major,
-    // lane-minor: "earlier pair, same tile" == stable rank (as wide_scatter_kernel of splat_bin.hip)
+    for (int w = 0; w < SCAT_WAVES; w++) { row_lo = min(row_lo, wlo[w]); row_hi = max(row_hi, whi[w]); }
+    int t_lo = sb == 0 ? 0 : min(row_lo, row_hi) * tw, t_hi = sb == 0 ? n_tiles : row_hi * tw;   // the band [t_lo, t_hi)
+    if (t_hi < t_lo) t_hi = t_lo;
+    const int nt = t_hi - t_lo;
+    if (n_pairs == 0 && sb != 0) return;
+
+    // ---- tile starts of the band = (sum of the tile totals in front of it) + exclusive scan inside it, + this superblock's prefix
+    {
+        int before = 0;
+        for (int b = tid; b < t_lo; b += SCAT_THREADS) before += (int)t.tile_total[b];
+        const int per = (nt + SCAT_THREADS - 1) / SCAT_THREADS;
+        const int lo = min(nt, tid * per), hi = min(nt, lo + per);
+        int sum = 0;
+        for (int b = lo; b < hi; b++) sum += (int)t.tile_total[t_lo + b];
+        const int incl = wave_incl_scan_i(sum);
+        before = wave_sum_i(before);
+        __syncthreads();
+        if (lane == 63) ws[wave] = incl;
+        if (lane == 0) wlo[wave] = before;
+        __syncthreads();
+        int woff = 0, total = 0, front = 0;
+        for (int w = 0; w < SCAT_WAVES; w++) { const int v = ws[w]; if (w < wave) woff += v; total += v; front += wlo[w]; }
+        int run = front + woff + incl - sum;
+        for (int b = lo; b < hi; b++) {
+            if (sb == 0) tile_offsets[b] = (int)min((int64_t)run, isect_cap);
+            base[b] = (uint32_t)run + t.P[(size_t)(t_lo + b) * SB_MAX + sb];
+            run += (int)t.tile_total[t_lo + b];
+        }
+        if (sb == 0 && tid == 0) {
+            int64_t ni = total;   // (band = the whole grid)
+            if (ni > isect_cap) { ni = isect_cap; counts[2] = 1; }   // sticky overflow word, as the sorted-key path
+            counts[0] = ni; counts[1] = 0;
+            int nv = 0;
+            for (int k = 0; k < gps::BWD_CLASSES; k++) nv += t.cls_prefix[8 * SB_MAX + k];
+            counts[3] = nv;
+        }
+    }
+    // ---- chunks of SCAT_CHUNK pairs in Gaussian order; wave w owns pairs [256 w, 256 w + 256) of a chunk, visited
+    // iteration-major, lane-minor: "earlier pair, same tile" == stable rank (as wide_scatter_kernel of splat_bin.hip)
     int bits = 1;
-    while ((1 << bits) < n_tiles) bits++;
+    while ((1 << bits) < max(nt, 2)) bits++;
     const unsigned long long lt = lanemask_lt();
     uint16_t* mycnt = wavecnt + wave * n_tiles;
     for (int c0 = 0; c0 < n_pairs; c0 += SCAT_CHUNK) {
-        for (int k = tid; k < SCAT_WAVES * n_tiles; k += SCAT_THREADS) wavecnt[k] = 0;
+        for (int k = tid; k < nt; k += SCAT_THREADS) {
+#pragma unroll
+            for (int w = 0; w < SCAT_WAVES; w++) wavecnt[w * n_tiles + k] = 0;
+        }
         __syncthreads();
         uint32_t tile[SCAT_ITEMS], gid[SCAT_ITEMS], rank[SCAT_ITEMS];
 #pragma unroll
@@ -175,14 +209,14 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
             uint32_t d = 0;
             gid[k] = 0;
             if (valid) {
-                int lo = 0, hi = sb_size;   // largest j with pre[j] <= p (pairs of Gaussians without tiles have equal prefixes: take the last)
+                int lo = 0, hi = sb_size;   // largest j with pre[j] <= p (Gaussians without tiles have equal prefixes: take the last)
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)pre[mid] <= p) lo = mid; else hi = mid; }
                 const uint32_t b = box[lo];
                 const uint32_t w = b >> 24, q = (uint32_t)(p - (int)pre[lo]);
-                d = ((b >> 12) & 0xfffu) * (uint32_t)tw + (b & 0xfffu) + (q / w) * (uint32_t)tw + q % w;
+                d = ((b >> 12) & 0xfffu) * (uint32_t)tw + (b & 0xfffu) + (q / w) * (uint32_t)tw + q % w - (uint32_t)t_lo;
                 gid[k] = (uint32_t)(g0 + lo);
             }
-            tile[k] = d;
+            tile[k] = d;   // tile id inside the band
             unsigned long long same = __ballot(valid);
             for (int bb = 0; bb < bits; bb++) {
                 const unsigned long long bal = __ballot(valid && ((d >> bb) & 1u));
@@ -194,9 +228,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        // per tile: exclusive prefix over the waves, the chunk's total
-        for (int b = tid; b < n_tiles; b += SCAT_THREADS) {
+        // per tile of the band: exclusive prefix over the waves, the chunk's total
+        for (int b = tid; b < nt; b += SCAT_THREADS) {
             uint32_t acc = 0;
+#pragma unroll
             for (int w = 0; w < SCAT_WAVES; w++) { const uint32_t c = wavecnt[w * n_tiles + b]; wavecnt[w * n_tiles + b] = (uint16_t)acc; acc += c; }
             tot16[b] = (uint16_t)acc;
         }
@@ -210,9 +245,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
                 if (pos < isect_cap) flatten_ids[pos] = (int32_t)gid[k];
             }
         }
-        __syncthreads();
-        // the next chunk's pairs of a tile go behind this chunk's
-        for (int b = tid; b < n_tiles; b += SCAT_THREADS) base[b] += tot16[b];
+        if (c0 + SCAT_CHUNK < n_pairs) {   // the next chunk's pairs of a tile go behind this chunk's
+            __syncthreads();
+            for (int b = tid; b < nt; b += SCAT_THREADS) base[b] += tot16[b];
+        }
     }
 }
 
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
 namespace gps {
 
 size_t sb_tables_bytes() {
-    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * 8 * 4 * 2 + 1024;
+    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * 8 * 4 * 2 + 2048;
 }
 
 void sb_tables_carve(char* base, SbTables* t) {
@@ -247,7 +283,7 @@ int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, co
     const int n_sb = (nblk + (1 << cnt.sb.sb_shift) - 1) >> cnt.sb.sb_shift;
     GPS_REQUIRE(n_sb <= SB_MAX);
     hipStream_t s = (hipStream_t)stream;
-    sb_scan_kernel<<<gps_div_up(n_tiles, 4), 256, 0, s>>>(n_tiles, cnt.sb, n_sb, cls_counts);
+    sb_scan_kernel<<<gps_div_up(n_tiles + BWD_CLASSES, 4), 256, 0, s>>>(n_tiles, cnt.sb, cls_counts);
     const int sb_size = BIN_BLOCK << cnt.sb.sb_shift;
     const size_t lds = ((size_t)n_tiles + ((SCAT_WAVES + 1) * (size_t)n_tiles + 1) / 2 + 2 * (size_t)sb_size + 2) * 4;
     GPS_REQUIRE(lds <= 160 * 1024);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
 #pragma unroll
         for (int k = 0; k < BWD_CLASSES; k++) {
             const unsigned long long m = __ballot(cls == k);
-            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt.sb.cls_count[sb * 8 + k], (int)__popcll(m));
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt.sb.cls_count[k * SB_MAX + sb], (int)__popcll(m));
         }
     }
 }

@@ -290,11 +290,14 @@ __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
 // Against the ticket version this takes three memory-side round trips out of every iteration's dependent chain (row
 // acknowledgement, ticket, mailbox acknowledgement); under the map stream's memory traffic each of them was ~2-3 us.
 __device__ __forceinline__ int chunk_word(int d) { return d + d / 15; }
+// words of the 16-word `sync` block besides [0] ticket and [1], [2] valid-pixel counts: the pre-launched evaluation's profile
+constexpr int SYNC_SPIN_TICKS = 8, SYNC_EVAL_TICKS = 9, SYNC_EVALS = 10, SYNC_SKIPPED = 11;
 constexpr long long ROW_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
 
 template <int ITER>
 __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
-                                          float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
+                                          float* __restrict__ result, volatile float* mailbox, int seq, int parity,
+                                          long long t_arrived = -1) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ, NQ = (NV + 3) / 4;
     static_assert(NV <= 29, "29 sums + the valid-pixel count fill the two 15-word chunks");
     __shared__ float red[EV_THREADS / 64][GH_SLOTS];
@@ -385,6 +388,9 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
         }
         result[tid] = __uint_as_float(wv);  // (device copy, same layout: the host_mailbox == NULL path reads it back)
         if (mailbox) reinterpret_cast<volatile uint32_t*>(mailbox)[tid] = wv;  // one store instruction: two 64-byte chunks
+        // profile words (gps_track_poll_profile): wall-clock ticks between the arrival of this launch's argument line and its
+        // result leaving, and the number of evaluations.  Launches of a stream run one after the other: plain read-modify-write
+        if (tid == 0 && t_arrived >= 0) { sync[SYNC_EVAL_TICKS] += (uint32_t)(wall_clock64() - t_arrived); sync[SYNC_EVALS] += 1u; }
     }
 }
 
@@ -426,6 +432,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
                                                                    uint32_t* __restrict__ sync, float* __restrict__ result,
                                                                    volatile float* mailbox, int seq, int parity) {
     __shared__ uint32_t line[16];
+    __shared__ long long t_arrived;
     if (threadIdx.x < 16) {
         // Workgroup 0 polls the host line and relays it through a device-memory copy the other workgroups poll: with all 256
         // workgroups reading the host line across PCIe, the CPU's store waited ~20 us for ownership of its own cache line
@@ -451,6 +458,12 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
             __builtin_amdgcn_s_sleep(1);
         }
         line[threadIdx.x] = v;
+        if (threadIdx.x == 0) {
+            // how long this launch sat on the GPU waiting for the host's decision (workgroup 0: the one that polls the host line)
+            const long long now = wall_clock64();
+            t_arrived = now;
+            if (relay) sync[SYNC_SPIN_TICKS] += (uint32_t)(now - t0);
+        }
         if (relay) {  // payload, wait for the acknowledgement (sc1 stores), then the sequence number
             if (threadIdx.x != 0) __hip_atomic_store(pa.dev_line + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -466,6 +479,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
         if (blockIdx.x == 0 && threadIdx.x == 0 && mailbox)
             __hip_atomic_store(reinterpret_cast<uint32_t*>(const_cast<float*>(mailbox)) + 32, (uint32_t)seq, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && threadIdx.x == 0) sync[SYNC_SKIPPED] += 1u;
         return;
     }
     const int kind = (int)((ctl >> 8) & 0xFF), level = (int)((ctl >> 16) & 0xFF);
@@ -489,9 +503,10 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
     a.scenePose = pa.scenePose;
     a.space_thresh = lt.space_thresh; a.tukey_cutoff = pa.tukey_cutoff; a.vf_min = pa.vf_min; a.vf_max = pa.vf_max;
     a.use_weights = pa.use_weights; a.frames_to_skip = pa.frames_to_skip; a.frames_to_weight = pa.frames_to_weight;
-    if (kind == TRK_ROTATION) eval_body<TRK_ROTATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity);
-    else if (kind == TRK_TRANSLATION) eval_body<TRK_TRANSLATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity);
-    else eval_body<TRK_BOTH>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity);
+    const long long ta = blockIdx.x == 0 ? t_arrived : -1;
+    if (kind == TRK_ROTATION) eval_body<TRK_ROTATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity, ta);
+    else if (kind == TRK_TRANSLATION) eval_body<TRK_TRANSLATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity, ta);
+    else eval_body<TRK_BOTH>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity, ta);
 }
 
 // ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
@@ -614,6 +629,15 @@ int gps_track_state_reset(gps_track_state* ts) {
     for (int i = 0; i < 16; i += 5) ts->pose_M[i] = ts->pose_invM[i] = ts->pose_pc_M[i] = 1.0f;
     ts->age_point_cloud = -1;
     return GPS_OK;
+}
+
+int gps_track_poll_profile(const void* scratch, int width, int height, uint32_t out[4], gps_stream stream) {
+    if (!scratch || !out || width <= 0 || height <= 0) return GPS_ERR_ARG;
+    Scratch w;
+    carve(&w, (char*)const_cast<void*>(scratch), width, height);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(out, w.sync + SYNC_SPIN_TICKS, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+    return hipStreamSynchronize(st) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
 int64_t gps_track_scratch_bytes(int width, int height) {

@@ -10,6 +10,8 @@ Host plumbing that the reference does with libtorch ops (masked_select / randper
 boolean-mask compaction in prunePoints) is done with the same torch ops here.
 """
 import math
+import os
+import sys
 
 import torch
 

@@ -163,6 +163,7 @@ PYBIND11_MODULE(_host, m) {
             for (int i = 0; i < 16; i++) t[i] = e.trackState().diag[i];
             return t;
         })
+        .def("trackPollProfile", &TsdfEngine::trackPollProfile)
         .def("ProcessFrame", [](TsdfEngine& e, const torch::Tensor& rgb, const torch::Tensor& depth) {
             e.ProcessFrame(rgb, depth);
         })

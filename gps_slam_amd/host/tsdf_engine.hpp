@@ -195,6 +195,15 @@ public:
                         float outlierSpaceF = 0.004f, float minstep = 1e-4f, float tukeyCutOff = 8.0f, int framesToSkip = 20,
                         int framesToWeight = 50);
     const gps_track_state& trackState() const { return track_state_; }
+    // gps_track_poll_profile of this engine's tracker scratch (blocking; measurement only): {ticks waiting for the host's
+    // argument line, ticks evaluating, evaluations, launches retired unused}, cumulative, 100 MHz ticks
+    std::vector<int64_t> trackPollProfile() const {
+        uint32_t out[4] = {0, 0, 0, 0};
+        if (track_scratch_.defined())
+            gpsh::check(gps_track_poll_profile(track_scratch_.data_ptr(), state_.width, state_.height, out, gpsh::current_stream()),
+                        "gps_track_poll_profile");
+        return {out[0], out[1], out[2], out[3]};
+    }
 
     // One-shot hook for the next ProcessFrame: called on the calling thread after the frame's tracking and before its fusion
     // (gps_tsdf_process_frame_tracked_gated); with given poses it runs right before the fusion kernels are enqueued.

@@ -141,6 +141,13 @@ class TsdfEngine:
         self.frames_processed += 1
         return M, invM
 
+    def track_poll_profile(self):
+        """gps_track_poll_profile of this engine's tracker scratch -> [spin ticks, evaluation ticks, evaluations, retired launches]
+        (cumulative, 100 MHz ticks; blocking read-back: measurement only)"""
+        out = (C.c_uint32 * 4)()
+        check(lib.gps_track_poll_profile(self.track_scratch.data_ptr(), self.W, self.H, out, self._stream()), "gps_track_poll_profile")
+        return [int(v) for v in out]
+
     def track_diag(self):
         return np.array(self.track_state.diag, dtype=np.float32)
 

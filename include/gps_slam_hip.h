@@ -676,6 +676,10 @@ GPS_API int gps_track_state_reset(gps_track_state *ts);
 
 /* Device scratch (depth pyramid levels >= 1, reduction partials) for images of this size. */
 GPS_API int64_t gps_track_scratch_bytes(int width, int height);
+/* Test / measurement hook: cumulative profile of the pre-launched evaluation kernels since the scratch block was last zeroed
+ * (blocking read-back): out = { wall-clock ticks (100 MHz) launches spent on the GPU WAITING for the host's argument line,
+ * ticks between the line's arrival and the result leaving (the evaluation proper), evaluations run, launches retired unused }. */
+GPS_API int gps_track_poll_profile(const void *scratch, int width, int height, uint32_t out[4], gps_stream stream);
 
 /* ITMExtendedTracker::TrackCamera (useDepth, !useColour): refines ts->pose_M / pose_invM against the ICP maps of the last
  * raycast (s->icp_points / s->icp_normals, rendered from ts->pose_pc_M) using s->depth.

@@ -131,3 +131,40 @@ def test_knn_and_normal_map_match_torch_formulations():
     n = n / (torch.norm(n, 2, -1, True) + 1e-8)
     n = torch.where((v[:, :, 2] <= 0).unsqueeze(-1), torch.zeros_like(n), n)
     torch.testing.assert_close(got, n, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_binning_and_class_lists_survive_add_and_prune():
+    """The fused iteration's superblock binning keeps tables in the caller's workspace ACROSS launches (zero between them)
+    while the Gaussian count changes with every prune / add: after each change the tile lists, tile offsets and the backward's
+    class lists must still be the oracle's for the state of that launch."""
+    from oracle import splat_ref as orc
+    model, cam, ref, base, gt = _model_and_maps()
+    model.initOptimizers(-1, 1.0)
+    W, H = cam.width, cam.height
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    g = torch.Generator().manual_seed(3)
+    removed = None
+    for round_ in range(4):
+        model.train_step(cam, ref, base, gt)
+        torch.cuda.synchronize()
+        B, N = model._B, model.getGaussianNum()
+        m2, r = B["means2d"][:N].cpu().numpy(), B["radii"][:N].cpu().numpy()
+        tpg, ids, flat, ggs, gst, offs = orc.isect_tiles(m2, r, 16, tw, th)
+        counts = B["counts"].cpu().numpy()
+        assert int(counts[0]) == flat.shape[0] and int(counts[2]) == 0 and int(counts[3]) == int((r > 0).sum()), (round_, counts)
+        assert np.array_equal(B["flatten_ids"][:flat.shape[0]].cpu().numpy(), flat), round_
+        assert np.array_equal(B["tile_offsets"].cpu().numpy(), offs.reshape(-1)), round_
+        cls = np.where(r > 0, np.searchsorted(np.array([4, 8, 16, 32]), r, side="left"), -1)
+        cc = B["cls_counts"].cpu().numpy()
+        for k in range(5):
+            want = np.nonzero(cls == k)[0]
+            assert int(cc[k]) == want.shape[0] and np.array_equal(B["cls_ids"][k, :want.shape[0]].cpu().numpy(), want), (round_, k)
+        p = model.opt_gs_params
+        if round_ % 2 == 0:   # prune a random third ...
+            mask = (torch.rand(N, generator=g) < 0.33).to(DEV)
+            removed = {n: getattr(p, n)[mask].clone() for n in p.NAMES}
+            model.prunePoints(mask)
+            assert model.getGaussianNum() < N
+        else:                 # ... and put them back behind the rest
+            model.add_params(removed)
+            assert model.getGaussianNum() == N + removed["means"].shape[0]

@@ -5,11 +5,13 @@ the start and end of every timed region and once more before its measurement sca
 micro-benchmark).  Kernels are assigned to the phase whose markers bracket their start time:
 
     setup            scene construction, priming run, prologue + warm-up frames of the first schedule
-    timed:<k>        the k-th timed region (sequential, then overlap when both schedules run) -- the SLAM frames `value` counts
+    timed            the timed windows -- the SLAM frames `value` counts.  bench.py times --windows consecutive windows per
+                     schedule (sequential, then overlap when both run): with --windows NW the NW windows of a schedule are
+                     summarised as ONE table (the per-frame column divides by NW x K frames)
     between          warm-up frames of the next schedule
     scaffolding      split pass + micro-benchmarks (not SLAM frames)
 
-usage: prof_summary.py <db> [rows] [--frames K]   (K = --steps of the profiled run: adds a per-frame column)
+usage: prof_summary.py <db> [rows] [--frames K] [--windows NW]   (K = --steps of the profiled run: adds a per-frame column)
 """
 import re
 import sqlite3
@@ -45,6 +47,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     top = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 40
     frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else None
+    nw = int(sys.argv[sys.argv.index("--windows") + 1]) if "--windows" in sys.argv else 1
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     marks = [s for n, s, e in rows if "spin_kernel" in n]
     body = [(n, s, e) for n, s, e in rows if "spin_kernel" not in n]
@@ -52,27 +55,38 @@ def main():
         print("(no phase markers in this trace: whole run)")
         table([(n, e - s) for n, s, e in body], top)
         return
-    # markers come in (start, end) pairs per timed region, then one scaffolding marker
-    n_timed = (len(marks) - 1) // 2 if len(marks) % 2 else len(marks) // 2
-    phases = []
-    for k in range(n_timed):
-        phases.append(("timed:%d" % k, marks[2 * k], marks[2 * k + 1]))
+    # markers come in (start, end) pairs per timed window: nw windows per schedule, 1 or 2 schedules; then one scaffolding marker
+    # followed by one marker in front of every micro-benchmark loop
+    n_sched = 2 if len(marks) >= 4 * nw + 1 else 1
+    n_timed = nw * n_sched
+    if len(marks) < 2 * n_timed:
+        n_timed, n_sched, nw = len(marks) // 2, 1, len(marks) // 2
+    names = ("sequential", "overlap") if n_sched == 2 else ("timed",)
+    for sidx in range(n_sched):
+        sel, span = [], 0
+        for k in range(sidx * nw, (sidx + 1) * nw):
+            lo, hi = marks[2 * k], marks[2 * k + 1]
+            sel += [(n, e - s) for n, s, e in body if lo <= s < hi]
+            span += hi - lo
+        print("\n### schedule %s: %d timed window(s), %.3f ms between their markers\n" % (names[sidx], nw, span / 1e6))
+        table(sel, top, frames * nw if frames else None)
     scaffold_from = marks[2 * n_timed] if len(marks) > 2 * n_timed else None
-    for name, lo, hi in phases:
-        sel = [(n, e - s) for n, s, e in body if lo <= s < hi]
-        print("\n### phase %s  (%.3f ms between the markers)\n" % (name, (hi - lo) / 1e6))
-        table(sel, top, frames)
     if scaffold_from is not None:
         sel = [(n, e - s) for n, s, e in body if s >= scaffold_from]
         print("\n### phase scaffolding (fusion-only split pass + roofline micro-benchmarks; NOT SLAM frames)\n")
         table(sel, 12)
-        for kname in ("raster_ges_bwd_gs_kernel", "raster_ges_fwd_pk_kernel"):
-            d = [e - s for n, s, e in body if s >= scaffold_from and kname in n]
-            if len(d) >= 50:
-                tail = d[1:51] if kname == "raster_ges_bwd_gs_kernel" else d[-50 - 21:-21] if len(d) >= 71 else d[-50:]
-                print("%s: the micro-benchmark's 50 launches avg %.2f us (min %.2f, max %.2f) -- bench.py's roofline.avg_launch_us must agree"
-                      % (kname, sum(tail) / len(tail) / 1e3, min(tail) / 1e3, max(tail) / 1e3))
-
+        micro = marks[2 * n_timed + 1:]
+        for j, lo in enumerate(micro):
+            hi = micro[j + 1] if j + 1 < len(micro) else (1 << 62)
+            loop = {}
+            for n, s0, e in body:
+                if lo <= s0 < hi:
+                    loop.setdefault(short(n), []).append(e - s0)
+            if loop:
+                k, d = max(loop.items(), key=lambda kv: sum(kv[1]))
+                d = d[1:] if len(d) > 1 else d
+                print("micro-benchmark loop %d: %s x %d, avg %.2f us (min %.2f, max %.2f) -- the bench line's live average must agree"
+                      % (j, k[:60], len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3))
 
 if __name__ == "__main__":
     main()
