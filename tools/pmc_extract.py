@@ -19,7 +19,7 @@ TARGETS = {
     "fwd": [("raster_ges_fwd_pk_kernel", ["raster_ges_fwd_pk_kernel"])],
     "pre": [("preprocess_fwd_kernel", ["preprocess_fwd_kernel"])],
     "render": [("binning (sb_scan_kernel + sb_scatter_kernel)", ["sb_scan_kernel", "sb_scatter_kernel"])],
-    "step": [("preprocess_bwd_kernel", ["preprocess_bwd_kernel"])],
+    "pbwd": [("preprocess_bwd_kernel", ["preprocess_bwd_kernel"])],
     "integrate": [("integrate_kernel", ["integrate_kernel"])],
     "raycast": [("raycast_kernel", ["raycast_kernel"])],
 }
