@@ -25,6 +25,7 @@
 // the binning; 64 / GW Gaussians per wave task.
 #include "common.hpp"
 #include "splat_bin.hpp"
+#include "splat_math.hpp"
 
 namespace {
 
@@ -284,6 +285,21 @@ __global__ __launch_bounds__(256) void pair_image_kernel(int P, const float* __r
     if (i < P) pix2[i] = make_float2(v_render_alphas[i], ref_depth[i] + delta_depth);
 }
 
+// the 48-byte records of gps_gauss_preprocess_fwd from the operator-level arrays (for callers that hold those, not records)
+__global__ __launch_bounds__(256) void pack_records_kernel(int N, const float2* __restrict__ means2d, const float* __restrict__ conics,
+                                                          const float4* __restrict__ colors, const float* __restrict__ opacities,
+                                                          const int32_t* __restrict__ radii, float4* __restrict__ recs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    gps::Proj o;
+    const float2 m = means2d[i];
+    const float4 c = colors[i];
+    o.mx = m.x; o.my = m.y; o.z = c.w;
+    o.ca = conics[3 * i]; o.cb = conics[3 * i + 1]; o.cc = conics[3 * i + 2];
+    o.radius = radii[i];
+    gps::pack_record(o, c.x, c.y, c.z, opacities[i], recs + 3 * (size_t)i);
+}
+
 }  // namespace
 
 namespace gps {
@@ -314,6 +330,18 @@ int gps_raster_ges_bwd_strips(int N, const float* records, const int32_t* radii,
                               int width, int height, float* v_rows, gps_stream stream) {
     return gps::raster_ges_bwd_strips_launch(N, records, radii, cls_ids, cls_counts, cls_stride, v_render_colors, pix2, width,
                                              height, v_rows, stream);
+}
+
+int gps_raster_pack_records(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
+                            const int32_t* radii, float* records, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(N >= 0);
+    if (N == 0) return GPS_OK;
+    GPS_REQUIRE(means2d && conics && colors && opacities && radii && records);
+    pack_records_kernel<<<gps_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(N, (const float2*)means2d, conics, (const float4*)colors,
+                                                                            opacities, radii, (float4*)records);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
 }
 
 int gps_raster_pair_image(int width, int height, const float* v_render_alphas, const float* ref_depth_map, float delta_depth,

@@ -221,6 +221,54 @@ def rasterize_to_pixels_bwd_ges_gs_parallel(means2d, conics, colors, opacities, 
     return v_m, v_c, v_col, v_o
 
 
+def rasterize_to_pixels_bwd_ges_strips(means2d, conics, colors, opacities, radii, ref_depth_map, width, height, delta_depth,
+                                       v_render_colors, v_render_alphas):
+    """The same operator through the kernel the fused train step runs (gps_raster_ges_bwd_strips: column strips, one 48-byte
+    gradient row per Gaussian, no group table): records, the {v_alpha, depth cut} pair image and the class lists are built here
+    from the operator-level arrays (the train step's binning writes them on the device; this wrapper, used by the parity tests,
+    orders the lists with torch).  Same outputs as rasterize_to_pixels_bwd_ges_gs_parallel; untouched rows are zero."""
+    means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
+    ref_depth_map, v_render_colors, v_render_alphas = _f32c(ref_depth_map), _f32c(v_render_colors), _f32c(v_render_alphas)
+    radii = radii.contiguous().view(-1)
+    N, dev = opacities.numel(), means2d.device
+    recs = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)
+    check(lib.gps_raster_pack_records(N, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(radii), _ptr(recs), _stream()),
+          "gps_raster_pack_records")
+    pix2 = torch.empty((height * width, 2), dtype=torch.float32, device=dev)
+    check(lib.gps_raster_pair_image(width, height, _ptr(v_render_alphas), _ptr(ref_depth_map), delta_depth, _ptr(pix2), _stream()),
+          "gps_raster_pair_image")
+    cls = torch.full((N,), -1, dtype=torch.long, device=dev)
+    vis = radii > 0
+    cls[vis] = torch.bucketize(radii[vis].long(), torch.tensor([4, 8, 16, 32], device=dev), right=False)
+    ids = torch.zeros((5, max(N, 1)), dtype=torch.int32, device=dev)
+    counts = torch.zeros(8, dtype=torch.int32, device=dev)
+    for k in range(5):
+        sel = torch.nonzero(cls == k)[:, 0].int()
+        ids[k, :sel.numel()] = sel
+        counts[k] = sel.numel()
+    rows = torch.zeros((max(N, 1), 12), dtype=torch.float32, device=dev)
+    check(lib.gps_raster_ges_bwd_strips(N, _ptr(recs), _ptr(radii), _ptr(ids), _ptr(counts), max(N, 1), _ptr(v_render_colors), _ptr(pix2),
+                                        width, height, _ptr(rows), _stream()), "gps_raster_ges_bwd_strips")
+    rows = rows[:N]
+    return (rows[:, 7:9].reshape(means2d.shape).contiguous(), rows[:, 4:7].reshape(conics.shape).contiguous(),
+            rows[:, 0:4].reshape(colors.shape).contiguous(), rows[:, 9].reshape(opacities.shape).contiguous())
+
+
+def rasterize_to_pixels_bwd_ges_exact(means2d, conics, colors, opacities, ref_depth_map, width, height, tile_size, isect, delta_depth,
+                                      v_render_colors, v_render_alphas):
+    """gsplat::rasterize_to_pixels_bwd_ges_tensor (rasterize_to_pixels_bwd_ges.cu:164-291): the exact tile-parallel adjoint of the
+    ges forward -> v_means2d, v_conics, v_colors, v_opacities"""
+    means2d, conics, colors, opacities = _f32c(means2d), _f32c(conics), _f32c(colors), _f32c(opacities)
+    ref_depth_map, v_render_colors, v_render_alphas = _f32c(ref_depth_map), _f32c(v_render_colors), _f32c(v_render_alphas)
+    N = opacities.numel()
+    out = (torch.empty_like(means2d), torch.empty_like(conics), torch.empty_like(colors), torch.empty_like(opacities))
+    check(lib.gps_raster_ges_bwd_exact(N, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(ref_depth_map), width, height,
+                                       tile_size, _ptr(isect.isect_offsets), _ptr(isect.flatten_ids), _ptr(isect.counts), delta_depth,
+                                       _ptr(v_render_colors), _ptr(v_render_alphas), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
+                                       _stream()), "gps_raster_ges_bwd_exact")
+    return out
+
+
 # ----------------------------------------------------------------------------- compose + loss, Adam
 def compose_l1(render_colors, weight_sum, base_color, ref_depth_raw, gt_rgb, need_grad=True, need_depth=True):
     """Fused raw_gs_model.cpp:318-326 + computeLoss (:369-417, L1 only) + backward.

@@ -409,14 +409,25 @@ std::vector<TensorDict> SLAMPipeline::renderEvalImgs(const std::vector<Camera>& 
         auto rc = runRaycastByCam(cam, false);
         r["raycast_color"] = rc.at("color_map");
         r["raycast_depth"] = rc.at("depth_map");
+        // what the reference writes to disk, as it quantises it (cv_utils.cpp:57-76 tensorToImage: (t * 255.0).toType(kU8),
+        // truncation; :79-101 tensorToDepth: convertTo(CV_16UC1, 1000) = saturate_cast<ushort>(round-half-even(d * 1000)))
+        r["raycast_color_u8"] = (r["raycast_color"] * 255.0).toType(torch::kUInt8);
+        r["raycast_depth_u16"] = torch::round(r["raycast_depth"] * 1000.0f).clamp(0.0, 65535.0).to(torch::kInt32);
+        if (cam.image.defined()) r["gt_u8"] = (cam.image.to(device) * 255.0).toType(torch::kUInt8);
         if (model->getGaussianNum() > 0) {
             auto res = model->forward(cam, rc.at("depth_map"), rc.at("color_map"));
             for (const std::string& name : names) {
                 if (name == "rgb") {
                     r["rgb"] = torch::clamp(res.at("rgb"), 0, 1);
+                    r["rgb_u8"] = (r["rgb"] * 255.0).toType(torch::kUInt8);   // render/<frame>.color.jpg before the JPEG encoder
                     if (cam.image.defined()) {
                         auto mse = torch::mean(torch::square(r["rgb"] - cam.image.to(device)));
                         r["psnr"] = -10.0 * torch::log10(mse);
+                        // the number the reference reports: scripts/metric.py reads the 8-bit render / gt files back as
+                        // u8 / 255 (to_tensor) and takes 20 log10(1 / sqrt(mse)) (scripts/utils/image_utils.py:19-21); the lossy
+                        // JPEG encoder in between is I/O outside this library
+                        auto a = r["rgb_u8"].to(torch::kFloat32) / 255.0f, b = r["gt_u8"].to(torch::kFloat32) / 255.0f;
+                        r["psnr_u8"] = 20.0 * torch::log10(1.0 / torch::sqrt(torch::mean(torch::square(a - b))));
                     }
                 } else if (name == "alpha" || name == "depth") {
                     r[name] = res.at(name).clone();

@@ -79,7 +79,10 @@ public:
     // renderEvalImgs (slam_pipeline.cpp:588-695), the compute half: for every camera the free-view raycast with the stored pose
     // and, if the model is not empty, forward() under NoGradGuard.  Returns per camera the tensors the reference turns into
     // image files with OpenCV ("raycast_color", "raycast_depth" and, per requested name, "rgb" clamped to [0,1], "alpha",
-    // "depth") plus "psnr" (run/read_results.py's metric) -- the JPEG/PNG writing itself is I/O outside this library.
+    // "depth") plus "psnr" -- and the same images AS THE REFERENCE QUANTISES THEM for its files: "rgb_u8", "gt_u8",
+    // "raycast_color_u8" ((t * 255.0).toType(kU8), cv_utils.cpp:57-76), "raycast_depth_u16" (millimetres, cv_utils.cpp:79-101)
+    // and "psnr_u8" = scripts/metric.py's PSNR of the 8-bit render against the 8-bit ground truth.  The JPEG / PNG encoders
+    // themselves are I/O outside this library.
     std::vector<TensorDict> renderEvalImgs(const std::vector<Camera>& cams, const std::vector<std::string>& names = {"rgb"});
 
     // slam_pipeline.h:32-49: mesh / engine state files under workspace_dir (empty names are skipped like the reference)

@@ -156,6 +156,10 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
 GPS_API int gps_raster_ges_bwd_strips(int N, const float *records, const int32_t *radii, const int32_t *cls_ids,
                                       const int32_t *cls_counts, int cls_stride, const float *v_render_colors,
                                       const float *pix2, int width, int height, float *v_rows, gps_stream stream);
+/* records[N,12] (the 48-byte records gps_gauss_preprocess_fwd writes, incl. the ellipse bounds) from the operator-level arrays
+ * means2d[N,2] conics[N,3] colors[N,4] (rgb + depth) opacities[N] radii[N]: lets a caller that holds those run the strip backward */
+GPS_API int gps_raster_pack_records(int N, const float *means2d, const float *conics, const float *colors,
+                                    const float *opacities, const int32_t *radii, float *records, gps_stream stream);
 GPS_API int gps_raster_pair_image(int width, int height, const float *v_render_alphas, const float *ref_depth_map,
                                   float delta_depth, float *pix2, gps_stream stream);
 

@@ -289,6 +289,38 @@ def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():
     assert float(ev[0]["rgb"].min()) >= 0.0 and float(ev[0]["rgb"].max()) <= 1.0
     torch.testing.assert_close(ev[0]["rgb"], res["rgb"].clamp(0, 1), rtol=1e-5, atol=1e-6)
     assert 10.0 < float(ev[0]["psnr"]) < 60.0 and not torch.equal(ev[0]["rgb"], ev[1]["rgb"])
+    # ---- the eval consumer as the reference measures it (slam_pipeline.cpp:588-695 -> scripts/metric.py): 8-bit images,
+    # PSNR of the quantised render against the quantised ground truth -- against the ORACLE's render of the same state
+    # (oracle/splat_ref.py: ges_render) quantised the same way.  A pixel channel may differ by one level only where the oracle's
+    # 255 * value lies within the float tolerance of the render (5e-4) of an integer: listed, counted, bounded.
+    from oracle import splat_ref as orc
+    n_ = lambda t: t.detach().cpu().numpy()
+    cp = model_c.getGaussianParms()
+    Kmat = np.array([[seq["fx"], 0, seq["cx"]], [0, seq["fy"], seq["cy"]], [0, 0, 1]], np.float32)
+    for k in range(2):
+        cam, e = cams[k], ev[k]
+        e_rgb, _ = orc.ges_render(n_(cp.getMeans()), n_(cp.getScales()), n_(cp.getQuats()), n_(cp.getFeaturesDc()), n_(cp.getFeaturesRest()),
+                                  n_(cp.getOpacities()), n_(cam.c2w_slam), Kmat, W, Hh, n_(e["raycast_depth"])[..., 0], n_(e["raycast_color"]),
+                                  delta_depth=0.1)
+        x = np.clip(e_rgb, 0.0, 1.0).astype(np.float32) * np.float32(255.0)
+        want = x.astype(np.uint8)                                   # truncation, as toType(kU8)
+        got = n_(e["rgb_u8"])
+        assert got.dtype == np.uint8 and got.shape == (Hh, W, 3)
+        diff = got.astype(np.int32) - want.astype(np.int32)
+        borderline = np.abs(x - np.round(x)) < 255.0 * 5e-4          # the oracle's value sits on a quantisation step
+        assert (np.abs(diff) <= 1).all() and not (diff != 0)[~borderline].any(), (int((diff != 0).sum()), int(borderline.sum()))
+        print("eval camera %d: %d of %d channels on a quantisation step, %d differ by one level" % (k, int(borderline.sum()), diff.size, int((diff != 0).sum())))
+        # (the synthetic frames are 8-bit, so wherever the TSDF colour dominates the value sits ON a step: what is bounded is the
+        # number of channels that actually land on the other side)
+        assert (diff != 0).sum() <= 1e-4 * diff.size
+        gt8 = (n_(cam.image) * np.float32(255.0)).astype(np.uint8)
+        assert np.array_equal(n_(e["gt_u8"]), gt8)
+        mse_o = np.mean((want.astype(np.float32) / 255.0 - gt8.astype(np.float32) / 255.0) ** 2, dtype=np.float64)
+        psnr_o = 20.0 * np.log10(1.0 / np.sqrt(mse_o))
+        assert abs(float(e["psnr_u8"]) - psnr_o) < 0.01, (float(e["psnr_u8"]), psnr_o)       # BASELINE's bar is 0.1 dB
+        assert np.array_equal(n_(e["raycast_color_u8"]), (n_(e["raycast_color"]) * np.float32(255.0)).astype(np.uint8))
+        d_mm = np.clip(np.rint(n_(e["raycast_depth"]) * np.float32(1000.0)), 0, 65535).astype(np.int32)
+        assert np.array_equal(n_(e["raycast_depth_u16"]), d_mm)
 
 
 def test_full_loop_at_1280x720_cpp_host():

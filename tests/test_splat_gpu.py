@@ -232,9 +232,73 @@ def test_raster_ges_fwd_bwd(N, W, H):
     flipped_g = int((db > REL * scale_b + 1e-30).any(-1).sum())
     assert flipped_g <= nb_g
     print("bwd: %d borderline slots on %d Gaussians, %d Gaussians flipped" % (nb_pairs, nb_g, flipped_g))
+    # the same operator through the kernel the fused train step runs (column strips; no group table): same oracle, same budgets
+    s_ = ops.rasterize_to_pixels_bwd_ges_strips(tm2, tcon, tcol, top, T(radii)[None], tref, W, H, delta, T(v_rc)[None], T(v_ra)[None, ..., None])
+    got_s = np.concatenate([N_(s_[2]).reshape(Ng, 4), N_(s_[1]).reshape(Ng, 3), N_(s_[0]).reshape(Ng, 2), N_(s_[3]).reshape(Ng, 1)], 1)
+    ds = np.abs(got_s - exp_b)
+    assert (ds <= REL * scale_b + 1e-30 + 1.001 * flip_b).all(), (int((ds > REL * scale_b + 1e-30 + 1.001 * flip_b).sum()), float(ds.max()))
+    flipped_s = int((ds > REL * scale_b + 1e-30).any(-1).sum())
+    assert flipped_s <= nb_g
+    s2 = ops.rasterize_to_pixels_bwd_ges_strips(tm2, tcon, tcol, top, T(radii)[None], tref, W, H, delta, T(v_rc)[None], T(v_ra)[None, ..., None])
+    assert all(torch.equal(a, b) for a, b in zip(s_, s2)), "the strip backward has no atomics: bit-reproducible"
+    print("bwd (strips): %d Gaussians flipped" % flipped_s)
     # determinism of the sorted order: two runs give bit-identical forward output
     rc2, ra2, _ = ops.rasterize_to_pixels_fwd_ges(tm2, tcon, tcol, top, tref, W, H, TS, isect, delta)
     assert torch.equal(rc, rc2) and torch.equal(ra, ra2)
+
+
+def test_box_backward_equals_exact_adjoint_where_the_box_holds_the_footprint():
+    """The shipped backward visits the 2r x 2r box of a Gaussian (rasterize_to_pixels_bwd_ges_new_parallel.cu:83-96); the
+    reference's unused exact adjoint (rasterize_to_pixels_bwd_ges.cu:164-291) visits every pixel of every tile the Gaussian is
+    binned to.  They must agree for every Gaussian whose {alpha >= 1/255} footprint -- the ellipse
+    0.5 (a dx^2 + c dy^2) + b dx dy <= ln(255 o) -- lies inside its box: checked at 640x480 on the HIP outputs of both box
+    kernels (32-pixel groups; column strips) against the HIP exact adjoint, with a realistic radius (ceil of 3 sigma of the major
+    axis, so that most footprints DO fit) and on the Gaussians where it does not fit the box version must be the smaller sum."""
+    from gps_slam_amd import gsplat_ops as ops
+    from oracle import splat_ref as orc
+    N, W, H, TS, delta = 100000, 640, 480, 16, 0.1
+    tw, th = W // TS, H // TS
+    radii, m2, depths, conics, colors, opac, ref_depth = _raster_state(N, W, H, seed=11)
+    tm2, tcon, tcol, top, tref = T(m2)[None], T(conics)[None], T(colors)[None], T(opac)[:, None], T(ref_depth)[None, ..., None]
+    isect = ops.isect_tiles_no_depth(tm2, T(radii)[None], TS, tw, th)
+    rng = np.random.default_rng(5)
+    v_rc, v_ra = rng.normal(size=(H, W, 4)).astype(np.float32), rng.normal(size=(H, W)).astype(np.float32)
+    tv_rc, tv_ra = T(v_rc)[None], T(v_ra)[None, ..., None]
+    ex = ops.rasterize_to_pixels_bwd_ges_exact(tm2, tcon, tcol, top, tref, W, H, TS, isect, delta, tv_rc, tv_ra)
+    gr = ops.rasterize_to_pixels_bwd_ges_gs_parallel(tm2, tcon, tcol, top, T(radii)[None], tref, W, H, isect, delta, tv_rc, tv_ra)
+    st = ops.rasterize_to_pixels_bwd_ges_strips(tm2, tcon, tcol, top, T(radii)[None], tref, W, H, delta, tv_rc, tv_ra)
+    cat = lambda o: np.concatenate([N_(o[2]).reshape(N, 4), N_(o[1]).reshape(N, 3), N_(o[0]).reshape(N, 2), N_(o[3]).reshape(N, 1)], 1)
+    g_ex, g_gr, g_st = cat(ex), cat(gr), cat(st)
+    # footprint inside the box?  half extents of the ellipse (+ 1 % and a pixel of slack), box = columns int(x) - r + 1 .. int(x) + r
+    a, b, c = conics[:, 0].astype(np.float64), conics[:, 1].astype(np.float64), conics[:, 2].astype(np.float64)
+    tau = np.log(np.maximum(255.0 * opac.astype(np.float64), 1e-30))
+    det = a * c - b * b
+    vis = (radii > 0) & (tau > 0) & (det > 0)
+    ex_ = np.sqrt(np.where(vis, 2 * tau * c / det, 0.0)) * 1.01 + 1.0
+    ey_ = np.sqrt(np.where(vis, 2 * tau * a / det, 0.0)) * 1.01 + 1.0
+    x0 = np.trunc(m2[:, 0]).astype(np.int64) - radii + 1
+    y0 = np.trunc(m2[:, 1]).astype(np.int64) - radii + 1
+    # pixel centres j + 0.5 in [x - ex, x + ex] must all be box columns (or outside the image, where neither version looks)
+    lo_ok = (np.maximum(m2[:, 0] - ex_ - 0.5, 0) >= x0) & (np.maximum(m2[:, 1] - ey_ - 0.5, 0) >= y0)
+    hi_ok = (np.minimum(m2[:, 0] + ex_ - 0.5, W - 1) <= x0 + 2 * radii - 1) & (np.minimum(m2[:, 1] + ey_ - 0.5, H - 1) <= y0 + 2 * radii - 1)
+    inside = vis & lo_ok & hi_ok
+    assert inside.sum() > 10000, (int(inside.sum()), int((radii > 0).sum()))  # (opacity 0.5: the 1/255 contour lies at 3.1 sigma, the box ends at ceil(3 sigma))
+    # budgets as in test_raster_ges_fwd_bwd: rounding relative to sum |terms| of the element + the oracle's borderline pairs
+    tpg, ids, flat, ggs, gst, offs = orc.isect_tiles(m2, radii, TS, tw, th)
+    REL, BAND, SIG = 2e-5, 1e-5, 2 * 2.0 ** -23
+    scale_b, _, _ = orc.raster_ges_bwd_gs_flip_budget(m2, conics, colors, opac, radii, ref_depth, W, H, ggs, gst, delta, v_rc, v_ra, rel_band=-1.0)
+    sig_b, _, _ = orc.raster_ges_bwd_gs_flip_budget(m2, conics, colors, opac, radii, ref_depth, W, H, ggs, gst, delta, v_rc, v_ra, rel_band=-2.0)
+    flip_b, _, nb_g = orc.raster_ges_bwd_gs_flip_budget(m2, conics, colors, opac, radii, ref_depth, W, H, ggs, gst, delta, v_rc, v_ra, rel_band=BAND)
+    tol = REL * (scale_b + (SIG / REL) * sig_b) + 1e-30 + 1.001 * flip_b
+    for name, g_box in (("groups", g_gr), ("strips", g_st)):
+        d = np.abs(g_box - g_ex)
+        bad = (d > 2 * tol)[inside]
+        assert not bad.any(), (name, int(bad.sum()), float(d[inside].max()))
+    # and where the footprint sticks out of the box the two versions really differ (the test is not vacuous)
+    outside = vis & ~inside
+    rel = np.abs(g_gr - g_ex)[outside].max(1) / (np.abs(g_ex)[outside].max(1) + 1e-30)
+    assert outside.sum() > 100 and (rel > 1e-3).mean() > 0.05, (int(outside.sum()), float((rel > 1e-3).mean()))
+    print("%d of %d visible Gaussians have their footprint inside the box; box == exact adjoint on all of them" % (int(inside.sum()), int((radii > 0).sum())))
 
 
 @pytest.mark.parametrize("N,W,H,with_bg", [(3000, 96, 64, True), (100000, 640, 480, False), (4000, 50, 37, True)])
