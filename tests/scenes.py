@@ -51,3 +51,41 @@ def pose_inv(c2w):
     w2c[:3, :3] = R.T
     w2c[:3, 3] = -R.T @ t
     return w2c
+
+
+def ulp_jitter(a, rng, ulps=1.0):
+    """a float32 array with every element moved by a random relative amount of at most `ulps` * 2^-23 (integers untouched)"""
+    a = np.asarray(a)
+    if a.dtype.kind != "f":
+        return a
+    return (a.astype(np.float64) * (1.0 + rng.uniform(-1.0, 1.0, a.shape) * ulps * 2.0 ** -23)).astype(np.float32)
+
+
+def condition_budget(fn, inputs, base, trials=3, seed=0, factor=32.0, floor=2e-5):
+    """Per-ROW error budget of a float32 adjoint `fn(*inputs) -> tuple of [N, ...] arrays` from its own sensitivity: the outputs
+    are re-evaluated `trials` times with every float input jittered by <= 1 ulp; a row's budget is
+        factor * max_trials max_columns |fn(jittered) - base|  +  floor * max_columns |base|
+    -- an ill-conditioned row (the projection adjoint inverts the 2x2 conic; gradients cancel) gets exactly the slack its own
+    amplification of input rounding justifies, a well-conditioned one gets a few ulps.  -> list of [N] budgets, one per output."""
+    rng = np.random.default_rng(seed)
+    worst = [np.zeros(b.shape[0]) for b in base]
+    for _ in range(trials):
+        out = fn(*[ulp_jitter(a, rng) for a in inputs])
+        for k, (o, b) in enumerate(zip(out, base)):
+            d = np.abs(o.astype(np.float64) - b.astype(np.float64)).reshape(b.shape[0], -1).max(1)
+            worst[k] = np.maximum(worst[k], d)
+    return [factor * w + floor * np.abs(b).reshape(b.shape[0], -1).max(1) for w, b in zip(worst, base)]
+
+
+def radius_is_borderline(conics, rel=2e-4):
+    """[N] bool: the projection's radius = ceil(3 sqrt(lambda_max)) (fully_fused_projection_fwd.cu:165-167) is decided within
+    `rel` of an integer -- the only Gaussians whose radius (or cull decision) float rounding may move.  lambda_max from the conic
+    (= inverse of the blurred 2-D covariance), in float64."""
+    a, b, c = (conics[:, k].astype(np.float64) for k in range(3))
+    det_c = a * c - b * b
+    with np.errstate(all="ignore"):
+        ca, cb, cc = c / det_c, -b / det_c, a / det_c      # covariance
+        det = ca * cc - cb * cb
+        mid = 0.5 * (ca + cc)
+        v = 3.0 * np.sqrt(mid + np.sqrt(np.maximum(0.01, mid * mid - det)))
+    return ~np.isfinite(v) | (np.abs(v - np.round(v)) < rel * np.maximum(v, 1.0))

@@ -54,12 +54,18 @@ def test_projection_fwd_bwd(N, W, H):
     r1, m1, d1, c1 = N_(r1)[0], N_(m1)[0], N_(d1)[0], N_(c1)[0]
     both = (r0 > 0) & (r1 > 0)
     assert both.sum() > 0.3 * N
-    # culling / radius decisions may flip only where a float sits on a rounding boundary
-    assert ((r0 > 0) != (r1 > 0)).mean() < 1e-3
-    assert (np.abs(r0 - r1)[both] <= 1).all() and (r0 != r1)[both].mean() < 1e-3
+    # a radius may differ (by one) only where ceil(3 sqrt(lambda)) is decided within rounding of an integer: listed from the
+    # conics, every difference must be on the list; cull decisions (on-screen tests use the radius) likewise
+    edge = scenes.radius_is_borderline(c0) | scenes.radius_is_borderline(c1)
+    assert (np.abs(r0 - r1)[both] <= 1).all() and not ((r0 != r1) & both & ~edge).any(), int(((r0 != r1) & both & ~edge).sum())
+    assert ((r0 > 0) != (r1 > 0)).sum() <= 1e-4 * N + 2
     np.testing.assert_allclose(m1[both], m0[both], rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(d1[both], d0[both], rtol=1e-5)
-    np.testing.assert_allclose(c1[both], c0[both], rtol=2e-3, atol=1e-6)
+    # conics: every row within its own condition budget (the 2x2 inverse amplifies rounding by the covariance's condition number)
+    cb_ = scenes.condition_budget(lambda mm, qq, ss: (orc.proj_fwd(mm, qq, ss, vm, K, W, H)[3],), (g["means"], g["quats"], scales), (c0,))[0]
+    cerr = np.abs(c1.astype(np.float64) - c0).max(1)
+    print("conics: max error / budget %.3f (budget / |row| max %.1e)" % ((cerr[both] / cb_[both]).max(), (cb_[both] / np.abs(c0[both]).max(1)).max()))
+    assert (cerr[both] <= cb_[both]).all()
     # backward on the oracle's forward state
     rng = np.random.default_rng(1)
     v_m2 = rng.normal(size=(N, 2)).astype(np.float32)
@@ -69,13 +75,18 @@ def test_projection_fwd_bwd(N, W, H):
     o = ops.fully_fused_projection_bwd(T(g["means"]), T(g["quats"]), T(scales), T(vm)[None], T(K)[None], W, H, 0.3,
                                        T(r0)[None], T(c0)[None], T(v_m2)[None], T(v_d)[None], T(v_c)[None])
     vis = r0 > 0
-    for got, ref, name in zip(o, e, ("v_means", "v_quats", "v_scales")):
+    # EVERY row within its own condition budget (tests/scenes.py: the oracle's sensitivity to 1-ulp jitter of its float inputs --
+    # the adjoint inverts the 2x2 conic and its terms cancel, so rows differ by orders of magnitude in what rounding can do)
+    fn = lambda mm, qq, ss, cc, a, b, c: orc.proj_bwd(mm, qq, ss, vm, K, W, H, r0, cc, a, b, c)
+    budget = scenes.condition_budget(fn, (g["means"], g["quats"], scales, c0, v_m2, v_d, v_c), e)
+    for got, ref, bud, name in zip(o, e, budget, ("v_means", "v_quats", "v_scales")):
         got = N_(got)
         assert (got[~vis] == 0).all()
-        # compare per Gaussian relative to that Gaussian's gradient magnitude (cancellation in the adjoint)
-        num = np.abs(got[vis] - ref[vis]).max(axis=1)
-        den = np.abs(ref[vis]).max(axis=1) + 1e-6 * np.abs(ref[vis]).max()
-        assert np.quantile(num / den, 0.999) < 5e-3, name
+        err = np.abs(got.astype(np.float64) - ref).reshape(N, -1).max(1)
+        ratio = err[vis] / (bud[vis] + 1e-300)
+        print("%s: max error / budget %.3f (budget / |row| median %.1e, max %.1e)" % (
+            name, ratio.max(), np.median(bud[vis] / (np.abs(ref[vis]).max(1) + 1e-300)), (bud[vis] / (np.abs(ref[vis]).max(1) + 1e-300)).max()))
+        assert (err[vis] <= bud[vis]).all(), (name, int((err[vis] > bud[vis]).sum()), float(ratio.max()))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])

@@ -172,9 +172,12 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
         n_cull_flip = int(((r0 > 0) != (r1 > 0)).sum())
         n_rad_flip = int((r0 != r1)[both].sum())
         assert both.sum() > 0.5 * N
-        assert n_cull_flip <= 1e-4 * N and n_rad_flip <= 1e-3 * N and (np.abs(r0 - r1)[both] <= 1).all()
+        edge = scenes.radius_is_borderline(c0) | scenes.radius_is_borderline(c1)   # ceil(3 sqrt(lambda)) decided within rounding
+        assert n_cull_flip <= 1e-4 * N and (np.abs(r0 - r1)[both] <= 1).all() and not ((r0 != r1) & both & ~edge).any(), n_rad_flip
         np.testing.assert_allclose(m1[both], m0[both], rtol=1e-4, atol=1e-3)
-        np.testing.assert_allclose(c1[both], c0[both], rtol=2e-3, atol=1e-6)
+        cbud = scenes.condition_budget(lambda pm, pls, pq: (_oracle_preprocess((pm, pls, pq, P_o[3], P_o[4], P_o[5]), vm, K, cam_pos, W, H)[3],),
+                                       (P_o[0], P_o[1], P_o[2]), (c0,), trials=2)[0]
+        assert (np.abs(c1.astype(np.float64) - c0).max(1)[both] <= cbud[both]).all()
         np.testing.assert_allclose(col1[both], col0[both], rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(op1, op0, rtol=2e-6)
 
@@ -257,11 +260,25 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
                                      np.ascontiguousarray(got_b[:, 9]))
         g_hip = [N_(t) for t in mA.grads()]                               # NAMES: means scales quats dc rest opac
         vis = r1 > 0
-        for name, got_g, ref_g in zip(("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"), g_hip,
-                                      (e_g[0], e_g[1], e_g[2], e_g[3], e_g[4], e_g[5])):
+        # EVERY Gaussian within its own condition budget: the oracle adjoint's sensitivity to 1-ulp jitter of its float inputs
+        # (tests/scenes.py: condition_budget) -- no quantiles, no global slack for the ill-conditioned rows
+        fn = lambda pm, pls, pq, pdc, prest, pol, cc, a, b, c, d: _oracle_preprocess_bwd(
+            (pm, pls, pq, pdc, prest, pol), vm, K, cam_pos, W, H, r1, cc, a, b, c, d)
+        ins = (P_o[0], P_o[1], P_o[2], P_o[3], P_o[4], P_o[5], c1, np.ascontiguousarray(got_b[:, 7:9]), np.ascontiguousarray(got_b[:, 4:7]),
+               np.ascontiguousarray(got_b[:, 0:4]), np.ascontiguousarray(got_b[:, 9]))
+        budget = scenes.condition_budget(fn, ins, e_g, trials=2)
+        # sigmoid': v o (1 - o) in float32 (ATen's sigmoid_backward does the same from the float32 y) loses (1 - o) to cancellation
+        # as o -> 1 -- an absolute error of a few ulp(1) on (1 - o) that the oracle's float64 evaluation does not have
+        o64 = 1.0 / (1.0 + np.exp(-P_o[5][:, 0].astype(np.float64)))
+        budget[5] = budget[5] + 4 * 2.0 ** -23 * np.abs(got_b[:, 9].astype(np.float64) * o64)
+        for name, got_g, ref_g, bud in zip(("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"), g_hip,
+                                           (e_g[0], e_g[1], e_g[2], e_g[3], e_g[4], e_g[5]), budget):
             assert (got_g.reshape(N, -1)[~vis] == 0).all() or name == "opacities", name
-            rel = _row_rel(got_g, ref_g, vis)
-            assert np.quantile(rel, 0.999) < 5e-3 and rel.max() < 0.2, (name, np.quantile(rel, 0.999), rel.max())
+            err = np.abs(got_g.reshape(N, -1).astype(np.float64) - ref_g.reshape(N, -1)).max(1)
+            ratio = err[vis] / (bud[vis] + 1e-300)
+            if step == 1:
+                print("  preprocess bwd %s: max error / budget %.3f" % (name, ratio.max()))
+            assert (err[vis] <= bud[vis]).all(), (name, int((err[vis] > bud[vis]).sum()), float(ratio.max()))
 
         # ---- (g) Adam (fused into the backward kernel in the timed path) vs ATen's op sequence on the HIP gradients
         G = list(mA.grads())
