@@ -384,9 +384,11 @@ class RawGaussianModel:
         if want != icap:
             self.isect_capacity = want
             self._step = None  # re-created (with zeroed counts) by the next _step_struct
-        if overflow:
-            raise RuntimeError("tile-intersection buffers overflowed (capacity %d): Gaussians were dropped from a render or a "
-                               "backward pass; capacity raised to %d for the following iterations" % (icap, want))
+        if overflow:  # grow and carry on, loudly (the reference sizes the buffers exactly per forward and never fails here)
+            import warnings
+            self.binning_overflows = getattr(self, "binning_overflows", 0) + 1
+            warnings.warn("tile-intersection buffers overflowed (capacity %d): Gaussians were dropped from a render or a backward "
+                          "pass since the last check; capacity raised to %d for the following iterations" % (icap, want))
         return ni, ng
 
     # ------------------------------------------------------------------ structure edits (every 10 frames)

@@ -47,32 +47,39 @@ Binned bin_tiles(const torch::Tensor& means2d, const torch::Tensor& radii, const
     TORCH_CHECK(radii.scalar_type() == torch::kInt32, "radii must be int32");
     const int N = (int)radii.numel();
     const auto dev = means2d.device();
-    const int64_t icap = std::max<int64_t>(1 << 20, 16 * (int64_t)N), gcap = std::max<int64_t>(1 << 20, 32 * (int64_t)N);
+    // capacity-sized buffers, the counts come back with ONE host read; if they did not fit (the sticky overflow word), the
+    // call is repeated with doubled capacities -- the reference sizes its buffers exactly and never fails here
+    int64_t icap = std::max<int64_t>(1 << 20, 16 * (int64_t)N), gcap = std::max<int64_t>(1 << 20, 32 * (int64_t)N);
     Binned b;
     b.tiles_per_gauss = torch::empty({1, N}, i32(dev));
-    auto isect_ids = torch::empty({icap}, i64(dev));
-    auto flatten_ids = torch::empty({icap}, i32(dev));
     auto offsets = torch::empty({1, (int64_t)tile_height, (int64_t)tile_width}, i32(dev));
-    auto counts = torch::zeros({4}, i64(dev));
-    const int64_t ws_bytes = gps_isect_workspace_bytes(N, icap);
-    auto ws = torch::empty({ws_bytes}, u8(dev));
-    torch::Tensor ggs, gst;
-    if (depths) {
-        f32_input(*depths, "depths");
-        check(gps_isect_tiles(N, fptr(means2d), iptr(radii), fptr(*depths), (int)tile_size, (int)tile_width, (int)tile_height,
-                              icap, iptr(b.tiles_per_gauss), ptr<int64_t>(isect_ids), iptr(flatten_ids), iptr(offsets),
-                              ptr<int64_t>(counts), ws.data_ptr(), ws_bytes, current_stream()), "gps_isect_tiles");
-    } else {
-        ggs = torch::empty({gcap}, i32(dev));
-        gst = torch::empty({gcap}, i32(dev));
-        check(gps_isect_tiles_no_depth(N, fptr(means2d), iptr(radii), (int)tile_size, (int)tile_width, (int)tile_height, icap,
-                                       gcap, iptr(b.tiles_per_gauss), ptr<int64_t>(isect_ids), iptr(flatten_ids), iptr(ggs),
-                                       iptr(gst), iptr(offsets), ptr<int64_t>(counts), ws.data_ptr(), ws_bytes,
-                                       current_stream()), "gps_isect_tiles_no_depth");
+    torch::Tensor isect_ids, flatten_ids, ggs, gst, c;
+    const int64_t* h = nullptr;
+    if (depths) f32_input(*depths, "depths");
+    for (int attempt = 0;; attempt++) {
+        isect_ids = torch::empty({icap}, i64(dev));
+        flatten_ids = torch::empty({icap}, i32(dev));
+        auto counts = torch::zeros({4}, i64(dev));
+        const int64_t ws_bytes = gps_isect_workspace_bytes(N, icap);
+        auto ws = torch::empty({ws_bytes}, u8(dev));
+        if (depths) {
+            check(gps_isect_tiles(N, fptr(means2d), iptr(radii), fptr(*depths), (int)tile_size, (int)tile_width, (int)tile_height,
+                                  icap, iptr(b.tiles_per_gauss), ptr<int64_t>(isect_ids), iptr(flatten_ids), iptr(offsets),
+                                  ptr<int64_t>(counts), ws.data_ptr(), ws_bytes, current_stream()), "gps_isect_tiles");
+        } else {
+            ggs = torch::empty({gcap}, i32(dev));
+            gst = torch::empty({gcap}, i32(dev));
+            check(gps_isect_tiles_no_depth(N, fptr(means2d), iptr(radii), (int)tile_size, (int)tile_width, (int)tile_height, icap,
+                                           gcap, iptr(b.tiles_per_gauss), ptr<int64_t>(isect_ids), iptr(flatten_ids), iptr(ggs),
+                                           iptr(gst), iptr(offsets), ptr<int64_t>(counts), ws.data_ptr(), ws_bytes,
+                                           current_stream()), "gps_isect_tiles_no_depth");
+        }
+        c = counts.cpu();
+        h = c.data_ptr<int64_t>();
+        if (h[2] == 0) break;
+        TORCH_CHECK(attempt < 10 && icap < ((int64_t)1 << 29), who, ": intersection capacity exceeded");
+        icap *= 2; gcap *= 2;
     }
-    auto c = counts.cpu();
-    const int64_t* h = c.data_ptr<int64_t>();
-    TORCH_CHECK(h[2] == 0, who, ": intersection capacity exceeded");
     using torch::indexing::Slice;
     b.isect_ids = isect_ids.index({Slice(0, h[0])});
     b.flatten_ids = flatten_ids.index({Slice(0, h[0])});

@@ -86,6 +86,7 @@ public:
     double means_lr = 1.6e-4, scales_lr = 5e-3, quats_lr = 1e-3, featuresDc_lr = 2.5e-3, featuresRest_lr = 5e-4,
            opacities_lr = 5e-2;
     int64_t isect_capacity = 0;  // 0 -> max(1M, 16 * capacity)
+    int64_t binning_overflows = 0;  // how often checkBinningCapacity() found the sticky overflow flag raised (and grew the buffers)
     // trainStep: step featuresRest inside the backward kernel (its gradient never reaches HBM; grads()[4] is then stale).
     // The parameter update is bit-identical either way.
     bool fuse_sh_rest_adam = true;

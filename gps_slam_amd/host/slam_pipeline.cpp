@@ -84,8 +84,18 @@ TensorDict SLAMPipeline::runRaycastByCam(const Camera& cam, bool use_cam_depth) 
     return m;
 }
 
+// slam_pipeline.cpp:367-379: a camera of the sequence is rendered with the intrinsics the engine stored for its frame
+// (camIntrincs[cam.id]), any other camera with its own fx / fy / cx / cy
+static ITMLib::ITMIntrinsics intrinsicsOf(const Camera& cam, const TsdfEngine* eng) {
+    if (cam.id >= 0 && cam.id < (int)eng->camIntrincs.size()) return eng->camIntrincs[cam.id];
+    ITMLib::ITMIntrinsics in;
+    in.SetFrom(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy);
+    return in;
+}
+
 TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses, void** ev_out) {
     TsdfEngine* eng = main_engine;
+    if (ev_out && !rc_stream_) beginAsyncRaycasts();  // (a caller that skipped localFrameRaycast: order the raycast stream now)
     ORUtils::SE3Pose pose;
     if (cam.id >= 0 && cam.id < (int)poses.size()) {
         pose = poses[cam.id];
@@ -107,7 +117,8 @@ TensorDict SLAMPipeline::raycastCam(const Camera& cam, const std::vector<ORUtils
     auto w2c = poseInv(cam.c2w.to(torch::kCPU, torch::kFloat32)).contiguous();  // poseInv(cam.c2w): dataset pose (:398)
     c10::optional<c10::hip::HIPStreamGuard> on_rc;
     if (ev_out) on_rc.emplace(static_cast<MapStream*>(rc_stream_)->s);
-    eng->runRaycast(&pose);
+    ITMLib::ITMIntrinsics intr = intrinsicsOf(cam, eng);
+    eng->runRaycast(&pose, &intr);
     check(gps_raycast_to_maps(W, H, reinterpret_cast<const float*>(eng->GetFreeVertex()->GetData(MEMORYDEVICE_CUDA)),
                               reinterpret_cast<const uint8_t*>(eng->GetFreeImage()->GetData(MEMORYDEVICE_CUDA)),
                               eng->getVoxelSize(), w2c.data_ptr<float>(), fptr(m["color_map"]), fptr(m["vertex_map"]),
@@ -205,7 +216,9 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
         }
         raycast_pool_warm_ = true;
     }
+    if (ev_out && !rc_stream_) beginAsyncRaycasts();  // (keyFrameRaycast() without a preceding localFrameRaycast())
     std::vector<ORUtils::SE3Pose> view_poses(cams.size());
+    std::vector<ITMLib::ITMIntrinsics> view_intr(cams.size());
     std::vector<torch::Tensor> w2c(cams.size());
     for (size_t k = 0; k < cams.size(); k++) {
         const Camera& cam = *cams[k];
@@ -216,6 +229,7 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
             view_poses[k].SetInvM(c.data_ptr<float>());
             view_poses[k].Coerce();
         }
+        view_intr[k] = intrinsicsOf(cam, eng);
         // (result tensors on the CONSUMER's stream, before the guard below, as in raycastCam)
         TensorDict m;
         m["color_map"] = torch::empty({cam.height, cam.width, 3}, F);
@@ -238,7 +252,8 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
                        fptr(m["depth_map"]), fptr(m["depth_map_clamped"])};
         }
         // (the tensor glue of every view -- gps_raycast_to_maps -- is written by the batch's last kernel)
-        eng->runRaycastBatch(std::vector<ORUtils::SE3Pose>(view_poses.begin() + base, view_poses.begin() + base + cnt), nullptr, &maps);
+        const std::vector<ITMLib::ITMIntrinsics> intr(view_intr.begin() + base, view_intr.begin() + base + cnt);
+        eng->runRaycastBatch(std::vector<ORUtils::SE3Pose>(view_poses.begin() + base, view_poses.begin() + base + cnt), nullptr, &maps, &intr);
     }
     if (ev_out) {
         if (rc_event_next_ == rc_events_.size()) {

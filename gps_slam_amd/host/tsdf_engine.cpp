@@ -193,7 +193,7 @@ void TsdfEngine::reserveViews(int n) {
 }
 
 void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics,
-                                 const std::vector<ViewMaps>* maps) {
+                                 const std::vector<ViewMaps>* maps, const std::vector<ITMLib::ITMIntrinsics>* per_view_intrinsics) {
     const int n = (int)poses.size();
     if (n == 0) return;
     TORCH_CHECK(n <= 12, "runRaycastBatch: at most 12 views per call");
@@ -207,6 +207,7 @@ void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITM
         cx = intrinsics->projectionParamsSimple.px; cy = intrinsics->projectionParamsSimple.py;
     }
     TORCH_CHECK(!maps || (int)maps->size() == n, "runRaycastBatch: one ViewMaps per pose");
+    TORCH_CHECK(!per_view_intrinsics || (int)per_view_intrinsics->size() == n, "runRaycastBatch: one ITMIntrinsics per pose");
     std::vector<gps_tsdf_view> recs(n);
     memset(recs.data(), 0, sizeof(gps_tsdf_view) * (size_t)n);
     for (int k = 0; k < n; k++) {
@@ -216,6 +217,12 @@ void TsdfEngine::runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITM
         memcpy(r.M, poses[k].GetM(), 64);
         memcpy(r.invM, poses[k].GetInvM(), 64);
         r.fx = fx; r.fy = fy; r.cx = cx; r.cy = cy;
+        if (per_view_intrinsics) {  // runRaycast(pose, intrinsics) per view (slam_pipeline.cpp:367-379: camIntrincs[cam.id] or the camera's own)
+            const ITMLib::ITMIntrinsics& in = (*per_view_intrinsics)[k];
+            TORCH_CHECK(in.imgSize.x == s.width && in.imgSize.y == s.height, "runRaycastBatch: the free-view render states have the depth camera's image size");
+            r.fx = in.projectionParamsSimple.fx; r.fy = in.projectionParamsSimple.fy;
+            r.cx = in.projectionParamsSimple.px; r.cy = in.projectionParamsSimple.py;
+        }
         r.visible_ids = iptr(v.visible_ids); r.minmax = fptr(v.minmax); r.raycast = fptr(v.raycast);
         r.colour = ptr<uint8_t>(v.colour); r.scratch = reinterpret_cast<int32_t*>(v.scratch.data_ptr()); r.counters = iptr(v.counters);
         if (maps) {

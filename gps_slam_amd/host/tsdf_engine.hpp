@@ -158,7 +158,8 @@ public:
     // `maps` (optional, one per pose): the runRaycastByCam tensor glue of the view (gps_raycast_to_maps), written by the batch.
     struct ViewMaps { const float* w2c_row_major; float *color_map, *vertex_map, *confidence_map, *depth_map, *depth_map_clamped; };
     void runRaycastBatch(const std::vector<ORUtils::SE3Pose>& poses, ITMLib::ITMIntrinsics* intrinsics = nullptr,
-                         const std::vector<ViewMaps>* maps = nullptr);
+                         const std::vector<ViewMaps>* maps = nullptr,
+                         const std::vector<ITMLib::ITMIntrinsics>* per_view_intrinsics = nullptr);
     // creates the render states of views 0 .. n-1 now (runRaycastBatch otherwise creates them on first use: ~20 MB of device
     // allocations per view in the middle of a keyframe update)
     void reserveViews(int n);
