@@ -129,6 +129,12 @@ __device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int
     return fabsf(d0) + fabsf(d1) + fabsf(d2);
 }
 
+#ifndef GPS_FWD_PREFETCH
+#define GPS_FWD_PREFETCH 1
+#endif
+#ifndef GPS_FWD_LDS_AHEAD
+#define GPS_FWD_LDS_AHEAD 1
+#endif
 #ifndef GPS_FWD_LIST_SPLIT
 #define GPS_FWD_LIST_SPLIT 4
 #endif
@@ -141,7 +147,11 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
     float* __restrict__ render_alphas, gps::FwdCompose fc) {
+#if GPS_FWD_PREFETCH
+    constexpr int BATCH = FWD_THREADS;   // every thread stages one record per batch
+#else
     constexpr int BATCH = 256;
+#endif
     __shared__ float4 r0[BATCH];   // {mx, my, 0.5*ca*log2e, cb*log2e}
     __shared__ float4 r1[BATCH];   // {0.5*cc*log2e, -log2(opac), depth, r}
     __shared__ float2 r2[BATCH];   // {g, b}
@@ -162,8 +172,32 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
     constexpr float LOG2E = 1.4426950408889634f;
 
+#if GPS_FWD_PREFETCH
+    // Staging is software-pipelined: the records of batch b + 1 (and the list entries of batch b + 2) are requested BEFORE batch b is
+    // evaluated and land in registers while the waves compute, so a tile pays the two dependent gathers (list entry -> record) once,
+    // not once per batch -- and the workgroups of a CU, which start together, no longer all sit in their staging phase at once.
+    // unconditional, clamped loads in straight-line code (a thread past the end of the list re-reads the last entry and does
+    // not store it): a branch around a load makes the compiler wait for it at the branch's merge point
+    const int last = max(range_end - 1, 0);
+    int g_next = flatten_ids[min(range_start + tid, last)];
+    float4 pa = recs[3 * (size_t)g_next], pb = recs[3 * (size_t)g_next + 1], pc = recs[3 * (size_t)g_next + 2];
+    g_next = flatten_ids[min(range_start + BATCH + tid, last)];
+#endif
     for (int batch_start = range_start; batch_start < range_end; batch_start += BATCH) {
         __syncthreads();
+#if GPS_FWD_PREFETCH
+        // (the empty asm pins the use of the prefetched registers HERE: without it the compiler hoists the record's rewrite to
+        // right behind the loads and waits for them before the evaluation loop)
+        asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w), "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w), "+v"(pc.x), "+v"(pc.y));
+        if (batch_start + tid < range_end) {
+            r0[tid] = make_float4(pa.x, pa.y, 0.5f * LOG2E * pa.z, LOG2E * pa.w);
+            r1[tid] = make_float4(0.5f * LOG2E * pb.x, -__log2f(pb.y), pb.z, pb.w);
+            r2[tid] = make_float2(pc.x, pc.y);
+        }
+        __syncthreads();
+        pa = recs[3 * (size_t)g_next]; pb = recs[3 * (size_t)g_next + 1]; pc = recs[3 * (size_t)g_next + 2];
+        g_next = flatten_ids[min(batch_start + 2 * BATCH + tid, last)];
+#else
         {
             const int idx = batch_start + tid;
             if (tid < BATCH && idx < range_end) {
@@ -175,6 +209,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
             }
         }
         __syncthreads();
+#endif
         const int n = min(BATCH, range_end - batch_start);
         // wave-uniform bounds -> scalar loop counter
         const int lo = __builtin_amdgcn_readfirstlane(list_part * n / FWD_SPLIT);
@@ -205,6 +240,31 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
             const v2f al = {hit0 ? al0 : 0.f, hit1 ? al1 : 0.f};
             o0 += g.b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += g.b.z * al; ws += al;
         };
+#if GPS_FWD_LDS_AHEAD
+        // The records of the NEXT pair are read from LDS while the current pair is evaluated (two pairs alternate, written out by
+        // hand so that no register moves are needed): a trip no longer starts by waiting for its own ds_reads -- the counters
+        // showed 43 % of the wave cycles parked on waits.  Reads past the part's end are clamped and their entries not evaluated.
+        const int last_t = max(hi - 1, lo);
+        auto fetch = [&](Entry& g, float2& c, int t) {
+            const int tt = min(t, last_t);
+            g.a = r0[tt]; g.b = r1[tt];
+            if (GPS_FWD_LDS_AHEAD >= 2) c = r2[tt];
+        };
+        auto eval = [&](Entry& g, const float2 c, int t) {
+            if (t < hi && test(g)) blend(g, GPS_FWD_LDS_AHEAD >= 2 ? c : r2[min(t, last_t)]);
+        };
+        if (lo < hi) {
+            Entry A0, A1, B0, B1;
+            float2 cA0 = {}, cA1 = {}, cB0 = {}, cB1 = {};
+            fetch(A0, cA0, lo); fetch(A1, cA1, lo + 1);
+            for (int t = lo; t < hi; t += 4) {
+                fetch(B0, cB0, t + 2); fetch(B1, cB1, t + 3);
+                eval(A0, cA0, t); eval(A1, cA1, t + 1);
+                fetch(A0, cA0, t + 4); fetch(A1, cA1, t + 5);
+                eval(B0, cB0, t + 2); eval(B1, cB1, t + 3);
+            }
+        }
+#else
         int t = lo;
         for (; t + 1 < hi; t += 2) {
             Entry g0, g1;
@@ -218,6 +278,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
             g0.a = r0[t]; g0.b = r1[t];
             if (test(g0)) blend(g0, r2[t]);
         }
+#endif
     }
     // list parts 1.. -> LDS -> part 0 adds them in order and stores
     const int slot = (pix_half * 64 + lane) * 10;
