@@ -35,22 +35,27 @@ __device__ __forceinline__ void tile_group_count(float mx, float my, int r, int 
 // ---- superblock binning (splat_bin_sb.hip): the fused model path's tile binning in two launches behind the preprocessing
 // kernel.  A superblock = SB_BLOCKS consecutive preprocessing workgroups (256 Gaussians each), at most SB_MAX superblocks.
 //   preprocessing kernel : per workgroup an LDS histogram of its (Gaussian, tile) pairs over the <= SB_MAX_TILES tile ids, added
-//                          to the count table C[tile][superblock]; per-class Gaussian counts into cls_count[superblock][k]
+//                          to the count table C[tile][superblock]; Gaussians per backward list key (class, image band) into
+//                          cls_count[key][superblock]
 //   scan kernel          : per tile the exclusive prefix over superblocks P[tile][sb] + the tile total; C is zeroed again
 //   scatter kernel       : one workgroup per superblock enumerates its pairs in Gaussian order and writes each Gaussian id to
 //                          tile_start[tile] + P[tile][sb] + (its stable rank inside the superblock): the order a stable sort
 //                          by tile id gives (isect_tiles_no_depth.cu:313-327), without ever materialising a key / value
-//                          array; tile_offsets = exclusive scan of the tile totals; the backward's class lists ride along.
+//                          array; tile_offsets = exclusive scan of the tile totals; the backward's class lists ride along,
+//                          each ordered by (image band, Gaussian id): a counting sort over the BWD_KEYS keys with the same
+//                          three steps, so that a contiguous piece of a class list gathers from one band of the image.
 // Invariant: C and cls_count are ZERO between launches (zeroed by gps_isect_workspace_init, then by the scan kernel).
 constexpr int SB_MAX = 512;          // superblocks (row length of the tables)
 constexpr int SB_MAX_TILES = 4096;   // tile ids the LDS histograms cover; more tiles -> the sorted-key path of splat_bin.hip
 constexpr int BWD_CLASSES = GPS_BWD_CLASSES;
+constexpr int BWD_BANDS = 16;        // horizontal image bands a class list is ordered by (first tile row of the Gaussian's box)
+constexpr int BWD_KEYS = BWD_CLASSES * BWD_BANDS;
 struct SbTables {
     uint32_t* C;           // [SB_MAX_TILES][SB_MAX] counts (zero between launches)
     uint32_t* P;           // [SB_MAX_TILES][SB_MAX] exclusive prefixes over superblocks
     uint32_t* tile_total;  // [SB_MAX_TILES]
-    int32_t* cls_count;    // [8][SB_MAX] Gaussians per backward class and superblock (zero between launches)
-    int32_t* cls_prefix;   // [8][SB_MAX] exclusive prefixes over superblocks, then a row of the 8 totals
+    int32_t* cls_count;    // [BWD_KEYS][SB_MAX] Gaussians per (class, band) and superblock (zero between launches)
+    int32_t* cls_prefix;   // [BWD_KEYS][SB_MAX] exclusive prefixes over superblocks, then a row of the BWD_KEYS totals
     int sb_shift;          // log2(preprocessing workgroups per superblock)
 };
 __host__ __device__ inline int sb_shift_for(int N) {  // smallest power of two of 256-Gaussian blocks with <= SB_MAX superblocks
@@ -60,6 +65,11 @@ __host__ __device__ inline int sb_shift_for(int N) {  // smallest power of two o
 }
 // backward class of a radius: the smallest k with 4 << k >= r, the last class takes everything wider
 __host__ __device__ inline int bwd_class(int r) { return r <= 4 ? 0 : r <= 8 ? 1 : r <= 16 ? 2 : r <= 32 ? 3 : 4; }
+// list key of a visible Gaussian: class-major, then the band of its box's first tile row y0 (0 when the box holds no tile)
+__host__ __device__ inline int bwd_key(int r, int n_tiles, unsigned y0, int th) {
+    const int band = n_tiles > 0 ? (int)(y0 * (unsigned)BWD_BANDS / (unsigned)(th > 0 ? th : 1)) : 0;
+    return bwd_class(r) * BWD_BANDS + (band < BWD_BANDS ? band : BWD_BANDS - 1);
+}
 
 // where the first pass's results live (pointers into the caller's binning workspace); tiles_per_gauss == nullptr: off
 struct BinCountOut {

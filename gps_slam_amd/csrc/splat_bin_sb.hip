@@ -40,7 +40,7 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
 }
 
 // ---- one wave per tile: exclusive prefix of the tile's row of C over the superblocks; C is left zero ----
-__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, int32_t* __restrict__ cls_counts) {
+__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
     static_assert(SB_MAX == 512, "a lane owns 8 consecutive superblocks");
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, i
         prow[0] = pa; prow[1] = pb;
         if (lane == 0) t.tile_total[tile] = (uint32_t)total;
     }
-    // the class counts (row k of cls_count = class k over the superblocks): the rows behind the last tile, one wave each
+    // the list-key counts (row k of cls_count = key k over the superblocks): the rows behind the last tile, one wave each
     const int k = tile - n_tiles;
-    if (k >= 0 && k < gps::BWD_CLASSES) {
+    if (k >= 0 && k < gps::BWD_KEYS) {
         int4* crow = reinterpret_cast<int4*>(t.cls_count + (size_t)k * SB_MAX) + 2 * lane;
         const int4 a = crow[0], b = crow[1];
         crow[0] = make_int4(0, 0, 0, 0); crow[1] = make_int4(0, 0, 0, 0);
@@ -72,10 +72,7 @@ __global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, i
         pb.x = run; run += b.x; pb.y = run; run += b.y; pb.z = run; run += b.z; pb.w = run;
         int4* prow = reinterpret_cast<int4*>(t.cls_prefix + (size_t)k * SB_MAX) + 2 * lane;
         prow[0] = pa; prow[1] = pb;
-        if (lane == 0) {
-            if (cls_counts) cls_counts[k] = total;
-            t.cls_prefix[8 * SB_MAX + k] = total;   // totals row (n_visible = their sum)
-        }
+        if (lane == 0) t.cls_prefix[gps::BWD_KEYS * SB_MAX + k] = total;   // totals row (n_visible = their sum)
     }
 }
 
@@ -86,7 +83,8 @@ __global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, i
 __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const int32_t* __restrict__ tiles_per_gauss,
     int tile_size, int tw, int th, SbTables t, int64_t isect_cap, int32_t* __restrict__ flatten_ids,
-    int32_t* __restrict__ tile_offsets, int64_t* __restrict__ counts, int32_t* __restrict__ cls_ids, int64_t cls_stride) {
+    int32_t* __restrict__ tile_offsets, int64_t* __restrict__ counts, int32_t* __restrict__ cls_ids,
+    int32_t* __restrict__ cls_counts, int64_t cls_stride) {
     extern __shared__ uint32_t lds[];
     const int n_tiles = tw * th;
     const int sb = blockIdx.x, sb_size = BIN_BLOCK << t.sb_shift;        // Gaussians per superblock
@@ -96,14 +94,19 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     uint32_t* pre = lds + n_tiles + ((SCAT_WAVES + 1) * n_tiles + 1) / 2; // [sb_size + 1] exclusive prefix of the tile counts
     uint32_t* box = pre + sb_size + 1;                                    // [sb_size] x0 | y0 << 12 | width << 24
     __shared__ int ws[SCAT_WAVES], wlo[SCAT_WAVES], whi[SCAT_WAVES];
-    __shared__ int cls_wave[SCAT_WAVES][8];
+    __shared__ int key_wave[SCAT_WAVES][gps::BWD_KEYS];   // a trip's Gaussians per wave and list key (zero between trips)
+    __shared__ int key_run[gps::BWD_KEYS];                // next free position of this superblock's run in a key's list piece
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g0 = sb * sb_size;
 
     // ---- this superblock's Gaussians: tile counts -> exclusive prefix, boxes, the band of tile rows; class lists
-    int running_cls[gps::BWD_CLASSES];
-#pragma unroll
-    for (int k = 0; k < gps::BWD_CLASSES; k++) running_cls[k] = cls_ids ? t.cls_prefix[k * SB_MAX + sb] : 0;
+    // class k's list = its bands in order, a band = the superblocks in order, a superblock's run in ascending id
+    if (cls_ids && tid < gps::BWD_KEYS) {
+        int start = t.cls_prefix[tid * SB_MAX + sb];
+        for (int k = tid - tid % gps::BWD_BANDS; k < tid; k++) start += t.cls_prefix[gps::BWD_KEYS * SB_MAX + k];
+        key_run[tid] = start;
+        for (int w = 0; w < SCAT_WAVES; w++) key_wave[w][tid] = 0;
+    }
     int carry = 0, row_lo = th, row_hi = 0;
     for (int j0 = 0; j0 < sb_size; j0 += SCAT_THREADS) {
         const int j = j0 + tid, g = g0 + j;
@@ -121,15 +124,18 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
             }
         }
         const int incl = wave_incl_scan_i(tcount);
-        __syncthreads();   // (ws / cls_wave of the previous trip consumed)
+        __syncthreads();   // (ws / key_wave of the previous trip consumed)
         if (lane == 63) ws[wave] = incl;
-        const int cls = (mine_j && g < N && r > 0) ? gps::bwd_class(r) : -1;
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int k = 0; k < gps::BWD_CLASSES; k++) {
-            const unsigned long long m = __ballot(cls == k);
-            if (lane == 0) cls_wave[wave][k] = __popcll(m);
-            if (cls == k) mine = m;
+        // rank among the wave's Gaussians of the same list key: one ballot per DISTINCT key in the wave (a few: neighbours in id
+        // are neighbours in the image and alike in size)
+        const int key = (cls_ids && mine_j && g < N && r > 0) ? gps::bwd_key(r, tcount, bx >> 12 & 0xfff, th) : -1;
+        int rank = 0;
+        for (unsigned long long rem = __ballot(key >= 0); rem;) {
+            const int kk = __shfl(key, __ffsll((long long)rem) - 1, 64);
+            const unsigned long long m = __ballot(key == kk);
+            if (key == kk) rank = __popcll(m & lanemask_lt());
+            if (lane == 0) key_wave[wave][kk] = __popcll(m);
+            rem &= ~m;
         }
         __syncthreads();
         int woff = 0, total = 0;
@@ -137,12 +143,16 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
         if (mine_j) { pre[j] = (uint32_t)(carry + woff + incl - tcount); box[j] = bx; }
         carry += total;
         if (cls_ids) {
-#pragma unroll
-            for (int k = 0; k < gps::BWD_CLASSES; k++) {
-                int before = 0, all = 0;
-                for (int w = 0; w < SCAT_WAVES; w++) { const int v = cls_wave[w][k]; if (w < wave) before += v; all += v; }
-                if (cls == k) cls_ids[k * cls_stride + running_cls[k] + before + __popcll(mine & lanemask_lt())] = g;
-                running_cls[k] += all;
+            if (key >= 0) {
+                int before = 0;
+                for (int w = 0; w < wave; w++) before += key_wave[w][key];
+                cls_ids[(key / gps::BWD_BANDS) * cls_stride + key_run[key] + before + rank] = g;
+            }
+            __syncthreads();
+            if (tid < gps::BWD_KEYS) {
+                int all = 0;
+                for (int w = 0; w < SCAT_WAVES; w++) { all += key_wave[w][tid]; key_wave[w][tid] = 0; }
+                key_run[tid] += all;
             }
         }
     }
@@ -185,7 +195,12 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
             if (ni > isect_cap) { ni = isect_cap; counts[2] = 1; }   // sticky overflow word, as the sorted-key path
             counts[0] = ni; counts[1] = 0;
             int nv = 0;
-            for (int k = 0; k < gps::BWD_CLASSES; k++) nv += t.cls_prefix[8 * SB_MAX + k];
+            for (int k = 0; k < gps::BWD_CLASSES; k++) {
+                int nk = 0;
+                for (int b = 0; b < gps::BWD_BANDS; b++) nk += t.cls_prefix[gps::BWD_KEYS * SB_MAX + k * gps::BWD_BANDS + b];
+                if (cls_counts) cls_counts[k] = nk;
+                nv += nk;
+            }
             counts[3] = nv;
         }
     }
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
 namespace gps {
 
 size_t sb_tables_bytes() {
-    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * 8 * 4 * 2 + 2048;
+    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * BWD_KEYS * 4 * 2 + 2048;
 }
 
 void sb_tables_carve(char* base, SbTables* t) {
@@ -266,8 +281,8 @@ void sb_tables_carve(char* base, SbTables* t) {
     t->C = (uint32_t*)take((size_t)SB_MAX_TILES * SB_MAX * 4);
     t->P = (uint32_t*)take((size_t)SB_MAX_TILES * SB_MAX * 4);
     t->tile_total = (uint32_t*)take((size_t)SB_MAX_TILES * 4);
-    t->cls_count = (int32_t*)take((size_t)(SB_MAX + 1) * 8 * 4);
-    t->cls_prefix = (int32_t*)take((size_t)(SB_MAX + 1) * 8 * 4);
+    t->cls_count = (int32_t*)take((size_t)(SB_MAX + 1) * BWD_KEYS * 4);
+    t->cls_prefix = (int32_t*)take((size_t)(SB_MAX + 1) * BWD_KEYS * 4);
     t->sb_shift = 0;
 }
 
@@ -283,14 +298,14 @@ int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, co
     const int n_sb = (nblk + (1 << cnt.sb.sb_shift) - 1) >> cnt.sb.sb_shift;
     GPS_REQUIRE(n_sb <= SB_MAX);
     hipStream_t s = (hipStream_t)stream;
-    sb_scan_kernel<<<gps_div_up(n_tiles + BWD_CLASSES, 4), 256, 0, s>>>(n_tiles, cnt.sb, cls_counts);
+    sb_scan_kernel<<<gps_div_up(n_tiles + BWD_KEYS, 4), 256, 0, s>>>(n_tiles, cnt.sb);
     const int sb_size = BIN_BLOCK << cnt.sb.sb_shift;
     const size_t lds = ((size_t)n_tiles + ((SCAT_WAVES + 1) * (size_t)n_tiles + 1) / 2 + 2 * (size_t)sb_size + 2) * 4;
     GPS_REQUIRE(lds <= 160 * 1024);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     sb_scatter_kernel<<<n_sb, SCAT_THREADS, lds, s>>>(N, means2d, radii, tiles_per_gauss, cnt.tile_size, cnt.tw, cnt.th, cnt.sb,
-                                                     isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_stride);
+                                                     isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_counts, cls_stride);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -136,25 +136,28 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t
         // Superblock binning, histogram pass (splat_bin.hpp): this workgroup's (Gaussian, tile) pairs counted per tile in LDS,
         // the non-zero bins added to the count table of its superblock; Gaussians per backward class likewise.
         __shared__ uint32_t hist[SB_MAX_TILES];
+        __shared__ int khist[BWD_KEYS];
         const int nt = cnt.tw * cnt.th;
         for (int b = threadIdx.x; b < nt; b += 256) hist[b] = 0;
+        if (threadIdx.x < BWD_KEYS) khist[threadIdx.x] = 0;
         __syncthreads();
+        unsigned y0 = 0;
         if (n_tiles > 0) {
             const TileBox bx = tile_bbox(box_mx, box_my, box_r, cnt.tile_size, cnt.tw, cnt.th);
+            y0 = bx.y0;
             for (uint32_t ty = bx.y0; ty < bx.y1; ty++)
                 for (uint32_t tx = bx.x0; tx < bx.x1; tx++) atomicAdd(&hist[ty * (uint32_t)cnt.tw + tx], 1u);
         }
+        if (box_r > 0) atomicAdd(&khist[bwd_key(box_r, n_tiles, y0, cnt.th)], 1);
         __syncthreads();
         const int sb = (int)blockIdx.x >> cnt.sb.sb_shift;
         for (int b = threadIdx.x; b < nt; b += 256) {
             const uint32_t c = hist[b];
             if (c) atomicAdd(&cnt.sb.C[(size_t)b * SB_MAX + sb], c);
         }
-        const int cls = box_r > 0 ? bwd_class(box_r) : -1;
-#pragma unroll
-        for (int k = 0; k < BWD_CLASSES; k++) {
-            const unsigned long long m = __ballot(cls == k);
-            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt.sb.cls_count[k * SB_MAX + sb], (int)__popcll(m));
+        if (threadIdx.x < BWD_KEYS) {
+            const int c = khist[threadIdx.x];
+            if (c) atomicAdd(&cnt.sb.cls_count[threadIdx.x * SB_MAX + sb], c);
         }
     }
 }

@@ -89,3 +89,22 @@ def radius_is_borderline(conics, rel=2e-4):
         mid = 0.5 * (ca + cc)
         v = 3.0 * np.sqrt(mid + np.sqrt(np.maximum(0.01, mid * mid - det)))
     return ~np.isfinite(v) | (np.abs(v - np.round(v)) < rel * np.maximum(v, 1.0))
+
+
+def bwd_class_lists(means2d, radii, tile_size, tw, th, bands=16):
+    """The strip backward's work lists as the binning writes them (splat_bin.hpp: bwd_key): per class k (smallest 4 << k >= radius,
+    the last class takes the rest) the visible Gaussians ordered by (band of the box's first tile row, id)."""
+    r = np.asarray(radii)
+    m = np.asarray(means2d, np.float32)
+    ts = np.float32(tile_size)
+    tr, tx, ty = r.astype(np.float32) / ts, m[:, 0] / ts, m[:, 1] / ts
+    x0 = np.clip(np.floor(tx - tr), 0, tw); x1 = np.clip(np.ceil(tx + tr), 0, tw)
+    y0 = np.clip(np.floor(ty - tr), 0, th); y1 = np.clip(np.ceil(ty + tr), 0, th)
+    n_tiles = ((y1 - y0) * (x1 - x0)).astype(np.int64)
+    band = np.where(n_tiles > 0, np.minimum(y0.astype(np.int64) * bands // th, bands - 1), 0)
+    cls = np.where(r > 0, np.searchsorted(np.array([4, 8, 16, 32]), r, side="left"), -1)
+    out = []
+    for k in range(5):
+        ids = np.nonzero(cls == k)[0]
+        out.append(ids[np.argsort(band[ids], kind="stable")])
+    return out

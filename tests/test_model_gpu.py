@@ -154,10 +154,10 @@ def test_fused_binning_and_class_lists_survive_add_and_prune():
         assert int(counts[0]) == flat.shape[0] and int(counts[2]) == 0 and int(counts[3]) == int((r > 0).sum()), (round_, counts)
         assert np.array_equal(B["flatten_ids"][:flat.shape[0]].cpu().numpy(), flat), round_
         assert np.array_equal(B["tile_offsets"].cpu().numpy(), offs.reshape(-1)), round_
-        cls = np.where(r > 0, np.searchsorted(np.array([4, 8, 16, 32]), r, side="left"), -1)
         cc = B["cls_counts"].cpu().numpy()
+        lists = scenes.bwd_class_lists(m2, r, 16, tw, th)
         for k in range(5):
-            want = np.nonzero(cls == k)[0]
+            want = lists[k]
             assert int(cc[k]) == want.shape[0] and np.array_equal(B["cls_ids"][k, :want.shape[0]].cpu().numpy(), want), (round_, k)
         p = model.opt_gs_params
         if round_ % 2 == 0:   # prune a random third ...

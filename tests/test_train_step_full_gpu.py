@@ -187,11 +187,11 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
         assert np.array_equal(N_(B["flatten_ids"][:ni]), flat) and np.array_equal(N_(B["tile_offsets"]), offs.reshape(-1))
         assert np.array_equal(N_(B["tiles_per_gauss"][:N]), tpg)
         if strips:
-            # the backward's work lists: ascending ids per class (smallest 4 << k >= radius; the last class takes the rest)
-            cls = np.where(r1 > 0, np.searchsorted(np.array([4, 8, 16, 32]), r1, side="left"), -1)
+            # the backward's work lists: per class (smallest 4 << k >= radius; the last class takes the rest) by (image band, id)
             cc = N_(B["cls_counts"])
+            lists = scenes.bwd_class_lists(m1, r1, TS, tw, th)
             for k in range(5):
-                want = np.nonzero(cls == k)[0]
+                want = lists[k]
                 assert int(cc[k]) == want.shape[0] and np.array_equal(N_(B["cls_ids"][k, :want.shape[0]]), want), k
             assert int(counts[3]) == int((r1 > 0).sum()) and ng == 0
         else:
