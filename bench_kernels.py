@@ -85,6 +85,15 @@ def _kernel_row(name, calls_per_frame, t, alg_bytes, hbm_peak_gbs, N, bound, not
         if rec.get("hbm_bytes_per_launch"):
             row["traffic"] = rec["hbm_bytes_per_launch"]
             row["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / max(1.0, alg_bytes)
+            if row["frac"] > 1.0:
+                # more algorithmic bytes per second than HBM delivers: part of them never reach HBM (the 256 MB MALL keeps
+                # state that the previous iteration wrote); the HBM-side rate is the honest occupancy of the 8 TB/s
+                row["hbm_side_GBs"] = rec["hbm_bytes_per_launch"] / t / 1e9
+                row["hbm_side_frac"] = row["hbm_side_GBs"] / hbm_peak_gbs
+                row["note"] = (row.get("note", "") + "; frac > 1: the algorithmic bytes (parameters + both Adam moments read and "
+                               "written) exceed what crosses the HBM interface -- the counters see traffic_over_algorithmic of them, "
+                               "the rest is served by the Infinity Cache between iterations; hbm_side_frac prices the counter "
+                               "bytes").lstrip("; ")
         v = (rec.get("sq") or {}).get("SQ_INSTS_VALU")
         if v:
             # counter collection serialises and slows the launches; the instruction COUNT carries over and is priced against

@@ -21,8 +21,9 @@
 //   * per-pixel inputs: d loss / d colours as float4 and {d loss / d weight sum, depth cut} as one float2 per pixel (written
 //     by the forward's compose epilogue): lanes of a group read r consecutive pixels -> 16 r and 8 r contiguous bytes.
 //
-// Work list: Gaussian ids by class (ascending inside a class, so neighbouring groups cover neighbouring pixels), built by
-// the binning; 64 / GW Gaussians per wave task.
+// Work list: Gaussian ids by class, inside a class by (image band, id) so that neighbouring groups -- and an XCD's contiguous
+// eighth of the list -- gather from neighbouring pixels; built by the binning (splat_bin.hpp: bwd_key); 64 / GW Gaussians per
+// wave task.  Any order gives the same rows.
 #include "common.hpp"
 #include "splat_bin.hpp"
 #include "splat_math.hpp"

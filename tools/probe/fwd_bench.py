@@ -69,6 +69,20 @@ to.copy_(uni)
 t_uni = min(1e6 * _time_launches(fwd(lib, *o2), 50, stream) for _ in range(3))
 to.copy_(keep)
 print("forward %.1f us; with all %d tile lists equally long (same total) %.1f us" % (t_real, nt, t_uni))
+# latency- or throughput-bound?  The same kernel with only the first M tiles' lists non-empty (the others return at once): if the
+# time does not grow with M up to one resident round (768 workgroups), a wave's own dependent chain sets it
+cnt0 = B["counts"].clone()
+line = "non-empty tiles -> us:"
+for M in (64, 256, 512, 768, 1024, 1200):
+    t2 = keep.clone()
+    if M < nt:
+        t2[M:] = keep[M]
+        B["counts"][0] = int(keep[M])
+    to.copy_(t2)
+    line += "  %d: %.1f" % (M, min(1e6 * _time_launches(fwd(lib, *o2), 50, stream) for _ in range(3)))
+    B["counts"].copy_(cnt0)
+to.copy_(keep)
+print(line)
 step = lambda: model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
 print("whole train step (shipped) %.1f us" % (1e6 * _time_launches(step, 20, stream)))
 scene.close()
