@@ -129,36 +129,51 @@ __device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int
     return fabsf(d0) + fabsf(d1) + fabsf(d2);
 }
 
-#ifndef GPS_FWD_PREFETCH
-#define GPS_FWD_PREFETCH 1
-#endif
-#ifndef GPS_FWD_LDS_AHEAD
-#define GPS_FWD_LDS_AHEAD 1
-#endif
 #ifndef GPS_FWD_LIST_SPLIT
 #define GPS_FWD_LIST_SPLIT 4
 #endif
-constexpr int FWD_SPLIT = GPS_FWD_LIST_SPLIT;  // waves per pixel half: the tile's list is added in this many parts.  The kernel is
-// VALU-bound with stalls (66 % of the issue slots at 2 parts): more waves per tile hide them -- 2 parts 63 us, 3: 60, 4: 55.5, 6: 57,
-// 8: 77 (bench scene, 1,200 tiles; the sums of the parts are added in order, so the split only changes the rounding of the total)
+#ifdef GPS_FWD_STAMPS
+// probe builds only (tools/probe/fwd_stamps.py): 100 MHz timestamps of workgroup phases, 8 per tile
+__device__ unsigned long long gps_fwd_stamps_buf[4096 * 8];
+extern "C" GPS_API void* gps_fwd_stamps() { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(gps_fwd_stamps_buf)); return p; }
+#define FWD_STAMP(k) do { if (threadIdx.x == 0) gps_fwd_stamps_buf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define FWD_STAMP(k) do { } while (0)
+#endif
+// A 16 x 16 tile = two 16 x 8 pixel halves (one wave each, 2 px per lane) x FWD_SPLIT list parts: 2 * FWD_SPLIT waves per tile.
+// History of the inner loop (bench scene, 1,200 tiles, ~500 k list entries):
+//   round 1   every entry evaluated for every pixel                                                   81.6 us
+//   round 2   wave-uniform skip in the loop (test e > 8 for all 128 pixels, ballot, branch)             55 us   (list in 4 parts)
+//   round 3   cull at staging time, then blend survivors only (below)                                   see DESIGN.md
+// The round-2 loop was bound by its own dependent chain per entry: LDS read -> 10 VALU -> ballot -> branch -> exp -> blend, ~400
+// cycles per entry for a lone wave (tools/probe/fwd_stamps.py), with a third of the issue slots used.  Now the staging thread of an
+// entry tests the entry's pixel bounds (pack_record: a conservative box around {alpha >= 1/255}; outside it the entry adds exact
+// zeros) against the two halves, and the survivors of each half are compacted, in list order, into an index list in LDS.  A
+// wave takes an equal share of ITS half's survivors, holds their record addresses in one or two registers (lane j = j-th
+// survivor) and walks them with v_readlane: no test, no ballot, no data-dependent branch in the loop, and no LDS reads for the
+// ~45 % of a tile's entries that do not reach a given half.  Sums are added in list order inside a part and the parts in order:
+// deterministic; a culled entry would have added +0.
+constexpr int FWD_SPLIT = GPS_FWD_LIST_SPLIT;
 constexpr int FWD_THREADS = 128 * FWD_SPLIT;
+constexpr int FWD_BATCH = FWD_THREADS;           // every thread stages one list entry per batch
+constexpr int FWD_SEGS = FWD_BATCH / 64;         // staging waves
+constexpr int FWD_VECS = (FWD_BATCH / FWD_SPLIT + 63) / 64;   // registers that hold a part's survivor addresses
 __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
     float* __restrict__ render_alphas, gps::FwdCompose fc) {
-#if GPS_FWD_PREFETCH
-    constexpr int BATCH = FWD_THREADS;   // every thread stages one record per batch
-#else
-    constexpr int BATCH = 256;
-#endif
-    __shared__ float4 r0[BATCH];   // {mx, my, 0.5*ca*log2e, cb*log2e}
-    __shared__ float4 r1[BATCH];   // {0.5*cc*log2e, -log2(opac), depth, r}
-    __shared__ float2 r2[BATCH];   // {g, b}
-    __shared__ float part[(FWD_SPLIT - 1) * 128 * 10];
+    // 48-byte records {mx, my, 0.5*ca*log2e, cb*log2e | 0.5*cc*log2e, -log2(opac), depth, r | g, b, -, -}; after the last batch the
+    // same memory carries the parts' partial sums
+    constexpr int PART_FLOATS = (FWD_SPLIT - 1) * 128 * 10;
+    constexpr int REC_FLOATS = FWD_BATCH * 12;
+    __shared__ float4 lds_rec[(REC_FLOATS > PART_FLOATS ? REC_FLOATS : PART_FLOATS) / 4];
+    __shared__ uint16_t sidx[2][FWD_BATCH];    // per pixel half: the batch's surviving entries (record byte offsets / 16), list order
+    __shared__ int scnt[2][FWD_SEGS];          // survivors per staging wave
+    FWD_STAMP(0);
     const int tile_id = blockIdx.x;
     const int ty = tile_id / tw, tx = tile_id - ty * tw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: loop bounds below)
     const int list_part = wave >> 1, pix_half = wave & 1;
     const int row = ty * 16 + pix_half * 8 + (lane >> 3), col = tx * 16 + 2 * (lane & 7);
     const bool in0 = (row < H) && (col < W), in1 = (row < H) && (col + 1 < W);
@@ -171,116 +186,83 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const int range_start = tile_offsets[tile_id];
     const int range_end = (tile_id == tw * th - 1) ? n_isects : tile_offsets[tile_id + 1];
     constexpr float LOG2E = 1.4426950408889634f;
+    const unsigned long long lt = lanemask_lt();
 
-#if GPS_FWD_PREFETCH
-    // Staging is software-pipelined: the records of batch b + 1 (and the list entries of batch b + 2) are requested BEFORE batch b is
-    // evaluated and land in registers while the waves compute, so a tile pays the two dependent gathers (list entry -> record) once,
-    // not once per batch -- and the workgroups of a CU, which start together, no longer all sit in their staging phase at once.
-    // unconditional, clamped loads in straight-line code (a thread past the end of the list re-reads the last entry and does
-    // not store it): a branch around a load makes the compiler wait for it at the branch's merge point
-    const int last = max(range_end - 1, 0);
-    int g_next = flatten_ids[min(range_start + tid, last)];
-    float4 pa = recs[3 * (size_t)g_next], pb = recs[3 * (size_t)g_next + 1], pc = recs[3 * (size_t)g_next + 2];
-    g_next = flatten_ids[min(range_start + BATCH + tid, last)];
-#endif
-    for (int batch_start = range_start; batch_start < range_end; batch_start += BATCH) {
-        __syncthreads();
-#if GPS_FWD_PREFETCH
-        // (the empty asm pins the use of the prefetched registers HERE: without it the compiler hoists the record's rewrite to
-        // right behind the loads and waits for them before the evaluation loop)
-        asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w), "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w), "+v"(pc.x), "+v"(pc.y));
-        if (batch_start + tid < range_end) {
-            r0[tid] = make_float4(pa.x, pa.y, 0.5f * LOG2E * pa.z, LOG2E * pa.w);
-            r1[tid] = make_float4(0.5f * LOG2E * pb.x, -__log2f(pb.y), pb.z, pb.w);
-            r2[tid] = make_float2(pc.x, pc.y);
+    for (int batch_start = range_start; batch_start < range_end; batch_start += FWD_BATCH) {
+        __syncthreads();   // the previous batch's records and lists are consumed
+        const int idx = batch_start + tid;
+        bool h0 = false, h1 = false;
+        if (idx < range_end) {
+            const size_t g = (size_t)flatten_ids[idx];
+            const float4 a = recs[3 * g], b = recs[3 * g + 1], c = recs[3 * g + 2];
+            lds_rec[3 * tid] = make_float4(a.x, a.y, 0.5f * LOG2E * a.z, LOG2E * a.w);
+            lds_rec[3 * tid + 1] = make_float4(0.5f * LOG2E * b.x, -__log2f(b.y), b.z, b.w);
+            lds_rec[3 * tid + 2] = make_float4(c.x, c.y, 0.f, 0.f);
+            const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
+            const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16, y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
+            const bool in_x = x_lo <= x_hi && y_lo <= y_hi && x_lo <= tx * 16 + 15 && x_hi >= tx * 16;
+            h0 = in_x && y_lo <= ty * 16 + 7 && y_hi >= ty * 16;
+            h1 = in_x && y_lo <= ty * 16 + 15 && y_hi >= ty * 16 + 8;
         }
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        if (lane == 0) { scnt[0][wave] = __popcll(m0); scnt[1][wave] = __popcll(m1); }
+        FWD_STAMP(1);
         __syncthreads();
-        pa = recs[3 * (size_t)g_next]; pb = recs[3 * (size_t)g_next + 1]; pc = recs[3 * (size_t)g_next + 2];
-        g_next = flatten_ids[min(batch_start + 2 * BATCH + tid, last)];
+        // survivors in front of this staging wave, per half; S = all survivors of the half this wave will EVALUATE
+        int base0 = 0, base1 = 0, S = 0;
+#pragma unroll
+        for (int w = 0; w < FWD_SEGS; w++) {
+            const int c0 = scnt[0][w], c1 = scnt[1][w];
+            if (w < wave) { base0 += c0; base1 += c1; }
+            S += pix_half ? c1 : c0;
+        }
+        if (h0) sidx[0][base0 + __popcll(m0 & lt)] = (uint16_t)(3 * tid);
+        if (h1) sidx[1][base1 + __popcll(m1 & lt)] = (uint16_t)(3 * tid);
+        __syncthreads();
+        FWD_STAMP(2);
+        S = __builtin_amdgcn_readfirstlane(S);
+        const int lo = list_part * S / FWD_SPLIT, cnt = (list_part + 1) * S / FWD_SPLIT - lo;   // this wave's survivors
+        // lane j of vector k holds the LDS byte address of survivor lo + 64 k + j
+        int addr[FWD_VECS];
+#pragma unroll
+        for (int k = 0; k < FWD_VECS; k++) addr[k] = (64 * k + lane < cnt) ? 16 * (int)sidx[pix_half][lo + 64 * k + lane] : 0;
+        const char* rec_bytes = reinterpret_cast<const char*>(lds_rec);
+        auto blend = [&](int byte_off) {
+            const float4 a = *reinterpret_cast<const float4*>(rec_bytes + byte_off);
+            const float4 b = *reinterpret_cast<const float4*>(rec_bytes + byte_off + 16);
+            const float2 c = *reinterpret_cast<const float2*>(rec_bytes + byte_off + 32);
+            const float dy = a.y - py;
+            const v2f dx = a.x - px;
+            const float cdy2 = b.x * dy * dy, bdy = a.w * dy;
+            const v2f w = a.z * dx + bdy;
+            const v2f sig = w * dx + cdy2;        // sigma * log2(e)
+            const v2f e = sig + b.y;              // sigma' - log2(opacity)
+            float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.x));
+            float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.y));
+#ifdef GPS_FWD_EXPERIMENT_NOTESTS   // (probe only: upper bound of what dropping the per-pixel depth / sigma tests can give)
+            const bool hit0 = !(al0 < 1.f / 255.f), hit1 = !(al1 < 1.f / 255.f);
 #else
-        {
-            const int idx = batch_start + tid;
-            if (tid < BATCH && idx < range_end) {
-                const size_t g = (size_t)flatten_ids[idx];
-                const float4 a = recs[3 * g], b = recs[3 * g + 1], c = recs[3 * g + 2];
-                r0[tid] = make_float4(a.x, a.y, 0.5f * LOG2E * a.z, LOG2E * a.w);
-                r1[tid] = make_float4(0.5f * LOG2E * b.x, -__log2f(b.y), b.z, b.w);
-                r2[tid] = make_float2(c.x, c.y);
-            }
-        }
-        __syncthreads();
+            const bool hit0 = !(b.z > cut0) && !(sig.x < 0.f) && !(al0 < 1.f / 255.f);
+            const bool hit1 = !(b.z > cut1) && !(sig.y < 0.f) && !(al1 < 1.f / 255.f);
 #endif
-        const int n = min(BATCH, range_end - batch_start);
-        // wave-uniform bounds -> scalar loop counter
-        const int lo = __builtin_amdgcn_readfirstlane(list_part * n / FWD_SPLIT);
-        const int hi = __builtin_amdgcn_readfirstlane((list_part + 1) * n / FWD_SPLIT);
-        // Wave-uniform skip (test()): if e > 8 for both pixels of every lane, no pixel of this wave's 16 x 8 half tile can reach
-        // alpha >= 1/255 (v_exp_f32 is within 1 ulp: exp2(-e) <= 2^-8 (1 + 2^-22) < 1/255), so the Gaussian adds exact zeros
-        // here -- and the two quarter-rate exponentials, the tests and the five packed accumulations are most of the body.
-        // 45 % of a tile's list entries do not reach a given half (radius-4.5 footprints on 16-pixel tiles): 81.6 -> 69.5 us,
-        // bit-identical output.
-        // Two entries per trip, written out by hand (the skip keeps the compiler from unrolling): both records' LDS reads leave
-        // together and the two independent test chains fill each other's packed-FP32 dependency slots (4 s_nop per entry in
-        // the one-at-a-time loop); entries still accumulate in list order, so the sums are bit-identical.
-        struct Entry { float4 a, b; v2f sig, e; };
-        auto test = [&](Entry& g) -> bool {
-            const float dy = g.a.y - py;
-            const v2f dx = g.a.x - px;
-            const float cdy2 = g.b.x * dy * dy, bdy = g.a.w * dy;
-            const v2f w = g.a.z * dx + bdy;
-            g.sig = w * dx + cdy2;        // sigma * log2(e)
-            g.e = g.sig + g.b.y;          // sigma' - log2(opacity)
-            return __builtin_amdgcn_ballot_w64(!(g.e.x > 8.0f) || !(g.e.y > 8.0f)) != 0;
-        };
-        auto blend = [&](const Entry& g, const float2 c) {
-            const float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-g.e.x));
-            const float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-g.e.y));
-            const bool hit0 = !(g.b.z > cut0) && !(g.sig.x < 0.f) && !(al0 < 1.f / 255.f);
-            const bool hit1 = !(g.b.z > cut1) && !(g.sig.y < 0.f) && !(al1 < 1.f / 255.f);
             const v2f al = {hit0 ? al0 : 0.f, hit1 ? al1 : 0.f};
-            o0 += g.b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += g.b.z * al; ws += al;
+            o0 += b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += b.z * al; ws += al;
         };
-#if GPS_FWD_LDS_AHEAD
-        // The records of the NEXT pair are read from LDS while the current pair is evaluated (two pairs alternate, written out by
-        // hand so that no register moves are needed): a trip no longer starts by waiting for its own ds_reads -- the counters
-        // showed 43 % of the wave cycles parked on waits.  Reads past the part's end are clamped and their entries not evaluated.
-        const int last_t = max(hi - 1, lo);
-        auto fetch = [&](Entry& g, float2& c, int t) {
-            const int tt = min(t, last_t);
-            g.a = r0[tt]; g.b = r1[tt];
-            if (GPS_FWD_LDS_AHEAD >= 2) c = r2[tt];
-        };
-        auto eval = [&](Entry& g, const float2 c, int t) {
-            if (t < hi && test(g)) blend(g, GPS_FWD_LDS_AHEAD >= 2 ? c : r2[min(t, last_t)]);
-        };
-        if (lo < hi) {
-            Entry A0, A1, B0, B1;
-            float2 cA0 = {}, cA1 = {}, cB0 = {}, cB1 = {};
-            fetch(A0, cA0, lo); fetch(A1, cA1, lo + 1);
-            for (int t = lo; t < hi; t += 4) {
-                fetch(B0, cB0, t + 2); fetch(B1, cB1, t + 3);
-                eval(A0, cA0, t); eval(A1, cA1, t + 1);
-                fetch(A0, cA0, t + 4); fetch(A1, cA1, t + 5);
-                eval(B0, cB0, t + 2); eval(B1, cB1, t + 3);
+#pragma unroll
+        for (int k = 0; k < FWD_VECS; k++) {
+            const int n_k = min(cnt - 64 * k, 64);   // wave-uniform
+            for (int j = 0; j + 1 < n_k; j += 2) {   // two survivors per trip: their records leave LDS together
+                const int t0 = __builtin_amdgcn_readlane(addr[k], j), t1 = __builtin_amdgcn_readlane(addr[k], j + 1);
+                blend(t0);
+                blend(t1);
             }
+            if (n_k > 0 && (n_k & 1)) blend(__builtin_amdgcn_readlane(addr[k], n_k - 1));
         }
-#else
-        int t = lo;
-        for (; t + 1 < hi; t += 2) {
-            Entry g0, g1;
-            g0.a = r0[t]; g0.b = r1[t]; g1.a = r0[t + 1]; g1.b = r1[t + 1];
-            const bool k0 = test(g0), k1 = test(g1);
-            if (k0) blend(g0, r2[t]);
-            if (k1) blend(g1, r2[t + 1]);
-        }
-        if (t < hi) {
-            Entry g0;
-            g0.a = r0[t]; g0.b = r1[t];
-            if (test(g0)) blend(g0, r2[t]);
-        }
-#endif
     }
-    // list parts 1.. -> LDS -> part 0 adds them in order and stores
+    // list parts 1.. -> LDS (over the records) -> part 0 adds them in order and stores
+    FWD_STAMP(3);
+    __syncthreads();   // every wave is done with the records
+    float* part = reinterpret_cast<float*>(lds_rec);
     const int slot = (pix_half * 64 + lane) * 10;
     if (list_part) {
         float* q = part + (list_part - 1) * 1280 + slot;
@@ -288,6 +270,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
         q[5] = o0.y; q[6] = o1.y; q[7] = o2.y; q[8] = o3.y; q[9] = ws.y;
     }
     __syncthreads();
+    FWD_STAMP(4);
     if (!list_part) {
         const int pix = row * W + col;
 #pragma unroll
@@ -310,7 +293,9 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
             if (lane == 0) atomicAdd(fc.loss, lsum * fc.inv_count);
         }
     }
+    FWD_STAMP(5);
 }
+
 
 __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restrict__ v_means2d,
                                                         float* __restrict__ v_conics, float* __restrict__ v_colors,

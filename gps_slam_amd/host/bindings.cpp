@@ -259,6 +259,13 @@ PYBIND11_MODULE(_host, m) {
             return std::make_tuple(p.trace_live, p.trace_counters, p.trace_poses);
         })
         .def("removeRedundantGs", &SLAMPipeline::removeRedundantGs)
+        .def("checkKeyFrameError", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } p.checkKeyFrameError(); })
+        .def("keyframeLossDict", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return p.keyframe_loss_dict; })
+        .def("appendOptView", [](SLAMPipeline& p, const Camera& cam, TensorDict rc) {   // tests: a history view by hand
+            p.opt_cam_list.push_back(cam); p.opt_raycast_list.push_back(std::move(rc));
+        })
+        .def_readwrite("sample_method", &SLAMPipeline::sample_method)
+        .def_readwrite("loss_thres", &SLAMPipeline::loss_thres)
         .def_readwrite("large_scale_thres", &SLAMPipeline::large_scale_thres)
         .def_readwrite("small_scale_thres", &SLAMPipeline::small_scale_thres)
         .def_readwrite("low_opac_thres", &SLAMPipeline::low_opac_thres)

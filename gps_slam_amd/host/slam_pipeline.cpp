@@ -71,6 +71,9 @@ void SLAMPipeline::loadConfig(const Config& c) {
     work_mode = c.gets("work_mode", work_mode);
     ssim_weight = (float)c.get("ssim_weight", ssim_weight);    // LOSS section of the configs (office0.yaml:37-39)
     depth_weight = (float)c.get("depth_weight", depth_weight);
+    sample_method = c.gets("sample_method", sample_method);   // keyframe_sample_configs
+    loss_thres = (float)c.get("loss_thres", loss_thres);
+    TORCH_CHECK(sample_method == "random" || sample_method == "ours", "sample_method: 'random' or 'ours', got '", sample_method, "'");
 }
 
 // ------------------------------------------------------------------ raycast -> tensors (runRaycastByCam :362-415)
@@ -186,7 +189,10 @@ void SLAMPipeline::updateFrameList() {
         const float trans = std::sqrt(dx * dx + dy * dy + dz * dz);
         is_key = theta > keyframe_theta_thres || trans > keyframe_trans_thres;
     }
-    if (is_key) keyframe_cam_list.push_back(curr_cam);
+    if (is_key) {
+        keyframe_cam_list.push_back(curr_cam);
+        keyframe_loss_dict[curr_cam.id] = {0.1f, (float)curr_frame_id, 0.f, 0.f, 0.f};   // slam_pipeline.cpp:355
+    }
 }
 
 void SLAMPipeline::localFrameRaycast() { raycastWindow(localframe_cam_window, main_engine->camPoses); }
@@ -285,7 +291,8 @@ void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std:
     opt_cam_list.assign(window.begin(), window.end());
     opt_raycast_list.assign(localframe_raycast_window.begin(), localframe_raycast_window.end());
     opt_raycast_events_ = window_raycast_events_;
-    const int n = std::min<int>(keyframe_select_max, (int)keyframes.size());
+    const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframes.size()) : 0;   // :538
+    if (n == 0) return;
     RandomSelector<Camera> sel(keyframes, rng_);
     std::vector<const Camera*> cams;
     for (int k = 0; k < n; k++) {
@@ -309,7 +316,7 @@ void SLAMPipeline::raycastWindowAndKeyframes(const std::deque<Camera>& window, c
     std::vector<const Camera*> cams;
     for (const Camera& cam : window) cams.push_back(&cam);
     opt_cam_list.assign(window.begin(), window.end());
-    const int n = std::min<int>(keyframe_select_max, (int)keyframes.size());
+    const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframes.size()) : 0;   // :538
     RandomSelector<Camera> sel(keyframes, rng_);
     for (int k = 0; k < n; k++) {
         const Camera* cam = sel.getNext().second;
@@ -354,6 +361,27 @@ void SLAMPipeline::initNewGaussiansFor(TensorDict& rm, const Camera& cam) {
                                 current_stream()), "gps_new_gaussian_mask");
     rm["normal_map"] = computeNormalMap(vertex);
     stats.added += model->addGaussians(cam, rm, mask, new_gs_sample_ratio, frame_num, gen_);
+}
+
+// ------------------------------------------------------------------ checkKeyFrameError :293-317
+// The loss record of every history keyframe in the current optimise list (the entries behind the local window's).
+void SLAMPipeline::checkKeyFrameError() {
+    torch::NoGradGuard no_grad;
+    Config wc;
+    wc.num["ssim_weight"] = ssim_weight; wc.num["depth_weight"] = depth_weight;
+    for (size_t k = localframe_cam_window.size(); k < opt_cam_list.size(); k++) {
+        const Camera& cam = opt_cam_list[k];
+        TensorDict& rc = opt_raycast_list[k];
+        if (k < opt_raycast_events_.size()) waitRaycast(opt_raycast_events_[k]);
+        auto res = model->forward(cam, rc.at("depth_map"), rc.at("color_map"));
+        auto loss = model->computeLoss(res, cam, wc, rc.at("depth_map") > 0);
+        const float total = loss.at("total").item<float>();
+        const float confidence_mean = rc.at("confidence_map").mean().item<float>();
+        auto it = keyframe_loss_dict.find(cam.id);
+        float opt_count = it != keyframe_loss_dict.end() && it->second.size() > 3 ? it->second[3] : 0.f;
+        if (total > loss_thres) opt_count += 1.f;
+        keyframe_loss_dict[cam.id] = {total, (float)curr_frame_id, confidence_mean, opt_count};
+    }
 }
 
 // ------------------------------------------------------------------ localOptimize :195-289
@@ -543,6 +571,7 @@ void SLAMPipeline::keyframeStep() {
     initNewGaussians(localframe_raycast_window.back());
     localOptimize();
     removeRedundantGs();
+    if (sample_method == "ours") checkKeyFrameError();   // slam_pipeline.cpp:130-131
     waitAllRaycasts();  // the next frame's fusion modifies the volume (results no iteration drew would still be in flight)
 }
 
@@ -557,7 +586,11 @@ void SLAMPipeline::keyframeStepOverlapped() {
     hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
     {
         c10::hip::HIPStreamGuard guard(ms);
-        if (prune_pending_) { removeRedundantGs(); prune_pending_ = false; }  // update k's prune, before update k+1 reads the model
+        if (prune_pending_) {   // update k's prune (and loss records), before update k+1 reads the model and replaces the lists
+            removeRedundantGs();
+            if (sample_method == "ours") checkKeyFrameError();
+            prune_pending_ = false;
+        }
         if (merge_keyframe_raycasts) raycastWindowAndKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses);
         else { localFrameRaycast(); keyFrameRaycast(); }
         if (async_raycasts) waitAllRaycasts();  // (this arrangement keeps its single map stream: the gate below covers them)
@@ -637,6 +670,7 @@ void SLAMPipeline::mapWorker(int device_index) {
             initNewGaussiansFor(localframe_raycast_window.back(), job_.curr_cam);
             localOptimize();
             removeRedundantGs();
+            if (sample_method == "ours") checkKeyFrameError();
             waitAllRaycasts();
             hip_ok(hipStreamSynchronize(ms.stream()), "hipStreamSynchronize");
             { std::lock_guard<std::mutex> lk(mu_); done_seq_ = seen; }
@@ -683,6 +717,7 @@ void SLAMPipeline::flush() {
     if (prune_pending_) {
         c10::hip::HIPStreamGuard guard(static_cast<MapStream*>(map_stream_)->s);
         removeRedundantGs();
+        if (sample_method == "ours") checkKeyFrameError();
         prune_pending_ = false;
         hip_ok(hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream()), "hipStreamSynchronize");
     }

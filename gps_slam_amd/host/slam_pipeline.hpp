@@ -13,6 +13,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -109,6 +110,13 @@ public:
     std::vector<Camera> opt_cam_list;
     std::vector<TensorDict> opt_raycast_list;
     float keyframe_theta_thres = 30.0f, keyframe_trans_thres = 0.3f;
+    // keyframe_sample_configs (slam_pipeline.cpp:130, 293-317, 538): "random" draws keyframe_select_max history keyframes per update;
+    // "ours" -- as the reference ships it -- adds NO history views (keyFrameRaycast has a "random" branch only) and keeps a loss
+    // record per keyframe: {loss, frame id of the check, mean raycast confidence, number of checks with loss > loss_thres}
+    std::string sample_method = "random";
+    float loss_thres = 0.0f;
+    std::map<int, std::vector<float>> keyframe_loss_dict;
+    void checkKeyFrameError();
     float new_gs_sample_ratio = 0.25f, color_error_thres = 0.05f;
     float depth_vis_max = 5.0f, depth_vis_min = 0.0f, alpha_vis_max = 5.0f;
     float large_scale_thres = 0.1f, small_scale_thres = 0.003f, low_opac_thres = 0.005f;

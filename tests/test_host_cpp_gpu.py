@@ -323,6 +323,57 @@ def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():
         assert np.array_equal(n_(e["raycast_depth_u16"]), d_mm)
 
 
+def test_sample_method_ours_keeps_a_loss_record_per_keyframe_and_adds_no_history_views():
+    """keyframe_sample_configs.sample_method == "ours" as the reference ships it (slam_pipeline.cpp:130-131, 293-317, 538): the
+    optimise list holds the local window only (keyFrameRaycast has a "random" branch and nothing else), every keyframe gets
+    the record {0.1, frame, 0, 0, 0} when it is added (:355), and checkKeyFrameError() rewrites the records of the history views in
+    the list as {loss.total with the raycast's depth > 0 mask, current frame, mean confidence, count of losses above loss_thres}."""
+    h = _host()
+    W, Hh, n = 160, 120, 21
+    seq = synth.make_sequence(W, Hh, n, step_deg=0.5)
+    rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
+    rgb = torch.as_tensor(rgba).to(DEV)
+    dep = torch.as_tensor(seq["depth"].astype(np.int16)).to(DEV)
+    eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    model = h.SLAMGaussianModel()
+    model.loadConfig(dict(capacity=1 << 17))
+    pipe = h.SLAMPipeline(eng, model, 7)
+    pipe.loadConfig(dict(sample_method="ours", loss_thres=0.01, keyframe_theta_thres=1.0, keyframe_trans_thres=0.02))
+    with pytest.raises(Exception):
+        pipe.loadConfig(dict(sample_method="nearest"))
+    cams = []
+    for i in range(n):
+        cam = h.Camera(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        cam.id = i
+        cam.image, cam.depth = rgb[i][..., :3].float() / 255.0, (dep[i].float() / 1000.0).unsqueeze(-1)
+        pipe.processFrame(i, cam, rgb[i], dep[i])
+        cams.append(cam)
+    torch.cuda.synchronize()
+    st = pipe.stats()
+    opt = pipe.optCams()
+    assert st["opt_iters"] == 40 and 1 <= len(opt) <= 2             # window views only: no history keyframes were raycast
+    rec = pipe.keyframeLossDict()
+    assert len(rec) >= 3 and all(v[0] == pytest.approx(0.1) and v[2:] == [0.0, 0.0, 0.0] for v in rec.values()), rec
+    assert all(v[1] == float(k) for k, v in rec.items())            # recorded at the frame that became the keyframe
+    # a history view by hand: the record becomes the loss of that view
+    key_id = sorted(rec)[1]
+    kc = cams[key_id]
+    rc = pipe.runRaycastByCam(kc, False)
+    pipe.appendOptView(kc, rc)
+    pipe.checkKeyFrameError()
+    with torch.no_grad():
+        res = model.forward(kc, rc["depth_map"], rc["color_map"])
+        m = (rc["depth_map"] > 0).expand_as(res["rgb"])
+        want = (kc.image.to(DEV)[m] - res["rgb"][m]).abs().mean().item()
+    got = pipe.keyframeLossDict()[key_id]
+    assert got[0] == pytest.approx(want, rel=1e-5) and got[1] == float(n - 1)
+    assert got[2] == pytest.approx(rc["confidence_map"].mean().item(), rel=1e-6) and got[3] == (1.0 if want > 0.01 else 0.0)
+    pipe.checkKeyFrameError()                                      # the count accumulates
+    assert pipe.keyframeLossDict()[key_id][3] == (2.0 if want > 0.01 else 0.0)
+    untouched = [k for k in rec if k != key_id]
+    assert all(pipe.keyframeLossDict()[k] == rec[k] for k in untouched)
+
+
 def test_full_loop_at_1280x720_cpp_host():
     """BASELINE configs[3] geometry (1280x720, 80x45 = 3600 tiles -> 12 sort bits, 921,600 rays): one keyframe block of the
     whole loop through the C++ host; TSDF state equals the Python host's, the optimised render beats the TSDF colour."""
