@@ -14,7 +14,7 @@ constexpr int REPS = 2000;
 #define BODY16(STMT) STMT(0) STMT(1) STMT(2) STMT(3) STMT(4) STMT(5) STMT(6) STMT(7) STMT(8) STMT(9) STMT(10) STMT(11) STMT(12) STMT(13) STMT(14) STMT(15)
 
 template <int OP>
-__global__ __launch_bounds__(512) void rate_kernel(uint64_t* __restrict__ out, float seed) {
+__global__ __launch_bounds__(1024) void rate_kernel(uint64_t* __restrict__ out, float seed) {
     __shared__ float4 lds[64];
     float a[16];
     float b = seed + 1.0f, c = seed * 0.5f;
@@ -109,6 +109,45 @@ __global__ __launch_bounds__(512) void rate_kernel(uint64_t* __restrict__ out, f
 #define S(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
             BODY16(S)
 #undef S
+        } else if (OP == 20) {  // packed FMA with one operand broadcast from a register half (what scalar x {px0, px1} compiles to)
+#define S(k) asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[0,1,1]" : "+v"(p[k]) : "v"(pb), "v"(pc));
+            BODY16(S)
+#undef S
+        } else if (OP == 21) {
+#define S(k) asm volatile("v_pk_add_f32 %0, %1, %0 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[k]) : "v"(pb));
+            BODY16(S)
+#undef S
+        } else if (OP == 22) {  // compare into an SGPR pair (VOP3)
+#define S(k) asm volatile("v_cmp_ngt_f32_e64 s[20:21], %0, %1" : : "v"(a[k]), "v"(b) : "s20", "s21");
+            BODY16(S)
+#undef S
+        } else if (OP == 23) {  // select by an SGPR-pair mask (VOP3)
+#define S(k) asm volatile("v_cndmask_b32_e64 %0, 0, %0, s[20:21]" : "+v"(a[k]) : : );
+            BODY16(S)
+#undef S
+        } else if (OP == 24) {
+#define S(k) asm volatile("v_readlane_b32 s22, %0, s23" : : "v"(a[k]) : "s22");
+            BODY16(S)
+#undef S
+        } else if (OP == 25) {  // 32-bit literal operand
+#define S(k) asm volatile("v_min_f32 %0, 0x3f7fbe77, %0" : "+v"(a[k]));
+            BODY16(S)
+#undef S
+        } else if (OP == 26) {  // SGPR operand
+#define S(k) asm volatile("v_mul_f32 %0, s24, %0" : "+v"(a[k]));
+            BODY16(S)
+#undef S
+        } else if (OP == 27) {  // VOP3 with a source modifier
+#define S(k) asm volatile("v_exp_f32_e64 %0, -%0" : "+v"(a[k]));
+            BODY16(S)
+#undef S
+        } else if (OP == 28) {  // the forward rasterizer's pair: 2 LDS reads (b128, b128 broadcast) per 8 FMAs
+#define S(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            BODY16(S)
+#undef S
+            float4 q0, q1;
+            asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(q0), "=v"(q1) : "v"(laddr));
+            a[0] += q0.x + q1.y;
         } else if (OP == 19) {  // DEPENDENT chain of v_fma (latency)
 #define S(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
             BODY16(S)
@@ -128,8 +167,11 @@ template <int OP>
 int run(const char* name, uint64_t* d_out) {
     printf("%-28s", name);
     for (int wps : {1, 2, 4, 8}) {
-        const int threads = 256 * (wps > 2 ? 2 : wps);           // 4 or 8 waves per workgroup
-        const int blocks_per_cu = wps > 2 ? wps / 2 : 1;
+        // ONE workgroup per CU up to 4 waves per SIMD (its waves start together and stay resident together: a steady state --
+        // several smaller workgroups per CU start skewed and the average per-wave time then underestimates the contention);
+        // 8 per SIMD = two 1,024-thread workgroups per CU
+        const int threads = 256 * (wps > 4 ? 4 : wps);
+        const int blocks_per_cu = wps > 4 ? wps / 4 : 1;
         const int blocks = 256 * blocks_per_cu;
         const int waves = blocks * threads / 64;
         CK(hipMemset(d_out, 0, (waves + 1) * 8));
@@ -168,6 +210,15 @@ int main() {
                REPS * 16, ms * 1e3, (unsigned long long)h[1], (double)h[1] / (ms * 1e6));
     }
     run<0>("v_fma_f32", d_out);
+    run<20>("v_pk_fma_f32 op_sel_hi", d_out);
+    run<21>("v_pk_add_f32 neg+op_sel", d_out);
+    run<22>("v_cmp_e64 -> sgpr pair", d_out);
+    run<23>("v_cndmask_e64 sgpr mask", d_out);
+    run<24>("v_readlane_b32", d_out);
+    run<25>("v_min_f32 literal", d_out);
+    run<26>("v_mul_f32 sgpr operand", d_out);
+    run<27>("v_exp_f32_e64 neg", d_out);
+    run<28>("16 v_fma + 2 ds_read_b128", d_out);
     run<19>("v_fma_f32 dependent", d_out);
     run<1>("v_pk_fma_f32", d_out);
     run<10>("v_pk_mul_f32", d_out);
