@@ -38,12 +38,13 @@ def fusion_bytes(P, V, S):
     return float(6 * P + 6 * P + 4 * P + 32 * P + 2 * S * 17 + V * 8192 + V * 16 + 8 * P / 64.0 + 20 * P)
 
 
-def _python_twin(scene, device):
+def _python_twin(scene, device, strip_backward=True):
     """The C++ model's state in the Python mirror (same C-ABI, same buffer layout) for the per-kernel measurements below;
-    the timed region never touched it."""
+    the timed region never touched it.  strip_backward=False: the round-2 route (sorted keys, group tables, group backward) --
+    what the probes that time the operator-level group kernel need."""
     from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
     cp = scene.model.getGaussianParms()
-    model = SLAMGaussianModel(dict(capacity=1 << 19, isect_capacity=8 << 20), device=device)
+    model = SLAMGaussianModel(dict(capacity=1 << 19, isect_capacity=8 << 20, strip_backward=strip_backward), device=device)
     model.add_params(dict(means=cp.getMeans().clone(), scales=cp.getScales().clone(), quats=cp.getQuats().clone(),
                           featuresDc=cp.getFeaturesDc().clone(), featuresRest=cp.getFeaturesRest().clone(),
                           opacities=cp.getOpacities().clone()))
@@ -55,8 +56,9 @@ def _python_twin(scene, device):
     return model, cam, rc
 
 
-VALU_CYCLES = 2.0   # a wave64 VALU instruction on CDNA4's SIMD-32 (MI355X_MICROARCH.md; tools/probe/valu_rate.hip measures 1.5-1.7
-#                     shader cycles per instruction per SIMD at 8 waves, 2.9 for v_exp / v_rcp, 3.5 for v_permlane*_swap)
+VALU_CYCLES = 2.0   # a wave64 VALU instruction on CDNA4's SIMD-32 (MI355X_MICROARCH.md; tools/probe/valu_rate.hip: 1.8 s_memtime
+#                     ticks per instruction per SIMD with 8 resident waves in steady state -- v_fma, packed and VOP3 / SGPR / literal
+#                     forms alike --, 3.4 for v_exp / v_rcp, 3.7 for v_readlane; ONE wave issues at most one per 5.3 ticks)
 SHADER_GHZ = 2.4
 
 

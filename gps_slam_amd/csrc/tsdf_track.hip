@@ -819,10 +819,28 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                 }
                 if (!got) {
-                    // the pre-launched kernel gave up before its line arrived (this thread was descheduled for longer than
-                    // ARG_TIMEOUT between the launch and the publish): retire what is queued and evaluate with a plain launch
+                    // No answer within the spin budget.  Either launch `seq` gave up before its line arrived (this thread was
+                    // descheduled for longer than ARG_TIMEOUT between the launch and the publish) or it has not STARTED yet (the
+                    // stream is held behind another stream's gate).  There is one argument line: launch seq + 1 may only be
+                    // retired through it once launch seq is known to have read it -- otherwise seq, starting late, would never
+                    // find its line and sit out ARG_TIMEOUT with the frame stream behind it.  So: leave RUN(seq) in place and wait
+                    // until seq has answered after all (tags) or has retired itself (acknowledgement word).
+                    bool late = false, gone = false;
+                    for (long spin = 0; spin < 400000000L && !late && !gone; spin++) {
+                        late = float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq;
+                        gone = float_bits(mailbox[32]) == seq;
+                        if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+                    }
+                    if (!late && !gone) return GPS_ERR_LAUNCH;   // the stream is wedged; ~Pending retires the queued launch
+                    got = late;
+                }
+                if (!got) {
                     retire(pending.seq);
                     pending.seq = 0;
+                    // a launch that gave up may have left the evaluation ticket partially counted and rows half delivered:
+                    // both start from zero for the plain launch (the valid-pixel counts next to the ticket stay)
+                    if (hipMemsetAsync(w.sync, 0, sizeof(uint32_t), st) != hipSuccess) return GPS_ERR_LAUNCH;
+                    if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) return GPS_ERR_LAUNCH;
                     const int seq2 = next_seq();
                     if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                     else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);

@@ -17,7 +17,7 @@ seq = bench.synthetic_sequence(W, H, 31, 1234)
 seeds = bench.seed_gaussians(seq, NG, 1234, "cuda:0")
 scene = bench.Scene(seq, seeds, 1234, True, False, 31, 1.0, 0.02)
 scene.run(0, 31)
-model, cam, rc = _python_twin(scene, "cuda:0")
+model, cam, rc = _python_twin(scene, "cuda:0", strip_backward=False)   # (group tables for the group kernel)
 model.initOptimizers(-1, 1.0)
 model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
 torch.cuda.synchronize()
