@@ -155,9 +155,14 @@ extern "C" GPS_API void* gps_fwd_stamps() { void* p = nullptr; (void)hipGetSymbo
 // deterministic; a culled entry would have added +0.
 constexpr int FWD_SPLIT = GPS_FWD_LIST_SPLIT;
 constexpr int FWD_THREADS = 128 * FWD_SPLIT;
-constexpr int FWD_BATCH = FWD_THREADS;           // every thread stages one list entry per batch
-constexpr int FWD_SEGS = FWD_BATCH / 64;         // staging waves
+#ifndef GPS_FWD_BATCH
+#define GPS_FWD_BATCH 512
+#endif
+constexpr int FWD_BATCH = GPS_FWD_BATCH;         // list entries staged per batch (a thread stages FWD_TRIPS of them)
+constexpr int FWD_TRIPS = (FWD_BATCH + FWD_THREADS - 1) / FWD_THREADS;
+constexpr int FWD_SEGS = FWD_BATCH / 64;         // 64-entry segments of a batch (one ballot each)
 constexpr int FWD_VECS = (FWD_BATCH / FWD_SPLIT + 63) / 64;   // registers that hold a part's survivor addresses
+static_assert(FWD_BATCH % 64 == 0 && FWD_BATCH * 3 < 65536, "segments are whole waves; record slots are 16-bit");
 __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
@@ -190,34 +195,49 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
 
     for (int batch_start = range_start; batch_start < range_end; batch_start += FWD_BATCH) {
         __syncthreads();   // the previous batch's records and lists are consumed
-        const int idx = batch_start + tid;
-        bool h0 = false, h1 = false;
-        if (idx < range_end) {
-            const size_t g = (size_t)flatten_ids[idx];
-            const float4 a = recs[3 * g], b = recs[3 * g + 1], c = recs[3 * g + 2];
-            lds_rec[3 * tid] = make_float4(a.x, a.y, 0.5f * LOG2E * a.z, LOG2E * a.w);
-            lds_rec[3 * tid + 1] = make_float4(0.5f * LOG2E * b.x, -__log2f(b.y), b.z, b.w);
-            lds_rec[3 * tid + 2] = make_float4(c.x, c.y, 0.f, 0.f);
-            const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
-            const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16, y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
-            const bool in_x = x_lo <= x_hi && y_lo <= y_hi && x_lo <= tx * 16 + 15 && x_hi >= tx * 16;
-            h0 = in_x && y_lo <= ty * 16 + 7 && y_hi >= ty * 16;
-            h1 = in_x && y_lo <= ty * 16 + 15 && y_hi >= ty * 16 + 8;
+        bool h0[FWD_TRIPS], h1[FWD_TRIPS];
+        int r0[FWD_TRIPS], r1[FWD_TRIPS];   // rank among the segment's survivors
+#pragma unroll
+        for (int u = 0; u < FWD_TRIPS; u++) {
+            const int k = u * FWD_THREADS + tid;   // slot in the batch; segment k >> 6 = u * (FWD_THREADS / 64) + wave
+            const int idx = batch_start + k;
+            h0[u] = false; h1[u] = false;
+            if (k < FWD_BATCH && idx < range_end) {
+                const size_t g = (size_t)flatten_ids[idx];
+                const float4 a = recs[3 * g], b = recs[3 * g + 1], c = recs[3 * g + 2];
+                lds_rec[3 * k] = make_float4(a.x, a.y, 0.5f * LOG2E * a.z, LOG2E * a.w);
+                lds_rec[3 * k + 1] = make_float4(0.5f * LOG2E * b.x, -__log2f(b.y), b.z, b.w);
+                lds_rec[3 * k + 2] = make_float4(c.x, c.y, 0.f, 0.f);
+                const int xb = __float_as_int(c.z), yb = __float_as_int(c.w);
+                const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16, y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
+                const bool in_x = x_lo <= x_hi && y_lo <= y_hi && x_lo <= tx * 16 + 15 && x_hi >= tx * 16;
+                h0[u] = in_x && y_lo <= ty * 16 + 7 && y_hi >= ty * 16;
+                h1[u] = in_x && y_lo <= ty * 16 + 15 && y_hi >= ty * 16 + 8;
+            }
+            const unsigned long long m0 = __ballot(h0[u]), m1 = __ballot(h1[u]);
+            r0[u] = __popcll(m0 & lt); r1[u] = __popcll(m1 & lt);
+            const int seg = u * (FWD_THREADS / 64) + wave;
+            if (lane == 0 && seg < FWD_SEGS) { scnt[0][seg] = __popcll(m0); scnt[1][seg] = __popcll(m1); }
         }
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-        if (lane == 0) { scnt[0][wave] = __popcll(m0); scnt[1][wave] = __popcll(m1); }
         FWD_STAMP(1);
         __syncthreads();
-        // survivors in front of this staging wave, per half; S = all survivors of the half this wave will EVALUATE
-        int base0 = 0, base1 = 0, S = 0;
+        // exclusive prefix of the segments' survivor counts, per half (wave-uniform values); S = all survivors of the half this
+        // wave will EVALUATE
+        int pre0[FWD_SEGS + 1], pre1[FWD_SEGS + 1];
+        pre0[0] = 0; pre1[0] = 0;
 #pragma unroll
-        for (int w = 0; w < FWD_SEGS; w++) {
-            const int c0 = scnt[0][w], c1 = scnt[1][w];
-            if (w < wave) { base0 += c0; base1 += c1; }
-            S += pix_half ? c1 : c0;
+        for (int w = 0; w < FWD_SEGS; w++) { pre0[w + 1] = pre0[w] + scnt[0][w]; pre1[w + 1] = pre1[w] + scnt[1][w]; }
+        int S = pix_half ? pre1[FWD_SEGS] : pre0[FWD_SEGS];
+#pragma unroll
+        for (int u = 0; u < FWD_TRIPS; u++) {
+            const int k = u * FWD_THREADS + tid;
+            int b0 = 0, b1 = 0;
+#pragma unroll
+            for (int w = 0; w < FWD_SEGS; w++)   // (the segment index is wave-uniform: a scalar select)
+                if (w == u * (FWD_THREADS / 64) + wave) { b0 = pre0[w]; b1 = pre1[w]; }
+            if (h0[u]) sidx[0][b0 + r0[u]] = (uint16_t)(3 * k);
+            if (h1[u]) sidx[1][b1 + r1[u]] = (uint16_t)(3 * k);
         }
-        if (h0) sidx[0][base0 + __popcll(m0 & lt)] = (uint16_t)(3 * tid);
-        if (h1) sidx[1][base1 + __popcll(m1 & lt)] = (uint16_t)(3 * tid);
         __syncthreads();
         FWD_STAMP(2);
         S = __builtin_amdgcn_readfirstlane(S);
