@@ -127,7 +127,19 @@ def _workspace(dev, nbytes):
 def isect_tiles_no_depth(means2d, radii, tile_size, tile_width, tile_height, isect_capacity=None, group_capacity=None,
                          want_isect_ids=False, out=None):
     """isectTilesNoDepth + isectOffsetEncodeNoDepth (gsplat_wapper.cpp:55-91, isect_tiles_no_depth.cu:132-461)
-    in one sync-free call.  means2d[1,N,2], radii[1,N] (clamped)."""
+    in one call.  means2d[1,N,2], radii[1,N] (clamped).
+    With explicit capacities (or `out` buffers) the call is sync-free and an overflow is REPORTED in counts[2] (the lists are then
+    truncated).  With the default capacities the result must be complete, as the reference's exactly-sized tensors are: the
+    overflow word is read back (the reference blocks on two .item() calls here, isect_tiles_no_depth.cu:238-239) and the call is
+    repeated with doubled capacities until everything fits."""
+    if isect_capacity is None and group_capacity is None and out is None:
+        N_ = radii.numel()
+        icap, gcap = max(1 << 20, 16 * N_), max(1 << 20, 32 * N_)
+        while True:
+            r = isect_tiles_no_depth(means2d, radii, tile_size, tile_width, tile_height, icap, gcap, want_isect_ids)
+            if int(r.counts[2]) == 0:
+                return r
+            icap, gcap = 2 * icap, 2 * gcap
     means2d = _f32c(means2d)
     radii = radii.contiguous()
     assert radii.dtype == torch.int32
@@ -156,7 +168,15 @@ def isect_tiles_no_depth(means2d, radii, tile_size, tile_width, tile_height, ise
 
 def isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, isect_capacity=None, want_isect_ids=True):
     """isectTiles + isectOffsetEncode (gsplat_wapper.cpp:3-48, isect_tiles.cu:30-430): depth-keyed binning for the `raw`
-    render method, one sync-free call.  means2d[1,N,2], radii[1,N] (clamped), depths[1,N]."""
+    render method, one call.  means2d[1,N,2], radii[1,N] (clamped), depths[1,N].  Explicit capacity: sync-free, overflow reported in
+    counts[2]; default capacity: repeated with a doubled capacity until complete (see isect_tiles_no_depth)."""
+    if isect_capacity is None:
+        icap = max(1 << 20, 16 * radii.numel())
+        while True:
+            r = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, icap, want_isect_ids)
+            if int(r.counts[2]) == 0:
+                return r
+            icap *= 2
     means2d, depths = _f32c(means2d), _f32c(depths)
     radii = radii.contiguous()
     assert radii.dtype == torch.int32

@@ -62,6 +62,38 @@ def test_fused_iteration_matches_autograd_of_operator_chain():
     assert torch.equal(res["radiis"], out["radiis"])
 
 
+def test_fused_iteration_above_4096_tiles_takes_the_sorted_key_route_and_matches_autograd():
+    """More than SB_MAX_TILES (4,096) tiles: the superblock binning's LDS histograms do not cover the tile ids, so the fused step
+    must fall back to the sorted-key binning + group backward (splat_step.hip: strips_on) with the strip buffers still allocated --
+    same gradients as autograd through the operator chain, and the same step as a model built without the strip buffers."""
+    from gps_slam_amd import gsplat_wapper as gw
+    from gps_slam_amd.gs_model import SLAMGaussianModel
+    W, H = 1600, 720   # 100 x 45 = 4,500 tiles
+    model, cam, ref, base, gt = _model_and_maps(N=20000, W=W, H=H, seed=11)
+    p = model.opt_gs_params
+    leaves = [t.clone().requires_grad_(True) for t in (p.means, p.scales, p.quats, p.featuresDc, p.featuresRest, p.opacities)]
+    out = gw.ges_forward(leaves, cam.toGPU(), cam.width, cam.height, ref, base)
+    loss = (gt - out["rgb"]).abs().mean()
+    loss.backward()
+    twin = SLAMGaussianModel(dict(strip_backward=False), device=DEV)
+    twin.add_params({k: getattr(p, k).clone() for k in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities")})
+    for m in (model, twin):
+        m.lrs = {k: 0.0 for k in m.lrs}
+        m.initOptimizers(-1, 1.0)
+        m.train_step(cam, ref, base, gt)
+    torch.cuda.synchronize()
+    assert model.strip_backward and not twin.strip_backward
+    torch.testing.assert_close(model.loss_sum()[0], loss.detach(), rtol=1e-4, atol=0)
+    for name, g_fused, g_twin, leaf in zip(("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"), model.grads(),
+                                           twin.grads(), leaves):
+        scale = leaf.grad.abs().max().item()
+        bad = (g_fused - leaf.grad).abs() > (2e-3 * leaf.grad.abs() + 1e-3 * scale)
+        assert scale > 0 and bad.float().mean().item() < 1e-4, (name, bad.float().mean().item())
+        # the group backward accumulates shared Gaussians with float atomics: equal up to summation order
+        torch.testing.assert_close(g_fused, g_twin, rtol=1e-4, atol=1e-5 * scale)
+    assert int(model._B["counts"][2]) == 0 and int(model._B["counts"][1]) > 0   # no overflow; the GROUP table was built
+
+
 def test_optimisation_reduces_the_loss():
     model, cam, ref, base, gt = _model_and_maps(N=30000, seed=5)
     model.initOptimizers(-1, 3.3)
