@@ -29,9 +29,10 @@ def _model_and_maps(N=20000, W=320, H=240, seed=3):
     return model, cam, ref, base, gt
 
 
-def test_fused_iteration_matches_autograd_of_operator_chain():
+@pytest.mark.parametrize("W,H", [(320, 240), (333, 250)])
+def test_fused_iteration_matches_autograd_of_operator_chain(W, H):
     from gps_slam_amd import gsplat_wapper as gw
-    model, cam, ref, base, gt = _model_and_maps()
+    model, cam, ref, base, gt = _model_and_maps(W=W, H=H)
     p = model.opt_gs_params
     # reference-style: autograd through the operator surface + libtorch glue + L1 (raw_gs_model.cpp:188-417)
     leaves = [t.clone().requires_grad_(True) for t in (p.means, p.scales, p.quats, p.featuresDc, p.featuresRest, p.opacities)]
@@ -165,12 +166,13 @@ def test_knn_and_normal_map_match_torch_formulations():
     torch.testing.assert_close(got, n, rtol=1e-4, atol=1e-5)
 
 
-def test_fused_binning_and_class_lists_survive_add_and_prune():
+@pytest.mark.parametrize("W,H", [(320, 240), (333, 250)])
+def test_fused_binning_and_class_lists_survive_add_and_prune(W, H):
     """The fused iteration's superblock binning keeps tables in the caller's workspace ACROSS launches (zero between them)
     while the Gaussian count changes with every prune / add: after each change the tile lists, tile offsets and the backward's
-    class lists must still be the oracle's for the state of that launch."""
+    class lists must still be the oracle's for the state of that launch.  (333 x 250: ragged last tile column and row.)"""
     from oracle import splat_ref as orc
-    model, cam, ref, base, gt = _model_and_maps()
+    model, cam, ref, base, gt = _model_and_maps(W=W, H=H)
     model.initOptimizers(-1, 1.0)
     W, H = cam.width, cam.height
     tw, th = (W + 15) // 16, (H + 15) // 16

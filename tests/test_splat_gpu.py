@@ -465,7 +465,7 @@ def test_adam_matches_libtorch_sequence():
             torch.testing.assert_close(a, b, rtol=1e-6, atol=3e-8)  # 1 ulp of the update term (cancellation p ~ -update)
 
 
-@pytest.mark.parametrize("N,W,H", [(3000, 96, 64), (150000, 640, 480)])
+@pytest.mark.parametrize("N,W,H", [(3000, 96, 64), (150000, 640, 480), (4000, 50, 37), (1, 33, 17), (30000, 1600, 720)])
 def test_record_streaming_forward_equals_lds_forward(N, W, H):
     """gps_raster_ges_fwd_rec (packed records, 2 px/lane packed math, exp2 with the opacity folded into the exponent -- the
     forward the fused path times) must reproduce the operator-level gps_raster_ges_fwd."""
@@ -485,7 +485,7 @@ def test_record_streaming_forward_equals_lds_forward(N, W, H):
     tref = T(ref_depth)[None, ..., None]
     rc1, ra1, _ = ops.rasterize_to_pixels_fwd_ges(m2, conics, colors, opac, tref, W, H, TS, isect, delta)
     rc2, ra2 = ops.rasterize_to_pixels_fwd_ges_rec(rec, tref, W, H, isect, delta)
-    assert ra1.max().item() > 1.0
+    assert N < 1000 or ra1.max().item() > 1.0
     # The streaming kernel folds the opacity into the exponent (alpha = exp2(-(sigma*log2e - log2 o))) and adds the
     # tile's list in two halves, so it agrees with the operator-level kernel to rounding, except for (pixel, Gaussian)
     # pairs whose alpha sits within rounding of the 1/255 cut-off (a flip moves the pixel by ~4e-3*|c|).  Same bar as
