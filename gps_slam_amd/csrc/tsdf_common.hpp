@@ -5,6 +5,14 @@
 
 #include "common.hpp"
 
+// Wave priority of the frame chain's kernels (tracking, fusion, raycast).  In the overlap schedule they share the SIMDs with the
+// map stream's rasterizer waves and the frame chain is the critical path: s_setprio raises their share of the issue slots
+// (user priority 0..3; it only orders instruction arbitration between resident waves, no effect when they run alone).
+#ifndef GPS_FRAME_PRIO_LEVEL
+#define GPS_FRAME_PRIO_LEVEL 3
+#endif
+#define GPS_FRAME_PRIO() __builtin_amdgcn_s_setprio(GPS_FRAME_PRIO_LEVEL)
+
 namespace gpst {
 
 typedef gps_tsdf_state TsdfState;

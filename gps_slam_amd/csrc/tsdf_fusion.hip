@@ -114,12 +114,14 @@ __device__ __forceinline__ bool band_begin(const TsdfState& s, const Mat4& invM,
 }
 
 __global__ __launch_bounds__(256) void mark_previous_visible_kernel(TsdfState s) {
+    GPS_FRAME_PRIO();
     const int n = s.counters[GPS_TSDF_N_VISIBLE];
     const int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s.visible_type[s.visible_ids[i]] = 3;
 }
 
 __global__ __launch_bounds__(256) void alloc_request_kernel(TsdfState s, Mat4 invM) {
+    GPS_FRAME_PRIO();
     const int loc = blockIdx.x * blockDim.x + threadIdx.x;
     if (loc >= s.width * s.height) return;
     const int y = loc / s.width, x = loc - y * s.width;
@@ -182,6 +184,7 @@ __device__ __forceinline__ int request_type(const TsdfState& s, int idx) {
 }
 
 __global__ __launch_bounds__(SWEEP) void alloc_count_kernel(TsdfState s, int32_t* __restrict__ blk1, int32_t* __restrict__ blk2) {
+    GPS_FRAME_PRIO();
     __shared__ int ws[17];
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
     const int n_total = s.n_buckets + s.n_excess;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(SWEEP) void alloc_count_kernel(TsdfState s, int32_t
 // single workgroup: exclusive scan of up to two arrays of per-block counts, totals to out_tot[0..1]
 __global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __restrict__ a, int32_t* __restrict__ b,
                                                           int32_t* __restrict__ out_tot, const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     __shared__ int ws[17];
     if (views) {  // free-view batch: the sweep counts and the list length of view blockIdx.z
         a = views[blockIdx.z].scratch + 2 * nblk; b = nullptr; out_tot = views[blockIdx.z].counters + GPS_TSDF_N_VISIBLE_FREE;
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __
 
 __global__ __launch_bounds__(SWEEP) void alloc_apply_kernel(TsdfState s, Mat4 invM, const int32_t* __restrict__ blk1,
                                                            const int32_t* __restrict__ blk2, uint32_t* __restrict__ bits) {
+    GPS_FRAME_PRIO();
     __shared__ int ws[17];
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
     const int n_total = s.n_buckets + s.n_excess;
@@ -287,6 +292,7 @@ __device__ __forceinline__ bool slot_visible(const TsdfState& s, const Mat4& M, 
 template <int MODE>
 __global__ __launch_bounds__(SWEEP) void visible_count_kernel(TsdfState s, Mat4 M, int32_t* __restrict__ blk,
                                                              uint8_t* __restrict__ flags, const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     __shared__ int ws[17];
     if (views) { apply_view(s, views[blockIdx.z]); M = views[blockIdx.z].M; blk = sweep_counts(s); flags = sweep_flags(s); }
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const
                                                              const uint8_t* __restrict__ flags,
                                                              int32_t* __restrict__ out_ids, int cap,
                                                              const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     __shared__ int ws[17];
     if (views) { apply_view(s, views[blockIdx.z]); blk = sweep_counts(s); flags = sweep_flags(s); out_ids = s.fv_visible_ids; }
     const int idx = blockIdx.x * SWEEP + threadIdx.x;
@@ -349,6 +356,7 @@ __device__ __forceinline__ bool project_voxel(const TsdfState& s, const Mat4& M,
 
 template <bool FAST_DIV>
 __global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
+    GPS_FRAME_PRIO();
     __shared__ uint16_t queue[4][BLK3];  // per wave: (slice << 6 | lane) of the voxels that take the colour update
     const int n_visible = s.counters[GPS_TSDF_N_VISIBLE];
     const int lane = threadIdx.x & 63;

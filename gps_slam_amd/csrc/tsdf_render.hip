@@ -37,6 +37,7 @@ __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(Tsd
                                                                      const int32_t* __restrict__ vis_ids, int count_slot,
                                                                      int sw, int sh, uint2* __restrict__ partial,
                                                                      const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     extern __shared__ uint2 img[];  // [sw*sh] {min bits, max bits}
     int32_t* const overflow_word = s.counters + GPS_TSDF_OVERFLOW;  // (of the scene, also for a view of a batch)
     if (views) { apply_view(s, views[blockIdx.z]); M = views[blockIdx.z].M; vis_ids = s.fv_visible_ids; partial = minmax_partials(s); }
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(Tsd
 __global__ __launch_bounds__(256) void expected_depths_reduce_kernel(TsdfState s, int sw, int sh, int groups,
                                                                     const uint2* __restrict__ partial,
                                                                     float2* __restrict__ mm, const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     if (views) { apply_view(s, views[blockIdx.z]); partial = minmax_partials(s); mm = reinterpret_cast<float2*>(s.fv_minmax); }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {  // pass A of this call is complete (stream order): publish its rendering-block count, clear the scratch
@@ -248,6 +250,7 @@ template <bool MODIFY_VISIBLE>
 __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
                                                      float4* __restrict__ rays, const uint32_t* __restrict__ bits,
                                                      const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     if (views) {
         apply_view(s, views[blockIdx.z]); invM = views[blockIdx.z].invM;
         minmax = reinterpret_cast<const float2*>(s.fv_minmax); rays = reinterpret_cast<float4*>(s.fv_raycast);
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
 // processPixelICP<useSmoothing = true, flipNormals = false> (Shared.h:252-330, 438-480)
 __global__ __launch_bounds__(256) void icp_kernel(TsdfState s, Mat4 invM, const float4* __restrict__ pr,
                                                  float4* __restrict__ points, float4* __restrict__ normals) {
+    GPS_FRAME_PRIO();
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     const int W = s.width, H = s.height;
     if (x >= W || y >= H) return;
@@ -527,6 +531,7 @@ __global__ __launch_bounds__(256) void raycast_maps_kernel(int P, const float4* 
 // (ITMRepresentationAccess.h:344-423) + drawPixelColour (Shared.h:384-394)
 __global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* __restrict__ rays, uchar4* __restrict__ out,
                                                     const ViewRec* __restrict__ views) {
+    GPS_FRAME_PRIO();
     const ViewRec* maps = nullptr;  // the view's tensor glue rides on this kernel (it holds the ray and the colour of the pixel)
     if (views) {
         apply_view(s, views[blockIdx.z]);

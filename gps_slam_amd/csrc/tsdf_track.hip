@@ -177,6 +177,7 @@ struct PrepArgs {
 // four level-(l-1) children, ITMLowLevelEngine_Shared.h:48-69), counts the valid full-resolution pixels and interleaves the
 // ICP maps.
 __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
+    GPS_FRAME_PRIO();
     const int L = a.cfg.n_levels;
     const int B = 1 << (L - 1);  // block edge in level-0 pixels
     const int bw = (a.W + B - 1) / B, bh = (a.H + B - 1) / B;
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
 // computed from the LDS copy of the level below by the first (16 >> l)^2 threads -- the first version gave each THREAD a whole
 // coarsest-level block and walked it with strided loads (25 us; this one: see DESIGN.md).
 __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
+    GPS_FRAME_PRIO();
     __shared__ float lv[2][16 * 16];
     __shared__ int wv[4];
     const int L = a.cfg.n_levels;
@@ -398,6 +400,7 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
 template <int ITER>
 __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
                                                               float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
+    GPS_FRAME_PRIO();
     eval_body<ITER>(a, (int)gridDim.x, partial, sync, result, mailbox, seq, parity);
 }
 
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
         }
     }
     __syncthreads();
+    GPS_FRAME_PRIO();   // (only now: a launch that is still waiting for its line should not crowd out anybody)
     const uint32_t ctl = __builtin_amdgcn_readfirstlane(line[1]);
     if ((ctl & 0xFF) != ARG_RUN) {
         // retired: tell the host its line has been consumed -- there is ONE argument line, and the host must not write the next
