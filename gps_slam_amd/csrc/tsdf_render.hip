@@ -246,23 +246,49 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
 }
 
 // castRay (Shared.h:122-221); 16x16 pixel workgroups of four 8x8 wave patches
+// `partial` != NULL: pass B of the expected depths (expected_depths_reduce_kernel) happens HERE -- a wave's 64 rays share ONE
+// cell of the min/max image, so its 64 lanes fetch the cell's ED_GROUPS partial values (one each), reduce them with six
+// shuffles, lane 0 writes the cell where pass B would have (the image other readers and the tests see), and the first wave
+// publishes + clears the rendering-block counter: one launch and its ~8-10 us leave the frame chain.
 template <bool MODIFY_VISIBLE>
 __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
                                                      float4* __restrict__ rays, const uint32_t* __restrict__ bits,
-                                                     const ViewRec* __restrict__ views) {
+                                                     const ViewRec* __restrict__ views, const uint2* __restrict__ partial, int sw,
+                                                     int sh, float2* __restrict__ mm_out) {
     GPS_FRAME_PRIO();
     if (views) {
         apply_view(s, views[blockIdx.z]); invM = views[blockIdx.z].invM;
         minmax = reinterpret_cast<const float2*>(s.fv_minmax); rays = reinterpret_cast<float4*>(s.fv_raycast);
+        if (sw) { partial = minmax_partials(s); mm_out = reinterpret_cast<float2*>(s.fv_minmax); }
     }
     // one wave64 = one 8x8 pixel patch = exactly one cell of the 1/8-resolution min/max image: all 64 rays share their
     // [min, max] range, so their free-space runs and step counts stay close (a 16x4 strip straddles two cells)
     const int wave_in_wg = threadIdx.x >> 6, lane_ = threadIdx.x & 63;
     const int x = blockIdx.x * 16 + (wave_in_wg & 1) * 8 + (lane_ & 7), y = blockIdx.y * 16 + (wave_in_wg >> 1) * 8 + (lane_ >> 3);
+    float2 mm_cell = make_float2(0.f, 0.f);
+    if (partial) {   // (before the early return: every lane of the wave takes part)
+        const int cell_x = (blockIdx.x * 16 + (wave_in_wg & 1) * 8) / MINMAX_SUB, cell_y = (blockIdx.y * 16 + (wave_in_wg >> 1) * 8) / MINMAX_SUB;
+        uint32_t lo = __float_as_uint(FAR_AWAY), hi = __float_as_uint(VERY_CLOSE);
+        if (cell_x < sw && cell_y < sh) {
+            for (int g = lane_; g < ED_GROUPS; g += 64) {
+                const uint2 pv = partial[(size_t)g * sw * sh + cell_x + cell_y * sw];
+                lo = min(lo, pv.x); hi = max(hi, pv.y);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64)); }
+        mm_cell = make_float2(__uint_as_float(lo), __uint_as_float(hi));
+        const bool first_pixel_inside = (int)(blockIdx.x * 16 + (wave_in_wg & 1) * 8) < s.width && (int)(blockIdx.y * 16 + (wave_in_wg >> 1) * 8) < s.height;
+        if (lane_ == 0 && first_pixel_inside) mm_out[cell_x + cell_y * s.width] = mm_cell;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // pass A of this call is complete (stream order)
+            s.counters[GPS_TSDF_RENDER_BLOCKS] = s.counters[GPS_TSDF_SCRATCH2];
+            s.counters[GPS_TSDF_SCRATCH2] = 0;
+        }
+    }
     if (x >= s.width || y >= s.height) return;
     const int W = s.width;
     const int loc2 = (int)floorf((float)x / MINMAX_SUB) + (int)floorf((float)y / MINMAX_SUB) * W;
-    const float2 mm = minmax[loc2];
+    const float2 mm = partial ? mm_cell : minmax[loc2];
     const float oneOverVoxelSize = 1.0f / s.voxel_size;
     const float ipx = 1.0f / s.fx, ipy = 1.0f / s.fy, ipz = -s.cx, ipw = -s.cy;
     const float stepScale = s.mu * oneOverVoxelSize;
@@ -644,17 +670,21 @@ int gps_tsdf_free_raycast_batch(const gps_tsdf_state* sp, int n_views, const gps
     const Mat4 none = {};
     expected_depths_partial_kernel<<<dim3(ED_GROUPS, 1, n_views), ED_THREADS, lds, st>>>(s, none, nullptr, GPS_TSDF_N_VISIBLE_FREE, sw,
                                                                                      sh, nullptr, tab);
-    expected_depths_reduce_kernel<<<dim3(gps_div_up(sw * sh, 256), 1, n_views), 256, 0, st>>>(s, sw, sh, ED_GROUPS, nullptr, nullptr,
-                                                                                          tab);
     const dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16), n_views);
-    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab);
+#ifdef GPS_ED_REDUCE_LAUNCH
+    expected_depths_reduce_kernel<<<dim3(gps_div_up(sw * sh, 256), 1, n_views), 256, 0, st>>>(s, sw, sh, ED_GROUPS, nullptr, nullptr, tab);
+    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, 0, 0, nullptr);
+#else
+    // (pass B of the expected depths rides in the raycaster)
+    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, sw, sh, nullptr);
+#endif
     colour_kernel<<<grid, 256, 0, st>>>(s, nullptr, nullptr, tab);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
 
-int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_view, gps_stream stream) {
-    GPS_ENTER();
+// pass A (+ pass B unless the raycaster that follows does it: gps_tsdf_expected_depths_and_raycast)
+static int expected_depths_impl(const gps_tsdf_state* sp, const float* M, int free_view, bool with_reduce, gps_stream stream) {
     GPS_REQUIRE(sp != nullptr && M != nullptr);
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
@@ -673,9 +703,14 @@ int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_
     expected_depths_partial_kernel<<<ED_GROUPS, ED_THREADS, lds, st>>>(s, load_mat(M), free_view ? s.fv_visible_ids : s.visible_ids,
                                                                 free_view ? GPS_TSDF_N_VISIBLE_FREE : GPS_TSDF_N_VISIBLE,
                                                                 sw, sh, partial, nullptr);
-    expected_depths_reduce_kernel<<<gps_div_up(sw * sh, 256), 256, 0, st>>>(s, sw, sh, ED_GROUPS, partial, mm, nullptr);
+    if (with_reduce) expected_depths_reduce_kernel<<<gps_div_up(sw * sh, 256), 256, 0, st>>>(s, sw, sh, ED_GROUPS, partial, mm, nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
+}
+
+int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_view, gps_stream stream) {
+    GPS_ENTER();
+    return expected_depths_impl(sp, M, free_view, true, stream);
 }
 
 int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_excess) {
@@ -689,20 +724,43 @@ int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_exces
     return 4 * (scratch_words_before_bits(t) + (n_buckets + 31) / 32 + 16);
 }
 
-int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, gps_stream stream) {
-    GPS_ENTER();
+static int raycast_impl(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, bool reduce_here,
+                        gps_stream stream) {
     GPS_REQUIRE(sp != nullptr && invM != nullptr);
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
     dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16));
-    const float2* mm = reinterpret_cast<const float2*>(free_view ? s.fv_minmax : s.minmax);
+    float2* mm = reinterpret_cast<float2*>(free_view ? s.fv_minmax : s.minmax);
     float4* rays = reinterpret_cast<float4*>(free_view ? s.fv_raycast : s.raycast);
+    const int sw = s.width / MINMAX_SUB + 2, sh = s.height / MINMAX_SUB + 2;
+    const int n_total = s.n_buckets + s.n_excess, nblk = gps_div_up(n_total, 1024);
+    // (where expected_depths_impl put the partial images)
+    const uint2* partial = reduce_here ? reinterpret_cast<const uint2*>(s.scan_scratch + 3 * nblk + 16 + (n_total + 3) / 4 + 2) : nullptr;
     if (update_visible)
-        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr);
+        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr, partial, sw, sh, mm);
     else
-        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr);
+        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr, partial, sw, sh, mm);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
+}
+
+int gps_tsdf_raycast(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, gps_stream stream) {
+    GPS_ENTER();
+    return raycast_impl(sp, invM, free_view, update_visible, false, stream);
+}
+
+// The two calls of the frame chain as one: pass B of the expected depths is done by the raycaster's waves (same images, same
+// counters afterwards, one launch less).
+int gps_tsdf_expected_depths_and_raycast(const gps_tsdf_state* sp, const float* M, const float* invM, int free_view,
+                                         int update_visible, gps_stream stream) {
+    GPS_ENTER();
+#ifdef GPS_ED_REDUCE_LAUNCH   // (probe builds: the three-launch form, for an A/B)
+    const int r = expected_depths_impl(sp, M, free_view, true, stream);
+    return r != GPS_OK ? r : raycast_impl(sp, invM, free_view, update_visible, false, stream);
+#else
+    const int r = expected_depths_impl(sp, M, free_view, false, stream);
+    return r != GPS_OK ? r : raycast_impl(sp, invM, free_view, update_visible, true, stream);
+#endif
 }
 
 int gps_tsdf_icp_maps(const gps_tsdf_state* sp, const float* invM, gps_stream stream) {
@@ -736,16 +794,14 @@ int gps_tsdf_process_frame(const gps_tsdf_state* s, const int16_t* depth_mm, con
     if ((r = gps_tsdf_convert_depth(s, depth_mm, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_allocate(s, M, invM, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_integrate(s, M, stream)) != GPS_OK) return r;
-    if ((r = gps_tsdf_expected_depths(s, M, 0, stream)) != GPS_OK) return r;
-    if ((r = gps_tsdf_raycast(s, invM, 0, 1, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_expected_depths_and_raycast(s, M, invM, 0, 1, stream)) != GPS_OK) return r;
     return gps_tsdf_icp_maps(s, invM, stream);
 }
 
 int gps_tsdf_free_raycast(const gps_tsdf_state* s, const float* M, const float* invM, gps_stream stream) {
     int r;
     if ((r = gps_tsdf_find_visible(s, M, stream)) != GPS_OK) return r;
-    if ((r = gps_tsdf_expected_depths(s, M, 1, stream)) != GPS_OK) return r;
-    if ((r = gps_tsdf_raycast(s, invM, 1, 0, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_expected_depths_and_raycast(s, M, invM, 1, 0, stream)) != GPS_OK) return r;
     return gps_tsdf_render_colour(s, stream);
 }
 

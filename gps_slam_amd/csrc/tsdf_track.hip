@@ -970,8 +970,7 @@ int gps_tsdf_process_frame_tracked_gated(const gps_tsdf_state* s, const int16_t*
     if (before_fusion) before_fusion(user);  // everything above only READ the volume; what follows modifies it
     if ((r = gps_tsdf_allocate(s, ts->pose_M, ts->pose_invM, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_integrate(s, ts->pose_M, stream)) != GPS_OK) return r;
-    if ((r = gps_tsdf_expected_depths(s, ts->pose_M, 0, stream)) != GPS_OK) return r;
-    if ((r = gps_tsdf_raycast(s, ts->pose_invM, 0, 1, stream)) != GPS_OK) return r;
+    if ((r = gps_tsdf_expected_depths_and_raycast(s, ts->pose_M, ts->pose_invM, 0, 1, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_icp_maps(s, ts->pose_invM, stream)) != GPS_OK) return r;
     memcpy(ts->pose_pc_M, ts->pose_M, 64);  // pose_pointCloud := pose_d (ITMTrackingController.h:87-93)
     ts->age_point_cloud = (ts->age_point_cloud == -1) ? -2 : 0;

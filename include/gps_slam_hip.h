@@ -548,6 +548,12 @@ GPS_API int gps_tsdf_expected_depths(const gps_tsdf_state *s, const float *M, in
 GPS_API int gps_tsdf_raycast(const gps_tsdf_state *s, const float *invM, int free_view, int update_visible,
                              gps_stream stream);
 
+/* gps_tsdf_expected_depths followed by gps_tsdf_raycast as the frame chain issues them, in two launches instead of three: the
+ * second pass of the expected depths (reduction of the per-workgroup min / max images) is done by the raycaster's waves.  Same
+ * min / max image (every cell the raycaster reads), rays, visibility updates and counters as the two calls. */
+GPS_API int gps_tsdf_expected_depths_and_raycast(const gps_tsdf_state *s, const float *M, const float *invM, int free_view,
+                                                 int update_visible, gps_stream stream);
+
 /* renderICP_device<false> with smoothing (ITMVisualisationHelpers_CUDA.h:71-81, Shared:438-480) on the live raycast */
 GPS_API int gps_tsdf_icp_maps(const gps_tsdf_state *s, const float *invM, gps_stream stream);
 
