@@ -41,7 +41,15 @@
 #include "wave_reduce.hpp"
 #include "tsdf_pose.hpp"
 
-using namespace gpst;
+using // a failure of the tracker's host loop names its line on stderr (as GPS_LAUNCH_CHECK does for launches): -2 alone says nothing
+#define GPS_FAIL_LAUNCH()                                                                                   \
+    do {                                                                                                    \
+        fprintf(stderr, "[gps_slam_hip] %s:%d tracker: no result / hip error (%s)\n", __FILE__, __LINE__,  \
+                hipGetErrorString(hipPeekAtLastError()));                                                   \
+        return GPS_ERR_LAUNCH;                                                                              \
+    } while (0)
+
+namespace gpst;
 
 namespace {
 
@@ -640,7 +648,7 @@ int gps_track_poll_profile(const void* scratch, int width, int height, uint32_t 
     Scratch w;
     carve(&w, (char*)const_cast<void*>(scratch), width, height);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemcpyAsync(out, w.sync + SYNC_SPIN_TICKS, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
+    if (hipMemcpyAsync(out, w.sync + SYNC_SPIN_TICKS, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
     return hipStreamSynchronize(st) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
@@ -700,9 +708,9 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     // other frame's count slot, so the steady state needs no memset launch in front of the frame.
     int parity = 0;
     if (ts->scratch_epoch == 0) {
-        if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) return GPS_ERR_LAUNCH;
+        if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) GPS_FAIL_LAUNCH();
         // row tags: sequence numbers are >= 1, so a zeroed table can never look like a delivered row
-        if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) return GPS_ERR_LAUNCH;
+        if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
     } else {
         parity = ts->scratch_epoch - 1;
     }
@@ -807,13 +815,13 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             if (mailbox) {
                 // this evaluation is the pre-launched kernel (or the frame's first launch): hand it its arguments, then put
                 // the NEXT evaluation on the stream before waiting -- its launch cost overlaps this evaluation
-                if (!pending.seq && prelaunch() != GPS_OK) return GPS_ERR_LAUNCH;
+                if (!pending.seq && prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
                 const int seq = pending.seq;
                 pending.seq = 0;
                 mailbox[15] = 0.0f; mailbox[31] = 0.0f;  // per-state sequence numbers (>= 1): nothing stale can match
                 publish(seq, ARG_RUN, it, level, approxInvPose);
                 eval_launches++;
-                if (prelaunch() != GPS_OK) return GPS_ERR_LAUNCH;
+                if (prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
                 // spin on the sequence number the kernel writes last (bounded)
                 bool got = false;
                 for (long spin = 0; spin < 200000000L; spin++) {
@@ -835,23 +843,32 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                         gone = float_bits(mailbox[32]) == seq;
                         if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                     }
-                    if (!late && !gone) return GPS_ERR_LAUNCH;   // the stream is wedged; ~Pending retires the queued launch
+                    if (!late && !gone) {
+                        // Neither an answer nor a retirement (e.g. the line arrived while part of the launch's workgroups had
+                        // already sat out ARG_TIMEOUT: the summer then waits for rows that never come and gives up silently).
+                        // Drain the stream instead of failing the frame: launch seq ends by one of its timeouts, the queued
+                        // launch seq + 1 never finds its line and retires itself; then nobody polls the line any more and the
+                        // plain launch below redoes the evaluation (same inputs, same fixed-order sums).
+                        fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d neither answered nor retired; draining the stream\n", seq);
+                        if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
+                        pending.seq = 0;
+                    }
                     got = late;
                 }
                 if (!got) {
-                    retire(pending.seq);
+                    if (pending.seq) retire(pending.seq);
                     pending.seq = 0;
                     // a launch that gave up may have left the evaluation ticket partially counted and rows half delivered:
                     // both start from zero for the plain launch (the valid-pixel counts next to the ticket stay)
-                    if (hipMemsetAsync(w.sync, 0, sizeof(uint32_t), st) != hipSuccess) return GPS_ERR_LAUNCH;
-                    if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) return GPS_ERR_LAUNCH;
+                    if (hipMemsetAsync(w.sync, 0, sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
+                    if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
                     const int seq2 = next_seq();
                     if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                     else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                     else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                     GPS_LAUNCH_CHECK();
                     if (hipStreamSynchronize(st) != hipSuccess || float_bits(mailbox[15]) != seq2 || float_bits(mailbox[31]) != seq2)
-                        return GPS_ERR_LAUNCH;
+                        GPS_FAIL_LAUNCH();
                 }
                 for (int k = 0; k < GH_SLOTS; k++) raw[k] = mailbox[k];
                 mailbox_iterations++;
@@ -863,9 +880,9 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                 GPS_LAUNCH_CHECK();
                 eval_launches++;
                 // the reference's GPU tracker reads its 32 accumulators back every iteration as well
-                if (hipMemcpyAsync(raw, w.result, sizeof(raw), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
-                if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
-                if (float_bits(raw[15]) != seq || float_bits(raw[31]) != seq) return GPS_ERR_LAUNCH;  // the summer gave up
+                if (hipMemcpyAsync(raw, w.result, sizeof(raw), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
+                if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
+                if (float_bits(raw[15]) != seq || float_bits(raw[31]) != seq) GPS_FAIL_LAUNCH();  // the summer gave up
             }
             float host[GH_SLOTS];
             for (int d = 0; d < 30; d++) host[d] = raw[d + d / 15];  // payload d lives in word d + d / 15
@@ -937,8 +954,8 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     if (eval_launches > 0) {
         n_max = n_valid_bits;  // delivered with every evaluation's sums
     } else {
-        if (hipMemcpyAsync(&n_max, w.sync + 1 + parity, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GPS_ERR_LAUNCH;
-        if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+        if (hipMemcpyAsync(&n_max, w.sync + 1 + parity, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
+        if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
     }
     ts->diag[8] = (float)nvalid_depth_good; ts->diag[9] = f_depth_good;
     ts->diag[10] = n_max > 0 ? sqrtf(((float)nvalid_depth_good * f_depth_good + (float)(n_max - nvalid_depth_good) * c->space_thresh[0]) /

@@ -9,7 +9,10 @@
  * this path and its implementation is CUDA-only (cannot run here), so this
  * restatement is pinned only by (i) line-by-line reading of the cited CUDA
  * sources and (ii) the autograd / finite-difference cross-checks in
- * tests/test_oracle_splat.py.
+ * tests/test_oracle_splat.py.  One exception: orc_ssim_fwd / orc_ssim_bwd ARE
+ * pinned by reference output -- gsplat/rasterizer/ssim.cu compiles for gfx950
+ * from its own source (oracle/ref_ssim_build.py) and its outputs are the
+ * fixture tests/golden/ssim_ref_gfx950.npz.
  *
  * Plain scalar fp32 C, compiled with -ffp-contract=off.  Every function cites
  * the reference file:line (relative to /root/reference) it restates.

@@ -5,6 +5,8 @@ the oracle is cross-checked here against an independent dense float64 PyTorch
 formulation of the same maths (values + autograd gradients) and against the
 exact tile adjoint.  CPU only.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -428,3 +430,21 @@ def test_ssim_restatement_matches_float64_conv_and_autograd():
     # identical images -> SSIM = 1 everywhere the window is inside; gradient of the map w.r.t. img1 vanishes there
     m3, e1, e2, e3 = orc.ssim_fwd(img2, img2, C1, C2)
     np.testing.assert_allclose(m3, 1.0, atol=1e-5)
+
+
+def test_ssim_restatement_matches_the_reference_kernels_outputs():
+    """tests/golden/ssim_ref_gfx950.npz holds what the REFERENCE's own fusedssimCUDA / fusedssim_backwardCUDA (gsplat/rasterizer/
+    ssim.cu compiled for gfx950 by oracle/ref_ssim_build.py, run on an MI355X by tests/golden/make_ssim_ref_golden.py) gave on two
+    seeded image pairs: the one part of the splat oracle that is pinned by reference OUTPUT (tolerance = float32 rounding of the
+    121-term window sums; the GPU test regenerates the fixture bit for bit)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_ref_gfx950.npz"))
+    C1, C2 = float(np.float32(0.01 * 0.01)), float(np.float32(0.03 * 0.03))
+    for tag in ("a", "b"):
+        img1, img2, dL = z[tag + "_img1"], z[tag + "_img2"], z[tag + "_dL"]
+        outs = orc.ssim_fwd(img1, img2, C1, C2)
+        for got, name in zip(outs, ("map", "dm_dmu1", "dm_dsigma1_sq", "dm_dsigma12")):
+            want = z[tag + "_" + name]
+            np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max()), err_msg=tag + name)
+        g = orc.ssim_bwd(img1, img2, dL, z[tag + "_dm_dmu1"], z[tag + "_dm_dsigma1_sq"], z[tag + "_dm_dsigma12"])
+        want = z[tag + "_grad"]
+        np.testing.assert_allclose(g, want, rtol=1e-3, atol=1e-4 * np.abs(want).max(), err_msg=tag + "grad")
