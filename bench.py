@@ -180,6 +180,11 @@ def _no_gpu_sync():
     pass
 
 
+def _device_mallocs(need_gpu):
+    """hipMalloc calls of the caching allocator so far (a segment allocated inside a timed window stalls every stream)"""
+    return int(torch.cuda.memory_stats().get("num_device_alloc", 0)) if need_gpu else 0
+
+
 def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=True):
     """argv / scene_factory / backend / need_gpu / extras exist for tests/test_multi_rank_cpu.py, which runs this very function
     with world_size 2 on gloo and a stub scene (no GPU in the build container): the N > 1 control flow -- ranks, seeds, barriers,
@@ -243,6 +248,7 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
         for w in range(NW):
             lo = first + w * K
             up0, st0 = scene.cli.uploadedBytes, dict(scene.pipe.stats())
+            mallocs0 = _device_mallocs(need_gpu)
             dev_sync()
             grp.barrier()
             dev_sync()
@@ -258,12 +264,14 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
             windows.append(dict(seconds=dt, frames_per_s=world * K / dt, ms_per_step=1000.0 * dt / K,
                                 uploaded_bytes_per_frame=(scene.cli.uploadedBytes - up0) / K,
                                 stats={k: int(v) - int(st0[k]) for k, v in dict(scene.pipe.stats()).items()},  # this window only
-                                gaussians=int(scene.model.getGaussianNum()) if hasattr(scene, "model") else 0))
+                                gaussians=int(scene.model.getGaussianNum()) if hasattr(scene, "model") else 0,
+                                device_mallocs=_device_mallocs(need_gpu) - mallocs0))
         order = sorted(range(NW), key=lambda i: windows[i]["seconds"])
         med = windows[order[NW // 2]]  # the median window (upper median for an even count): every reported number is of ONE window
         ms = [w["ms_per_step"] for w in windows]
         results[sched] = dict(med, windows_ms_per_step=ms, window_spread=(max(ms) - min(ms)) / med["ms_per_step"],
-                              window_spread_detrended=_detrended_spread(ms), windows_gaussians=[w["gaussians"] for w in windows])
+                              window_spread_detrended=_detrended_spread(ms), windows_gaussians=[w["gaussians"] for w in windows],
+                              windows_device_mallocs=[w["device_mallocs"] for w in windows])
     main_sched = "overlap" if "overlap" in results else schedules[0]
     dt = results[main_sched]["seconds"]
 

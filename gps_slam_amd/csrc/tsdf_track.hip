@@ -476,6 +476,8 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
             if (relay) sync[SYNC_SPIN_TICKS] += (uint32_t)(now - t0);
         }
         if (relay) {  // payload, wait for the acknowledgement (sc1 stores), then the sequence number
+            // (round 3: the whole line as ONE 16-lane store instruction, torn lines left to the xor word -- no faster in an A/B:
+            // 1,175 vs 1,187 frames/s, within noise; the ordered form stays)
             if (threadIdx.x != 0) __hip_atomic_store(pa.dev_line + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (threadIdx.x == 0) __hip_atomic_store(pa.dev_line, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

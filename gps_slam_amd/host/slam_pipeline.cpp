@@ -1,5 +1,8 @@
 #include "slam_pipeline.hpp"
 
+#include <chrono>
+#include <cstdlib>
+
 #include <c10/hip/HIPGuard.h>
 #include <hip/hip_runtime_api.h>
 
@@ -484,8 +487,21 @@ std::vector<TensorDict> SLAMPipeline::renderEvalImgs(const std::vector<Camera>& 
 }
 
 // ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
+// debug aid (GPS_PIPE_TIMES=<ms>): a processFrame call that took longer than <ms> of host time prints where it went
+static double pipe_times_threshold_ms() {
+    static const double v = [] { const char* e = std::getenv("GPS_PIPE_TIMES"); return e ? std::atof(e) : -1.0; }();
+    return v;
+}
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static thread_local double g_gate_wait_ms = 0.0, g_handover_wait_ms = 0.0;
+static double g_job_post_ms = 0.0;  // (debug aid only: when the frame thread woke the mapping thread)
+
 void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     curr_frame_id = i;
+    const double tt0 = now_ms();
+    g_gate_wait_ms = g_handover_wait_ms = 0.0;
     if (!main_engine->trackingActive && (int)main_engine->gtC2wPoses.size() <= main_engine->framesProcessed)
         main_engine->gtC2wPoses.push_back(cam.c2w);
     ITMTrackingState* ts;
@@ -515,10 +531,16 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) est.data_ptr<float>()[4 * r + c] = invM[4 * c + r];
     cam.c2w_slam = est;
-    cam.invalidate();
-    cam.toGPU(device, frame_rgba);
-    if (frame_rgba.defined()) tsdf_engine->markConsumed();  // the staging slot's last reader is the conversion toGPU just enqueued
+    // `curr_cam = cams[i]; curr_cam.toGPU();` (:83-84): a COPY of the caller's camera goes to the device -- the caller's keeps the
+    // pose and no device tensors, so a frame's 12-byte-per-pixel image lives exactly as long as the pipeline's lists hold it
+    // (held by the caller's camera it stayed for the whole run: 3.7 MB per frame at 640x480, i.e. a fresh 20 MB hipMalloc by the
+    // frame thread every fifth frame instead of the caching allocator handing the previous frame's block out again)
     curr_cam = cam;
+    curr_cam.invalidate();
+    const double tt1 = now_ms();
+    curr_cam.toGPU(device, frame_rgba);
+    const double tt2 = now_ms();
+    if (frame_rgba.defined()) tsdf_engine->markConsumed();  // the staging slot's last reader is the conversion toGPU just enqueued
     updateFrameList();
     stats.frames++;
     if (work_mode == "recon") return;
@@ -531,6 +553,10 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
         else if (overlap_mapping) keyframeStepOverlapped();
         else keyframeStep();
     }
+    const double thr = pipe_times_threshold_ms(), tt3 = now_ms();
+    if (thr >= 0.0 && tt3 - tt0 > thr)
+        fprintf(stderr, "[pipe] frame %d: %.3f ms = engine %.3f (gate wait %.3f) + toGPU %.3f + lists / keyframe step %.3f (hand-over wait %.3f)\n",
+                i, tt3 - tt0, tt1 - tt0, g_gate_wait_ms, tt2 - tt1, tt3 - tt2, g_handover_wait_ms);
 }
 
 // ------------------------------------------------------------------ tracking / mapping overlap (see slam_pipeline.hpp)
@@ -621,7 +647,9 @@ void SLAMPipeline::keyframeStepThreaded() {
     const hipStream_t frames = c10::hip::getCurrentHIPStream().stream();
     std::unique_lock<std::mutex> lk(mu_);
     if (!worker_.joinable()) worker_ = std::thread([this, dev = (int)c10::hip::current_device()] { mapWorker(dev); });
+    const double tw0 = now_ms();
     cv_.wait(lk, [&] { return done_seq_ == job_seq_ || worker_error_; });
+    g_handover_wait_ms = now_ms() - tw0;
     if (worker_error_) { lk.unlock(); rethrowWorkerError(); }
     hip_ok(hipEventRecord((hipEvent_t)ev_frame_, frames), "hipEventRecord");
     job_.curr_cam = curr_cam;
@@ -629,6 +657,7 @@ void SLAMPipeline::keyframeStepThreaded() {
     job_.keyframes = keyframe_cam_list;
     job_.poses = main_engine->camPoses;
     job_seq_++;
+    g_job_post_ms = now_ms();
     cv_.notify_all();
     // The next frame's fusion must not modify the volume (or reuse the engine's free-view scratch) before the update's raycasts
     // have read it -- but its TRACKING may run meanwhile: the wait (for the worker to have recorded the event, then the
@@ -637,8 +666,10 @@ void SLAMPipeline::keyframeStepThreaded() {
     (void)frames;
     main_engine->beforeNextFusion = [this, want] {
         {
+            const double tw1 = now_ms();
             std::unique_lock<std::mutex> lk2(mu_);
             cv_.wait(lk2, [&] { return raycasts_seq_ >= want || worker_error_; });
+            g_gate_wait_ms = now_ms() - tw1;
         }
         rethrowWorkerError();
         hip_ok(hipStreamWaitEvent(c10::hip::getCurrentHIPStream().stream(), (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
@@ -658,6 +689,7 @@ void SLAMPipeline::mapWorker(int device_index) {
                 if (stop_) return;
                 seen = job_seq_;
             }
+            const double t_woke = now_ms();
             // job_ is stable until done_seq_ catches up (the frame thread waits for that before it writes the next one)
             hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
             if (merge_keyframe_raycasts) raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
@@ -667,6 +699,9 @@ void SLAMPipeline::mapWorker(int device_index) {
                                                                                          : ms.stream()), "hipEventRecord");
             { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
             cv_.notify_all();
+            if (pipe_times_threshold_ms() >= 0.0 && now_ms() - g_job_post_ms > 1.0)
+                fprintf(stderr, "[pipe] update %lld: raycasts enqueued %.3f ms after the hand-over (woke after %.3f)\n", (long long)seen,
+                        now_ms() - g_job_post_ms, t_woke - g_job_post_ms);
             initNewGaussiansFor(localframe_raycast_window.back(), job_.curr_cam);
             localOptimize();
             removeRedundantGs();

@@ -358,6 +358,7 @@ def test_sample_method_ours_keeps_a_loss_record_per_keyframe_and_adds_no_history
     # a history view by hand: the record becomes the loss of that view
     key_id = sorted(rec)[1]
     kc = cams[key_id]
+    kc.toGPU()   # (processFrame sends a COPY of the caller's camera to the device, slam_pipeline.cpp:83-84)
     rc = pipe.runRaycastByCam(kc, False)
     pipe.appendOptView(kc, rc)
     pipe.checkKeyFrameError()
