@@ -99,6 +99,8 @@ class Scene:
         self.cli = H_.createTsdfEngine(reader, dict(voxel_size=0.005, trunc_dist=0.02, viewFrustum_min=0.2, viewFrustum_max=10.0,
                                                     use_gt_pose=1 if use_gt_pose else 0))
         self.engine = self.cli.getMainEngine()
+        if os.environ.get("GPS_BENCH_PINNED_LINE"):  # A/B aid: the tracker's argument line in the pinned mailbox (relay path)
+            self.engine.setBarArgLine(False)
         self.model = H_.SLAMGaussianModel()
         self.model.loadConfig(dict(capacity=1 << 19, isect_capacity=8 << 20))
         self.model.getGaussianParms().add([t.clone() for t in seeds])

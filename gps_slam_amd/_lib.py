@@ -38,7 +38,7 @@ class TrackConfig(C.Structure):
 class TrackState(C.Structure):
     """gps_track_state (host memory)"""
     _fields_ = [("pose_M", f32 * 16), ("pose_invM", f32 * 16), ("pose_pc_M", f32 * 16), ("age_point_cloud", i32),
-                ("frames_processed", i32), ("diag", f32 * 16), ("host_mailbox", vp), ("mail_seq", i32), ("scratch_epoch", i32)]
+                ("frames_processed", i32), ("diag", f32 * 16), ("host_mailbox", vp), ("mail_seq", i32), ("scratch_epoch", i32), ("dev_arg_line", vp)]
 
 
 class SplatStep(C.Structure):
@@ -103,6 +103,8 @@ PROTOTYPES = {
     "gps_tsdf_mesh_scene": (i32, [C.POINTER(TsdfState), i64, vp, vp, vp, i64, vp]),
     "gps_track_config_init": (i32, [C.POINTER(TrackConfig), C.c_char_p, i32, i32, f32, f32, f32, f32, i32, i32]),
     "gps_track_state_reset": (i32, [C.POINTER(TrackState)]),
+    "gps_track_arg_line_alloc": (i32, [C.POINTER(vp)]),
+    "gps_track_arg_line_free": (i32, [vp]),
     "gps_track_scratch_bytes": (i64, [i32, i32]),
     "gps_track_poll_profile": (i32, [vp, i32, i32, vp, vp]),
     "gps_tsdf_track_camera": (i32, [C.POINTER(TsdfState), C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64, vp]),

@@ -32,6 +32,7 @@
 // The reduction is a fixed tree (per-thread register sums -> wave -> workgroup -> 8 row groups added in order), so results
 // are reproducible run to run; they differ from the CPU engine's scan-order sums only by float re-association (poses agree
 // to ~1e-5, tests/test_tsdf_gpu.py).
+#include <immintrin.h>
 #include <math.h>
 #include <sched.h>
 #include <stdlib.h>
@@ -435,6 +436,8 @@ struct PollArgs {
     LevelTab tab[GPS_TRACK_MAX_LEVELS];  // per-level constants (kernel arguments: selected with static indices, no memory round trip)
     const uint32_t* arg_line;  // pinned host memory, 64-byte aligned
     uint32_t* dev_line;        // device copy of the line (relayed by workgroup 0)
+    const uint32_t* bar_line;  // != NULL: the host writes the line into THIS block of fine-grained device memory through the
+                               // BAR (gps_track_state.dev_arg_line) and every workgroup polls it here: no PCIe read, no relay
 };
 constexpr uint32_t ARG_RUN = 1, ARG_SKIP = 2;
 constexpr long long ARG_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
@@ -448,18 +451,26 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
         // Workgroup 0 polls the host line and relays it through a device-memory copy the other workgroups poll: with all 256
         // workgroups reading the host line across PCIe, the CPU's store waited ~20 us for ownership of its own cache line
         // (measured: 33 us per iteration instead of ~20; one poller: 1.7 us host -> GPU -> host round trip).
-        const bool relay = blockIdx.x == 0;
-        const uint32_t* src = relay ? pa.arg_line : pa.dev_line;
+        const bool direct = pa.bar_line != nullptr;   // (wave-uniform: a kernel argument)
+        const bool relay = !direct && blockIdx.x == 0;
+        const uint32_t* src = direct ? pa.bar_line : relay ? pa.arg_line : pa.dev_line;
         const long long t0 = wall_clock64();
         uint32_t v;
         for (;;) {
-            v = relay ? __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                      : __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = (relay || direct) ? __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                  : __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t x = threadIdx.x < 15 ? v : 0u;  // xor of words 0..14 over the 16 active lanes (row 0 of the wave)
             x ^= __shfl_xor(x, 1, 16); x ^= __shfl_xor(x, 2, 16); x ^= __shfl_xor(x, 4, 16); x ^= __shfl_xor(x, 8, 16);
             const uint32_t w0 = __shfl(v, 0, 16), w15 = __shfl(v, 15, 16);
             if (w0 == (uint32_t)seq && w15 == x) break;
-            if (wall_clock64() - t0 > ARG_TIMEOUT) {  // give up: behave like ARG_SKIP (and relay that)
+            // A valid line of a LATER launch: this launch's line has come and gone.  The host publishes launch seq + 1 only after
+            // launch seq has answered (RUN: every workgroup with pixels has delivered its row, so this one has none) or has
+            // acknowledged its retirement (SKIP, workgroup 0) -- either way there is nothing left for this workgroup to do.
+            // Only the direct (BAR) line can show this: a workgroup that became resident late, beside another stream's
+            // kernels, after workgroup 0 had answered (the relayed copy is rewritten by the NEXT launch, which cannot start
+            // before this one has drained).  Without it such a workgroup sat out ARG_TIMEOUT with the frame stream behind it.
+            const bool superseded = w15 == x && (int32_t)(w0 - (uint32_t)seq) > 0 && w0 < 0x40000000u;
+            if (superseded || wall_clock64() - t0 > ARG_TIMEOUT) {  // give up: behave like ARG_SKIP (and relay that)
                 v = threadIdx.x == 0 ? (uint32_t)seq : threadIdx.x == 1 ? ARG_SKIP : 0u;
                 uint32_t y = threadIdx.x < 15 ? v : 0u;
                 y ^= __shfl_xor(y, 1, 16); y ^= __shfl_xor(y, 2, 16); y ^= __shfl_xor(y, 4, 16); y ^= __shfl_xor(y, 8, 16);
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
             // how long this launch sat on the GPU waiting for the host's decision (workgroup 0: the one that polls the host line)
             const long long now = wall_clock64();
             t_arrived = now;
-            if (relay) sync[SYNC_SPIN_TICKS] += (uint32_t)(now - t0);
+            if (blockIdx.x == 0) sync[SYNC_SPIN_TICKS] += (uint32_t)(now - t0);
         }
         if (relay) {  // payload, wait for the acknowledgement (sc1 stores), then the sequence number
             // (round 3: the whole line as ONE 16-lane store instruction, torn lines left to the xor word -- no faster in an A/B:
@@ -636,13 +647,36 @@ int gps_track_config_init(gps_track_config* c, const char* levels, int num_iter_
 int gps_track_state_reset(gps_track_state* ts) {
     if (!ts) return GPS_ERR_ARG;
     void* mailbox = ts->host_mailbox;  // the mailbox and the sequence counter belong to the state's owner / the library
+    void* line = ts->dev_arg_line;
     const int32_t seq = ts->mail_seq;
     memset(ts, 0, sizeof(*ts));
     ts->host_mailbox = mailbox;
+    ts->dev_arg_line = line;
     ts->mail_seq = seq;
     for (int i = 0; i < 16; i += 5) ts->pose_M[i] = ts->pose_invM[i] = ts->pose_pc_M[i] = 1.0f;
     ts->age_point_cloud = -1;
     return GPS_OK;
+}
+
+int gps_track_arg_line_alloc(void** line) {
+    if (!line) return GPS_ERR_ARG;
+    *line = nullptr;
+    int dev = 0, large_bar = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GPS_ERR_LAUNCH;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess || !large_bar) {
+        (void)hipGetLastError();
+        return GPS_OK;  // device memory is not host-visible: the pinned line stays
+    }
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return GPS_OK; }
+    if (hipMemset(p, 0, 4096) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return GPS_ERR_LAUNCH; }
+    *line = p;
+    return GPS_OK;
+}
+
+int gps_track_arg_line_free(void* line) {
+    if (!line) return GPS_OK;
+    return hipFree(line) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
 int gps_track_poll_profile(const void* scratch, int width, int height, uint32_t out[4], gps_stream stream) {
@@ -741,7 +775,10 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         for (int l = 0; l < GPS_TRACK_MAX_LEVELS; l++) pl.tab[l] = pa.tab_vals[l];
         pl.arg_line = const_cast<const uint32_t*>(arg_line);
         pl.dev_line = w.dev_line;
+        pl.bar_line = reinterpret_cast<const uint32_t*>(ts->dev_arg_line);
     }
+    GPS_REQUIRE((reinterpret_cast<uintptr_t>(ts->dev_arg_line) & 63) == 0);
+    volatile uint32_t* const bar_line = mailbox ? reinterpret_cast<volatile uint32_t*>(ts->dev_arg_line) : nullptr;
     auto next_seq = [&]() { return (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1); };
     // payload first, sequence number last (x86 stores are not reordered with each other; the compiler barrier keeps the order)
     auto publish = [&](int seq, uint32_t cmd, int kind, int level, const float* pose) {
@@ -754,6 +791,15 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         uint32_t x = 0;
         for (int k = 0; k < 15; k++) x ^= wds[k];
         wds[15] = x;
+        if (bar_line) {
+            // through the BAR: the mapping is write-combining, so the 64 bytes gather in one of the core's WC buffers and leave
+            // as one posted write when the sfence drains it (without the fence the line sits there until something evicts
+            // it: tools/probe/pingpong.hip reads 560 us per round trip instead of 1.8).  A torn line fails the xor word.
+            for (int k = 0; k < 16; k += 2)
+                reinterpret_cast<volatile uint64_t*>(bar_line)[k >> 1] = (uint64_t)wds[k] | ((uint64_t)wds[k + 1] << 32);
+            _mm_sfence();
+            return;
+        }
         for (int k = 1; k < 16; k++) arg_line[k] = wds[k];
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         arg_line[0] = wds[0];
@@ -858,6 +904,9 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                     got = late;
                 }
                 if (!got) {
+                    static int warned = 0;   // (rare by construction; a steady stream of these is a bug worth seeing)
+                    if (warned < 8 && ++warned)
+                        fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d gave up waiting for its argument line; redone by a plain launch\n", seq);
                     if (pending.seq) retire(pending.seq);
                     pending.seq = 0;
                     // a launch that gave up may have left the evaluation ticket partially counted and rows half delivered:

@@ -152,6 +152,8 @@ PYBIND11_MODULE(_host, m) {
         .def("pushGtPose", [](TsdfEngine& e, const torch::Tensor& c2w) { e.gtC2wPoses.push_back(c2w); })
         .def("turnOffTracking", &TsdfEngine::turnOffTracking)
         .def("turnOnTracking", [](TsdfEngine& e) { e.turnOnTracking(); })
+        .def("setBarArgLine", &TsdfEngine::setBarArgLine)
+        .def("usesBarArgLine", &TsdfEngine::usesBarArgLine)
         .def("lastPose", [](TsdfEngine& e) {
             auto t = torch::empty({2, 16}, torch::kFloat32);
             const ORUtils::SE3Pose& p = e.camPoses.back();

@@ -14,6 +14,7 @@
 // GetTrackingState()->pose_d->GetInvM(), camPoses, camIntrincs, gtC2wPoses, turnOffTracking, SaveToFile, LoadFromFile,
 // SaveSceneToMesh.
 #pragma once
+#include <memory>
 #include <functional>
 #include <mutex>
 
@@ -192,6 +193,9 @@ public:
     // InfiniTAM_tools.cpp:59-62): poses then come from gtC2wPoses.  With tracking active (the reference's default) the
     // depth-only ExtendedTracker of ITMLibSettings.cpp:54-57 estimates them (gps_tsdf_process_frame_tracked).
     void turnOffTracking() { trackingActive = false; }
+    // the tracker's argument line through the BAR (default, when the device memory is host-visible) or in the pinned mailbox
+    void setBarArgLine(bool on) { bar_arg_line = on; track_state_.dev_arg_line = on ? track_arg_line_.get() : nullptr; }
+    bool usesBarArgLine() const { return track_state_.dev_arg_line != nullptr; }
     void turnOnTracking(const char* levels = "rrbb", int numIterC = 20, int numIterF = 50, float outlierSpaceC = 0.1f,
                         float outlierSpaceF = 0.004f, float minstep = 1e-4f, float tukeyCutOff = 8.0f, int framesToSkip = 20,
                         int framesToWeight = 50);
@@ -240,6 +244,10 @@ private:
     gps_track_config track_cfg_{};
     gps_track_state track_state_{};
     torch::Tensor track_scratch_, track_mailbox_;
+    // the tracker's argument line in host-writable device memory (gps_track_arg_line_alloc; null without a large BAR).  The
+    // switch exists for A/B measurements and for the tests that cover both hand-over paths.
+    std::shared_ptr<void> track_arg_line_;
+    bool bar_arg_line = true;
     ORUtils::SE3Pose pose_d_;
     ITMTrackingState tracking_state_{&pose_d_};
     ITMUChar4Image free_image_;

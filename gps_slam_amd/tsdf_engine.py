@@ -9,6 +9,8 @@ gps_tsdf_state struct once and afterwards only passes pointers.  All compute is 
 import ctypes as C
 
 import numpy as np
+import weakref
+
 import torch
 
 from ._lib import TrackConfig, TrackState, TsdfState, check, lib
@@ -110,7 +112,7 @@ class TsdfEngine:
 
     # ---- ITMBasicEngine::ProcessFrame with the tracker ON (use_gt_pose: false)
     def turnOnTracking(self, levels="rrbb", num_iter_coarse=20, num_iter_fine=50, thresh_coarse=0.1, thresh_fine=0.004,
-                       term_thresh=1e-4, tukey_cutoff=8.0, frames_to_skip=20, frames_to_weight=50):
+                       term_thresh=1e-4, tukey_cutoff=8.0, frames_to_skip=20, frames_to_weight=50, bar_arg_line=True):
         """Depth-only ExtendedTracker with the parameters of ITMLibSettings.cpp:54-57 (defaults)."""
         self.track_cfg = TrackConfig()
         check(lib.gps_track_config_init(C.byref(self.track_cfg), levels.encode(), num_iter_coarse, num_iter_fine, thresh_coarse,
@@ -122,6 +124,16 @@ class TsdfEngine:
         self.track_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._mailbox = torch.zeros(64, dtype=torch.float32).pin_memory()  # kernel -> host accumulators, no memcpy
         self.track_state.host_mailbox = self._mailbox.data_ptr()
+        # the argument line in host-writable device memory (written through the BAR; None without a large BAR)
+        if not hasattr(self, "_arg_line"):
+            self._arg_line = None
+        if bar_arg_line and self._arg_line is None:
+            line = C.c_void_p()
+            check(lib.gps_track_arg_line_alloc(C.byref(line)), "gps_track_arg_line_alloc")
+            self._arg_line = line if line.value else None
+            if self._arg_line is not None:
+                weakref.finalize(self, lib.gps_track_arg_line_free, self._arg_line)
+        self.track_state.dev_arg_line = self._arg_line if bar_arg_line else None
 
     def ProcessFrameTracked(self, rgb_u8, depth_mm_i16):
         """-> (M, invM) estimated by the tracker (ORUtils layout, numpy float32[16]).  Host-synchronous (see

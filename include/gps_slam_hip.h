@@ -672,6 +672,11 @@ typedef struct {
     /* 0: the next tracking call zeroes its scratch words first (set by gps_track_state_reset and after a failed call; set it
      * to 0 yourself when you hand the state a DIFFERENT scratch buffer); otherwise owned by the library */
     int32_t scratch_epoch;
+    /* optional (with host_mailbox): 64 bytes of HOST-WRITABLE DEVICE memory from gps_track_arg_line_alloc.  If set, the host
+     * writes a pre-launched evaluation's argument line straight into HBM through the PCIe BAR (write-combining stores + sfence)
+     * and every workgroup polls it there; NULL = the line lives in the pinned mailbox, one workgroup polls it across PCIe and
+     * relays it.  Owned by the caller; kept by gps_track_state_reset. */
+    void *dev_arg_line;
 } gps_track_state;
 
 /* Builds the configuration from the reference's tracker string parameters (ITMLibSettings.cpp:54-57 default:
@@ -683,6 +688,13 @@ GPS_API int gps_track_config_init(gps_track_config *c, const char *levels, int n
 
 /* ITMTrackingState::Reset: identity poses, no point cloud yet. */
 GPS_API int gps_track_state_reset(gps_track_state *ts);
+
+/* 64 bytes (one line, 64-byte aligned) of fine-grained device memory the HOST can write through the BAR, for
+ * gps_track_state.dev_arg_line.  *line = NULL (and GPS_OK) when the device's memory is not host-visible (no large BAR): the
+ * tracker then keeps its pinned argument line.  The one place the library allocates: ordinary device memory (hipMalloc, a torch
+ * tensor) is not host-writable, so the caller cannot provide this block itself.  Free with gps_track_arg_line_free. */
+GPS_API int gps_track_arg_line_alloc(void **line);
+GPS_API int gps_track_arg_line_free(void *line);
 
 /* Device scratch (depth pyramid levels >= 1, reduction partials) for images of this size. */
 GPS_API int64_t gps_track_scratch_bytes(int width, int height);

@@ -272,9 +272,12 @@ def test_tracker_without_mailbox_gives_the_same_poses():
     seq = synth.make_sequence(W, H, n, step_deg=0.4)
     rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
     runs = []
-    for mode in ("mailbox", "memcpy", "new-scratch"):
+    for mode in ("mailbox", "memcpy", "new-scratch", "pinned-line"):
         eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.01, mu=0.04, device="cuda:0")
-        eng.turnOnTracking()
+        # "mailbox": the default hand-over -- pre-launched evaluations, argument line written through the BAR into device memory
+        # (gps_track_state.dev_arg_line) when the device has a large BAR; "pinned-line": the line in the pinned mailbox, relayed
+        eng.turnOnTracking(bar_arg_line=mode != "pinned-line")
+        assert (eng.track_state.dev_arg_line is None) == (mode == "pinned-line" or eng._arg_line is None)
         if mode == "memcpy":
             eng.track_state.host_mailbox = None
         poses = []
@@ -285,7 +288,7 @@ def test_tracker_without_mailbox_gives_the_same_poses():
             M, invM = eng.ProcessFrameTracked(_dev(rgba[f]), _dev(seq["depth"][f].astype(np.int16)))
             poses.append(invM.copy())
         runs.append(np.stack(poses))
-    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    assert all(np.array_equal(runs[0], r) for r in runs[1:])
     assert np.abs(runs[0][-1] - runs[0][0]).max() > 1e-3  # the camera actually moved
 
 
