@@ -35,6 +35,8 @@
 #include <immintrin.h>
 #include <math.h>
 #include <sched.h>
+#include <setjmp.h>
+#include <signal.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -658,6 +660,28 @@ int gps_track_state_reset(gps_track_state* ts) {
     return GPS_OK;
 }
 
+static thread_local sigjmp_buf g_probe_jmp;
+static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+static bool host_can_write(void* p) {
+    struct sigaction sa = {}, old_segv = {}, old_bus = {};
+    sa.sa_handler = probe_fault;
+    sigemptyset(&sa.sa_mask);
+    if (sigaction(SIGSEGV, &sa, &old_segv) != 0) return false;
+    if (sigaction(SIGBUS, &sa, &old_bus) != 0) { sigaction(SIGSEGV, &old_segv, nullptr); return false; }
+    bool ok = false;
+    if (sigsetjmp(g_probe_jmp, 1) == 0) {
+        volatile uint64_t* q = static_cast<volatile uint64_t*>(p);
+        q[7] = 0x5A5A5A5A5A5A5A5Aull;
+        _mm_sfence();
+        ok = q[7] == 0x5A5A5A5A5A5A5A5Aull;
+        q[7] = 0;
+        _mm_sfence();
+    }
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    sigaction(SIGBUS, &old_bus, nullptr);
+    return ok;
+}
+
 int gps_track_arg_line_alloc(void** line) {
     if (!line) return GPS_ERR_ARG;
     *line = nullptr;
@@ -670,6 +694,9 @@ int gps_track_arg_line_alloc(void** line) {
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return GPS_OK; }
     if (hipMemset(p, 0, 4096) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return GPS_ERR_LAUNCH; }
+    // The attribute says the aperture exists, not that THIS process may store through it (a restricted container can map the
+    // device without it): probe one store + load under a fault handler, once, here -- never in the tracking loop.
+    if (!host_can_write(p)) { (void)hipFree(p); return GPS_OK; }
     *line = p;
     return GPS_OK;
 }
