@@ -33,6 +33,7 @@
 // are reproducible run to run; they differ from the CPU engine's scan-order sums only by float re-association (poses agree
 // to ~1e-5, tests/test_tsdf_gpu.py).
 #include <immintrin.h>
+#include <x86intrin.h>
 #include <math.h>
 #include <sched.h>
 #include <setjmp.h>
@@ -899,11 +900,26 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                 if (prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
                 // spin on the sequence number the kernel writes last (bounded)
                 bool got = false;
+                // (diagnostic, free: the time-stamp counter around every poll tells a GPU that answered late from a host
+                // thread that was not running -- the longest gap between two consecutive polls is ~20 ns unless the thread
+                // was descheduled in between)
+                const unsigned long long tsc0 = __rdtsc();
+                unsigned long long tsc_prev = tsc0, tsc_gap = 0;
                 for (long spin = 0; spin < 200000000L; spin++) {
                     if (float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq) { got = true; break; }
+                    const unsigned long long now = __rdtsc();
+                    if (now - tsc_prev > tsc_gap) tsc_gap = now - tsc_prev;
+                    tsc_prev = now;
                     // a result normally lands within ~20 us (a few thousand polls); a host that is still spinning far beyond
                     // that is oversubscribed or the GPU is busy elsewhere: stop burning the core between polls
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+                }
+                if (tsc_prev - tsc0 > 6000000ull) {  // > ~2-3 ms at 2-3 GHz: rare; say which side lost the time
+                    static int said = 0;
+                    if (said < 16 && ++said)
+                        fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d answered after %.2f Mcycles (TSC); longest gap between two "
+                                        "polls of this thread %.2f Mcycles (level %d, iteration %d)\n", seq, (tsc_prev - tsc0) * 1e-6,
+                                tsc_gap * 1e-6, level, iter);
                 }
                 if (!got) {
                     // No answer within the spin budget.  Either launch `seq` gave up before its line arrived (this thread was

@@ -7,4 +7,4 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l); c = j['config']; print('overlap %.1f' % (j['value']), [round(x, 3) for x in c['windows_ms_per_step']], 'mallocs', c['schedules']['overlap'].get('windows_device_mallocs'))
-"; grep "^frame\|^flush" gpurun_out/rep_err_$i.log | awk '$1 == "frame" && $3 > 2.5 {printf "   %s %s ms;", $2, $3} END {print ""}'; grep "^\[pipe\]\|gps_slam_hip" gpurun_out/rep_err_$i.log | tail -12; done
+"; grep "^frame\|^flush" gpurun_out/rep_err_$i.log | awk '$1 == "frame" && $3 > 2.5 {printf "   %s %s ms;", $2, $3} END {print ""}'; grep "^\[pipe\]\|gps_slam_hip" gpurun_out/rep_err_$i.log | grep -v "frame 1[01]:\|update 1:" | tail -12; done
