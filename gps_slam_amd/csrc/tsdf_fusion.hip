@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void alloc_request_kernel(TsdfState s, Mat4 in
 
 // ---------------------------------------------------------------- ordered sweeps over the hash slots
 constexpr int SWEEP = 1024;  // slots per workgroup
+constexpr int SCAN_THREADS = 256;  // the single-workgroup scan of the per-workgroup counts (<= 1,152 of them: 5 per thread)
 
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* ws /*[17]*/, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -165,9 +166,10 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* ws /*[17]*/, int
     if (lane == 63) ws[wave] = incl;
     __syncthreads();
     if (wave == 0) {
-        int sv = lane < 16 ? ws[lane] : 0;
+        const int nw = (int)blockDim.x >> 6;  // (16 waves or fewer)
+        int sv = lane < nw ? ws[lane] : 0;
         int si = wave_incl_scan_i(sv);
-        if (lane < 16) ws[lane] = si - sv;
+        if (lane < nw) ws[lane] = si - sv;
         if (lane == 63) ws[16] = si;
     }
     __syncthreads();
@@ -177,33 +179,65 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* ws /*[17]*/, int
     return r;
 }
 
+// The sweeps' workgroups: SWEEP slots each, walked by SWEEP_THREADS threads that own SLOTS_PER_THREAD CONSECUTIVE slots (so the
+// order of a compaction is still the slot order).  Round 3: 256 threads x 4 slots instead of 1,024 x 1 -- a 16-wave workgroup
+// needs four free wave slots on every SIMD of ONE compute unit at the same moment, and beside the map stream's rasterizer
+// (8-wave workgroups that refill a unit as soon as one of them retires) it waited for that for up to 50 us (rocprof, overlap
+// table: alloc_count / alloc_apply / visible_count 13-16 us on average against 8 alone, max 48-52); a 4-wave workgroup fits into
+// the hole ANY retiring rasterizer workgroup leaves.
+constexpr int SWEEP_THREADS = 256, SLOTS_PER_THREAD = SWEEP / SWEEP_THREADS;
+static_assert(SLOTS_PER_THREAD == 4 && SWEEP_THREADS == 256, "block_excl_scan_4 is written for 4 waves x 4 slots");
+
+// exclusive prefix of v[0..3] of every thread over the workgroup's 1,024 slots (thread-major), total to `total`
+__device__ __forceinline__ void block_excl_scan_4(const int (&v)[4], int* ws /*[5]*/, int (&excl)[4], int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    const int incl = wave_incl_scan_i(mine);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int a = ws[0], b = ws[1], c = ws[2], d = ws[3];
+        ws[0] = 0; ws[1] = a; ws[2] = a + b; ws[3] = a + b + c; ws[4] = a + b + c + d;
+    }
+    __syncthreads();
+    excl[0] = ws[wave] + incl - mine;
+    excl[1] = excl[0] + v[0]; excl[2] = excl[1] + v[1]; excl[3] = excl[2] + v[2];
+    total = ws[4];
+    __syncthreads();
+}
+
 // request type of a slot given the PRE-allocation table: empty bucket -> 1 (ordered), occupied chain end -> 2
 __device__ __forceinline__ int request_type(const TsdfState& s, int idx) {
     if (s.alloc_prio[idx] == 0u) return 0;
     return s.hash[idx].ptr < -1 ? 1 : 2;
 }
 
-__global__ __launch_bounds__(SWEEP) void alloc_count_kernel(TsdfState s, int32_t* __restrict__ blk1, int32_t* __restrict__ blk2) {
+__global__ __launch_bounds__(SWEEP_THREADS) void alloc_count_kernel(TsdfState s, int32_t* __restrict__ blk1, int32_t* __restrict__ blk2) {
     GPS_FRAME_PRIO();
-    __shared__ int ws[17];
-    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    __shared__ int ws[5];
+    const int idx0 = blockIdx.x * SWEEP + threadIdx.x * SLOTS_PER_THREAD;
     const int n_total = s.n_buckets + s.n_excess;
-    const int t = idx < n_total ? request_type(s, idx) : 0;
+    int t1[4], t2[4], e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int t = idx0 + j < n_total ? request_type(s, idx0 + j) : 0;
+        t1[j] = t == 1; t2[j] = t == 2;
+    }
     int tot1, tot2;
-    block_excl_scan_1024(t == 1, ws, tot1);
-    block_excl_scan_1024(t == 2, ws, tot2);
+    block_excl_scan_4(t1, ws, e, tot1);
+    block_excl_scan_4(t2, ws, e, tot2);
     if (threadIdx.x == 0) { blk1[blockIdx.x] = tot1; blk2[blockIdx.x] = tot2; }
 }
 
 // single workgroup: exclusive scan of up to two arrays of per-block counts, totals to out_tot[0..1]
-__global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __restrict__ a, int32_t* __restrict__ b,
-                                                          int32_t* __restrict__ out_tot, const ViewRec* __restrict__ views) {
+__global__ __launch_bounds__(SCAN_THREADS) void scan_counts_kernel(int nblk, int32_t* __restrict__ a, int32_t* __restrict__ b,
+                                                                  int32_t* __restrict__ out_tot, const ViewRec* __restrict__ views) {
     GPS_FRAME_PRIO();
     __shared__ int ws[17];
     if (views) {  // free-view batch: the sweep counts and the list length of view blockIdx.z
         a = views[blockIdx.z].scratch + 2 * nblk; b = nullptr; out_tot = views[blockIdx.z].counters + GPS_TSDF_N_VISIBLE_FREE;
     }
-    const int per = (nblk + 1023) / 1024;
+    const int per = (nblk + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = min(nblk, (int)threadIdx.x * per), hi = min(nblk, lo + per);
     for (int which = 0; which < 2; which++) {
         int32_t* arr = which == 0 ? a : b;
@@ -217,53 +251,65 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(int nblk, int32_t* __
     }
 }
 
-__global__ __launch_bounds__(SWEEP) void alloc_apply_kernel(TsdfState s, Mat4 invM, const int32_t* __restrict__ blk1,
-                                                           const int32_t* __restrict__ blk2, uint32_t* __restrict__ bits) {
+__global__ __launch_bounds__(SWEEP_THREADS) void alloc_apply_kernel(TsdfState s, Mat4 invM, const int32_t* __restrict__ blk1,
+                                                                   const int32_t* __restrict__ blk2, uint32_t* __restrict__ bits) {
     GPS_FRAME_PRIO();
-    __shared__ int ws[17];
-    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    __shared__ int ws[5];
+    const int idx0 = blockIdx.x * SWEEP + threadIdx.x * SLOTS_PER_THREAD;
     const int n_total = s.n_buckets + s.n_excess;
-    const uint32_t prio = idx < n_total ? s.alloc_prio[idx] : 0u;
-    const int t = prio == 0u ? 0 : (s.hash[idx].ptr < -1 ? 1 : 2);
+    uint32_t prio[4];
+    int t[4], t1[4], t2[4], c1[4], c2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        prio[j] = idx0 + j < n_total ? s.alloc_prio[idx0 + j] : 0u;
+        t[j] = prio[j] == 0u ? 0 : (s.hash[idx0 + j].ptr < -1 ? 1 : 2);
+        t1[j] = t[j] == 1; t2[j] = t[j] == 2;
+    }
     int tot;
-    const int c1 = blk1[blockIdx.x] + block_excl_scan_1024(t == 1, ws, tot);
-    const int c2 = blk2[blockIdx.x] + block_excl_scan_1024(t == 2, ws, tot);
-    if (t == 0) return;
-    s.alloc_prio[idx] = 0u;  // leave the scratch clean for the next frame
-    // state of the sequential allocator when it reaches this slot (CPU.tpp:196-265): every earlier
+    block_excl_scan_4(t1, ws, c1, tot);
+    block_excl_scan_4(t2, ws, c2, tot);
+    if ((t[0] | t[1] | t[2] | t[3]) == 0) return;
+    const int base1 = blk1[blockIdx.x], base2 = blk2[blockIdx.x];
+    // state of the sequential allocator when it reaches a slot (CPU.tpp:196-265): every earlier
     // type-1 request and the first E type-2 requests consumed one voxel block each.
     const int lastBlock = s.counters[GPS_TSDF_LAST_FREE_BLOCK], lastExcess = s.counters[GPS_TSDF_LAST_FREE_EXCESS];
     const int E = lastExcess + 1;
-    const int vbaIdx = lastBlock - (c1 + min(c2, E));
-    const int exlIdx = lastExcess - c2;
-    // winner's block coordinates, re-derived from (pixel, step)
-    const int loc = (int)(prio >> BAND_STEP_BITS) - 1, step = (int)(prio & ((1u << BAND_STEP_BITS) - 1u));
-    const int y = loc / s.width, x = loc - y * s.width;
-    BandWalk w;
-    band_begin(s, invM, x, y, w);
-    for (int i = 0; i < step; i++) { w.px += w.dx; w.py += w.dy; w.pz += w.dz; }
-    gps_hash_entry ne;
-    ne.pos[0] = (short)floorf(w.px); ne.pos[1] = (short)floorf(w.py); ne.pos[2] = (short)floorf(w.pz);
-    ne.pad_ = 0; ne.offset = 0;
-    if (t == 1) {
-        if (vbaIdx >= 0) {
-            ne.ptr = s.vba_alloc_list[vbaIdx];
-            s.hash[idx] = ne;
-            atomicOr(&bits[idx >> 5], 1u << (idx & 31));  // bucket head now non-empty (idx < n_buckets for type-1 requests)
-            s.visible_type[idx] = 1;  // "new entry is visible" (Shared.h:311)
-            atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
+    for (int j = 0; j < 4; j++) {
+        if (t[j] == 0) continue;
+        const int idx = idx0 + j;
+        s.alloc_prio[idx] = 0u;  // leave the scratch clean for the next frame
+        const int n1 = base1 + c1[j], n2 = base2 + c2[j];
+        const int vbaIdx = lastBlock - (n1 + min(n2, E));
+        const int exlIdx = lastExcess - n2;
+        // winner's block coordinates, re-derived from (pixel, step)
+        const int loc = (int)(prio[j] >> BAND_STEP_BITS) - 1, step = (int)(prio[j] & ((1u << BAND_STEP_BITS) - 1u));
+        const int y = loc / s.width, x = loc - y * s.width;
+        BandWalk w;
+        band_begin(s, invM, x, y, w);
+        for (int i = 0; i < step; i++) { w.px += w.dx; w.py += w.dy; w.pz += w.dz; }
+        gps_hash_entry ne;
+        ne.pos[0] = (short)floorf(w.px); ne.pos[1] = (short)floorf(w.py); ne.pos[2] = (short)floorf(w.pz);
+        ne.pad_ = 0; ne.offset = 0;
+        if (t[j] == 1) {
+            if (vbaIdx >= 0) {
+                ne.ptr = s.vba_alloc_list[vbaIdx];
+                s.hash[idx] = ne;
+                atomicOr(&bits[idx >> 5], 1u << (idx & 31));  // bucket head now non-empty (idx < n_buckets for type-1 requests)
+                s.visible_type[idx] = 1;  // "new entry is visible" (Shared.h:311)
+                atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
+            } else {
+                s.visible_type[idx] = 0;
+            }
         } else {
-            s.visible_type[idx] = 0;
-        }
-    } else {
-        if (vbaIdx >= 0 && exlIdx >= 0) {
-            ne.ptr = s.vba_alloc_list[vbaIdx];
-            const int exlOffset = s.excess_list[exlIdx];
-            s.hash[idx].offset = exlOffset + 1;
-            s.hash[s.n_buckets + exlOffset] = ne;
-            s.visible_type[s.n_buckets + exlOffset] = 1;
-            atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
-            atomicAdd(&s.counters[GPS_TSDF_SCRATCH1], 1);
+            if (vbaIdx >= 0 && exlIdx >= 0) {
+                ne.ptr = s.vba_alloc_list[vbaIdx];
+                const int exlOffset = s.excess_list[exlIdx];
+                s.hash[idx].offset = exlOffset + 1;
+                s.hash[s.n_buckets + exlOffset] = ne;
+                s.visible_type[s.n_buckets + exlOffset] = 1;
+                atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
+                atomicAdd(&s.counters[GPS_TSDF_SCRATCH1], 1);
+            }
         }
     }
 }
@@ -290,12 +336,12 @@ __device__ __forceinline__ bool slot_visible(const TsdfState& s, const Mat4& M, 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(SWEEP) void visible_count_kernel(TsdfState s, Mat4 M, int32_t* __restrict__ blk,
-                                                             uint8_t* __restrict__ flags, const ViewRec* __restrict__ views) {
+__global__ __launch_bounds__(SWEEP_THREADS) void visible_count_kernel(TsdfState s, Mat4 M, int32_t* __restrict__ blk,
+                                                                     uint8_t* __restrict__ flags, const ViewRec* __restrict__ views) {
     GPS_FRAME_PRIO();
-    __shared__ int ws[17];
+    __shared__ int ws[5];
     if (views) { apply_view(s, views[blockIdx.z]); M = views[blockIdx.z].M; blk = sweep_counts(s); flags = sweep_flags(s); }
-    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    const int idx0 = blockIdx.x * SWEEP + threadIdx.x * SLOTS_PER_THREAD;
     const int n_total = s.n_buckets + s.n_excess;
     if (MODE == VIS_LIVE && blockIdx.x == 0 && threadIdx.x == 0) {
         // fold the allocation bookkeeping of this frame into the counters (ordered after alloc_apply)
@@ -304,26 +350,35 @@ __global__ __launch_bounds__(SWEEP) void visible_count_kernel(TsdfState s, Mat4 
         s.counters[GPS_TSDF_SCRATCH0] = 0;
         s.counters[GPS_TSDF_SCRATCH1] = 0;
     }
-    const bool v = idx < n_total ? slot_visible<MODE>(s, M, idx, true) : false;
-    if (idx < n_total) flags[idx] = v ? 1 : 0;
+    int v[4], e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j] = idx0 + j < n_total ? (slot_visible<MODE>(s, M, idx0 + j, true) ? 1 : 0) : 0;
+        if (idx0 + j < n_total) flags[idx0 + j] = (uint8_t)v[j];
+    }
     int tot;
-    block_excl_scan_1024(v ? 1 : 0, ws, tot);
+    block_excl_scan_4(v, ws, e, tot);
     if (threadIdx.x == 0) blk[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(SWEEP) void visible_write_kernel(TsdfState s, const int32_t* __restrict__ blk,
-                                                             const uint8_t* __restrict__ flags,
-                                                             int32_t* __restrict__ out_ids, int cap,
-                                                             const ViewRec* __restrict__ views) {
+__global__ __launch_bounds__(SWEEP_THREADS) void visible_write_kernel(TsdfState s, const int32_t* __restrict__ blk,
+                                                                     const uint8_t* __restrict__ flags,
+                                                                     int32_t* __restrict__ out_ids, int cap,
+                                                                     const ViewRec* __restrict__ views) {
     GPS_FRAME_PRIO();
-    __shared__ int ws[17];
+    __shared__ int ws[5];
     if (views) { apply_view(s, views[blockIdx.z]); blk = sweep_counts(s); flags = sweep_flags(s); out_ids = s.fv_visible_ids; }
-    const int idx = blockIdx.x * SWEEP + threadIdx.x;
+    const int idx0 = blockIdx.x * SWEEP + threadIdx.x * SLOTS_PER_THREAD;
     const int n_total = s.n_buckets + s.n_excess;
-    const bool v = idx < n_total ? flags[idx] != 0 : false;
+    int v[4], e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = idx0 + j < n_total ? (flags[idx0 + j] != 0 ? 1 : 0) : 0;
     int tot;
-    const int pos = blk[blockIdx.x] + block_excl_scan_1024(v ? 1 : 0, ws, tot);
-    if (v && pos < cap) out_ids[pos] = idx;
+    block_excl_scan_4(v, ws, e, tot);
+    const int base = blk[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (v[j] && base + e[j] < cap) out_ids[base + e[j]] = idx0 + j;
 }
 
 // ---------------------------------------------------------------- integration
@@ -562,14 +617,14 @@ int gps_tsdf_allocate(const gps_tsdf_state* sp, const float* M, const float* inv
     int32_t* tot = s.scan_scratch + 3 * nblk;  // [2] totals scratch
     mark_previous_visible_kernel<<<256, 256, 0, st>>>(s);
     alloc_request_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(s, im);
-    alloc_count_kernel<<<nblk, SWEEP, 0, st>>>(s, blk1, blk2);
-    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blk1, blk2, tot, nullptr);
-    alloc_apply_kernel<<<nblk, SWEEP, 0, st>>>(s, im, blk1, blk2, bucket_bits(s));
+    alloc_count_kernel<<<nblk, SWEEP_THREADS, 0, st>>>(s, blk1, blk2);
+    scan_counts_kernel<<<1, SCAN_THREADS, 0, st>>>(nblk, blk1, blk2, tot, nullptr);
+    alloc_apply_kernel<<<nblk, SWEEP_THREADS, 0, st>>>(s, im, blk1, blk2, bucket_bits(s));
     // ordered visible list (byte flags live behind the per-block counts in scan_scratch)
     uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
-    visible_count_kernel<VIS_LIVE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags, nullptr);
-    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE], nullptr);
-    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.visible_ids, s.n_blocks, nullptr);
+    visible_count_kernel<VIS_LIVE><<<nblk, SWEEP_THREADS, 0, st>>>(s, m, blkv, flags, nullptr);
+    scan_counts_kernel<<<1, SCAN_THREADS, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE], nullptr);
+    visible_write_kernel<<<nblk, SWEEP_THREADS, 0, st>>>(s, blkv, flags, s.visible_ids, s.n_blocks, nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -585,9 +640,9 @@ int gps_tsdf_find_visible(const gps_tsdf_state* sp, const float* M, gps_stream s
     const int nblk = gps_div_up(n_total, SWEEP);
     int32_t* blkv = s.scan_scratch + 2 * nblk;
     uint8_t* flags = reinterpret_cast<uint8_t*>(s.scan_scratch + 3 * nblk + 16);
-    visible_count_kernel<VIS_FREE><<<nblk, SWEEP, 0, st>>>(s, m, blkv, flags, nullptr);
-    scan_counts_kernel<<<1, 1024, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE_FREE], nullptr);
-    visible_write_kernel<<<nblk, SWEEP, 0, st>>>(s, blkv, flags, s.fv_visible_ids, s.n_blocks, nullptr);
+    visible_count_kernel<VIS_FREE><<<nblk, SWEEP_THREADS, 0, st>>>(s, m, blkv, flags, nullptr);
+    scan_counts_kernel<<<1, SCAN_THREADS, 0, st>>>(nblk, blkv, nullptr, &s.counters[GPS_TSDF_N_VISIBLE_FREE], nullptr);
+    visible_write_kernel<<<nblk, SWEEP_THREADS, 0, st>>>(s, blkv, flags, s.fv_visible_ids, s.n_blocks, nullptr);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -599,9 +654,9 @@ namespace gpst {
 int find_visible_batch(const TsdfState& s, int n, const ViewRec* table, hipStream_t st) {
     const int nblk = sweep_blocks(s);
     const Mat4 none = {};
-    visible_count_kernel<VIS_FREE><<<dim3(nblk, 1, n), SWEEP, 0, st>>>(s, none, nullptr, nullptr, table);
-    scan_counts_kernel<<<dim3(1, 1, n), 1024, 0, st>>>(nblk, nullptr, nullptr, nullptr, table);
-    visible_write_kernel<<<dim3(nblk, 1, n), SWEEP, 0, st>>>(s, nullptr, nullptr, nullptr, s.n_blocks, table);
+    visible_count_kernel<VIS_FREE><<<dim3(nblk, 1, n), SWEEP_THREADS, 0, st>>>(s, none, nullptr, nullptr, table);
+    scan_counts_kernel<<<dim3(1, 1, n), SCAN_THREADS, 0, st>>>(nblk, nullptr, nullptr, nullptr, table);
+    visible_write_kernel<<<dim3(nblk, 1, n), SWEEP_THREADS, 0, st>>>(s, nullptr, nullptr, nullptr, s.n_blocks, table);
     return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 }  // namespace gpst
