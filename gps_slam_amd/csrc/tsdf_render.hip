@@ -31,7 +31,10 @@ namespace {
 //     rewrites them every call; here gps_tsdf_reset writes them once and nothing ever touches them again.
 // The rendering-block count accumulates in a scratch counter that pass B publishes and clears, so no memset launch
 // precedes pass A.
-constexpr int ED_THREADS = 1024;  // ~45k visible blocks over 64 x 1024 threads: one block per thread, no dependent second trip
+#ifndef GPS_ED_THREADS
+#define GPS_ED_THREADS 512
+#endif
+constexpr int ED_THREADS = GPS_ED_THREADS;  // ~45k visible blocks over 64 x 1024 threads: one block per thread, no dependent second trip
 
 __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
                                                                      const int32_t* __restrict__ vis_ids, int count_slot,
