@@ -315,8 +315,9 @@ def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():
         assert (diff != 0).sum() <= 1e-4 * diff.size
         gt8 = (n_(cam.image) * np.float32(255.0)).astype(np.uint8)
         assert np.array_equal(n_(e["gt_u8"]), gt8)
-        mse_o = np.mean((want.astype(np.float32) / 255.0 - gt8.astype(np.float32) / 255.0) ** 2, dtype=np.float64)
-        psnr_o = 20.0 * np.log10(1.0 / np.sqrt(mse_o))
+        # the reference's own PSNR (scripts/utils/image_utils.py:19-21; the helper is pinned by its output in the CPU suite)
+        from tests.test_reference_python_pin import psnr_like_the_reference
+        psnr_o = psnr_like_the_reference(want / 255.0, gt8 / 255.0)
         assert abs(float(e["psnr_u8"]) - psnr_o) < 0.01, (float(e["psnr_u8"]), psnr_o)       # BASELINE's bar is 0.1 dB
         assert np.array_equal(n_(e["raycast_color_u8"]), (n_(e["raycast_color"]) * np.float32(255.0)).astype(np.uint8))
         d_mm = np.clip(np.rint(n_(e["raycast_depth"]) * np.float32(1000.0)), 0, 65535).astype(np.int32)
