@@ -137,6 +137,59 @@ def test_engine_matches_oracle_full_size(W, H, voxel, mu, frames):
     o.close()
 
 
+def test_engine_matches_the_reference_engine_when_the_block_array_is_exhausted():
+    """Maximum size: 0x40000 voxel blocks exhausted in frame 5, two more frames fused with nothing left to allocate -- the HIP
+    engine against the REFERENCE engine's own digests (tests/golden/refdigest_tsdf_exhaustion_320x240_v2mm.npz), every frame."""
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    from tests.test_oracle_tsdf import check_against_fullsize_digest, exhaustion_scene
+    G, seq, args, n = exhaustion_scene()
+    eng = TsdfEngine(*args)
+    v = EngineView(eng)
+    for f in range(n):
+        eng.ProcessFrame(_dev(seq["rgb"][f]), _dev(seq["depth"][f].astype(np.int16)), seq["c2w"][f])
+        check_against_fullsize_digest(v, G, f)
+    assert v.last_free_block == -1
+    assert int(v._c()[5]) == 0  # the rendering-block cap was not hit (its order dependence is the one documented difference)
+
+
+@pytest.mark.parametrize("W,H,n_blocks,n_buckets,n_excess", [(100, 75, 3000, 1 << 12, 64), (160, 120, 1 << 14, 1 << 10, 1 << 9),
+                                                            (77, 50, 1 << 15, 1 << 16, 1 << 12)])
+def test_small_tables_ragged_images_and_empty_frames_match_the_oracle(W, H, n_blocks, n_buckets, n_excess):
+    """Exhaustion of the voxel-block array (n_blocks) AND of the excess list (few buckets: long chains, then no excess entry left),
+    image sizes that are no multiple of the 8-pixel min/max cell or the 16-pixel workgroup patch, a frame without a single valid
+    depth (all zero) in the middle and one with a hole: HIP == the CPU restatement bit for bit, frame by frame."""
+    from gps_slam_amd.tsdf_engine import TsdfEngine
+    from oracle import tsdf_ref as R
+    frames = 6
+    seq = synth.make_sequence(W, H, frames, step_deg=12.0)
+    depth = seq["depth"].copy()
+    depth[2] = 0                                   # an empty frame
+    depth[3, H // 4:H // 2, W // 3:2 * W // 3] = 0  # a hole
+    geo = (W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.01, 0.04, 0.2, 10.0)
+    o = R.TsdfOracle(*geo, n_blocks=n_blocks, n_buckets=n_buckets, n_excess=n_excess)
+    eng = TsdfEngine(*geo, n_blocks=n_blocks, n_buckets=n_buckets, n_excess=n_excess)
+    v = EngineView(eng)
+    for f in range(frames):
+        M, invM = eng.ProcessFrame(_dev(seq["rgb"][f]), _dev(depth[f].astype(np.int16)), seq["c2w"][f])
+        oM, oInv = R.pose_from_c2w(seq["c2w"][f])
+        o.process_frame(seq["rgb"][f], depth[f], oM, oInv)
+        assert [v.n_visible, v.last_free_block, v.last_free_excess] == [o.n_visible, o.last_free_block, o.last_free_excess], f
+        assert bits_equal(v.visible_ids(), o.visible_ids()), f
+        assert bits_equal(v.hash_rows(), o.hash_rows()), f
+        assert bits_equal(v.visible_type(), o.visible_type()), f
+        for name in ("depth", "raycast", "icp_points", "icp_normals"):
+            assert bits_equal(v.image(name), o.image(name)), (name, f)
+        assert minmax_equal(v.image("minmax"), o.image("minmax"), True), f
+        assert crc_of_blocks(v.allocated_blocks()) == crc_of_blocks(o.allocated_blocks()), f
+    print("counters at the end:", [v.n_visible, v.last_free_block, v.last_free_excess])
+    fM, fInv = eng.runRaycast(seq["c2w"][1])
+    o.free_raycast(fM, fInv)
+    assert bits_equal(v.fv_visible_ids(), o.fv_visible_ids())
+    for name in ("fv_raycast", "fv_colour"):
+        assert bits_equal(v.image(name), o.image(name)), name
+    o.close()
+
+
 @pytest.mark.parametrize("W,H,voxel,mu,frames,n_views", [(160, 120, 0.01, 0.04, 6, 5), (640, 480, 0.005, 0.02, 12, 9)])
 def test_batched_free_views_equal_one_view_at_a_time(W, H, voxel, mu, frames, n_views):
     """gps_tsdf_free_raycast_batch (every launch of the free-view chain covers all views, per-view render state) against
