@@ -9,10 +9,14 @@
  * this path and its implementation is CUDA-only (cannot run here), so this
  * restatement is pinned only by (i) line-by-line reading of the cited CUDA
  * sources and (ii) the autograd / finite-difference cross-checks in
- * tests/test_oracle_splat.py.  One exception: orc_ssim_fwd / orc_ssim_bwd ARE
- * pinned by reference output -- gsplat/rasterizer/ssim.cu compiles for gfx950
- * from its own source (oracle/ref_ssim_build.py) and its outputs are the
- * fixture tests/golden/ssim_ref_gfx950.npz.
+ * tests/test_oracle_splat.py.  Two exceptions ARE pinned by reference output:
+ * orc_ssim_fwd / orc_ssim_bwd -- gsplat/rasterizer/ssim.cu compiles for gfx950
+ * from its own source (oracle/ref_ssim_build.py), its outputs are the fixture
+ * tests/golden/ssim_ref_gfx950.npz; and orc_sh_fwd / orc_sh_bwd -- the
+ * reference's own Python scripts/utils/sh_utils.eval_sh (+ autograd), degrees
+ * 0..4, outputs in tests/golden/refpy_sh_ssim_psnr.npz
+ * (tests/test_reference_python_pin.py).  Projection, binning and the
+ * rasterizers remain UNPINNED.
  *
  * Plain scalar fp32 C, compiled with -ffp-contract=off.  Every function cites
  * the reference file:line (relative to /root/reference) it restates.
