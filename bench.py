@@ -156,12 +156,21 @@ def setup_ranks(backend="nccl", need_gpu=True):
     from gps_slam_amd.dist_util import Group, env_ranks, pin_to_gpu_numa
     rank, local_rank, world = env_ranks()
     device = None
+    grp_device = None
     if need_gpu:
         assert torch.cuda.is_available(), "bench.py needs the MI355X"
-        torch.cuda.set_device(local_rank)
-        device = "cuda:%d" % local_rank
-    placement = pin_to_gpu_numa(local_rank, world)
-    grp = Group(backend=backend, device=device)
+        dev_index = local_rank
+        ndev = torch.cuda.device_count()
+        if ndev < world and os.environ.get("GPS_BENCH_SHARE_GPU"):
+            # rehearsal of the N > 1 launch on a box with fewer GPUs than ranks (tools/probe/share_gpu.sh): the ranks share the
+            # devices there are and meet over gloo (RCCL refuses two ranks on one device).  Exercises everything per-rank --
+            # seeds, threads, pinned buffers, BAR lines, barriers, the aggregate line -- NOT a scaling measurement.
+            dev_index, backend = local_rank % ndev, "gloo"
+        torch.cuda.set_device(dev_index)
+        device = "cuda:%d" % dev_index
+        grp_device = device if backend == "nccl" else None
+    placement = pin_to_gpu_numa(dev_index if need_gpu else local_rank, world)
+    grp = Group(backend=backend, device=grp_device)
     return rank, local_rank, world, grp, placement, device
 
 
