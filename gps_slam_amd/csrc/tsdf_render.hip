@@ -200,14 +200,9 @@ __device__ __forceinline__ float blend_corners(const uint64_t (&r)[8], float cx,
 //    exactly like the first (no side effects, cache untouched);
 //  * cell straddling blocks: the eight bucket heads are fetched together, the eight lookups are replayed in the
 //    reference's order from registers (identical cache evolution), then the eight voxels are loaded together.
-template <bool WITH_CONF>
-__device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, float py, float pz, int& vmIndex,
-                                                 BlockCache& c, float& conf) {
-    const float fx_ = floorf(px), fy_ = floorf(py), fz_ = floorf(pz);
-    const float cx = px - fx_, cy = py - fy_, cz = pz - fz_;
-    const int ix = (int)fx_, iy = (int)fy_, iz = (int)fz_;
+// the eight voxels of the interpolation cell at (ix, iy, iz), x fastest: r[dx + 2*dy + 4*dz]; unallocated -> EMPTY_VOXEL
+__device__ __forceinline__ void fetch_cell(const TsdfState& s, int ix, int iy, int iz, int& vmIndex, BlockCache& c, uint64_t (&r)[8]) {
     const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
-    uint64_t r[8];  // x fastest: r[dx + 2*dy + 4*dz]
     if ((ix & 7) < 7 && (iy & 7) < 7 && (iz & 7) < 7) {
         int lin;
         const int base = resolve_block(s, ix, iy, iz, lin, vmIndex, c);
@@ -244,6 +239,15 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = idx[k] >= 0 ? t[k] : EMPTY_VOXEL;
     }
+}
+
+template <bool WITH_CONF>
+__device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, float py, float pz, int& vmIndex,
+                                                 BlockCache& c, float& conf) {
+    const float fx_ = floorf(px), fy_ = floorf(py), fz_ = floorf(pz);
+    const float cx = px - fx_, cy = py - fy_, cz = pz - fz_;
+    uint64_t r[8];  // x fastest: r[dx + 2*dy + 4*dz]
+    fetch_cell(s, (int)fx_, (int)fy_, (int)fz_, vmIndex, c, r);
     vmIndex = 1;
     return blend_corners<WITH_CONF>(r, cx, cy, cz, conf);
 }
@@ -583,11 +587,16 @@ __global__ __launch_bounds__(256) void colour_kernel(TsdfState s, const float4* 
     const int ix = (int)fx_, iy = (int)fy_, iz = (int)fz_;
     BlockCache c = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, wsum = 0.f;
-    int vm;
+    int vm = 0;
+    // the reference reads the eight corners one after the other through the block cache (up to 16 dependent round trips for a
+    // cell that straddles blocks); the lookups have no side effect the colour depends on, so they go out as the raycaster's
+    // interpolated read does: one lookup + eight voxels for a cell inside one block, eight heads then eight voxels otherwise
+    uint64_t corner[8];
+    fetch_cell(s, ix, iy, iz, vm, c, corner);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
-        const uint64_t raw = read_voxel_raw(s, ix + dx, iy + dy, iz + dz, vm, c);
+        const uint64_t raw = corner[k];
         if (((raw >> 48) & 0xFF) >= 1) {
             const float wx = dx ? cx : (1.0f - cx), wy = dy ? cy : (1.0f - cy), wz = dz ? cz : (1.0f - cz);
             const float w = wx * wy * wz;
