@@ -165,6 +165,13 @@ constexpr int EV_MAX_WGS = GPS_TRACK_EV_MAX_WGS;           // rows of the partia
                                           // nothing either, 0.721: launch + tail + the host round trip dominate an iteration.)
 constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 
+// The frame's valid-pixel count lives behind the 16-word block, spread over VC_SLOTS words per frame parity: the prepare
+// kernel's workgroups add into slot (workgroup % VC_SLOTS) -- 1,200 atomics on ONE word cost the kernel 10 of its 16 us
+// (tools/probe/prep_probe.sh: 16.3 us, 6.1 without the atomic, 15.3 without the point / normal interleave) -- and the summer's
+// first 32 lanes add the slots up (and clear the other parity's) where one lane used to read the word.
+constexpr int VC_BASE = 16, VC_SLOTS = 32;
+static_assert(VC_SLOTS == GH_SLOTS, "one slot per lane of the result's half-wave");
+
 // per-level constants of the evaluation (kernel arguments of track_eval_poll_kernel)
 struct LevelTab { const float* depth; int vw, vh; float ix, iy, iz, iw; float space_thresh; int n_wgs; };
 
@@ -179,7 +186,7 @@ struct PrepArgs {
     const float4* normals;
     float4* pn;
     int W, H;
-    uint32_t* sync;                     // [0] the evaluation's ticket, [1 + parity] valid-pixel count of this frame (zero on entry)
+    uint32_t* sync;                     // [0] the evaluation's ticket, [VC_BASE + parity * VC_SLOTS + k] valid-pixel count slots of this frame (zero on entry)
     int parity;
 };
 
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
     }
     for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o, 64);
     // zero on entry: the evaluation launches of the PREVIOUS frame cleared this slot (they read the other one)
-    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.sync[1 + a.parity], (uint32_t)valid);
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.sync[VC_BASE + a.parity * VC_SLOTS + (blockIdx.x & (VC_SLOTS - 1))], (uint32_t)valid);
 }
 
 // The same for pyramids of up to 5 levels (coarsest pixel <= 16 x 16 full-resolution pixels; the default "rrbb" has 4): one
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
     if (threadIdx.x == 0) {
         const int v = (wv[0] + wv[1]) + (wv[2] + wv[3]);
         // zero on entry: the evaluation launches of the PREVIOUS frame cleared this slot (they read the other one)
-        if (v) atomicAdd(&a.sync[1 + a.parity], (uint32_t)v);
+        if (v) atomicAdd(&a.sync[VC_BASE + a.parity * VC_SLOTS + (blockIdx.x & (VC_SLOTS - 1))], (uint32_t)v);
     }
     // level l from level l - 1: filterSubsampleWithHoles (mean of the valid children, ITMLowLevelEngine_Shared.h:48-69)
     for (int l = 1; l < L; l++) {
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
 // Against the ticket version this takes three memory-side round trips out of every iteration's dependent chain (row
 // acknowledgement, ticket, mailbox acknowledgement); under the map stream's memory traffic each of them was ~2-3 us.
 __device__ __forceinline__ int chunk_word(int d) { return d + d / 15; }
-// words of the 16-word `sync` block besides [0] ticket and [1], [2] valid-pixel counts: the pre-launched evaluation's profile
+// words of the 16-word `sync` block besides [0] ticket ([1], [2]: unused since the valid-pixel counts moved behind the block): the pre-launched evaluation's profile
 constexpr int SYNC_SPIN_TICKS = 8, SYNC_EVAL_TICKS = 9, SYNC_EVALS = 10, SYNC_SKIPPED = 11;
 constexpr long long ROW_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
 
@@ -390,14 +397,18 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
         const int d = tid - (tid >> 4);
         uint32_t wv = (uint32_t)seq;
         float t = 0.0f;
+        // the frame's valid-pixel count: lane k fetches slot k, clears the next frame's slot k; five shuffles add them up
+        uint32_t vc = __hip_atomic_load(&sync[VC_BASE + parity * VC_SLOTS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[VC_BASE + (1 - parity) * VC_SLOTS + tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) vc += (uint32_t)__shfl_xor((int)vc, o, 32);
         if ((tid & 15) != 15) {
             if (d < 29) {
 #pragma unroll
                 for (int g2 = 0; g2 < EV_ROW_GROUPS; g2++) t += group[g2][tid];
                 wv = __float_as_uint(t);
             } else {  // d == 29: the frame's valid-pixel count
-                wv = __hip_atomic_load(&sync[1 + parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&sync[2 - parity], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next frame's count slot
+                wv = vc;
             }
         }
         result[tid] = __uint_as_float(wv);  // (device copy, same layout: the host_mailbox == NULL path reads it back)
@@ -613,7 +624,7 @@ size_t carve(Scratch* w, char* base, int W, int H) {
     }
     char* p = take((size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;
     p = take(64 * sizeof(float)); if (w) w->result = (float*)p;
-    p = take(64); if (w) w->sync = (uint32_t*)p;
+    p = take((VC_BASE + 2 * VC_SLOTS) * sizeof(uint32_t)); if (w) w->sync = (uint32_t*)p;   // 16 control words + the valid-count slots of both parities
     p = take(64); if (w) w->dev_line = (uint32_t*)p;
     p = take((size_t)W * H * 2 * sizeof(float4)); if (w) w->pn = (float4*)p;
     return off;
@@ -772,7 +783,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     // other frame's count slot, so the steady state needs no memset launch in front of the frame.
     int parity = 0;
     if (ts->scratch_epoch == 0) {
-        if (hipMemsetAsync(w.sync, 0, 64, st) != hipSuccess) GPS_FAIL_LAUNCH();
+        if (hipMemsetAsync(w.sync, 0, (VC_BASE + 2 * VC_SLOTS) * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
         // row tags: sequence numbers are >= 1, so a zeroed table can never look like a delivered row
         if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
     } else {
@@ -1048,8 +1059,10 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     if (eval_launches > 0) {
         n_max = n_valid_bits;  // delivered with every evaluation's sums
     } else {
-        if (hipMemcpyAsync(&n_max, w.sync + 1 + parity, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
+        int slots[VC_SLOTS];
+        if (hipMemcpyAsync(slots, w.sync + VC_BASE + parity * VC_SLOTS, sizeof(slots), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
         if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
+        for (int k = 0; k < VC_SLOTS; k++) n_max += slots[k];
     }
     ts->diag[8] = (float)nvalid_depth_good; ts->diag[9] = f_depth_good;
     ts->diag[10] = n_max > 0 ? sqrtf(((float)nvalid_depth_good * f_depth_good + (float)(n_max - nvalid_depth_good) * c->space_thresh[0]) /
