@@ -268,12 +268,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void alloc_apply_kernel(TsdfState s,
     int tot;
     block_excl_scan_4(t1, ws, c1, tot);
     block_excl_scan_4(t2, ws, c2, tot);
-    if ((t[0] | t[1] | t[2] | t[3]) == 0) return;
+    if (__ballot((t[0] | t[1] | t[2] | t[3]) != 0) == 0ull) return;  // (wave-uniform: every lane of a wave with requests stays for the count reduction)
     const int base1 = blk1[blockIdx.x], base2 = blk2[blockIdx.x];
     // state of the sequential allocator when it reaches a slot (CPU.tpp:196-265): every earlier
     // type-1 request and the first E type-2 requests consumed one voxel block each.
     const int lastBlock = s.counters[GPS_TSDF_LAST_FREE_BLOCK], lastExcess = s.counters[GPS_TSDF_LAST_FREE_EXCESS];
     const int E = lastExcess + 1;
+    int n_blocks_taken = 0, n_excess_taken = 0;  // this thread's allocations: added to the frame's scratch counters once per wave
     for (int j = 0; j < 4; j++) {
         if (t[j] == 0) continue;
         const int idx = idx0 + j;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void alloc_apply_kernel(TsdfState s,
                 s.hash[idx] = ne;
                 atomicOr(&bits[idx >> 5], 1u << (idx & 31));  // bucket head now non-empty (idx < n_buckets for type-1 requests)
                 s.visible_type[idx] = 1;  // "new entry is visible" (Shared.h:311)
-                atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
+                n_blocks_taken++;
             } else {
                 s.visible_type[idx] = 0;
             }
@@ -307,10 +308,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void alloc_apply_kernel(TsdfState s,
                 s.hash[idx].offset = exlOffset + 1;
                 s.hash[s.n_buckets + exlOffset] = ne;
                 s.visible_type[s.n_buckets + exlOffset] = 1;
-                atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], 1);
-                atomicAdd(&s.counters[GPS_TSDF_SCRATCH1], 1);
+                n_blocks_taken++;
+                n_excess_taken++;
             }
         }
+    }
+    int nb = n_blocks_taken, ne = n_excess_taken;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nb += __shfl_xor(nb, o, 64); ne += __shfl_xor(ne, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nb) atomicAdd(&s.counters[GPS_TSDF_SCRATCH0], nb);
+        if (ne) atomicAdd(&s.counters[GPS_TSDF_SCRATCH1], ne);
     }
 }
 

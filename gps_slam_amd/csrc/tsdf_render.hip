@@ -90,12 +90,21 @@ __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(Tsd
                 atomicMax(&img[x + y * sw].y, __float_as_uint(zmax));
             }
     }
-    const int tot = wave_sum_i(my_blocks);
-    if ((threadIdx.x & 63) == 0 && tot) {
-        const int before = atomicAdd(&s.counters[GPS_TSDF_SCRATCH2], tot);
-        if (before + tot >= MAX_RENDERING_BLOCKS) *overflow_word = 1;
-    }
+    // one atomic per WORKGROUP on the rendering-block counter (same-address atomics serialise at the memory side: the tracker's
+    // prepare kernel spent 10 of its 16 us on 1,200 of them)
+    __shared__ int wave_tot[ED_THREADS / 64];
+    const int tot_w = wave_sum_i(my_blocks);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = tot_w;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < ED_THREADS / 64; k++) tot += wave_tot[k];
+        if (tot) {
+            const int before = atomicAdd(&s.counters[GPS_TSDF_SCRATCH2], tot);
+            if (before + tot >= MAX_RENDERING_BLOCKS) *overflow_word = 1;
+        }
+    }
     uint2* out = partial + (size_t)blockIdx.x * sw * sh;
     for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) out[i] = img[i];
 }
