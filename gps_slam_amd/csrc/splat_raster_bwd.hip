@@ -24,9 +24,28 @@
 // Work list: Gaussian ids by class, inside a class by (image band, id) so that neighbouring groups -- and an XCD's contiguous
 // eighth of the list -- gather from neighbouring pixels; built by the binning (splat_bin.hpp: bwd_key); 64 / GW Gaussians per
 // wave task.  Any order gives the same rows.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "splat_bin.hpp"
 #include "splat_math.hpp"
+
+// Residency reserve for the frame chain (gps_set_frame_chain_reserve; GPS_MAP_RESERVE=0/1 in the environment overrides it).
+// The strip kernel runs 6 workgroups = 6 waves x 80 VGPRs per SIMD: 480 of the 512 registers, and a wave of it that retires
+// frees 80 -- never the 112 one wave of the tracker's pre-launched evaluation needs, so beside this kernel an evaluation's
+// workgroups waited until two strip waves of one SIMD retired at the same moment, while every freed slot went to the next strip
+// workgroup (kernel timeline around a keyframe: 17 evaluations in 626 us instead of ~190).  With the reserve on, 28 KB of unused
+// dynamic LDS per workgroup lets 5 of them share a compute unit (5 x 28 <= 160 KB < 6 x 28): 400 registers per SIMD, 112 free.
+// Measured (tools/probe/ab_envval.sh, 3 + 3 runs): overlap schedule 1,290 -> 1,315 frames/s; the strip kernel alone is slower
+// with 5 waves (sequential schedule 963 -> 951), so the pipeline switches the reserve on only while tracking and mapping overlap.
+// The forward rasterizer (a retiring workgroup frees 2 x 64), the batched free-view raycaster and colour kernels: no gain, left alone.
+static int g_frame_chain_reserve = 0;
+static inline int frame_chain_reserve_lds() {
+    static const int env = [] { const char* e = std::getenv("GPS_MAP_RESERVE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+    const int on = env >= 0 ? env : __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED);
+    return on ? 28 * 1024 : 0;
+}
+
 
 namespace {
 
@@ -317,7 +336,7 @@ int raster_ges_bwd_strips_launch(int N, const float* records, const int32_t* rad
 #ifndef GPS_BWD_STRIP_BLOCKS
 #define GPS_BWD_STRIP_BLOCKS (256 * GPS_STRIP_WAVES)   // every wave resident at once: 256 CUs x GPS_STRIP_WAVES workgroups of 4 waves
 #endif
-    raster_ges_bwd_strip_kernel<<<GPS_BWD_STRIP_BLOCKS, 256, 0, (hipStream_t)stream>>>(a);
+    raster_ges_bwd_strip_kernel<<<GPS_BWD_STRIP_BLOCKS, 256, frame_chain_reserve_lds(), (hipStream_t)stream>>>(a);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -325,6 +344,9 @@ int raster_ges_bwd_strips_launch(int N, const float* records, const int32_t* rad
 }  // namespace gps
 
 extern "C" {
+
+void gps_set_frame_chain_reserve(int on) { __atomic_store_n(&g_frame_chain_reserve, on ? 1 : 0, __ATOMIC_RELAXED); }
+
 
 int gps_raster_ges_bwd_strips(int N, const float* records, const int32_t* radii, const int32_t* cls_ids,
                               const int32_t* cls_counts, int cls_stride, const float* v_render_colors, const float* pix2,

@@ -156,6 +156,13 @@ GPS_API int gps_raster_ges_bwd_gs(int N, const float *means2d, const float *coni
 GPS_API int gps_raster_ges_bwd_strips(int N, const float *records, const int32_t *radii, const int32_t *cls_ids,
                                       const int32_t *cls_counts, int cls_stride, const float *v_render_colors,
                                       const float *pix2, int width, int height, float *v_rows, gps_stream stream);
+/* Scheduling hint, process-wide (no reference counterpart: the reference runs tracking and mapping one after the other).  on != 0:
+ * gps_raster_ges_bwd_strips / gps_splat_train_step launch the strip backward with 28 KB of unused dynamic LDS per workgroup, so
+ * that 5 instead of 6 of its workgroups share a compute unit and one workgroup of the tracker's pre-launched evaluation (112
+ * VGPRs per wave) always finds room beside it.  For hosts that run a frame chain (tracking / fusion) on one stream WHILE the map
+ * update runs on another (host/slam_pipeline.cpp: overlap_mapping); a host that runs them in turn leaves it off -- the strip
+ * kernel alone is faster with 6.  Results do not depend on it.  GPS_MAP_RESERVE=0/1 in the environment overrides the call. */
+GPS_API void gps_set_frame_chain_reserve(int on);
 /* records[N,12] (the 48-byte records gps_gauss_preprocess_fwd writes, incl. the ellipse bounds) from the operator-level arrays
  * means2d[N,2] conics[N,3] colors[N,4] (rgb + depth) opacities[N] radii[N]: lets a caller that holds those run the strip backward */
 GPS_API int gps_raster_pack_records(int N, const float *means2d, const float *conics, const float *colors,
