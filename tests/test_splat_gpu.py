@@ -252,6 +252,15 @@ def test_raster_ges_fwd_bwd(N, W, H):
     assert flipped_s <= nb_g
     s2 = ops.rasterize_to_pixels_bwd_ges_strips(tm2, tcon, tcol, top, T(radii)[None], tref, W, H, delta, T(v_rc)[None], T(v_ra)[None, ..., None])
     assert all(torch.equal(a, b) for a, b in zip(s_, s2)), "the strip backward has no atomics: bit-reproducible"
+    # the residency reserve (gps_set_frame_chain_reserve: unused dynamic LDS, 5 instead of 6 workgroups per compute unit) is a
+    # scheduling hint: the same bits with it on
+    from gps_slam_amd import _lib
+    _lib.load_library().gps_set_frame_chain_reserve(1)
+    try:
+        s3 = ops.rasterize_to_pixels_bwd_ges_strips(tm2, tcon, tcol, top, T(radii)[None], tref, W, H, delta, T(v_rc)[None], T(v_ra)[None, ..., None])
+    finally:
+        _lib.load_library().gps_set_frame_chain_reserve(0)
+    assert all(torch.equal(a, b) for a, b in zip(s_, s3)), "results must not depend on the residency reserve"
     print("bwd (strips): %d Gaussians flipped" % flipped_s)
     # determinism of the sorted order: two runs give bit-identical forward output
     rc2, ra2, _ = ops.rasterize_to_pixels_fwd_ges(tm2, tcon, tcol, top, tref, W, H, TS, isect, delta)
