@@ -66,6 +66,7 @@ class AdamSegment(C.Structure):
 # name -> (restype, argtypes); mirrors include/gps_slam_hip.h one to one
 PROTOTYPES = {
     "gps_version": (C.c_char_p, []),
+    "gps_build_flags": (C.c_char_p, []),
     "gps_proj_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
     "gps_proj_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_sh_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),

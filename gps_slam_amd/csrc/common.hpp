@@ -30,6 +30,20 @@
 
 static inline int gps_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- build-time probe switches (gps_build_flags) ----
+// The kernels keep a few compile-time tunables (-DGPS_...=n) for A/B builds (tools/probe/variant.py).  Every translation unit
+// reports the ones it was compiled with: a tunable whose value differs from the shipped default, or a defined probe switch,
+// lands in the string gps_build_flags() returns.  The shipped library reports "" -- tests/test_abi_cpu.py and
+// __graft_entry__.smoke() assert it.
+namespace gps {
+void report_build_flag(const char* name, long value);   // splat_project.hip
+struct BuildFlag {
+    BuildFlag(const char* name, long value, long shipped) { if (value != shipped) report_build_flag(name, value); }
+};
+}  // namespace gps
+#define GPS_TUNABLE_REPORT(name, shipped) static const gps::BuildFlag gps_build_flag_##name(#name, (long)(name), (long)(shipped))
+#define GPS_SWITCH_REPORT(name) static const gps::BuildFlag gps_build_flag_##name(#name, 1L, 0L)
+
 // ---- wave64 reductions (DPP-free, shuffle based; all 64 lanes active) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -20,6 +20,7 @@ using namespace gps;
 #ifndef GPS_FUSED_ADAM_THREADS
 #define GPS_FUSED_ADAM_THREADS 128
 #endif
+GPS_TUNABLE_REPORT(GPS_FUSED_ADAM_THREADS, 128);
 
 namespace {
 

@@ -7,6 +7,8 @@
 // 256-thread workgroups, grid >> 256 CUs for N >= 100k, no LDS, no atomics
 // (C = 1 camera so the reference's warp-reduce + atomicAdd degenerates to a
 // plain store; the reference's zeros_like memsets are folded into the stores).
+#include <string>
+
 #include "splat_math.hpp"
 
 using namespace gps;
@@ -129,6 +131,16 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int K, const float* 
     if (v_dirs != nullptr) { v_dirs[3 * i] = vd[0]; v_dirs[3 * i + 1] = vd[1]; v_dirs[3 * i + 2] = vd[2]; }
 }
 
+// registry behind gps_build_flags(): filled by the static gps::BuildFlag objects of every translation unit while the library loads
+static std::string& build_flags() { static std::string f; return f; }
+void gps::report_build_flag(const char* name, long value) {
+    std::string& f = build_flags();
+    const std::string item = std::string(name) + "=" + std::to_string(value);
+    if ((" " + f + " ").find(" " + item + " ") != std::string::npos) return;   // (a header's tunable: one copy)
+    if (!f.empty()) f += ' ';
+    f += item;
+}
+
 extern "C" {
 
 int gps_proj_fwd(int N, const float* means, const float* quats, const float* scales, const float* viewmat,
@@ -200,6 +212,8 @@ int gps_sh_bwd(int N, int K, int degrees_to_use, const float* dirs, const float*
     return GPS_OK;
 }
 
-const char* gps_version(void) { return "gps-slam-hip 0.1 (gfx950)"; }
+const char* gps_version(void) { return "gps-slam-hip 0.4 (gfx950)"; }
+
+const char* gps_build_flags(void) { return build_flags().c_str(); }
 
 }  // extern "C"

@@ -132,7 +132,9 @@ __device__ __forceinline__ float compose_l1_pixel(const gps::FwdCompose& fc, int
 #ifndef GPS_FWD_LIST_SPLIT
 #define GPS_FWD_LIST_SPLIT 4
 #endif
+GPS_TUNABLE_REPORT(GPS_FWD_LIST_SPLIT, 4);
 #ifdef GPS_FWD_STAMPS
+GPS_SWITCH_REPORT(GPS_FWD_STAMPS);
 // probe builds only (tools/probe/fwd_stamps.py): 100 MHz timestamps of workgroup phases, 8 per tile
 __device__ unsigned long long gps_fwd_stamps_buf[4096 * 8];
 extern "C" GPS_API void* gps_fwd_stamps() { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(gps_fwd_stamps_buf)); return p; }
@@ -158,6 +160,7 @@ constexpr int FWD_THREADS = 128 * FWD_SPLIT;
 #ifndef GPS_FWD_BATCH
 #define GPS_FWD_BATCH 512
 #endif
+GPS_TUNABLE_REPORT(GPS_FWD_BATCH, 512);
 constexpr int FWD_BATCH = GPS_FWD_BATCH;         // list entries staged per batch (a thread stages FWD_TRIPS of them)
 constexpr int FWD_TRIPS = (FWD_BATCH + FWD_THREADS - 1) / FWD_THREADS;
 constexpr int FWD_SEGS = FWD_BATCH / 64;         // 64-entry segments of a batch (one ballot each)
@@ -259,12 +262,8 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
             const v2f e = sig + b.y;              // sigma' - log2(opacity)
             float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.x));
             float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.y));
-#ifdef GPS_FWD_EXPERIMENT_NOTESTS   // (probe only: upper bound of what dropping the per-pixel depth / sigma tests can give)
-            const bool hit0 = !(al0 < 1.f / 255.f), hit1 = !(al1 < 1.f / 255.f);
-#else
             const bool hit0 = !(b.z > cut0) && !(sig.x < 0.f) && !(al0 < 1.f / 255.f);
             const bool hit1 = !(b.z > cut1) && !(sig.y < 0.f) && !(al1 < 1.f / 255.f);
-#endif
             const v2f al = {hit0 ? al0 : 0.f, hit1 ? al1 : 0.f};
             o0 += b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += b.z * al; ws += al;
         };
@@ -421,6 +420,7 @@ struct __attribute__((aligned(16))) BwdRec {
 #ifndef GPS_BWD_INFLIGHT
 #define GPS_BWD_INFLIGHT 1
 #endif
+GPS_TUNABLE_REPORT(GPS_BWD_INFLIGHT, 1);
 constexpr int BWD_INFLIGHT = GPS_BWD_INFLIGHT;
 struct BwdPix { bool on; float alpha, vis, dx, dy, cut; float4 vc; float va; };
 
@@ -650,3 +650,6 @@ int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, cons
 }
 
 }  // extern "C"
+
+// build-time tunables defined inside functions above (gps_build_flags)
+GPS_TUNABLE_REPORT(GPS_BWD_BLOCKS, 4096);

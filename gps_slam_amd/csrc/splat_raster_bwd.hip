@@ -30,7 +30,7 @@
 #include "splat_bin.hpp"
 #include "splat_math.hpp"
 
-// Residency reserve for the frame chain (gps_set_frame_chain_reserve; GPS_MAP_RESERVE=0/1 in the environment overrides it).
+// Residency reserve for the frame chain (gps_set_frame_chain_reserve).
 // The strip kernel runs 6 workgroups = 6 waves x 80 VGPRs per SIMD: 480 of the 512 registers, and a wave of it that retires
 // frees 80 -- never the 112 one wave of the tracker's pre-launched evaluation needs, so beside this kernel an evaluation's
 // workgroups waited until two strip waves of one SIMD retired at the same moment, while every freed slot went to the next strip
@@ -41,9 +41,7 @@
 // The forward rasterizer (a retiring workgroup frees 2 x 64), the batched free-view raycaster and colour kernels: no gain, left alone.
 static int g_frame_chain_reserve = 0;
 static inline int frame_chain_reserve_lds() {
-    static const int env = [] { const char* e = std::getenv("GPS_MAP_RESERVE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
-    const int on = env >= 0 ? env : __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED);
-    return on ? 28 * 1024 : 0;
+    return __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED) ? 28 * 1024 : 0;
 }
 
 
@@ -101,15 +99,14 @@ struct StripPix {
     int W, H;
 };
 
-#ifndef GPS_STRIP_EXPERIMENT
-#define GPS_STRIP_EXPERIMENT 0
-#endif
 #ifndef GPS_STRIP_PIPE
 #define GPS_STRIP_PIPE 0
 #endif
+GPS_TUNABLE_REPORT(GPS_STRIP_PIPE, 0);
 #ifndef GPS_STRIP_WAVES
 #define GPS_STRIP_WAVES 6
 #endif
+GPS_TUNABLE_REPORT(GPS_STRIP_WAVES, 6);
 constexpr float STRIP_LOG2E = 1.4426950408889634f;
 constexpr uint32_t STRIP_OOB = 0x7FFFFFF0u;  // a byte offset past every buffer: the load returns 0 without touching memory
 
@@ -173,18 +170,9 @@ __device__ __forceinline__ bool strip_task(const float4* __restrict__ recs, cons
             R.onB = rowok && !(s.y < 0.f) && !(R.alB < 1.f / 255.f);
             const uint32_t fA = R.onA ? offA : STRIP_OOB, fB = R.onB ? offB : STRIP_OOB;
             R.vcA = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(px.rc, fA, 0, 0));
-#if GPS_STRIP_EXPERIMENT != 2
             R.vcB = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(px.rc, fB, 0, 0));
-#endif
-#if GPS_STRIP_EXPERIMENT == 1   // timing experiment only (wrong results): no {v_alpha, cut} gathers
-            R.pA = make_float2(R.dy, 1000.f); R.pB = make_float2(R.alA, 1000.f);
-#else
             R.pA = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(px.p2, fA >> 1, 0, 0));
             R.pB = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(px.p2, fB >> 1, 0, 0));
-#endif
-#if GPS_STRIP_EXPERIMENT == 2   // timing experiment only (wrong results): the right-hand column reads nothing
-            R.vcB = R.vcA; R.pB = R.pA;
-#endif
             pyf += 1.0f;
             offA += row_bytes; offB += row_bytes;
             ++q;
@@ -379,3 +367,6 @@ int gps_raster_pair_image(int width, int height, const float* v_render_alphas, c
 }
 
 }  // extern "C"
+
+// build-time tunables defined inside functions above (gps_build_flags)
+GPS_TUNABLE_REPORT(GPS_BWD_STRIP_BLOCKS, 256 * 6);

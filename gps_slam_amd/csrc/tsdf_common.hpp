@@ -12,6 +12,7 @@
 #define GPS_FRAME_PRIO_LEVEL 3
 #endif
 #define GPS_FRAME_PRIO() __builtin_amdgcn_s_setprio(GPS_FRAME_PRIO_LEVEL)
+GPS_TUNABLE_REPORT(GPS_FRAME_PRIO_LEVEL, 3);   // (once per including translation unit; the registry keeps one copy)
 
 namespace gpst {
 

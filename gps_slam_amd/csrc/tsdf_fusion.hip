@@ -689,3 +689,7 @@ int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stre
 }
 
 }  // extern "C"
+
+// build-time tunables defined inside functions above (gps_build_flags)
+GPS_TUNABLE_REPORT(GPS_INTEGRATE_SLICES, 4);
+GPS_TUNABLE_REPORT(GPS_INTEGRATE_WGS, 4096);

@@ -34,6 +34,7 @@ namespace {
 #ifndef GPS_ED_THREADS
 #define GPS_ED_THREADS 512
 #endif
+GPS_TUNABLE_REPORT(GPS_ED_THREADS, 512);
 constexpr int ED_THREADS = GPS_ED_THREADS;  // ~45k visible blocks over 64 x 1024 threads: one block per thread, no dependent second trip
 
 __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
@@ -135,6 +136,10 @@ __global__ __launch_bounds__(256) void expected_depths_reduce_kernel(TsdfState s
 struct BlockCache { int bx, by, bz, ptr; };
 #ifndef GPS_RAYCAST_SKIP
 #define GPS_RAYCAST_SKIP 5
+#endif
+GPS_TUNABLE_REPORT(GPS_RAYCAST_SKIP, 5);
+#ifdef GPS_ED_REDUCE_LAUNCH   // (probe builds: pass B of the expected depths as its own launch)
+GPS_SWITCH_REPORT(GPS_ED_REDUCE_LAUNCH);
 #endif
 constexpr int SKIP = GPS_RAYCAST_SKIP;  // free-space look-ahead of the raycaster, 1..31
 
@@ -272,6 +277,9 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
                                                      const ViewRec* __restrict__ views, const uint2* __restrict__ partial, int sw,
                                                      int sh, float2* __restrict__ mm_out) {
     GPS_FRAME_PRIO();
+    __shared__ uint32_t wg_acc[4];  // this workgroup's {steps, reads, rays, waves done}
+    if (threadIdx.x < 4) wg_acc[threadIdx.x] = 0;
+    __syncthreads();
     if (views) {
         apply_view(s, views[blockIdx.z]); invM = views[blockIdx.z].invM;
         minmax = reinterpret_cast<const float2*>(s.fv_minmax); rays = reinterpret_cast<float4*>(s.fv_raycast);
@@ -301,10 +309,12 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
             s.counters[GPS_TSDF_SCRATCH2] = 0;
         }
     }
-    if (x >= s.width || y >= s.height) return;
+    // Lanes outside the image stay in the wave with an empty range (no loop trip, no store): the step statistics below are summed
+    // with cross-lane operations that every lane takes part in.
+    const bool inside = x < s.width && y < s.height;
     const int W = s.width;
     const int loc2 = (int)floorf((float)x / MINMAX_SUB) + (int)floorf((float)y / MINMAX_SUB) * W;
-    const float2 mm = partial ? mm_cell : minmax[loc2];
+    const float2 mm = !inside ? make_float2(0.f, 0.f) : partial ? mm_cell : minmax[loc2];
     const float oneOverVoxelSize = 1.0f / s.voxel_size;
     const float ipx = 1.0f / s.fx, ipy = 1.0f / s.fy, ipz = -s.cx, ipw = -s.cy;
     const float stepScale = s.mu * oneOverVoxelSize;
@@ -329,29 +339,13 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     BlockCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
     float sdfValue = 1.0f, confidence = 0.f, stepLength;
     int vmIndex = 0;
-#ifdef GPS_RAYCAST_STATS
-    int n_un = 0, n_co = 0, n_in = 0, adv_sum = 0;
-    const float range0 = totalLengthMax - totalLength;
-    const uint64_t t_start = wall_clock64();
-    uint64_t tk_heads = 0, tk_vox = 0, tk_interp = 0, tk_tail = 0, tk0;
-#ifdef GPS_RAYCAST_STATS_TICKS  // (s_memrealtime costs ~1 us per call: off unless the per-section sums are wanted)
-#define TICK0() (tk0 = wall_clock64())
-#define TICK(acc) do { const uint64_t now_ = wall_clock64(); acc += now_ - tk0; tk0 = now_; } while (0)
-#else
-#define TICK0() ((void)tk0)
-#define TICK(acc) ((void)acc)
-#endif
-#else
-#define TICK0()
-#define TICK(acc)
-#endif
+    int n_steps = 0, n_reads = 0;  // castRay steps as the reference counts them / samples this loop actually reads
     const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
     while (totalLength < totalLengthMax) {
         // Candidate positions: [0] is this step's sample; [1..SKIP] are where the next steps land IF this and the
         // following lookups fail (a failed lookup always advances by one block edge, stepLength = 8 voxels) -- the same
         // float additions in the same order as the one-lookup-per-step loop.  A lane whose sample is in its cached
         // block needs no bucket at all; the others fetch all 1+SKIP bucket heads in one batch.
-        TICK0();
         const int vx = (int)roundf_ref(px), vy = (int)roundf_ref(py), vz = (int)roundf_ref(pz);
         const int kx0 = floor_div_blk(vx), ky0 = floor_div_blk(vy), kz0 = floor_div_blk(vz);
         const int lin = vx + (vy - kx0) * BLK + (vz - ky0) * BLK * BLK - kz0 * BLK3;
@@ -390,10 +384,6 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
         int base;
         if (cached) { vmIndex = 1; base = cache.ptr; }
         else base = resolve_with_head(s, kx0, ky0, kz0, head0, hidx0, vmIndex, cache);
-#ifdef GPS_RAYCAST_STATS
-        asm volatile("" : "+v"(base));
-        TICK(tk_heads);
-#endif
         // The sample voxel round(p) is a corner of the interpolation cell [floor(p), floor(p)+1]^3.  If that cell lies
         // inside one block it is this block, so its eight voxels ride along with the sample in the same round trip and
         // the interpolated read below -- whose corner lookups would all hit the cache that now holds this block --
@@ -413,14 +403,8 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
             }
         }
         sdfValue = vox_sdf(raw) / 32767.0f;
-#ifdef GPS_RAYCAST_STATS
-        asm volatile("" : "+v"(sdfValue));
-        TICK(tk_vox);
-#endif
         if (MODIFY_VISIBLE) { if (vmIndex) s.visible_type[vmIndex - 1] = 1; }  // incl. the vmIndex==1 cache-hit quirk
-#ifdef GPS_RAYCAST_STATS
-        if (!vmIndex) n_un++; else if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) n_in++; else n_co++;
-#endif
+        n_reads++;
         if (!vmIndex) {
             stepLength = BLK;
             // advance over the candidates that are certainly unallocated steps inside the range (empty bucket head); the
@@ -434,23 +418,16 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
                 const bool plain = cl_ < totalLengthMax && !((occupied >> j) & 1u);
                 if (adv == j - 1 && plain) { adv = j; px = cx_; py = cy_; pz = cz_; totalLength = cl_; }
             }
-#ifdef GPS_RAYCAST_STATS
-            adv_sum += adv;
-#endif
+            n_steps += adv;  // (each skipped candidate is one failed lookup = one step of the reference loop)
         } else {
             if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
                 float dummy;
-                TICK0();
                 if (cell_in_block) {
                     sdfValue = blend_corners<false>(corner, px - ffx, py - ffy, pz - ffz, dummy);
                     vmIndex = 1;
                 } else {
                     sdfValue = read_sdf_interp<false>(s, px, py, pz, vmIndex, cache, dummy);
                 }
-#ifdef GPS_RAYCAST_STATS
-                asm volatile("" : "+v"(sdfValue));
-                TICK(tk_interp);
-#endif
             }
             if (sdfValue <= 0.0f) break;
             const float a = sdfValue * stepScale;
@@ -458,10 +435,6 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
         }
         px += stepLength * rx; py += stepLength * ry; pz += stepLength * rz;
         totalLength += stepLength;
-#ifdef GPS_RAYCAST_STATS
-        asm volatile("" : "+v"(totalLength));
-        TICK(tk_tail);
-#endif
     }
     bool found;
     if (sdfValue <= 0.0f) {
@@ -474,17 +447,24 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     } else {
         found = false;
     }
-#ifdef GPS_RAYCAST_STATS
-    const uint64_t t_end = wall_clock64();
-#ifdef GPS_RAYCAST_STATS_SECTIONS
-    rays[x + y * W] = make_float4((float)n_un, (float)adv_sum, (float)(n_co + n_in), range0);
-#else
-    rays[x + y * W] = make_float4((float)(n_un + n_co + n_in), (float)n_un, __uint_as_float((uint32_t)t_start),
-                                  __uint_as_float((uint32_t)t_end));
-#endif
-    return;
-#endif
-    rays[x + y * W] = make_float4(px, py, pz, found ? confidence + 1.0f : 0.0f);
+    if (inside) rays[x + y * W] = make_float4(px, py, pz, found ? confidence + 1.0f : 0.0f);
+    // S-bar ("mean steps/ray logged by the kernel"): cumulative 64-bit sums in the counter block -- castRay steps as
+    // the reference's loop counts them (Shared.h:158-190: one per lookup; the free-space look-ahead above folds up to 1 + SKIP of
+    // them into one trip), the trips of THIS loop (= voxel reads), and the rays cast.  One sum per wave (shuffles), the four
+    // waves of a workgroup meet in LDS, the last one to arrive issues the workgroup's three atomics: 3,600 fire-and-forget atomics
+    // per 640x480 launch, spread over the kernel's duration (rays finish at different times).
+    const int wave_steps = wave_sum_i(n_steps + n_reads), wave_reads = wave_sum_i(n_reads), wave_rays = wave_sum_i(inside ? 1 : 0);
+    if (lane_ == 0) {
+        atomicAdd(&wg_acc[0], (uint32_t)wave_steps);
+        atomicAdd(&wg_acc[1], (uint32_t)wave_reads);
+        atomicAdd(&wg_acc[2], (uint32_t)wave_rays);
+        if (atomicAdd(&wg_acc[3], 1u) == 3u) {   // (LDS operations of one wave complete in order: the three sums are whole)
+            unsigned long long* st = reinterpret_cast<unsigned long long*>(s.counters + GPS_TSDF_RAY_STEPS);
+            atomicAdd(st, (unsigned long long)atomicAdd(&wg_acc[0], 0u));
+            atomicAdd(st + 1, (unsigned long long)atomicAdd(&wg_acc[1], 0u));
+            atomicAdd(st + 2, (unsigned long long)atomicAdd(&wg_acc[2], 0u));
+        }
+    }
 }
 
 // processPixelICP<useSmoothing = true, flipNormals = false> (Shared.h:252-330, 438-480)

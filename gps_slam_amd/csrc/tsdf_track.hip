@@ -154,10 +154,12 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float de
 #ifndef GPS_TRACK_EV_THREADS
 #define GPS_TRACK_EV_THREADS 256
 #endif
+GPS_TUNABLE_REPORT(GPS_TRACK_EV_THREADS, 256);
 constexpr int EV_THREADS = GPS_TRACK_EV_THREADS;
 #ifndef GPS_TRACK_EV_MAX_WGS
 #define GPS_TRACK_EV_MAX_WGS 256
 #endif
+GPS_TUNABLE_REPORT(GPS_TRACK_EV_MAX_WGS, 256);
 constexpr int EV_MAX_WGS = GPS_TRACK_EV_MAX_WGS;           // rows of the partial table.  Measured on the 640x480 loop (ms per tracked frame): 128 rows
                                           // 0.750, 256 rows 0.725, 512 rows 0.735, 1280 rows (one pixel per thread) 0.818 -- the last
                                           // workgroup's fixed-order sum costs what the evaluation's extra parallelism buys.  (Two

@@ -33,6 +33,13 @@ def pose_from_c2w(c2w):
     return M, invM
 
 
+def ray_stats_of(counters):
+    """{steps, reads, rays} from a counter block (int32[16] as numpy / tensor): castRay steps as the reference's loop counts
+    them, voxel reads of the kernel's own loop, rays cast -- cumulative since the last reset (S-bar = steps / rays)"""
+    c = np.ascontiguousarray(np.asarray(counters, dtype=np.int32)[10:16]).view(np.uint64)
+    return {"steps": int(c[0]), "reads": int(c[1]), "rays": int(c[2])}
+
+
 class TsdfEngine:
     """ITMBasicEngine with tracking switched off (use_gt_pose: true in every shipped config)."""
 
@@ -267,6 +274,10 @@ class TsdfEngine:
     # ---- host views for tests / persistence (sync)
     def counters_host(self):
         return self.counters.cpu().numpy()
+
+    def ray_stats(self):
+        """cumulative ray statistics of the live raycaster (include/gps_slam_hip.h GPS_TSDF_RAY_STEPS): see ray_stats_of"""
+        return ray_stats_of(self.counters_host())
 
     def hash_host(self):
         return self.hash.cpu().numpy().view(HASH_DT)

@@ -38,6 +38,10 @@ typedef void *gps_stream; /* hipStream_t */
 #define GPS_API __attribute__((visibility("default")))
 
 GPS_API const char *gps_version(void);
+/* Compile-time probe switches / tunables (-DGPS_...) this library was built with that differ from the shipped defaults, as
+ * "NAME=value NAME=value"; "" for the shipped build (asserted by tests/test_abi_cpu.py and __graft_entry__.smoke()): A/B
+ * builds made with tools/probe/variant.py identify themselves. */
+GPS_API const char *gps_build_flags(void);
 
 /* ------------------------------------------------------------------ */
 /* Splat: projection                                                   */
@@ -482,6 +486,13 @@ enum {
     GPS_TSDF_SCRATCH0 = 6,
     GPS_TSDF_SCRATCH1 = 7,
     GPS_TSDF_SCRATCH2 = 8,         /* rendering blocks of the CreateExpectedDepths in flight (published to [4], then cleared) */
+    /* ray statistics of gps_tsdf_raycast (S-bar, the mean steps per ray): three CUMULATIVE unsigned 64-bit sums in
+     * words [10..15] -- castRay steps as the reference's loop counts them (ITMVisualisationEngine_Shared.h:158-190), voxel
+     * reads of the kernel's own loop (it folds runs of unallocated steps into one trip), rays cast.  A free view of a batch logs
+     * into the view's own counter block.  Cleared by gps_tsdf_reset only: take differences. */
+    GPS_TSDF_RAY_STEPS = 10,
+    GPS_TSDF_RAY_READS = 12,
+    GPS_TSDF_RAYS = 14,
     GPS_TSDF_N_COUNTERS = 16
 };
 

@@ -69,6 +69,8 @@ typedef struct {
     int age_point_cloud, trk_frames;
     float trk_diag[16];
     float *trk_scratch;
+    /* ray statistics (SURVEY 8(d) S-bar): trips of castRay's loop and rays cast since creation, live + free views */
+    int64_t ray_steps, rays;
 } Tsdf;
 
 /* ---------------- construction / reset: Engines/Reconstruction/CPU/ITMSceneReconstructionEngine_CPU.tpp:26-50 ------------- */
@@ -640,7 +642,9 @@ static int cast_ray(Tsdf *t, V4 *out, uint8_t *visible_type /* NULL = do not mod
     Cache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
     float sdfValue = 1.0f, confidence = 0.f, stepLength;
     int vmIndex = 0;
+    t->rays++;
     while (totalLength < totalLengthMax) {
+        t->ray_steps++;
         sdfValue = read_sdf_uninterp(t, pr, &vmIndex, &cache);
         if (visible_type) { if (vmIndex) visible_type[vmIndex - 1] = 1; }
         if (!vmIndex) {
@@ -1200,6 +1204,8 @@ GETTER(trk_diag, void *, t->trk_diag)
 
 /* accessors for the python side */
 GETTER(n_visible, int, t->n_visible)
+GETTER(ray_steps, int64_t, t->ray_steps)
+GETTER(rays, int64_t, t->rays)
 GETTER(fv_n_visible, int, t->fv_n_visible)
 GETTER(last_free_block, int, t->last_free_block)
 GETTER(last_free_excess, int, t->last_free_excess)

@@ -142,6 +142,8 @@ def _lib():
             subprocess.check_call(["make", "-s", "-C", _HERE, so])
         _LIB = C.CDLL(so)
         _LIB.orc_tsdf_create.restype = C.c_void_p
+        _LIB.orc_tsdf_ray_steps.restype = C.c_int64
+        _LIB.orc_tsdf_rays.restype = C.c_int64
         for n in ("hash", "vba", "vba_alloc_list", "excess_list", "visible_ids", "visible_type", "minmax", "raycast", "icp_points", "icp_normals",
                   "depth", "fv_visible_ids", "fv_minmax", "fv_raycast", "fv_colour", "trk_diag"):
             getattr(_LIB, "orc_tsdf_" + n).restype = C.c_void_p
@@ -242,6 +244,10 @@ class TsdfOracle:
     @property
     def n_visible(self):
         return _lib().orc_tsdf_n_visible(self.h)
+
+    def ray_stats(self):
+        """{steps, rays}: trips of castRay's loop (Shared.h:158-190) and rays cast since creation (live + free views)"""
+        return {"steps": int(_lib().orc_tsdf_ray_steps(self.h)), "rays": int(_lib().orc_tsdf_rays(self.h))}
 
     @property
     def fv_n_visible(self):

@@ -33,6 +33,18 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.PROTOTYPES, "python binding lacks %s" % name
     lib = _lib.load_library()
     assert b"gfx950" in lib.gps_version()
+    # the shipped library carries no probe switch and every tunable at its shipped value (A/B variants say what they are)
+    assert lib.gps_build_flags() == b"", lib.gps_build_flags()
+
+
+def test_no_wrong_result_experiment_paths_in_the_product_kernels():
+    """Timing experiments that produce wrong results live in tools/probe/ (or in the history), not behind macros in csrc/."""
+    import re
+    csrc = os.path.join(ROOT, "gps_slam_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        txt = open(os.path.join(csrc, f), errors="ignore").read()
+        assert "wrong results" not in txt and not re.search(r"GPS_\w*EXPERIMENT", txt) and "GPS_RAYCAST_STATS" not in txt, f
+        assert "getenv" not in txt, "%s: no environment overrides inside the kernel library" % f
 
 
 def test_no_cpu_fallback_when_library_missing(tmp_path):

@@ -181,9 +181,15 @@ def test_small_tables_ragged_images_and_empty_frames_match_the_oracle(W, H, n_bl
             assert bits_equal(v.image(name), o.image(name)), (name, f)
         assert minmax_equal(v.image("minmax"), o.image("minmax"), True), f
         assert crc_of_blocks(v.allocated_blocks()) == crc_of_blocks(o.allocated_blocks()), f
-    print("counters at the end:", [v.n_visible, v.last_free_block, v.last_free_excess])
+        # S-bar: the kernel's step log counts the steps of the reference's castRay loop -- an integer, equal to the
+        # oracle's trip count although the kernel folds runs of unallocated steps into one trip (reads <= steps)
+        hs, os_ = eng.ray_stats(), o.ray_stats()
+        assert (hs["steps"], hs["rays"]) == (os_["steps"], os_["rays"]) and hs["reads"] <= hs["steps"], (f, hs, os_)
+    print("counters at the end:", [v.n_visible, v.last_free_block, v.last_free_excess], "ray stats:", eng.ray_stats())
     fM, fInv = eng.runRaycast(seq["c2w"][1])
     o.free_raycast(fM, fInv)
+    hs, os_ = eng.ray_stats(), o.ray_stats()
+    assert (hs["steps"], hs["rays"]) == (os_["steps"], os_["rays"]), (hs, os_)
     assert bits_equal(v.fv_visible_ids(), o.fv_visible_ids())
     for name in ("fv_raycast", "fv_colour"):
         assert bits_equal(v.image(name), o.image(name)), name

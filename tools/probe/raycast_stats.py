@@ -1,4 +1,8 @@
-"""Raycaster step / time statistics on the bench scene (instrumented library variants: tools/probe/variant.py stats tsdf_render.hip -DGPS_RAYCAST_STATS ...).
+"""Raycaster step / time statistics on the bench scene.  The instrumented kernel (per-ray step counts and 100 MHz ticks written OVER the
+ray image) left the product source in round 4 -- the product kernel now logs S-bar itself (counters[GPS_TSDF_RAY_STEPS..], TsdfEngine.ray_stats());
+for the per-wave distributions build the round-3 kernel as a variant:
+    mkdir -p /tmp/r3 && git show 0ef4a24:gps_slam_amd/csrc/tsdf_render.hip > /tmp/r3/tsdf_render.hip
+    python tools/probe/variant.py stats /tmp/r3/tsdf_render.hip -DGPS_RAYCAST_STATS
 usage (GPU box):  GPS_SLAM_HIP_LIB=tools/probe/libgps_stats.so python tools/probe/raycast_stats.py
                   GPS_SLAM_HIP_LIB=tools/probe/libgps_sections.so python tools/probe/raycast_stats.py sections"""
 import os, sys
