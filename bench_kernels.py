@@ -31,11 +31,12 @@ def iteration_bytes(N, Nv, I, G, P, T):
     return float(sum(terms.values())), {k: float(v) for k, v in terms.items()}
 
 
-def fusion_bytes(P, V, S):
-    """Algorithmic HBM bytes of one TSDF frame, SURVEY.md 8(d), WITHOUT the ray term (hash / voxel gathers of neighbouring
-    rays are largely L2 resident; S-bar, the mean steps per ray, is not logged by the kernel): upload + convert + allocate (depth
-    + 2 probes x 16 B) + two table sweeps + integrate R/W + visible list + min/max image + raycast outputs."""
-    return float(6 * P + 6 * P + 4 * P + 32 * P + 2 * S * 17 + V * 8192 + V * 16 + 8 * P / 64.0 + 20 * P)
+def fusion_bytes(P, V, S, s_bar=0.0):
+    """Algorithmic HBM bytes of one TSDF frame, SURVEY.md 8(d): upload + convert + allocate (depth + 2 probes x 16 B) + two table
+    sweeps + integrate R/W + visible list + min/max image + raycast outputs, plus the ray term P * S-bar * 24 (one 16-byte hash
+    entry + one 8-byte voxel per castRay step; S-bar = mean steps per ray as the kernel logs them, GPS_TSDF_RAY_STEPS).  The ray
+    term is an upper bound -- neighbouring rays share entries and voxels in the caches -- so callers report both figures."""
+    return float(6 * P + 6 * P + 4 * P + 32 * P + 2 * S * 17 + V * 8192 + V * 16 + 8 * P / 64.0 + 20 * P + 24.0 * P * s_bar)
 
 
 def _python_twin(scene, device, strip_backward=True):
@@ -66,7 +67,9 @@ def _pmc(kernel, N, tol=0.02):
     """profiles/pmc_<kernel>.json (tools/profile.sh: separate --pmc passes over THIS program's micro-benchmark loops) if it was
     collected on a scene of the same size (its recorded Gaussian count within 2 %), else None"""
     import json
-    fn = "pmc_binning.json" if kernel.startswith("binning") else "pmc_%s.json" % kernel
+    import re
+    fn = "pmc_binning.json" if kernel.startswith("binning") else \
+        "pmc_%s.json" % re.sub(r"[^A-Za-z0-9_]+", "_", kernel.split(" (")[0]).strip("_")   # (tools/pmc_extract.pmc_file_name)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fn)
     try:
         rec = json.load(open(path))
@@ -87,15 +90,6 @@ def _kernel_row(name, calls_per_frame, t, alg_bytes, hbm_peak_gbs, N, bound, not
         if rec.get("hbm_bytes_per_launch"):
             row["traffic"] = rec["hbm_bytes_per_launch"]
             row["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / max(1.0, alg_bytes)
-            if row["frac"] > 1.0:
-                # more algorithmic bytes per second than HBM delivers: part of them never reach HBM (the 256 MB MALL keeps
-                # state that the previous iteration wrote); the HBM-side rate is the honest occupancy of the 8 TB/s
-                row["hbm_side_GBs"] = rec["hbm_bytes_per_launch"] / t / 1e9
-                row["hbm_side_frac"] = row["hbm_side_GBs"] / hbm_peak_gbs
-                row["note"] = (row.get("note", "") + "; frac > 1: the algorithmic bytes (parameters + both Adam moments read and "
-                               "written) exceed what crosses the HBM interface -- the counters see traffic_over_algorithmic of them, "
-                               "the rest is served by the Infinity Cache between iterations; hbm_side_frac prices the counter "
-                               "bytes").lstrip("; ")
         v = (rec.get("sq") or {}).get("SQ_INSTS_VALU")
         if v:
             # counter collection serialises and slows the launches; the instruction COUNT carries over and is priced against
@@ -105,6 +99,20 @@ def _kernel_row(name, calls_per_frame, t, alg_bytes, hbm_peak_gbs, N, bound, not
         for k in ("wait_any_frac", "lds_conflict_per_active_lds"):
             if k in (rec.get("sq") or {}):
                 row[k] = rec["sq"][k]
+    return row
+
+
+def fused_pbwd_bytes(N, Nv):
+    """what the fused preprocessing backward + Adam kernel has to move: parameters, exp_avg and exp_avg_sq of all 59 floats per
+    Gaussian read and written (24 x 59 N), the radius of every Gaussian (4 N), the rasterizer's 10-float gradient row and the
+    conic of every visible one (52 Nv).  The 59-float gradient itself lives in registers."""
+    return 24.0 * 59 * N + 4.0 * N + 52.0 * Nv
+
+
+def _with_survey_formula(row, survey_bytes, t, hbm_peak_gbs, note):
+    row["survey_formula_bytes"] = survey_bytes
+    row["survey_formula_frac"] = survey_bytes / t / 1e9 / hbm_peak_gbs
+    row["survey_formula_note"] = note
     return row
 
 
@@ -206,19 +214,31 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     V = fus["visible_blocks"]
     S = 0x100000 + 0x20000
     b_iter, terms = iteration_bytes(N, nvis, ni, ng, P, T)
+    s_bar = fus["s_bar"]
     b_fuse = fusion_bytes(P, V, S)
+    b_fuse_rays = fusion_bytes(P, V, S, s_bar)
     rows = [
         _kernel_row("raster_ges_bwd_strip_kernel" if strips else "raster_ges_bwd_gs_kernel", 2.0, t["bwd"], 92.0 * ng + 24.0 * P,
                     hbm_peak_gbs, N, "latency (pixel gathers) / valu"),
         _kernel_row("raster_ges_fwd_pk_kernel", 2.1, t["fwd"], 44.0 * ni + 28.0 * P, hbm_peak_gbs, N, "valu issue + per-tile tail"),
-        _kernel_row("preprocess_bwd_kernel", 2.0, t_pbwd, 524.0 * nvis + 40.0 * N + 28.0 * 59 * N, hbm_peak_gbs, N, "hbm",
-                    "projection + SH backward with the Adam step of all 59 parameters fused (fuse mode 2)"),
+        _with_survey_formula(
+            _kernel_row("preprocess_bwd_kernel", 2.0, t_pbwd, fused_pbwd_bytes(N, nvis), hbm_peak_gbs, N, "hbm",
+                        "projection + SH backward with the Adam step of all 59 parameters fused (fuse mode 2): the gradient is "
+                        "consumed in registers, never written or re-read -- algorithmic_bytes = 24 x 59 N (parameters and both "
+                        "moments, read and written) + 4 N (radii) + 52 Nv (the rasterizer's gradient row + conic)"),
+            524.0 * nvis + 40.0 * N + 28.0 * 59 * N, t_pbwd, hbm_peak_gbs,
+            "SURVEY 8(d)'s figure for the UNFUSED reference chain (SH bwd 408 Nv + projection bwd 116 Nv + 40 N + Adam 28 x 59 N: "
+            "gradients written, zeroed and re-read); above 1 because those bytes do not exist in the fused kernel"),
         _kernel_row("preprocess_fwd_kernel", 2.1, t["pre"], 68.0 * N + 217.0 * nvis, hbm_peak_gbs, N, "hbm"),
         _kernel_row("binning (sb_scan_kernel + sb_scatter_kernel)", 2.1, t_bin, 24.0 * N + 44.0 * ni + 8.0 * ng + 4.0 * T, hbm_peak_gbs,
                     N, "launch latency", "derived: render - preprocess - forward rasterizer; bytes = SURVEY's figure for the reference's "
                     "count + sort + offsets, this implementation writes no key / value arrays"),
-        _kernel_row("raycast_kernel", 1.0, fus["raycast_s"], 20.0 * P, hbm_peak_gbs, N, "latency (dependent gathers along the ray)",
-                    "bytes without the ray term (S-bar is not logged): outputs only"),
+        dict(_kernel_row("raycast_kernel", 1.0, fus["raycast_s"], 24.0 * P * s_bar + 20.0 * P, hbm_peak_gbs, N,
+                         "latency (dependent gathers along the ray)",
+                         "algorithmic_bytes = P x S-bar x 24 (one hash entry + one voxel per castRay step, an upper bound: neighbouring "
+                         "rays share them in the caches) + 20 P of outputs; S-bar logged by the kernel itself"),
+             s_bar=s_bar, reads_per_ray=fus["reads_per_ray"], bytes_without_ray_term=20.0 * P,
+             frac_without_ray_term=20.0 * P / fus["raycast_s"] / 1e9 / hbm_peak_gbs),
         _kernel_row("integrate_kernel", 1.0, fus["integrate_s"], 8192.0 * V, hbm_peak_gbs, N, "hbm / valu"),
     ]
     if fus.get("evals_per_frame"):
@@ -230,6 +250,18 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
                          spin_us=fus["poll_spin_s"] * 1e6, eval_us=fus["poll_eval_s"] * 1e6,
                          gpu_held_idle_us_per_frame=ev * fus["poll_spin_s"] * 1e6,
                          tracking_ms_per_frame=fus["tracking_ms_per_frame"]))
+    if fus.get("freeview"):
+        fv = fus["freeview"]
+        rows.append(dict(_kernel_row("raycast_kernel<false> (free views)", 0.9, fv["raycast_s"], 24.0 * P * fv["s_bar"] + 20.0 * P,
+                                     hbm_peak_gbs, N, "latency (dependent gathers along the ray)",
+                                     "the 2 + 7 free views of a map update, 9 per 10 frames; timed one view per launch"),
+                         s_bar=fv["s_bar"]))
+        rows.append(_kernel_row("colour_kernel", 0.9, fv["colour_s"], 56.0 * P, hbm_peak_gbs, N, "latency (corner gathers)",
+                                "16 P of rays in, 4 P of colour + 36 P of view maps out (the batched launch writes the maps; timed "
+                                "here without them); the eight corner voxels are cache-served gathers, not counted"))
+        rows.append(_kernel_row("expected_depths_partial_kernel", 1.9, fv["ed_s"], 16.0 * fv["visible_blocks"] + 64.0 * fv["cells"] * 8,
+                                hbm_peak_gbs, N, "latency (one entry per thread, LDS atomics)",
+                                "16 B per visible entry in, 64 partial min/max images out; timed with its reduce pass (two launches)"))
     rows.sort(key=lambda x: -x["us_per_frame"])
     top = rows[0]
     t_frame = result["ms_per_step"] * 1e-3
@@ -242,10 +274,13 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
             "units": {"gaussians": N, "n_visible": nvis, "n_isects": ni, "n_groups": ng, "pixels": P, "tiles": T, "visible_blocks": V},
             "iteration": {"algorithmic_bytes": b_iter, "terms": terms, "avg_us": t["step"] * 1e6,
                           "achieved_GBs": b_iter / t["step"] / 1e9, "frac": b_iter / t["step"] / 1e9 / hbm_peak_gbs},
-            "frame": {"algorithmic_bytes": b_frame, "fusion_bytes_without_ray_term": b_fuse, "ms": t_frame * 1e3,
-                      "achieved_GBs": b_frame / t_frame / 1e9, "frac": b_frame / t_frame / 1e9 / hbm_peak_gbs},
+            "frame": {"algorithmic_bytes": b_frame, "fusion_bytes_without_ray_term": b_fuse, "fusion_bytes_with_ray_term": b_fuse_rays,
+                      "s_bar": s_bar, "ms": t_frame * 1e3, "achieved_GBs": b_frame / t_frame / 1e9,
+                      "frac": b_frame / t_frame / 1e9 / hbm_peak_gbs,
+                      "frac_with_ray_term": (2.0 * b_iter + b_fuse_rays) / t_frame / 1e9 / hbm_peak_gbs},
             "fusion": {k: v for k, v in fus.items() if k.endswith("_ms_per_frame") or k in ("visible_blocks", "evals_per_frame")},
-            "micro_order": ["bwd", "fwd", "pre", "render", "step", "pbwd", "integrate", "raycast"],
+            "micro_order": ["bwd", "fwd", "pre", "render", "step", "pbwd", "integrate", "raycast", "freeview"] +
+                           (["tracked"] if fus.get("evals_per_frame") else []),
             "note": "no kernel on this path is a dense contraction (no MFMA); the rasterizers are latency / VALU-issue bound, their HBM "
                     "fraction is small by construction and is reported because it is the contract's yardstick"}
 
@@ -273,10 +308,28 @@ def _fusion_timings(seq, gt_pose, device, n_sub=12):
     torch.cuda._sleep(1)
     t_int = _time_launches(lambda: lib.gps_tsdf_integrate(C.byref(eng.state), M.ctypes.data, sp), 20, stream)
     torch.cuda._sleep(1)
+    st0 = eng.ray_stats()
     t_ray = _time_launches(lambda: lib.gps_tsdf_raycast(C.byref(eng.state), invM.ctypes.data, 0, 1, sp), 20, stream)
+    st1 = eng.ray_stats()
     k_last = len(c2w) - 1
     t_frame = _time_launches(lambda: eng.ProcessFrame(rgba[k_last], dmm[k_last], c2w[k_last]), 10, stream)
-    out = {"visible_blocks": V, "integrate_s": t_int, "raycast_s": t_ray, "untracked_ms_per_frame": t_frame * 1e3}
+    d_rays = max(1, st1["rays"] - st0["rays"])
+    out = {"visible_blocks": V, "integrate_s": t_int, "raycast_s": t_ray, "untracked_ms_per_frame": t_frame * 1e3,
+           "s_bar": (st1["steps"] - st0["steps"]) / d_rays, "reads_per_ray": (st1["reads"] - st0["reads"]) / d_rays}
+    # the kernels of a map update's free views, one view per launch (the product batches 2 + 7 views per launch: same kernels with
+    # blockIdx.z = view), on a pose a few frames back
+    fM, fInv = pose_from_c2w(c2w[max(0, k_last - 5)])
+    torch.cuda._sleep(1)   # marker: "freeview"
+    state = C.byref(eng.state)
+    lib.gps_tsdf_find_visible(state, fM.ctypes.data, sp)
+    t_ed = _time_launches(lambda: lib.gps_tsdf_expected_depths(state, fM.ctypes.data, 1, sp), 20, stream)
+    fs0 = eng.ray_stats()
+    t_fray = _time_launches(lambda: lib.gps_tsdf_raycast(state, fInv.ctypes.data, 1, 0, sp), 20, stream)
+    fs1 = eng.ray_stats()
+    t_col = _time_launches(lambda: lib.gps_tsdf_render_colour(state, sp), 20, stream)
+    out["freeview"] = {"ed_s": t_ed, "raycast_s": t_fray, "colour_s": t_col, "visible_blocks": int(eng.counters_host()[3]),
+                       "cells": (W // 8 + 2) * (H // 8 + 2),
+                       "s_bar": (fs1["steps"] - fs0["steps"]) / max(1, fs1["rays"] - fs0["rays"])}
     if not gt_pose:
         trk = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0, device=device)
         trk.turnOnTracking()
@@ -284,6 +337,7 @@ def _fusion_timings(seq, gt_pose, device, n_sub=12):
         trk.ProcessFrameTracked(rgba[1], dmm[1])
         torch.cuda.synchronize()
         prof0 = trk.track_poll_profile()
+        torch.cuda._sleep(1)   # marker: "tracked"
         t0 = time.perf_counter()
         for k in range(2, len(c2w)):
             trk.ProcessFrameTracked(rgba[k], dmm[k])

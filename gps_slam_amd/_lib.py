@@ -131,6 +131,8 @@ PROTOTYPES = {
     "gps_pose_from_c2w": (i32, [vp, vp, vp]),
     "gps_raycast_to_maps": (i32, [i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_knn_mean_dist2": (i32, [i32, vp, vp, vp]),
+    "gps_knn_grid_workspace_bytes": (i64, [i32]),
+    "gps_knn_mean_dist2_grid": (i32, [i32, vp, vp, vp, i64, vp]),
     "gps_normal_map": (i32, [i32, i32, vp, vp, vp]),
     "gps_zero_floats": (i32, [i32, vp, vp, vp]),
     "gps_rgba8_to_rgbf": (i32, [i32, vp, vp, vp]),

@@ -3,24 +3,22 @@
 //
 // gps_knn_mean_dist2 <- distCUDA2 (gsplat/rasterizer/simple_knn.cu:191-240): mean squared distance to the 3 nearest
 //                       neighbours.  The reference builds a Morton order + 1024-point boxes with cub/thrust,
-//                       cudaMalloc/cudaFree and two blocking memcpys per call; P is 1e2..1e4 here, so an exact
-//                       LDS-tiled brute force (P^2 / 2^24 lane-steps) is both simpler and faster and needs no
-//                       scratch memory.  Same result: the 3 smallest squared distances are a set property.
+//                       cudaMalloc/cudaFree and two blocking memcpys per call; P is 1e2..1e4 on a steady keyframe, where an
+//                       exact LDS-tiled brute force (P^2 / 2^24 lane-steps) is both simpler and faster and needs no
+//                       scratch memory.  Same result: the 3 smallest squared distances are a set property.  Larger sets
+//                       (a first keyframe, a newly revealed room): the exact uniform-grid search of splat_knn.hip.
 // gps_normal_map     <- computeNormalMap (src/tensor_math.cpp:217-248, 278-300): Sobel gradients of the vertex map
 //                       with replicate padding, cross(dy, dx), normalise, zero where vertex z <= 0.
 #include <float.h>
 
 #include "common.hpp"
+#include "splat_knn.hpp"
 
 namespace {
 
 constexpr int KNN_TILE = 256;
 
-__device__ __forceinline__ void keep3(float d, float& b0, float& b1, float& b2) {  // simple_knn.cu:137-150
-    if (b0 > d) { float t = b0; b0 = d; d = t; }
-    if (b1 > d) { float t = b1; b1 = d; d = t; }
-    if (b2 > d) { b2 = d; }
-}
+using gps::keep3;
 
 // 16 queries x 16 candidate slices per workgroup: thread (q, slice) scans the candidates t == slice (mod 16) of every
 // 256-point LDS tile, so P points give P/16 workgroups (P is only 1e3..1e4 on the per-keyframe path -- one thread per
@@ -44,8 +42,7 @@ __global__ __launch_bounds__(KNN_TILE) void knn_kernel(int P, const float* __res
 #pragma unroll 4
         for (int t = slice; t < n; t += KNN_S) {
             if (base + t == q) continue;
-            const float dx = sx[t] - qx, dy = sy[t] - qy, dz = sz[t] - qz;
-            keep3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+            keep3(gps::knn_dist2(sx[t] - qx, sy[t] - qy, sz[t] - qz), b0, b1, b2);
         }
     }
     best[slice][ql][0] = b0; best[slice][ql][1] = b1; best[slice][ql][2] = b2;

@@ -187,12 +187,23 @@ for _n in RawGaussianParams.NAMES:
     setattr(RawGaussianParams, _n, property(lambda self, _n=_n: self._buf[_n][:self.N]))
 
 
-def knn_mean_dist2(points):
-    """distCUDA2 (gsplat/rasterizer/simple_knn.cu:191-240) -> gps_knn_mean_dist2"""
+KNN_GRID_MIN_POINTS = 4096   # include/gps_slam_hip.h GPS_KNN_GRID_MIN_POINTS
+
+
+def knn_mean_dist2(points, method=None):
+    """distCUDA2 (gsplat/rasterizer/simple_knn.cu:191-240) -> gps_knn_mean_dist2 (tiled brute force) up to a few thousand
+    points, gps_knn_mean_dist2_grid (exact uniform-grid search, same bits) above; method = "brute" / "grid" forces one"""
     points = points.contiguous()
-    out = torch.empty(points.shape[0], dtype=torch.float32, device=points.device)
-    check(lib.gps_knn_mean_dist2(points.shape[0], points.data_ptr(), out.data_ptr(),
-                                 C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream)), "gps_knn_mean_dist2")
+    P = points.shape[0]
+    out = torch.empty(P, dtype=torch.float32, device=points.device)
+    stream = C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream)
+    if method == "grid" or (method is None and P > KNN_GRID_MIN_POINTS):
+        nbytes = int(lib.gps_knn_grid_workspace_bytes(P))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+        check(lib.gps_knn_mean_dist2_grid(P, points.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, stream),
+              "gps_knn_mean_dist2_grid")
+    else:
+        check(lib.gps_knn_mean_dist2(P, points.data_ptr(), out.data_ptr(), stream), "gps_knn_mean_dist2")
     return out
 
 

@@ -397,6 +397,13 @@ torch::Tensor distCUDA2(const torch::Tensor& points_in) {
     auto points = points_in.contiguous();
     TORCH_CHECK(points.dim() == 2 && points.size(1) == 3, "points[P,3]");
     auto out = torch::empty({points.size(0)}, points.options());
-    check(gps_knn_mean_dist2((int)points.size(0), fptr(points), fptr(out), current_stream()), "gps_knn_mean_dist2");
+    const int P = (int)points.size(0);
+    if (P > GPS_KNN_GRID_MIN_POINTS) {   // exact uniform-grid search (same bits as the brute force, sub-quadratic)
+        const int64_t nbytes = gps_knn_grid_workspace_bytes(P);
+        auto ws = torch::empty({nbytes}, points.options().dtype(torch::kUInt8));
+        check(gps_knn_mean_dist2_grid(P, fptr(points), fptr(out), ws.data_ptr(), nbytes, current_stream()), "gps_knn_mean_dist2_grid");
+    } else {
+        check(gps_knn_mean_dist2(P, fptr(points), fptr(out), current_stream()), "gps_knn_mean_dist2");
+    }
     return out;
 }

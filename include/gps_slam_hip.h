@@ -335,6 +335,15 @@ GPS_API int gps_gauss_preprocess_bwd_adam(int N, int K, int sh_degree, const flo
  * P < 4, as in the reference).  Exact, no scratch memory, no host sync. */
 GPS_API int gps_knn_mean_dist2(int P, const float *points, float *mean_dist2, gps_stream stream);
 
+/* The same numbers, bit for bit, in sub-quadratic time for large P (the reference prunes with Morton-ordered boxes,
+ * simple_knn.cu:67-227; here: counting sort into a uniform grid over the bounding box, then an exact ring-by-ring search per
+ * point).  workspace: gps_knn_grid_workspace_bytes(P) bytes of device memory, 16-byte aligned, no initialisation needed, free
+ * for other use between calls.  Seven short launches, no host sync.  Callers use it above a few thousand points. */
+#define GPS_KNN_GRID_MIN_POINTS 4096 /* below: the brute force (one launch) is faster than the grid's seven */
+GPS_API int64_t gps_knn_grid_workspace_bytes(int P);
+GPS_API int gps_knn_mean_dist2_grid(int P, const float *points, float *mean_dist2, void *workspace, int64_t workspace_bytes,
+                                    gps_stream stream);
+
 /* The sample mask of SLAMPipeline::initNewGaussians (slam/slam_pipeline.cpp:450-526) in one launch instead of ~12 tensor ops:
  *   valid = depth in (depth_vis_min, depth_vis_max) and vertex.sum(-1) != 0
  *   mask  = mean(|src_rgb - image|, -1) > color_error_thres  and  valid  [and alpha < alpha_vis_max, if alpha != NULL]

@@ -186,6 +186,95 @@ def test_init_params_match_reference_restatement(which):
     assert torch.equal(got[5], exp[5]) and (got[5] == 0).all()             # logit(0.5)
 
 
+def _surface_points(W, H, seed):
+    """W x H / 4-ish samples of the synthetic room's surfaces as a first keyframe adds them: back-projected depth of one view
+    (tests/synth.py), every pixel -> W * H points in pixel order (the caller subsamples)"""
+    from tests import synth
+    seq = synth.make_sequence(W, H, 1, step_deg=0.5)
+    d = torch.as_tensor(seq["depth"][0].astype(np.float32) / 1000.0)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    pc = torch.stack([(xs - seq["cx"]) / seq["fx"] * d, (ys - seq["cy"]) / seq["fy"] * d, d], -1).reshape(-1, 3)
+    c2w = torch.as_tensor(seq["c2w"][0])
+    pw = pc @ c2w[:3, :3].T + c2w[:3, 3]
+    gen = torch.Generator().manual_seed(seed)
+    return pw[d.reshape(-1) > 0], gen
+
+
+def _knn3_float64(x, chunk=4096):
+    """mean of the three smallest squared distances to OTHER points, float64, chunked on the device"""
+    xd = x.double()
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    for lo in range(0, x.shape[0], chunk):
+        d2 = torch.cdist(xd[lo:lo + chunk], xd) ** 2
+        d2[torch.arange(d2.shape[0], device=x.device), torch.arange(lo, lo + d2.shape[0], device=x.device)] = float("inf")
+        out[lo:lo + chunk] = torch.topk(d2, 3, dim=1, largest=False).values.sum(1) / 3.0
+    return out
+
+
+@pytest.mark.parametrize("P,W,H", [(76800, 640, 480), (230400, 1280, 720)])
+def test_grid_knn_is_exact_on_a_first_keyframe_of_surface_points(P, W, H):
+    """distCUDA2 at the size a first keyframe / a newly revealed room adds (0.25 x W x H surface samples): the uniform-grid
+    search (gps_knn_mean_dist2_grid) returns the tiled brute force's numbers BIT FOR BIT, and both agree with a float64 cdist;
+    timed: the grid search is the sub-quadratic one (reported, asserted < 2 ms at 76,800 points)."""
+    from gps_slam_amd.gs_model import knn_mean_dist2
+    pts, gen = _surface_points(W, H, seed=P)
+    sel = torch.randperm(pts.shape[0], generator=gen)[:P].sort().values       # a random quarter of the pixels, pixel order
+    x = pts[sel].contiguous().to(DEV)
+    assert x.shape[0] == P
+    grid = knn_mean_dist2(x, method="grid")
+    brute = knn_mean_dist2(x, method="brute")
+    assert torch.equal(grid, brute)
+    ref = _knn3_float64(x)
+    torch.testing.assert_close(grid.double(), ref, rtol=2e-5, atol=1e-12)
+    assert torch.equal(knn_mean_dist2(x), grid)                                # the default picks the grid above 4,096 points
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(5):
+        knn_mean_dist2(x, method="grid")
+    ev[1].record()
+    knn_mean_dist2(x, method="brute")
+    ev[2].record()
+    torch.cuda.synchronize()
+    t_grid, t_brute = ev[0].elapsed_time(ev[1]) / 5, ev[1].elapsed_time(ev[2])
+    print("P = %d: grid %.3f ms, brute force %.1f ms" % (P, t_grid, t_brute))
+    if P == 76800:
+        assert t_grid < 2.0, t_grid
+
+
+@pytest.mark.parametrize("case", ["cube", "plane", "duplicates", "outlier", "line", "tiny", "two_clusters"])
+def test_grid_knn_equals_the_brute_force_on_awkward_sets(case):
+    """shapes that stress the grid: uniform volume, an exactly planar set (one axis of the bounding box is zero), many exact
+    duplicates (zero distances, one crowded cell), a dense cluster with one far outlier (the outlier's rings cross the whole
+    grid), a line, fewer than four points (FLT_MAX terms -> inf, as the brute force), two far clusters (empty middle)."""
+    from gps_slam_amd.gs_model import knn_mean_dist2
+    gen = torch.Generator().manual_seed(11)
+    P = 6000
+    x = torch.rand((P, 3), generator=gen)
+    if case == "plane":
+        x[:, 2] = 0.25
+    elif case == "duplicates":
+        x[: P // 2] = x[P // 2:P // 2 * 2][torch.randint(0, 20, (P // 2,), generator=gen)]
+    elif case == "outlier":
+        x *= 0.01
+        x[17] = torch.tensor([5.0, -3.0, 2.0])
+    elif case == "line":
+        x[:, 1] = x[:, 0] * 0.5
+        x[:, 2] = -x[:, 0]
+    elif case == "tiny":
+        x = x[:3]
+    elif case == "two_clusters":
+        x *= 0.02
+        x[P // 2:] += torch.tensor([4.0, 4.0, -4.0])
+    x = x.contiguous().to(DEV)
+    grid, brute = knn_mean_dist2(x, method="grid"), knn_mean_dist2(x, method="brute")
+    assert torch.equal(grid, brute), (case, (grid != brute).sum())
+    if case == "tiny":
+        assert torch.isinf(grid).all()
+    else:
+        torch.testing.assert_close(grid.double(), _knn3_float64(x), rtol=2e-5, atol=1e-12)
+
+
 @pytest.mark.parametrize("which", ["cpp", "python"])
 def test_add_gaussians_samples_masked_pixels_and_appends(which):
     """slam_gs_model.cpp:5-56: masked_select of vertex / colour / normal maps, a random subset of floor(n * ratio) of them,

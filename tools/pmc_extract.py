@@ -22,7 +22,18 @@ TARGETS = {
     "pbwd": [("preprocess_bwd_kernel", ["preprocess_bwd_kernel"])],
     "integrate": [("integrate_kernel", ["integrate_kernel"])],
     "raycast": [("raycast_kernel", ["raycast_kernel"])],
+    "freeview": [("colour_kernel", ["colour_kernel"]), ("expected_depths_partial_kernel", ["expected_depths_partial_kernel"]),
+                 ("raycast_kernel<false> (free views)", ["raycast_kernel"])],
+    "tracked": [("track_eval_poll_kernel", ["track_eval_poll_kernel"])],
 }
+
+
+def pmc_file_name(kernel):
+    """profiles/pmc_<...>.json of a roofline row (bench_kernels._pmc uses the same rule)"""
+    import re
+    if kernel.startswith("binning"):
+        return "pmc_binning.json"
+    return "pmc_%s.json" % re.sub(r"[^A-Za-z0-9_]+", "_", kernel.split(" (")[0]).strip("_")
 
 
 def bench_line(log):
@@ -106,9 +117,7 @@ def main():
             if sq.get("SQ_ACTIVE_INST_LDS"):
                 sq["lds_conflict_per_active_lds"] = sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_ACTIVE_INST_LDS"]
             rec["sq"] = sq
-            fn = "pmc_%s.json" % kname.split(" ")[0].replace("(", "").replace(")", "")
-            if kname.startswith("binning"):
-                fn = "pmc_binning.json"
+            fn = pmc_file_name(kname)
             json.dump(rec, open(os.path.join(out_dir, fn), "w"), indent=1)
             print(fn, json.dumps({k: rec[k] for k in ("launches", "hbm_bytes_per_launch", "algorithmic_bytes")}), json.dumps(sq)[:300])
 
