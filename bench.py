@@ -47,6 +47,55 @@ def synthetic_sequence(W, H, n_frames, seed):
     return seq
 
 
+def synthetic_sequence_device(W, H, n_frames, seed, device, intrinsics=None):
+    """tests/synth.py's room rendered with torch on the GPU (float64, the same formulas): the numpy renderer needs 0.2-0.6 s per
+    frame, too slow for the extra configurations measured after the main windows (config.other_configs).  Same dictionary as
+    synthetic_sequence (arrays on the host).  intrinsics = (fx, fy, cx, cy) or None for the 90-degree pinhole."""
+    from tests import synth
+    fx, fy, cx, cy = intrinsics if intrinsics else (0.5 * W, 0.5 * W, (W - 1) / 2.0, (H - 1) / 2.0)
+    poses = synth.orbit_poses(n_frames, step_deg=0.25 + 0.01 * (seed % 7))
+    dd = dict(dtype=torch.float64, device=device)
+    ys, xs = torch.meshgrid(torch.arange(H, **dd), torch.arange(W, **dd), indexing="ij")
+    d_cam = torch.stack([(xs - cx) / fx, (ys - cy) / fy, torch.ones_like(xs)], -1)
+    half = torch.tensor((3.0, 1.5, 2.5), **dd)
+    spheres = ((0.4, 0.2, 0.3, 0.45), (-0.8, 0.5, -0.4, 0.35))
+    rgbs, depths = [], []
+    for c2w in poses:
+        R, o = torch.as_tensor(c2w[:3, :3], **dd), torch.as_tensor(c2w[:3, 3], **dd)
+        d = d_cam @ R.T
+        t_best = torch.full((H, W), float("inf"), **dd)
+        for ax in range(3):
+            for sgn in (-1.0, 1.0):
+                t = (sgn * half[ax] - o[ax]) / d[..., ax]
+                p = o + t[..., None] * d
+                ok = t > 1e-6
+                for a2 in range(3):
+                    if a2 != ax:
+                        ok &= p[..., a2].abs() <= half[a2] + 1e-9
+                t_best = torch.where(ok & (t < t_best), t, t_best)
+        for sx, sy, sz, sr in spheres:
+            oc = o - torch.tensor((sx, sy, sz), **dd)
+            a, b, cc = (d * d).sum(-1), 2 * (d * oc).sum(-1), (oc * oc).sum() - sr * sr
+            disc = b * b - 4 * a * cc
+            t = (-b - torch.sqrt(disc)) / (2 * a)
+            ok = (disc > 0) & (t > 1e-6)
+            t_best = torch.where(ok & (t < t_best), t, t_best)
+        hit = torch.isfinite(t_best)
+        tb = torch.where(hit, t_best, torch.zeros_like(t_best))
+        p = o + tb[..., None] * d
+        r = 0.5 + 0.5 * torch.sin(3.1 * p[..., 0] + 1.7 * p[..., 1])
+        g = 0.5 + 0.5 * torch.sin(2.3 * p[..., 1] - 2.9 * p[..., 2] + 1.0)
+        b_ = 0.5 + 0.5 * torch.sin(4.1 * p[..., 2] + 0.7 * p[..., 0] - 0.5)
+        checker = ((torch.floor(p[..., 0] * 2) + torch.floor(p[..., 1] * 2) + torch.floor(p[..., 2] * 2)) % 2) * 0.25
+        tex = (torch.stack([r, g, b_], -1) * 0.75 + checker[..., None]).clamp(0, 1)
+        rgbs.append((torch.where(hit[..., None], tex, torch.zeros_like(tex)) * 255.0 + 0.5).to(torch.uint8).cpu())
+        depths.append(torch.where(hit, torch.round(tb * 1000.0).clamp(0, 65535), torch.zeros_like(tb)).to(torch.int32).cpu())
+    c2w = np.stack(poses).astype(np.float64)
+    c0inv = np.linalg.inv(c2w[0])
+    return dict(W=W, H=H, fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy), rgb=torch.stack(rgbs).numpy(),
+                depth=torch.stack(depths).numpy().astype(np.uint16), c2w=np.stack([c0inv @ c for c in c2w]).astype(np.float32))
+
+
 def seed_gaussians(seq, n_gauss, seed, device):
     """~n_gauss Gaussians on the scene surfaces: a few views' depth back-projected, RawGaussianParams::init on the samples
     (KNN scale, normal -> quaternion, colour -> SH DC), small random higher-order SH so all 16 bands carry signal."""
@@ -219,6 +268,8 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     ap.add_argument("--keyframe-trans", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-psnr", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip config.other_configs (BASELINE configs[0], [1], [3] measured after the main windows at N = 1)")
     ap.add_argument("--gt-pose", action="store_true",
                     help="use_gt_pose: true (what every shipped config sets: the tracker is off, poses are given).  Default: the "
                          "depth-only ExtendedTracker estimates the pose of every frame, as BASELINE configs[2] "
@@ -292,7 +343,9 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"schedule": main_sched, "windows": NW, "windows_ms_per_step": results[main_sched]["windows_ms_per_step"],
+            "config": {"keyframe_thresholds": {"theta_deg": args.keyframe_theta, "trans_m": args.keyframe_trans,
+                                               "reference": {"theta_deg": 30.0, "trans_m": 0.3}},
+                       "schedule": main_sched, "windows": NW, "windows_ms_per_step": results[main_sched]["windows_ms_per_step"],
                        "window_spread": results[main_sched]["window_spread"],
                        "window_spread_detrended": results[main_sched]["window_spread_detrended"],
                        "windows_gaussians": results[main_sched]["windows_gaussians"],
@@ -301,13 +354,17 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                                       "(windows_gaussians), window_spread_detrended is the spread around that trend" % (NW, K),
                        "local_opt_interval": PERIOD, "local_opt_iters": 20, "frames_per_step": 1,
                        "use_gt_pose": bool(args.gt_pose), "prologue_frames": prologue,
-                       "keyframe_thresholds": {"theta_deg": args.keyframe_theta, "trans_m": args.keyframe_trans},
                        "schedules": {k: {kk: vv for kk, vv in v.items() if kk != "seconds"} for k, v in results.items()},
                        "stats": results[main_sched]["stats"], "placement": placement},
         }
         if extras:
             out["config"].update(_describe_and_measure(args, scene, seq, results[main_sched], first, K, dt, marker))
             out["roofline"] = out["config"].pop("roofline")
+            if world == 1 and not args.no_other_configs:
+                scene.close()
+                scene = None
+                torch.cuda.empty_cache()
+                out["config"]["other_configs"] = other_configs(args, seq, seed, device, first)
             if not args.no_cpu_baseline and world == 1:
                 from bench_kernels import cpu_baseline
                 out["cpu_baseline"] = cpu_baseline(seq, W, H)
@@ -315,8 +372,97 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     # ranks != 0 wait here while rank 0 runs its post-window measurements and prints: no rank tears the process group down
     # (or exits, which torch.distributed.run treats as the job ending) under another rank's feet
     grp.barrier()
-    scene.close()
+    if scene is not None:
+        scene.close()
     grp.close()
+
+
+def _time_scene(factory, first, K, NW):
+    """median-of-NW-windows frames/s of one scene per schedule (world size 1: no barriers), as main() times the headline scene"""
+    out = {}
+    for sched in ("sequential", "overlap"):
+        scene = factory(sched == "overlap")
+        torch.cuda.synchronize()
+        scene.run(0, first)
+        ms = []
+        for w in range(NW):
+            lo = first + w * K
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            scene.run(lo, lo + K)
+            torch.cuda.synchronize()
+            ms.append(1000.0 * (time.perf_counter() - t0) / K)
+        out[sched] = {"frames_per_s": 1000.0 / sorted(ms)[len(ms) // 2], "windows_ms_per_step": ms,
+                      "gaussians": int(scene.model.getGaussianNum())}
+        last = scene
+        if sched == "sequential":
+            scene.close()
+            del scene
+            torch.cuda.empty_cache()
+    return out, last
+
+
+def other_configs(args, seq, seed, device, first):
+    """The other single-GPU configurations of BASELINE.json, measured after the headline windows on the same box (N = 1 only;
+    bounded: three 20-step windows per schedule, device-rendered input):
+      configs[0]  TSDF-only `recon` loop with given poses, HIP engine (the cpu_baseline's counterpart)
+      configs[1]  640x480, use_gt_pose=true, ~100 k Gaussians: frames/s of the loop and optimise iterations/s (fwd + L1 + bwd + Adam)
+      configs[3]  1280x720 (Azure Kinect intrinsics), tracking on, ~400 k Gaussians: both schedules, its own roofline units"""
+    from bench_kernels import fusion_split, iteration_bytes
+    t_all = time.perf_counter()
+    K, NW = 20, 3
+    res = {"note": "N = 1, after the headline windows, same box; %d windows x %d steps per schedule, median; timed step 0 is frame %d "
+                   "(a keyframe) as in the headline run" % (NW, K, first)}
+    kf = dict(keyframe_theta=args.keyframe_theta, keyframe_trans=args.keyframe_trans)
+    # configs[0]
+    t0 = time.perf_counter()
+    r0 = fusion_split(seq, first, 2 * K, True, 1.0)
+    res["configs0_tsdf_only_gt_pose"] = {"frames_per_s": r0["fusion_fps"], "ms_per_frame": r0["fusion_ms_per_frame"], "size": "%dx%d" % (seq["W"], seq["H"]),
+                                         "what": "upload + TSDF fuse + live raycast + ICP maps, HIP engine, given poses, no Gaussians (work_mode recon)",
+                                         "seconds": time.perf_counter() - t0}
+    # configs[1]
+    t0 = time.perf_counter()
+    n1 = first + NW * K
+    seeds1 = seed_gaussians(seq, 100000, seed, device)
+    r1, sc = _time_scene(lambda ov: Scene(seq, seeds1, seed, True, overlap=ov, n_frames=n1, **kf), first, K, NW)
+    cam, rc = sc.pipe.optCams()[-1], sc.pipe.optRaycasts()[-1]
+    sc.pipe.flush()
+    sc.model.initOptimizers(-1, 1.0)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sc.model.trainStep(cam, rc["depth_map"], rc["color_map"])
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(50):
+        sc.model.trainStep(cam, rc["depth_map"], rc["color_map"])
+    ev1.record()
+    torch.cuda.synchronize()
+    it_s = ev0.elapsed_time(ev1) * 1e-3 / 50
+    sc.close()
+    del sc
+    torch.cuda.empty_cache()
+    res["configs1_gt_pose_100k"] = {"size": "%dx%d" % (seq["W"], seq["H"]), "schedules": r1, "frames_per_s": r1["overlap"]["frames_per_s"],
+                                    "iterations_per_s": 1.0 / it_s, "iteration_us": it_s * 1e6,
+                                    "what": "use_gt_pose=true (tracker off), ~100 k Gaussians; iterations = forward + L1 + backward + fused Adam "
+                                            "of one optimise camera, 50 back-to-back (HIP events)",
+                                    "seconds": time.perf_counter() - t0}
+    # configs[3]
+    t0 = time.perf_counter()
+    W3, H3 = 1280, 720
+    n3 = first + NW * K
+    seq3 = synthetic_sequence_device(W3, H3, n3, seed, device, intrinsics=(605.0, 605.0, 635.3, 366.5))
+    t_gen = time.perf_counter() - t0
+    seeds3 = seed_gaussians(seq3, 400000, seed, device)
+    r3, sc = _time_scene(lambda ov: Scene(seq3, seeds3, seed, False, overlap=ov, n_frames=n3, **kf), first, K, NW)
+    st = dict(sc.pipe.stats())
+    sc.close()
+    del sc
+    torch.cuda.empty_cache()
+    res["configs3_720p_400k"] = {"size": "%dx%d" % (W3, H3), "schedules": r3, "frames_per_s": r3["overlap"]["frames_per_s"],
+                                 "what": "Azure-Kinect-like 720p intrinsics (fx = fy = 605), depth ICP tracking + TSDF fuse + ges splat optimise, "
+                                         "~400 k Gaussians", "pipeline_stats": {k: int(v) for k, v in st.items()},
+                                 "input_render_seconds": t_gen, "seconds": time.perf_counter() - t0}
+    res["seconds"] = time.perf_counter() - t_all
+    return res
 
 
 def _describe_and_measure(args, scene, seq, result, first, K, dt, marker):

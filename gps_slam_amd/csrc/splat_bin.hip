@@ -501,7 +501,7 @@ int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss,
     carve(&w, (char*)workspace, N, isect_capacity);
     *out = {tiles_per_gauss, w.groups_per_gauss, w.blk_tiles, w.blk_groups, w.blk_vis, tile_size, tile_width, tile_height, {}};
     if (superblock) {
-        GPS_REQUIRE(tile_width * tile_height <= SB_MAX_TILES);
+        GPS_REQUIRE(sb_supported(N, tile_width, tile_height));
         sb_tables_carve(w.sb_region, &out->sb);
         out->sb.sb_shift = sb_shift_for(N);
     }

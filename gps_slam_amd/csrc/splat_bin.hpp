@@ -58,6 +58,10 @@ struct SbTables {
     int32_t* cls_prefix;   // [BWD_KEYS][SB_MAX] exclusive prefixes over superblocks, then a row of the BWD_KEYS totals
     int sb_shift;          // log2(preprocessing workgroups per superblock)
 };
+// splat_bin_sb.hip: can the superblock binning take N Gaussians on a tile_width x tile_height grid on THIS device (tile count,
+// packed box fields, superblock count, the scatter kernel's dynamic LDS incl. its > 64 KB opt-in)?  False -> sorted-key binning.
+bool sb_supported(int N, int tile_width, int tile_height);
+int sb_tables_clear(const struct SbTables& t, gps_stream stream);
 __host__ __device__ inline int sb_shift_for(int N) {  // smallest power of two of 256-Gaussian blocks with <= SB_MAX superblocks
     int s = 0;
     while ((((int64_t)N + 255) / 256 + ((int64_t)1 << s) - 1) >> s > SB_MAX) s++;

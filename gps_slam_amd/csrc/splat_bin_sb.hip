@@ -7,6 +7,8 @@
 // whose "blocks" are runs of consecutive GAUSSIANS instead of runs of intersections, so that no (key, value) array is ever
 // written or read: the histogram pass runs inside the preprocessing kernel on the bounding boxes still in registers, and the
 // scatter re-derives a superblock's pairs from the same boxes.
+#include <mutex>
+
 #include "splat_bin.hpp"
 
 namespace {
@@ -271,8 +273,49 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
 
 namespace gps {
 
+// Dynamic LDS of sb_scatter_kernel: per-tile histogram + per-wave cursors (n_tiles words + (SCAT_WAVES + 1) n_tiles halves) + two
+// words per Gaussian of a superblock.  It grows with the tile count (79 KB at 1200x680, up to 160 KB): above the default 64 KB a
+// workgroup needs the opt-in attribute, which a device with less LDS per workgroup refuses.
+static size_t sb_scatter_lds_bytes(int N, int n_tiles) {
+    const size_t sb_size = (size_t)BIN_BLOCK << sb_shift_for(N);
+    return ((size_t)n_tiles + ((SCAT_WAVES + 1) * (size_t)n_tiles + 1) / 2 + 2 * sb_size + 2) * 4;
+}
+
+// Everything the superblock binning needs, checked BEFORE the preprocessing kernel adds its counts to the persistent tables
+// (isect_count_targets / strips_on): a configuration that fails here takes the sorted-key binning of splat_bin.hip instead.
+bool sb_supported(int N, int tile_width, int tile_height) {
+    if (N <= 0 || tile_width <= 0 || tile_height <= 0) return false;
+    const int64_t n_tiles = (int64_t)tile_width * tile_height;
+    // (the scatter packs a box's width and height into 8 bits each)
+    if (n_tiles > SB_MAX_TILES || tile_width > 255 || tile_height > 255) return false;
+    const int shift = sb_shift_for(N);
+    const int64_t nblk = ((int64_t)N + BIN_BLOCK - 1) / BIN_BLOCK;
+    if (((nblk + ((int64_t)1 << shift) - 1) >> shift) > SB_MAX) return false;
+    const size_t lds = sb_scatter_lds_bytes(N, (int)n_tiles);
+    if (lds > 160 * 1024) return false;
+    // the opt-in for more than 64 KB of dynamic LDS, granted once per size class (monotonic; two host threads may ask)
+    static std::mutex mu;
+    static size_t granted = 64 * 1024;
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds <= granted) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    granted = lds;
+    return true;
+}
+
 size_t sb_tables_bytes() {
     return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * BWD_KEYS * 4 * 2 + 2048;
+}
+
+// the tables back to "zero between launches" (after a failed launch of the preprocessing kernel or a rejected binning call)
+int sb_tables_clear(const SbTables& t, gps_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const bool ok = hipMemsetAsync(t.C, 0, (size_t)SB_MAX_TILES * SB_MAX * 4, s) == hipSuccess &&
+                    hipMemsetAsync(t.cls_count, 0, (size_t)(SB_MAX + 1) * BWD_KEYS * 4, s) == hipSuccess;
+    return ok ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
 void sb_tables_carve(char* base, SbTables* t) {
@@ -291,19 +334,21 @@ int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, co
                            int32_t* cls_ids, int32_t* cls_counts, int64_t cls_stride, gps_stream stream) {
     GPS_ENTER();
     const int n_tiles = cnt.tw * cnt.th;
-    GPS_REQUIRE(N > 0 && cnt.sb.C && n_tiles <= SB_MAX_TILES && cnt.tw < 4096 && cnt.th < 4096 && isect_capacity > 0);
-    GPS_REQUIRE(means2d && radii && tiles_per_gauss && flatten_ids && tile_offsets && counts);
-    GPS_REQUIRE(!cls_ids || (cls_counts && cls_stride >= N));
+    hipStream_t s = (hipStream_t)stream;
+    // The preprocessing kernel has already added this launch's counts to the persistent tables, which only sb_scan_kernel clears:
+    // an argument error from here on must not leave them dirty for the next binning (every size-dependent condition was checked
+    // by sb_supported() before that kernel ran; what is left are the caller's pointers).
+    const bool ok = N > 0 && cnt.sb.C && isect_capacity > 0 && means2d && radii && tiles_per_gauss && flatten_ids && tile_offsets &&
+                    counts && (!cls_ids || (cls_counts && cls_stride >= N)) && cnt.sb.sb_shift == sb_shift_for(N) &&
+                    sb_supported(N, cnt.tw, cnt.th);
+    if (!ok) {
+        if (cnt.sb.C) (void)sb_tables_clear(cnt.sb, stream);
+        return GPS_ERR_ARG;
+    }
     const int nblk = gps_div_up(N, BIN_BLOCK);
     const int n_sb = (nblk + (1 << cnt.sb.sb_shift) - 1) >> cnt.sb.sb_shift;
-    GPS_REQUIRE(n_sb <= SB_MAX);
-    hipStream_t s = (hipStream_t)stream;
     sb_scan_kernel<<<gps_div_up(n_tiles + BWD_KEYS, 4), 256, 0, s>>>(n_tiles, cnt.sb);
-    const int sb_size = BIN_BLOCK << cnt.sb.sb_shift;
-    const size_t lds = ((size_t)n_tiles + ((SCAT_WAVES + 1) * (size_t)n_tiles + 1) / 2 + 2 * (size_t)sb_size + 2) * 4;
-    GPS_REQUIRE(lds <= 160 * 1024);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = sb_scatter_lds_bytes(N, n_tiles);
     sb_scatter_kernel<<<n_sb, SCAT_THREADS, lds, s>>>(N, means2d, radii, tiles_per_gauss, cnt.tile_size, cnt.tw, cnt.th, cnt.sb,
                                                      isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_counts, cls_stride);
     GPS_LAUNCH_CHECK();

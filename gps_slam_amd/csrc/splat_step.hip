@@ -13,7 +13,8 @@ extern "C" {
 // the strip backward's buffers are all there and the tile ids fit the superblock binning's LDS histograms
 static bool strips_on(const gps_splat_step* a) {
     const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
-    return a->v_rows && a->pix2 && a->cls_ids && a->cls_counts && a->cls_stride >= a->N && a->records && tw * th <= gps::SB_MAX_TILES;
+    return a->v_rows && a->pix2 && a->cls_ids && a->cls_counts && a->cls_stride >= a->N && a->records &&
+           (a->N <= 0 || gps::sb_supported(a->N, tw, th));   // (tile count, packed box fields, the scatter's LDS on this device)
 }
 
 // projection + binning + forward rasterizer; `compose` / `zero`: the train step's compose + L1 and gradient zero-fill riding
@@ -33,7 +34,10 @@ static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose,
                                    a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
                                    a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
                                    a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, zero, stream);
-    if (r != GPS_OK) return r;
+    if (r != GPS_OK) {
+        if (sb) (void)gps::sb_tables_clear(cnt.sb, stream);   // (the kernel may have added counts that no scan will clear)
+        return r;
+    }
     if (sb)   // scan + scatter (+ the backward's class lists when this is a train step)
         r = gps::isect_tiles_superblock(a->N, a->means2d, a->radii, cnt, a->isect_capacity, a->tiles_per_gauss, a->flatten_ids,
                                         a->tile_offsets, a->counts, zero ? a->cls_ids : nullptr, zero ? a->cls_counts : nullptr,

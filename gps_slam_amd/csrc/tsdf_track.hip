@@ -32,11 +32,15 @@
 // The reduction is a fixed tree (per-thread register sums -> wave -> workgroup -> 8 row groups added in order), so results
 // are reproducible run to run; they differ from the CPU engine's scan-order sums only by float re-association (poses agree
 // to ~1e-5, tests/test_tsdf_gpu.py).
+#if defined(__x86_64__)
 #include <immintrin.h>
 #include <x86intrin.h>
+#endif
 #include <math.h>
 #include <sched.h>
 #include <setjmp.h>
+#include <mutex>
+#include <pthread.h>
 #include <signal.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,7 +49,7 @@
 #include "wave_reduce.hpp"
 #include "tsdf_pose.hpp"
 
-using // a failure of the tracker's host loop names its line on stderr (as GPS_LAUNCH_CHECK does for launches): -2 alone says nothing
+// a failure of the tracker's host loop names its line on stderr (as GPS_LAUNCH_CHECK does for launches): -2 alone says nothing
 #define GPS_FAIL_LAUNCH()                                                                                   \
     do {                                                                                                    \
         fprintf(stderr, "[gps_slam_hip] %s:%d tracker: no result / hip error (%s)\n", __FILE__, __LINE__,  \
@@ -53,7 +57,23 @@ using // a failure of the tracker's host loop names its line on stderr (as GPS_L
         return GPS_ERR_LAUNCH;                                                                              \
     } while (0)
 
-namespace gpst;
+using namespace gpst;
+
+// Host-side store fence and cycle counter of the argument-line protocol.  x86-64: sfence drains the write-combining buffer a
+// BAR line gathers in (see publish()), rdtsc is the free diagnostic clock of the poll loop; elsewhere a full fence and the
+// steady clock (nanoseconds) stand in.
+#if defined(__x86_64__)
+static inline void host_store_fence() { _mm_sfence(); }
+static inline unsigned long long host_cycles() { return __rdtsc(); }
+#else
+#include <time.h>
+static inline void host_store_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline unsigned long long host_cycles() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (unsigned long long)t.tv_sec * 1000000000ull + (unsigned long long)t.tv_nsec;
+}
+#endif
 
 namespace {
 
@@ -674,25 +694,49 @@ int gps_track_state_reset(gps_track_state* ts) {
     return GPS_OK;
 }
 
-static thread_local sigjmp_buf g_probe_jmp;
-static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+// Probe of one host store + load through the BAR mapping under a fault handler.  Process-wide signal dispositions are involved:
+// the probe is serialised (one at a time), the handler only takes a fault of the PROBING thread at an address inside the
+// probed 4 KB block and otherwise hands the signal to whoever was installed before (Python's faulthandler, torch's crash
+// handlers, the default action).
+static std::mutex g_probe_mu;
+static sigjmp_buf g_probe_jmp;
+static volatile uintptr_t g_probe_lo = 0;
+static pthread_t g_probe_thread;
+static struct sigaction g_probe_old_segv, g_probe_old_bus;
+static void probe_fault(int sig, siginfo_t* info, void* ctx) {
+    const uintptr_t a = info ? reinterpret_cast<uintptr_t>(info->si_addr) : 0;
+    if (g_probe_lo && pthread_equal(pthread_self(), g_probe_thread) && a >= g_probe_lo && a < g_probe_lo + 4096) siglongjmp(g_probe_jmp, 1);
+    const struct sigaction& old = sig == SIGBUS ? g_probe_old_bus : g_probe_old_segv;
+    if (old.sa_flags & SA_SIGINFO) {
+        if (old.sa_sigaction) { old.sa_sigaction(sig, info, ctx); return; }
+    } else if (old.sa_handler != SIG_DFL && old.sa_handler != SIG_IGN) {
+        old.sa_handler(sig);
+        return;
+    }
+    signal(sig, SIG_DFL);   // not ours and nobody else's: the default action on return (the faulting instruction re-executes)
+}
 static bool host_can_write(void* p) {
-    struct sigaction sa = {}, old_segv = {}, old_bus = {};
-    sa.sa_handler = probe_fault;
+    std::lock_guard<std::mutex> lock(g_probe_mu);
+    struct sigaction sa = {};
+    sa.sa_sigaction = probe_fault;
+    sa.sa_flags = SA_SIGINFO;
     sigemptyset(&sa.sa_mask);
-    if (sigaction(SIGSEGV, &sa, &old_segv) != 0) return false;
-    if (sigaction(SIGBUS, &sa, &old_bus) != 0) { sigaction(SIGSEGV, &old_segv, nullptr); return false; }
+    g_probe_thread = pthread_self();
+    if (sigaction(SIGSEGV, &sa, &g_probe_old_segv) != 0) return false;
+    if (sigaction(SIGBUS, &sa, &g_probe_old_bus) != 0) { sigaction(SIGSEGV, &g_probe_old_segv, nullptr); return false; }
     bool ok = false;
+    g_probe_lo = reinterpret_cast<uintptr_t>(p);
     if (sigsetjmp(g_probe_jmp, 1) == 0) {
         volatile uint64_t* q = static_cast<volatile uint64_t*>(p);
         q[7] = 0x5A5A5A5A5A5A5A5Aull;
-        _mm_sfence();
+        host_store_fence();
         ok = q[7] == 0x5A5A5A5A5A5A5A5Aull;
         q[7] = 0;
-        _mm_sfence();
+        host_store_fence();
     }
-    sigaction(SIGSEGV, &old_segv, nullptr);
-    sigaction(SIGBUS, &old_bus, nullptr);
+    g_probe_lo = 0;
+    sigaction(SIGSEGV, &g_probe_old_segv, nullptr);
+    sigaction(SIGBUS, &g_probe_old_bus, nullptr);
     return ok;
 }
 
@@ -820,7 +864,18 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     }
     GPS_REQUIRE((reinterpret_cast<uintptr_t>(ts->dev_arg_line) & 63) == 0);
     volatile uint32_t* const bar_line = mailbox ? reinterpret_cast<volatile uint32_t*>(ts->dev_arg_line) : nullptr;
-    auto next_seq = [&]() { return (int)(ts->mail_seq = ts->mail_seq >= 0x3FFFFFFF ? 1 : ts->mail_seq + 1); };
+    // (when the sequence wraps, the line of the last launch before the wrap -- a LARGER number than everything that follows -- is
+    // wiped first: a late workgroup must not mistake it for a later launch's line, see `superseded` in the kernel)
+    auto next_seq = [&]() {
+        if (ts->mail_seq >= 0x3FFFFFFF) {
+            ts->mail_seq = 0;
+            if (bar_line) {
+                for (int k = 0; k < 8; k++) reinterpret_cast<volatile uint64_t*>(bar_line)[k] = 0;
+                host_store_fence();
+            }
+        }
+        return (int)(++ts->mail_seq);
+    };
     // payload first, sequence number last (x86 stores are not reordered with each other; the compiler barrier keeps the order)
     auto publish = [&](int seq, uint32_t cmd, int kind, int level, const float* pose) {
         uint32_t wds[16] = {0};
@@ -838,7 +893,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             // it: tools/probe/pingpong.hip reads 560 us per round trip instead of 1.8).  A torn line fails the xor word.
             for (int k = 0; k < 16; k += 2)
                 reinterpret_cast<volatile uint64_t*>(bar_line)[k >> 1] = (uint64_t)wds[k] | ((uint64_t)wds[k + 1] << 32);
-            _mm_sfence();
+            host_store_fence();
             return;
         }
         for (int k = 1; k < 16; k++) arg_line[k] = wds[k];
@@ -916,11 +971,11 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                 // (diagnostic, free: the time-stamp counter around every poll tells a GPU that answered late from a host
                 // thread that was not running -- the longest gap between two consecutive polls is ~20 ns unless the thread
                 // was descheduled in between)
-                const unsigned long long tsc0 = __rdtsc();
+                const unsigned long long tsc0 = host_cycles();
                 unsigned long long tsc_prev = tsc0, tsc_gap = 0;
                 for (long spin = 0; spin < 200000000L; spin++) {
                     if (float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq) { got = true; break; }
-                    const unsigned long long now = __rdtsc();
+                    const unsigned long long now = host_cycles();
                     if (now - tsc_prev > tsc_gap) tsc_gap = now - tsc_prev;
                     tsc_prev = now;
                     // a result normally lands within ~20 us (a few thousand polls); a host that is still spinning far beyond

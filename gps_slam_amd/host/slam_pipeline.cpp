@@ -1,5 +1,7 @@
 #include "slam_pipeline.hpp"
 
+#include <atomic>
+
 #include <chrono>
 #include <cstdlib>
 
@@ -194,12 +196,13 @@ void SLAMPipeline::updateFrameList() {
     }
     if (is_key) {
         keyframe_cam_list.push_back(curr_cam);
+        std::lock_guard<std::mutex> lk(loss_mu_);
         keyframe_loss_dict[curr_cam.id] = {0.1f, (float)curr_frame_id, 0.f, 0.f, 0.f};   // slam_pipeline.cpp:355
     }
 }
 
 void SLAMPipeline::localFrameRaycast() { raycastWindow(localframe_cam_window, main_engine->camPoses); }
-void SLAMPipeline::keyFrameRaycast() { raycastKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses); }
+void SLAMPipeline::keyFrameRaycast() { update_frame_id_ = curr_frame_id; raycastKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses); }
 void SLAMPipeline::initNewGaussians(TensorDict& rm) { initNewGaussiansFor(rm, curr_cam); }
 
 // runRaycastByCam for several cameras of ONE volume state: one batched free-view chain (TsdfEngine::runRaycastBatch) instead
@@ -292,6 +295,7 @@ void SLAMPipeline::raycastWindow(const std::deque<Camera>& window, const std::ve
 void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
                                     const std::vector<ORUtils::SE3Pose>& poses) {
     opt_cam_list.assign(window.begin(), window.end());
+    opt_window_len_ = window.size(); opt_frame_id_ = update_frame_id_;   // (what checkKeyFrameError indexes / stamps with)
     opt_raycast_list.assign(localframe_raycast_window.begin(), localframe_raycast_window.end());
     opt_raycast_events_ = window_raycast_events_;
     const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframes.size()) : 0;   // :538
@@ -319,6 +323,7 @@ void SLAMPipeline::raycastWindowAndKeyframes(const std::deque<Camera>& window, c
     std::vector<const Camera*> cams;
     for (const Camera& cam : window) cams.push_back(&cam);
     opt_cam_list.assign(window.begin(), window.end());
+    opt_window_len_ = window.size(); opt_frame_id_ = update_frame_id_;   // (what checkKeyFrameError indexes / stamps with)
     const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframes.size()) : 0;   // :538
     RandomSelector<Camera> sel(keyframes, rng_);
     for (int k = 0; k < n; k++) {
@@ -372,7 +377,10 @@ void SLAMPipeline::checkKeyFrameError() {
     torch::NoGradGuard no_grad;
     Config wc;
     wc.num["ssim_weight"] = ssim_weight; wc.num["depth_weight"] = depth_weight;
-    for (size_t k = localframe_cam_window.size(); k < opt_cam_list.size(); k++) {
+    // The window length and frame number are those of the update the lists belong to (recorded when the lists were built): with
+    // overlapped / threaded mapping this check runs while the frame thread keeps pushing into localframe_cam_window and
+    // advancing curr_frame_id, or one update late.  keyframe_loss_dict is shared with updateFrameList (frame thread): loss_mu_.
+    for (size_t k = opt_window_len_; k < opt_cam_list.size(); k++) {
         const Camera& cam = opt_cam_list[k];
         TensorDict& rc = opt_raycast_list[k];
         if (k < opt_raycast_events_.size()) waitRaycast(opt_raycast_events_[k]);
@@ -380,10 +388,11 @@ void SLAMPipeline::checkKeyFrameError() {
         auto loss = model->computeLoss(res, cam, wc, rc.at("depth_map") > 0);
         const float total = loss.at("total").item<float>();
         const float confidence_mean = rc.at("confidence_map").mean().item<float>();
+        std::lock_guard<std::mutex> lk(loss_mu_);
         auto it = keyframe_loss_dict.find(cam.id);
         float opt_count = it != keyframe_loss_dict.end() && it->second.size() > 3 ? it->second[3] : 0.f;
         if (total > loss_thres) opt_count += 1.f;
-        keyframe_loss_dict[cam.id] = {total, (float)curr_frame_id, confidence_mean, opt_count};
+        keyframe_loss_dict[cam.id] = {total, (float)opt_frame_id_, confidence_mean, opt_count};
     }
 }
 
@@ -496,7 +505,7 @@ static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 static thread_local double g_gate_wait_ms = 0.0, g_handover_wait_ms = 0.0;
-static double g_job_post_ms = 0.0;  // (debug aid only: when the frame thread woke the mapping thread)
+static std::atomic<double> g_job_post_ms{0.0};  // (debug aid only: when the frame thread woke the mapping thread)
 
 void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     curr_frame_id = i;
@@ -620,6 +629,7 @@ void SLAMPipeline::keyframeStepOverlapped() {
             if (sample_method == "ours") checkKeyFrameError();
             prune_pending_ = false;
         }
+        update_frame_id_ = curr_frame_id;
         if (merge_keyframe_raycasts) raycastWindowAndKeyframes(localframe_cam_window, keyframe_cam_list, main_engine->camPoses);
         else { localFrameRaycast(); keyFrameRaycast(); }
         if (async_raycasts) waitAllRaycasts();  // (this arrangement keeps its single map stream: the gate below covers them)
@@ -656,6 +666,7 @@ void SLAMPipeline::keyframeStepThreaded() {
     if (worker_error_) { lk.unlock(); rethrowWorkerError(); }
     hip_ok(hipEventRecord((hipEvent_t)ev_frame_, frames), "hipEventRecord");
     job_.curr_cam = curr_cam;
+    job_.frame_id = curr_frame_id;
     job_.window = localframe_cam_window;
     job_.keyframes = keyframe_cam_list;
     job_.poses = main_engine->camPoses;
@@ -695,6 +706,7 @@ void SLAMPipeline::mapWorker(int device_index) {
             const double t_woke = now_ms();
             // job_ is stable until done_seq_ catches up (the frame thread waits for that before it writes the next one)
             hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
+            update_frame_id_ = job_.frame_id;
             if (merge_keyframe_raycasts) raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
             else { raycastWindow(job_.window, job_.poses); raycastKeyframes(job_.window, job_.keyframes, job_.poses); }
             // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)

@@ -175,8 +175,11 @@ private:
     void keyframeStepThreaded();
     void mapWorker(int device_index);
     void rethrowWorkerError();
-    struct MapJob { Camera curr_cam; std::deque<Camera> window; std::vector<Camera> keyframes; std::vector<ORUtils::SE3Pose> poses; };
+    struct MapJob { Camera curr_cam; int frame_id = 0; std::deque<Camera> window; std::vector<Camera> keyframes; std::vector<ORUtils::SE3Pose> poses; };
     MapJob job_;
+    size_t opt_window_len_ = 0;                  // length of the local window at the front of opt_cam_list (the rest: history keyframes)
+    int opt_frame_id_ = 0, update_frame_id_ = 0; // frame number of the update opt_cam_list belongs to / of the update being built
+    std::mutex loss_mu_;                         // keyframe_loss_dict: written by updateFrameList (frame thread) and checkKeyFrameError (map thread)
     std::thread worker_;
     std::mutex mu_;
     std::condition_variable cv_;
