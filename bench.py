@@ -218,7 +218,8 @@ def setup_ranks(backend="nccl", need_gpu=True):
         torch.cuda.set_device(dev_index)
         device = "cuda:%d" % dev_index
         grp_device = device if backend == "nccl" else None
-    placement = pin_to_gpu_numa(dev_index if need_gpu else local_rank, world)
+    ndev_ = torch.cuda.device_count() if need_gpu else 0
+    placement = pin_to_gpu_numa(local_rank, world, device_of_rank=(lambda r: r % ndev_) if 0 < ndev_ < world else None)
     grp = Group(backend=backend, device=grp_device)
     return rank, local_rank, world, grp, placement, device
 

@@ -82,36 +82,89 @@ def gpu_numa_node(local_rank):
         return None
 
 
-def pin_to_gpu_numa(local_rank, world=1):
-    """Pin this process (and the threads it starts later: the tracker's frame thread, the mapping worker) to the cores of its
-    GPU's NUMA node, divided evenly between the ranks that share the node; if the node is unknown, to an equal slice of the
-    cores this process may use.  Returns a short description for the bench line.  One scene per GPU means the only shared
-    host resources are cores and PCIe root complexes -- keeping each rank's threads and pinned buffers next to its GPU is
-    all the placement the path needs."""
+def plan_affinity(world, gpu_nodes, node_cpus, allowed, core_of=None):
+    """Pure placement rule -> the cpu list of every local rank (tests/test_multi_rank_cpu.py drives it with fixtures).
+    gpu_nodes[r]: NUMA node of rank r's GPU (None or < 0: unknown); node_cpus: {node: cpus of that node}; allowed: cpus this
+    process may run on.  Ranks whose GPUs sit on the same node split that node's allowed cores evenly, in rank order -- whatever
+    the GPU-to-node mapping is (contiguous, interleaved, uneven); if any rank's node is unknown or has no allowed core, every
+    rank takes an equal slice of `allowed` instead.  Slices are non-empty, and disjoint whenever there is at least one core per
+    rank to hand out.  core_of: {cpu: physical core key}; the cpus are dealt out core by core (SMT siblings stay together:
+    Linux numbers them far apart, "0-63,128-191" being the 64 cores of one socket twice), so two ranks never share a physical core
+    when there are enough of them."""
+    key = (lambda c: core_of.get(c, c)) if core_of else (lambda c: c)
+
+    def deal(cpus, n):
+        """n slices of cpus: whole physical cores each while there are at least n cores, single cpus otherwise"""
+        cores = {}
+        for c in sorted(cpus, key=lambda c: (key(c), c)):
+            cores.setdefault(key(c), []).append(c)
+        groups = list(cores.values())
+        if len(groups) < n:
+            groups = [[c] for g in groups for c in g]
+        share = max(1, len(groups) // n)
+        out = []
+        for k in range(n):
+            part = groups[k * share:(k + 1) * share] or groups[-share:]
+            out.append(sorted(c for g in part for c in g))
+        return out
+
+    plans, usable = [None] * world, True
+    by_node = {}
+    for r in range(world):
+        n = gpu_nodes[r] if r < len(gpu_nodes) else None
+        if n is None or n < 0 or not (set(node_cpus.get(n, ())) & set(allowed)):
+            usable = False
+            break
+        by_node.setdefault(n, []).append(r)
+    if usable:
+        for n, ranks in by_node.items():
+            for r, part in zip(ranks, deal(set(node_cpus[n]) & set(allowed), len(ranks))):
+                plans[r] = part
+        return plans, "numa"
+    return deal(allowed, max(1, world)), "even"
+
+
+def _core_of():
+    """{cpu: (package, core)} from /sys/devices/system/cpu/cpu*/topology (empty when the platform does not say)"""
+    out = {}
+    base = "/sys/devices/system/cpu"
+    try:
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                t = os.path.join(base, d, "topology")
+                out[int(d[3:])] = (int(open(os.path.join(t, "physical_package_id")).read()), int(open(os.path.join(t, "core_id")).read()))
+    except (OSError, ValueError):
+        return {}
+    return out
+
+
+def _node_cpus():
+    out = {}
+    try:
+        for d in os.listdir("/sys/devices/system/node"):
+            if d.startswith("node") and d[4:].isdigit():
+                out[int(d[4:])] = sorted(_parse_cpulist(open("/sys/devices/system/node/%s/cpulist" % d).read()))
+    except OSError:
+        pass
+    return out
+
+
+def pin_to_gpu_numa(local_rank, world=1, device_of_rank=None):
+    """Pin this process (and the threads it starts later: the tracker's frame thread, the mapping worker) to its share of the
+    cores of its GPU's NUMA node (plan_affinity: the ranks of a node split it evenly; without NUMA information every rank takes
+    an equal slice of the cores this process may use).  device_of_rank(r) -> GPU index of local rank r (default: r; a rehearsal
+    on fewer GPUs than ranks maps several ranks to one device).  Returns a short description for the bench line.  One scene per
+    GPU means the only shared host resources are cores and PCIe root complexes -- keeping each rank's threads and pinned
+    buffers next to its GPU is all the placement the path needs."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return "affinity: unsupported"
-    node = gpu_numa_node(local_rank)
-    cpus = None
-    if node is not None and node >= 0:
-        try:
-            cpus = sorted(_parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) & set(allowed))
-        except OSError:
-            cpus = None
-    if cpus:
-        # ranks whose GPUs sit on the same node split it; without topology knowledge of the other ranks assume GPUs are
-        # spread evenly over the nodes (8 GPUs / 2 sockets -> 4 ranks per node)
-        n_nodes = max(1, len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]))
-        per_node = max(1, (world + n_nodes - 1) // n_nodes)
-        k = local_rank % per_node
-        share = max(2, len(cpus) // per_node)
-        mine = cpus[k * share:(k + 1) * share] or cpus
-        where = "numa node %d" % node
-    else:
-        share = max(2, len(allowed) // max(1, world))
-        mine = allowed[local_rank * share:(local_rank + 1) * share] or allowed
-        where = "no numa info"
+    dev = device_of_rank or (lambda r: r)
+    gpu_nodes = [gpu_numa_node(dev(r)) for r in range(world)]
+    plans, how = plan_affinity(world, gpu_nodes, _node_cpus(), allowed, core_of=_core_of())
+    mine = plans[local_rank % max(1, world)]
+    where = "numa node %d" % gpu_nodes[local_rank] if how == "numa" else "no numa info"
     try:
         os.sched_setaffinity(0, mine)
     except OSError as e:
@@ -121,4 +174,4 @@ def pin_to_gpu_numa(local_rank, world=1):
     # of this path is bookkeeping: a handful of threads is plenty.
     import torch
     torch.set_num_threads(max(1, min(8, len(mine))))
-    return "affinity: %s, %d cores (%d..%d), %d intra-op threads" % (where, len(mine), mine[0], mine[-1], torch.get_num_threads())
+    return "affinity: %s, %d cpus (%d..%d), %d intra-op threads" % (where, len(mine), min(mine), max(mine), torch.get_num_threads())

@@ -68,11 +68,16 @@ def _bench_worker(rank, world, port, q):
     grp.close()
 
 
-def test_bench_multi_gpu_entry_path_with_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_multi_gpu_entry_path_with_gloo(world):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: the rank set-up bench.py runs before any GPU work
     (device choice aside) -- environment ranks, NUMA / core pinning per rank, process-group init, barrier, max-over-ranks --
-    exercised with world_size 2 on gloo; plus the timed-window arithmetic every rank must agree on."""
-    world, port = 2, _free_port()
+    exercised with world_size 2 and 8 (BASELINE configs[4]: one scene per GPU of an 8-GPU node) on gloo; plus the timed-window
+    arithmetic every rank must agree on."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
@@ -82,13 +87,66 @@ def test_bench_multi_gpu_entry_path_with_gloo():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    assert [r[0] for r in res] == [0, 1] and all(r[1] == 2 for r in res)
-    assert res[0][2] != res[1][2]                                  # independent scenes
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] == world for r in res)
+    assert len({r[2] for r in res}) == world                       # independent scenes
     assert all(r[3] == 30 and r[4] == 25 for r in res)             # --warmup 5: timed step 0 = frame 30 (a keyframe), 25 prologue frames
-    assert all(abs(r[5] - 0.75) < 1e-12 for r in res)              # slowest rank's time on every rank
+    assert all(abs(r[5] - (0.5 + 0.25 * (world - 1))) < 1e-12 for r in res)   # slowest rank's time on every rank
     assert all(r[6].startswith("affinity:") for r in res)
-    if len(os.sched_getaffinity(0)) >= 4:                          # the two ranks were given disjoint core sets
-        assert not (set(res[0][7]) & set(res[1][7]))
+    if len(os.sched_getaffinity(0)) >= world:                      # the ranks were given disjoint, non-empty core sets
+        sets = [set(r[7]) for r in res]
+        assert all(sets) and sum(len(x) for x in sets) == len(set().union(*sets))
+
+
+def _cpus(text):
+    from gps_slam_amd.dist_util import _parse_cpulist
+    return sorted(_parse_cpulist(text))
+
+
+@pytest.mark.parametrize("name,node_cpus,gpu_nodes,allowed", [
+    # two sockets, SMT siblings numbered after the physical cores (the usual EPYC layout), 4 GPUs per socket
+    ("2 nodes contiguous", {0: "0-63,128-191", 1: "64-127,192-255"}, [0, 0, 0, 0, 1, 1, 1, 1], "0-255"),
+    ("2 nodes interleaved", {0: "0-63,128-191", 1: "64-127,192-255"}, [0, 1, 0, 1, 0, 1, 0, 1], "0-255"),
+    ("2 nodes uneven", {0: "0-63,128-191", 1: "64-127,192-255"}, [0, 0, 0, 0, 0, 0, 1, 1], "0-255"),
+    ("1 node", {0: "0-255"}, [0] * 8, "0-255"),
+    ("1 node, container cpuset", {0: "0-255"}, [0] * 8, "8-39"),
+    ("2 nodes, cpuset inside node 0 only", {0: "0-63,128-191", 1: "64-127,192-255"}, [0, 0, 0, 0, 1, 1, 1, 1], "0-31"),
+    ("no numa information", {}, [None] * 8, "0-63"),
+    ("numa_node = -1 (a VM)", {0: "0-63"}, [-1] * 8, "0-63"),
+    ("8 nodes (NPS4 x 2 sockets)", {n: "%d-%d" % (16 * n, 16 * n + 15) for n in range(8)}, list(range(8)), "0-127"),
+])
+def test_eight_ranks_get_disjoint_non_empty_core_sets(name, node_cpus, gpu_nodes, allowed):
+    """BASELINE configs[4] placement without the hardware: plan_affinity (what pin_to_gpu_numa applies) on cpulist fixtures of
+    2-node, 1-node, 8-node and NUMA-less hosts, with contiguous / interleaved / uneven GPU-to-node maps and container cpusets:
+    the 8 slices are non-empty, pairwise disjoint, inside the allowed set, and on the rank's own node whenever the plan is `numa`."""
+    from gps_slam_amd.dist_util import plan_affinity
+    nodes = {n: _cpus(t) for n, t in node_cpus.items()}
+    allow = _cpus(allowed)
+    # SMT siblings as Linux numbers them on these hosts: cpu c and c + 128 are one physical core (fixtures with < 128 cpus: no SMT)
+    core_of = {c: c % 128 for c in allow} if max(allow) >= 128 else None
+    plans, how = plan_affinity(8, gpu_nodes, nodes, allow, core_of=core_of)
+    assert len(plans) == 8 and all(plans), name
+    if core_of:   # no physical core is shared by two ranks
+        owners = {}
+        for r, p in enumerate(plans):
+            for c in p:
+                assert owners.setdefault(core_of[c], r) == r, (name, c)
+    flat = [c for p in plans for c in p]
+    assert len(flat) == len(set(flat)) and set(flat) <= set(allow), name
+    if how == "numa":
+        for r, p in enumerate(plans):
+            assert set(p) <= set(nodes[gpu_nodes[r]]), (name, r)
+        # ranks of one node share it evenly (sizes differ by nothing: integer division of the node's allowed cores)
+        for n in set(gpu_nodes):
+            sizes = {len(plans[r]) for r in range(8) if gpu_nodes[r] == n}
+            assert len(sizes) == 1, (name, n, sizes)
+    else:
+        assert name.startswith(("no numa", "numa_node", "2 nodes, cpuset inside")), name
+
+
+def test_fewer_cores_than_ranks_still_gives_every_rank_a_core():
+    from gps_slam_amd.dist_util import plan_affinity
+    plans, _ = plan_affinity(8, [None] * 8, {}, [0, 1, 2])
+    assert len(plans) == 8 and all(plans) and all(set(p) <= {0, 1, 2} for p in plans)
 
 
 class _StubScene:
@@ -139,13 +197,15 @@ def _main_worker(rank, world, port, out_dir):
         json.dump({"stdout": buf.getvalue(), "log": [s.log for s in scenes], "overlap": [s.overlap for s in scenes]}, f)
 
 
-def test_bench_main_end_to_end_with_two_ranks_on_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_main_end_to_end_on_gloo(tmp_path, world):
     """The WHOLE bench.main() -- argument parsing, rank set-up, per-rank seeds, both schedules, prologue + warm-up, the timed
     windows each bracketed by barriers, max-over-ranks, whole-job aggregation, the rank-0-only JSON line, the final barrier
-    before the group is torn down -- with world_size 2 on gloo and a stub scene whose frames take 2 ms on rank 0 and 4 ms on
-    rank 1: the line must carry n_gpus = 2, value = 2 ranks x K frames / the SLOW rank's median window, and no cpu_baseline."""
+    before the group is torn down -- with world_size 2 and 8 (the driver's N = 8 launch of BASELINE configs[4], one independent
+    scene per rank) on gloo and a stub scene whose frames take 2 ms x (1 + rank): the line must carry n_gpus = world, value =
+    world x K frames / the SLOWEST rank's median window, and no cpu_baseline."""
     import json
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     ps = [ctx.Process(target=_main_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
     for p in ps:
@@ -154,16 +214,16 @@ def test_bench_main_end_to_end_with_two_ranks_on_gloo(tmp_path):
         p.join(240)
         assert p.exitcode == 0
     res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
-    assert res[1]["stdout"].strip() == ""                                   # only rank 0 prints
+    assert all(res[r]["stdout"].strip() == "" for r in range(1, world))     # only rank 0 prints
     lines = [l for l in res[0]["stdout"].splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["n_gpus"] == world and out["steps"] == 10 and out["warmup"] == 5 and out["scaling"] == "weak"
     assert "cpu_baseline" not in out and out["higher_is_better"] is True and out["unit"] == "frames/s"
     assert out["config"]["windows"] == 3 and len(out["config"]["windows_ms_per_step"]) == 3
-    # the slow rank sets the time: ~4 ms per frame (rank 0 alone needs ~2 ms) -> ~2 x 10 frames / 0.040 s for the job
-    assert 3.9 < out["ms_per_step"] < 8.0, out["ms_per_step"]
-    assert abs(out["value"] - 2 * 10 / (out["ms_per_step"] * 1e-3 * 10)) < 1e-6 * out["value"]
+    # the slowest rank sets the time: ~2 ms x world per frame (rank 0 alone needs ~2 ms) -> world x 10 frames / that for the job
+    assert 1.95 * world < out["ms_per_step"] < 4.0 * world, out["ms_per_step"]
+    assert abs(out["value"] - world * 10 / (out["ms_per_step"] * 1e-3 * 10)) < 1e-6 * out["value"]
     assert sorted(out["config"]["schedules"]) == ["overlap", "sequential"]
     assert out["config"]["stats"]["frames"] == 10                           # stats of ONE window
     # every rank ran the same frame ranges: prologue + warm-up to frame 30, then three 10-frame windows, per schedule
