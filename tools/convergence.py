@@ -1,0 +1,145 @@
+"""Convergence evidence for the metric's second half ("render PSNR"): the bench's SLAM loop over a 300-frame synthetic orbit, and
+per keyframe update the render-vs-input PSNR on HELD-OUT frames (frames that are never an optimise camera: the local window takes
+every 5th frame, keyframes are picked from those), next to the PSNR of the TSDF colour raycast the Gaussians are composed over
+(the `base colour` of the ges model: rgb = (sum alpha c + base) / (W + 1), src/raw_gs_model.cpp:330-352) and, at every 5th
+checkpoint, the CPU oracle's render of the same state.  A last section answers "does the optimiser converge when it is given
+more than the reference's 20 iterations per keyframe": one camera optimised alone for 400 iterations, PSNR every 50.
+
+usage (GPU box):  python tools/convergence.py [--frames 300] [--seeded | --empty] [--out gpurun_out/r04_convergence]
+writes <out>.json and <out>.md (table + curves); copy both into profiles/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def psnr(a, b):
+    """scripts/utils/image_utils.py:19-21 (pinned by tests/test_reference_python_pin.py): 20 log10(1 / sqrt(mse)) on [0,1] images"""
+    mse = float(((a.clamp(0, 1) - b) ** 2).mean())
+    return float("inf") if mse == 0 else -10.0 * float(np.log10(mse))
+
+
+def spark(vals, lo, hi):
+    bars = " .:-=+*#%@"
+    return "".join(bars[int(max(0, min(len(bars) - 1, (v - lo) / max(1e-9, hi - lo) * (len(bars) - 1))))] for v in vals)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--gaussians", type=int, default=200000)
+    ap.add_argument("--empty", action="store_true", help="start with a handful of seeds only: (nearly) every Gaussian is added by the "
+                    "pipeline's own addGaussians, as in a run of the reference")
+    ap.add_argument("--gt-pose", action="store_true")
+    ap.add_argument("--oracle-every", type=int, default=5)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_convergence"))
+    args = ap.parse_args()
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    W, H, n = 640, 480, args.frames
+    seed = 1234
+    seq = bench.synthetic_sequence_device(W, H, n, seed, dev)
+    seeds = bench.seed_gaussians(seq, 2000 if args.empty else args.gaussians, seed, dev)
+    bench.prime(dev)
+    scene = bench.Scene(seq, seeds, seed, args.gt_pose, overlap=False, n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02)
+    gt = lambda j: torch.as_tensor(seq["rgb"][j]).to(dev).float() / 255.0
+    K = np.array([[seq["fx"], 0, seq["cx"]], [0, seq["fy"], seq["cy"]], [0, 0, 1]], np.float32)
+    rows = []
+    t0 = time.perf_counter()
+    for i in range(n):
+        scene.pipe.processFrameCLI(i, scene.cams[i])
+        if i % bench.PERIOD != bench.PERIOD - 1:
+            continue
+        scene.pipe.flush()   # the update of keyframe i - 9 is complete
+        held = [i - 7, i - 3]   # never optimise cameras (not multiples of 5)
+        with torch.no_grad():
+            r_psnr, t_psnr, o_psnr = [], [], []
+            for j in held:
+                cam = scene.cams[j]
+                rc = scene.pipe.runRaycastByCam(cam, False)
+                img = gt(j)
+                cam.image = img
+                cam.toGPU()
+                rgb = scene.model.forward(cam, rc["depth_map"], rc["color_map"])["rgb"]
+                r_psnr.append(psnr(rgb, img)); t_psnr.append(psnr(rc["color_map"], img))
+            # the views the update optimised (train views) on the same state
+            views = list(zip(scene.pipe.optCams(), scene.pipe.optRaycasts()))
+            tr = [psnr(scene.model.forward(c, r["depth_map"], r["color_map"])["rgb"], c.image) for c, r in views[:2]]
+            row = {"frame": i, "gaussians": int(scene.model.getGaussianNum()), "held_out_frames": held,
+                   "render_psnr_held_out": float(np.mean(r_psnr)), "tsdf_colour_psnr_held_out": float(np.mean(t_psnr)),
+                   "render_psnr_train_views": float(np.mean(tr)) if tr else None, "opt_views": len(views)}
+            if args.oracle_every and (len(rows) % args.oracle_every) == args.oracle_every - 1:
+                from oracle import splat_ref as orc
+                cp = scene.model.getGaussianParms()
+                nn = lambda t: t.detach().cpu().numpy()
+                j = held[-1]
+                cam = scene.cams[j]
+                rc = scene.pipe.runRaycastByCam(cam, False)
+                e_rgb, _ = orc.ges_render(nn(cp.getMeans()), nn(cp.getScales()), nn(cp.getQuats()), nn(cp.getFeaturesDc()),
+                                          nn(cp.getFeaturesRest()), nn(cp.getOpacities()), nn(cam.c2w_slam), K, W, H,
+                                          nn(rc["depth_map"])[..., 0], nn(rc["color_map"]), delta_depth=0.1)
+                row["oracle_render_psnr_last_held_out"] = psnr(torch.as_tensor(e_rgb).to(dev), gt(j))
+                row["hip_render_psnr_last_held_out"] = r_psnr[-1]
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    loop_s = time.perf_counter() - t0
+
+    # does the optimiser converge beyond the per-keyframe budget?  One held-out camera, optimised alone, 400 iterations
+    cam = scene.cams[n - 4]
+    rc = scene.pipe.runRaycastByCam(cam, False)
+    cam.image = gt(n - 4)
+    cam.toGPU()
+    scene.model.initOptimizers(-1, 1.0)
+    alone = []
+    for it in range(401):
+        if it % 50 == 0:
+            with torch.no_grad():
+                alone.append({"iteration": it, "psnr": psnr(scene.model.forward(cam, rc["depth_map"], rc["color_map"])["rgb"], cam.image)})
+        scene.model.trainStep(cam, rc["depth_map"], rc["color_map"])
+    torch.cuda.synchronize()
+    out = {"frames": n, "seeded_gaussians": 0 if args.empty else args.gaussians, "use_gt_pose": bool(args.gt_pose), "loop_seconds": loop_s,
+           "settings": {"local_opt_iters": 20, "local_opt_interval": 10, "window": "2 local frames (every 5th) + <= 7 random keyframes",
+                        "keyframe_thresholds": "1 deg / 2 cm (bench)", "loss": "L1 (ssim_weight 0, depth_weight 0: configs/release/replica/office0.yaml:38-40)"},
+           "per_keyframe": rows, "one_camera_alone": alone,
+           "tsdf_colour_psnr_of_that_camera": psnr(rc["color_map"], cam.image)}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(out, open(args.out + ".json", "w"), indent=1)
+    r = [x["render_psnr_held_out"] for x in rows]
+    t = [x["tsdf_colour_psnr_held_out"] for x in rows]
+    g = [x["render_psnr_held_out"] - x["tsdf_colour_psnr_held_out"] for x in rows]
+    lo, hi = min(r + t), max(r + t)
+    with open(args.out + ".md", "w") as f:
+        f.write("# Render PSNR per keyframe update on held-out frames (tools/convergence.py, MI355X)\n\n")
+        f.write("%d frames of the synthetic orbit (640x480), %s, tracking %s, sequential schedule; after every update the two frames of\n"
+                "the last period that are never optimise cameras are rendered from their tracked pose.\n\n"
+                % (n, "start from ~%d k seeded Gaussians" % (args.gaussians // 1000) if not args.empty else "start from 2,000 seeds "
+                   "(everything else added by addGaussians)", "off (given poses)" if args.gt_pose else "on"))
+        f.write("```\nrender  %s  %.2f .. %.2f dB\ntsdf    %s  %.2f .. %.2f dB\ngain    %s  %+.2f .. %+.2f dB (render - tsdf colour)\n```\n\n"
+                % (spark(r, lo, hi), min(r), max(r), spark(t, lo, hi), min(t), max(t), spark(g, min(g), max(g)), min(g), max(g)))
+        f.write("| frame | Gaussians | render PSNR held-out | TSDF colour PSNR held-out | gain | render PSNR train views | oracle render (same state) |\n|---|---|---|---|---|---|---|\n")
+        for x in rows:
+            f.write("| %d | %d | %.2f | %.2f | %+.2f | %s | %s |\n" % (
+                x["frame"], x["gaussians"], x["render_psnr_held_out"], x["tsdf_colour_psnr_held_out"],
+                x["render_psnr_held_out"] - x["tsdf_colour_psnr_held_out"],
+                "%.2f" % x["render_psnr_train_views"] if x["render_psnr_train_views"] is not None else "-",
+                "%.2f (HIP %.2f)" % (x["oracle_render_psnr_last_held_out"], x["hip_render_psnr_last_held_out"])
+                if "oracle_render_psnr_last_held_out" in x else ""))
+        f.write("\nOne camera optimised alone from the final state (TSDF colour of that view: %.2f dB):\n\n| iteration | PSNR |\n|---|---|\n"
+                % out["tsdf_colour_psnr_of_that_camera"])
+        for a in alone:
+            f.write("| %d | %.2f |\n" % (a["iteration"], a["psnr"]))
+    print("wrote", args.out + ".json / .md")
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()
