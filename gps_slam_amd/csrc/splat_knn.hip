@@ -5,7 +5,7 @@
 // prunes boxes by their distance to the query.  On this path the points are samples of SURFACES seen by a depth camera (a first
 // keyframe or a newly revealed room adds up to 0.25 x W x H of them: 76,800 at 640x480, 230,400 at 720p), so a uniform grid over
 // their bounding box is the better fit for a wide machine: a counting sort by cell (histogram, scan, scatter -- no comparison
-// sort, no cub), then one thread per point IN CELL ORDER that searches its own cell and grows the searched cube ring by ring
+// sort, no cub), then eight lanes per point IN CELL ORDER that search the point's own cell and grow the searched cube ring by ring
 // until the third-best distance found is no larger than the distance to the nearest face of the cube that still has grid behind
 // it -- the exact termination test, so the result is the brute force's: the three smallest squared distances are a set
 // property, both kernels keep them sorted ascending and add them in that order, and both compute a squared distance with
@@ -214,17 +214,37 @@ __global__ __launch_bounds__(256) void knn_scatter_kernel(int P, const float* __
     sorted[slot] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float(i));
 }
 
-// (6) one thread per point in cell order
+// (6) KQ_LANES lanes per point, points in cell order.  The lanes of a point walk the same cells and split every run of
+// candidates between them (candidate lo + lane, + KQ_LANES, ...): KQ_LANES independent loads in flight per point instead of one
+// dependent chain -- one lane per point made the search latency-bound (94 us for 5 k points: ~100 candidates x one L2 round
+// trip each).  Every lane keeps the three smallest distances of ITS candidates; the termination test and the result use their
+// merge (three xor-shuffles; the private triples are never overwritten, so no candidate is counted twice).
+constexpr int KQ_LANES = 8;
+__device__ __forceinline__ void merge3(float& b0, float& b1, float& b2) {
+#pragma unroll
+    for (int o = 1; o < KQ_LANES; o <<= 1) {
+        const float o0 = __shfl_xor(b0, o, 64), o1 = __shfl_xor(b1, o, 64), o2 = __shfl_xor(b2, o, 64);
+        gps::keep3(o0, b0, b1, b2); gps::keep3(o1, b0, b1, b2); gps::keep3(o2, b0, b1, b2);
+    }
+}
 __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnGrid* __restrict__ grid, const int* __restrict__ starts,
                                                         const float4* __restrict__ sorted, float* __restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P) return;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) / KQ_LANES, sub = threadIdx.x & (KQ_LANES - 1);
+    if (t >= P) return;   // (whole sub-groups leave together: the shuffles below stay inside a sub-group)
     const KnnGrid g = *grid;
     const float4 q = sorted[t];
     const int self = __float_as_int(q.w);
     const int cx = cell_coord(q.x, g.minx, g.inv_h, g.gx), cy = cell_coord(q.y, g.miny, g.inv_h, g.gy),
               cz = cell_coord(q.z, g.minz, g.inv_h, g.gz);
-    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;   // of this lane's candidates
+    float m0 = FLT_MAX, m1 = FLT_MAX, m2 = FLT_MAX;   // merged over the point's lanes
+    auto scan_run = [&](int lo, int hi) {
+        for (int k = lo + sub; k < hi; k += KQ_LANES) {
+            const float4 c = sorted[k];
+            if (__float_as_int(c.w) == self) continue;
+            gps::keep3(gps::knn_dist2(c.x - q.x, c.y - q.y, c.z - q.z), b0, b1, b2);
+        }
+    };
     // a point's computed cell can differ from its exact one by rounding at a face: the faces of the searched cube are trusted only
     // up to a margin of 1 % of a cell (the coordinate error is < 1e-4 cells at <= 1024 cells per axis)
     const float margin = 0.01f * g.h;
@@ -236,28 +256,15 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnGrid* __
                 // the shell of ring r: whole x-runs on its z / y faces, the two end cells elsewhere
                 const bool face = (z == cz - r) | (z == cz + r) | (y == cy - r) | (y == cy + r);
                 const int row = g.gx * (y + g.gy * z);
-                if (face || r == 0) {
-                    // cells x0..x1 of a row are consecutive: one run of sorted points
-                    const int lo = starts[row + x0], hi = starts[row + x1 + 1];
-                    for (int k = lo; k < hi; k++) {
-                        const float4 c = sorted[k];
-                        if (__float_as_int(c.w) == self) continue;
-                        gps::keep3(gps::knn_dist2(c.x - q.x, c.y - q.y, c.z - q.z), b0, b1, b2);
-                    }
+                if (face) {
+                    scan_run(starts[row + x0], starts[row + x1 + 1]);   // cells x0..x1 of a row are consecutive: one run of sorted points
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int x = e ? cx + r : cx - r;
-                        if (x < 0 || x >= g.gx) continue;
-                        const int lo = starts[row + x], hi = starts[row + x + 1];
-                        for (int k = lo; k < hi; k++) {
-                            const float4 c = sorted[k];
-                            if (__float_as_int(c.w) == self) continue;
-                            gps::keep3(gps::knn_dist2(c.x - q.x, c.y - q.y, c.z - q.z), b0, b1, b2);
-                        }
-                    }
+                    if (cx - r >= 0) scan_run(starts[row + cx - r], starts[row + cx - r + 1]);
+                    if (cx + r < g.gx) scan_run(starts[row + cx + r], starts[row + cx + r + 1]);
                 }
             }
+        m0 = b0; m1 = b1; m2 = b2;
+        merge3(m0, m1, m2);
         // distance from the query to the nearest face of the searched cube that has grid behind it
         float dmin = FLT_MAX;
         bool open = false;
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnGrid* __
         if (cz + r < g.gz - 1) { open = true; dmin = fminf(dmin, (g.minz + (float)(cz + r + 1) * g.h) - q.z); }
         if (!open) break;                       // the cube covers the grid
         dmin -= margin;
-        if (dmin > 0.f && b2 <= dmin * dmin) break;   // nothing outside the cube can be closer than the third best
+        if (dmin > 0.f && m2 <= dmin * dmin) break;   // nothing outside the cube can be closer than the third best
     }
-    out[self] = (b0 + b1 + b2) / 3.0f;
+    if (sub == 0) out[self] = (m0 + m1 + m2) / 3.0f;
 }
 
 }  // namespace
@@ -296,7 +303,7 @@ int gps_knn_mean_dist2_grid(int P, const float* points, float* mean_dist2, void*
     knn_scan_sums_kernel<<<KG_MAX_SCAN_BLOCKS, KG_SCAN_THREADS, 0, st>>>(w.grid, w.starts, w.block_sums);
     knn_scan_apply_kernel<<<KG_MAX_SCAN_BLOCKS, KG_SCAN_THREADS, 0, st>>>(w.grid, w.starts, w.block_sums, P);
     knn_scatter_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(P, points, w.cell_of, w.starts, w.fill, w.sorted);
-    knn_query_kernel<<<gps_div_up(P, 256), 256, 0, st>>>(P, w.grid, w.starts, w.sorted, mean_dist2);
+    knn_query_kernel<<<gps_div_up((int64_t)P * KQ_LANES, 256), 256, 0, st>>>(P, w.grid, w.starts, w.sorted, mean_dist2);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
