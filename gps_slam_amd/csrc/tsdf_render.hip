@@ -272,13 +272,12 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
 // shuffles, lane 0 writes the cell where pass B would have (the image other readers and the tests see), and the first wave
 // publishes + clears the rendering-block counter: one launch and its ~8-10 us leave the frame chain.
 template <bool MODIFY_VISIBLE>
-__global__ __launch_bounds__(256, 5) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
+__global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
                                                      float4* __restrict__ rays, const uint32_t* __restrict__ bits,
                                                      const ViewRec* __restrict__ views, const uint2* __restrict__ partial, int sw,
                                                      int sh, float2* __restrict__ mm_out) {
     GPS_FRAME_PRIO();
     __shared__ uint32_t wg_acc[4];  // this workgroup's {steps, reads, rays, waves done}
-    __shared__ int2 nc_tab[8][256];  // per lane: what the hash table says about the 2 x 2 x 2 blocks around the ray's position (see the loop)
     if (threadIdx.x < 4) wg_acc[threadIdx.x] = 0;
     __syncthreads();
     if (views) {
@@ -342,45 +341,30 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(TsdfState s, Mat4 invM,
     int vmIndex = 0;
     int n_steps = 0, n_reads = 0;  // castRay steps as the reference counts them / samples this loop actually reads
     const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
-    // Neighbourhood table.  Every lookup of one castRay step -- the sample voxel round(p) and, in the band, the eight corners of the
-    // interpolation cell [floor(p), floor(p) + 1]^3 -- lands in the 2 x 2 x 2 blocks starting at B0 = block of floor(p).  What the hash
-    // table says about those blocks is kept per lane while B0 stays the same ({first voxel index or -1, entry index} per
-    // neighbour, in LDS; a bit per neighbour = "known"): bucket heads are fetched only for neighbours not yet known, all in one
-    // batch, so a step costs ONE memory round trip (its eight corner voxels; the sample is one of them) once the table is warm.
-    // The reference's lookups are then replayed in its order from the table -- same cache evolution, same vmIndex values, no
-    // memory access.  Before: a straddling cell in the band cost three dependent round trips per step (sample, eight heads, eight
-    // voxels), and grazing rays that creep along a block face for tens of one-voxel steps were the kernel's tail.
-    int nc_bx = 0x7fffffff, nc_by = 0x7fffffff, nc_bz = 0x7fffffff;
-    uint32_t nc_known = 0;
-    const int tid = threadIdx.x;
     while (totalLength < totalLengthMax) {
-        const float ffx = floorf(px), ffy = floorf(py), ffz = floorf(pz);
-        const int cix = (int)ffx, ciy = (int)ffy, ciz = (int)ffz;
-        const int b0x = floor_div_blk(cix), b0y = floor_div_blk(ciy), b0z = floor_div_blk(ciz);
-        if ((b0x != nc_bx) | (b0y != nc_by) | (b0z != nc_bz)) { nc_bx = b0x; nc_by = b0y; nc_bz = b0z; nc_known = 0; }
-        const bool sx = (cix & 7) == 7, sy = (ciy & 7) == 7, sz = (ciz & 7) == 7;   // the cell straddles a block face in x / y / z
-        uint32_t need = 1u;                     // bit j = neighbour (j & 1, j >> 1 & 1, j >> 2) holds a corner of the cell
-        need |= sx ? need << 1 : 0u; need |= sy ? need << 2 : 0u; need |= sz ? need << 4 : 0u;
-        const int vx = (int)roundf_ref(px), vy = (int)roundf_ref(py), vz = (int)roundf_ref(pz);   // the sample: a corner of the cell
-        const int sbx = floor_div_blk(vx), sby = floor_div_blk(vy), sbz = floor_div_blk(vz);
-        const uint32_t js = (uint32_t)(sbx - b0x) | ((uint32_t)(sby - b0y) << 1) | ((uint32_t)(sbz - b0z) << 2);
-        const uint32_t missing = need & ~nc_known;
-        uint32_t occupied = 1u;  // bit j: the bucket of free-space candidate j has a non-empty head (or was not looked at)
-        if (__any(missing != 0u)) {
-            // heads of the neighbours not yet known, one batch (a lane / neighbour with nothing to ask re-reads bucket 0: a broadcast)
-            uint4 hraw[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int h = hash_index(b0x + (j & 1), b0y + ((j >> 1) & 1), b0z + (j >> 2), s.n_buckets - 1);
-                hraw[j] = load_raw(s.hash, ((missing >> j) & 1u) ? h : 0);
-            }
-            // If the sample's block is among them, the occupancy bits of the next SKIP free-space steps ride along: candidates
-            // 1..SKIP are where the next steps land IF this and the following lookups fail (a failed lookup always advances by one
-            // block edge) -- the same float additions in the same order as the one-lookup-per-step loop.  One batch of dword loads
-            // from the 128 KB bucket bitmap (tsdf_common.hpp); an empty head is a certain miss (ITMRepresentationAccess.h:95-110).
-            // Measured on the bench scene (tools/probe/raycast_time.py, live raycast): 16-byte heads x 4: 137.5 us; bits x 1 / 2 /
-            // 3 / 5 / 7 / 9 / 15: 123.6 / 115.4 / 116.5 / 112.5 / 116.1 / 122.2 / 141.1 us.
-            const bool ask_bits = (missing >> js) & 1u;
+        // Candidate positions: [0] is this step's sample; [1..SKIP] are where the next steps land IF this and the
+        // following lookups fail (a failed lookup always advances by one block edge, stepLength = 8 voxels) -- the same
+        // float additions in the same order as the one-lookup-per-step loop.  A lane whose sample is in its cached
+        // block needs no bucket at all; the others fetch all 1+SKIP bucket heads in one batch.
+        const int vx = (int)roundf_ref(px), vy = (int)roundf_ref(py), vz = (int)roundf_ref(pz);
+        const int kx0 = floor_div_blk(vx), ky0 = floor_div_blk(vy), kz0 = floor_div_blk(vz);
+        const int lin = vx + (vy - kx0) * BLK + (vz - ky0) * BLK * BLK - kz0 * BLK3;
+        const bool cached = kx0 == cache.bx && ky0 == cache.by && kz0 == cache.bz;
+        int hidx0 = 0;
+        uint4 hraw0 = {};
+        uint32_t occupied = ~0u;  // bit j: the bucket of candidate j has a non-empty head (or was not looked at)
+        if (!cached) {
+            hidx0 = hash_index(kx0, ky0, kz0, s.n_buckets - 1);
+            hraw0 = load_raw(s.hash, hidx0);
+            // candidates 1..SKIP: where the next steps land IF this and the following lookups fail (a failed lookup always
+            // advances by one block edge) -- the same float additions in the same order as the one-lookup-per-step loop.
+            // Only the occupancy BIT of their buckets is fetched (one batch of dword loads from a 128 KB bitmap, see
+            // tsdf_common.hpp); an empty head is a certain miss (ITMRepresentationAccess.h:95-110: no entry, no chain).
+            // Round 1 fetched the 16-byte heads of 4 candidates; measured on the bench scene (tools/probe/raycast_time.py,
+            // live raycast): heads x 4: 137.5 us; bits x 1 / 2 / 3 / 5 / 7 / 9 / 15: 123.6 / 115.4 / 116.5 / 112.5 / 116.1 /
+            // 122.2 / 141.1 us -- past ~7 the per-candidate index arithmetic (round, shift, hash: ~25 VALU ops) outweighs
+            // the saved round trips (on a scene of 10 m free-space runs: 926 -> 673 us with ONE candidate, slower again
+            // with more).
             uint32_t word[SKIP], shift[SKIP];
             float cx_ = px, cy_ = py, cz_ = pz;
 #pragma unroll
@@ -388,48 +372,40 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(TsdfState s, Mat4 invM,
                 cx_ += (float)BLK * rx; cy_ += (float)BLK * ry; cz_ += (float)BLK * rz;
                 const int h = hash_index(floor_div_blk((int)roundf_ref(cx_)), floor_div_blk((int)roundf_ref(cy_)),
                                          floor_div_blk((int)roundf_ref(cz_)), s.n_buckets - 1);
-                word[j] = bits[ask_bits ? h >> 5 : 0];
+                word[j] = bits[h >> 5];
                 shift[j] = (uint32_t)h & 31u;
             }
+            pin(hraw0);
+            occupied = 1u;
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) pin(hraw[j], hraw[j + 1]);
-            if (ask_bits) {
-#pragma unroll
-                for (int j = 0; j < SKIP; j++) occupied |= ((word[j] >> shift[j]) & 1u) << (j + 1);
-            } else {
-                occupied = ~0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if ((missing >> j) & 1u) {
-                    // findVoxel's walk (ITMRepresentationAccess.h:95-110): bucket head, then its excess-list chain (rare)
-                    HashEntry he = decode_entry(hraw[j]);
-                    int idx = hash_index(b0x + (j & 1), b0y + ((j >> 1) & 1), b0z + (j >> 2), s.n_buckets - 1), ptr = -1;   // (recomputed: registers)
-                    while (true) {
-                        if (entry_is(he, b0x + (j & 1), b0y + ((j >> 1) & 1), b0z + (j >> 2)) & (he.ptr >= 0)) { ptr = he.ptr * BLK3; break; }
-                        if (he.offset < 1) break;
-                        idx = s.n_buckets + he.offset - 1;
-                        he = load_entry(s.hash, idx);
-                    }
-                    nc_tab[j][tid] = make_int2(ptr, idx);
-                }
-            }
-            nc_known |= missing;
-        } else {
-            occupied = ~0u;
+            for (int j = 0; j < SKIP; j++) occupied |= ((word[j] >> shift[j]) & 1u) << (j + 1);
         }
-        // the sample's lookup, replayed: cache hit -> vmIndex = 1; table says present -> vmIndex = entry + 1 and the cache moves
+        const HashEntry head0 = decode_entry(hraw0);
         int base;
-        if ((sbx == cache.bx) & (sby == cache.by) & (sbz == cache.bz)) { vmIndex = 1; base = cache.ptr; }
-        else {
-            const int2 e = nc_tab[js][tid];
-            if (e.x >= 0) { cache.bx = sbx; cache.by = sby; cache.bz = sbz; cache.ptr = e.x; vmIndex = e.y + 1; base = e.x; }
-            else { vmIndex = 0; base = -1; }
+        if (cached) { vmIndex = 1; base = cache.ptr; }
+        else base = resolve_with_head(s, kx0, ky0, kz0, head0, hidx0, vmIndex, cache);
+        // The sample voxel round(p) is a corner of the interpolation cell [floor(p), floor(p)+1]^3.  If that cell lies
+        // inside one block it is this block, so its eight voxels ride along with the sample in the same round trip and
+        // the interpolated read below -- whose corner lookups would all hit the cache that now holds this block --
+        // needs no memory access at all.
+        const float ffx = floorf(px), ffy = floorf(py), ffz = floorf(pz);
+        const int cix = (int)ffx, ciy = (int)ffy, ciz = (int)ffz;
+        const bool cell_in_block = (cix & 7) < 7 && (ciy & 7) < 7 && (ciz & 7) < 7;
+        uint64_t raw = EMPTY_VOXEL;
+        uint64_t corner[8];
+        if (base >= 0) {  // (skipped entirely by a wave whose live lanes are all in free space)
+            raw = vox[base + lin];
+            if (cell_in_block) {
+                const uint64_t* v = vox + base + (cix & 7) + (ciy & 7) * BLK + (ciz & 7) * BLK * BLK;
+                corner[0] = v[0]; corner[1] = v[1]; corner[2] = v[BLK]; corner[3] = v[BLK + 1];
+                corner[4] = v[BLK * BLK]; corner[5] = v[BLK * BLK + 1]; corner[6] = v[BLK * BLK + BLK];
+                corner[7] = v[BLK * BLK + BLK + 1];
+            }
         }
+        sdfValue = vox_sdf(raw) / 32767.0f;
         if (MODIFY_VISIBLE) { if (vmIndex) s.visible_type[vmIndex - 1] = 1; }  // incl. the vmIndex==1 cache-hit quirk
         n_reads++;
         if (!vmIndex) {
-            sdfValue = vox_sdf(EMPTY_VOXEL) / 32767.0f;
             stepLength = BLK;
             // advance over the candidates that are certainly unallocated steps inside the range (empty bucket head); the
             // first one that is anything else is sampled by the next iteration.  (One batch per iteration: an inner
@@ -444,47 +420,14 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(TsdfState s, Mat4 invM,
             }
             n_steps += adv;  // (each skipped candidate is one failed lookup = one step of the reference loop)
         } else {
-            // the eight corner voxels of the cell in ONE batch (the sample is corner ks): first voxel index of every neighbour from
-            // the table (-1: unallocated or not asked), corner k sits in neighbour k & (sx, sy, sz)
-            int P[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) P[j] = ((nc_known >> j) & 1u) ? nc_tab[j][tid].x : -1;
-            int cidx[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int pa = (k & 1) ? (sx ? P[1] : P[0]) : P[0], pb = (k & 1) ? (sx ? P[3] : P[2]) : P[2];
-                const int pc = (k & 1) ? (sx ? P[5] : P[4]) : P[4], pd = (k & 1) ? (sx ? P[7] : P[6]) : P[6];
-                const int pab = (k & 2) ? (sy ? pb : pa) : pa, pcd = (k & 2) ? (sy ? pd : pc) : pc;
-                const int pk = (k & 4) ? (sz ? pcd : pab) : pab;
-                const int lin = ((cix + (k & 1)) & 7) + ((ciy + ((k >> 1) & 1)) & 7) * BLK + ((ciz + (k >> 2)) & 7) * BLK * BLK;
-                cidx[k] = pk >= 0 ? pk + lin : -1;
-            }
-            uint64_t corner[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) corner[k] = vox[cidx[k] >= 0 ? cidx[k] : 0];  // unconditional: one batch, no branches
-#pragma unroll
-            for (int k = 0; k < 8; k++) corner[k] = cidx[k] >= 0 ? corner[k] : EMPTY_VOXEL;
-            const uint32_t ks = (uint32_t)(vx - cix) | ((uint32_t)(vy - ciy) << 1) | ((uint32_t)(vz - ciz) << 2);
-            uint32_t lo01 = (ks & 1u) ? (uint32_t)corner[1] : (uint32_t)corner[0], lo23 = (ks & 1u) ? (uint32_t)corner[3] : (uint32_t)corner[2];
-            uint32_t lo45 = (ks & 1u) ? (uint32_t)corner[5] : (uint32_t)corner[4], lo67 = (ks & 1u) ? (uint32_t)corner[7] : (uint32_t)corner[6];
-            const uint32_t lo0123 = (ks & 2u) ? lo23 : lo01, lo4567 = (ks & 2u) ? lo67 : lo45;
-            const uint32_t raw_lo = (ks & 4u) ? lo4567 : lo0123;
-            sdfValue = (float)(int16_t)(raw_lo & 0xFFFFu) / 32767.0f;
             if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
-                // readFromSDF_float_interpolated: the eight corner lookups in the reference's order move the cache to the block of
-                // every corner found that is not the cached one (ITMRepresentationAccess.h:117-150 through findVoxel)
                 float dummy;
-                sdfValue = blend_corners<false>(corner, px - ffx, py - ffy, pz - ffz, dummy);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int kbx = b0x + (((k & 1) && sx) ? 1 : 0), kby = b0y + (((k & 2) && sy) ? 1 : 0), kbz = b0z + (((k & 4) && sz) ? 1 : 0);
-                    const bool hit = (kbx == cache.bx) & (kby == cache.by) & (kbz == cache.bz);
-                    if (!hit && cidx[k] >= 0) {
-                        cache.bx = kbx; cache.by = kby; cache.bz = kbz;
-                        cache.ptr = cidx[k] - (((cix + (k & 1)) & 7) + ((ciy + ((k >> 1) & 1)) & 7) * BLK + ((ciz + (k >> 2)) & 7) * BLK * BLK);
-                    }
+                if (cell_in_block) {
+                    sdfValue = blend_corners<false>(corner, px - ffx, py - ffy, pz - ffz, dummy);
+                    vmIndex = 1;
+                } else {
+                    sdfValue = read_sdf_interp<false>(s, px, py, pz, vmIndex, cache, dummy);
                 }
-                vmIndex = 1;
             }
             if (sdfValue <= 0.0f) break;
             const float a = sdfValue * stepScale;

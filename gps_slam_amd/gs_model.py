@@ -187,7 +187,7 @@ for _n in RawGaussianParams.NAMES:
     setattr(RawGaussianParams, _n, property(lambda self, _n=_n: self._buf[_n][:self.N]))
 
 
-KNN_GRID_MIN_POINTS = 4096   # include/gps_slam_hip.h GPS_KNN_GRID_MIN_POINTS
+KNN_GRID_MIN_POINTS = 8192   # include/gps_slam_hip.h GPS_KNN_GRID_MIN_POINTS
 
 
 def knn_mean_dist2(points, method=None):

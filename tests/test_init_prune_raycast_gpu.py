@@ -226,7 +226,7 @@ def test_grid_knn_is_exact_on_a_first_keyframe_of_surface_points(P, W, H):
     assert torch.equal(grid, brute)
     ref = _knn3_float64(x)
     torch.testing.assert_close(grid.double(), ref, rtol=2e-5, atol=1e-12)
-    assert torch.equal(knn_mean_dist2(x), grid)                                # the default picks the grid above 4,096 points
+    assert torch.equal(knn_mean_dist2(x), grid)                                # the default picks the grid above 8,192 points
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     torch.cuda.synchronize()
     ev[0].record()
