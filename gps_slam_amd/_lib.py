@@ -121,6 +121,7 @@ PROTOTYPES = {
     "gps_tsdf_raycast": (i32, [C.POINTER(TsdfState), vp, i32, i32, vp]),
     "gps_tsdf_expected_depths_and_raycast": (i32, [C.POINTER(TsdfState), vp, vp, i32, i32, vp]),
     "gps_tsdf_icp_maps": (i32, [C.POINTER(TsdfState), vp, vp]),
+    "gps_tsdf_ray_stats": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_find_visible": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_render_colour": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_process_frame": (i32, [C.POINTER(TsdfState), vp, vp, vp, vp]),

@@ -37,6 +37,8 @@ constexpr int ED_GROUPS = 64;  // per-workgroup partial min/max images of Create
 //                               never freed, so alloc_apply only ever sets bits; gps_tsdf_reset clears them,
 //                               gps_tsdf_rebuild_index recomputes them from the table (after a scene was loaded into it).
 //                               The raycaster's free-space march asks this 128 KB bitmap instead of the 16 MB table.
+//   [16]                        pad
+//   [4 + 4 * waves]             ray statistics of the last raycast launch (ray_stats_rows below), waves = 4 per 16 x 16 pixel patch
 static inline int64_t scratch_words_before_bits(const gps_tsdf_state& s) {
     const int64_t n_total = (int64_t)s.n_buckets + s.n_excess;
     const int64_t nblk = (n_total + 1023) / 1024;
@@ -45,6 +47,19 @@ static inline int64_t scratch_words_before_bits(const gps_tsdf_state& s) {
 }
 static inline uint32_t* bucket_bits(const gps_tsdf_state& s) {
     return reinterpret_cast<uint32_t*>(s.scan_scratch) + scratch_words_before_bits(s);
+}
+// behind the bitmap (+ 16 words of pad): the ray statistics of the LAST raycast launch on this scratch, one {castRay steps,
+// voxel reads, rays, 0} quadruple of floats per wave of that launch, written with plain stores (no atomics, no zero-fill;
+// gps_tsdf_ray_stats sums them into counters[GPS_TSDF_RAY_STEPS..] on demand)
+__host__ __device__ inline int ray_stat_waves(const gps_tsdf_state& s) { return ((s.width + 15) / 16) * ((s.height + 15) / 16) * 4; }
+__host__ __device__ inline int64_t ray_stats_offset_words(const gps_tsdf_state& s) {
+    const int64_t n_total = (int64_t)s.n_buckets + s.n_excess;
+    const int64_t nblk = (n_total + 1023) / 1024;
+    const int64_t sw = s.width / 8 + 2, sh = s.height / 8 + 2;
+    return 3 * nblk + 16 + (n_total + 3) / 4 + 2 + (int64_t)64 * sw * sh * 2 + 16 + ((int64_t)s.n_buckets + 31) / 32 + 16;
+}
+__host__ __device__ inline float4* ray_stats_rows(const gps_tsdf_state& s) {
+    return reinterpret_cast<float4*>(s.scan_scratch + ((ray_stats_offset_words(s) + 3) & ~(int64_t)3));   // (16-byte aligned rows)
 }
 
 struct Mat4 { float m[16]; };  // ORUtils layout m[col*4 + row]

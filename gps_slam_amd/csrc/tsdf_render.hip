@@ -16,6 +16,7 @@
 
 #include "tsdf_common.hpp"
 #include "tsdf_pose.hpp"
+#include "wave_reduce.hpp"
 
 using namespace gpst;
 
@@ -277,9 +278,6 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
                                                      const ViewRec* __restrict__ views, const uint2* __restrict__ partial, int sw,
                                                      int sh, float2* __restrict__ mm_out) {
     GPS_FRAME_PRIO();
-    __shared__ uint32_t wg_acc[4];  // this workgroup's {steps, reads, rays, waves done}
-    if (threadIdx.x < 4) wg_acc[threadIdx.x] = 0;
-    __syncthreads();
     if (views) {
         apply_view(s, views[blockIdx.z]); invM = views[blockIdx.z].invM;
         minmax = reinterpret_cast<const float2*>(s.fv_minmax); rays = reinterpret_cast<float4*>(s.fv_raycast);
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     BlockCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
     float sdfValue = 1.0f, confidence = 0.f, stepLength;
     int vmIndex = 0;
-    int n_steps = 0, n_reads = 0;  // castRay steps as the reference counts them / samples this loop actually reads
+    uint32_t n_log = 0;  // S-bar log, packed: trips of this loop (= voxel reads) in the low half, skipped candidates in the high half
     const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
     while (totalLength < totalLengthMax) {
         // Candidate positions: [0] is this step's sample; [1..SKIP] are where the next steps land IF this and the
@@ -404,7 +402,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
         }
         sdfValue = vox_sdf(raw) / 32767.0f;
         if (MODIFY_VISIBLE) { if (vmIndex) s.visible_type[vmIndex - 1] = 1; }  // incl. the vmIndex==1 cache-hit quirk
-        n_reads++;
+        n_log++;
         if (!vmIndex) {
             stepLength = BLK;
             // advance over the candidates that are certainly unallocated steps inside the range (empty bucket head); the
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
                 const bool plain = cl_ < totalLengthMax && !((occupied >> j) & 1u);
                 if (adv == j - 1 && plain) { adv = j; px = cx_; py = cy_; pz = cz_; totalLength = cl_; }
             }
-            n_steps += adv;  // (each skipped candidate is one failed lookup = one step of the reference loop)
+            n_log += (uint32_t)adv << 16;  // (each skipped candidate is one failed lookup = one step of the reference loop)
         } else {
             if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
                 float dummy;
@@ -448,22 +446,34 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
         found = false;
     }
     if (inside) rays[x + y * W] = make_float4(px, py, pz, found ? confidence + 1.0f : 0.0f);
-    // S-bar ("mean steps/ray logged by the kernel"): cumulative 64-bit sums in the counter block -- castRay steps as
-    // the reference's loop counts them (Shared.h:158-190: one per lookup; the free-space look-ahead above folds up to 1 + SKIP of
-    // them into one trip), the trips of THIS loop (= voxel reads), and the rays cast.  One sum per wave (shuffles), the four
-    // waves of a workgroup meet in LDS, the last one to arrive issues the workgroup's three atomics: 3,600 fire-and-forget atomics
-    // per 640x480 launch, spread over the kernel's duration (rays finish at different times).
-    const int wave_steps = wave_sum_i(n_steps + n_reads), wave_reads = wave_sum_i(n_reads), wave_rays = wave_sum_i(inside ? 1 : 0);
-    if (lane_ == 0) {
-        atomicAdd(&wg_acc[0], (uint32_t)wave_steps);
-        atomicAdd(&wg_acc[1], (uint32_t)wave_reads);
-        atomicAdd(&wg_acc[2], (uint32_t)wave_rays);
-        if (atomicAdd(&wg_acc[3], 1u) == 3u) {   // (LDS operations of one wave complete in order: the three sums are whole)
-            unsigned long long* st = reinterpret_cast<unsigned long long*>(s.counters + GPS_TSDF_RAY_STEPS);
-            atomicAdd(st, (unsigned long long)atomicAdd(&wg_acc[0], 0u));
-            atomicAdd(st + 1, (unsigned long long)atomicAdd(&wg_acc[1], 0u));
-            atomicAdd(st + 2, (unsigned long long)atomicAdd(&wg_acc[2], 0u));
-        }
+    // S-bar ("mean steps/ray logged by the kernel"): castRay steps as the reference's loop counts them (Shared.h:158-190:
+    // one per lookup; the free-space look-ahead above folds up to 1 + SKIP of them into one trip), the trips of THIS loop (= voxel
+    // reads) and the rays cast, summed over the wave (swap / DPP adds of small exact floats, no LDS) and stored as this wave's
+    // row: plain stores, no atomics, no zero-fill (an atomic per workgroup on shared counters cost 8 us of the kernel's 115).
+    const float f_reads = (float)(n_log & 0xFFFFu), f_steps = f_reads + (float)(n_log >> 16);
+    const float tot = gps::reduce4(f_steps, f_reads, inside ? 1.0f : 0.0f, 0.0f);   // rows 0..3, lane 15: sums of (steps, rays, reads, 0)
+    if ((lane_ & 15) == 15 && lane_ < 48) {
+        float* row = reinterpret_cast<float*>(ray_stats_rows(s) + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_in_wg));
+        row[lane_ == 15 ? 0 : lane_ == 31 ? 2 : 1] = tot;   // {steps, reads, rays}
+    }
+}
+
+// the rows of the last raycast launch summed into counters[GPS_TSDF_RAY_STEPS / _READS / _RAYS] (three unsigned 64-bit sums)
+__global__ __launch_bounds__(256) void ray_stats_sum_kernel(TsdfState s) {
+    __shared__ double part[3][4];
+    const float4* rows = ray_stats_rows(s);
+    double a[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < ray_stat_waves(s); i += blockDim.x) { const float4 r = rows[i]; a[0] += r.x; a[1] += r.y; a[2] += r.z; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o, 64);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(s.counters + GPS_TSDF_RAY_STEPS);
+        st[threadIdx.x] = (unsigned long long)(part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
     }
 }
 
@@ -722,7 +732,7 @@ int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_exces
     (void)nblk; (void)sw; (void)sh;
     gps_tsdf_state t = {};
     t.width = width; t.height = height; t.n_buckets = n_buckets; t.n_excess = n_excess;
-    return 4 * (scratch_words_before_bits(t) + (n_buckets + 31) / 32 + 16);
+    return 4 * (ray_stats_offset_words(t) + 4 + 4 * (int64_t)ray_stat_waves(t));
 }
 
 static int raycast_impl(const gps_tsdf_state* sp, const float* invM, int free_view, int update_visible, bool reduce_here,
@@ -762,6 +772,15 @@ int gps_tsdf_expected_depths_and_raycast(const gps_tsdf_state* sp, const float* 
     const int r = expected_depths_impl(sp, M, free_view, false, stream);
     return r != GPS_OK ? r : raycast_impl(sp, invM, free_view, update_visible, true, stream);
 #endif
+}
+
+int gps_tsdf_ray_stats(const gps_tsdf_state* sp, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr);
+    GPS_REQUIRE(state_valid(*sp));
+    ray_stats_sum_kernel<<<1, 256, 0, (hipStream_t)stream>>>(*sp);
+    GPS_LAUNCH_CHECK();
+    return GPS_OK;
 }
 
 int gps_tsdf_icp_maps(const gps_tsdf_state* sp, const float* invM, gps_stream stream) {

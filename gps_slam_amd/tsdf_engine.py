@@ -35,7 +35,7 @@ def pose_from_c2w(c2w):
 
 def ray_stats_of(counters):
     """{steps, reads, rays} from a counter block (int32[16] as numpy / tensor): castRay steps as the reference's loop counts
-    them, voxel reads of the kernel's own loop, rays cast -- cumulative since the last reset (S-bar = steps / rays)"""
+    them, voxel reads of the kernel's own loop, rays cast -- of one raycast launch (S-bar = steps / rays)"""
     c = np.ascontiguousarray(np.asarray(counters, dtype=np.int32)[10:16]).view(np.uint64)
     return {"steps": int(c[0]), "reads": int(c[1]), "rays": int(c[2])}
 
@@ -276,7 +276,9 @@ class TsdfEngine:
         return self.counters.cpu().numpy()
 
     def ray_stats(self):
-        """cumulative ray statistics of the live raycaster (include/gps_slam_hip.h GPS_TSDF_RAY_STEPS): see ray_stats_of"""
+        """ray statistics of the LAST raycast launch on this scene (live, or a single free view): gps_tsdf_ray_stats sums the
+        raycaster's per-wave rows into the counter block, see ray_stats_of (blocking read-back: measurement only)"""
+        check(lib.gps_tsdf_ray_stats(C.byref(self.state), self._stream()), "gps_tsdf_ray_stats")
         return ray_stats_of(self.counters_host())
 
     def hash_host(self):

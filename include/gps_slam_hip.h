@@ -495,10 +495,11 @@ enum {
     GPS_TSDF_SCRATCH0 = 6,
     GPS_TSDF_SCRATCH1 = 7,
     GPS_TSDF_SCRATCH2 = 8,         /* rendering blocks of the CreateExpectedDepths in flight (published to [4], then cleared) */
-    /* ray statistics of gps_tsdf_raycast (S-bar, the mean steps per ray): three CUMULATIVE unsigned 64-bit sums in
-     * words [10..15] -- castRay steps as the reference's loop counts them (ITMVisualisationEngine_Shared.h:158-190), voxel
-     * reads of the kernel's own loop (it folds runs of unallocated steps into one trip), rays cast.  A free view of a batch logs
-     * into the view's own counter block.  Cleared by gps_tsdf_reset only: take differences. */
+    /* ray statistics (S-bar, the mean steps per ray): three unsigned 64-bit sums in words [10..15] -- castRay steps
+     * as the reference's loop counts them (ITMVisualisationEngine_Shared.h:158-190), voxel reads of the kernel's own loop (it folds
+     * runs of unallocated steps into one trip), rays cast -- of the LAST raycast launch on the scene's scratch (live or single free
+     * view).  The raycaster writes one row per wave into the scratch area (plain stores); gps_tsdf_ray_stats() sums the rows
+     * into these words on demand (measurement only). */
     GPS_TSDF_RAY_STEPS = 10,
     GPS_TSDF_RAY_READS = 12,
     GPS_TSDF_RAYS = 14,
@@ -583,6 +584,9 @@ GPS_API int gps_tsdf_expected_depths_and_raycast(const gps_tsdf_state *s, const 
 
 /* renderICP_device<false> with smoothing (ITMVisualisationHelpers_CUDA.h:71-81, Shared:438-480) on the live raycast */
 GPS_API int gps_tsdf_icp_maps(const gps_tsdf_state *s, const float *invM, gps_stream stream);
+/* counters[GPS_TSDF_RAY_STEPS / _READS / _RAYS] := the ray statistics of the last raycast launch on this scene's scratch
+ * (one short launch; measurement only -- bench.py prices the raycaster's ray term with them) */
+GPS_API int gps_tsdf_ray_stats(const gps_tsdf_state *s, gps_stream stream);
 
 /* ITMVisualisationEngine::FindVisibleBlocks for a free view (…_CUDA.tcu:77-92, buildCompleteVisibleList_device) */
 GPS_API int gps_tsdf_find_visible(const gps_tsdf_state *s, const float *M, gps_stream stream);
