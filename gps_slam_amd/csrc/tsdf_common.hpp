@@ -51,7 +51,7 @@ static inline uint32_t* bucket_bits(const gps_tsdf_state& s) {
 // behind the bitmap (+ 16 words of pad): the ray statistics of the LAST raycast launch on this scratch, one {castRay steps,
 // voxel reads, rays, 0} quadruple of floats per wave of that launch, written with plain stores (no atomics, no zero-fill;
 // gps_tsdf_ray_stats sums them into counters[GPS_TSDF_RAY_STEPS..] on demand)
-__host__ __device__ inline int ray_stat_waves(const gps_tsdf_state& s) { return ((s.width + 15) / 16) * ((s.height + 15) / 16) * 4; }
+__host__ __device__ inline int ray_stat_waves(const gps_tsdf_state& s) { return ((s.width + 7) / 8) * ((s.height + 7) / 8) * 4; }  // (room for 4 x 4 pixel waves)
 __host__ __device__ inline int64_t ray_stats_offset_words(const gps_tsdf_state& s) {
     const int64_t n_total = (int64_t)s.n_buckets + s.n_excess;
     const int64_t nblk = (n_total + 1023) / 1024;

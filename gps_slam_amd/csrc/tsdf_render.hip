@@ -142,7 +142,15 @@ GPS_TUNABLE_REPORT(GPS_RAYCAST_SKIP, 5);
 #ifdef GPS_ED_REDUCE_LAUNCH   // (probe builds: pass B of the expected depths as its own launch)
 GPS_SWITCH_REPORT(GPS_ED_REDUCE_LAUNCH);
 #endif
-constexpr int SKIP = GPS_RAYCAST_SKIP;  // free-space look-ahead of the raycaster, 1..31
+constexpr int SKIP = GPS_RAYCAST_SKIP;
+#ifndef GPS_RAYCAST_RAYS_PER_WAVE
+#define GPS_RAYCAST_RAYS_PER_WAVE 64
+#endif
+GPS_TUNABLE_REPORT(GPS_RAYCAST_RAYS_PER_WAVE, 64);
+// pixels a wave's rays cover: 8 x 8 (one cell of the min/max image), 8 x 4 or 4 x 4 (fewer rays per wave: less divergence between
+// the lanes of a wave, more waves; the patch stays inside one min/max cell)
+constexpr int RC_PW = GPS_RAYCAST_RAYS_PER_WAVE >= 32 ? 8 : 4, RC_PH = GPS_RAYCAST_RAYS_PER_WAVE >= 64 ? 8 : 4;
+static_assert(GPS_RAYCAST_RAYS_PER_WAVE == 64 || GPS_RAYCAST_RAYS_PER_WAVE == 32 || GPS_RAYCAST_RAYS_PER_WAVE == 16, "rays per wave");  // free-space look-ahead of the raycaster, 1..31
 
 __device__ __forceinline__ int floor_div_blk(int v) { return v >> 3; }  // floor(v / 8): arithmetic shift (BLK == 8)
 
@@ -286,10 +294,13 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     // one wave64 = one 8x8 pixel patch = exactly one cell of the 1/8-resolution min/max image: all 64 rays share their
     // [min, max] range, so their free-space runs and step counts stay close (a 16x4 strip straddles two cells)
     const int wave_in_wg = threadIdx.x >> 6, lane_ = threadIdx.x & 63;
-    const int x = blockIdx.x * 16 + (wave_in_wg & 1) * 8 + (lane_ & 7), y = blockIdx.y * 16 + (wave_in_wg >> 1) * 8 + (lane_ >> 3);
+    // RC_PW x RC_PH pixels per wave (GPS_RAYCAST_RAYS_PER_WAVE rays; lanes beyond them idle), 2 x 2 waves per workgroup
+    const int wave_x0 = blockIdx.x * (2 * RC_PW) + (wave_in_wg & 1) * RC_PW, wave_y0 = blockIdx.y * (2 * RC_PH) + (wave_in_wg >> 1) * RC_PH;
+    const int x = wave_x0 + (lane_ % RC_PW), y = wave_y0 + (lane_ / RC_PW);
+    const bool ray_lane = lane_ < RC_PW * RC_PH;
     float2 mm_cell = make_float2(0.f, 0.f);
     if (partial) {   // (before the early return: every lane of the wave takes part)
-        const int cell_x = (blockIdx.x * 16 + (wave_in_wg & 1) * 8) / MINMAX_SUB, cell_y = (blockIdx.y * 16 + (wave_in_wg >> 1) * 8) / MINMAX_SUB;
+        const int cell_x = wave_x0 / MINMAX_SUB, cell_y = wave_y0 / MINMAX_SUB;
         uint32_t lo = __float_as_uint(FAR_AWAY), hi = __float_as_uint(VERY_CLOSE);
         if (cell_x < sw && cell_y < sh) {
             for (int g = lane_; g < ED_GROUPS; g += 64) {
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64)); }
         mm_cell = make_float2(__uint_as_float(lo), __uint_as_float(hi));
-        const bool first_pixel_inside = (int)(blockIdx.x * 16 + (wave_in_wg & 1) * 8) < s.width && (int)(blockIdx.y * 16 + (wave_in_wg >> 1) * 8) < s.height;
+        const bool first_pixel_inside = wave_x0 < s.width && wave_y0 < s.height;
         if (lane_ == 0 && first_pixel_inside) mm_out[cell_x + cell_y * s.width] = mm_cell;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // pass A of this call is complete (stream order)
             s.counters[GPS_TSDF_RENDER_BLOCKS] = s.counters[GPS_TSDF_SCRATCH2];
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     }
     // Lanes outside the image stay in the wave with an empty range (no loop trip, no store): the step statistics below are summed
     // with cross-lane operations that every lane takes part in.
-    const bool inside = x < s.width && y < s.height;
+    const bool inside = ray_lane && x < s.width && y < s.height;
     const int W = s.width;
     const int loc2 = (int)floorf((float)x / MINMAX_SUB) + (int)floorf((float)y / MINMAX_SUB) * W;
     const float2 mm = !inside ? make_float2(0.f, 0.f) : partial ? mm_cell : minmax[loc2];
@@ -463,7 +474,8 @@ __global__ __launch_bounds__(256) void ray_stats_sum_kernel(TsdfState s) {
     __shared__ double part[3][4];
     const float4* rows = ray_stats_rows(s);
     double a[3] = {0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < ray_stat_waves(s); i += blockDim.x) { const float4 r = rows[i]; a[0] += r.x; a[1] += r.y; a[2] += r.z; }
+    const int n_rows = ((s.width + 2 * RC_PW - 1) / (2 * RC_PW)) * ((s.height + 2 * RC_PH - 1) / (2 * RC_PH)) * 4;   // waves of one raycast launch
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) { const float4 r = rows[i]; a[0] += r.x; a[1] += r.y; a[2] += r.z; }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
 #pragma unroll
@@ -681,7 +693,7 @@ int gps_tsdf_free_raycast_batch(const gps_tsdf_state* sp, int n_views, const gps
     const Mat4 none = {};
     expected_depths_partial_kernel<<<dim3(ED_GROUPS, 1, n_views), ED_THREADS, lds, st>>>(s, none, nullptr, GPS_TSDF_N_VISIBLE_FREE, sw,
                                                                                      sh, nullptr, tab);
-    const dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16), n_views);
+    const dim3 grid(gps_div_up(s.width, 2 * RC_PW), gps_div_up(s.height, 2 * RC_PH), n_views);   // (the raycaster's)
 #ifdef GPS_ED_REDUCE_LAUNCH
     expected_depths_reduce_kernel<<<dim3(gps_div_up(sw * sh, 256), 1, n_views), 256, 0, st>>>(s, sw, sh, ED_GROUPS, nullptr, nullptr, tab);
     raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, 0, 0, nullptr);
@@ -689,7 +701,7 @@ int gps_tsdf_free_raycast_batch(const gps_tsdf_state* sp, int n_views, const gps
     // (pass B of the expected depths rides in the raycaster)
     raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, sw, sh, nullptr);
 #endif
-    colour_kernel<<<grid, 256, 0, st>>>(s, nullptr, nullptr, tab);
+    colour_kernel<<<dim3(gps_div_up(s.width, 16), gps_div_up(s.height, 16), n_views), 256, 0, st>>>(s, nullptr, nullptr, tab);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -740,7 +752,7 @@ static int raycast_impl(const gps_tsdf_state* sp, const float* invM, int free_vi
     GPS_REQUIRE(sp != nullptr && invM != nullptr);
     GPS_REQUIRE(state_valid(*sp));
     TsdfState s = *sp;
-    dim3 grid(gps_div_up(s.width, 16), gps_div_up(s.height, 16));
+    dim3 grid(gps_div_up(s.width, 2 * RC_PW), gps_div_up(s.height, 2 * RC_PH));
     float2* mm = reinterpret_cast<float2*>(free_view ? s.fv_minmax : s.minmax);
     float4* rays = reinterpret_cast<float4*>(free_view ? s.fv_raycast : s.raycast);
     const int sw = s.width / MINMAX_SUB + 2, sh = s.height / MINMAX_SUB + 2;
