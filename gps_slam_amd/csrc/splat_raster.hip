@@ -146,7 +146,7 @@ extern "C" GPS_API void* gps_fwd_stamps() { void* p = nullptr; (void)hipGetSymbo
 // History of the inner loop (bench scene, 1,200 tiles, ~500 k list entries):
 //   round 1   every entry evaluated for every pixel                                                   81.6 us
 //   round 2   wave-uniform skip in the loop (test e > 8 for all 128 pixels, ballot, branch)             55 us   (list in 4 parts)
-//   round 3   cull at staging time, then blend survivors only (below)                                   see DESIGN.md
+//   round 3   cull at staging time, then blend survivors only (below)                                   see LABBOOK.md section 4
 // The round-2 loop was bound by its own dependent chain per entry: LDS read -> 10 VALU -> ballot -> branch -> exp -> blend, ~400
 // cycles per entry for a lone wave (tools/probe/fwd_stamps.py), with a third of the issue slots used.  Now the staging thread of an
 // entry tests the entry's pixel bounds (pack_record: a conservative box around {alpha >= 1/255}; outside it the entry adds exact

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void track_prepare_kernel(PrepArgs a) {
 // The same for pyramids of up to 5 levels (coarsest pixel <= 16 x 16 full-resolution pixels; the default "rrbb" has 4): one
 // workgroup per 16 x 16 tile, thread = pixel.  Level 0 goes through LDS once (row-coalesced loads), every level above is
 // computed from the LDS copy of the level below by the first (16 >> l)^2 threads -- the first version gave each THREAD a whole
-// coarsest-level block and walked it with strided loads (25 us; this one: see DESIGN.md).
+// coarsest-level block and walked it with strided loads (25 us; this one: see LABBOOK.md section 4).
 __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
     GPS_FRAME_PRIO();
     __shared__ float lv[2][16 * 16];

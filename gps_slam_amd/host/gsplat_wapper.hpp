@@ -64,7 +64,7 @@ struct RasterizeToPixelsGes : public torch::autograd::Function<RasterizeToPixels
 // isect_offsets, flatten_ids, absgrad) -> {render_colors[1,H,W,4], render_alphas[1,H,W,1]}.  As in the reference the
 // backward runs WITHOUT the backgrounds (gsplat_wapper.hpp:307-315 passes an empty optional) and v_backgrounds is the
 // sum of v_render_colors * (1 - render_alphas).  masks throw (never used); absgrad computes v_means2d_abs, which the
-// reference discards (:323-326 overwrites means2d with |means2d| instead -- not reproduced).
+// reference discards (:323-326 overwrites means2d with |means2d| instead -- not reproduced, see LABBOOK.md).
 struct RasterizeToPixels : public torch::autograd::Function<RasterizeToPixels> {
     static torch::autograd::tensor_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor means2d,
                                                 torch::Tensor conics, torch::Tensor colors, torch::Tensor opacities,

@@ -279,7 +279,7 @@ def test_grid_knn_equals_the_brute_force_on_awkward_sets(case):
 def test_add_gaussians_samples_masked_pixels_and_appends(which):
     """slam_gs_model.cpp:5-56: masked_select of vertex / colour / normal maps, a random subset of floor(n * ratio) of them,
     init(), append after the existing Gaussians.  With ratio 1 the subset is everything -> fully deterministic comparison
-    (this repository appends the subset in pixel order); with ratio 0.25 the count and membership are checked."""
+    (this repository appends the subset in pixel order, LABBOOK.md section 4 "Order of new Gaussians"); with ratio 0.25 the count and membership are checked."""
     h = _host()
     H, W = 48, 64
     gen = torch.Generator().manual_seed(3)
