@@ -93,6 +93,23 @@ static void quat_scale_to_covar(const float *q, const float *s, float *covar) {
     m3_mul(M, Mt, covar);
 }
 
+/* The two sub-steps above as entry points of their own: the reference's Python holds independent statements of exactly these
+ * (scripts/utils/general_utils.py:78-110 build_rotation / build_scaling_rotation), which pin them by reference output
+ * (tests/golden/refpy_quat_covar.npz, tests/test_reference_python_pin.py).  R row-major [N,9], covar row-major [N,9];
+ * v_quats from a given dL/dR (row-major) through quat_to_rotmat_vjp. */
+ORC_API void orc_quat_to_rotmat(int N, const float *quats, float *R) {
+    for (int i = 0; i < N; i++) quat_to_rotmat(quats + 4 * i, R + 9 * i);
+}
+ORC_API void orc_quat_scale_to_covar(int N, const float *quats, const float *scales, float *covars) {
+    for (int i = 0; i < N; i++) quat_scale_to_covar(quats + 4 * i, scales + 3 * i, covars + 9 * i);
+}
+ORC_API void orc_quat_to_rotmat_vjp(int N, const float *quats, const float *v_R, float *v_quats) {
+    for (int i = 0; i < N; i++) {
+        for (int k = 0; k < 4; k++) v_quats[4 * i + k] = 0.f;
+        quat_to_rotmat_vjp(quats + 4 * i, v_R + 9 * i, v_quats + 4 * i);
+    }
+}
+
 /* utils.cuh:253-292  pinhole projection of mean + covariance, with fov clamp */
 static void persp_proj(const float *mc, const float *cov3, float fx, float fy, float cx, float cy, uint32_t W,
                        uint32_t H, float *cov2 /*[4] row-major 2x2*/, float *m2) {

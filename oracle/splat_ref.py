@@ -52,6 +52,30 @@ def proj_fwd(means, quats, scales, viewmat, K, W, H, eps2d=0.3, near=0.01, far=1
     return radii, means2d, depths, conics
 
 
+def quat_to_rotmat(quats):
+    """orc_quat_to_rotmat (utils.cuh:14-36): [N,4] (w, x, y, z; normalised inside) -> [N,3,3] row-major"""
+    quats = _f32(quats)
+    R = np.zeros((quats.shape[0], 3, 3), np.float32)
+    _lib().orc_quat_to_rotmat(C.c_int(quats.shape[0]), _p(quats), _p(R))
+    return R
+
+
+def quat_scale_to_covar(quats, scales):
+    """orc_quat_scale_to_covar (utils.cuh:64-96): (R S)(R S)^T -> [N,3,3]"""
+    quats, scales = _f32(quats), _f32(scales)
+    cov = np.zeros((quats.shape[0], 3, 3), np.float32)
+    _lib().orc_quat_scale_to_covar(C.c_int(quats.shape[0]), _p(quats), _p(scales), _p(cov))
+    return cov
+
+
+def quat_to_rotmat_vjp(quats, v_R):
+    """orc_quat_to_rotmat_vjp (utils.cuh:38-62): dL/dR [N,3,3] row-major -> dL/dq [N,4]"""
+    quats, v_R = _f32(quats), _f32(v_R)
+    vq = np.zeros((quats.shape[0], 4), np.float32)
+    _lib().orc_quat_to_rotmat_vjp(C.c_int(quats.shape[0]), _p(quats), _p(v_R), _p(vq))
+    return vq
+
+
 def proj_bwd(means, quats, scales, viewmat, K, W, H, radii, conics, v_means2d, v_depths, v_conics):
     means, quats, scales, viewmat, K, conics = map(_f32, (means, quats, scales, viewmat, K, conics))
     v_means2d, v_depths, v_conics = map(_f32, (v_means2d, v_depths, v_conics))
