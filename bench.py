@@ -411,7 +411,7 @@ def other_configs(args, seq, seed, device, first):
       configs[0]  TSDF-only `recon` loop with given poses, HIP engine (the cpu_baseline's counterpart)
       configs[1]  640x480, use_gt_pose=true, ~100 k Gaussians: frames/s of the loop and optimise iterations/s (fwd + L1 + bwd + Adam)
       configs[3]  1280x720 (Azure Kinect intrinsics), tracking on, ~400 k Gaussians: both schedules, its own roofline units"""
-    from bench_kernels import fusion_split, iteration_bytes
+    from bench_kernels import config_units, fusion_split
     t_all = time.perf_counter()
     K, NW = 20, 3
     res = {"note": "N = 1, after the headline windows, same box; %d windows x %d steps per schedule, median; timed step 0 is frame %d "
@@ -440,10 +440,11 @@ def other_configs(args, seq, seed, device, first):
     ev1.record()
     torch.cuda.synchronize()
     it_s = ev0.elapsed_time(ev1) * 1e-3 / 50
+    roof1 = config_units(sc, seq, 1000.0 / r1["overlap"]["frames_per_s"], HBM_PEAK_GBS)
     sc.close()
     del sc
     torch.cuda.empty_cache()
-    res["configs1_gt_pose_100k"] = {"size": "%dx%d" % (seq["W"], seq["H"]), "schedules": r1, "frames_per_s": r1["overlap"]["frames_per_s"],
+    res["configs1_gt_pose_100k"] = {"roofline": roof1, "size": "%dx%d" % (seq["W"], seq["H"]), "schedules": r1, "frames_per_s": r1["overlap"]["frames_per_s"],
                                     "iterations_per_s": 1.0 / it_s, "iteration_us": it_s * 1e6,
                                     "what": "use_gt_pose=true (tracker off), ~100 k Gaussians; iterations = forward + L1 + backward + fused Adam "
                                             "of one optimise camera, 50 back-to-back (HIP events)",
@@ -457,10 +458,11 @@ def other_configs(args, seq, seed, device, first):
     seeds3 = seed_gaussians(seq3, 400000, seed, device)
     r3, sc = _time_scene(lambda ov: Scene(seq3, seeds3, seed, False, overlap=ov, n_frames=n3, **kf), first, K, NW)
     st = dict(sc.pipe.stats())
+    roof3 = config_units(sc, seq3, 1000.0 / r3["overlap"]["frames_per_s"], HBM_PEAK_GBS)
     sc.close()
     del sc
     torch.cuda.empty_cache()
-    res["configs3_720p_400k"] = {"size": "%dx%d" % (W3, H3), "schedules": r3, "frames_per_s": r3["overlap"]["frames_per_s"],
+    res["configs3_720p_400k"] = {"roofline": roof3,"size": "%dx%d" % (W3, H3), "schedules": r3, "frames_per_s": r3["overlap"]["frames_per_s"],
                                  "what": "Azure-Kinect-like 720p intrinsics (fx = fy = 605), depth ICP tracking + TSDF fuse + ges splat optimise, "
                                          "~400 k Gaussians", "pipeline_stats": {k: int(v) for k, v in st.items()},
                                  "input_render_seconds": t_gen, "seconds": time.perf_counter() - t0}

@@ -285,6 +285,37 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
                     "fraction is small by construction and is reported because it is the contract's yardstick"}
 
 
+def config_units(scene, seq, ms_per_step, hbm_peak_gbs, with_tracking_bytes=True):
+    """Roofline units of ONE extra configuration (bench.other_configs): the scene's own N, Nv, I, G, P, T, V after its timed
+    windows (Python twin of the model: one train step on the last optimise camera; the engine's counters), the algorithmic
+    bytes of an optimise iteration and of a frame (the frame without the ray term -- S-bar is logged on the
+    headline configuration), a live iteration time (20 back-to-back steps, HIP events) and the two HBM fractions."""
+    device = "cuda:%d" % torch.cuda.current_device()
+    model, cam, rc = _python_twin(scene, device)
+    model.initOptimizers(-1, 1.0)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
+    step()
+    torch.cuda.synchronize()
+    B, st = model._B, model._step
+    counts = B["counts"].cpu().tolist()
+    ni, nvis = int(counts[0]), int(counts[3])
+    W, H, N = st.width, st.height, st.N
+    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    r = B["radii"][:N].long()
+    ng = int(((4 * r * r + 31) // 32)[r > 0].sum())
+    V = int(scene.engine.counters().cpu()[2])
+    t_iter = _time_launches(step, 20, stream)
+    b_iter, _ = iteration_bytes(N, nvis, ni, ng, P, T)
+    b_frame = 2.0 * b_iter + fusion_bytes(P, V, 0x100000 + 0x20000)
+    t_frame = ms_per_step * 1e-3
+    return {"units": {"gaussians": N, "n_visible": nvis, "n_isects": ni, "n_groups": ng, "pixels": P, "tiles": T, "visible_blocks": V},
+            "iteration": {"algorithmic_bytes": b_iter, "avg_us": t_iter * 1e6, "frac": b_iter / t_iter / 1e9 / hbm_peak_gbs},
+            "frame": {"algorithmic_bytes": b_frame, "ms": ms_per_step, "frac": b_frame / t_frame / 1e9 / hbm_peak_gbs}}
+
+
 def _fusion_timings(seq, gt_pose, device, n_sub=12):
     """TSDF side of the roofline section on a Python twin engine fed the LAST n_sub frames of the sequence (re-based to their
     first camera): live durations of integrate_kernel and raycast_kernel (HIP events, 20 launches), the untracked and tracked
