@@ -63,13 +63,14 @@ def test_fused_iteration_matches_autograd_of_operator_chain(W, H):
     assert torch.equal(res["radiis"], out["radiis"])
 
 
-def test_fused_iteration_above_4096_tiles_takes_the_sorted_key_route_and_matches_autograd():
-    """More than SB_MAX_TILES (4,096) tiles: the superblock binning's LDS histograms do not cover the tile ids, so the fused step
-    must fall back to the sorted-key binning + group backward (splat_step.hip: strips_on) with the strip buffers still allocated --
-    same gradients as autograd through the operator chain, and the same step as a model built without the strip buffers."""
+@pytest.mark.parametrize("W,H", [(1600, 720), (4112, 48)], ids=["4500-tiles", "257-tiles-wide"])
+def test_fused_iteration_outside_the_superblock_binnings_limits_takes_the_sorted_key_route_and_matches_autograd(W, H):
+    """What gps::sb_supported() rejects must run, not fail: more than SB_MAX_TILES (4,096) tiles (100 x 45) -- the LDS histograms
+    do not cover the tile ids -- or a grid more than 255 tiles wide (257 x 3: the scatter packs a box's width into 8 bits).  The
+    fused step falls back to the sorted-key binning + group backward (splat_step.hip: strips_on) with the strip buffers still
+    allocated -- same gradients as autograd through the operator chain, and the same step as a model built without the strip buffers."""
     from gps_slam_amd import gsplat_wapper as gw
     from gps_slam_amd.gs_model import SLAMGaussianModel
-    W, H = 1600, 720   # 100 x 45 = 4,500 tiles
     model, cam, ref, base, gt = _model_and_maps(N=20000, W=W, H=H, seed=11)
     p = model.opt_gs_params
     leaves = [t.clone().requires_grad_(True) for t in (p.means, p.scales, p.quats, p.featuresDc, p.featuresRest, p.opacities)]
