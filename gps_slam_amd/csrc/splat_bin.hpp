@@ -57,6 +57,7 @@ struct SbTables {
     int32_t* cls_count;    // [BWD_KEYS][SB_MAX] Gaussians per (class, band) and superblock (zero between launches)
     int32_t* cls_prefix;   // [BWD_KEYS][SB_MAX] exclusive prefixes over superblocks, then a row of the BWD_KEYS totals
     int sb_shift;          // log2(preprocessing workgroups per superblock)
+    int32_t* tile_order;   // [SB_MAX_TILES] the tiles by descending list length (sb_scatter's extra workgroup): the forward rasterizer's launch order
 };
 // splat_bin_sb.hip: can the superblock binning take N Gaussians on a tile_width x tile_height grid on THIS device (tile count,
 // packed box fields, superblock count, the scatter kernel's dynamic LDS incl. its > 64 KB opt-in)?  False -> sorted-key binning.
@@ -114,7 +115,7 @@ struct FwdCompose {
 // splat_raster.hip
 int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_depth_map, int width, int height,
                               const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts, float delta_depth,
-                              float* render_colors, float* render_alphas, const FwdCompose* compose, gps_stream stream);
+                              float* render_colors, float* render_alphas, const FwdCompose* compose, gps_stream stream, const int32_t* tile_order = nullptr);
 // gps_raster_ges_bwd_gs with zero_mode: 0 zero-fill here, 1 accumulate onto the buffers, 2 the buffers are already zero
 int raster_ges_bwd_gs_launch(int N, const float* means2d, const float* conics, const float* colors, const float* opacities,
                              const int32_t* radii, const float* ref_depth_map, int width, int height,

@@ -89,6 +89,26 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     int32_t* __restrict__ cls_counts, int64_t cls_stride) {
     extern __shared__ uint32_t lds[];
     const int n_tiles = tw * th;
+    if (blockIdx.x == gridDim.x - 1) {
+        // The extra workgroup: the forward rasterizer's launch order = tiles by descending list length (a counting sort over 64
+        // length classes; the order inside a class does not matter).  1,200 tiles are 1.2 rounds of the 1,024 tile workgroups the
+        // chip holds: with the longest lists first, the part-filled second round is the short ones.
+        __shared__ int hist[64];
+        const int tid_ = threadIdx.x;
+        if (tid_ < 64) hist[tid_] = 0;
+        __syncthreads();
+        for (int b = tid_; b < n_tiles; b += SCAT_THREADS) atomicAdd(&hist[63 - min(63, (int)(t.tile_total[b] >> 5))], 1);
+        __syncthreads();
+        if (tid_ < 64) {
+            const int v = hist[tid_];
+            int total;
+            const int ex = wave_excl_scan_i(v, total);
+            hist[tid_] = ex;
+        }
+        __syncthreads();
+        for (int b = tid_; b < n_tiles; b += SCAT_THREADS) t.tile_order[atomicAdd(&hist[63 - min(63, (int)(t.tile_total[b] >> 5))], 1)] = b;
+        return;
+    }
     const int sb = blockIdx.x, sb_size = BIN_BLOCK << t.sb_shift;        // Gaussians per superblock
     uint32_t* base = lds;                                                 // [n_tiles] absolute start of this superblock's run in a tile
     uint16_t* wavecnt = reinterpret_cast<uint16_t*>(lds + n_tiles);       // [SCAT_WAVES][n_tiles] per-wave running counts of a chunk
@@ -307,7 +327,7 @@ bool sb_supported(int N, int tile_width, int tile_height) {
 }
 
 size_t sb_tables_bytes() {
-    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 + (size_t)(SB_MAX + 1) * BWD_KEYS * 4 * 2 + 2048;
+    return (size_t)SB_MAX_TILES * SB_MAX * 4 * 2 + (size_t)SB_MAX_TILES * 4 * 2 + (size_t)(SB_MAX + 1) * BWD_KEYS * 4 * 2 + 2048;
 }
 
 // the tables back to "zero between launches" (after a failed launch of the preprocessing kernel or a rejected binning call)
@@ -326,6 +346,7 @@ void sb_tables_carve(char* base, SbTables* t) {
     t->tile_total = (uint32_t*)take((size_t)SB_MAX_TILES * 4);
     t->cls_count = (int32_t*)take((size_t)(SB_MAX + 1) * BWD_KEYS * 4);
     t->cls_prefix = (int32_t*)take((size_t)(SB_MAX + 1) * BWD_KEYS * 4);
+    t->tile_order = (int32_t*)take((size_t)SB_MAX_TILES * 4);
     t->sb_shift = 0;
 }
 
@@ -349,7 +370,7 @@ int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, co
     const int n_sb = (nblk + (1 << cnt.sb.sb_shift) - 1) >> cnt.sb.sb_shift;
     sb_scan_kernel<<<gps_div_up(n_tiles + BWD_KEYS, 4), 256, 0, s>>>(n_tiles, cnt.sb);
     const size_t lds = sb_scatter_lds_bytes(N, n_tiles);
-    sb_scatter_kernel<<<n_sb, SCAT_THREADS, lds, s>>>(N, means2d, radii, tiles_per_gauss, cnt.tile_size, cnt.tw, cnt.th, cnt.sb,
+    sb_scatter_kernel<<<n_sb + 1, SCAT_THREADS, lds, s>>>(N, means2d, radii, tiles_per_gauss, cnt.tile_size, cnt.tw, cnt.th, cnt.sb,
                                                      isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_counts, cls_stride);
     GPS_LAUNCH_CHECK();
     return GPS_OK;

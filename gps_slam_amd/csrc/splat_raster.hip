@@ -170,7 +170,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
-    float* __restrict__ render_alphas, gps::FwdCompose fc) {
+    float* __restrict__ render_alphas, gps::FwdCompose fc, const int32_t* __restrict__ tile_order) {
     // 48-byte records {mx, my, 0.5*ca*log2e, cb*log2e | 0.5*cc*log2e, -log2(opac), depth, r | g, b, -, -}; after the last batch the
     // same memory carries the parts' partial sums
     constexpr int PART_FLOATS = (FWD_SPLIT - 1) * 128 * 10;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     __shared__ uint16_t sidx[2][FWD_BATCH];    // per pixel half: the batch's surviving entries (record byte offsets / 16), list order
     __shared__ int scnt[2][FWD_SEGS];          // survivors per staging wave
     FWD_STAMP(0);
-    const int tile_id = blockIdx.x;
+    const int tile_id = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;   // (longest lists first when the binning provides the order)
     const int ty = tile_id / tw, tx = tile_id - ty * tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: loop bounds below)
     const int list_part = wave >> 1, pix_half = wave & 1;
@@ -565,7 +565,8 @@ namespace gps {
 
 int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_depth_map, int width, int height,
                               const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts, float delta_depth,
-                              float* render_colors, float* render_alphas, const FwdCompose* compose, gps_stream stream) {
+                              float* render_colors, float* render_alphas, const FwdCompose* compose, gps_stream stream,
+                              const int32_t* tile_order) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0);
     GPS_REQUIRE(ref_depth_map && tile_offsets && flatten_ids && counts && render_colors && render_alphas);
@@ -578,7 +579,7 @@ int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_dept
     const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
     raster_ges_fwd_pk_kernel<<<tw * th, FWD_THREADS, 0, (hipStream_t)stream>>>(
         (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
-        (float4*)render_colors, render_alphas, fc);
+        (float4*)render_colors, render_alphas, fc, tile_order);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 cp gps_slam_amd/libgpsslam_hip.so /tmp/libgps_shipped.so
 for i in $(seq 1 $ROUNDS); do for v in $NAMES; do
   cp tools/probe/libgps_$v.so gps_slam_amd/libgpsslam_hip.so
-  timeout 300 python bench.py --steps 20 --warmup 5 --windows 5 --no-cpu-baseline --no-oracle-psnr > gpurun_out/abn_${v}_$i.log 2>&1
+  timeout 300 python bench.py --steps 20 --warmup 5 --windows 5 --no-cpu-baseline --no-oracle-psnr --no-other-configs > gpurun_out/abn_${v}_$i.log 2>&1
 done; done
 cp /tmp/libgps_shipped.so gps_slam_amd/libgpsslam_hip.so
 NAMES="$NAMES" ROUNDS=$ROUNDS python - <<'PY'
