@@ -149,9 +149,12 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     ptr = lambda t: C.c_void_p(t.data_ptr())
     strips = "v_rows" in B
 
+    # (the fused step deals the tile workgroups by descending list length: the order the superblock binning left in the workspace)
+    order = C.c_void_p(lib.gps_isect_workspace_tile_order(ptr(B["workspace"]), N, st.isect_capacity)) if strips else C.c_void_p(0)
+
     def fwd():  # the forward the fused step launches (packed-math kernel over the preprocess records), without the compose epilogue
-        lib.gps_raster_ges_fwd_rec(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]),
-                                   ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), sp)
+        lib.gps_raster_ges_fwd_rec_ordered(N, ptr(B["records"]), ptr(ref), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]),
+                                           ptr(B["counts"]), model.delta_depth, ptr(B["render_colors"]), ptr(B["weight_sum"]), order, sp)
 
     def bwd():
         if strips:

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "gps_gauss_preprocess_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32,
                                        i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_raster_ges_fwd_rec": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp]),
+    "gps_raster_ges_fwd_rec_ordered": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
+    "gps_isect_workspace_tile_order": (vp, [vp, i32, i64]),
     "gps_gauss_preprocess_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_gauss_preprocess_bwd_adam": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp,

@@ -527,6 +527,15 @@ int64_t gps_isect_workspace_bytes(int N, int64_t isect_capacity) {
     return (int64_t)carve(nullptr, nullptr, N, isect_capacity);
 }
 
+const int32_t* gps_isect_workspace_tile_order(void* workspace, int N, int64_t isect_capacity) {
+    if (!workspace || N < 0 || isect_capacity <= 0) return nullptr;
+    Workspace w;
+    carve(&w, (char*)workspace, N, isect_capacity);
+    gps::SbTables t;
+    gps::sb_tables_carve(w.sb_region, &t);
+    return t.tile_order;
+}
+
 int gps_isect_workspace_init(void* workspace, int64_t workspace_bytes, gps_stream stream) {
     GPS_REQUIRE(workspace && workspace_bytes > 0);
     return hipMemsetAsync(workspace, 0, (size_t)workspace_bytes, (hipStream_t)stream) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;

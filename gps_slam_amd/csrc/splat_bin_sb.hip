@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t) {
 
 // ---- one workgroup per superblock: stable scatter of its (Gaussian, tile) pairs + the backward's class lists ----
 // Everything that is "per tile" runs over the band of tile rows the superblock's boxes touch (consecutive Gaussians cover
-// neighbouring pixels, so the band is a few rows of the tile grid, not all of it); workgroup 0 takes the whole grid because it
-// also writes tile_offsets.
+// neighbouring pixels, so the band is a few rows of the tile grid, not all of it); what concerns the whole grid -- tile_offsets,
+// the counts, the forward rasterizer's launch order -- is the extra (last) workgroup's.
 __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const int32_t* __restrict__ tiles_per_gauss,
     int tile_size, int tw, int th, SbTables t, int64_t isect_cap, int32_t* __restrict__ flatten_ids,
@@ -90,19 +90,49 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     extern __shared__ uint32_t lds[];
     const int n_tiles = tw * th;
     if (blockIdx.x == gridDim.x - 1) {
-        // The extra workgroup: the forward rasterizer's launch order = tiles by descending list length (a counting sort over 64
-        // length classes; the order inside a class does not matter).  1,200 tiles are 1.2 rounds of the 1,024 tile workgroups the
-        // chip holds: with the longest lists first, the part-filled second round is the short ones.
+        // The extra workgroup does what concerns the WHOLE tile grid, so that no scattering workgroup has to (round 3 gave these
+        // duties to superblock 0, whose "band" then was every tile: its per-tile loops and ballot ranks ran over 1,200 tiles
+        // instead of ~100 and it finished last): tile_offsets = exclusive scan of the tile totals, the counts, and the forward
+        // rasterizer's launch order = tiles by descending list length (a counting sort over 64 length classes; the order inside a
+        // class does not matter) -- 1,200 tiles are 1.2 rounds of the 1,024 tile workgroups the chip holds: with the longest
+        // lists first, the part-filled second round is the short ones.
         __shared__ int hist[64];
-        const int tid_ = threadIdx.x;
+        __shared__ int gws[SCAT_WAVES];
+        const int tid_ = threadIdx.x, lane_ = tid_ & 63, wave_ = tid_ >> 6;
         if (tid_ < 64) hist[tid_] = 0;
+        const int per = (n_tiles + SCAT_THREADS - 1) / SCAT_THREADS;
+        const int lo = min(n_tiles, tid_ * per), hi = min(n_tiles, lo + per);
+        int sum = 0;
+        for (int b = lo; b < hi; b++) sum += (int)t.tile_total[b];
+        const int incl = wave_incl_scan_i(sum);
+        if (lane_ == 63) gws[wave_] = incl;
         __syncthreads();
-        for (int b = tid_; b < n_tiles; b += SCAT_THREADS) atomicAdd(&hist[63 - min(63, (int)(t.tile_total[b] >> 5))], 1);
+        int woff = 0, total = 0;
+        for (int w = 0; w < SCAT_WAVES; w++) { const int v = gws[w]; if (w < wave_) woff += v; total += v; }
+        int64_t run = woff + incl - sum;
+        for (int b = lo; b < hi; b++) {
+            const int tt = (int)t.tile_total[b];
+            tile_offsets[b] = (int)min(run, isect_cap);
+            atomicAdd(&hist[63 - min(63, tt >> 5)], 1);
+            run += tt;
+        }
+        if (tid_ == 0) {
+            int64_t ni = total;
+            if (ni > isect_cap) { ni = isect_cap; counts[2] = 1; }   // sticky overflow word, as the sorted-key path
+            counts[0] = ni; counts[1] = 0;
+            int nv = 0;
+            for (int k = 0; k < gps::BWD_CLASSES; k++) {
+                int nk = 0;
+                for (int b = 0; b < gps::BWD_BANDS; b++) nk += t.cls_prefix[gps::BWD_KEYS * SB_MAX + k * gps::BWD_BANDS + b];
+                if (cls_counts) cls_counts[k] = nk;
+                nv += nk;
+            }
+            counts[3] = nv;
+        }
         __syncthreads();
         if (tid_ < 64) {
-            const int v = hist[tid_];
-            int total;
-            const int ex = wave_excl_scan_i(v, total);
+            int tot_;
+            const int ex = wave_excl_scan_i(hist[tid_], tot_);
             hist[tid_] = ex;
         }
         __syncthreads();
@@ -185,10 +215,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     if (tid == 0) pre[sb_size] = (uint32_t)carry;
     __syncthreads();
     for (int w = 0; w < SCAT_WAVES; w++) { row_lo = min(row_lo, wlo[w]); row_hi = max(row_hi, whi[w]); }
-    int t_lo = sb == 0 ? 0 : min(row_lo, row_hi) * tw, t_hi = sb == 0 ? n_tiles : row_hi * tw;   // the band [t_lo, t_hi)
+    int t_lo = min(row_lo, row_hi) * tw, t_hi = row_hi * tw;   // the band [t_lo, t_hi)
     if (t_hi < t_lo) t_hi = t_lo;
     const int nt = t_hi - t_lo;
-    if (n_pairs == 0 && sb != 0) return;
+    if (n_pairs == 0) return;
 
     // ---- tile starts of the band = (sum of the tile totals in front of it) + exclusive scan inside it, + this superblock's prefix
     {
@@ -208,23 +238,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
         for (int w = 0; w < SCAT_WAVES; w++) { const int v = ws[w]; if (w < wave) woff += v; total += v; front += wlo[w]; }
         int run = front + woff + incl - sum;
         for (int b = lo; b < hi; b++) {
-            if (sb == 0) tile_offsets[b] = (int)min((int64_t)run, isect_cap);
             base[b] = (uint32_t)run + t.P[(size_t)(t_lo + b) * SB_MAX + sb];
             run += (int)t.tile_total[t_lo + b];
         }
-        if (sb == 0 && tid == 0) {
-            int64_t ni = total;   // (band = the whole grid)
-            if (ni > isect_cap) { ni = isect_cap; counts[2] = 1; }   // sticky overflow word, as the sorted-key path
-            counts[0] = ni; counts[1] = 0;
-            int nv = 0;
-            for (int k = 0; k < gps::BWD_CLASSES; k++) {
-                int nk = 0;
-                for (int b = 0; b < gps::BWD_BANDS; b++) nk += t.cls_prefix[gps::BWD_KEYS * SB_MAX + k * gps::BWD_BANDS + b];
-                if (cls_counts) cls_counts[k] = nk;
-                nv += nk;
-            }
-            counts[3] = nv;
-        }
+        (void)total;
     }
     // ---- chunks of SCAT_CHUNK pairs in Gaussian order; wave w owns pairs [256 w, 256 w + 256) of a chunk, visited
     // iteration-major, lane-minor: "earlier pair, same tile" == stable rank (as wide_scatter_kernel of splat_bin.hip)

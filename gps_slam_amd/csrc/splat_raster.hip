@@ -639,6 +639,14 @@ int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_m
                                           delta_depth, render_colors, render_alphas, nullptr, stream);
 }
 
+int gps_raster_ges_fwd_rec_ordered(int N, const float* records, const float* ref_depth_map, int width, int height,
+                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts,
+                                   float delta_depth, float* render_colors, float* render_alphas, const int32_t* tile_order,
+                                   gps_stream stream) {
+    return gps::raster_ges_fwd_rec_launch(N, records, ref_depth_map, width, height, tile_offsets, flatten_ids, counts,
+                                          delta_depth, render_colors, render_alphas, nullptr, stream, tile_order);
+}
+
 int gps_raster_ges_bwd_gs(int N, const float* means2d, const float* conics, const float* colors,
                           const float* opacities, const int32_t* radii, const float* ref_depth_map, int width,
                           int height, const int32_t* group_gs_ids, const int32_t* group_starts, const int64_t* counts,

@@ -132,6 +132,16 @@ GPS_API int gps_raster_ges_fwd(int N, const float *means2d, const float *conics,
 GPS_API int gps_raster_ges_fwd_rec(int N, const float *records, const float *ref_depth_map, int width, int height,
                                    const int32_t *tile_offsets, const int32_t *flatten_ids, const int64_t *counts,
                                    float delta_depth, float *render_colors, float *render_alphas, gps_stream stream);
+/* The same launch with its tile workgroups dealt in a given order (tile_order[tile_width * tile_height]: a permutation of the
+ * tile ids; NULL = row-major).  The fused path passes the tiles by descending list length, which the superblock binning leaves in
+ * its workspace (gps_isect_workspace_tile_order: a device pointer into `workspace`, valid after gps_splat_render /
+ * gps_splat_train_step with the strip buffers present): the chip holds 1,024 tile workgroups, 640x480 has 1,200 -- the part-filled
+ * second round should be the short lists.  Same output. */
+GPS_API int gps_raster_ges_fwd_rec_ordered(int N, const float *records, const float *ref_depth_map, int width, int height,
+                                           const int32_t *tile_offsets, const int32_t *flatten_ids, const int64_t *counts,
+                                           float delta_depth, float *render_colors, float *render_alphas,
+                                           const int32_t *tile_order, gps_stream stream);
+GPS_API const int32_t *gps_isect_workspace_tile_order(void *workspace, int N, int64_t isect_capacity);
 
 /* replaces gsplat::rasterize_to_pixels_bwd_ges_gs_parallel_tensor
  * (rasterize_to_pixels_bwd_ges_new_parallel.cu:203-385): Gaussian-parallel backward over the

@@ -96,6 +96,42 @@ def test_fused_iteration_outside_the_superblock_binnings_limits_takes_the_sorted
     assert int(model._B["counts"][2]) == 0 and int(model._B["counts"][1]) > 0   # no overflow; the GROUP table was built
 
 
+def test_forward_launch_order_is_a_permutation_by_list_length_and_changes_nothing():
+    """The superblock binning leaves the forward rasterizer's launch order in the workspace (tiles by descending list length,
+    64 classes of 32 entries): a permutation of the tile ids, non-increasing in the class of the tile's list length; the ordered
+    launch writes the same image, bit for bit, as the row-major one."""
+    import ctypes as C
+    from gps_slam_amd._lib import lib
+    W, H = 640, 480
+    model, cam, ref, base, gt = _model_and_maps(N=60000, W=W, H=H, seed=5)
+    model.initOptimizers(-1, 1.0)
+    model.train_step(cam, ref, base, gt)
+    torch.cuda.synchronize()
+    B, st = model._B, model._step
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    p = lib.gps_isect_workspace_tile_order(C.c_void_p(B["workspace"].data_ptr()), st.N, st.isect_capacity)
+    off = p - B["workspace"].data_ptr()
+    assert 0 < off < B["workspace"].numel()
+    order = B["workspace"][off:off + 4 * T].view(torch.int32).cpu().numpy()
+    assert sorted(order.tolist()) == list(range(T))
+    offs = B["tile_offsets"][:T].cpu().numpy().astype(np.int64)
+    n_isects = int(B["counts"][0])
+    length = np.diff(np.concatenate([offs, [n_isects]]))
+    cls = np.minimum(63, length[order] >> 5)
+    assert (np.diff(cls) <= 0).all() and cls[0] > cls[-1]
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    refc = model.clamp_ref_depth(ref)
+    outs = []
+    for o in (C.c_void_p(0), C.c_void_p(p)):
+        rc, ws = torch.zeros_like(B["render_colors"]), torch.zeros_like(B["weight_sum"])
+        assert lib.gps_raster_ges_fwd_rec_ordered(st.N, ptr(B["records"]), ptr(refc), W, H, ptr(B["tile_offsets"]), ptr(B["flatten_ids"]),
+                                                  ptr(B["counts"]), model.delta_depth, ptr(rc), ptr(ws), o, sp) == 0
+        outs.append((rc, ws))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][1].abs().sum() > 0
+
+
 def test_optimisation_reduces_the_loss():
     model, cam, ref, base, gt = _model_and_maps(N=30000, seed=5)
     model.initOptimizers(-1, 3.3)
