@@ -116,6 +116,22 @@ def _with_survey_formula(row, survey_bytes, t, hbm_peak_gbs, note):
     return row
 
 
+def measured_copy_bandwidth(device, nbytes=1 << 30, reps=10):
+    """"record the measured copy bandwidth of the box" -- a device-to-device copy of 1 GiB (read + write counted),
+    best of `reps`, HIP events on the current stream.  `roofline.peak` stays the nominal 8 TB/s; this is the box's own ceiling."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    best = float("inf")
+    for _ in range(reps):
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record(); b.copy_(a); s1.record()
+        torch.cuda.synchronize()
+        best = min(best, s0.elapsed_time(s1) * 1e-3)
+    del a, b
+    return 2.0 * nbytes / best / 1e9
+
+
 def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     """`roofline` of the bench line.  Every duration is measured live, here, with HIP events on the launch stream over 50
     back-to-back launches of the kernel on the state the timed run ended in (Python twins of the model and of the TSDF
@@ -269,7 +285,10 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     top = rows[0]
     t_frame = result["ms_per_step"] * 1e-3
     b_frame = 2.0 * b_iter + b_fuse
+    copy_gbs = measured_copy_bandwidth(device)
     return {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_GBs"], "peak": hbm_peak_gbs, "unit": "GB/s",
+            "measured_copy_GBs": copy_gbs,
+            "measured_copy_note": "device-to-device copy of 1 GiB on this box, read + write bytes / best of 10 (SURVEY 8(d)); fractions use the nominal peak",
             "frac": top["frac"], "traffic": top.get("traffic"), "avg_launch_us": top["avg_us"],
             "algorithmic_bytes": top["algorithmic_bytes"],
             "dominant_by": "calls per frame x live average launch time (kernels[] is sorted by it)",
