@@ -80,7 +80,10 @@ __global__ __launch_bounds__(KG_BBOX_THREADS) void knn_bbox_kernel(int P, const 
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) { const float v = pts[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+        for (int a = 0; a < 3; a++) {   // (finite coordinates only: a NaN / inf point must not decide the grid)
+            const float v = pts[3 * i + a];
+            if (fabsf(v) <= FLT_MAX) { lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+        }
     }
     __shared__ float red[KG_BBOX_THREADS / 64][6];
 #pragma unroll
@@ -110,7 +113,9 @@ __global__ __launch_bounds__(64) void knn_grid_kernel(int P, const float* __rest
     float ext[3], emax = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; a++) { ext[a] = fmaxf(hi[a] - lo[a], 0.f); emax = fmaxf(emax, ext[a]); }
-    if (!(emax > 0.f) || !(emax < FLT_MAX)) emax = 1.f;   // a single point (or nothing finite): one cell
+    if (!(emax > 0.f) || !(emax < FLT_MAX)) { emax = 1.f; ext[0] = ext[1] = ext[2] = 0.f; }   // a single point (or nothing finite): one cell
+#pragma unroll
+    for (int a = 0; a < 3; a++) if (!(lo[a] <= hi[a])) lo[a] = 0.f;   // (no finite coordinate on this axis)
 #pragma unroll
     for (int a = 0; a < 3; a++) ext[a] = fmaxf(ext[a], 1e-3f * emax);   // planar sets: no axis thinner than 1/1000 of the longest
     int64_t target = 16 * (int64_t)P;
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(64) void knn_grid_kernel(int P, const float* __rest
 }
 
 __device__ __forceinline__ int cell_coord(float v, float lo, float inv_h, int g) {
-    const int c = (int)((v - lo) * inv_h);
-    return c < 0 ? 0 : (c >= g ? g - 1 : c);
+    const float f = (v - lo) * inv_h;                    // (NaN / inf / out-of-range coordinates: clamped before the conversion)
+    return f > 0.f ? (int)fminf(f, (float)(g - 1)) : 0;
 }
 
 // (2) zero the counters of the grid in use (+ the end marker); n_cells is only known on the device
@@ -238,6 +243,12 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnGrid* __
               cz = cell_coord(q.z, g.minz, g.inv_h, g.gz);
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;   // of this lane's candidates
     float m0 = FLT_MAX, m1 = FLT_MAX, m2 = FLT_MAX;   // merged over the point's lanes
+    if (!(fabsf(q.x) <= FLT_MAX) || !(fabsf(q.y) <= FLT_MAX) || !(fabsf(q.z) <= FLT_MAX)) {
+        // a NaN / inf query is at no finite distance from anything: the brute force leaves its three slots at FLT_MAX (every
+        // comparison fails) -- the same expression here, without walking the whole grid for it
+        if (sub == 0) out[self] = (m0 + m1 + m2) / 3.0f;
+        return;
+    }
     auto scan_run = [&](int lo, int hi) {
         for (int k = lo + sub; k < hi; k += KQ_LANES) {
             const float4 c = sorted[k];

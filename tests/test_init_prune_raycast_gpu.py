@@ -242,11 +242,11 @@ def test_grid_knn_is_exact_on_a_first_keyframe_of_surface_points(P, W, H):
         assert t_grid < 2.0, t_grid
 
 
-@pytest.mark.parametrize("case", ["cube", "plane", "duplicates", "outlier", "line", "tiny", "two_clusters"])
+@pytest.mark.parametrize("case", ["cube", "plane", "duplicates", "outlier", "line", "tiny", "two_clusters", "nan_inf"])
 def test_grid_knn_equals_the_brute_force_on_awkward_sets(case):
     """shapes that stress the grid: uniform volume, an exactly planar set (one axis of the bounding box is zero), many exact
     duplicates (zero distances, one crowded cell), a dense cluster with one far outlier (the outlier's rings cross the whole
-    grid), a line, fewer than four points (a FLT_MAX term, as the brute force and the reference), two far clusters (empty middle)."""
+    grid), a line, fewer than four points (a FLT_MAX term, as the brute force and the reference), two far clusters (empty middle), NaN / inf coordinates."""
     from gps_slam_amd.gs_model import knn_mean_dist2
     gen = torch.Generator().manual_seed(11)
     P = 6000
@@ -266,9 +266,14 @@ def test_grid_knn_equals_the_brute_force_on_awkward_sets(case):
     elif case == "two_clusters":
         x *= 0.02
         x[P // 2:] += torch.tensor([4.0, 4.0, -4.0])
+    elif case == "nan_inf":   # non-finite points: no neighbour of anything, their own result inf -- and they must not decide the grid
+        x[5] = float("nan"); x[77, 1] = float("inf"); x[4000] = torch.tensor([float("-inf"), 0.5, float("nan")])
     x = x.contiguous().to(DEV)
     grid, brute = knn_mean_dist2(x, method="grid"), knn_mean_dist2(x, method="brute")
     assert torch.equal(grid, brute), (case, (grid != brute).sum())
+    if case == "nan_inf":
+        assert torch.isinf(grid[[5, 77, 4000]]).all() and torch.isfinite(grid).sum() == P - 3
+        return
     if case == "tiny":
         assert (grid > 1e37).all()     # two real distances + one FLT_MAX term, / 3 (simple_knn.cu:186: best[] starts at FLT_MAX)
     else:
