@@ -59,6 +59,8 @@ struct SbTables {
     int sb_shift;          // log2(preprocessing workgroups per superblock)
     int32_t* tile_order;   // [SB_MAX_TILES] the tiles by descending list length (sb_scatter's extra workgroup): the forward rasterizer's launch order
 };
+// splat_raster_bwd.hip: gps_set_frame_chain_reserve(on) -- the host runs tracking / fusion on another stream beside the map update
+bool map_runs_beside_frame_chain();
 // splat_bin_sb.hip: can the superblock binning take N Gaussians on a tile_width x tile_height grid on THIS device (tile count,
 // packed box fields, superblock count, the scatter kernel's dynamic LDS incl. its > 64 KB opt-in)?  False -> sorted-key binning.
 bool sb_supported(int N, int tile_width, int tile_height);

@@ -329,6 +329,9 @@ int raster_ges_bwd_strips_launch(int N, const float* records, const int32_t* rad
     return GPS_OK;
 }
 
+// (splat_step.hip: the forward's launch order by list length only pays when the map kernels have the chip to themselves)
+bool map_runs_beside_frame_chain() { return __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED) != 0; }
+
 }  // namespace gps
 
 extern "C" {

@@ -175,7 +175,10 @@ GPS_API int gps_raster_ges_bwd_strips(int N, const float *records, const int32_t
  * that 5 instead of 6 of its workgroups share a compute unit and one workgroup of the tracker's pre-launched evaluation (112
  * VGPRs per wave) always finds room beside it.  For hosts that run a frame chain (tracking / fusion) on one stream WHILE the map
  * update runs on another (host/slam_pipeline.cpp: overlap_mapping); a host that runs them in turn leaves it off -- the strip
- * kernel alone is faster with 6.  Results do not depend on it.  GPS_MAP_RESERVE=0/1 in the environment overrides the call. */
+ * kernel alone is faster with 6.  The same switch picks the forward rasterizer's launch order inside gps_splat_render /
+ * gps_splat_train_step: off -> tiles by descending list length (the chip holds 1,024 of the 1,200 tile workgroups of 640x480: the
+ * part-filled second round is then the short lists; iteration 257 -> 248 us), on -> row-major (beside a frame chain the ordered
+ * launch is 0.7 % slower).  Results do not depend on it. */
 GPS_API void gps_set_frame_chain_reserve(int on);
 /* records[N,12] (the 48-byte records gps_gauss_preprocess_fwd writes, incl. the ellipse bounds) from the operator-level arrays
  * means2d[N,2] conics[N,3] colors[N,4] (rgb + depth) opacities[N] radii[N]: lets a caller that holds those run the strip backward */

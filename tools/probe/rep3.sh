@@ -2,7 +2,7 @@
 N=${1:-10}
 mkdir -p gpurun_out
 for i in $(seq 1 $N); do
-  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-oracle-psnr > gpurun_out/rep3_$i.log 2> gpurun_out/rep3_err_$i.log
+  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-oracle-psnr --no-other-configs > gpurun_out/rep3_$i.log 2> gpurun_out/rep3_err_$i.log
   echo "run $i rc $?"
 done
 python - <<'PY'
