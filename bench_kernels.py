@@ -149,6 +149,7 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     model.initOptimizers(-1, 1.0)
+    lib.gps_set_frame_chain_reserve(0)   # the micro-loops below time kernels that have the chip to themselves (the last scene ran overlapped)
 
     def step():
         model.train_step(cam, rc["depth_map"], rc["color_map"], cam.image, ref_depth_clamped=rc["depth_map_clamped"])
@@ -312,9 +313,11 @@ def config_units(scene, seq, ms_per_step, hbm_peak_gbs, with_tracking_bytes=True
     windows (Python twin of the model: one train step on the last optimise camera; the engine's counters), the algorithmic
     bytes of an optimise iteration and of a frame (the frame without the ray term -- S-bar is logged on the
     headline configuration), a live iteration time (20 back-to-back steps, HIP events) and the two HBM fractions."""
+    from gps_slam_amd._lib import lib
     device = "cuda:%d" % torch.cuda.current_device()
     model, cam, rc = _python_twin(scene, device)
     model.initOptimizers(-1, 1.0)
+    lib.gps_set_frame_chain_reserve(0)   # (kernels alone, as in roofline_section)
     stream = torch.cuda.current_stream()
 
     def step():
