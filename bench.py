@@ -159,6 +159,8 @@ class Scene:
         self.pipe.loadConfig(dict(keyframe_theta_thres=keyframe_theta, keyframe_trans_thres=keyframe_trans))
         self.pipe.overlap_mapping = bool(overlap)
         self.pipe.mapping_thread = bool(overlap)
+        if os.environ.get("GPS_BENCH_PREFETCH"):  # A/B aid: the next iteration's preprocessing in the backward kernel's tail (1, default) or its own launch (0)
+            self.pipe.prefetch_next_preprocess = os.environ["GPS_BENCH_PREFETCH"] != "0"
         if os.environ.get("GPS_BENCH_ASYNC_RAYCASTS"):  # A/B aid (tools/probe/outliers.sh): the keyframe views' raycasts beside the first iterations (1, default) or before them (0)
             self.pipe.async_raycasts = os.environ["GPS_BENCH_ASYNC_RAYCASTS"] != "0"
         self.model.reserveWorkspace(W, H)

@@ -56,7 +56,8 @@ class SplatStep(C.Structure):
                 [(p + n, vp) for p in ("g_", "m_", "v_") for n in ("means", "log_scales", "quats", "opac_logit", "sh_dc",
                                                                    "sh_rest")] +
                 [("lr", f64 * 6), ("beta1", f64), ("beta2", f64), ("adam_eps", f64), ("fuse_sh_rest_adam", i32)] +
-                [(n, vp) for n in ("v_rows", "pix2", "cls_ids", "cls_counts")] + [("cls_stride", i64)])
+                [(n, vp) for n in ("v_rows", "pix2", "cls_ids", "cls_counts")] + [("cls_stride", i64)] +
+                [(n, vp) for n in ("next_viewmat", "next_Kmat", "next_cam_pos")] + [("preprocessed", i32)])
 
 
 class AdamSegment(C.Structure):
@@ -147,6 +148,7 @@ PROTOTYPES = {
     "gps_compact_mask_workspace_bytes": (i64, [i32]),
     "gps_compact_mask": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "gps_gather_pixels": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gps_splat_can_prefetch": (i32, [C.POINTER(SplatStep)]),
     "gps_splat_render": (i32, [C.POINTER(SplatStep), vp]),
     "gps_splat_train_step": (i32, [C.POINTER(SplatStep), i32, vp]),
 }

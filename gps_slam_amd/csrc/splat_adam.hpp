@@ -35,6 +35,19 @@ __device__ __forceinline__ void adam_update(const AdamScalars& a, float g, float
 }
 
 // splat_fused.hip: backward of the per-Gaussian preprocessing, optionally with the Adam step of sh_rest fused in
+// The NEXT optimise iteration's preprocessing forward, run in the tail of this iteration's backward + Adam kernel
+// (gps_splat_step::next_viewmat; splat_fused.hip NextFwd): the next camera, the forward's thresholds and outputs, the superblock
+// binning's count targets.
+struct BinCountOut;
+struct NextForward {
+    const float *viewmat, *Kmat, *cam_pos;
+    int max_gs_radii;
+    float near_plane, far_plane, radius_clip;
+    int32_t* radii;
+    float *means2d, *depths, *conics, *colors, *opacities, *records;
+    const BinCountOut* count;
+};
+
 int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const float* log_scales, const float* quats,
                           const float* opac_logit, const float* sh_dc, const float* sh_rest, const float* viewmat,
                           const float* Kmat, const float* cam_pos, int width, int height, float eps2d,
@@ -42,6 +55,7 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
                           const float* v_colors, const float* v_opacities, float* v_means, float* v_log_scales,
                           float* v_quats, float* v_opac_logit, float* v_sh_dc, float* v_sh_rest, float* adam_param,
                           float* adam_m, float* adam_v, AdamScalars sc, const gps_adam_segment* small5,
-                          const float* small_step, gps_stream stream, const float* v_rows = nullptr);
+                          const float* small_step, gps_stream stream, const float* v_rows = nullptr,
+                          const NextForward* next = nullptr);
 
 }  // namespace gps

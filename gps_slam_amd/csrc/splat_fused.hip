@@ -73,93 +73,111 @@ __device__ __forceinline__ void stage_rows_out(const float* __restrict__ lds, fl
     for (int e = (n4 << 2) + threadIdx.x; e < n_floats; e += blockDim.x) g[first_float + e] = lds[e];
 }
 
+// What the forward writes per Gaussian, and what the binning's block-level passes need of it afterwards.
+struct FwdOut { int32_t* radii; float* means2d; float* depths; float* conics; float* colors; float* opac; float4* recs; };
+struct FwdBox { int n_tiles, n_groups, vis; float mx, my; int r; };
+
+// The forward of ONE Gaussian from its parameters in registers (the SH-rest row behind `cf`: global memory in the forward
+// kernel, the workgroup's LDS tile in the backward kernel's next-iteration tail): projection, SH colour, record, the backward
+// rasterizer's zero-fill, the binning's per-Gaussian counts.  One body for both callers.
 template <int DEG>
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, int32_t* __restrict__ radii,
-                                                             float* __restrict__ means2d, float* __restrict__ depths,
-                                                             float* __restrict__ conics, float* __restrict__ colors,
-                                                             float* __restrict__ opac, float4* __restrict__ recs,
-                                                             BinCountOut cnt, ZeroGrads zg) {
+__device__ __forceinline__ FwdBox preprocess_fwd_gaussian(const FusedIn& in, int i, const float (&p)[3], const float (&q)[4],
+                                                          const float (&logs)[3], const float (&dc)[3], const float* cf,
+                                                          float opac_logit, const FwdOut& w, const BinCountOut& cnt,
+                                                          const ZeroGrads& zg) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    FwdBox bx = {0, 0, 0, 0.f, 0.f, 0};
+    Cam cam;
+    cam_from_arrays(in.viewmat, in.Kmat, in.W, in.H, cam);
+    const float s[3] = {expf(logs[0]), expf(logs[1]), expf(logs[2])};
+    Proj o = project_gaussian(cam, p, q, s, in.eps2d, in.near_plane, in.far_plane, in.radius_clip);
+    if (in.max_radii > 0) o.radius = min(o.radius, in.max_radii);
+    w.radii[i] = o.radius;
+    *reinterpret_cast<float2*>(w.means2d + 2 * (size_t)i) = make_float2(o.mx, o.my);
+    w.depths[i] = o.z;
+    w.conics[3 * i] = o.ca; w.conics[3 * i + 1] = o.cb; w.conics[3 * i + 2] = o.cc;
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (o.radius > 0) {
+        const float dx = p[0] - in.cam_pos[0], dy = p[1] - in.cam_pos[1], dz = p[2] - in.cam_pos[2];
+        const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+        float Y[NB];
+        sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
+        r = Y[0] * dc[0]; g = Y[0] * dc[1]; b = Y[0] * dc[2];
+        // (forward kernel: direct reads -- only visible Gaussians need their row here, staging all 256 through LDS measured slower)
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+            r += Y[k] * cf[3 * (k - 1)]; g += Y[k] * cf[3 * (k - 1) + 1]; b += Y[k] * cf[3 * (k - 1) + 2];
+        }
+        r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
+    }
+    *reinterpret_cast<float4*>(w.colors + 4 * (size_t)i) = make_float4(r, g, b, o.z);
+    const float op = 1.f / (1.f + expf(-opac_logit));
+    w.opac[i] = op;
+    if (w.recs) pack_record(o, r, g, b, op, w.recs + 3 * (size_t)i);
+    if (zg.v_colors) {  // the backward rasterizer's accumulators of this Gaussian (its zero-fill launch, folded in)
+        *reinterpret_cast<float4*>(zg.v_colors + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        zg.v_conics[3 * i] = 0.f; zg.v_conics[3 * i + 1] = 0.f; zg.v_conics[3 * i + 2] = 0.f;
+        *reinterpret_cast<float2*>(zg.v_means2d + 2 * (size_t)i) = make_float2(0.f, 0.f);
+        zg.v_opacities[i] = 0.f;
+    }
+    if (cnt.tiles_per_gauss) {
+        // first pass of the tile binning (count_kernel of splat_bin.hip) on the values still in registers
+        if (o.radius > 0) {
+            tile_group_count(o.mx, o.my, o.radius, cnt.tile_size, cnt.tw, cnt.th, bx.n_tiles, bx.n_groups); bx.vis = 1;
+            bx.mx = o.mx; bx.my = o.my; bx.r = o.radius;
+        }
+        cnt.tiles_per_gauss[i] = bx.n_tiles;
+        cnt.groups_per_gauss[i] = bx.n_groups;
+    }
+    return bx;
+}
+
+// Superblock binning, histogram pass (splat_bin.hpp) for the Gaussians of one workgroup (any size that divides BIN_BLOCK; its
+// first Gaussian names the superblock): the (Gaussian, tile) pairs counted per tile in LDS (hist[SB_MAX_TILES]), the non-zero bins
+// added to the count table of the superblock; Gaussians per backward class likewise (khist[BWD_KEYS]).  Every thread arrives.
+__device__ __forceinline__ void sb_histogram_block(const BinCountOut& cnt, uint32_t* hist, int* khist, const FwdBox& bx,
+                                                   int first_gaussian) {
+    const int nt = cnt.tw * cnt.th;
+    for (int b = threadIdx.x; b < nt; b += blockDim.x) hist[b] = 0;
+    if (threadIdx.x < BWD_KEYS) khist[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned y0 = 0;
+    if (bx.n_tiles > 0) {
+        const TileBox tb = tile_bbox(bx.mx, bx.my, bx.r, cnt.tile_size, cnt.tw, cnt.th);
+        y0 = tb.y0;
+        for (uint32_t ty = tb.y0; ty < tb.y1; ty++)
+            for (uint32_t tx = tb.x0; tx < tb.x1; tx++) atomicAdd(&hist[ty * (uint32_t)cnt.tw + tx], 1u);
+    }
+    if (bx.r > 0) atomicAdd(&khist[bwd_key(bx.r, bx.n_tiles, y0, cnt.th)], 1);
+    __syncthreads();
+    const int sb = (first_gaussian / BIN_BLOCK) >> cnt.sb.sb_shift;
+    for (int b = threadIdx.x; b < nt; b += blockDim.x) {
+        const uint32_t c = hist[b];
+        if (c) atomicAdd(&cnt.sb.C[(size_t)b * SB_MAX + sb], c);
+    }
+    if (threadIdx.x < BWD_KEYS) {
+        const int c = khist[threadIdx.x];
+        if (c) atomicAdd(&cnt.sb.cls_count[threadIdx.x * SB_MAX + sb], c);
+    }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, FwdOut w, BinCountOut cnt, ZeroGrads zg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int n_tiles = 0, n_groups = 0, vis = 0;
-    float box_mx = 0.f, box_my = 0.f;   // what the superblock histogram below needs of this Gaussian
-    int box_r = 0;
+    FwdBox bx = {0, 0, 0, 0.f, 0.f, 0};
     if (i < in.N) {
-        constexpr int NB = (DEG + 1) * (DEG + 1);
-        Cam cam;
-        cam_from_arrays(in.viewmat, in.Kmat, in.W, in.H, cam);
         const float p[3] = {in.means[3 * i], in.means[3 * i + 1], in.means[3 * i + 2]};
         const float4 q4 = *reinterpret_cast<const float4*>(in.quats + 4 * (size_t)i);
         const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float s[3] = {expf(in.log_scales[3 * i]), expf(in.log_scales[3 * i + 1]), expf(in.log_scales[3 * i + 2])};
-        Proj o = project_gaussian(cam, p, q, s, in.eps2d, in.near_plane, in.far_plane, in.radius_clip);
-        if (in.max_radii > 0) o.radius = min(o.radius, in.max_radii);
-        radii[i] = o.radius;
-        *reinterpret_cast<float2*>(means2d + 2 * (size_t)i) = make_float2(o.mx, o.my);
-        depths[i] = o.z;
-        conics[3 * i] = o.ca; conics[3 * i + 1] = o.cb; conics[3 * i + 2] = o.cc;
-        float r = 0.f, g = 0.f, b = 0.f;
-        if (o.radius > 0) {
-            const float dx = p[0] - in.cam_pos[0], dy = p[1] - in.cam_pos[1], dz = p[2] - in.cam_pos[2];
-            const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
-            float Y[NB];
-            sh_basis<DEG>(dx * inorm, dy * inorm, dz * inorm, Y);
-            r = Y[0] * in.sh_dc[3 * i]; g = Y[0] * in.sh_dc[3 * i + 1]; b = Y[0] * in.sh_dc[3 * i + 2];
-            // (direct reads: only visible Gaussians need their row here, staging all 256 through LDS measured slower)
-            const float* cf = in.sh_rest + (size_t)i * (in.K - 1) * 3;
-#pragma unroll
-            for (int k = 1; k < NB; k++) {
-                r += Y[k] * cf[3 * (k - 1)]; g += Y[k] * cf[3 * (k - 1) + 1]; b += Y[k] * cf[3 * (k - 1) + 2];
-            }
-            r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
-        }
-        *reinterpret_cast<float4*>(colors + 4 * (size_t)i) = make_float4(r, g, b, o.z);
-        const float op = 1.f / (1.f + expf(-in.opac_logit[i]));
-        opac[i] = op;
-        if (recs) pack_record(o, r, g, b, op, recs + 3 * (size_t)i);
-        if (zg.v_colors) {  // the backward rasterizer's accumulators of this Gaussian (its zero-fill launch, folded in)
-            *reinterpret_cast<float4*>(zg.v_colors + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
-            zg.v_conics[3 * i] = 0.f; zg.v_conics[3 * i + 1] = 0.f; zg.v_conics[3 * i + 2] = 0.f;
-            *reinterpret_cast<float2*>(zg.v_means2d + 2 * (size_t)i) = make_float2(0.f, 0.f);
-            zg.v_opacities[i] = 0.f;
-        }
-        if (cnt.tiles_per_gauss) {
-            // first pass of the tile binning (count_kernel of splat_bin.hip) on the values still in registers
-            if (o.radius > 0) {
-                tile_group_count(o.mx, o.my, o.radius, cnt.tile_size, cnt.tw, cnt.th, n_tiles, n_groups); vis = 1;
-                box_mx = o.mx; box_my = o.my; box_r = o.radius;
-            }
-            cnt.tiles_per_gauss[i] = n_tiles;
-            cnt.groups_per_gauss[i] = n_groups;
-        }
+        const float logs[3] = {in.log_scales[3 * i], in.log_scales[3 * i + 1], in.log_scales[3 * i + 2]};
+        const float dc[3] = {in.sh_dc[3 * i], in.sh_dc[3 * i + 1], in.sh_dc[3 * i + 2]};
+        bx = preprocess_fwd_gaussian<DEG>(in, i, p, q, logs, dc, in.sh_rest + (size_t)i * (in.K - 1) * 3, in.opac_logit[i], w, cnt, zg);
     }
-    if (cnt.tiles_per_gauss) bin_block_sums(cnt, n_tiles, n_groups, vis);  // (uniform branch: every thread arrives)
+    if (cnt.tiles_per_gauss) bin_block_sums(cnt, bx.n_tiles, bx.n_groups, bx.vis);  // (uniform branch: every thread arrives)
     if (cnt.sb.C) {
-        // Superblock binning, histogram pass (splat_bin.hpp): this workgroup's (Gaussian, tile) pairs counted per tile in LDS,
-        // the non-zero bins added to the count table of its superblock; Gaussians per backward class likewise.
         __shared__ uint32_t hist[SB_MAX_TILES];
         __shared__ int khist[BWD_KEYS];
-        const int nt = cnt.tw * cnt.th;
-        for (int b = threadIdx.x; b < nt; b += 256) hist[b] = 0;
-        if (threadIdx.x < BWD_KEYS) khist[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned y0 = 0;
-        if (n_tiles > 0) {
-            const TileBox bx = tile_bbox(box_mx, box_my, box_r, cnt.tile_size, cnt.tw, cnt.th);
-            y0 = bx.y0;
-            for (uint32_t ty = bx.y0; ty < bx.y1; ty++)
-                for (uint32_t tx = bx.x0; tx < bx.x1; tx++) atomicAdd(&hist[ty * (uint32_t)cnt.tw + tx], 1u);
-        }
-        if (box_r > 0) atomicAdd(&khist[bwd_key(box_r, n_tiles, y0, cnt.th)], 1);
-        __syncthreads();
-        const int sb = (int)blockIdx.x >> cnt.sb.sb_shift;
-        for (int b = threadIdx.x; b < nt; b += 256) {
-            const uint32_t c = hist[b];
-            if (c) atomicAdd(&cnt.sb.C[(size_t)b * SB_MAX + sb], c);
-        }
-        if (threadIdx.x < BWD_KEYS) {
-            const int c = khist[threadIdx.x];
-            if (c) atomicAdd(&cnt.sb.cls_count[threadIdx.x * SB_MAX + sb], c);
-        }
+        sb_histogram_block(cnt, hist, khist, bx, (int)(blockIdx.x * blockDim.x));
     }
 }
 
@@ -180,12 +198,26 @@ struct FusedAdam {
     float sstep[5];     // lr_k / (1 - beta1^t)
 };
 
+// NEXT ITERATION'S FORWARD in the tail of this iteration's backward (gps_splat_step::next_viewmat): the thread that has just
+// stepped a Gaussian's 59 parameters holds them in registers / the LDS tile -- the preprocessing forward of the next optimise
+// iteration (another camera of the same update) runs right there instead of re-reading them in a launch of its own: one launch
+// and 68 N + 217 Nv bytes of reads less per iteration.  viewmat == nullptr: off.
+struct NextFwd {
+    const float* viewmat;     // the NEXT camera (device arrays, as FusedIn's)
+    const float* Kmat;
+    const float* cam_pos;
+    int max_radii;
+    float near_plane, far_plane, radius_clip;
+    FwdOut out;               // the per-Gaussian outputs of the forward (this iteration's values have been read by then)
+    BinCountOut cnt;          // the superblock binning's count targets (tables zero: this iteration's scan has cleared them)
+};
+
 // The five small tensors (3 + 3 + 4 + 3 + 1 = 14 floats per Gaussian), stepped by the thread that owns the Gaussian: all 42
 // loads (parameter, both moments) are issued before the first update -- row by row with the stores in between, every
 // component was its own memory round trip (the compiler cannot move a load of m[c+1] above the store of p[c]).
-__device__ __forceinline__ void adam_small_rows(const FusedAdam& ad, int i, const float* const g[5]) {
+__device__ __forceinline__ void adam_small_rows(const FusedAdam& ad, int i, const float* const g[5], float (&P)[14]) {
     constexpr int L[5] = {3, 3, 4, 3, 1};
-    float P[14], M[14], V[14];
+    float M[14], V[14];   // (P: the stepped parameters, means[3] | log_scales[3] | quats[4] | sh_dc[3] | opac_logit, for the caller)
     int o = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
                                                              float* __restrict__ v_quats,
                                                              float* __restrict__ v_opac_logit,
                                                              float* __restrict__ v_sh_dc,
-                                                             float* __restrict__ v_sh_rest) {
+                                                             float* __restrict__ v_sh_rest, NextFwd nf) {
     // sh_tile: this workgroup's sh_rest rows.  Without FUSE_ADAM their gradients overwrite them in place; with it the
     // gradients go to a second tile so that parameter and gradient are both at hand for the update.
     extern __shared__ float sh_tile[];
@@ -347,6 +379,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
                         adam_update(ad.sc, g.x, m[u].x, v[u].x, p.x); adam_update(ad.sc, g.y, m[u].y, v[u].y, p.y);
                         adam_update(ad.sc, g.z, m[u].z, v[u].z, p.z); adam_update(ad.sc, g.w, m[u].w, v[u].w, p.w);
                         gm[e] = m[u]; gv[e] = v[u]; gp[e] = p;
+                        if (nf.viewmat) reinterpret_cast<float4*>(sh_tile)[e] = p;   // (the next forward reads the stepped row from LDS)
                     }
                 }
             }
@@ -354,24 +387,44 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
                 float p = sh_tile[e], m = ad.exp_avg[tile_first + e], v = ad.exp_avg_sq[tile_first + e];
                 adam_update(ad.sc, g_tile[e], m, v, p);
                 ad.exp_avg[tile_first + e] = m; ad.exp_avg_sq[tile_first + e] = v; ad.param[tile_first + e] = p;
+                if (nf.viewmat) sh_tile[e] = p;
             }
         }
     }
-    if (!live) return;
-    // opac = sigmoid(logit): receives gradient for every Gaussian the rasterizer touched (0 otherwise)
-    const float o = 1.f / (1.f + expf(-in.opac_logit[i]));
-    const float vo = v_opac_i * o * (1.f - o);
-    if (v_means) {  // gradient outputs (optional when the small tensors are stepped below)
-        v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
-        v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
-        *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
-        v_sh_dc[3 * i] = vdc[0]; v_sh_dc[3 * i + 1] = vdc[1]; v_sh_dc[3 * i + 2] = vdc[2];
-        v_opac_logit[i] = vo;
+    if (!live && !nf.viewmat) return;
+    float P14[14];
+    if (live) {
+        // opac = sigmoid(logit): receives gradient for every Gaussian the rasterizer touched (0 otherwise)
+        const float o = 1.f / (1.f + expf(-in.opac_logit[i]));
+        const float vo = v_opac_i * o * (1.f - o);
+        if (v_means) {  // gradient outputs (optional when the small tensors are stepped below)
+            v_means[3 * i] = vp[0]; v_means[3 * i + 1] = vp[1]; v_means[3 * i + 2] = vp[2];
+            v_log_scales[3 * i] = vs[0]; v_log_scales[3 * i + 1] = vs[1]; v_log_scales[3 * i + 2] = vs[2];
+            *reinterpret_cast<float4*>(v_quats + 4 * (size_t)i) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            v_sh_dc[3 * i] = vdc[0]; v_sh_dc[3 * i + 1] = vdc[1]; v_sh_dc[3 * i + 2] = vdc[2];
+            v_opac_logit[i] = vo;
+        }
+        if (ad.small) {  // every read of this Gaussian's parameters is done: step them in place
+            const float* const gs[5] = {vp, vs, vq, vdc, &vo};
+            adam_small_rows(ad, i, gs, P14);
+        }
     }
-    if (ad.small) {  // every read of this Gaussian's parameters is done: step them in place
-        const float* const gs[5] = {vp, vs, vq, vdc, &vo};
-        adam_small_rows(ad, i, gs);
+    if (!nf.viewmat) return;
+    // ---- the next iteration's preprocessing forward (launcher: only with all six tensors stepped above and K > 1) ----
+    __syncthreads();   // the tile holds the stepped sh_rest rows of every thread's Gaussian; the gradient tile is free
+    FusedIn in2 = in;
+    in2.viewmat = nf.viewmat; in2.Kmat = nf.Kmat; in2.cam_pos = nf.cam_pos;
+    in2.max_radii = nf.max_radii; in2.near_plane = nf.near_plane; in2.far_plane = nf.far_plane; in2.radius_clip = nf.radius_clip;
+    FwdBox bx = {0, 0, 0, 0.f, 0.f, 0};
+    if (live) {
+        const float p[3] = {P14[0], P14[1], P14[2]}, logs[3] = {P14[3], P14[4], P14[5]};
+        const float q[4] = {P14[6], P14[7], P14[8], P14[9]}, dc[3] = {P14[10], P14[11], P14[12]};
+        const ZeroGrads none = {};
+        bx = preprocess_fwd_gaussian<DEG>(in2, i, p, q, logs, dc, sh_tile + threadIdx.x * row, P14[13], nf.out, nf.cnt, none);
     }
+    // the binning's histogram pass in the gradient tile's memory (SB_MAX_TILES words + the class keys: <= the tile, see the launcher)
+    uint32_t* hist = reinterpret_cast<uint32_t*>(g_tile);
+    sb_histogram_block(nf.cnt, hist, reinterpret_cast<int*>(hist + SB_MAX_TILES), bx, (int)(blockIdx.x * blockDim.x));
 }
 
 }  // namespace
@@ -387,7 +440,7 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
                           const float* v_colors, const float* v_opacities, float* v_means, float* v_log_scales,
                           float* v_quats, float* v_opac_logit, float* v_sh_dc, float* v_sh_rest, float* adam_param,
                           float* adam_m, float* adam_v, AdamScalars sc, const gps_adam_segment* small5,
-                          const float* small_step, gps_stream stream, const float* v_rows) {
+                          const float* small_step, gps_stream stream, const float* v_rows, const NextForward* next) {
     GPS_ENTER();
     GPS_REQUIRE(N >= 0 && width > 0 && height > 0 && sh_degree >= 0 && sh_degree <= 4 && K >= sh_num_bases(sh_degree));
     if (N == 0) return GPS_OK;
@@ -421,11 +474,23 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
     dim3 g(gps_div_up(N, threads)), b(threads);
     const size_t lds = lds_bytes(threads);
     GPS_REQUIRE(lds <= 65536);
+    NextFwd nf = {};
+    if (next) {
+        // only behind the fully fused step (every parameter stepped in this kernel), with the superblock binning's count targets,
+        // a workgroup that divides the binning's 256-Gaussian blocks and a gradient tile that holds the histogram
+        GPS_REQUIRE(fuse && small5 && !grads_out && next->viewmat && next->Kmat && next->cam_pos && next->count && next->count->sb.C);
+        GPS_REQUIRE(next->radii && next->means2d && next->depths && next->conics && next->colors && next->opacities && next->records);
+        GPS_REQUIRE(BIN_BLOCK % threads == 0 && lds / 2 >= (size_t)(SB_MAX_TILES + BWD_KEYS) * 4);
+        nf.viewmat = next->viewmat; nf.Kmat = next->Kmat; nf.cam_pos = next->cam_pos;
+        nf.max_radii = next->max_gs_radii; nf.near_plane = next->near_plane; nf.far_plane = next->far_plane; nf.radius_clip = next->radius_clip;
+        nf.out = {next->radii, next->means2d, next->depths, next->conics, next->colors, next->opacities, reinterpret_cast<float4*>(next->records)};
+        nf.cnt = *next->count;
+    }
     hipStream_t s = (hipStream_t)stream;
 #define GPS_BWD(D)                                                                                                 \
     preprocess_bwd_kernel<D><<<g, b, lds, s>>>(in, ad, radii, conics, v_means2d, v_conics, v_colors, v_opacities,         \
                                                reinterpret_cast<const float4*>(v_rows), v_means,                         \
-                                               v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest)
+                                               v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest, nf)
     switch (sh_degree) {
         case 0: GPS_BWD(0); break;
         case 1: GPS_BWD(1); break;
@@ -459,12 +524,13 @@ int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const
     static_assert(BIN_BLOCK == 256, "the binning's per-block sums are per preprocessing workgroup");
     dim3 g(gps_div_up(N, 256)), b(256);
     hipStream_t s = (hipStream_t)stream;
+    const FwdOut w = {radii, means2d, depths, conics, colors, opacities, recs};
     switch (sh_degree) {
-        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
-        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
-        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
-        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
-        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, radii, means2d, depths, conics, colors, opacities, recs, cnt, zg); break;
+        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, w, cnt, zg); break;
+        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, w, cnt, zg); break;
+        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, w, cnt, zg); break;
+        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, w, cnt, zg); break;
+        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, w, cnt, zg); break;
     }
     GPS_LAUNCH_CHECK();
     return GPS_OK;

@@ -40,6 +40,7 @@ __host__ __device__ inline void cam_from_arrays(const float* viewmat, const floa
 struct Sym3 { float xx, xy, xz, yy, yz, zz; };
 
 __device__ __forceinline__ void quat_to_R(const float q[4], float R[9], float& inv_norm) {
+#pragma clang fp contract(off)   // (inlined into several kernels: unfused mul / add give every copy the same bits, see project_gaussian)
     float w = q[0], x = q[1], y = q[2], z = q[3];
     inv_norm = rsqrtf(x * x + y * y + z * z + w * w);
     x *= inv_norm; y *= inv_norm; z *= inv_norm; w *= inv_norm;
@@ -51,6 +52,7 @@ __device__ __forceinline__ void quat_to_R(const float q[4], float R[9], float& i
 
 // M = A * diag(s)  (3x3 row-major), cov = M M^T (symmetric)
 __device__ __forceinline__ Sym3 outer_MMt(const float M[9]) {
+#pragma clang fp contract(off)   // (inlined into several kernels: unfused mul / add give every copy the same bits, see project_gaussian)
     Sym3 c;
     c.xx = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
     c.xy = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
@@ -71,6 +73,7 @@ struct Proj {
 // camera-space covariance cov_c = (R_cam Rq S)(R_cam Rq S)^T computed as one
 // 3x3 product T = R_cam * Rq then scaled columns.
 __device__ __forceinline__ void gaussian_cov_cam(const Cam& cam, const float q[4], const float s[3], Sym3& cov_c) {
+#pragma clang fp contract(off)   // (inlined into several kernels: unfused mul / add give every copy the same bits, see project_gaussian)
     float Rq[9], inv_norm;
     quat_to_R(q, Rq, inv_norm);
     float T[9];
@@ -84,6 +87,7 @@ __device__ __forceinline__ void gaussian_cov_cam(const Cam& cam, const float q[4
 
 __device__ __forceinline__ void persp_jacobian(const Cam& cam, float x, float y, float z, float& j00, float& j02,
                                                float& j11, float& j12, float& tx, float& ty) {
+#pragma clang fp contract(off)   // (inlined into several kernels: unfused mul / add give every copy the same bits, see project_gaussian)
     float rz = 1.f / z, rz2 = rz * rz;
     tx = z * fminf(cam.lim_x_pos, fmaxf(-cam.lim_x_neg, x * rz));
     ty = z * fminf(cam.lim_y_pos, fmaxf(-cam.lim_y_neg, y * rz));
@@ -92,8 +96,14 @@ __device__ __forceinline__ void persp_jacobian(const Cam& cam, float x, float y,
 }
 
 // Full forward projection of one Gaussian.  Returns radius==0 when culled.
+// The forward projection (this function, its helpers and pack_record) is compiled WITHOUT fp contraction: it is inlined into the
+// forward kernel, the operator-level kernel and the backward kernel's next-iteration tail (splat_fused.hip), and with contraction
+// the compiler fused different mul / add pairs in each copy -- conics differed in the last bit between the stand-alone forward
+// and the tail (tools/probe/prefetch_diff.py).  Plain IEEE operations give every copy the same bits (and are what the CPU oracle,
+// built without FMA, computes).
 __device__ __forceinline__ Proj project_gaussian(const Cam& cam, const float p[3], const float q[4], const float s[3],
                                                  float eps2d, float near_plane, float far_plane, float radius_clip) {
+#pragma clang fp contract(off)   // (inlined into several kernels: unfused mul / add give every copy the same bits, see project_gaussian)
     Proj o; o.radius = 0; o.mx = o.my = o.z = o.ca = o.cb = o.cc = 0.f;
     float x = cam.R[0] * p[0] + cam.R[1] * p[1] + cam.R[2] * p[2] + cam.t[0];
     float y = cam.R[3] * p[0] + cam.R[4] * p[1] + cam.R[5] * p[2] + cam.t[1];
@@ -240,6 +250,7 @@ __device__ __forceinline__ void project_gaussian_vjp(const Cam& cam, const float
 // (det = ca*cc - cb^2); they are inflated by 1 % + 0.01 px so that rounding of exp can never exclude a contributing
 // pixel, and an empty box (hi < lo) is stored when opac < 1/255 or the Gaussian is culled.
 __device__ __forceinline__ void pack_record(const Proj& o, float r, float g, float b, float opac, float4* rec) {
+#pragma clang fp contract(off)   // (inlined into several kernels: unfused mul / add give every copy the same bits, see project_gaussian)
     float ex = -1.f, ey = -1.f;
     if (o.radius > 0) {
         const float tau = logf(255.f * opac);

@@ -20,7 +20,8 @@ static bool strips_on(const gps_splat_step* a) {
 // projection + binning + forward rasterizer; `compose` / `zero`: the train step's compose + L1 and gradient zero-fill riding
 // along in those kernels (nullptr: the plain render; zero != nullptr also marks a train step: the binning then writes the
 // backward's class lists)
-static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose, const gps::ZeroGrads* zero, gps_stream stream) {
+static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose, const gps::ZeroGrads* zero, gps_stream stream,
+                        bool preprocessed = false) {
     GPS_REQUIRE(a != nullptr);
     const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
     int r;
@@ -30,10 +31,13 @@ static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose,
     gps::BinCountOut cnt;
     r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, sb, &cnt);
     if (r != GPS_OK) return r;
-    r = gps::preprocess_fwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
-                                   a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
-                                   a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
-                                   a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, zero, stream);
+    // (preprocessed: the previous train step's backward kernel has already run this forward -- gps_splat_step::next_viewmat)
+    GPS_REQUIRE(!preprocessed || sb);
+    r = preprocessed ? GPS_OK
+                     : gps::preprocess_fwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
+                                                  a->sh_rest, a->viewmat, a->Kmat, a->cam_pos, a->width, a->height, a->eps2d,
+                                                  a->near_plane, a->far_plane, a->radius_clip, a->max_gs_radii, a->radii, a->means2d,
+                                                  a->depths, a->conics, a->colors, a->opacities, a->records, &cnt, zero, stream);
     if (r != GPS_OK) {
         if (sb) (void)gps::sb_tables_clear(cnt.sb, stream);   // (the kernel may have added counts that no scan will clear)
         return r;
@@ -63,6 +67,15 @@ static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose,
 
 int gps_splat_render(const gps_splat_step* a, gps_stream stream) { return render_chain(a, nullptr, nullptr, stream); }
 
+int gps_splat_can_prefetch(const gps_splat_step* a) {
+    if (!a || a->N <= 0 || a->K <= 1 || a->fuse_sh_rest_adam < 2 || !strips_on(a)) return 0;
+    // the backward kernel's workgroup (splat_fused.hip: GPS_FUSED_ADAM_THREADS, halved until two row tiles fit 64 KB) must divide
+    // the binning's 256-Gaussian blocks and its gradient tile must hold the binning's histogram
+    int threads = 128;
+    while (threads > 64 && (size_t)threads * (a->K - 1) * 3 * 4 * 2 > 65536) threads >>= 1;
+    return (size_t)threads * (a->K - 1) * 3 * 4 >= (size_t)(gps::SB_MAX_TILES + gps::BWD_KEYS) * 4 ? 1 : 0;
+}
+
 int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stream) {
     GPS_REQUIRE(a != nullptr && adam_step >= 1);
     GPS_REQUIRE(a->gt_rgb && a->loss && a->v_render_colors && a->v_render_alphas);
@@ -78,7 +91,9 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
     // group kernel: its four accumulator arrays are zero-filled by the preprocessing kernel; strips: every row is a plain store
     gps::ZeroGrads zg = {a->v_means2d, a->v_conics, a->v_colors, a->v_opacities};
     gps::ZeroGrads no_zero = {};
-    int r = render_chain(a, fused_fwd ? &fc : nullptr, strips ? &no_zero : &zg, stream);
+    GPS_REQUIRE(!a->preprocessed || gps_splat_can_prefetch(a));
+    GPS_REQUIRE(!a->next_viewmat || (a->next_Kmat && a->next_cam_pos && gps_splat_can_prefetch(a)));
+    int r = render_chain(a, fused_fwd ? &fc : nullptr, strips ? &no_zero : &zg, stream, a->preprocessed != 0);
     if (r != GPS_OK) return r;
     if (!fused_fwd) {
         r = gps_compose_l1(a->width, a->height, a->render_colors, a->weight_sum, a->base_color, nullptr, a->gt_rgb, a->rgb,
@@ -104,6 +119,16 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
         {a->opac_logit, a->g_opac_logit, a->m_opac_logit, a->v_opac_logit, (int64_t)a->N, a->lr[5]},
         {a->sh_rest, a->g_sh_rest, a->m_sh_rest, a->v_sh_rest, (int64_t)a->N * (a->K - 1) * 3, a->lr[4]},
     };
+    // the next iteration's preprocessing in this kernel's tail: its binning count targets are the same carve as this iteration's
+    gps::BinCountOut next_cnt;
+    gps::NextForward next = {};
+    if (a->next_viewmat) {
+        const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
+        r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, true, &next_cnt);
+        if (r != GPS_OK) return r;
+        next = {a->next_viewmat, a->next_Kmat, a->next_cam_pos, a->max_gs_radii, a->near_plane, a->far_plane, a->radius_clip,
+                a->radii, a->means2d, a->depths, a->conics, a->colors, a->opacities, a->records, &next_cnt};
+    }
     float sstep[5];
     for (int k = 0; k < 5; k++) sstep[k] = gps::adam_scalars(seg[k].lr, a->beta1, a->beta2, a->adam_eps, adam_step).step_size;
     r = gps::preprocess_bwd_launch(a->N, a->K, a->sh_degree, a->means, a->log_scales, a->quats, a->opac_logit, a->sh_dc,
@@ -113,7 +138,8 @@ int gps_splat_train_step(const gps_splat_step* a, int adam_step, gps_stream stre
                                    fuse ? nullptr : a->g_sh_rest, fuse ? a->sh_rest : nullptr,
                                    fuse ? a->m_sh_rest : nullptr, fuse ? a->v_sh_rest : nullptr,
                                    gps::adam_scalars(a->lr[4], a->beta1, a->beta2, a->adam_eps, adam_step),
-                                   all ? seg : nullptr, all ? sstep : nullptr, stream, strips ? a->v_rows : nullptr);
+                                   all ? seg : nullptr, all ? sstep : nullptr, stream, strips ? a->v_rows : nullptr,
+                                   a->next_viewmat ? &next : nullptr);
     if (r != GPS_OK || all) return r;
     return gps_adam_step(seg, fuse ? 5 : 6, a->beta1, a->beta2, a->adam_eps, adam_step, stream);
 }

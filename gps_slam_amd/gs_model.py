@@ -318,6 +318,9 @@ class RawGaussianModel:
         st.ref_depth_clamped = ref_depth_clamped.data_ptr()
         st.base_color = base_color.data_ptr()
         st.gt_rgb = 0 if gt_rgb is None else gt_rgb.data_ptr()
+        st.next_viewmat = st.next_Kmat = st.next_cam_pos = None
+        st.preprocessed = 0
+        self._prefetched = None   # (whatever runs on the step buffers invalidates a prefetched forward; train_step re-arms it)
         self._keep = (ref_depth_clamped, base_color, gt_rgb)  # alive until the next call
 
     def _stream(self):
@@ -364,13 +367,24 @@ class RawGaussianModel:
         N = self.getGaussianNum()
         return [t[:N] for t in self._opt["g"]]
 
-    def train_step(self, cam, ref_depth, base_color, gt_rgb, ref_depth_clamped=None):
+    def train_step(self, cam, ref_depth, base_color, gt_rgb, ref_depth_clamped=None, next_cam=None):
         """model.forward -> computeLoss -> loss.backward -> optimizersStep/ZeroGrad (slam_pipeline.cpp:247-254) as one
-        C-ABI call (gps_splat_train_step).  The L1 loss accumulates in a device scalar (loss_sum())."""
+        C-ABI call (gps_splat_train_step).  The L1 loss accumulates in a device scalar (loss_sum()).
+        next_cam: the camera of the NEXT train_step call (same size) -- its preprocessing forward then runs in the tail of this
+        step's backward kernel (gps_splat_step::next_viewmat) and the next call skips its preprocessing launch, provided it is
+        called with that camera and nothing else has used the model in between; ignored where the step cannot prefetch."""
         if ref_depth_clamped is None:
             ref_depth_clamped = self.clamp_ref_depth(ref_depth)
         st = self._step_struct(cam.width, cam.height)
+        c = cam.toGPU()
+        key = (c["viewmat"].data_ptr(), c["K"].data_ptr(), c["cam_pos"].data_ptr(), int(st.N), cam.width, cam.height)
+        skip = getattr(self, "_prefetched", None) == key
         self._bind_camera(st, cam, ref_depth_clamped, base_color, gt_rgb)
+        st.preprocessed = 1 if skip else 0
+        if next_cam is not None and (next_cam.width, next_cam.height) == (cam.width, cam.height) and lib.gps_splat_can_prefetch(C.byref(st)):
+            n = next_cam.toGPU()
+            st.next_viewmat, st.next_Kmat, st.next_cam_pos = n["viewmat"].data_ptr(), n["K"].data_ptr(), n["cam_pos"].data_ptr()
+            self._prefetched = (n["viewmat"].data_ptr(), n["K"].data_ptr(), n["cam_pos"].data_ptr(), int(st.N), cam.width, cam.height)
         o = self._opt
         o["step"] += 1
         check(lib.gps_splat_train_step(C.byref(st), o["step"], self._stream()), "gps_splat_train_step")

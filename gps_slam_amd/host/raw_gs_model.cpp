@@ -143,6 +143,10 @@ void RawGaussianModel::bindCamera(gps_splat_step& st, const Camera& cam, const t
     st.ref_depth_clamped = fptr(ref_depth_clamped);
     st.base_color = fptr(base_color);
     st.gt_rgb = gt_rgb.defined() ? fptr(gt_rgb) : nullptr;
+    // whatever runs on the step buffers invalidates a forward the last trainStep() ran ahead (trainStep re-arms it itself)
+    st.next_viewmat = st.next_Kmat = st.next_cam_pos = nullptr;
+    st.preprocessed = 0;
+    prefetched_ = PrefetchKey{};
     keep_ = {ref_depth_clamped, base_color, gt_rgb};
 }
 
@@ -421,14 +425,23 @@ void RawGaussianModel::optimizersStep() {
 }
 
 void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color,
-                                 const torch::Tensor& ref_depth_clamped) {
+                                 const torch::Tensor& ref_depth_clamped, const Camera* next_cam) {
     TORCH_CHECK(have_opt_ && adam_cap_ == opt_gs_params.capacity(), "initOptimizers() first");
     TORCH_CHECK(cam.image.defined() && cam.image.is_cuda(), "camera image must be on the device");
     applyPendingPrunes();
     auto clamped = ref_depth_clamped.defined() ? ref_depth_clamped : clampRefDepth(ref_depth);
     gps_splat_step& st = stepStruct(cam.width, cam.height);
-    bindCamera(st, cam, clamped, base_color, cam.image);
+    // did the previous trainStep() run this camera's preprocessing forward in its backward kernel's tail (next_cam)?
+    const PrefetchKey mine{cam.on_device() ? cam.viewmat() : nullptr, cam.on_device() ? cam.Kmat() : nullptr,
+                           cam.on_device() ? cam.cam_pos() : nullptr, (int64_t)st.N, cam.width, cam.height};
+    const bool skip = prefetched_.viewmat != nullptr && prefetched_ == mine;
+    bindCamera(st, cam, clamped, base_color, cam.image);   // (clears prefetched_)
     st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 2 : 0;  // all six tensors stepped inside the backward kernel
+    st.preprocessed = skip ? 1 : 0;
+    if (next_cam && next_cam->on_device() && next_cam->width == cam.width && next_cam->height == cam.height && gps_splat_can_prefetch(&st)) {
+        st.next_viewmat = next_cam->viewmat(); st.next_Kmat = next_cam->Kmat(); st.next_cam_pos = next_cam->cam_pos();
+        prefetched_ = PrefetchKey{st.next_viewmat, st.next_Kmat, st.next_cam_pos, (int64_t)st.N, cam.width, cam.height};
+    }
     adam_step_ += 1;
     check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");
     nextLaunchId();

@@ -29,8 +29,11 @@ public:
                            const torch::Tensor& mask = torch::Tensor());
 
     // One optimise iteration as a single C-ABI call; the L1 loss accumulates in lossSum().
+    // next_cam (optional): the camera of the NEXT trainStep() -- its preprocessing forward then runs in the tail of this step's
+    // backward + Adam kernel (gps_splat_step::next_viewmat) and that next call skips its preprocessing launch, provided it comes
+    // with exactly that camera and nothing else has used the model in between (any other launch on the step buffers disarms it).
     void trainStep(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color,
-                   const torch::Tensor& ref_depth_clamped = torch::Tensor());
+                   const torch::Tensor& ref_depth_clamped = torch::Tensor(), const Camera* next_cam = nullptr);
     torch::Tensor lossSum() const { return B_.loss; }
 
     // Allocate everything an iteration at this image size needs (intermediates, Adam state) now instead of lazily on the
@@ -113,6 +116,16 @@ public:
     // and refuses to run if another launch has replaced them in between.
     int64_t launchId() const { return launch_id_; }
     int64_t nextLaunchId() { return ++launch_id_; }
+    // the forward the last trainStep() ran ahead for its next_cam: camera arrays, Gaussian count, image size (viewmat == nullptr: none)
+    struct PrefetchKey {
+        const float *viewmat = nullptr, *Kmat = nullptr, *cam_pos = nullptr;
+        int64_t N = 0;
+        int W = 0, H = 0;
+        bool operator==(const PrefetchKey& o) const {
+            return viewmat == o.viewmat && Kmat == o.Kmat && cam_pos == o.cam_pos && N == o.N && W == o.W && H == o.H;
+        }
+    };
+    PrefetchKey prefetched_;
 
 protected:
     Buffers B_;

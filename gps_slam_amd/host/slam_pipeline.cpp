@@ -407,16 +407,26 @@ void SLAMPipeline::localOptimizeBegin() {
     if (model->getGaussianNum() == 0) return;
     model->initOptimizers(-1, scene_scale);
     opt_loader_.reset(new RandomSelector<Camera>(opt_cam_list, rng_));
+    opt_peek_valid_ = false;
     opt_pending_ = local_opt_iters;
 }
 
 // the next `count` iterations of the current localOptimize (cameras drawn in the same order as the all-at-once loop)
 void SLAMPipeline::optimizeIterations(int count) {
     for (; count > 0 && opt_pending_ > 0; count--, opt_pending_--) {
-        auto pick = opt_loader_->getNext();
+        // the camera of THIS iteration was drawn one iteration early (same draws in the same order), so that the previous
+        // iteration's backward kernel could run its preprocessing forward in its tail (RawGaussianModel::trainStep next_cam)
+        auto pick = opt_peek_valid_ ? opt_peek_ : opt_loader_->getNext();
+        opt_peek_valid_ = false;
         const Camera& cam = *pick.second;
         TensorDict& rc = opt_raycast_list[pick.first];
         if (pick.first < (int)opt_raycast_events_.size()) waitRaycast(opt_raycast_events_[pick.first]);
+        const Camera* next_cam = nullptr;
+        if (prefetch_next_preprocess && opt_pending_ > 1 && !(ssim_weight > 0 || depth_weight > 0)) {
+            opt_peek_ = opt_loader_->getNext();
+            opt_peek_valid_ = true;
+            next_cam = opt_peek_.second;
+        }
         if (ssim_weight > 0 || depth_weight > 0) {
             // losses beyond L1: the reference's own sequence (slam_pipeline.cpp:247-254) through the autograd route
             Config wc;
@@ -427,7 +437,7 @@ void SLAMPipeline::optimizeIterations(int count) {
             model->optimizersStep();
             model->optimizersZeroGrad();
         } else {
-            model->trainStep(cam, rc.at("depth_map"), rc.at("color_map"), rc.at("depth_map_clamped"));
+            model->trainStep(cam, rc.at("depth_map"), rc.at("color_map"), rc.at("depth_map_clamped"), next_cam);
         }
         stats.opt_iters++;
     }

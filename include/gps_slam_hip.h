@@ -469,7 +469,19 @@ typedef struct {
     float *v_rows, *pix2;
     int32_t *cls_ids, *cls_counts;
     int64_t cls_stride;
+    /* Cross-iteration fusion inside an optimise loop (optional; gps_splat_can_prefetch() says whether this step supports it).
+     * next_viewmat / next_Kmat / next_cam_pos != NULL in gps_splat_train_step: the camera of the NEXT iteration -- its
+     * preprocessing forward (projection, SH, records, the binning's count pass) runs in the tail of this iteration's backward +
+     * Adam kernel, on the parameters that kernel has just stepped and still holds, instead of re-reading them in a launch of its
+     * own.  The caller then sets `preprocessed` != 0 on that next call (same N, same camera arrays, nothing else run on these
+     * buffers in between): its preprocessing launch is skipped.  Same arithmetic on the same values as the separate launch. */
+    const float *next_viewmat, *next_Kmat, *next_cam_pos;
+    int32_t preprocessed;
 } gps_splat_step;
+
+/* != 0: gps_splat_train_step(a) can run the next iteration's preprocessing in its tail (strip backward + superblock binning in
+ * use, all six tensors stepped inside the backward kernel, K > 1, a workgroup / LDS tile that holds the binning's histogram). */
+GPS_API int gps_splat_can_prefetch(const gps_splat_step *a);
 
 /* gesForward up to the rasterizer (preprocess -> binning -> ges forward): fills render_colors / weight_sum. */
 GPS_API int gps_splat_render(const gps_splat_step *a, gps_stream stream);

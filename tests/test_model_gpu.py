@@ -132,6 +132,73 @@ def test_forward_launch_order_is_a_permutation_by_list_length_and_changes_nothin
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][1].abs().sum() > 0
 
 
+def _two_cameras(W, H, seed):
+    from gps_slam_amd.gs_model import Camera
+    cams = []
+    for k in range(2):
+        c2w, K = scenes.default_camera(W, H, seed=seed + k)
+        cams.append(Camera(k, W, H, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), c2w, device=DEV))
+    return cams
+
+
+@pytest.mark.parametrize("N,W,H", [(20000, 320, 240), (70001, 640, 480)])
+def test_next_iterations_preprocess_in_the_backward_kernel_changes_nothing(N, W, H):
+    """gps_splat_step::next_viewmat: the NEXT iteration's preprocessing forward runs in the tail of this iteration's backward +
+    Adam kernel (on the parameters that kernel has just stepped) and the next call skips its preprocessing launch.  Six
+    iterations alternating between two cameras, with and without it, on twin models: every per-Gaussian intermediate of the last
+    forward, the binning's lists, the parameters and both Adam moments after every step are EQUAL (same arithmetic on the same
+    values; N = 70,001: a last workgroup with one Gaussian, two workgroups of the backward kernel per 256-Gaussian binning block)."""
+    from gps_slam_amd.gs_model import SLAMGaussianModel
+    from gps_slam_amd._lib import lib
+    import ctypes as C
+    g = scenes.random_gaussians(N, seed=21, scale_range=(0.004, 0.03))
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    models = []
+    for _ in range(2):
+        m = SLAMGaussianModel(dict(fuse_sh_rest_adam=2), device=DEV)
+        m.add_params(dict(means=T(g["means"]), scales=T(g["log_scales"]), quats=T(g["quats"]), featuresDc=T(g["sh"][:, 0].copy()),
+                          featuresRest=T(g["sh"][:, 1:].copy()), opacities=T(g["opac_logit"])))
+        m.initOptimizers(-1, 1.0)
+        models.append(m)
+    cams = _two_cameras(W, H, seed=4)
+    gen = torch.Generator().manual_seed(9)
+    gts = [torch.rand((H, W, 3), generator=gen).to(DEV) for _ in range(2)]
+    base = torch.rand((H, W, 3), generator=gen).to(DEV)
+    ref = (torch.rand((H, W, 1), generator=gen) * 4).to(DEV)
+    seq = [0, 1, 0, 0, 1, 0]
+    a, b = models
+    held = None
+    for it, k in enumerate(seq):
+        nxt = cams[seq[it + 1]] if it + 1 < len(seq) else None
+        a.train_step(cams[k], ref, base, gts[k], next_cam=nxt)
+        if nxt is not None:
+            assert a._prefetched is not None and lib.gps_splat_can_prefetch(C.byref(a._step)) == 1
+        b.train_step(cams[k], ref, base, gts[k])
+        torch.cuda.synchronize()
+        if it > 0:
+            assert int(a._step.preprocessed) == 1 and int(b._step.preprocessed) == 0
+        for name in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"):
+            assert torch.equal(getattr(a.opt_gs_params, name), getattr(b.opt_gs_params, name)), (it, name)
+        for k2 in range(6):
+            assert torch.equal(a._opt["m"][k2][:N], b._opt["m"][k2][:N]) and torch.equal(a._opt["v"][k2][:N], b._opt["v"][k2][:N]), (it, k2)
+        # the per-Gaussian intermediates: `a` holds the NEXT iteration's already (written by this step's backward kernel), `b` gets
+        # them at the start of its next step -- compare a's of step it - 1 with b's of step it
+        inter = ("radii", "means2d", "depths", "conics", "colors", "opacities", "records", "tiles_per_gauss")
+        if it > 0:
+            for name in inter:
+                assert torch.equal(held[name], b._B[name][:N]), (it, name)
+        held = {name: a._B[name][:N].clone() for name in inter}
+        ni = int(a._B["counts"][0])
+        assert ni == int(b._B["counts"][0]) and torch.equal(a._B["flatten_ids"][:ni], b._B["flatten_ids"][:ni]), it
+        assert torch.equal(a._B["render_colors"], b._B["render_colors"]), it
+    torch.testing.assert_close(a.loss_sum(), b.loss_sum(), rtol=1e-5, atol=0)   # (a sum of per-tile float atomics: order-dependent)
+    # anything else on the step buffers disarms the prefetch: a render in between, then a step -> the step preprocesses itself
+    a.train_step(cams[0], ref, base, gts[0], next_cam=cams[1])
+    a.forward(cams[1], ref, base)
+    a.train_step(cams[1], ref, base, gts[1])
+    assert int(a._step.preprocessed) == 0
+
+
 def test_optimisation_reduces_the_loss():
     model, cam, ref, base, gt = _model_and_maps(N=30000, seed=5)
     model.initOptimizers(-1, 3.3)
