@@ -149,6 +149,7 @@ PROTOTYPES = {
     "gps_compact_mask": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "gps_gather_pixels": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_splat_can_prefetch": (i32, [C.POINTER(SplatStep)]),
+    "gps_splat_discard_prefetch": (i32, [C.POINTER(SplatStep), vp]),
     "gps_splat_render": (i32, [C.POINTER(SplatStep), vp]),
     "gps_splat_train_step": (i32, [C.POINTER(SplatStep), i32, vp]),
 }

@@ -67,6 +67,17 @@ static int render_chain(const gps_splat_step* a, const gps::FwdCompose* compose,
 
 int gps_splat_render(const gps_splat_step* a, gps_stream stream) { return render_chain(a, nullptr, nullptr, stream); }
 
+int gps_splat_discard_prefetch(const gps_splat_step* a, gps_stream stream) {
+    GPS_REQUIRE(a != nullptr && a->workspace != nullptr);
+    // the prefetched forward has added its counts to the superblock binning's persistent tables, which only the scan of the step
+    // that consumes it would clear: back to "zero between launches"
+    const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
+    gps::BinCountOut cnt;
+    const int r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, true, &cnt);
+    if (r != GPS_OK) return r;
+    return gps::sb_tables_clear(cnt.sb, stream);
+}
+
 int gps_splat_can_prefetch(const gps_splat_step* a) {
     if (!a || a->N <= 0 || a->K <= 1 || a->fuse_sh_rest_adam < 2 || !strips_on(a)) return 0;
     // the backward kernel's workgroup (splat_fused.hip: GPS_FUSED_ADAM_THREADS, halved until two row tiles fit 64 KB) must divide

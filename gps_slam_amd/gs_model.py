@@ -312,7 +312,10 @@ class RawGaussianModel:
                 st.lr[j] = float(o["lrs"][j])
         return st
 
-    def _bind_camera(self, st, cam, ref_depth_clamped, base_color, gt_rgb):
+    def _bind_camera(self, st, cam, ref_depth_clamped, base_color, gt_rgb, consumes_prefetch=False):
+        if getattr(self, "_prefetched", None) is not None and not consumes_prefetch:
+            # a forward was run ahead for a train step that is not coming: its counts must leave the binning's tables
+            check(lib.gps_splat_discard_prefetch(C.byref(st), self._stream()), "gps_splat_discard_prefetch")
         c = cam.toGPU()
         st.viewmat, st.Kmat, st.cam_pos = c["viewmat"].data_ptr(), c["K"].data_ptr(), c["cam_pos"].data_ptr()
         st.ref_depth_clamped = ref_depth_clamped.data_ptr()
@@ -379,7 +382,7 @@ class RawGaussianModel:
         c = cam.toGPU()
         key = (c["viewmat"].data_ptr(), c["K"].data_ptr(), c["cam_pos"].data_ptr(), int(st.N), cam.width, cam.height)
         skip = getattr(self, "_prefetched", None) == key
-        self._bind_camera(st, cam, ref_depth_clamped, base_color, gt_rgb)
+        self._bind_camera(st, cam, ref_depth_clamped, base_color, gt_rgb, consumes_prefetch=skip)
         st.preprocessed = 1 if skip else 0
         if next_cam is not None and (next_cam.width, next_cam.height) == (cam.width, cam.height) and lib.gps_splat_can_prefetch(C.byref(st)):
             n = next_cam.toGPU()

@@ -135,8 +135,10 @@ std::pair<int64_t, int64_t> RawGaussianModel::checkBinningCapacity() {
 }
 
 void RawGaussianModel::bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
-                                  const torch::Tensor& base_color, const torch::Tensor& gt_rgb) {
+                                  const torch::Tensor& base_color, const torch::Tensor& gt_rgb, bool consumes_prefetch) {
     TORCH_CHECK(cam.on_device(), "Camera::toGPU() must run before the camera is rendered (slam_pipeline.cpp:84)");
+    if (prefetched_.viewmat != nullptr && !consumes_prefetch)   // a forward run ahead for a train step that is not coming
+        check(gps_splat_discard_prefetch(&st, current_stream()), "gps_splat_discard_prefetch");
     check_f32_dev(ref_depth_clamped, "ref_depth");
     check_f32_dev(base_color, "base_color");
     st.viewmat = cam.viewmat(); st.Kmat = cam.Kmat(); st.cam_pos = cam.cam_pos();
@@ -435,7 +437,7 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
     const PrefetchKey mine{cam.on_device() ? cam.viewmat() : nullptr, cam.on_device() ? cam.Kmat() : nullptr,
                            cam.on_device() ? cam.cam_pos() : nullptr, (int64_t)st.N, cam.width, cam.height};
     const bool skip = prefetched_.viewmat != nullptr && prefetched_ == mine;
-    bindCamera(st, cam, clamped, base_color, cam.image);   // (clears prefetched_)
+    bindCamera(st, cam, clamped, base_color, cam.image, skip);   // (clears prefetched_)
     st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 2 : 0;  // all six tensors stepped inside the backward kernel
     st.preprocessed = skip ? 1 : 0;
     if (next_cam && next_cam->on_device() && next_cam->width == cam.width && next_cam->height == cam.height && gps_splat_can_prefetch(&st)) {

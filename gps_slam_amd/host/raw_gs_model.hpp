@@ -109,7 +109,7 @@ public:
     };
     gps_splat_step& stepStruct(int W, int H);
     void bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
-                    const torch::Tensor& base_color, const torch::Tensor& gt_rgb);
+                    const torch::Tensor& base_color, const torch::Tensor& gt_rgb, bool consumes_prefetch = false);
     Buffers& buffers() { return B_; }
     // Every launch that overwrites the per-launch intermediates (radii, means2d, conics, colors, the tile / group tables, the
     // render) gets a new id.  The grad-mode forward stamps it into its autograd node; its backward reads those intermediates

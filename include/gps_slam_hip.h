@@ -482,6 +482,10 @@ typedef struct {
 /* != 0: gps_splat_train_step(a) can run the next iteration's preprocessing in its tail (strip backward + superblock binning in
  * use, all six tensors stepped inside the backward kernel, K > 1, a workgroup / LDS tile that holds the binning's histogram). */
 GPS_API int gps_splat_can_prefetch(const gps_splat_step *a);
+/* A prefetched forward that will NOT be consumed (the caller runs something else on these buffers before the train step it was
+ * meant for) has left its counts in the binning's persistent tables: this clears them (two memsets).  Hosts call it when they
+ * disarm a pending prefetch; a prefetch consumed by the next gps_splat_train_step(preprocessed != 0) needs nothing. */
+GPS_API int gps_splat_discard_prefetch(const gps_splat_step *a, gps_stream stream);
 
 /* gesForward up to the rasterizer (preprocess -> binning -> ges forward): fills render_colors / weight_sum. */
 GPS_API int gps_splat_render(const gps_splat_step *a, gps_stream stream);

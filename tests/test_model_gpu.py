@@ -193,10 +193,19 @@ def test_next_iterations_preprocess_in_the_backward_kernel_changes_nothing(N, W,
         assert torch.equal(a._B["render_colors"], b._B["render_colors"]), it
     torch.testing.assert_close(a.loss_sum(), b.loss_sum(), rtol=1e-5, atol=0)   # (a sum of per-tile float atomics: order-dependent)
     # anything else on the step buffers disarms the prefetch: a render in between, then a step -> the step preprocesses itself
+    # (and returns the binning's tables to zero -- the forward that was run ahead had added its counts to them)
     a.train_step(cams[0], ref, base, gts[0], next_cam=cams[1])
-    a.forward(cams[1], ref, base)
+    ra = a.forward(cams[1], ref, base)["rgb"].clone()
     a.train_step(cams[1], ref, base, gts[1])
     assert int(a._step.preprocessed) == 0
+    b.train_step(cams[0], ref, base, gts[0])
+    rb = b.forward(cams[1], ref, base)["rgb"].clone()
+    b.train_step(cams[1], ref, base, gts[1])
+    torch.cuda.synchronize()
+    assert torch.equal(ra, rb)
+    for name in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"):
+        assert torch.equal(getattr(a.opt_gs_params, name), getattr(b.opt_gs_params, name)), name
+    assert int(a._B["counts"][2]) == 0 and int(b._B["counts"][2]) == 0   # no binning overflow on either side
 
 
 def test_optimisation_reduces_the_loss():
