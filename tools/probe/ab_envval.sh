@@ -3,7 +3,7 @@ VAR=$1; VALS=$2; N=${3:-3}
 mkdir -p gpurun_out
 for i in $(seq 1 $N); do for v in $VALS; do
   if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
-  timeout 300 python bench.py --steps 20 --warmup 5 --windows 5 --no-cpu-baseline --no-oracle-psnr > gpurun_out/abval_${v}_$i.log 2>&1
+  timeout 300 python bench.py --steps 20 --warmup 5 --windows 5 --no-cpu-baseline --no-oracle-psnr --no-other-configs > gpurun_out/abval_${v}_$i.log 2>&1
 done; done
 unset $VAR
 VALS="$VALS" N=$N python - <<'PY'
