@@ -122,9 +122,10 @@ PYBIND11_MODULE(_host, m) {
             return s.computeLoss(r, cam, config_from_dict(w));
         })
         .def("trainStep", [](SLAMGaussianModel& s, const Camera& cam, const torch::Tensor& ref_depth,
-                             const torch::Tensor& base_color, c10::optional<torch::Tensor> clamped) {
-            s.trainStep(cam, ref_depth, base_color, clamped.has_value() ? *clamped : torch::Tensor());
-        }, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"), py::arg("ref_depth_clamped") = py::none())
+                             const torch::Tensor& base_color, c10::optional<torch::Tensor> clamped, const Camera* next_cam) {
+            s.trainStep(cam, ref_depth, base_color, clamped.has_value() ? *clamped : torch::Tensor(), next_cam);
+        }, py::arg("cam"), py::arg("ref_depth"), py::arg("base_color"), py::arg("ref_depth_clamped") = py::none(),
+             py::arg("next_cam") = (const Camera*)nullptr)
         .def("reserveWorkspace", &SLAMGaussianModel::reserveWorkspace)
         .def("checkBinningCapacity", &SLAMGaussianModel::checkBinningCapacity)
         .def("adamState", [](SLAMGaussianModel& s) { return s.adamState(); })
