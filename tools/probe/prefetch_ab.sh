@@ -1,3 +1,5 @@
+# Kernel-level A/B of the cross-iteration fusion (GPS_BENCH_PREFETCH=0/1): rocprofv3 kernel trace of the sequential schedule, the
+# preprocessing / rasterizer rows of both runs (run ON the GPU box: bash tools/probe/prefetch_ab.sh)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for v in 0 1; do
   rm -rf /tmp/pf_$v
