@@ -508,6 +508,14 @@ int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss,
     return GPS_OK;
 }
 
+int isect_workspace_tables(void* workspace, int64_t workspace_bytes, SbTables* t) {
+    GPS_REQUIRE(workspace && t && workspace_bytes >= (int64_t)align_up(gps::sb_tables_bytes()));
+    Workspace w;
+    carve(&w, (char*)workspace, 0, 1);   // (the tables sit first, at an offset that does not depend on N)
+    sb_tables_carve(w.sb_region, t);
+    return GPS_OK;
+}
+
 int isect_tiles_no_depth_counted(int N, const float* means2d, const int32_t* radii, int tile_size, int tile_width,
                                  int tile_height, int64_t isect_capacity, int64_t group_capacity, int32_t* tiles_per_gauss,
                                  int32_t* flatten_ids, int32_t* group_gs_ids, int32_t* group_starts, int32_t* tile_offsets,

@@ -132,6 +132,8 @@ int isect_count_targets(int N, int64_t isect_capacity, int32_t* tiles_per_gauss,
 // splat_bin_sb.hip: bytes of the superblock tables; scan + scatter behind a preprocessing kernel that filled `cnt.sb`.
 // cls_ids / cls_counts may be NULL (render only).  counts = {n_isects, 0, overflow (sticky), n_visible}.
 size_t sb_tables_bytes();
+// the persistent tables of a workspace whatever N it is used with next (clearing them after a discarded prefetch)
+int isect_workspace_tables(void* workspace, int64_t workspace_bytes, struct SbTables* t);
 void sb_tables_carve(char* base, SbTables* t);
 int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, const BinCountOut& cnt, int64_t isect_capacity,
                            const int32_t* tiles_per_gauss, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* counts,

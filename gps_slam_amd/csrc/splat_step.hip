@@ -71,11 +71,11 @@ int gps_splat_discard_prefetch(const gps_splat_step* a, gps_stream stream) {
     GPS_REQUIRE(a != nullptr && a->workspace != nullptr);
     // the prefetched forward has added its counts to the superblock binning's persistent tables, which only the scan of the step
     // that consumes it would clear: back to "zero between launches"
-    const int tw = gps_div_up(a->width, 16), th = gps_div_up(a->height, 16);
-    gps::BinCountOut cnt;
-    const int r = gps::isect_count_targets(a->N, a->isect_capacity, a->tiles_per_gauss, 16, tw, th, a->workspace, a->workspace_bytes, true, &cnt);
+    // (whatever N and image size the struct holds by now: the model may have been pruned or grown since)
+    gps::SbTables t;
+    const int r = gps::isect_workspace_tables(a->workspace, a->workspace_bytes, &t);
     if (r != GPS_OK) return r;
-    return gps::sb_tables_clear(cnt.sb, stream);
+    return gps::sb_tables_clear(t, stream);
 }
 
 int gps_splat_can_prefetch(const gps_splat_step* a) {

@@ -9,6 +9,7 @@ sites per iteration instead of the reference's ~150 libtorch + gsplat launches a
 Host plumbing that the reference does with libtorch ops (masked_select / randperm / cat in addGaussians,
 boolean-mask compaction in prunePoints) is done with the same torch ops here.
 """
+import itertools
 import math
 import os
 import sys
@@ -45,6 +46,9 @@ def pose_inv(c2w):
     return out
 
 
+_PACK_SERIAL = itertools.count(1)
+
+
 class Camera:
     """dataset_reader.h:111-169 (fields the hot path reads)"""
 
@@ -65,7 +69,9 @@ class Camera:
             d = self.device
             c2w = self.c2w_slam.to(torch.float32)
             pack = torch.cat([pose_inv(c2w).reshape(-1), self.K.reshape(-1), c2w[:3, 3].reshape(-1)]).to(d)
-            self._dev = dict(viewmat=pack[:16].view(4, 4), K=pack[16:25].view(3, 3), cam_pos=pack[25:28], _pack=pack)
+            # serial: identity of this upload (an address can come back from the allocator with another pose in it)
+            self._dev = dict(viewmat=pack[:16].view(4, 4), K=pack[16:25].view(3, 3), cam_pos=pack[25:28], _pack=pack,
+                             serial=next(_PACK_SERIAL))
             if self.image is not None:
                 self.image = self.image.to(d)
             if self.depth is not None:
@@ -90,6 +96,7 @@ class RawGaussianParams:
         self.cap = 0
         self._buf, self._alt = {}, {}
         self.exposure = None
+        self.version = 0   # bumped by every add / remove / load: part of the key of a forward run ahead (GaussianModel.train_step)
         self._reserve(capacity)
 
     def _shapes(self):
@@ -123,6 +130,7 @@ class RawGaussianParams:
         for name in self.NAMES:
             self._buf[name][self.N:self.N + n] = new[name]
         self.N += n
+        self.version += 1
 
     def savePly(self, filename):
         """RawGaussianParams::savePly (raw_gs_param.cpp:159-217): binary little-endian 3DGS PLY, one float row per Gaussian:
@@ -143,6 +151,7 @@ class RawGaussianParams:
             torch.index_select(self._buf[name][:self.N], 0, keep_idx, out=self._alt[name][:m])
             self._buf[name], self._alt[name] = self._alt[name], self._buf[name]
         self.N = m
+        self.version += 1
 
 
 def gaussian_ply_properties(n_dc, n_rest):
@@ -375,19 +384,22 @@ class RawGaussianModel:
         C-ABI call (gps_splat_train_step).  The L1 loss accumulates in a device scalar (loss_sum()).
         next_cam: the camera of the NEXT train_step call (same size) -- its preprocessing forward then runs in the tail of this
         step's backward kernel (gps_splat_step::next_viewmat) and the next call skips its preprocessing launch, provided it is
-        called with that camera and nothing else has used the model in between; ignored where the step cannot prefetch."""
+        called with that camera and nothing else has used the model in between (any other call, an add / prune / load of the
+        parameters: the forward run ahead is discarded and the step preprocesses again; editing the parameter tensors in place is
+        the one thing this cannot see); ignored where the step cannot prefetch."""
         if ref_depth_clamped is None:
             ref_depth_clamped = self.clamp_ref_depth(ref_depth)
         st = self._step_struct(cam.width, cam.height)
         c = cam.toGPU()
-        key = (c["viewmat"].data_ptr(), c["K"].data_ptr(), c["cam_pos"].data_ptr(), int(st.N), cam.width, cam.height)
+        ver = self.opt_gs_params.version
+        key = (c["serial"], int(st.N), cam.width, cam.height, ver)
         skip = getattr(self, "_prefetched", None) == key
         self._bind_camera(st, cam, ref_depth_clamped, base_color, gt_rgb, consumes_prefetch=skip)
         st.preprocessed = 1 if skip else 0
         if next_cam is not None and (next_cam.width, next_cam.height) == (cam.width, cam.height) and lib.gps_splat_can_prefetch(C.byref(st)):
             n = next_cam.toGPU()
             st.next_viewmat, st.next_Kmat, st.next_cam_pos = n["viewmat"].data_ptr(), n["K"].data_ptr(), n["cam_pos"].data_ptr()
-            self._prefetched = (n["viewmat"].data_ptr(), n["K"].data_ptr(), n["cam_pos"].data_ptr(), int(st.N), cam.width, cam.height)
+            self._prefetched = (n["serial"], int(st.N), cam.width, cam.height, ver)
         o = self._opt
         o["step"] += 1
         check(lib.gps_splat_train_step(C.byref(st), o["step"], self._stream()), "gps_splat_train_step")

@@ -137,7 +137,7 @@ std::pair<int64_t, int64_t> RawGaussianModel::checkBinningCapacity() {
 void RawGaussianModel::bindCamera(gps_splat_step& st, const Camera& cam, const torch::Tensor& ref_depth_clamped,
                                   const torch::Tensor& base_color, const torch::Tensor& gt_rgb, bool consumes_prefetch) {
     TORCH_CHECK(cam.on_device(), "Camera::toGPU() must run before the camera is rendered (slam_pipeline.cpp:84)");
-    if (prefetched_.viewmat != nullptr && !consumes_prefetch)   // a forward run ahead for a train step that is not coming
+    if (prefetched_.camera != 0 && !consumes_prefetch)   // a forward run ahead for a train step that is not coming
         check(gps_splat_discard_prefetch(&st, current_stream()), "gps_splat_discard_prefetch");
     check_f32_dev(ref_depth_clamped, "ref_depth");
     check_f32_dev(base_color, "base_color");
@@ -434,15 +434,14 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
     auto clamped = ref_depth_clamped.defined() ? ref_depth_clamped : clampRefDepth(ref_depth);
     gps_splat_step& st = stepStruct(cam.width, cam.height);
     // did the previous trainStep() run this camera's preprocessing forward in its backward kernel's tail (next_cam)?
-    const PrefetchKey mine{cam.on_device() ? cam.viewmat() : nullptr, cam.on_device() ? cam.Kmat() : nullptr,
-                           cam.on_device() ? cam.cam_pos() : nullptr, (int64_t)st.N, cam.width, cam.height};
-    const bool skip = prefetched_.viewmat != nullptr && prefetched_ == mine;
+    const PrefetchKey mine{cam.pack_serial(), (int64_t)st.N, cam.width, cam.height, opt_gs_params.version()};
+    const bool skip = prefetched_.camera != 0 && prefetched_ == mine;
     bindCamera(st, cam, clamped, base_color, cam.image, skip);   // (clears prefetched_)
     st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 2 : 0;  // all six tensors stepped inside the backward kernel
     st.preprocessed = skip ? 1 : 0;
     if (next_cam && next_cam->on_device() && next_cam->width == cam.width && next_cam->height == cam.height && gps_splat_can_prefetch(&st)) {
         st.next_viewmat = next_cam->viewmat(); st.next_Kmat = next_cam->Kmat(); st.next_cam_pos = next_cam->cam_pos();
-        prefetched_ = PrefetchKey{st.next_viewmat, st.next_Kmat, st.next_cam_pos, (int64_t)st.N, cam.width, cam.height};
+        prefetched_ = PrefetchKey{next_cam->pack_serial(), (int64_t)st.N, cam.width, cam.height, opt_gs_params.version()};
     }
     adam_step_ += 1;
     check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");

@@ -118,11 +118,12 @@ public:
     int64_t nextLaunchId() { return ++launch_id_; }
     // the forward the last trainStep() ran ahead for its next_cam: camera arrays, Gaussian count, image size (viewmat == nullptr: none)
     struct PrefetchKey {
-        const float *viewmat = nullptr, *Kmat = nullptr, *cam_pos = nullptr;
+        uint64_t camera = 0;   // Camera::pack_serial() of the camera the forward was run for; 0 = nothing run ahead
         int64_t N = 0;
         int W = 0, H = 0;
+        uint64_t version = 0;  // RawGaussianParams::version(): an add / prune between the two steps voids the forward run ahead
         bool operator==(const PrefetchKey& o) const {
-            return viewmat == o.viewmat && Kmat == o.Kmat && cam_pos == o.cam_pos && N == o.N && W == o.W && H == o.H;
+            return camera == o.camera && N == o.N && W == o.W && H == o.H && version == o.version;
         }
     };
     PrefetchKey prefetched_;

@@ -1,4 +1,5 @@
 #include "raw_gs_param.hpp"
+#include <atomic>
 
 #include <fstream>
 
@@ -43,6 +44,8 @@ void Camera::toGPU(const torch::Device& device, const torch::Tensor& frame_rgba_
         h[25] = m[3]; h[26] = m[7]; h[27] = m[11];
         // through the kernel argument buffer: no pinned staging tensor, no copy-engine latency on the frame stream
         pack_ = torch::empty({28}, f32(device));
+        static std::atomic<uint64_t> serial{0};
+        pack_serial_ = ++serial;
         if (convert) {
             check(gps_rgba8_to_rgbf_and_floats((int)(frame_rgba_u8.size(0) * frame_rgba_u8.size(1)), ptr<uint8_t>(frame_rgba_u8),
                                                fptr(image), fptr(pack_), h, 28, current_stream()), "gps_rgba8_to_rgbf_and_floats");
@@ -109,6 +112,7 @@ void RawGaussianParams::appendInit(const torch::Tensor& xyz, const torch::Tensor
     // quats rows are 16 bytes: any row offset keeps the float4 store aligned
     init_rows(xyz, rgb, normals, K, init_opacs, max_scale, min_scale, out);
     N_ += n;
+    version_++;
 }
 
 void RawGaussianParams::reserve(int64_t capacity, int sh_k, const torch::Device& device) {
@@ -127,6 +131,7 @@ void RawGaussianParams::reserve(int64_t capacity, int sh_k, const torch::Device&
     }
     if (old_k != K_) N_ = 0;
     cap_ = capacity;
+    version_++;
 }
 
 void RawGaussianParams::init(const torch::Tensor& xyz, const torch::Tensor& rgb, const torch::Tensor& normals,
@@ -145,6 +150,7 @@ void RawGaussianParams::add(const std::vector<torch::Tensor>& t) {
         reserve(std::max<int64_t>(2 * cap_, std::max<int64_t>(1 << 19, N_ + n)), K_, t[0].device());
     for (int k = 0; k < NUM; k++) buf_[k].slice(0, N_, N_ + n).copy_(t[k]);
     N_ += n;
+    version_++;
 }
 
 void RawGaussianParams::add(const RawGaussianParams& other) {
@@ -181,6 +187,7 @@ int64_t RawGaussianParams::removeKeep(const torch::Tensor& keep_mask) {
     check(gps_gather_rows((int)m, iptr(ids), NUM, srcs, dsts, rows, (gps_stream)stream.stream()), "gps_gather_rows");
     for (int k = 0; k < NUM; k++) std::swap(buf_[k], alt_[k]);
     N_ = m;
+    version_++;
     return m;
 }
 

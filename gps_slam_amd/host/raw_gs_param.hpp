@@ -37,9 +37,11 @@ struct Camera {
     torch::Tensor K_tensor() const { return pack_.slice(0, 16, 25).view({3, 3}); }
     torch::Tensor cam_pos_tensor() const { return pack_.slice(0, 25, 28); }
     const torch::Tensor& pack_tensor() const { return pack_; }  // device float[28] = viewmat | K | cam_pos
+    uint64_t pack_serial() const { return pack_.defined() ? pack_serial_ : 0; }  // identity of this upload (addresses get recycled)
 
 private:
     torch::Tensor pack_;  // device float[28] = viewmat(16) | K(9) | cam_pos(3)
+    uint64_t pack_serial_ = 0;
 };
 
 torch::Tensor poseInv(const torch::Tensor& c2w);  // src/tensor_math.cpp:56-67 (host tensors)
@@ -60,6 +62,7 @@ public:
                                            float max_scale, float min_scale);
 
     bool isDefined() const { return N_ > 0; }
+    uint64_t version() const { return version_; }
     int getGaussianNum() const { return (int)N_; }
     void reserve(int64_t capacity, int sh_k, const torch::Device& device);
     // make() + add() in place: the new rows are initialised directly behind the existing ones
@@ -100,6 +103,7 @@ protected:
     mutable torch::Tensor keep_idx_;
     torch::Tensor keep_ids32_, host_count_;
     int64_t N_ = 0, cap_ = 0;
+    uint64_t version_ = 0;  // bumped by every change of the row set (add / remove / reserve / load): part of RawGaussianModel's prefetch key
     int K_ = 16;
     torch::Device device_ = torch::kCUDA;
 };

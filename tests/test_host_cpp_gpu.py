@@ -231,6 +231,53 @@ def test_cpp_model_matches_python_model_and_autograd_route_matches_fused():
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)
 
 
+def test_cpp_train_step_run_ahead_equals_plain_steps_and_is_void_after_prune_or_new_pose():
+    """RawGaussianModel::trainStep(next_cam): twin C++ models, one running the next camera's preprocessing ahead -- equal
+    parameters after every step; a prune between two steps, or a camera whose pose was uploaded again, voids the forward that
+    was run ahead (PrefetchKey: Camera::pack_serial + RawGaussianParams::version) and the results still agree."""
+    h = _host()
+    W, H = 320, 240
+    tensors, c2w, K, gt, base, ref = _scene(N=24000, seed=5)
+    c2w_b, _ = scenes.default_camera(W, H, seed=6)
+    a, b = _cpp_model(h, tensors), _cpp_model(h, tensors)
+    a.initOptimizers(-1, 1.0)
+    b.initOptimizers(-1, 1.0)
+    cams = [_cpp_cam(h, W, H, K, c2w, gt), _cpp_cam(h, W, H, K, c2w_b, gt)]
+
+    def same():
+        torch.cuda.synchronize()
+        ap, bp = a.getGaussianParms(), b.getGaussianParms()
+        assert ap.getGaussianNum() == bp.getGaussianNum()
+        for name in ("getMeans", "getScales", "getQuats", "getFeaturesDc", "getFeaturesRest", "getOpacities"):
+            assert torch.equal(getattr(ap, name)(), getattr(bp, name)()), name
+
+    seq = [0, 1, 1, 0]
+    for it, k in enumerate(seq):
+        a.trainStep(cams[k], ref, base, next_cam=cams[seq[it + 1]] if it + 1 < len(seq) else None)
+        b.trainStep(cams[k], ref, base)
+        same()
+    # prune with a forward run ahead outstanding
+    a.trainStep(cams[0], ref, base, next_cam=cams[1])
+    b.trainStep(cams[0], ref, base)
+    delete = torch.zeros(a.getGaussianNum(), dtype=torch.bool, device=DEV)
+    delete[::9] = True
+    a.prunePoints(delete)
+    b.prunePoints(delete)
+    a.trainStep(cams[1], ref, base, next_cam=cams[0])
+    b.trainStep(cams[1], ref, base)
+    same()
+    # the camera the forward was run ahead for gets another pose
+    moved = torch.as_tensor(np.asarray(c2w, np.float32)).clone()
+    moved[:3, 3] += torch.tensor([0.01, -0.02, 0.005])
+    cams[0].c2w_slam = moved
+    cams[0].invalidate()
+    cams[0].toGPU()
+    a.trainStep(cams[0], ref, base)
+    b.trainStep(cams[0], ref, base)
+    same()
+    assert a.checkBinningCapacity() == b.checkBinningCapacity()
+
+
 def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():
     h = _host()
     from gps_slam_amd.gs_model import Camera, SLAMGaussianModel

@@ -208,6 +208,87 @@ def test_next_iterations_preprocess_in_the_backward_kernel_changes_nothing(N, W,
     assert int(a._B["counts"][2]) == 0 and int(b._B["counts"][2]) == 0   # no binning overflow on either side
 
 
+def test_a_forward_run_ahead_is_void_after_a_structure_edit_or_a_new_pose():
+    """The key of a forward run ahead (gs_model.train_step / RawGaussianModel::trainStep) holds the camera's upload serial and the
+    parameter container's version: a prune + add that leaves N unchanged, a prune that changes it, and a camera whose pose was
+    re-uploaded (possibly to the same address) all void it -- the next step preprocesses itself, the binning's tables are back to
+    zero, and the twin model that never prefetches ends with the same bits."""
+    from gps_slam_amd.gs_model import SLAMGaussianModel
+    N, W, H = 30000, 320, 240
+    g = scenes.random_gaussians(N, seed=33, scale_range=(0.004, 0.03))
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    rows = dict(means=T(g["means"]), scales=T(g["log_scales"]), quats=T(g["quats"]), featuresDc=T(g["sh"][:, 0].copy()),
+                featuresRest=T(g["sh"][:, 1:].copy()), opacities=T(g["opac_logit"]))
+    models = []
+    for _ in range(2):
+        m = SLAMGaussianModel(dict(fuse_sh_rest_adam=2), device=DEV)
+        m.add_params(rows)
+        m.initOptimizers(-1, 1.0)
+        models.append(m)
+    a, b = models
+    cams = _two_cameras(W, H, seed=6)
+    gen = torch.Generator().manual_seed(10)
+    gts = [torch.rand((H, W, 3), generator=gen).to(DEV) for _ in range(2)]
+    base = torch.rand((H, W, 3), generator=gen).to(DEV)
+    ref = (torch.rand((H, W, 1), generator=gen) * 4).to(DEV)
+
+    def same():
+        torch.cuda.synchronize()
+        assert a.getGaussianNum() == b.getGaussianNum()
+        n = a.getGaussianNum()
+        for name in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"):
+            assert torch.equal(getattr(a.opt_gs_params, name), getattr(b.opt_gs_params, name)), name
+        for k in range(6):
+            assert torch.equal(a._opt["m"][k][:n], b._opt["m"][k][:n]) and torch.equal(a._opt["v"][k][:n], b._opt["v"][k][:n]), k
+        assert torch.equal(a._B["render_colors"], b._B["render_colors"])
+        assert int(a._B["counts"][2]) == 0 and int(b._B["counts"][2]) == 0
+
+    def edit(m, delete, extra):
+        m.prunePoints(delete)
+        if extra is not None:
+            m.add_params(extra)
+            n = m.getGaussianNum()
+            for k in ("m", "v"):   # the appended rows start with zero moments on both twins
+                for t in m._opt[k]:
+                    t[n - extra["means"].shape[0]:n].zero_()
+
+    # 1. prune 500 + add 500: N unchanged, different rows
+    delete = torch.zeros(N, dtype=torch.bool, device=DEV)
+    delete[torch.arange(0, 500 * 7, 7, device=DEV)] = True
+    extra = {k: v[1000:1500].clone() for k, v in rows.items()}
+    a.train_step(cams[0], ref, base, gts[0], next_cam=cams[1])
+    b.train_step(cams[0], ref, base, gts[0])
+    edit(a, delete, extra); edit(b, delete, extra)
+    assert a.getGaussianNum() == N and a._prefetched is not None
+    a.train_step(cams[1], ref, base, gts[1], next_cam=cams[0])
+    assert int(a._step.preprocessed) == 0
+    b.train_step(cams[1], ref, base, gts[1])
+    same()
+    # 2. prune only (N changes) with a forward run ahead outstanding
+    delete = torch.zeros(N, dtype=torch.bool, device=DEV)
+    delete[-700:] = True
+    edit(a, delete, None); edit(b, delete, None)
+    a.train_step(cams[0], ref, base, gts[0], next_cam=cams[1])
+    assert int(a._step.preprocessed) == 0
+    b.train_step(cams[0], ref, base, gts[0])
+    same()
+    # 3. the next camera's pose is re-uploaded between the two steps
+    cams[1].c2w_slam = cams[1].c2w_slam.clone()
+    cams[1].c2w_slam[:3, 3] += torch.tensor([0.01, -0.02, 0.005])
+    cams[1].invalidate()
+    a.train_step(cams[1], ref, base, gts[1])
+    assert int(a._step.preprocessed) == 0
+    b.train_step(cams[1], ref, base, gts[1])
+    same()
+    # ... and an undisturbed pair of steps still takes the forward that was run ahead
+    a.train_step(cams[0], ref, base, gts[0], next_cam=cams[1])
+    b.train_step(cams[0], ref, base, gts[0])
+    a.train_step(cams[1], ref, base, gts[1])
+    assert int(a._step.preprocessed) == 1
+    b.train_step(cams[1], ref, base, gts[1])
+    same()
+
+
 def test_optimisation_reduces_the_loss():
     model, cam, ref, base, gt = _model_and_maps(N=30000, seed=5)
     model.initOptimizers(-1, 3.3)
