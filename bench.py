@@ -150,6 +150,8 @@ class Scene:
         self.engine = self.cli.getMainEngine()
         if os.environ.get("GPS_BENCH_PINNED_LINE"):  # A/B aid: the tracker's argument line in the pinned mailbox (relay path)
             self.engine.setBarArgLine(False)
+        if os.environ.get("GPS_BENCH_RIDING_ALONG"):  # A/B aid: poses of the LM loop's reject branch evaluated with every evaluation (0..2, default 1)
+            self.engine.setPosesRidingAlong(int(os.environ["GPS_BENCH_RIDING_ALONG"]))
         self.model = H_.SLAMGaussianModel()
         self.model.loadConfig(dict(capacity=1 << 19, isect_capacity=8 << 20))
         self.model.getGaussianParms().add([t.clone() for t in seeds])
@@ -157,6 +159,8 @@ class Scene:
         self.pipe.setTsdfEngine(self.cli)
         self.pipe.setModel(self.model)
         self.pipe.loadConfig(dict(keyframe_theta_thres=keyframe_theta, keyframe_trans_thres=keyframe_trans))
+        if os.environ.get("GPS_BENCH_OPT_ITERS"):  # probe aid (tools/probe/critical_path.sh): NOT the metric's workload -- the line says so
+            self.pipe.loadConfig(dict(local_opt_iters=int(os.environ["GPS_BENCH_OPT_ITERS"])))
         self.pipe.overlap_mapping = bool(overlap)
         self.pipe.mapping_thread = bool(overlap)
         if os.environ.get("GPS_BENCH_PREFETCH"):  # A/B aid: the next iteration's preprocessing in the backward kernel's tail (1, default) or its own launch (0)
@@ -357,7 +361,7 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                        "window_note": "%d consecutive %d-step windows per schedule, each bracketed by barrier + synchronize and "
                                       "maxed over ranks; value / ms_per_step = the MEDIAN window; the scene grows from window to window "
                                       "(windows_gaussians), window_spread_detrended is the spread around that trend" % (NW, K),
-                       "local_opt_interval": PERIOD, "local_opt_iters": 20, "frames_per_step": 1,
+                       "local_opt_interval": PERIOD, "local_opt_iters": int(os.environ.get("GPS_BENCH_OPT_ITERS", 20)), "frames_per_step": 1,
                        "use_gt_pose": bool(args.gt_pose), "prologue_frames": prologue,
                        "schedules": {k: {kk: vv for kk, vv in v.items() if kk != "seconds"} for k, v in results.items()},
                        "stats": results[main_sched]["stats"], "placement": placement},

@@ -38,7 +38,7 @@ class TrackConfig(C.Structure):
 class TrackState(C.Structure):
     """gps_track_state (host memory)"""
     _fields_ = [("pose_M", f32 * 16), ("pose_invM", f32 * 16), ("pose_pc_M", f32 * 16), ("age_point_cloud", i32),
-                ("frames_processed", i32), ("diag", f32 * 16), ("host_mailbox", vp), ("mail_seq", i32), ("scratch_epoch", i32), ("dev_arg_line", vp)]
+                ("frames_processed", i32), ("diag", f32 * 16), ("host_mailbox", vp), ("mail_seq", i32), ("scratch_epoch", i32), ("dev_arg_line", vp), ("mailbox_bytes", i32)]
 
 
 class SplatStep(C.Structure):

@@ -186,6 +186,16 @@ constexpr int EV_MAX_WGS = GPS_TRACK_EV_MAX_WGS;           // rows of the partia
                                           // pixels in flight per thread -- both depth loads, then both bilinear footprints -- changed
                                           // nothing either, 0.721: launch + tail + the host round trip dominate an iteration.)
 constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
+// Poses one pre-launched evaluation can take: the LM loop's next pose + the poses the loop would evaluate AFTER it if it is
+// rejected (they depend on the last good state only, so the host knows them before the evaluation returns -- see
+// track_camera_impl).  Each pose is evaluated by its own group of EV_MAX_WGS workgroups with its own argument line, row table
+// and result block.
+#ifndef GPS_TRACK_EV_GROUPS
+#define GPS_TRACK_EV_GROUPS 3
+#endif
+GPS_TUNABLE_REPORT(GPS_TRACK_EV_GROUPS, 3);
+constexpr int EV_GROUPS = GPS_TRACK_EV_GROUPS;
+constexpr int MAILBOX_GROUP_WORDS = 64;   // a group's block of the host mailbox (words 0..31: its result row)
 
 // The frame's valid-pixel count lives behind the 16-word block, spread over VC_SLOTS words per frame parity: the prepare
 // kernel's workgroups add into slot (workgroup % VC_SLOTS) -- 1,200 atomics on ONE word cost the kernel 10 of its 16 us
@@ -338,7 +348,8 @@ constexpr int SYNC_SPIN_TICKS = 8, SYNC_EVAL_TICKS = 9, SYNC_EVALS = 10, SYNC_SK
 constexpr long long ROW_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
 
 template <int ITER>
-__device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
+__device__ __forceinline__ void eval_body(const GhArgs& a, int bid /* workgroup of this evaluation */, int n_rows,
+                                          uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
                                           float* __restrict__ result, volatile float* mailbox, int seq, int parity,
                                           long long t_arrived = -1) {
     constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ, NQ = (NV + 3) / 4;
@@ -353,7 +364,7 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
     // (prefetching the next pixel's depth ahead of this pixel's bilinear gather -- one dependent round trip per trip instead of
     // two -- and two pixels in flight were both measured: no change; launch-to-launch overhead and the hand-over chain set
     // an iteration's length, not this loop)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_rows * blockDim.x) {
+    for (int i = bid * blockDim.x + threadIdx.x; i < n; i += n_rows * blockDim.x) {
         const int y = i / a.vw, x = i - y * a.vw;
         gh_point<ITER>(a, x, y, a.depth[i], acc[0], acc[1], acc + 2, acc + 2 + NP);
     }
@@ -377,9 +388,9 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int n_rows, uint32_t*
             }
             wv = __float_as_uint(t);
         }
-        __hip_atomic_store(partial + (size_t)blockIdx.x * GH_SLOTS + tid, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partial + (size_t)bid * GH_SLOTS + tid, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (blockIdx.x != 0) return;
+    if (bid != 0) return;
     // ---- workgroup 0, the summer: word k of rows r, r + 8, ... by thread (r, k); a round is ONE batch of loads
     const int k = tid & (GH_SLOTS - 1), r = tid >> 5;
     const int rows = n_rows;
@@ -446,7 +457,7 @@ template <int ITER>
 __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
                                                               float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
     GPS_FRAME_PRIO();
-    eval_body<ITER>(a, (int)gridDim.x, partial, sync, result, mailbox, seq, parity);
+    eval_body<ITER>(a, (int)blockIdx.x, (int)gridDim.x, partial, sync, result, mailbox, seq, parity);
 }
 
 // (2) PRE-LAUNCHED evaluation (mailbox path).  What an LM iteration evaluates -- level, kind, pose -- is decided by the host
@@ -483,13 +494,16 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
                                                                    volatile float* mailbox, int seq, int parity) {
     __shared__ uint32_t line[16];
     __shared__ long long t_arrived;
+    // group 0 = the LM loop's evaluation; groups 1 .. EV_GROUPS - 1 (BAR line only: the grid has them only then) = the poses the
+    // loop would evaluate next if that one is rejected.  A group has its own argument line (64 bytes apart), rows and result.
+    const int grp = (int)blockIdx.x / EV_MAX_WGS, bid = (int)blockIdx.x - grp * EV_MAX_WGS;
     if (threadIdx.x < 16) {
         // Workgroup 0 polls the host line and relays it through a device-memory copy the other workgroups poll: with all 256
         // workgroups reading the host line across PCIe, the CPU's store waited ~20 us for ownership of its own cache line
         // (measured: 33 us per iteration instead of ~20; one poller: 1.7 us host -> GPU -> host round trip).
         const bool direct = pa.bar_line != nullptr;   // (wave-uniform: a kernel argument)
         const bool relay = !direct && blockIdx.x == 0;
-        const uint32_t* src = direct ? pa.bar_line : relay ? pa.arg_line : pa.dev_line;
+        const uint32_t* src = direct ? pa.bar_line + 16 * grp : relay ? pa.arg_line : pa.dev_line;
         const long long t0 = wall_clock64();
         uint32_t v;
         for (;;) {
@@ -500,11 +514,12 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
             const uint32_t w0 = __shfl(v, 0, 16), w15 = __shfl(v, 15, 16);
             if (w0 == (uint32_t)seq && w15 == x) break;
             // A valid line of a LATER launch: this launch's line has come and gone.  The host publishes launch seq + 1 only after
-            // launch seq has answered (RUN: every workgroup with pixels has delivered its row, so this one has none) or has
-            // acknowledged its retirement (SKIP, workgroup 0) -- either way there is nothing left for this workgroup to do.
-            // Only the direct (BAR) line can show this: a workgroup that became resident late, beside another stream's
-            // kernels, after workgroup 0 had answered (the relayed copy is rewritten by the NEXT launch, which cannot start
-            // before this one has drained).  Without it such a workgroup sat out ARG_TIMEOUT with the frame stream behind it.
+            // every group of launch seq that was told to RUN has answered (every workgroup with pixels has delivered its row, so
+            // this one has none) and group 0 has acknowledged a retirement (SKIP, workgroup 0) -- either way there is nothing
+            // left for this workgroup to do.  Only the direct (BAR) line can show this: a workgroup that became resident late,
+            // beside another stream's kernels, after its group had answered (the relayed copy is rewritten by the NEXT launch,
+            // which cannot start before this one has drained).  Without it such a workgroup sat out ARG_TIMEOUT with the frame
+            // stream behind it.
             const bool superseded = w15 == x && (int32_t)(w0 - (uint32_t)seq) > 0 && w0 < 0x40000000u;
             if (superseded || wall_clock64() - t0 > ARG_TIMEOUT) {  // give up: behave like ARG_SKIP (and relay that)
                 v = threadIdx.x == 0 ? (uint32_t)seq : threadIdx.x == 1 ? ARG_SKIP : 0u;
@@ -534,9 +549,10 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
     GPS_FRAME_PRIO();   // (only now: a launch that is still waiting for its line should not crowd out anybody)
     const uint32_t ctl = __builtin_amdgcn_readfirstlane(line[1]);
     if ((ctl & 0xFF) != ARG_RUN) {
-        // retired: tell the host its line has been consumed -- there is ONE argument line, and the host must not write the next
-        // launch's arguments into it while this launch, queued but not yet running, still has to find its own (it would then
-        // wait out ARG_TIMEOUT with the whole frame stream behind it)
+        // retired: tell the host its line has been consumed -- the host must not write the next launch's arguments into a line
+        // while this launch, queued but not yet running, still has to find its own (it would then wait out ARG_TIMEOUT with the
+        // whole frame stream behind it).  Group 0 answers for the launch; the other groups' late workgroups are covered by
+        // `superseded` above (their lines are rewritten together with group 0's).
         if (blockIdx.x == 0 && threadIdx.x == 0 && mailbox)
             __hip_atomic_store(reinterpret_cast<uint32_t*>(const_cast<float*>(mailbox)) + 32, (uint32_t)seq, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
 #pragma unroll
     for (int l = 1; l < GPS_TRACK_MAX_LEVELS; l++)  // (a dynamically indexed kernel-argument array would be copied to scratch)
         if (level == l) lt = pa.tab[l];
-    if ((int)blockIdx.x >= lt.n_wgs) return;
+    if (bid >= lt.n_wgs) return;
     GhArgs a;
     a.depth = lt.depth; a.vw = lt.vw; a.vh = lt.vh;
     a.view_intr = make_float4(lt.ix, lt.iy, lt.iz, lt.iw);
@@ -565,9 +581,12 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
     a.space_thresh = lt.space_thresh; a.tukey_cutoff = pa.tukey_cutoff; a.vf_min = pa.vf_min; a.vf_max = pa.vf_max;
     a.use_weights = pa.use_weights; a.frames_to_skip = pa.frames_to_skip; a.frames_to_weight = pa.frames_to_weight;
     const long long ta = blockIdx.x == 0 ? t_arrived : -1;
-    if (kind == TRK_ROTATION) eval_body<TRK_ROTATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity, ta);
-    else if (kind == TRK_TRANSLATION) eval_body<TRK_TRANSLATION>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity, ta);
-    else eval_body<TRK_BOTH>(a, lt.n_wgs, partial, sync, result, mailbox, seq, parity, ta);
+    uint32_t* const rows = partial + (size_t)grp * EV_MAX_WGS * GH_SLOTS;
+    float* const res = result + grp * MAILBOX_GROUP_WORDS;
+    volatile float* const mb = mailbox ? mailbox + grp * MAILBOX_GROUP_WORDS : nullptr;
+    if (kind == TRK_ROTATION) eval_body<TRK_ROTATION>(a, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta);
+    else if (kind == TRK_TRANSLATION) eval_body<TRK_TRANSLATION>(a, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta);
+    else eval_body<TRK_BOTH>(a, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta);
 }
 
 // ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
@@ -627,6 +646,126 @@ bool set_invM_coerce(const float* invM_in, float* M, float* invM) {  // pose_d->
 
 inline int float_bits(float f) { int i; memcpy(&i, &f, 4); return i; }
 
+// The host half of ITMExtendedTracker::TrackCamera (ITMExtendedTracker.cpp:470-665; oracle/tsdf_oracle.c: orc_track_camera) as
+// a state machine: request() = what the loop evaluates next, apply() = what it does with an evaluation's sums (accept / reject,
+// damping, Cholesky solve, SE3 update, convergence test, level change).  apply(nullptr) is the REJECT branch, which reads
+// nothing of the evaluation it rejects: run on a copy of the state it tells, before an evaluation has returned, which pose the
+// loop evaluates after it should it be rejected (and after that one, and ...) -- those poses ride along with the evaluation.
+struct LmRequest {
+    bool valid = false;
+    int level = 0, kind = 0;
+    float pose[16] = {0};   // approxInvPose
+    bool same(const LmRequest& o) const { return valid == o.valid && level == o.level && kind == o.kind && memcmp(pose, o.pose, 64) == 0; }
+};
+
+struct LmLoop {
+    const gps_track_config* c = nullptr;
+    bool active = false, bad_pose = false;
+    int level = 0, iter = 0;
+    float M[16], invM[16], approxInvPose[16], lastGoodM[16], lastGoodInvM[16];
+    float f_old = 0, lambda = 0;
+    float hessian_good[36] = {0}, nabla_good[6] = {0}, hessian_depth_good[36] = {0}, f_depth_good = 0;
+    int nvalid_depth_good = 0, last_type = TRK_NONE, n_valid_bits = 0;
+    int evals[GPS_TRACK_MAX_LEVELS] = {0};   // evaluations consumed per level
+
+    void start(const gps_track_config* cfg, const float* M0, const float* invM0) {
+        c = cfg;
+        memcpy(M, M0, 64); memcpy(invM, invM0, 64);
+        level = c->n_levels;
+        next_level();
+    }
+    void next_level() {
+        active = false;
+        for (level--; level >= 0; level--) {
+            const int it = c->iter_type[level];
+            if (it == TRK_NONE) continue;
+            last_type = it;
+            memcpy(approxInvPose, invM, 64);
+            memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
+            f_old = 3.402823466e+38f; lambda = 1.0f;
+            iter = 0;
+            if (c->n_iter[level] > 0) { active = true; return; }
+        }
+    }
+    LmRequest request() const {
+        LmRequest r;
+        if (!active) return r;
+        r.valid = true; r.level = level; r.kind = c->iter_type[level];
+        memcpy(r.pose, approxInvPose, 64);
+        return r;
+    }
+    // host = the 30 payload words of an evaluation's result (eval_body), or nullptr = the evaluation is taken as rejected.
+    // Returns whether the evaluation was rejected.
+    bool apply(const float* host) {
+        const int it = c->iter_type[level], noPara = it == TRK_BOTH ? 6 : 3;
+        bool reject = true;
+        float hessian_depth[36] = {0}, nabla_depth[6] = {0}, f_depth = 0.0f;
+        int nvalid = 0;
+        if (host) {
+            n_valid_bits = float_bits(host[29]);
+            nvalid = (int)host[0];
+            f_depth = host[1];
+            for (int r = 0; r < noPara; r++) nabla_depth[r] = host[2 + r];
+            for (int r = 0, counter = 0; r < noPara; r++)
+                for (int cc = 0; cc <= r; cc++, counter++) hessian_depth[r + cc * 6] = host[2 + noPara + counter];
+            for (int r = 0; r < noPara; ++r)
+                for (int cc = r + 1; cc < noPara; cc++) hessian_depth[r + cc * 6] = hessian_depth[cc + r * 6];
+            if (nvalid > 100) {
+                for (int i = 0; i < 36; ++i) hessian_depth[i] /= nvalid;
+                for (int i = 0; i < 6; ++i) nabla_depth[i] /= nvalid;
+                f_depth /= nvalid;
+            } else {
+                f_depth = 3.402823466e+38f;
+            }
+            evals[level] += 1;
+            reject = (nvalid <= 0) || (f_depth >= f_old);
+        }
+        if (reject) {
+            memcpy(M, lastGoodM, 64); memcpy(invM, lastGoodInvM, 64);
+            memcpy(approxInvPose, invM, 64);
+            lambda *= 10.0f;
+        } else {
+            memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
+            f_old = f_depth;
+            memcpy(hessian_good, hessian_depth, sizeof(hessian_good));
+            memcpy(nabla_good, nabla_depth, sizeof(nabla_good));
+            lambda /= 10.0f;
+            nvalid_depth_good = nvalid; f_depth_good = f_depth;
+            memcpy(hessian_depth_good, hessian_depth, sizeof(hessian_depth));
+        }
+        float A[36];
+        for (int i = 0; i < 36; ++i) A[i] = hessian_good[i];
+        for (int i = 0; i < 6; ++i) A[i + i * 6] *= 1.0f + lambda;
+        float step[6] = {0, 0, 0, 0, 0, 0};
+        if (it != TRK_BOTH) {
+            float small[9];
+            for (int r = 0; r < 3; r++)
+                for (int cc = 0; cc < 3; cc++) small[r + cc * 3] = A[r + cc * 6];
+            Chol(small, 3).backsub(step, nabla_good);
+        } else {
+            Chol(A, 6).backsub(step, nabla_good);
+        }
+        float s6[6] = {0, 0, 0, 0, 0, 0};
+        if (it == TRK_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
+        else if (it == TRK_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
+        else { for (int i = 0; i < 6; i++) s6[i] = step[i]; }
+        float Tinc[16];
+        Tinc[0 * 4 + 0] = 1.0f;   Tinc[1 * 4 + 0] = s6[2];  Tinc[2 * 4 + 0] = -s6[1]; Tinc[3 * 4 + 0] = s6[3];
+        Tinc[0 * 4 + 1] = -s6[2]; Tinc[1 * 4 + 1] = 1.0f;   Tinc[2 * 4 + 1] = s6[0];  Tinc[3 * 4 + 1] = s6[4];
+        Tinc[0 * 4 + 2] = s6[1];  Tinc[1 * 4 + 2] = -s6[0]; Tinc[2 * 4 + 2] = 1.0f;   Tinc[3 * 4 + 2] = s6[5];
+        Tinc[0 * 4 + 3] = 0.0f;   Tinc[1 * 4 + 3] = 0.0f;   Tinc[2 * 4 + 3] = 0.0f;   Tinc[3 * 4 + 3] = 1.0f;
+        m4_mul(Tinc, approxInvPose, approxInvPose);
+        if (!set_invM_coerce(approxInvPose, M, invM)) { bad_pose = true; active = false; return reject; }
+        memcpy(approxInvPose, invM, 64);
+        bool converged = true;
+        for (int i = 0; i < 6; i++)
+            if (fabs(step[i]) > c->term_thresh) { converged = false; break; }
+        iter++;
+        if (converged || iter >= c->n_iter[level]) next_level();
+        return reject;
+    }
+};
+
 struct Scratch {
     float* level[GPS_TRACK_MAX_LEVELS];  // [0] unused (= s.depth)
     uint32_t *partial, *sync;
@@ -644,8 +783,8 @@ size_t carve(Scratch* w, char* base, int W, int H) {
         char* p = take((size_t)(lw > 0 && lh > 0 ? lw * lh : 1) * sizeof(float));
         if (w) w->level[l] = (float*)p;
     }
-    char* p = take((size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;
-    p = take(64 * sizeof(float)); if (w) w->result = (float*)p;
+    char* p = take((size_t)EV_GROUPS * EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t)); if (w) w->partial = (uint32_t*)p;   // a row table per group
+    p = take((size_t)EV_GROUPS * MAILBOX_GROUP_WORDS * sizeof(float)); if (w) w->result = (float*)p;
     p = take((VC_BASE + 2 * VC_SLOTS) * sizeof(uint32_t)); if (w) w->sync = (uint32_t*)p;   // 16 control words + the valid-count slots of both parities
     p = take(64); if (w) w->dev_line = (uint32_t*)p;
     p = take((size_t)W * H * 2 * sizeof(float4)); if (w) w->pn = (float4*)p;
@@ -684,9 +823,10 @@ int gps_track_state_reset(gps_track_state* ts) {
     if (!ts) return GPS_ERR_ARG;
     void* mailbox = ts->host_mailbox;  // the mailbox and the sequence counter belong to the state's owner / the library
     void* line = ts->dev_arg_line;
-    const int32_t seq = ts->mail_seq;
+    const int32_t seq = ts->mail_seq, mailbox_bytes = ts->mailbox_bytes;
     memset(ts, 0, sizeof(*ts));
     ts->host_mailbox = mailbox;
+    ts->mailbox_bytes = mailbox_bytes;
     ts->dev_arg_line = line;
     ts->mail_seq = seq;
     for (int i = 0; i < 16; i += 5) ts->pose_M[i] = ts->pose_invM[i] = ts->pose_pc_M[i] = 1.0f;
@@ -831,7 +971,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     if (ts->scratch_epoch == 0) {
         if (hipMemsetAsync(w.sync, 0, (VC_BASE + 2 * VC_SLOTS) * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
         // row tags: sequence numbers are >= 1, so a zeroed table can never look like a delivered row
-        if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
+        if (hipMemsetAsync(w.partial, 0, (size_t)EV_GROUPS * EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
     } else {
         parity = ts->scratch_epoch - 1;
     }
@@ -870,14 +1010,18 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         if (ts->mail_seq >= 0x3FFFFFFF) {
             ts->mail_seq = 0;
             if (bar_line) {
-                for (int k = 0; k < 8; k++) reinterpret_cast<volatile uint64_t*>(bar_line)[k] = 0;
+                for (int k = 0; k < 8 * EV_GROUPS; k++) reinterpret_cast<volatile uint64_t*>(bar_line)[k] = 0;
                 host_store_fence();
             }
         }
         return (int)(++ts->mail_seq);
     };
-    // payload first, sequence number last (x86 stores are not reordered with each other; the compiler barrier keeps the order)
-    auto publish = [&](int seq, uint32_t cmd, int kind, int level, const float* pose) {
+    // groups of an evaluation launch: the loop's pose + the poses that ride along (BAR lines and a mailbox block per group)
+    const int mailbox_groups = ts->mailbox_bytes >= 2 * MAILBOX_GROUP_WORDS * 4 ? ts->mailbox_bytes / (MAILBOX_GROUP_WORDS * 4) : 1;
+    const int n_groups = (mailbox && bar_line) ? max(1, min(EV_GROUPS, mailbox_groups)) : 1;
+    // One argument line: payload first, sequence number last (x86 stores are not reordered with each other; the compiler barrier
+    // keeps the order).  Group g's line sits 64 bytes behind group g - 1's in the BAR block; the pinned line has group 0 only.
+    auto write_line = [&](int grp, int seq, uint32_t cmd, int kind, int level, const float* pose) {
         uint32_t wds[16] = {0};
         wds[1] = cmd | ((uint32_t)kind << 8) | ((uint32_t)level << 16);
         if (pose)
@@ -891,20 +1035,25 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             // through the BAR: the mapping is write-combining, so the 64 bytes gather in one of the core's WC buffers and leave
             // as one posted write when the sfence drains it (without the fence the line sits there until something evicts
             // it: tools/probe/pingpong.hip reads 560 us per round trip instead of 1.8).  A torn line fails the xor word.
-            for (int k = 0; k < 16; k += 2)
-                reinterpret_cast<volatile uint64_t*>(bar_line)[k >> 1] = (uint64_t)wds[k] | ((uint64_t)wds[k + 1] << 32);
-            host_store_fence();
+            volatile uint64_t* dst = reinterpret_cast<volatile uint64_t*>(bar_line + 16 * grp);
+            for (int k = 0; k < 16; k += 2) dst[k >> 1] = (uint64_t)wds[k] | ((uint64_t)wds[k + 1] << 32);
             return;
         }
         for (int k = 1; k < 16; k++) arg_line[k] = wds[k];
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         arg_line[0] = wds[0];
     };
+    // group 0's line, then the fence that sends every line written since the last one on its way
+    auto publish = [&](int seq, uint32_t cmd, int kind, int level, const float* pose) {
+        write_line(0, seq, cmd, kind, level, pose);
+        if (bar_line) host_store_fence();
+    };
     // Retire a pre-launched evaluation the loop did not need: ARG_SKIP, then wait until the launch has SEEN it (mailbox word
     // 32 := its sequence number).  Usually that launch is already polling and answers within a PCIe round trip; when it is
     // still queued behind other streams' kernels the wait is what keeps the next frame's first arguments from overwriting the
     // line it has yet to read (measured without it: 1 overlap run in ~10 lost 50 ms -- one ARG_TIMEOUT -- in a single frame).
     auto retire = [&](int seq) {
+        for (int g = 1; g < n_groups; g++) write_line(g, seq, ARG_SKIP, 0, 0, nullptr);
         publish(seq, ARG_SKIP, 0, 0, nullptr);
         for (long spin = 0; spin < 400000000L; spin++) {  // (bounded; the launch gives up by itself after ARG_TIMEOUT)
             if (float_bits(mailbox[32]) == seq) break;
@@ -920,195 +1069,184 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     pending.ret = &retire;
     auto prelaunch = [&]() -> int {
         pending.seq = next_seq();
-        track_eval_poll_kernel<<<EV_MAX_WGS, EV_THREADS, 0, st>>>(pl, w.partial, w.sync, w.result, mailbox, pending.seq, parity);
+        track_eval_poll_kernel<<<n_groups * EV_MAX_WGS, EV_THREADS, 0, st>>>(pl, w.partial, w.sync, w.result, mailbox, pending.seq, parity);
         return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
     };
 
-    float hessian_good[36] = {0}, nabla_good[6] = {0}, hessian_depth_good[36] = {0}, f_depth_good = 0;
-    int nvalid_depth_good = 0, eval_launches = 0;
-    float M[16], invM[16];
-    memcpy(M, ts->pose_M, 64);
-    memcpy(invM, ts->pose_invM, 64);  // kept consistent with pose_M by every writer of the state
-    int last_type = TRK_NONE;
+    // The LM loop.  An evaluation is handed the loop's next pose AND (BAR line + a mailbox with room for the answers,
+    // gps_track_state.mailbox_bytes) the poses the loop would evaluate after it if it is rejected: a rejection reads nothing of
+    // the evaluation it rejects (the pose goes back to the last good one, the damping goes up, the step is solved from the
+    // last good Hessian), so those poses are known now.  28 % of the evaluations of a frame are rejections, mostly in runs
+    // (tools/lm_trace.py); with the follow-up already evaluated the loop goes on without another host <-> device round trip.
+    // The sums it consumes are those of the same launches of the same kernel body: the poses are bit-equal with and without.
+    LmLoop lm;
+    lm.start(c, ts->pose_M, ts->pose_invM);
+    int eval_launches = 0, spec_issued = 0, spec_used = 0;
     for (int k = 0; k < 16; k++) ts->diag[k] = 0;
     const int use_weights = ts->frames_processed >= 100;
-    int mailbox_iterations = 0, n_valid_bits = 0;
 
-    for (int level = c->n_levels - 1; level >= 0; level--) {
-        const int it = c->iter_type[level];
-        if (it == TRK_NONE) continue;
-        last_type = it;
-        float approxInvPose[16], lastGoodM[16], lastGoodInvM[16];
-        memcpy(approxInvPose, invM, 64);
-        memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
-        float f_old = 3.402823466e+38f, lambda = 1.0f;
-        const int noPara = it == TRK_BOTH ? 6 : 3;
-        for (int iter = 0; iter < c->n_iter[level]; iter++) {
-            GhArgs a;
-            a.depth = dl[level]; a.vw = lw[level]; a.vh = lh[level];
-            a.view_intr = make_float4(lintr[level][0], lintr[level][1], lintr[level][2], lintr[level][3]);
-            a.pn = w.pn;
-            a.sw = W; a.sh = H;
-            a.scene_intr = make_float4(lintr[0][0], lintr[0][1], lintr[0][2], lintr[0][3]);
-            a.approxInvPose = load_mat(approxInvPose); a.scenePose = load_mat(ts->pose_pc_M);
-            a.space_thresh = c->space_thresh[level]; a.tukey_cutoff = c->tukey_cutoff; a.vf_min = s.view_frustum_min;
-            a.vf_max = s.view_frustum_max; a.use_weights = use_weights; a.frames_to_skip = c->frames_to_skip;
-            a.frames_to_weight = c->frames_to_weight;
-            const int n_wgs = min(EV_MAX_WGS, gps_div_up(a.vw * a.vh, EV_THREADS));
-            float raw[GH_SLOTS];  // two 64-byte chunks: 15 payload words + the sequence number each (eval_body)
-            if (mailbox) {
-                // this evaluation is the pre-launched kernel (or the frame's first launch): hand it its arguments, then put
-                // the NEXT evaluation on the stream before waiting -- its launch cost overlaps this evaluation
-                if (!pending.seq && prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
-                const int seq = pending.seq;
-                pending.seq = 0;
-                mailbox[15] = 0.0f; mailbox[31] = 0.0f;  // per-state sequence numbers (>= 1): nothing stale can match
-                publish(seq, ARG_RUN, it, level, approxInvPose);
-                eval_launches++;
-                if (prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
-                // spin on the sequence number the kernel writes last (bounded)
-                bool got = false;
-                // (diagnostic, free: the time-stamp counter around every poll tells a GPU that answered late from a host
-                // thread that was not running -- the longest gap between two consecutive polls is ~20 ns unless the thread
-                // was descheduled in between)
-                const unsigned long long tsc0 = host_cycles();
-                unsigned long long tsc_prev = tsc0, tsc_gap = 0;
-                for (long spin = 0; spin < 200000000L; spin++) {
-                    if (float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq) { got = true; break; }
-                    const unsigned long long now = host_cycles();
-                    if (now - tsc_prev > tsc_gap) tsc_gap = now - tsc_prev;
-                    tsc_prev = now;
-                    // a result normally lands within ~20 us (a few thousand polls); a host that is still spinning far beyond
-                    // that is oversubscribed or the GPU is busy elsewhere: stop burning the core between polls
+    while (lm.active) {
+        const LmRequest req = lm.request();
+        const int level = req.level, it = req.kind;
+        LmRequest cand[EV_GROUPS];
+        int nc = 0;
+        // (the first evaluation of a level is only rejected when it has no valid pixel at all: nothing rides along with it)
+        if (n_groups > 1 && lm.iter > 0) {
+            LmLoop sim = lm;
+            while (nc < n_groups - 1) {
+                sim.apply(nullptr);
+                if (!sim.active) break;
+                cand[nc++] = sim.request();
+            }
+        }
+        GhArgs a;
+        a.depth = dl[level]; a.vw = lw[level]; a.vh = lh[level];
+        a.view_intr = make_float4(lintr[level][0], lintr[level][1], lintr[level][2], lintr[level][3]);
+        a.pn = w.pn;
+        a.sw = W; a.sh = H;
+        a.scene_intr = make_float4(lintr[0][0], lintr[0][1], lintr[0][2], lintr[0][3]);
+        a.approxInvPose = load_mat(req.pose); a.scenePose = load_mat(ts->pose_pc_M);
+        a.space_thresh = c->space_thresh[level]; a.tukey_cutoff = c->tukey_cutoff; a.vf_min = s.view_frustum_min;
+        a.vf_max = s.view_frustum_max; a.use_weights = use_weights; a.frames_to_skip = c->frames_to_skip;
+        a.frames_to_weight = c->frames_to_weight;
+        const int n_wgs = min(EV_MAX_WGS, gps_div_up(a.vw * a.vh, EV_THREADS));
+        float raw[EV_GROUPS][GH_SLOTS];  // per group two 64-byte chunks: 15 payload words + the sequence number each (eval_body)
+        int answers = 1;                 // raw[0 .. answers) hold results: the evaluation itself, then the poses that rode along
+        if (mailbox) {
+            // this evaluation is the pre-launched kernel (or the frame's first launch): hand it its arguments, then put
+            // the NEXT evaluation on the stream before waiting -- its launch cost overlaps this evaluation
+            if (!pending.seq && prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
+            const int seq = pending.seq;
+            pending.seq = 0;
+            for (int g = 0; g < n_groups; g++) {   // per-state sequence numbers (>= 1): nothing stale can match
+                mailbox[g * MAILBOX_GROUP_WORDS + 15] = 0.0f; mailbox[g * MAILBOX_GROUP_WORDS + 31] = 0.0f;
+            }
+            for (int g = 1; g < n_groups; g++) {
+                if (g <= nc) write_line(g, seq, ARG_RUN, cand[g - 1].kind, cand[g - 1].level, cand[g - 1].pose);
+                else write_line(g, seq, ARG_SKIP, 0, 0, nullptr);
+            }
+            publish(seq, ARG_RUN, it, level, req.pose);
+            eval_launches++;
+            spec_issued += nc;
+            if (prelaunch() != GPS_OK) GPS_FAIL_LAUNCH();
+            // spin on the sequence number the kernel writes last (bounded)
+            bool got = false, by_mailbox = true;
+            // (diagnostic, free: the time-stamp counter around every poll tells a GPU that answered late from a host
+            // thread that was not running -- the longest gap between two consecutive polls is ~20 ns unless the thread
+            // was descheduled in between)
+            const unsigned long long tsc0 = host_cycles();
+            unsigned long long tsc_prev = tsc0, tsc_gap = 0;
+            for (long spin = 0; spin < 200000000L; spin++) {
+                if (float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq) { got = true; break; }
+                const unsigned long long now = host_cycles();
+                if (now - tsc_prev > tsc_gap) tsc_gap = now - tsc_prev;
+                tsc_prev = now;
+                // a result normally lands within ~20 us (a few thousand polls); a host that is still spinning far beyond
+                // that is oversubscribed or the GPU is busy elsewhere: stop burning the core between polls
+                if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+            }
+            if (tsc_prev - tsc0 > 6000000ull) {  // > ~2-3 ms at 2-3 GHz: rare; say which side lost the time
+                static int said = 0;
+                if (said < 16 && ++said)
+                    fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d answered after %.2f Mcycles (TSC); longest gap between two "
+                                    "polls of this thread %.2f Mcycles (level %d, iteration %d)\n", seq, (tsc_prev - tsc0) * 1e-6,
+                            tsc_gap * 1e-6, level, lm.iter);
+            }
+            if (!got) {
+                // No answer within the spin budget.  Either launch `seq` gave up before its line arrived (this thread was
+                // descheduled for longer than ARG_TIMEOUT between the launch and the publish) or it has not STARTED yet (the
+                // stream is held behind another stream's gate).  Launch seq + 1 may only be retired through the argument line
+                // once launch seq is known to have read it -- otherwise seq, starting late, would never find its line and sit
+                // out ARG_TIMEOUT with the frame stream behind it.  So: leave RUN(seq) in place and wait until seq has answered
+                // after all (tags) or has retired itself (acknowledgement word).
+                bool late = false, gone = false;
+                for (long spin = 0; spin < 400000000L && !late && !gone; spin++) {
+                    late = float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq;
+                    gone = float_bits(mailbox[32]) == seq;
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                 }
-                if (tsc_prev - tsc0 > 6000000ull) {  // > ~2-3 ms at 2-3 GHz: rare; say which side lost the time
-                    static int said = 0;
-                    if (said < 16 && ++said)
-                        fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d answered after %.2f Mcycles (TSC); longest gap between two "
-                                        "polls of this thread %.2f Mcycles (level %d, iteration %d)\n", seq, (tsc_prev - tsc0) * 1e-6,
-                                tsc_gap * 1e-6, level, iter);
-                }
-                if (!got) {
-                    // No answer within the spin budget.  Either launch `seq` gave up before its line arrived (this thread was
-                    // descheduled for longer than ARG_TIMEOUT between the launch and the publish) or it has not STARTED yet (the
-                    // stream is held behind another stream's gate).  There is one argument line: launch seq + 1 may only be
-                    // retired through it once launch seq is known to have read it -- otherwise seq, starting late, would never
-                    // find its line and sit out ARG_TIMEOUT with the frame stream behind it.  So: leave RUN(seq) in place and wait
-                    // until seq has answered after all (tags) or has retired itself (acknowledgement word).
-                    bool late = false, gone = false;
-                    for (long spin = 0; spin < 400000000L && !late && !gone; spin++) {
-                        late = float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq;
-                        gone = float_bits(mailbox[32]) == seq;
-                        if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
-                    }
-                    if (!late && !gone) {
-                        // Neither an answer nor a retirement (e.g. the line arrived while part of the launch's workgroups had
-                        // already sat out ARG_TIMEOUT: the summer then waits for rows that never come and gives up silently).
-                        // Drain the stream instead of failing the frame: launch seq ends by one of its timeouts, the queued
-                        // launch seq + 1 never finds its line and retires itself; then nobody polls the line any more and the
-                        // plain launch below redoes the evaluation (same inputs, same fixed-order sums).
-                        fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d neither answered nor retired; draining the stream\n", seq);
-                        if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
-                        pending.seq = 0;
-                    }
-                    got = late;
-                }
-                if (!got) {
-                    static int warned = 0;   // (rare by construction; a steady stream of these is a bug worth seeing)
-                    if (warned < 8 && ++warned)
-                        fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d gave up waiting for its argument line; redone by a plain launch\n", seq);
-                    if (pending.seq) retire(pending.seq);
+                if (!late && !gone) {
+                    // Neither an answer nor a retirement (e.g. the line arrived while part of the launch's workgroups had
+                    // already sat out ARG_TIMEOUT: the summer then waits for rows that never come and gives up silently).
+                    // Drain the stream instead of failing the frame: launch seq ends by one of its timeouts, the queued
+                    // launch seq + 1 never finds its line and retires itself; then nobody polls the line any more and the
+                    // plain launch below redoes the evaluation (same inputs, same fixed-order sums).
+                    fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d neither answered nor retired; draining the stream\n", seq);
+                    if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
                     pending.seq = 0;
-                    // a launch that gave up may have left the evaluation ticket partially counted and rows half delivered:
-                    // both start from zero for the plain launch (the valid-pixel counts next to the ticket stay)
-                    if (hipMemsetAsync(w.sync, 0, sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
-                    if (hipMemsetAsync(w.partial, 0, (size_t)EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
-                    const int seq2 = next_seq();
-                    if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
-                    else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
-                    else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
-                    GPS_LAUNCH_CHECK();
-                    if (hipStreamSynchronize(st) != hipSuccess || float_bits(mailbox[15]) != seq2 || float_bits(mailbox[31]) != seq2)
-                        GPS_FAIL_LAUNCH();
                 }
-                for (int k = 0; k < GH_SLOTS; k++) raw[k] = mailbox[k];
-                mailbox_iterations++;
-            } else {
-                const int seq = next_seq();
-                if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
-                else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
-                else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+                got = late;
+            }
+            if (!got) {
+                static int warned = 0;   // (rare by construction; a steady stream of these is a bug worth seeing)
+                if (warned < 8 && ++warned)
+                    fprintf(stderr, "[gps_slam_hip] tracker: evaluation %d gave up waiting for its argument line; redone by a plain launch\n", seq);
+                if (pending.seq) retire(pending.seq);
+                pending.seq = 0;
+                // a launch that gave up may have left the evaluation ticket partially counted and rows half delivered:
+                // both start from zero for the plain launch (the valid-pixel counts next to the ticket stay)
+                if (hipMemsetAsync(w.sync, 0, sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
+                if (hipMemsetAsync(w.partial, 0, (size_t)EV_GROUPS * EV_MAX_WGS * GH_SLOTS * sizeof(uint32_t), st) != hipSuccess) GPS_FAIL_LAUNCH();
+                const int seq2 = next_seq();
+                if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
+                else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
+                else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, mailbox, seq2, parity);
                 GPS_LAUNCH_CHECK();
-                eval_launches++;
-                // the reference's GPU tracker reads its 32 accumulators back every iteration as well
-                if (hipMemcpyAsync(raw, w.result, sizeof(raw), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
-                if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
-                if (float_bits(raw[15]) != seq || float_bits(raw[31]) != seq) GPS_FAIL_LAUNCH();  // the summer gave up
+                if (hipStreamSynchronize(st) != hipSuccess || float_bits(mailbox[15]) != seq2 || float_bits(mailbox[31]) != seq2)
+                    GPS_FAIL_LAUNCH();
+                by_mailbox = false;   // (whatever rode along with launch seq is not waited for)
+            }
+            for (int k = 0; k < GH_SLOTS; k++) raw[0][k] = mailbox[k];
+            // The poses that rode along: their groups started with group 0's and end within a few microseconds of it.  ALWAYS waited
+            // for, needed or not: the next launch's lines may only be written once every workgroup of this one that has pixels has
+            // delivered its row (a workgroup that finds a later line takes itself out -- its group's summer would then wait
+            // for that row until ROW_TIMEOUT, with the frame stream behind it).
+            for (int g = 1; by_mailbox && g <= nc; g++) {
+                volatile float* const mb = mailbox + g * MAILBOX_GROUP_WORDS;
+                bool have = false;
+                for (long spin = 0; spin < 200000000L; spin++) {
+                    if (float_bits(mb[15]) == seq && float_bits(mb[31]) == seq) { have = true; break; }
+                    if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+                }
+                if (!have) {
+                    static int warned2 = 0;
+                    if (warned2 < 8 && ++warned2)
+                        fprintf(stderr, "[gps_slam_hip] tracker: the pose riding along with evaluation %d (group %d) never answered\n", seq, g);
+                    break;
+                }
+                for (int k = 0; k < GH_SLOTS; k++) raw[g][k] = mb[k];
+                answers = g + 1;
+            }
+        } else {
+            const int seq = next_seq();
+            if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+            else if (it == TRK_TRANSLATION) track_eval_kernel<TRK_TRANSLATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+            else track_eval_kernel<TRK_BOTH><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
+            GPS_LAUNCH_CHECK();
+            eval_launches++;
+            // the reference's GPU tracker reads its 32 accumulators back every iteration as well
+            if (hipMemcpyAsync(raw[0], w.result, sizeof(raw[0]), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
+            if (hipStreamSynchronize(st) != hipSuccess) GPS_FAIL_LAUNCH();
+            if (float_bits(raw[0][15]) != seq || float_bits(raw[0][31]) != seq) GPS_FAIL_LAUNCH();  // the summer gave up
+        }
+        // the loop's decision on the evaluation -- and, while it keeps rejecting, on the poses that rode along with it
+        bool rejected = true;
+        for (int g = 0; g < answers && rejected && lm.active; g++) {
+            if (g > 0) {
+                if (!lm.request().same(cand[g - 1])) break;   // (cannot happen: the same arithmetic on the same state)
+                spec_used++;
             }
             float host[GH_SLOTS];
-            for (int d = 0; d < 30; d++) host[d] = raw[d + d / 15];  // payload d lives in word d + d / 15
-            n_valid_bits = float_bits(host[29]);
-
-            float hessian_depth[36] = {0}, nabla_depth[6] = {0};
-            const int nvalid = (int)host[0];
-            float f_depth = host[1];
-            for (int r = 0; r < noPara; r++) nabla_depth[r] = host[2 + r];
-            for (int r = 0, counter = 0; r < noPara; r++)
-                for (int cc = 0; cc <= r; cc++, counter++) hessian_depth[r + cc * 6] = host[2 + noPara + counter];
-            for (int r = 0; r < noPara; ++r)
-                for (int cc = r + 1; cc < noPara; cc++) hessian_depth[r + cc * 6] = hessian_depth[cc + r * 6];
-            if (nvalid > 100) {
-                for (int i = 0; i < 36; ++i) hessian_depth[i] /= nvalid;
-                for (int i = 0; i < 6; ++i) nabla_depth[i] /= nvalid;
-                f_depth /= nvalid;
-            } else {
-                f_depth = 3.402823466e+38f;
-            }
-            ts->diag[level] += 1;
-            if ((nvalid <= 0) || (f_depth >= f_old)) {
-                memcpy(M, lastGoodM, 64); memcpy(invM, lastGoodInvM, 64);
-                memcpy(approxInvPose, invM, 64);
-                lambda *= 10.0f;
-            } else {
-                memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
-                f_old = f_depth;
-                memcpy(hessian_good, hessian_depth, sizeof(hessian_good));
-                memcpy(nabla_good, nabla_depth, sizeof(nabla_good));
-                lambda /= 10.0f;
-                nvalid_depth_good = nvalid; f_depth_good = f_depth;
-                memcpy(hessian_depth_good, hessian_depth, sizeof(hessian_depth));
-            }
-            float A[36];
-            for (int i = 0; i < 36; ++i) A[i] = hessian_good[i];
-            for (int i = 0; i < 6; ++i) A[i + i * 6] *= 1.0f + lambda;
-            float step[6] = {0, 0, 0, 0, 0, 0};
-            if (it != TRK_BOTH) {
-                float small[9];
-                for (int r = 0; r < 3; r++)
-                    for (int cc = 0; cc < 3; cc++) small[r + cc * 3] = A[r + cc * 6];
-                Chol(small, 3).backsub(step, nabla_good);
-            } else {
-                Chol(A, 6).backsub(step, nabla_good);
-            }
-            float s6[6] = {0, 0, 0, 0, 0, 0};
-            if (it == TRK_ROTATION) { s6[0] = step[0]; s6[1] = step[1]; s6[2] = step[2]; }
-            else if (it == TRK_TRANSLATION) { s6[3] = step[0]; s6[4] = step[1]; s6[5] = step[2]; }
-            else { for (int i = 0; i < 6; i++) s6[i] = step[i]; }
-            float Tinc[16];
-            Tinc[0 * 4 + 0] = 1.0f;   Tinc[1 * 4 + 0] = s6[2];  Tinc[2 * 4 + 0] = -s6[1]; Tinc[3 * 4 + 0] = s6[3];
-            Tinc[0 * 4 + 1] = -s6[2]; Tinc[1 * 4 + 1] = 1.0f;   Tinc[2 * 4 + 1] = s6[0];  Tinc[3 * 4 + 1] = s6[4];
-            Tinc[0 * 4 + 2] = s6[1];  Tinc[1 * 4 + 2] = -s6[0]; Tinc[2 * 4 + 2] = 1.0f;   Tinc[3 * 4 + 2] = s6[5];
-            Tinc[0 * 4 + 3] = 0.0f;   Tinc[1 * 4 + 3] = 0.0f;   Tinc[2 * 4 + 3] = 0.0f;   Tinc[3 * 4 + 3] = 1.0f;
-            m4_mul(Tinc, approxInvPose, approxInvPose);
-            if (!set_invM_coerce(approxInvPose, M, invM)) return GPS_ERR_ARG;
-            memcpy(approxInvPose, invM, 64);
-            bool converged = true;
-            for (int i = 0; i < 6; i++)
-                if (fabs(step[i]) > c->term_thresh) { converged = false; break; }
-            if (converged) break;
+            for (int d = 0; d < 30; d++) host[d] = raw[g][d + d / 15];  // payload d lives in word d + d / 15
+            rejected = lm.apply(host);
+            if (lm.bad_pose) return GPS_ERR_ARG;
         }
     }
+    const int n_valid_bits = lm.n_valid_bits, last_type = lm.last_type, nvalid_depth_good = lm.nvalid_depth_good;
+    const float f_depth_good = lm.f_depth_good;
+    const float *M = lm.M, *invM = lm.invM, *hessian_depth_good = lm.hessian_depth_good;
+    for (int l = 0; l < GPS_TRACK_MAX_LEVELS && l < 8; l++) ts->diag[l] = (float)lm.evals[l];
+    ts->diag[12] = (float)spec_issued; ts->diag[13] = (float)spec_used;   // poses that rode along / that the loop then consumed
     memcpy(ts->pose_M, M, 64); memcpy(ts->pose_invM, invM, 64);
     // UpdatePoseQuality: the residual score (the SVM verdict only feeds failure modes that are off by default,
     // ITMLibSettings.cpp:42 behaviourOnFailure = FAILUREMODE_IGNORE)

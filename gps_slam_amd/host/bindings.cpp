@@ -155,6 +155,9 @@ PYBIND11_MODULE(_host, m) {
         .def("turnOnTracking", [](TsdfEngine& e) { e.turnOnTracking(); })
         .def("setBarArgLine", &TsdfEngine::setBarArgLine)
         .def("usesBarArgLine", &TsdfEngine::usesBarArgLine)
+        .def("setPosesRidingAlong", &TsdfEngine::setPosesRidingAlong)
+        .def("posesRidingAlong", &TsdfEngine::posesRidingAlong)
+        .def("ridingAlongStats", &TsdfEngine::ridingAlongStats)
         .def("lastPose", [](TsdfEngine& e) {
             auto t = torch::empty({2, 16}, torch::kFloat32);
             const ORUtils::SE3Pose& p = e.camPoses.back();

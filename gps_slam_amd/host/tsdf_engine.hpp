@@ -196,6 +196,15 @@ public:
     // the tracker's argument line through the BAR (default, when the device memory is host-visible) or in the pinned mailbox
     void setBarArgLine(bool on) { bar_arg_line = on; track_state_.dev_arg_line = on ? track_arg_line_.get() : nullptr; }
     bool usesBarArgLine() const { return track_state_.dev_arg_line != nullptr; }
+    // how many of the poses the LM loop would evaluate after a REJECTION ride along with every evaluation (0..2; BAR line only;
+    // gps_track_state.mailbox_bytes).  Same poses, fewer round trips; the switch exists for A/B measurements and the equality test.
+    void setPosesRidingAlong(int n) {
+        poses_riding_along = n < 0 ? 0 : n > kMaxRidingAlong ? kMaxRidingAlong : n;
+        track_state_.mailbox_bytes = 256 * (1 + poses_riding_along);
+    }
+    int posesRidingAlong() const { return poses_riding_along; }
+    // of the last tracked frame: {poses that rode along with evaluations, poses the loop consumed}
+    std::pair<int, int> ridingAlongStats() const { return {(int)track_state_.diag[12], (int)track_state_.diag[13]}; }
     void turnOnTracking(const char* levels = "rrbb", int numIterC = 20, int numIterF = 50, float outlierSpaceC = 0.1f,
                         float outlierSpaceF = 0.004f, float minstep = 1e-4f, float tukeyCutOff = 8.0f, int framesToSkip = 20,
                         int framesToWeight = 50);
@@ -248,6 +257,8 @@ private:
     // switch exists for A/B measurements and for the tests that cover both hand-over paths.
     std::shared_ptr<void> track_arg_line_;
     bool bar_arg_line = true;
+    static constexpr int kMaxRidingAlong = 2;
+    int poses_riding_along = 1;   // (0 / 1 / 2 measured on the 640x480 loop: 973 / 993 / 980 frames/s sequential, 1,316 / 1,324 / 1,306 overlap)
     ORUtils::SE3Pose pose_d_;
     ITMTrackingState tracking_state_{&pose_d_};
     ITMUChar4Image free_image_;

@@ -715,7 +715,8 @@ typedef struct {
 } gps_track_config;
 
 /* ITMTrackingState as the tracker uses it (host memory): pose_d (M / invM), pose_pointCloud (M), age_pointCloud,
- * framesProcessed; diag = {iterations run on level 0..7, noValidPoints, f, trackerScore, det(H), ...} of the last call.
+ * framesProcessed; diag = {iterations run on level 0..7, noValidPoints, f, trackerScore, det(H), [12] poses that rode along with
+ * evaluations, [13] those the loop consumed} of the last call.
  * Matrices in ORUtils layout m[col*4 + row]. */
 typedef struct {
     float pose_M[16], pose_invM[16], pose_pc_M[16];
@@ -737,6 +738,13 @@ typedef struct {
      * and every workgroup polls it there; NULL = the line lives in the pinned mailbox, one workgroup polls it across PCIe and
      * relays it.  Owned by the caller; kept by gps_track_state_reset. */
     void *dev_arg_line;
+    /* size of host_mailbox in bytes; 0 = the 256 bytes above.  With dev_arg_line set and 256 * G bytes (G <= 3) an evaluation
+     * also takes the G - 1 poses the LM loop would evaluate next IF the evaluation is rejected (a rejection reads nothing of
+     * the evaluation it rejects -- ITMExtendedTracker.cpp:601-612 -- so the host knows them in advance): group g's answer lands
+     * in words 64 g .. 64 g + 31 of the mailbox, its argument line 64 g bytes into dev_arg_line's block (the block
+     * gps_track_arg_line_alloc returns has room).  Same poses, bit for bit; fewer host <-> device round trips per frame
+     * (diag[12] / diag[13] = poses that rode along / that the loop consumed).  Kept by gps_track_state_reset. */
+    int32_t mailbox_bytes;
 } gps_track_state;
 
 /* Builds the configuration from the reference's tracker string parameters (ITMLibSettings.cpp:54-57 default:
@@ -749,7 +757,7 @@ GPS_API int gps_track_config_init(gps_track_config *c, const char *levels, int n
 /* ITMTrackingState::Reset: identity poses, no point cloud yet. */
 GPS_API int gps_track_state_reset(gps_track_state *ts);
 
-/* 64 bytes (one line, 64-byte aligned) of fine-grained device memory the HOST can write through the BAR, for
+/* A 4 KB block (64-byte aligned; the tracker uses its first 64 * G bytes, one line per group) of fine-grained device memory the HOST can write through the BAR, for
  * gps_track_state.dev_arg_line.  *line = NULL (and GPS_OK) when the device's memory is not host-visible (no large BAR): the
  * tracker then keeps its pinned argument line.  The one place the library allocates: ordinary device memory (hipMalloc, a torch
  * tensor) is not host-writable, so the caller cannot provide this block itself.  Free with gps_track_arg_line_free. */

@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
@@ -1004,6 +1005,11 @@ static void pose_set_invM_coerce(const float *invM_in, float *M, float *invM) {
  * diag[0..n_levels-1] = iterations run per level, diag[8] = noValidPoints of the last accepted evaluation,
  * diag[9] = its f, diag[10] = trackerScore (finalResidual_v2).  scratch: >= (W/2)*(H/2)*4/3 floats.
  * Returns the tracker-level framesProcessed to carry to the next call. */
+/* accept / reject decisions of the last orc_track_camera call, e.g. "3:AAR 2:AA 1:AARA 0:AA" (a probe aid for tools/: which
+ * evaluations of the LM loop are rejections, and where in a level they fall) */
+static char g_track_trace[1024];
+ORC_API const char *orc_track_trace(void) { return g_track_trace; }
+
 ORC_API int orc_track_camera(int W, int H, const float *intr /* fx fy cx cy */, const float *depth0, const V4 *points,
                              const V4 *normals, const float *scenePose, float *pose_M, float *pose_invM, const TrackCfg *c,
                              int frames_processed, float *scratch, float *diag) {
@@ -1029,10 +1035,13 @@ ORC_API int orc_track_camera(int W, int H, const float *intr /* fx fy cx cy */, 
     orc_mat4_inv(M, invM);
     int last_type = TRK_NONE;
     for (int k = 0; k < 16; k++) diag[k] = 0;
+    int tp = 0;
+    g_track_trace[0] = 0;
     for (int level = c->n_levels - 1; level >= 0; level--) {
         const int it = c->iter_type[level];
         if (it == TRK_NONE) continue;
         last_type = it;
+        if (tp < (int)sizeof(g_track_trace) - 8) tp += sprintf(g_track_trace + tp, "%s%d:", tp ? " " : "", level);
         float approxInvPose[16], lastGoodM[16], lastGoodInvM[16];
         memcpy(approxInvPose, invM, 64);
         memcpy(lastGoodM, M, 64); memcpy(lastGoodInvM, invM, 64);
@@ -1051,6 +1060,7 @@ ORC_API int orc_track_camera(int W, int H, const float *intr /* fx fy cx cy */, 
                 f_depth = 3.402823466e+38f;
             }
             diag[level] += 1;
+            if (tp < (int)sizeof(g_track_trace) - 8) { g_track_trace[tp++] = ((nvalid <= 0) || (f_depth >= f_old)) ? 'R' : 'A'; g_track_trace[tp] = 0; }
             if ((nvalid <= 0) || (f_depth >= f_old)) {
                 memcpy(M, lastGoodM, 64); memcpy(invM, lastGoodInvM, 64);
                 memcpy(approxInvPose, invM, 64);

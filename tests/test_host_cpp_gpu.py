@@ -468,13 +468,25 @@ def test_cpp_engine_tracks_like_the_reference():
     W, Hh, n = int(G["W"]), int(G["H"]), int(G["n_frames"])
     seq = synth.make_sequence(W, Hh, n, step_deg=float(G["step_deg"]))
     rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
-    eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], float(G["voxel"]), float(G["mu"]),
-                           float(G["vf_min"]), float(G["vf_max"]))
-    for f in range(n):
-        eng.ProcessFrame(T(rgba[f]), T(seq["depth"][f].astype(np.int16)))
-        pose = eng.lastPose().numpy()
-        assert np.abs(pose[0] - G["M"][f]).max() < 2e-5 and np.abs(pose[1] - G["invM"][f]).max() < 2e-5, f
-    assert eng.trackDiag()[8] > 10000  # inliers of the last accepted evaluation
+    runs = []
+    for riders in (1, 0, 2):   # poses of the LM loop's reject branch riding along with every evaluation (setPosesRidingAlong)
+        eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], float(G["voxel"]), float(G["mu"]),
+                               float(G["vf_min"]), float(G["vf_max"]))
+        assert eng.posesRidingAlong() == 1   # the default
+        eng.setPosesRidingAlong(riders)
+        poses, consumed = [], 0
+        for f in range(n):
+            eng.ProcessFrame(T(rgba[f]), T(seq["depth"][f].astype(np.int16)))
+            pose = eng.lastPose().numpy()
+            assert np.abs(pose[0] - G["M"][f]).max() < 2e-5 and np.abs(pose[1] - G["invM"][f]).max() < 2e-5, f
+            poses.append(pose.copy())
+            rode, used = eng.ridingAlongStats()
+            assert 0 <= used <= rode and (riders > 0 or rode == 0)
+            consumed += used
+        assert eng.trackDiag()[8] > 10000  # inliers of the last accepted evaluation
+        assert riders == 0 or not eng.usesBarArgLine() or consumed > 0
+        runs.append(np.stack(poses))
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])   # the same poses, bit for bit
 
 
 def test_cpp_engine_mesh_and_state_files_equal_python_host(tmp_path):

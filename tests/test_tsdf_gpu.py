@@ -327,30 +327,43 @@ def test_tracker_follows_ground_truth_at_full_size():
 def test_tracker_without_mailbox_gives_the_same_poses():
     """gps_track_state.host_mailbox == NULL: every evaluation is a plain launch and the sums come back by memcpy -- the same
     kernels' body, the same fixed-order sums, so the poses are bit-identical to the pre-launched / mailbox path; a state that is
-    handed a fresh scratch buffer (scratch_epoch = 0) keeps working."""
+    handed a fresh scratch buffer (scratch_epoch = 0) keeps working.  "alone" / "two-along": the default hand-over evaluates,
+    with every evaluation, the pose the LM loop would take next after a rejection (gps_track_state.mailbox_bytes) -- with none
+    or two of them riding along the poses and the per-level evaluation counts are the same, bit for bit."""
     from gps_slam_amd.tsdf_engine import TsdfEngine
     W, H, n = 320, 240, 8
     seq = synth.make_sequence(W, H, n, step_deg=0.4)
     rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
-    runs = []
-    for mode in ("mailbox", "memcpy", "new-scratch", "pinned-line"):
+    runs, counts, along = [], [], {}
+    for mode in ("mailbox", "memcpy", "new-scratch", "pinned-line", "alone", "two-along"):
         eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.01, mu=0.04, device="cuda:0")
         # "mailbox": the default hand-over -- pre-launched evaluations, argument line written through the BAR into device memory
         # (gps_track_state.dev_arg_line) when the device has a large BAR; "pinned-line": the line in the pinned mailbox, relayed
-        eng.turnOnTracking(bar_arg_line=mode != "pinned-line")
+        eng.turnOnTracking(bar_arg_line=mode != "pinned-line", poses_riding_along={"alone": 0, "two-along": 2}.get(mode, 1))
         assert (eng.track_state.dev_arg_line is None) == (mode == "pinned-line" or eng._arg_line is None)
         if mode == "memcpy":
             eng.track_state.host_mailbox = None
-        poses = []
+        poses, levels, rode, used = [], [], 0, 0
         for f in range(n):
             if mode == "new-scratch" and f == 4:
                 eng.track_scratch = torch.full_like(eng.track_scratch, 0x5A)  # garbage, not zeros
                 eng.track_state.scratch_epoch = 0
             M, invM = eng.ProcessFrameTracked(_dev(rgba[f]), _dev(seq["depth"][f].astype(np.int16)))
             poses.append(invM.copy())
+            d = np.array(eng.track_state.diag[:], np.float32)
+            levels.append(d[:12].copy())
+            rode += int(d[12]); used += int(d[13])
         runs.append(np.stack(poses))
+        counts.append(np.stack(levels))
+        along[mode] = (rode, used)
     assert all(np.array_equal(runs[0], r) for r in runs[1:])
+    assert all(np.array_equal(counts[0], c) for c in counts[1:])   # evaluations per level, valid points, f, score, det(H)
     assert np.abs(runs[0][-1] - runs[0][0]).max() > 1e-3  # the camera actually moved
+    assert along["memcpy"] == (0, 0) and along["pinned-line"] == (0, 0) and along["alone"] == (0, 0)
+    if eng._arg_line is not None:   # (a device whose memory the host can write: the BAR line)
+        rode, used = along["mailbox"]
+        assert rode > 0 and 0 < used <= rode, along
+        assert along["two-along"][0] > rode and along["two-along"][1] >= used, along
 
 
 # ----------------------------------------------------------------------------- meshing + persistence (SURVEY 8(f) rank 3)
