@@ -167,6 +167,11 @@ class Scene:
             self.pipe.prefetch_next_preprocess = os.environ["GPS_BENCH_PREFETCH"] != "0"
         if os.environ.get("GPS_BENCH_ASYNC_RAYCASTS"):  # A/B aid (tools/probe/outliers.sh): the keyframe views' raycasts beside the first iterations (1, default) or before them (0)
             self.pipe.async_raycasts = os.environ["GPS_BENCH_ASYNC_RAYCASTS"] != "0"
+        if os.environ.get("GPS_BENCH_STREAMS"):  # A/B aid: stream kinds "frame,map,raycast" (SLAMPipeline::frame_stream_kind ...; default 0,1,2)
+            f_, m_, r_ = (int(x) for x in os.environ["GPS_BENCH_STREAMS"].split(","))
+            self.pipe.frame_stream_kind, self.pipe.map_stream_kind, self.pipe.raycast_stream_kind = f_, m_, r_
+        if os.environ.get("GPS_BENCH_MERGE"):  # A/B aid: window and keyframe views raycast as one batch (default 0)
+            self.pipe.merge_keyframe_raycasts = os.environ["GPS_BENCH_MERGE"] != "0"
         self.model.reserveWorkspace(W, H)
 
     def run(self, lo, hi):

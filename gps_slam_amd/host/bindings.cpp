@@ -255,6 +255,9 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("overlap_mapping", &SLAMPipeline::overlap_mapping)
         .def_readwrite("mapping_thread", &SLAMPipeline::mapping_thread)
         .def_readwrite("async_raycasts", &SLAMPipeline::async_raycasts)
+        .def_readwrite("frame_stream_kind", &SLAMPipeline::frame_stream_kind)
+        .def_readwrite("map_stream_kind", &SLAMPipeline::map_stream_kind)
+        .def_readwrite("raycast_stream_kind", &SLAMPipeline::raycast_stream_kind)
         .def_readwrite("prefetch_next_preprocess", &SLAMPipeline::prefetch_next_preprocess)
         .def_readwrite("merge_keyframe_raycasts", &SLAMPipeline::merge_keyframe_raycasts)
         .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)

@@ -15,6 +15,18 @@ using namespace gpsh;
 namespace {
 inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
 struct MapStream { c10::hip::HIPStream s; };
+// kind 0 / 1: torch's high- / normal-priority pool; 2 / 3 / 4: a stream of this pipeline's own (hipStreamCreateWithPriority,
+// non-blocking) at the lowest / highest / default priority, wrapped for the stream guards
+c10::hip::HIPStream make_stream(int kind) {
+    const auto dev = c10::hip::current_device();
+    if (kind == 0) return c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev);
+    if (kind == 1) return c10::hip::getStreamFromPool(/*isHighPriority=*/false, dev);
+    int least = 0, greatest = 0;
+    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    hipStream_t st = nullptr;
+    hip_ok(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, kind == 2 ? least : kind == 3 ? greatest : 0), "hipStreamCreateWithPriority");
+    return c10::hip::getStreamFromExternal(st, dev);
+}
 }  // namespace
 using torch::indexing::Slice;
 
@@ -150,7 +162,7 @@ void SLAMPipeline::beginAsyncRaycasts() {
     rc_event_next_ = 0;
     if (!async_raycasts) return;
     if (!rc_stream_) {
-        rc_stream_ = new MapStream{c10::hip::getStreamFromPool(/*isHighPriority=*/true, c10::hip::current_device())};
+        rc_stream_ = new MapStream{make_stream(raycast_stream_kind)};
         hipEvent_t ev;
         hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
         ev_rc_begin_ = ev;
@@ -603,8 +615,8 @@ void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8,
 
 void SLAMPipeline::ensureStreams() {
     if (map_stream_) return;
-    map_stream_ = new MapStream{c10::hip::getStreamFromPool(/*isHighPriority=*/false, c10::hip::current_device())};
-    frame_stream_ = new MapStream{c10::hip::getStreamFromPool(/*isHighPriority=*/true, c10::hip::current_device())};
+    map_stream_ = new MapStream{make_stream(map_stream_kind)};
+    frame_stream_ = new MapStream{make_stream(frame_stream_kind)};
     for (void** e : {&ev_frame_, &ev_raycasts_, &ev_map_, &ev_caller_}) {
         hipEvent_t ev;
         hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");

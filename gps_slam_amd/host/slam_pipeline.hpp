@@ -144,6 +144,9 @@ public:
     bool merge_keyframe_raycasts = false;
     bool views_reserved_ = false, raycast_pool_warm_ = false;
     bool async_raycasts = true;   // the update's free-view raycasts run beside its optimise iterations (same results)
+    // which stream each chain gets (slam_pipeline.cpp: make_stream): 0 / 1 = torch's high- / normal-priority pool, 2 / 3 / 4 = a
+    // stream of the pipeline's own at the lowest / highest / default priority
+    int frame_stream_kind = 0, map_stream_kind = 1, raycast_stream_kind = 2;
     // an optimise iteration's backward + Adam kernel also runs the NEXT iteration's preprocessing forward (the next camera is drawn
     // one iteration early: same draws, same order): one launch and one pass over the parameters less per iteration, same results
     bool prefetch_next_preprocess = true;

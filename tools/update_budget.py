@@ -48,6 +48,7 @@ def main():
     print("frame stream %s (%s): update kernels %d, %d updates in the window set; frame-chain kernels: %d" %
           (frame_stream, "shared with the update" if shared else "update on other streams", len(ms), len(starts), len(other)))
     agg = defaultdict(lambda: [0.0, 0.0, 0])
+    with_iters = [u for u in range(len(starts) - 1) if any("preprocess_bwd" in r[0] for r in ms[starts[u]:starts[u + 1]])]
     for u in range(len(starts) - 1):
         ks = ms[starts[u]:starts[u + 1]]
         bw = [i for i, r in enumerate(ks) if "preprocess_bwd" in r[0]]
@@ -82,7 +83,7 @@ def main():
             a[0] += wall; a[1] += busy; a[2] += 1
             prev_end = part[-1][2]
         print(line)
-        if u == len(starts) - 2:   # the last complete update in detail: every kernel outside the iterations, gaps > 8 us inside them
+        if with_iters and u == with_iters[-1]:   # the last complete update in detail: every kernel outside the iterations, gaps > 8 us inside them
             print("  -- detail of this update (t from its first kernel; gap = idle time on the map stream before the kernel)")
             last_end = ks[0][1]
             for i, (n, s, e, st) in enumerate(ks):
