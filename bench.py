@@ -498,6 +498,14 @@ def _describe_and_measure(args, scene, seq, result, first, K, dt, marker):
                "tsdf_colour_psnr_db_vs_input": sum(psnr_tsdf) / max(1, len(views))}
     if not args.no_oracle_psnr and views:
         quality.update(render_psnr_vs_oracle(scene.model, views[-1][0], views[-1][1], seq))
+    tracker = None
+    if not args.gt_pose:   # the LM loop of the whole run of this scene (prologue + warm-up + timed windows)
+        fr, ev, rode, used = scene.engine.trackerTotals()
+        tracker = {"poses_riding_along": scene.engine.posesRidingAlong(), "evaluations_per_frame": ev / max(1, fr),
+                   "rode_along_per_frame": rode / max(1, fr), "consumed_per_frame": used / max(1, fr),
+                   "note": "with every evaluation the pose the LM loop would take next after a REJECTION is evaluated too (known "
+                           "beforehand: a rejection reads nothing of the evaluation it rejects); consumed = evaluations answered "
+                           "without another host <-> device round trip"}
     marker()  # phase marker: everything below is measurement scaffolding, not SLAM frames
     split = fusion_split(seq, first, K, args.gt_pose, dt)
     roof = roofline_section(scene, seq, result, HBM_PEAK_GBS, K, gt_pose=args.gt_pose)
@@ -506,6 +514,7 @@ def _describe_and_measure(args, scene, seq, result, first, K, dt, marker):
                         % (W, H, "given poses (use_gt_pose=true, as every shipped config)" if args.gt_pose else
                            "depth ICP tracking (ExtendedTracker, use_gt_pose=false)", N // 1000),
             "gaussians": N, "host": "cpp (createTsdfEngine -> CLIEngine -> SLAMPipeline)", "quality": quality, "split": split,
+            "tracker": tracker,
             "roofline": roof}
 
 

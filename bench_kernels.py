@@ -272,7 +272,9 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
         rows.append(dict(_kernel_row("track_eval_poll_kernel", ev, fus["poll_eval_s"] + fus["poll_spin_s"],
                                      36.0 * P * 0.332, hbm_peak_gbs, N, "host <-> device loop",
                                      "avg_us = GPU residency of one pre-launched evaluation = waiting for the host's argument line + "
-                                     "evaluating; bytes assume the evaluations spread evenly over the 4 pyramid levels"),
+                                     "evaluating; bytes assume the evaluations spread evenly over the 4 pyramid levels and count ONE evaluation per "
+                                     "launch (the pose that rides along, config.tracker, reads as much again when it runs: not counted, the "
+                                     "counters see it)"),
                          spin_us=fus["poll_spin_s"] * 1e6, eval_us=fus["poll_eval_s"] * 1e6,
                          gpu_held_idle_us_per_frame=ev * fus["poll_spin_s"] * 1e6,
                          tracking_ms_per_frame=fus["tracking_ms_per_frame"]))

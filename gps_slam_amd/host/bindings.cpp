@@ -158,6 +158,7 @@ PYBIND11_MODULE(_host, m) {
         .def("setPosesRidingAlong", &TsdfEngine::setPosesRidingAlong)
         .def("posesRidingAlong", &TsdfEngine::posesRidingAlong)
         .def("ridingAlongStats", &TsdfEngine::ridingAlongStats)
+        .def("trackerTotals", &TsdfEngine::trackerTotals)
         .def("lastPose", [](TsdfEngine& e) {
             auto t = torch::empty({2, 16}, torch::kFloat32);
             const ORUtils::SE3Pose& p = e.camPoses.back();

@@ -72,6 +72,7 @@ TsdfEngine::TsdfEngine(int width, int height, float fx, float fy, float cx, floa
 void TsdfEngine::resetAll() {
     check(gps_tsdf_reset(&state_, current_stream()), "gps_tsdf_reset");
     framesProcessed = 0;
+    tracked_frames_ = evals_total_ = rode_total_ = used_total_ = 0;
     camPoses.clear();
     camIntrincs.clear();
     check(gps_track_state_reset(&track_state_), "gps_track_state_reset");
@@ -117,6 +118,9 @@ ITMTrackingState* TsdfEngine::ProcessFrame(const torch::Tensor& rgb_u8, const to
                                                    gate ? &gate : nullptr),
               "gps_tsdf_process_frame_tracked");
         pose_d_.SetBoth(track_state_.pose_M, track_state_.pose_invM);
+        tracked_frames_++;
+        for (int l = 0; l < 8; l++) evals_total_ += (int64_t)track_state_.diag[l];
+        rode_total_ += (int64_t)track_state_.diag[12]; used_total_ += (int64_t)track_state_.diag[13];
     } else {
         TORCH_CHECK((int)gtC2wPoses.size() > framesProcessed, "gtC2wPoses must hold the pose of frame ", framesProcessed);
         auto c2w = gtC2wPoses[framesProcessed].to(torch::kCPU, torch::kFloat32).contiguous();

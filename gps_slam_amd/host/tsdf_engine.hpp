@@ -205,6 +205,8 @@ public:
     int posesRidingAlong() const { return poses_riding_along; }
     // of the last tracked frame: {poses that rode along with evaluations, poses the loop consumed}
     std::pair<int, int> ridingAlongStats() const { return {(int)track_state_.diag[12], (int)track_state_.diag[13]}; }
+    // since construction / resetAll: {tracked frames, evaluations the LM loop consumed, poses that rode along, of those consumed}
+    std::vector<int64_t> trackerTotals() const { return {tracked_frames_, evals_total_, rode_total_, used_total_}; }
     void turnOnTracking(const char* levels = "rrbb", int numIterC = 20, int numIterF = 50, float outlierSpaceC = 0.1f,
                         float outlierSpaceF = 0.004f, float minstep = 1e-4f, float tukeyCutOff = 8.0f, int framesToSkip = 20,
                         int framesToWeight = 50);
@@ -258,6 +260,7 @@ private:
     std::shared_ptr<void> track_arg_line_;
     bool bar_arg_line = true;
     static constexpr int kMaxRidingAlong = 2;
+    int64_t tracked_frames_ = 0, evals_total_ = 0, rode_total_ = 0, used_total_ = 0;
     int poses_riding_along = 1;   // (0 / 1 / 2 measured on the 640x480 loop: 973 / 993 / 980 frames/s sequential, 1,316 / 1,324 / 1,306 overlap)
     ORUtils::SE3Pose pose_d_;
     ITMTrackingState tracking_state_{&pose_d_};
