@@ -920,6 +920,10 @@ int64_t gps_track_scratch_bytes(int width, int height) {
 
 static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c, gps_track_state* ts, void* scratch,
                              int64_t scratch_bytes, gps_stream stream, const int16_t* depth_mm);
+static inline double wall_ms() {
+    timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
 
 int gps_tsdf_track_camera(const gps_tsdf_state* sp, const gps_track_config* c, gps_track_state* ts, void* scratch,
                           int64_t scratch_bytes, gps_stream stream) {
@@ -1282,17 +1286,21 @@ int gps_tsdf_process_frame_tracked_gated(const gps_tsdf_state* s, const int16_t*
     if (ts->age_point_cloud != -1) {  // ITMTrackingState::HasValidPointCloud
         if (ts->age_point_cloud >= 0) ts->frames_processed++; else ts->frames_processed = 0;
         // (the depth conversion rides in the tracker's prepare launch)
+        const double t0 = wall_ms();
         if ((r = track_camera_impl(s, cfg, ts, scratch, scratch_bytes, stream, depth_mm)) != GPS_OK) return r;
+        ts->diag[14] = (float)(wall_ms() - t0);   // host milliseconds in the tracker (launches + LM loop)
     } else {
         if ((r = gps_tsdf_convert_depth(s, depth_mm, stream)) != GPS_OK) return r;
     }
     if (before_fusion) before_fusion(user);  // everything above only READ the volume; what follows modifies it
+    const double t1 = wall_ms();
     if ((r = gps_tsdf_allocate(s, ts->pose_M, ts->pose_invM, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_integrate(s, ts->pose_M, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_expected_depths_and_raycast(s, ts->pose_M, ts->pose_invM, 0, 1, stream)) != GPS_OK) return r;
     if ((r = gps_tsdf_icp_maps(s, ts->pose_invM, stream)) != GPS_OK) return r;
     memcpy(ts->pose_pc_M, ts->pose_M, 64);  // pose_pointCloud := pose_d (ITMTrackingController.h:87-93)
     ts->age_point_cloud = (ts->age_point_cloud == -1) ? -2 : 0;
+    ts->diag[15] = (float)(wall_ms() - t1);   // host milliseconds spent ENQUEUEING the fusion + raycast + ICP-map kernels
     return GPS_OK;
 }
 

@@ -586,8 +586,8 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     }
     const double thr = pipe_times_threshold_ms(), tt3 = now_ms();
     if (thr >= 0.0 && tt3 - tt0 > thr)
-        fprintf(stderr, "[pipe] frame %d: %.3f ms = engine %.3f (gate wait %.3f) + toGPU %.3f + lists / keyframe step %.3f (hand-over wait %.3f)\n",
-                i, tt3 - tt0, tt1 - tt0, g_gate_wait_ms, tt2 - tt1, tt3 - tt2, g_handover_wait_ms);
+        fprintf(stderr, "[pipe] frame %d: %.3f ms = engine %.3f (tracker %.3f, fusion enqueue %.3f, gate wait %.3f) + toGPU %.3f + lists / keyframe step %.3f (hand-over wait %.3f)\n",
+                i, tt3 - tt0, tt1 - tt0, main_engine->trackDiag(14), main_engine->trackDiag(15), g_gate_wait_ms, tt2 - tt1, tt3 - tt2, g_handover_wait_ms);
 }
 
 // ------------------------------------------------------------------ tracking / mapping overlap (see slam_pipeline.hpp)

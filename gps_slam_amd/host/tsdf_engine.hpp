@@ -204,6 +204,7 @@ public:
     }
     int posesRidingAlong() const { return poses_riding_along; }
     // of the last tracked frame: {poses that rode along with evaluations, poses the loop consumed}
+    float trackDiag(int k) const { return k >= 0 && k < 16 ? track_state_.diag[k] : 0.0f; }
     std::pair<int, int> ridingAlongStats() const { return {(int)track_state_.diag[12], (int)track_state_.diag[13]}; }
     // since construction / resetAll: {tracked frames, evaluations the LM loop consumed, poses that rode along, of those consumed}
     std::vector<int64_t> trackerTotals() const { return {tracked_frames_, evals_total_, rode_total_, used_total_}; }

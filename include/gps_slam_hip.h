@@ -716,7 +716,8 @@ typedef struct {
 
 /* ITMTrackingState as the tracker uses it (host memory): pose_d (M / invM), pose_pointCloud (M), age_pointCloud,
  * framesProcessed; diag = {iterations run on level 0..7, noValidPoints, f, trackerScore, det(H), [12] poses that rode along with
- * evaluations, [13] those the loop consumed} of the last call.
+ * evaluations, [13] those the loop consumed, [14] host ms in the tracker, [15] host ms enqueueing the fusion kernels
+ * (gps_tsdf_process_frame_tracked)} of the last call.
  * Matrices in ORUtils layout m[col*4 + row]. */
 typedef struct {
     float pose_M[16], pose_invM[16], pose_pc_M[16];
