@@ -123,10 +123,21 @@ def seed_gaussians(seq, n_gauss, seed, device):
     return [new[k].contiguous() for k in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities")]
 
 
-class Scene:
-    """One scene on the C++ host layer, built the way slam_trainer.cpp builds it."""
+ENV_SWITCHES = ("GPS_BENCH_PINNED_LINE", "GPS_BENCH_RIDING_ALONG", "GPS_BENCH_OPT_ITERS", "GPS_BENCH_PREFETCH", "GPS_BENCH_ASYNC_RAYCASTS",
+                "GPS_BENCH_STREAMS", "GPS_BENCH_MERGE", "GPS_BENCH_FRAME_TIMES", "GPS_BENCH_PIPE_TIMES", "GPS_BENCH_SHARE_GPU")
 
-    def __init__(self, seq, seeds, seed, use_gt_pose, overlap, n_frames, keyframe_theta, keyframe_trans):
+
+def env_overrides():
+    """the A/B switches of this file that are set in the environment, as one string ("" in a normal run): every one of them
+    changes what the line's numbers mean, so the line says which were on"""
+    return ",".join("%s=%s" % (k, os.environ[k]) for k in ENV_SWITCHES if os.environ.get(k))
+
+
+class Scene:
+    """One scene on the C++ host layer, built the way slam_trainer.cpp builds it.  `seeds` = None: the model starts EMPTY, as the
+    reference's does (the first keyframe update fills it from the whole first view)."""
+
+    def __init__(self, seq, seeds, seed, use_gt_pose, overlap, n_frames, keyframe_theta, keyframe_trans, capacity=1 << 19):
         import gps_slam_amd._host as H_
         self.H_ = H_
         W, H = seq["W"], seq["H"]
@@ -135,10 +146,11 @@ class Scene:
         for k in range(n_frames):
             c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k]))
             c.id = k
-            # what the dataset reader holds in host memory (float image / depth); createTsdfEngine turns them into the
-            # uchar4 / short images the engine consumes
-            c.image = torch.as_tensor(seq["rgb"][k].astype(np.float32) / 255.0)
-            c.depth = torch.as_tensor(seq["depth"][k].astype(np.float32) / 1000.0)[..., None]
+            # what the dataset's files hold (uint8 colour, uint16 millimetres): createTsdfEngine turns them into the uchar4 / short
+            # images the engine consumes -- the same bytes as from the reader's float image / depth (tests/test_tsdf_facade_gpu.py),
+            # without 16 bytes per pixel and frame of host memory for the floats
+            c.image = torch.as_tensor(seq["rgb"][k])
+            c.depth = torch.as_tensor(seq["depth"][k].view(np.int16))
             reader.addTrainCamera(c)
             # the pipeline's camera of this frame carries no float image: it is derived on the device from the frame the
             # engine uploads (3 of its 4 bytes per pixel) instead of a second, 12-byte-per-pixel upload
@@ -153,8 +165,9 @@ class Scene:
         if os.environ.get("GPS_BENCH_RIDING_ALONG"):  # A/B aid: poses of the LM loop's reject branch evaluated with every evaluation (0..2, default 1)
             self.engine.setPosesRidingAlong(int(os.environ["GPS_BENCH_RIDING_ALONG"]))
         self.model = H_.SLAMGaussianModel()
-        self.model.loadConfig(dict(capacity=1 << 19, isect_capacity=8 << 20))
-        self.model.getGaussianParms().add([t.clone() for t in seeds])
+        self.model.loadConfig(dict(capacity=capacity, isect_capacity=8 << 20))
+        if seeds is not None:
+            self.model.getGaussianParms().add([t.clone() for t in seeds])
         self.pipe = H_.SLAMPipeline(seed)
         self.pipe.setTsdfEngine(self.cli)
         self.pipe.setModel(self.model)
@@ -172,6 +185,8 @@ class Scene:
             self.pipe.frame_stream_kind, self.pipe.map_stream_kind, self.pipe.raycast_stream_kind = f_, m_, r_
         if os.environ.get("GPS_BENCH_MERGE"):  # A/B aid: window and keyframe views raycast as one batch (default 0)
             self.pipe.merge_keyframe_raycasts = os.environ["GPS_BENCH_MERGE"] != "0"
+        if os.environ.get("GPS_BENCH_PIPE_TIMES"):  # debug aid: processFrame calls longer than this many ms print where the host time went
+            self.pipe.frame_report_ms = float(os.environ["GPS_BENCH_PIPE_TIMES"])
         self.model.reserveWorkspace(W, H)
 
     def run(self, lo, hi):
@@ -284,6 +299,9 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     ap.add_argument("--no-oracle-psnr", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip config.other_configs (BASELINE configs[0], [1], [3] measured after the main windows at N = 1)")
+    ap.add_argument("--whole-run-frames", type=int, default=1000,
+                    help="frames of the whole-sequence run from frame 0 (the reference's own FPS definition; N = 1 only, after the "
+                         "headline windows; 0 = skip): config.whole_run_fps / whole_run_fps_sequential")
     ap.add_argument("--gt-pose", action="store_true",
                     help="use_gt_pose: true (what every shipped config sets: the tracker is off, poses are given).  Default: the "
                          "depth-only ExtendedTracker estimates the pose of every frame, as BASELINE configs[2] "
@@ -301,7 +319,9 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     seed = scene_seed(rank)
     seq = None
     if scene_factory is None:
-        seq = synthetic_sequence(W, H, n_frames, seed)
+        # (rendered on the device: the numpy ray-tracer of tests/synth.py needs 0.2-0.6 s per frame -- with N ranks on one host that
+        # was 30-60 s per rank before the first barrier; same formulas, float64)
+        seq = synthetic_sequence_device(W, H, n_frames, seed, device)
         seeds = seed_gaussians(seq, args.gaussians, seed, device)
         # One-off costs that are not part of any SLAM frame -- loading the code objects of every kernel, first-touch of the
         # allocator -- are paid here, before the warm-up frames.
@@ -371,17 +391,54 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                        "schedules": {k: {kk: vv for kk, vv in v.items() if kk != "seconds"} for k, v in results.items()},
                        "stats": results[main_sched]["stats"], "placement": placement},
         }
+        flat = {"keyframe_theta_deg": args.keyframe_theta, "keyframe_trans_m": args.keyframe_trans, "env_overrides": env_overrides()}
+        if "sequential" in results:
+            flat["sequential_fps"] = world * K / results["sequential"]["seconds"]
+        if "overlap" in results:
+            flat["overlap_fps"] = world * K / results["overlap"]["seconds"]
         if extras:
             out["config"].update(_describe_and_measure(args, scene, seq, results[main_sched], first, K, dt, marker))
             out["roofline"] = out["config"].pop("roofline")
-            if world == 1 and not args.no_other_configs:
+            flat["frame_frac"] = out["roofline"]["frame"]["frac"]
+            flat["iteration_frac"] = out["roofline"]["iteration"]["frac"]
+            flat["iteration_us"] = out["roofline"]["iteration"]["avg_us"]
+            if world == 1 and (not args.no_other_configs or args.whole_run_frames > 0):
                 scene.close()
                 scene = None
                 torch.cuda.empty_cache()
-                out["config"]["other_configs"] = other_configs(args, seq, seed, device, first)
+            if world == 1 and not args.no_other_configs:
+                oc = other_configs(args, seq, seed, device, first)
+                out["config"]["other_configs"] = oc
+                flat.update(cfg0_fps=oc["configs0_tsdf_only_gt_pose"]["frames_per_s"],
+                            cfg1_fps=oc["configs1_gt_pose_100k"]["frames_per_s"],
+                            cfg1_fps_sequential=oc["configs1_gt_pose_100k"]["schedules"]["sequential"]["frames_per_s"],
+                            cfg1_iters_per_s=oc["configs1_gt_pose_100k"]["iterations_per_s"],
+                            cfg3_fps=oc["configs3_720p_400k"]["frames_per_s"],
+                            cfg3_fps_sequential=oc["configs3_720p_400k"]["schedules"]["sequential"]["frames_per_s"],
+                            cfg3_gaussians=oc["configs3_720p_400k"]["schedules"]["overlap"]["gaussians"],
+                            cfgR_fps=oc["configsR_replica_1200x680_300k"]["frames_per_s"],
+                            cfgR_fps_sequential=oc["configsR_replica_1200x680_300k"]["schedules"]["sequential"]["frames_per_s"],
+                            cfgR_gaussians=oc["configsR_replica_1200x680_300k"]["schedules"]["overlap"]["gaussians"],
+                            other_configs_seconds=oc["seconds"])
+            if world == 1 and args.whole_run_frames > 0:
+                t_w = time.perf_counter()
+                wr = whole_run(args, seed, device, args.whole_run_frames)
+                wr["seconds_total"] = time.perf_counter() - t_w
+                out["config"]["whole_run"] = wr
+                flat.update(whole_run_fps=wr["overlap"]["fps"], whole_run_fps_sequential=wr["sequential"]["fps"],
+                            whole_run_frames=wr["frames"], whole_run_gaussians_end=wr["overlap"]["gaussians_end"],
+                            whole_run_fusion_fps=wr["overlap"]["fusion_fps"], whole_run_gaussian_fps=wr["overlap"]["gaussian_fps"],
+                            whole_run_fusion_fps_sequential=wr["sequential"]["fusion_fps"],
+                            whole_run_gaussian_fps_sequential=wr["sequential"]["gaussian_fps"],
+                            whole_run_slowest_frame_ms=wr["overlap"]["slowest_frame_ms_after_30"],
+                            whole_run_seconds_total=wr["seconds_total"])
             if not args.no_cpu_baseline and world == 1:
                 from bench_kernels import cpu_baseline
                 out["cpu_baseline"] = cpu_baseline(seq, W, H)
+        # flat scalars FIRST in `config`: the driver's record keeps scalar fields only -- every number that matters beside `value`
+        # (the reference's own whole-run FPS, the sequential schedule, the other single-GPU configurations, the keyframe
+        # thresholds, the frame / iteration HBM fractions, which A/B switches were set) is one of them
+        out["config"] = dict(flat, **out["config"])
         print(json.dumps(out), flush=True)
     # ranks != 0 wait here while rank 0 runs its post-window measurements and prints: no rank tears the process group down
     # (or exits, which torch.distributed.run treats as the job ending) under another rank's feet
@@ -414,6 +471,51 @@ def _time_scene(factory, first, K, NW):
             del scene
             torch.cuda.empty_cache()
     return out, last
+
+
+def whole_run(args, seed, device, n_frames):
+    """The metric as the reference defines it (slam/slam_pipeline.cpp:52-173 with LOG_PIPELINE_TIME): SLAMTrainCams over the WHOLE
+    sequence from frame 0 with an EMPTY model -- the first keyframe update (the whole first view sampled into Gaussians + its KNN),
+    the keyframe list filling up, the hash table filling up, the growth of N with every newly seen surface are all inside --
+    FPS = frames / wall (:162-167; here the clock stops after flush() and a device synchronise), and the Fusion / Gaussian split
+    run/read_results.py:38-39 derives from "per frame fusion time".  Both schedules on the same sequence (device-rendered, held
+    as uint8 / uint16 like the dataset's files); N = 1 only, after the headline windows."""
+    W, H = args.width, args.height
+    t0 = time.perf_counter()
+    seq = synthetic_sequence_device(W, H, n_frames, seed, device)
+    t_gen = time.perf_counter() - t0
+    res = {"frames": n_frames, "size": "%dx%d" % (W, H), "input_render_seconds": t_gen,
+           "what": "SLAMPipeline::SLAMTrainCams from frame 0, empty model, %s, keyframe thresholds %.3g deg / %.3g m; "
+                   "frames / wall with the clock stopped after flush() + device synchronise"
+                   % ("given poses" if args.gt_pose else "depth ICP tracking", args.keyframe_theta, args.keyframe_trans)}
+    for sched in ("sequential", "overlap"):
+        t0 = time.perf_counter()
+        sc = Scene(seq, None, seed, args.gt_pose, overlap=sched == "overlap", n_frames=n_frames,
+                   keyframe_theta=args.keyframe_theta, keyframe_trans=args.keyframe_trans)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        mallocs0 = _device_mallocs(True)
+        tm = sc.pipe.SLAMTrainCamsTimed(sc.model, sc.cams)
+        st = {k: int(v) for k, v in dict(sc.pipe.stats()).items()}
+        res[sched] = {"fps": tm.fps(), "seconds": tm.slam_total * 1e-3, "fusion_fps": tm.fusion_fps(), "gaussian_fps": tm.gaussian_fps(),
+                      "per_frame_fusion_ms": tm.per_frame / max(1, tm.frames), "keyframe_step_host_ms_per_frame": tm.keyframe_step / max(1, tm.frames),
+                      "stage_ms_per_frame": {k: getattr(tm, k) / max(1, tm.frames) for k in
+                                             ("localFrameRaycast", "keyFrameRaycast", "initNewGaussians", "localOptimize", "removeGaussian")},
+                      "slowest_frame_ms_after_30": tm.max_frame_after_30, "slowest_frame_id": tm.max_frame_id,
+                      "gaussians_end": int(sc.model.getGaussianNum()), "pipeline_stats": st, "device_mallocs": _device_mallocs(True) - mallocs0,
+                      "visible_blocks_end": int(sc.engine.counters().cpu()[2]), "allocated_blocks_end": int((1 << 18) - 1 - int(sc.engine.counters().cpu()[0])),
+                      "scene_build_seconds": t_build}
+        if not args.gt_pose:
+            fr, ev, rode, used = sc.engine.trackerTotals()
+            res[sched]["tracker_evaluations_per_frame"] = ev / max(1, fr)
+            # tracked against ground truth: the final estimated pose of the orbit (camera 0 is the world frame)
+            est = sc.engine.lastPose()[1].reshape(4, 4).T.numpy().astype(np.float64)   # invM, column-major -> c2w
+            gt = seq["c2w"][n_frames - 1].astype(np.float64)
+            res[sched]["final_pose_trans_err_mm"] = float(np.linalg.norm(est[:3, 3] - gt[:3, 3]) * 1e3)
+        sc.close()
+        del sc
+        torch.cuda.empty_cache()
+    return res
 
 
 def other_configs(args, seq, seed, device, first):
@@ -477,6 +579,24 @@ def other_configs(args, seq, seed, device, first):
                                  "what": "Azure-Kinect-like 720p intrinsics (fx = fy = 605), depth ICP tracking + TSDF fuse + ges splat optimise, "
                                          "~400 k Gaussians", "pipeline_stats": {k: int(v) for k, v in st.items()},
                                  "input_render_seconds": t_gen, "seconds": time.perf_counter() - t0}
+    # Replica-native geometry: every Replica config is 1200x680, f = 600, c = (599.5, 339.5) (configs/release/replica/office0.yaml:18-20):
+    # 75 x 43 tiles with a ragged last tile row (680 = 42 x 16 + 8), 13 sort bits
+    t0 = time.perf_counter()
+    WR, HR = 1200, 680
+    nR = first + NW * K
+    seqR = synthetic_sequence_device(WR, HR, nR, seed, device, intrinsics=(600.0, 600.0, 599.5, 339.5))
+    t_gen = time.perf_counter() - t0
+    seedsR = seed_gaussians(seqR, 300000, seed, device)
+    rR, sc = _time_scene(lambda ov: Scene(seqR, seedsR, seed, False, overlap=ov, n_frames=nR, **kf), first, K, NW)
+    st = dict(sc.pipe.stats())
+    roofR = config_units(sc, seqR, 1000.0 / rR["overlap"]["frames_per_s"], HBM_PEAK_GBS)
+    sc.close()
+    del sc
+    torch.cuda.empty_cache()
+    res["configsR_replica_1200x680_300k"] = {"roofline": roofR, "size": "%dx%d" % (WR, HR), "schedules": rR, "frames_per_s": rR["overlap"]["frames_per_s"],
+                                             "what": "Replica's camera (1200x680, fx = fy = 600, c = (599.5, 339.5)), depth ICP tracking + TSDF fuse + "
+                                                     "ges splat optimise, ~300 k Gaussians", "pipeline_stats": {k: int(v) for k, v in st.items()},
+                                             "input_render_seconds": t_gen, "seconds": time.perf_counter() - t0}
     res["seconds"] = time.perf_counter() - t_all
     return res
 

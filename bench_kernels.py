@@ -446,8 +446,8 @@ def fusion_split(seq, first, K, gt_pose, dt_total):
     for k in range(first + K):
         c = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k]))
         c.id = k
-        c.image = torch.as_tensor(seq["rgb"][k].astype(np.float32) / 255.0)
-        c.depth = torch.as_tensor(seq["depth"][k].astype(np.float32) / 1000.0)[..., None]
+        c.image = torch.as_tensor(seq["rgb"][k])                       # uint8 / uint16 millimetres, as bench.Scene hands them over
+        c.depth = torch.as_tensor(seq["depth"][k].view(np.int16))
         reader.addTrainCamera(c)
         pc = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k]))
         pc.id = k

@@ -276,6 +276,7 @@ class RawGaussianModel:
         key = (p.cap, W, H)
         d = self.device
         if self._step is None or self._step_key != key:
+            self._prefetched = None   # a forward run ahead lived in the buffers replaced below
             cap = p.cap
             tw, th = math.ceil(W / self.tile_size), math.ceil(H / self.tile_size)
             icap = int(self.isect_capacity or max(1 << 20, 16 * cap))
@@ -399,10 +400,13 @@ class RawGaussianModel:
         if next_cam is not None and (next_cam.width, next_cam.height) == (cam.width, cam.height) and lib.gps_splat_can_prefetch(C.byref(st)):
             n = next_cam.toGPU()
             st.next_viewmat, st.next_Kmat, st.next_cam_pos = n["viewmat"].data_ptr(), n["K"].data_ptr(), n["cam_pos"].data_ptr()
-            self._prefetched = (n["serial"], int(st.N), cam.width, cam.height, ver)
+            armed = (n["serial"], int(st.N), cam.width, cam.height, ver)
+        else:
+            armed = None
         o = self._opt
         o["step"] += 1
-        check(lib.gps_splat_train_step(C.byref(st), o["step"], self._stream()), "gps_splat_train_step")
+        check(lib.gps_splat_train_step(C.byref(st), o["step"], self._stream()), "gps_splat_train_step")  # raises on error: nothing armed
+        self._prefetched = armed
 
     def loss_sum(self):
         return self._B["loss"]

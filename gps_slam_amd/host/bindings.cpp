@@ -233,6 +233,22 @@ PYBIND11_MODULE(_host, m) {
           py::return_value_policy::reference);
 
     // ---- pipeline
+    py::class_<SLAMPipeline::PipelineTimes>(m, "PipelineTimes")
+        .def_readonly("frames", &SLAMPipeline::PipelineTimes::frames)
+        .def_readonly("slam_total", &SLAMPipeline::PipelineTimes::slam_total)
+        .def_readonly("per_frame", &SLAMPipeline::PipelineTimes::per_frame)
+        .def_readonly("keyframe_step", &SLAMPipeline::PipelineTimes::keyframe_step)
+        .def_readonly("localFrameRaycast", &SLAMPipeline::PipelineTimes::localFrameRaycast)
+        .def_readonly("keyFrameRaycast", &SLAMPipeline::PipelineTimes::keyFrameRaycast)
+        .def_readonly("initNewGaussians", &SLAMPipeline::PipelineTimes::initNewGaussians)
+        .def_readonly("localOptimize", &SLAMPipeline::PipelineTimes::localOptimize)
+        .def_readonly("removeGaussian", &SLAMPipeline::PipelineTimes::removeGaussian)
+        .def_readonly("checkError", &SLAMPipeline::PipelineTimes::checkError)
+        .def_readonly("max_frame_after_30", &SLAMPipeline::PipelineTimes::max_frame_after_30)
+        .def_readonly("max_frame_id", &SLAMPipeline::PipelineTimes::max_frame_id)
+        .def("fps", &SLAMPipeline::PipelineTimes::fps)
+        .def("fusion_fps", &SLAMPipeline::PipelineTimes::fusion_fps)
+        .def("gaussian_fps", &SLAMPipeline::PipelineTimes::gaussian_fps);
     py::class_<SLAMPipeline>(m, "SLAMPipeline")
         .def(py::init<TsdfEngine*, SLAMGaussianModel*, uint64_t, bool>(), py::arg("engine"), py::arg("model"),
              py::arg("seed") = 1234, py::arg("use_gt_pose") = true, py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
@@ -243,6 +259,16 @@ PYBIND11_MODULE(_host, m) {
             p.SLAMTrainCams(m, cams);
             return cams;  // with c2w_slam filled in
         }, py::call_guard<py::gil_scoped_release>())
+        // the reference's whole-run clock (LOG_PIPELINE_TIME): SLAMTrainCams over `cams` from frame 0, -> the [PIPELINE AVG TIME] numbers
+        .def("SLAMTrainCamsTimed", [](SLAMPipeline& p, SLAMGaussianModel& m, std::vector<Camera>& cams) {
+            { py::gil_scoped_release nogil; p.SLAMTrainCams(m, cams); }
+            return p.times;
+        })
+        .def_readonly("times", &SLAMPipeline::times)
+        .def_readwrite("log_pipeline_time", &SLAMPipeline::log_pipeline_time)
+        .def_readwrite("frame_report_ms", &SLAMPipeline::frame_report_ms)
+        .def_readwrite("keep_frame_ms", &SLAMPipeline::keep_frame_ms)
+        .def_readonly("frame_ms", &SLAMPipeline::frame_ms)
         .def("processFrameCLI", [](SLAMPipeline& p, int i, Camera& cam) { p.processFrame(i, cam); },
              py::call_guard<py::gil_scoped_release>())
         .def("loadConfig", [](SLAMPipeline& p, const py::dict& d) { p.loadConfig(config_from_dict(d)); })

@@ -133,22 +133,42 @@ CLIEngine* createTsdfEngine(const DatasetReader& data_reader, const Config& conf
     for (int i = 0; i < image_num; i++) {
         const Camera& cam = data_reader.train_vec[i];
         TORCH_CHECK(cam.image.defined() && cam.depth.defined(), "createTsdfEngine: camera ", i, " has no image / depth");
-        auto img = cam.image.detach().to(torch::kCPU, torch::kFloat32);
-        TORCH_CHECK(img.dim() == 3 && img.size(0) == dims.y && img.size(1) == dims.x && img.size(2) == 3,
-                    "Only images with 3 channels are supported");
-        auto u8img = (img * 255.0).toType(torch::kUInt8).contiguous();  // tensorToImage: truncation, not rounding
+        // The image as the reader holds it -- float [H,W,3] in [0,1] (the reference's DatasetReader) -- or as the dataset's FILES hold
+        // it, uint8 [H,W,3]: a thousand-frame sequence is 4.9 GB as floats and 1.5 GB as bytes.  The reference turns a file's
+        // byte k into the float k / 255 (imageToTensor, cv_utils.cpp:208-213) and back with (t * 255).toType(uint8) (truncation): the 256-entry
+        // table below is that round trip, so both inputs give the same uchar4 frame.
         rgb_images[i] = new ITMUChar4Image(dims, true, false);
         {
-            const uint8_t* src = u8img.data_ptr<uint8_t>();
-            Vector4u* dst = rgb_images[i]->GetData(MEMORYDEVICE_CPU);
-            for (int64_t k = 0; k < P; k++) dst[k] = Vector4u{src[3 * k], src[3 * k + 1], src[3 * k + 2], 255};
+            if (cam.image.scalar_type() == torch::kUInt8) {
+                static const torch::Tensor lut = ((torch::arange(256, torch::kFloat32) / 255.0) * 255.0).toType(torch::kUInt8);
+                auto raw = cam.image.detach().to(torch::kCPU).contiguous();
+                TORCH_CHECK(raw.dim() == 3 && raw.size(0) == dims.y && raw.size(1) == dims.x && raw.size(2) == 3,
+                            "Only images with 3 channels are supported");
+                const uint8_t* t = lut.data_ptr<uint8_t>();
+                const uint8_t* src = raw.data_ptr<uint8_t>();
+                Vector4u* dst = rgb_images[i]->GetData(MEMORYDEVICE_CPU);
+                for (int64_t k = 0; k < P; k++) dst[k] = Vector4u{t[src[3 * k]], t[src[3 * k + 1]], t[src[3 * k + 2]], 255};
+            } else {
+                auto img = cam.image.detach().to(torch::kCPU, torch::kFloat32);
+                TORCH_CHECK(img.dim() == 3 && img.size(0) == dims.y && img.size(1) == dims.x && img.size(2) == 3,
+                            "Only images with 3 channels are supported");
+                auto u8img = (img * 255.0).toType(torch::kUInt8).contiguous();  // tensorToImage: truncation, not rounding
+                const uint8_t* src = u8img.data_ptr<uint8_t>();
+                Vector4u* dst = rgb_images[i]->GetData(MEMORYDEVICE_CPU);
+                for (int64_t k = 0; k < P; k++) dst[k] = Vector4u{src[3 * k], src[3 * k + 1], src[3 * k + 2], 255};
+            }
         }
-        auto d = cam.depth.detach().to(torch::kCPU, torch::kFloat32);
-        TORCH_CHECK(d.numel() == P, "Only images with 1 channels are supported");
-        // cv::Mat::convertTo(CV_16UC1, 1000): saturate_cast<ushort>(cvRound(v * 1000)), round half to even
-        auto mm = torch::round(d * 1000.0f).clamp(0.0, 65535.0).to(torch::kInt32).contiguous();
+        TORCH_CHECK(cam.depth.numel() == P, "Only images with 1 channels are supported");
         depth_images[i] = new ITMShortImage(dims, true, false);
-        {
+        if (cam.depth.scalar_type() == torch::kInt16 || cam.depth.scalar_type() == torch::kUInt16) {
+            // millimetres as the depth PNG holds them: the reference's float metres (mm / 1000.f) come back as the same integer
+            // under convertTo(CV_16UC1, 1000) for every uint16 (|error| < 0.008 mm), so the shorts are copied as they are
+            auto raw = cam.depth.detach().to(torch::kCPU).contiguous();
+            std::memcpy(depth_images[i]->GetData(MEMORYDEVICE_CPU), raw.data_ptr(), (size_t)P * sizeof(short));
+        } else {
+            auto d = cam.depth.detach().to(torch::kCPU, torch::kFloat32);
+            // cv::Mat::convertTo(CV_16UC1, 1000): saturate_cast<ushort>(cvRound(v * 1000)), round half to even
+            auto mm = torch::round(d * 1000.0f).clamp(0.0, 65535.0).to(torch::kInt32).contiguous();
             const int32_t* src = mm.data_ptr<int32_t>();
             short* dst = depth_images[i]->GetData(MEMORYDEVICE_CPU);
             for (int64_t k = 0; k < P; k++) dst[k] = (short)(unsigned short)src[k];

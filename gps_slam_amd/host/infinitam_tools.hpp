@@ -118,7 +118,8 @@ private:
 }  // namespace InfiniTAM
 
 // include/dataset_reader.h:111-169, 171-230: what createTsdfEngine reads from the reader -- image size, pinhole intrinsics
-// and the training cameras (image float [H,W,3] in [0,1], depth float [H,W,1] metres, c2w [4,4]), on the host
+// and the training cameras (image float [H,W,3] in [0,1], depth float [H,W,1] metres, c2w [4,4]), on the host.  createTsdfEngine also
+// takes the image as uint8 [H,W,3] and the depth as (u)int16 millimetres -- what the dataset's files hold -- with the same bytes out
 struct DatasetReader {
     int width = 0, height = 0;
     float fx = 0.f, fy = 0.f, cx = 0.f, cy = 0.f;

@@ -88,6 +88,9 @@ gps_splat_step& RawGaussianModel::stepStruct(int W, int H) {
         }
         s.beta1 = 0.9; s.beta2 = 0.999; s.adam_eps = 1e-15;
         step_cap_ = cap; step_w_ = W; step_h_ = H;
+        // fresh intermediates: a forward the last trainStep() ran ahead lived in the buffers just replaced (checkBinningCapacity()
+        // growing the tables, a parameter-capacity change, another image size) -- the next step preprocesses itself
+        prefetched_ = PrefetchKey{};
     }
     gps_splat_step& s = step_;
     s.N = p.getGaussianNum(); s.K = p.shK(); s.sh_degree = degreesToUse; s.max_gs_radii = max_gs_radii;
@@ -439,12 +442,12 @@ void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_dep
     bindCamera(st, cam, clamped, base_color, cam.image, skip);   // (clears prefetched_)
     st.fuse_sh_rest_adam = fuse_sh_rest_adam ? 2 : 0;  // all six tensors stepped inside the backward kernel
     st.preprocessed = skip ? 1 : 0;
-    if (next_cam && next_cam->on_device() && next_cam->width == cam.width && next_cam->height == cam.height && gps_splat_can_prefetch(&st)) {
-        st.next_viewmat = next_cam->viewmat(); st.next_Kmat = next_cam->Kmat(); st.next_cam_pos = next_cam->cam_pos();
-        prefetched_ = PrefetchKey{next_cam->pack_serial(), (int64_t)st.N, cam.width, cam.height, opt_gs_params.version()};
-    }
+    const bool ahead = next_cam && next_cam->on_device() && next_cam->width == cam.width && next_cam->height == cam.height &&
+                       gps_splat_can_prefetch(&st);
+    if (ahead) { st.next_viewmat = next_cam->viewmat(); st.next_Kmat = next_cam->Kmat(); st.next_cam_pos = next_cam->cam_pos(); }
     adam_step_ += 1;
-    check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");
+    check(gps_splat_train_step(&st, adam_step_, current_stream()), "gps_splat_train_step");   // throws on error: nothing armed then
+    if (ahead) prefetched_ = PrefetchKey{next_cam->pack_serial(), (int64_t)st.N, cam.width, cam.height, opt_gs_params.version()};
     nextLaunchId();
 }
 

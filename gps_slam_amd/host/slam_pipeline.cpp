@@ -56,11 +56,33 @@ void SLAMPipeline::setTsdfEngine(InfiniTAM::Engine::CLIEngine* engine) {
     voxel_size = be->getVoxelSize();
 }
 
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// slam_pipeline.cpp:52-173 with its LOG_PIPELINE_TIME clock: `times` holds what the reference prints as "[PIPELINE AVG TIME]"
 void SLAMPipeline::SLAMTrainCams(SLAMGaussianModel& model_, std::vector<Camera>& cams) {
     model = &model_;
     device = model->device;
-    for (size_t i = 0; i < cams.size(); i++) processFrame((int)i, cams[i]);
+    times = PipelineTimes();
+    frame_ms.clear();
+    const double t0 = now_ms();
+    for (size_t i = 0; i < cams.size(); i++) {
+        const double tf = now_ms();
+        processFrame((int)i, cams[i]);
+        const double dt = now_ms() - tf;
+        if (keep_frame_ms) frame_ms.push_back((float)dt);
+        if (i >= 30 && dt > times.max_frame_after_30) { times.max_frame_after_30 = dt; times.max_frame_id = (int)i; }
+    }
     flush();
+    hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    times.slam_total = now_ms() - t0;
+    times.frames = (int)cams.size();
+    if (log_pipeline_time)
+        printf("[PIPELINE AVG TIME] GS num: %d, per frame fusion time: %f, localFrameRaycast time: %f, keyFrameRaycast time: %f, "
+               "initNewGaussians time: %f, localOptimize time: %f, FPS: %f\n", model->getGaussianNum(), times.per_frame / times.frames,
+               times.localFrameRaycast / times.frames, times.keyFrameRaycast / times.frames, times.initNewGaussians / times.frames,
+               times.localOptimize / times.frames, times.fps());
 }
 
 void SLAMPipeline::processFrame(int i, Camera& cam) {
@@ -518,14 +540,6 @@ std::vector<TensorDict> SLAMPipeline::renderEvalImgs(const std::vector<Camera>& 
 }
 
 // ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
-// debug aid (GPS_PIPE_TIMES=<ms>): a processFrame call that took longer than <ms> of host time prints where it went
-static double pipe_times_threshold_ms() {
-    static const double v = [] { const char* e = std::getenv("GPS_PIPE_TIMES"); return e ? std::atof(e) : -1.0; }();
-    return v;
-}
-static inline double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 static thread_local double g_gate_wait_ms = 0.0, g_handover_wait_ms = 0.0;
 static std::atomic<double> g_job_post_ms{0.0};  // (debug aid only: when the frame thread woke the mapping thread)
 
@@ -574,6 +588,8 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
     if (frame_rgba.defined()) tsdf_engine->markConsumed();  // the staging slot's last reader is the conversion toGPU just enqueued
     updateFrameList();
     stats.frames++;
+    const double tt_lists = now_ms();
+    times.per_frame += tt_lists - tt0;   // the reference's perFrame_start .. perFrame_end (slam_pipeline.cpp:73-96)
     if (work_mode == "recon") return;
     if (i % local_opt_interval == 0 && i > 0) {
         if (!views_reserved_) {  // every free-view render state an update can need, once, before the first update
@@ -583,8 +599,9 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
         if (overlap_mapping && mapping_thread) keyframeStepThreaded();
         else if (overlap_mapping) keyframeStepOverlapped();
         else keyframeStep();
+        times.keyframe_step += now_ms() - tt_lists;
     }
-    const double thr = pipe_times_threshold_ms(), tt3 = now_ms();
+    const double thr = frame_report_ms, tt3 = now_ms();
     if (thr >= 0.0 && tt3 - tt0 > thr)
         fprintf(stderr, "[pipe] frame %d: %.3f ms = engine %.3f (tracker %.3f, fusion enqueue %.3f, gate wait %.3f) + toGPU %.3f + lists / keyframe step %.3f (hand-over wait %.3f)\n",
                 i, tt3 - tt0, tt1 - tt0, main_engine->trackDiag(14), main_engine->trackDiag(15), g_gate_wait_ms, tt2 - tt1, tt3 - tt2, g_handover_wait_ms);
@@ -626,13 +643,21 @@ void SLAMPipeline::ensureStreams() {
 
 void SLAMPipeline::keyframeStep() {
     // two batches: initNewGaussians only needs the window's views and starts while the keyframes' views render
+    const double t0 = now_ms();
     localFrameRaycast();
+    const double t1 = now_ms();
     keyFrameRaycast();
+    const double t2 = now_ms();
     initNewGaussians(localframe_raycast_window.back());
+    const double t3 = now_ms();
     localOptimize();
+    const double t4 = now_ms();
     removeRedundantGs();
+    const double t5 = now_ms();
     if (sample_method == "ours") checkKeyFrameError();   // slam_pipeline.cpp:130-131
     waitAllRaycasts();  // the next frame's fusion modifies the volume (results no iteration drew would still be in flight)
+    times.localFrameRaycast += t1 - t0; times.keyFrameRaycast += t2 - t1; times.initNewGaussians += t3 - t2;
+    times.localOptimize += t4 - t3; times.removeGaussian += t5 - t4; times.checkError += now_ms() - t5;
 }
 
 void SLAMPipeline::keyframeStepOverlapped() {
@@ -736,7 +761,7 @@ void SLAMPipeline::mapWorker(int device_index) {
                                                                                          : ms.stream()), "hipEventRecord");
             { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
             cv_.notify_all();
-            if (pipe_times_threshold_ms() >= 0.0 && now_ms() - g_job_post_ms > 1.0)
+            if (frame_report_ms >= 0.0 && now_ms() - g_job_post_ms > 1.0)
                 fprintf(stderr, "[pipe] update %lld: raycasts enqueued %.3f ms after the hand-over (woke after %.3f)\n", (long long)seen,
                         now_ms() - g_job_post_ms, t_woke - g_job_post_ms);
             initNewGaussiansFor(localframe_raycast_window.back(), job_.curr_cam);

@@ -123,6 +123,30 @@ public:
     float scene_scale = 1.1f * 3.0f;
     float ssim_weight = 0.0f, depth_weight = 0.0f;  // both 0 in every shipped config -> the fused L1 trainStep
 
+    // LOG_PIPELINE_TIME of the reference (slam_pipeline.cpp:54-67, 73-96, 141-167): host wall-clock totals of one SLAMTrainCams run in
+    // milliseconds.  `per_frame` is the reference's "per frame fusion time" (ProcessFrame + pose + toGPU + updateFrameList); FPS =
+    // frames / (slam_total / 1000); run/read_results.py:38-39 derives Fusion-FPS = 1000 / per_frame and Gaussian-FPS =
+    // 1000 / (1000 / FPS - per_frame) from them.  The five per-stage totals are taken in the sequential keyframe step only (the
+    // overlapped schedules run the stages on another stream / thread; their host share of the frame thread is `keyframe_step`).
+    // slam_total here ends AFTER flush() and a device synchronise (the reference stops its clock with kernels still in flight).
+    struct PipelineTimes {
+        int frames = 0;
+        double slam_total = 0, per_frame = 0, keyframe_step = 0, localFrameRaycast = 0, keyFrameRaycast = 0, initNewGaussians = 0,
+               localOptimize = 0, removeGaussian = 0, checkError = 0;
+        double max_frame_after_30 = 0;   // slowest processFrame call (host wall) from frame 30 on
+        int max_frame_id = -1;
+        double fps() const { return slam_total > 0 ? frames / (slam_total / 1000.0) : 0.0; }
+        double fusion_fps() const { return per_frame > 0 ? 1000.0 / (per_frame / frames) : 0.0; }
+        double gaussian_fps() const {
+            const double rest = slam_total > 0 && frames > 0 ? (slam_total - per_frame) / frames : 0.0;
+            return rest > 0 ? 1000.0 / rest : 0.0;
+        }
+    } times;
+    bool log_pipeline_time = false;        // print the reference's "[PIPELINE AVG TIME]" line at the end of SLAMTrainCams
+    double frame_report_ms = -1.0;         // debug aid: a processFrame call that took longer than this many ms of host time prints where it went
+    std::vector<float> frame_ms;           // host wall of every processFrame call of the last SLAMTrainCams (filled when keep_frame_ms)
+    bool keep_frame_ms = false;
+
     // counters are bumped by the frame thread AND (mapping_thread) by the map worker: atomics
     struct Stats { std::atomic<int64_t> frames{0}, opt_iters{0}, raycasts{0}, added{0}, pruned{0}; } stats;
 

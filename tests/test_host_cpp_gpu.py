@@ -276,6 +276,24 @@ def test_cpp_train_step_run_ahead_equals_plain_steps_and_is_void_after_prune_or_
     b.trainStep(cams[0], ref, base)
     same()
     assert a.checkBinningCapacity() == b.checkBinningCapacity()
+    # the step buffers are re-created between the two steps (checkBinningCapacity() growing the intersection tables): the forward
+    # that was run ahead lived in the old buffers and must not be consumed
+    ni, ng = b.checkBinningCapacity()
+    tight = dict(capacity=1 << 16, isect_capacity=int(1.5 * max(ni, (ng + 1) // 2)))
+    a, b = h.SLAMGaussianModel(), h.SLAMGaussianModel()
+    for m in (a, b):
+        m.loadConfig(tight)
+        m.getGaussianParms().add([t.clone() for t in tensors])
+        m.initOptimizers(-1, 1.0)
+    a.trainStep(cams[0], ref, base, next_cam=cams[1])
+    b.trainStep(cams[0], ref, base)
+    assert a.checkBinningCapacity() == b.checkBinningCapacity()   # more than half in use: both grow, the next step re-creates B_
+    a.trainStep(cams[1], ref, base, next_cam=cams[0])
+    b.trainStep(cams[1], ref, base)
+    same()
+    a.trainStep(cams[0], ref, base)
+    b.trainStep(cams[0], ref, base)
+    same()
 
 
 def test_cpp_pipeline_runs_and_tsdf_state_equals_python_pipeline():

@@ -2,7 +2,7 @@
 # time is listed with its frame index, next to the windows' ms per step -- finds the rare frame that costs one window ~4.7 ms
 N=${1:-6}
 mkdir -p gpurun_out
-for i in $(seq 1 $N); do GPS_PIPE_TIMES=4 GPS_BENCH_FRAME_TIMES=1 python bench.py --steps 20 --warmup 5 --windows 5 --schedule overlap --no-cpu-baseline --no-oracle-psnr 2> gpurun_out/rep_err_$i.log | python -c "
+for i in $(seq 1 $N); do GPS_BENCH_PIPE_TIMES=4 GPS_BENCH_FRAME_TIMES=1 python bench.py --steps 20 --warmup 5 --windows 5 --schedule overlap --no-cpu-baseline --no-oracle-psnr 2> gpurun_out/rep_err_$i.log | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
