@@ -137,7 +137,7 @@ class Scene:
     """One scene on the C++ host layer, built the way slam_trainer.cpp builds it.  `seeds` = None: the model starts EMPTY, as the
     reference's does (the first keyframe update fills it from the whole first view)."""
 
-    def __init__(self, seq, seeds, seed, use_gt_pose, overlap, n_frames, keyframe_theta, keyframe_trans, capacity=1 << 19):
+    def __init__(self, seq, seeds, seed, use_gt_pose, overlap, n_frames, keyframe_theta, keyframe_trans, capacity=1 << 19, tsdf=None):
         import gps_slam_amd._host as H_
         self.H_ = H_
         W, H = seq["W"], seq["H"]
@@ -157,8 +157,8 @@ class Scene:
             pc = H_.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][k]))
             pc.id = k
             self.cams.append(pc)
-        self.cli = H_.createTsdfEngine(reader, dict(voxel_size=0.005, trunc_dist=0.02, viewFrustum_min=0.2, viewFrustum_max=10.0,
-                                                    use_gt_pose=1 if use_gt_pose else 0))
+        self.cli = H_.createTsdfEngine(reader, dict(dict(voxel_size=0.005, trunc_dist=0.02, viewFrustum_min=0.2, viewFrustum_max=10.0,
+                                                         use_gt_pose=1 if use_gt_pose else 0), **(tsdf or {})))
         self.engine = self.cli.getMainEngine()
         if os.environ.get("GPS_BENCH_PINNED_LINE"):  # A/B aid: the tracker's argument line in the pinned mailbox (relay path)
             self.engine.setBarArgLine(False)

@@ -128,6 +128,8 @@ PYBIND11_MODULE(_host, m) {
              py::arg("next_cam") = (const Camera*)nullptr)
         .def("reserveWorkspace", &SLAMGaussianModel::reserveWorkspace)
         .def("checkBinningCapacity", &SLAMGaussianModel::checkBinningCapacity)
+        .def_readonly("binning_overflows", &SLAMGaussianModel::binning_overflows)
+        .def("capacity", [](SLAMGaussianModel& s) { return s.getGaussianParms().capacity(); })
         .def("adamState", [](SLAMGaussianModel& s) { return s.adamState(); })
         .def("lossSum", &SLAMGaussianModel::lossSum)
         .def("initOptimizers", &SLAMGaussianModel::initOptimizers, py::arg("max_iterations") = -1,
@@ -269,6 +271,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("frame_report_ms", &SLAMPipeline::frame_report_ms)
         .def_readwrite("keep_frame_ms", &SLAMPipeline::keep_frame_ms)
         .def_readonly("frame_ms", &SLAMPipeline::frame_ms)
+        .def_readonly("frame_wait_ms", &SLAMPipeline::frame_wait_ms)
         .def("processFrameCLI", [](SLAMPipeline& p, int i, Camera& cam) { p.processFrame(i, cam); },
              py::call_guard<py::gil_scoped_release>())
         .def("loadConfig", [](SLAMPipeline& p, const py::dict& d) { p.loadConfig(config_from_dict(d)); })

@@ -181,6 +181,12 @@ CLIEngine* createTsdfEngine(const DatasetReader& data_reader, const Config& conf
     internalSettings->sceneParams.mu = (float)config.get("trunc_dist", 0.02);
     internalSettings->sceneParams.viewFrustum_min = (float)config.get("viewFrustum_min", 0.2);
     internalSettings->sceneParams.viewFrustum_max = (float)config.get("viewFrustum_max", 10.0);
+    // table sizes: compile-time constants of the reference (SDF_LOCAL_BLOCK_NUM 0x40000, SDF_BUCKET_NUM 0x100000, SDF_EXCESS_LIST_SIZE
+    // 0x20000, ITMLib/Objects/Scene/ITMVoxelBlockHash.h:15-22) and the defaults here; smaller tables are a test aid (the CPU oracle's
+    // per-frame cost is its sweeps over them)
+    internalSettings->noTotalEntries_blocks = (int)config.get("sdf_local_block_num", internalSettings->noTotalEntries_blocks);
+    internalSettings->noBuckets = (int)config.get("sdf_bucket_num", internalSettings->noBuckets);
+    internalSettings->excessListSize = (int)config.get("sdf_excess_list_size", internalSettings->excessListSize);
     ITMMainEngine* mainEngine =
         new ITMBasicEngine<ITMVoxel, ITMVoxelIndex>(internalSettings, rgbd_calib, rgb_images[0]->noDims, depth_images[0]->noDims);
     if (config.get("use_gt_pose", 1.0) != 0.0) {

@@ -59,19 +59,22 @@ void SLAMPipeline::setTsdfEngine(InfiniTAM::Engine::CLIEngine* engine) {
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// host time the frame thread spent WAITING for the map worker inside the last processFrame call: for the previous update to finish
+// (hand-over at a keyframe) and for this update's raycasts to be enqueued (gate of the next frame's fusion)
+static thread_local double g_gate_wait_ms = 0.0, g_handover_wait_ms = 0.0;
 
 // slam_pipeline.cpp:52-173 with its LOG_PIPELINE_TIME clock: `times` holds what the reference prints as "[PIPELINE AVG TIME]"
 void SLAMPipeline::SLAMTrainCams(SLAMGaussianModel& model_, std::vector<Camera>& cams) {
     model = &model_;
     device = model->device;
     times = PipelineTimes();
-    frame_ms.clear();
+    frame_ms.clear(); frame_wait_ms.clear();
     const double t0 = now_ms();
     for (size_t i = 0; i < cams.size(); i++) {
         const double tf = now_ms();
         processFrame((int)i, cams[i]);
         const double dt = now_ms() - tf;
-        if (keep_frame_ms) frame_ms.push_back((float)dt);
+        if (keep_frame_ms) { frame_ms.push_back((float)dt); frame_wait_ms.push_back((float)(g_gate_wait_ms + g_handover_wait_ms)); }
         if (i >= 30 && dt > times.max_frame_after_30) { times.max_frame_after_30 = dt; times.max_frame_id = (int)i; }
     }
     flush();
@@ -540,7 +543,6 @@ std::vector<TensorDict> SLAMPipeline::renderEvalImgs(const std::vector<Camera>& 
 }
 
 // ------------------------------------------------------------------ one SLAM frame (body of SLAMTrainCams :69-132)
-static thread_local double g_gate_wait_ms = 0.0, g_handover_wait_ms = 0.0;
 static std::atomic<double> g_job_post_ms{0.0};  // (debug aid only: when the frame thread woke the mapping thread)
 
 void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {

@@ -145,6 +145,7 @@ public:
     bool log_pipeline_time = false;        // print the reference's "[PIPELINE AVG TIME]" line at the end of SLAMTrainCams
     double frame_report_ms = -1.0;         // debug aid: a processFrame call that took longer than this many ms of host time prints where it went
     std::vector<float> frame_ms;           // host wall of every processFrame call of the last SLAMTrainCams (filled when keep_frame_ms)
+    std::vector<float> frame_wait_ms;      // ... of which: waiting for the map worker (previous update's completion / this update's raycasts)
     bool keep_frame_ms = false;
 
     // counters are bumped by the frame thread AND (mapping_thread) by the map worker: atomics

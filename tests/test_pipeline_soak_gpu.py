@@ -1,0 +1,114 @@
+"""Soak of what bench.py's whole-run leg exercises (SLAMPipeline::SLAMTrainCams from frame 0, slam/slam_pipeline.cpp:52-173):
+1,000 frames at 640x480, depth-ICP tracking on, the overlap schedule (frames on their own stream, every keyframe's map update on
+the worker thread), with a parameter capacity small enough that the model outgrows it TWICE while the worker is in flight
+(host/raw_gs_param.cpp: reserve() re-allocates all six parameter tensors; the step buffers and the Adam state follow).
+
+Checked: no sticky overflow word anywhere (tile-intersection tables, TSDF rendering blocks, block array), no stalled frame (host
+wall of every processFrame call after frame 30, the scheduled waits for the map worker taken out, < 5 ms but for the two
+re-allocations), the tracked
+trajectory stays on the ground-truth orbit (frames 100 / 500 / 999), the optimised model renders closer to the input than the
+TSDF colour it is composed over -- and, on a 160x120 twin of the same orbit run the same way, the engine's hash / block counters
+at every 100th frame and the final live raycast equal the CPU restatement's (oracle/tsdf_oracle.c, itself pinned bit for bit by
+the reference's ITMLib engine) fed the same frames and the poses the HIP tracker produced."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pose_err(est, gt):
+    cos = (np.trace(est[:3, :3].T @ gt[:3, :3]) - 1.0) / 2.0
+    return float(np.linalg.norm(est[:3, 3] - gt[:3, 3])), float(np.degrees(np.arccos(np.clip(cos, -1, 1))))
+
+
+def test_soak_1000_frames_overlap_schedule_capacity_growth_under_the_worker():
+    import bench
+    n, seed, W, H = 1000, 1234, 640, 480
+    seq = bench.synthetic_sequence_device(W, H, n, seed, DEV)
+    # ~150 k seeds + what the run adds itself (this orbit saturates near 400 k Gaussians at the configs' new_gs_sample_ratio of 0.25;
+    # 0.5 doubles every keyframe's new Gaussians): the capacity of 1 << 18 is crossed first (reserve -> the 1 << 19 floor,
+    # raw_gs_param.cpp appendInit), then 1 << 19 itself (-> 1 << 20), both inside addGaussians on the map worker's thread while the
+    # frame thread keeps tracking and fusing
+    seeds = bench.seed_gaussians(seq, 150000, seed, DEV)
+    bench.prime(DEV)
+    sc = bench.Scene(seq, seeds, seed, use_gt_pose=False, overlap=True, n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02,
+                     capacity=1 << 18)
+    sc.pipe.loadConfig(dict(new_gs_sample_ratio=0.5))
+    assert sc.model.capacity() == 1 << 18
+    sc.pipe.keep_frame_ms = True
+    torch.cuda.synchronize()
+    cams = sc.pipe.SLAMTrainCamsModel(sc.model, sc.cams)   # (returns the cameras with c2w_slam filled in)
+    tm = sc.pipe.times
+    st = dict(sc.pipe.stats())
+    N = sc.model.getGaussianNum()
+    print("soak: %.0f frames/s over %d frames, N = %d (capacity %d), stats %s" % (tm.fps(), tm.frames, N, sc.model.capacity(), st))
+    assert st["frames"] == n and st["opt_iters"] == 20 * 99, st
+    assert N > 1 << 19 and sc.model.capacity() == 1 << 20, (N, sc.model.capacity())   # both capacity steps were crossed
+    # no sticky overflow word
+    assert sc.model.binning_overflows == 0
+    c = sc.engine.counters().cpu().numpy()
+    assert int(c[5]) == 0, "MAX_RENDERING_BLOCKS exceeded"
+    assert int(c[0]) > 0 and int(c[1]) > 0, "block array / excess list exhausted: %s" % c[:2]
+    # no stalled frame: the only long calls are the scheduled waits for the map worker (at N > 330 k an update takes longer than
+    # the ten frames it runs beside: the keyframe's hand-over then waits for it, by design)
+    ms, wait = np.asarray(sc.pipe.frame_ms), np.asarray(sc.pipe.frame_wait_ms)
+    own = (ms - wait)[30:]
+    print("soak: slowest processFrame after frame 30: %.2f ms (frame %d), without the waits for the map worker %.2f ms (frame %d); "
+          "waits %.1f ms of %.1f ms" % (ms[30:].max(), 30 + int(ms[30:].argmax()), own.max(), 30 + int(own.argmax()), wait.sum(), ms.sum()))
+    # (the two capacity steps re-allocate ~1.5 GB on the worker's thread; hipMalloc / hipFree take the runtime's lock and the frame
+    # thread's launches queue behind it: at most those two calls may exceed the bound, and not by much)
+    slow = np.nonzero(own > 5.0)[0]
+    assert len(slow) <= 2 and own.max() < 12.0, [(30 + int(i), float(own[i])) for i in slow]
+    assert tm.fps() > 300.0
+    # trajectory against the ground-truth orbit (camera 0 is the world frame of both)
+    for i in (100, 500, 999):
+        dt, dr = _pose_err(cams[i].c2w_slam.cpu().numpy().astype(np.float64), seq["c2w"][i].astype(np.float64))
+        print("soak: frame %d pose error %.2f mm / %.3f deg" % (i, dt * 1e3, dr))
+        assert dt < 0.01 and dr < 0.3, (i, dt, dr)
+    # the optimised model against the TSDF colour it is composed over, on the last update's views
+    views = list(zip(sc.pipe.optCams(), sc.pipe.optRaycasts()))
+    assert len(views) >= 2
+    with torch.no_grad():
+        e_r = np.mean([(sc.model.forward(cam, rc["depth_map"], rc["color_map"])["rgb"].clamp(0, 1) - cam.image).pow(2).mean().item()
+                       for cam, rc in views])
+        e_t = np.mean([(rc["color_map"] - cam.image).pow(2).mean().item() for cam, rc in views])
+    psnr_r, psnr_t = -10 * np.log10(e_r), -10 * np.log10(e_t)
+    print("soak: render PSNR %.2f dB, TSDF colour %.2f dB on the last update's %d views" % (psnr_r, psnr_t, len(views)))
+    assert psnr_r >= psnr_t
+    sc.close()
+
+
+def test_soak_twin_160x120_counters_equal_the_oracle_every_100th_frame():
+    """The same 1,000-frame orbit, schedule and tracker at 160x120 with 2 cm voxels and small tables (the single-threaded CPU
+    restatement integrates every visible block and sweeps the whole hash table per frame: 0.3 s per frame at 5 mm / full tables)."""
+    import bench
+    from oracle import tsdf_ref as R
+    n, seed, W, H = 1000, 1234, 160, 120
+    voxel, mu, blocks, buckets, excess = 0.02, 0.08, 0x4000, 0x8000, 0x1000
+    seq = bench.synthetic_sequence_device(W, H, n, seed, DEV)
+    seeds = bench.seed_gaussians(seq, 20000, seed, DEV)
+    sc = bench.Scene(seq, seeds, seed, use_gt_pose=False, overlap=True, n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02,
+                     tsdf=dict(voxel_size=voxel, trunc_dist=mu, sdf_local_block_num=blocks, sdf_bucket_num=buckets, sdf_excess_list_size=excess))
+    sc.pipe.trace_frames = True
+    sc.run(0, n)
+    torch.cuda.synchronize()
+    live, counters, poses = sc.pipe.frameTrace()
+    assert len(live) == n
+    o = R.TsdfOracle(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel, mu, 0.2, 10.0, n_blocks=blocks, n_buckets=buckets, n_excess=excess)
+    lut = (np.arange(256, dtype=np.float32) / np.float32(255.0) * np.float32(255.0)).astype(np.uint8)   # createTsdfEngine's round trip
+    for i in range(n):
+        pose = poses[i].numpy()
+        o.process_frame(lut[seq["rgb"][i]], seq["depth"][i], pose[0].copy(), pose[1].copy())
+        if i % 100 == 0 or i == n - 1:
+            c = counters[i].cpu().numpy()
+            assert [int(c[2]), int(c[0]), int(c[1])] == [o.n_visible, o.last_free_block, o.last_free_excess], i
+    c = counters[n - 1].cpu().numpy()
+    print("twin: %d visible blocks, %d allocated, %d excess entries used at the end" % (int(c[2]), blocks - 1 - int(c[0]), excess - 1 - int(c[1])))
+    assert live[n - 1].cpu().numpy().reshape(H, W, 4).tobytes() == o.image("raycast").tobytes()
+    o.close()
+    dt, dr = _pose_err(sc.cams[n - 1].c2w_slam.cpu().numpy().astype(np.float64), seq["c2w"][n - 1].astype(np.float64))
+    print("twin: final pose error %.2f mm / %.3f deg" % (dt * 1e3, dr))
+    assert dt < 0.03 and dr < 1.0, (dt, dr)
+    sc.close()

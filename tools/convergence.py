@@ -41,7 +41,7 @@ def main():
                     "pipeline's own addGaussians, as in a run of the reference")
     ap.add_argument("--gt-pose", action="store_true")
     ap.add_argument("--oracle-every", type=int, default=5)
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_convergence"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_convergence"))
     args = ap.parse_args()
     dev = "cuda:0"
     torch.cuda.set_device(0)
@@ -62,21 +62,38 @@ def main():
         scene.pipe.flush()   # the update of keyframe i - 9 is complete
         held = [i - 7, i - 3]   # never optimise cameras (not multiples of 5)
         with torch.no_grad():
-            r_psnr, t_psnr, o_psnr = [], [], []
+            r_psnr, t_psnr, o_psnr, diag = [], [], [], []
             for j in held:
                 cam = scene.cams[j]
                 rc = scene.pipe.runRaycastByCam(cam, False)
                 img = gt(j)
                 cam.image = img
                 cam.toGPU()
-                rgb = scene.model.forward(cam, rc["depth_map"], rc["color_map"])["rgb"]
+                res = scene.model.forward(cam, rc["depth_map"], rc["color_map"])
+                rgb = res["rgb"]
                 r_psnr.append(psnr(rgb, img)); t_psnr.append(psnr(rc["color_map"], img))
+                # why the gain is what it is (diag): where can Gaussians improve on the TSDF colour at all?  Only pixels whose TSDF
+                # colour is off by more than color_error_thres ever receive Gaussians (initNewGaussians' mask), and a pixel's render
+                # moves away from the base colour in proportion to W / (W + 1)
+                err_t = (rc["color_map"] - img).abs().mean(-1)
+                err_r = (rgb.clamp(0, 1) - img).abs().mean(-1)
+                valid = rc["depth_map"][..., 0] > 0
+                masked = (err_t > 0.05) & valid
+                se_t, se_r = ((rc["color_map"] - img) ** 2).mean(-1), ((rgb.clamp(0, 1) - img) ** 2).mean(-1)
+                diag.append(dict(mask_frac=float(masked.float().mean()), mean_weight=float(res["alpha"].mean()),
+                                 mean_weight_masked=float(res["alpha"][..., 0][masked].mean()) if masked.any() else 0.0,
+                                 sq_err_share_masked_tsdf=float(se_t[masked].sum() / se_t.sum()),
+                                 mse_tsdf_masked=float(se_t[masked].mean()) if masked.any() else 0.0,
+                                 mse_render_masked=float(se_r[masked].mean()) if masked.any() else 0.0,
+                                 mse_tsdf_rest=float(se_t[~masked].mean()), mse_render_rest=float(se_r[~masked].mean()),
+                                 mean_depth=float(rc["depth_map"][..., 0][valid].mean()), err_render_mean=float(err_r.mean())))
             # the views the update optimised (train views) on the same state
             views = list(zip(scene.pipe.optCams(), scene.pipe.optRaycasts()))
             tr = [psnr(scene.model.forward(c, r["depth_map"], r["color_map"])["rgb"], c.image) for c, r in views[:2]]
             row = {"frame": i, "gaussians": int(scene.model.getGaussianNum()), "held_out_frames": held,
                    "render_psnr_held_out": float(np.mean(r_psnr)), "tsdf_colour_psnr_held_out": float(np.mean(t_psnr)),
-                   "render_psnr_train_views": float(np.mean(tr)) if tr else None, "opt_views": len(views)}
+                   "render_psnr_train_views": float(np.mean(tr)) if tr else None, "opt_views": len(views),
+                   "diag": {k: float(np.mean([d[k] for d in diag])) for k in diag[0]}}
             if args.oracle_every and (len(rows) % args.oracle_every) == args.oracle_every - 1:
                 from oracle import splat_ref as orc
                 cp = scene.model.getGaussianParms()
@@ -133,6 +150,15 @@ def main():
                 "%.2f" % x["render_psnr_train_views"] if x["render_psnr_train_views"] is not None else "-",
                 "%.2f (HIP %.2f)" % (x["oracle_render_psnr_last_held_out"], x["hip_render_psnr_last_held_out"])
                 if "oracle_render_psnr_last_held_out" in x else ""))
+        f.write("\nWhere the gain can come from (held-out views): `masked` = pixels whose TSDF colour is off by more than color_error_thres "
+                "(0.05) -- the only pixels initNewGaussians ever samples Gaussians on; W = the render's weight sum (the render moves "
+                "away from the TSDF colour by W / (W + 1)).\n\n| frame | masked px | share of the TSDF colour's squared error on masked px | mean W "
+                "(all / masked) | MSE masked px: tsdf -> render | MSE other px: tsdf -> render | mean depth m |\n|---|---|---|---|---|---|---|\n")
+        for x in rows:
+            d = x["diag"]
+            f.write("| %d | %.1f %% | %.1f %% | %.2f / %.2f | %.5f -> %.5f | %.5f -> %.5f | %.2f |\n" % (
+                x["frame"], 100 * d["mask_frac"], 100 * d["sq_err_share_masked_tsdf"], d["mean_weight"], d["mean_weight_masked"],
+                d["mse_tsdf_masked"], d["mse_render_masked"], d["mse_tsdf_rest"], d["mse_render_rest"], d["mean_depth"]))
         f.write("\nOne camera optimised alone from the final state (TSDF colour of that view: %.2f dB):\n\n| iteration | PSNR |\n|---|---|\n"
                 % out["tsdf_colour_psnr_of_that_camera"])
         for a in alone:
