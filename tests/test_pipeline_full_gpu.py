@@ -22,8 +22,11 @@ _STATS = {}
 
 
 @pytest.mark.parametrize("overlap", [False, True], ids=["sequential", "overlap"])
-@pytest.mark.parametrize("W,H,n_gauss,oracle_frames", [(1280, 720, 400000, 12), (640, 480, 200000, 31)], ids=["720p-400k", "480p-200k"])
-def test_full_pipeline_tracking_on_at_baseline_size(W, H, n_gauss, oracle_frames, overlap):
+@pytest.mark.parametrize("W,H,n_gauss,oracle_frames,intr", [(1280, 720, 400000, 12, None), (640, 480, 200000, 31, None),
+                                                            # Replica's own camera (configs/release/replica/office0.yaml:18-20)
+                                                            (1200, 680, 300000, 12, (600.0, 600.0, 599.5, 339.5))],
+                         ids=["720p-400k", "480p-200k", "replica-1200x680-300k"])
+def test_full_pipeline_tracking_on_at_baseline_size(W, H, n_gauss, oracle_frames, intr, overlap):
     """overlap = True is the schedule bench.py's `value` reports (bench.Scene sets overlap_mapping + mapping_thread): frames on
     a high-priority stream with pre-launched tracker evaluations, the keyframe's map update on a worker thread / second stream,
     batched free views racing the next frame's fusion.  Same assertions as the reference's sequential schedule."""
@@ -31,7 +34,7 @@ def test_full_pipeline_tracking_on_at_baseline_size(W, H, n_gauss, oracle_frames
     from bench_kernels import render_psnr_vs_oracle
     from oracle import tsdf_ref as R
     n, seed = 31, 1234
-    seq = bench.synthetic_sequence(W, H, n, seed)
+    seq = bench.synthetic_sequence(W, H, n, seed) if intr is None else bench.synthetic_sequence_device(W, H, n, seed, DEV, intrinsics=intr)
     seeds = bench.seed_gaussians(seq, n_gauss, seed, DEV)
     scene = bench.Scene(seq, seeds, seed, use_gt_pose=False, overlap=overlap, n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02)
     eng = scene.engine

@@ -119,8 +119,9 @@ def _bin_inputs(N, W, H, seed, rmax=40):
 
 # 96x64: 24 tiles; 640x480: 1,200; 1280x720: 3,600 (the one-pass counting sort on the whole tile id, <= 4,096 tiles);
 # 2048x1200: 9,600 tiles (two LSD passes + offsets pass)
+# 1200x680: Replica's image size (75 x 43 = 3,225 tiles, ragged last tile row)
 @pytest.mark.parametrize("N,W,H", [(0, 96, 64), (1, 96, 64), (3000, 96, 64), (100000, 640, 480), (60000, 1280, 720),
-                                   (777, 50, 37), (50000, 2048, 1200)])
+                                   (777, 50, 37), (50000, 2048, 1200), (80000, 1200, 680)])
 def test_binning_bit_exact(N, W, H):
     from gps_slam_amd import gsplat_ops as ops
     from oracle import splat_ref as orc

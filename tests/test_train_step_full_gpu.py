@@ -43,10 +43,12 @@ def N_(t):
     return t.detach().cpu().numpy()
 
 
-def _build(N, W, H, scale_range, seed, strips=True):
+def _build(N, W, H, scale_range, seed, strips=True, intr=None):
     from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
     g = scenes.random_gaussians(N, seed=seed, scale_range=scale_range)
     c2w, K = scenes.default_camera(W, H, seed=seed)
+    if intr is not None:   # (fx, fy, cx, cy) instead of the 90-degree pinhole
+        K = np.array([[intr[0], 0, intr[2]], [0, intr[1], intr[3]], [0, 0, 1]], np.float32)
     models = []
     for mode in (0, 2):
         m = SLAMGaussianModel(dict(capacity=1 << 19, fuse_sh_rest_adam=mode, strip_backward=strips), device=DEV)
@@ -114,15 +116,21 @@ def _rasterizer_grads(B, N, strips):
     return np.concatenate([N_(B["v_colors"][:N]), N_(B["v_conics"][:N]), N_(B["v_means2d"][:N]), N_(B["v_opacities"][:N])[:, None]], 1)
 
 
-@pytest.mark.parametrize("N,W,H,scale_range,strips", [(200000, 640, 480, (0.003, 0.02), True), (400000, 1280, 720, (0.002, 0.011), True),
-                                                      (200000, 640, 480, (0.003, 0.02), False)],
-                         ids=["640x480-200k", "1280x720-400k", "640x480-200k-group-kernel"])
-def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_range, strips):
+# Replica's camera (every configs/release/replica/*.yaml, e.g. office0.yaml:18-20): 1200 x 680, fx = fy = 600, c = (599.5, 339.5) --
+# 75 x 43 tiles with a ragged last tile row (680 = 42 x 16 + 8), 3,225 tiles (the superblock scatter's LDS grows with the tile count)
+REPLICA = (600.0, 600.0, 599.5, 339.5)
+
+
+@pytest.mark.parametrize("N,W,H,scale_range,strips,intr", [(200000, 640, 480, (0.003, 0.02), True, None), (400000, 1280, 720, (0.002, 0.011), True, None),
+                                                           (200000, 640, 480, (0.003, 0.02), False, None),
+                                                           (300000, 1200, 680, (0.002, 0.012), True, REPLICA)],
+                         ids=["640x480-200k", "1280x720-400k", "640x480-200k-group-kernel", "replica-1200x680-300k"])
+def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_range, strips, intr):
     """strips = True: what bench.py times -- superblock binning (histogram in the preprocessing kernel, scan, scatter + class
     lists) and the column-strip backward; False: the sorted-key binning + 32-pixel-group backward (the operator-level kernels,
     and the train step's path when a host does not provide the strip buffers)."""
     from oracle import splat_ref as orc
-    (mA, mB), cam, ref, base, gt, c2w, K = _build(N, W, H, scale_range, seed=N // 1000, strips=strips)
+    (mA, mB), cam, ref, base, gt, c2w, K = _build(N, W, H, scale_range, seed=N // 1000, strips=strips, intr=intr)
     TS, delta = 16, mA.delta_depth
     tw, th = math.ceil(W / TS), math.ceil(H / TS)
     vm = scenes.pose_inv(c2w)
