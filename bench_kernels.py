@@ -91,6 +91,10 @@ def _kernel_row(name, calls_per_frame, t, alg_bytes, hbm_peak_gbs, N, bound, not
         if rec.get("hbm_bytes_per_launch"):
             row["traffic"] = rec["hbm_bytes_per_launch"]
             row["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / max(1.0, alg_bytes)
+            # 2 x FETCH_SIZE + WRITE_SIZE.  The factor 2 is measured for streams AND for narrow gathers on this gfx950: every L2 miss
+            # -- a 4-byte gather of an otherwise untouched line included -- is ONE 128-byte memory-side request that FETCH_SIZE
+            # tallies as 64 bytes (tools/probe/fetch_calib.hip, profiles/r05_fetch_calibration.md: TCC_EA0_RDREQ_128B == lines touched)
+            row["traffic_calibrated"] = True
         v = (rec.get("sq") or {}).get("SQ_INSTS_VALU")
         if v:
             # counter collection serialises and slows the launches; the instruction COUNT carries over and is priced against
@@ -108,6 +112,18 @@ def fused_pbwd_bytes(N, Nv):
     Gaussian read and written (24 x 59 N), the radius of every Gaussian (4 N), the rasterizer's 10-float gradient row and the
     conic of every visible one (52 Nv).  The 59-float gradient itself lives in registers."""
     return 24.0 * 59 * N + 4.0 * N + 52.0 * Nv
+
+
+def _with_own_bytes(row, own_bytes, t, hbm_peak_gbs, note):
+    """the bytes THIS kernel has to move (its own inputs once + its own outputs), beside SURVEY 8(d)'s figure for the reference's
+    algorithm in `algorithmic_bytes` (the contract's yardstick): where the two differ the fraction of peak on the kernel's own
+    bytes is the one that says how well the kernel runs"""
+    row["own_bytes"] = own_bytes
+    row["own_frac"] = own_bytes / t / 1e9 / hbm_peak_gbs
+    row["own_bytes_note"] = note
+    if row.get("traffic"):
+        row["traffic_over_own"] = row["traffic"] / max(1.0, own_bytes)
+    return row
 
 
 def _with_survey_formula(row, survey_bytes, t, hbm_peak_gbs, note):
@@ -243,9 +259,16 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     s_bar = fus["s_bar"]
     b_fuse = fusion_bytes(P, V, S)
     b_fuse_rays = fusion_bytes(P, V, S, s_bar)
+    bwd_row = _kernel_row("raster_ges_bwd_strip_kernel" if strips else "raster_ges_bwd_gs_kernel", 2.0, t["bwd"], 92.0 * ng + 24.0 * P,
+                          hbm_peak_gbs, N, "latency (pixel gathers) / valu")
+    if strips:
+        bwd_row = _with_own_bytes(bwd_row, 104.0 * nvis + 24.0 * P, t["bwd"], hbm_peak_gbs,
+                                  "one task per visible Gaussian: class-list id 4 + radius 4 + 48-byte record in, ONE 48-byte gradient row out "
+                                  "(104 Nv); the gradient image and the {v_alpha, depth cut} pair image once (24 P); the box's pixel "
+                                  "gathers are cache-served re-reads.  algorithmic_bytes is SURVEY's 92 G + 24 P for the reference's "
+                                  "32-pixel groups, which this kernel does not have")
     rows = [
-        _kernel_row("raster_ges_bwd_strip_kernel" if strips else "raster_ges_bwd_gs_kernel", 2.0, t["bwd"], 92.0 * ng + 24.0 * P,
-                    hbm_peak_gbs, N, "latency (pixel gathers) / valu"),
+        bwd_row,
         _kernel_row("raster_ges_fwd_pk_kernel", 2.1, t["fwd"], 44.0 * ni + 28.0 * P, hbm_peak_gbs, N, "valu issue + per-tile tail"),
         _with_survey_formula(
             _kernel_row("preprocess_bwd_kernel", 2.0, t_pbwd, fused_pbwd_bytes(N, nvis), hbm_peak_gbs, N, "hbm",
@@ -256,9 +279,14 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
             "SURVEY 8(d)'s figure for the UNFUSED reference chain (SH bwd 408 Nv + projection bwd 116 Nv + 40 N + Adam 28 x 59 N: "
             "gradients written, zeroed and re-read); above 1 because those bytes do not exist in the fused kernel"),
         _kernel_row("preprocess_fwd_kernel", 2.1, t["pre"], 68.0 * N + 217.0 * nvis, hbm_peak_gbs, N, "hbm"),
-        _kernel_row("binning (sb_scan_kernel + sb_scatter_kernel)", 2.1, t_bin, 24.0 * N + 44.0 * ni + 8.0 * ng + 4.0 * T, hbm_peak_gbs,
-                    N, "launch latency", "derived: render - preprocess - forward rasterizer; bytes = SURVEY's figure for the reference's "
-                    "count + sort + offsets, this implementation writes no key / value arrays"),
+        _with_own_bytes(
+            _kernel_row("binning (sb_scan_kernel + sb_scatter_kernel)", 2.1, t_bin, 24.0 * N + 44.0 * ni + 8.0 * ng + 4.0 * T, hbm_peak_gbs,
+                        N, "launch latency", "derived: render - preprocess - forward rasterizer; bytes = SURVEY's figure for the reference's "
+                        "count + sort + offsets, this implementation writes no key / value arrays"),
+            16.0 * N + 4.0 * ni + 4.0 * nvis + 6152.0 * T, t_bin, hbm_peak_gbs,
+            "scan: a tile's row of the count table read, zeroed and its prefix written (3 x 512 x 4 B per tile) + tile totals; scatter: "
+            "tiles-per-Gaussian 4 + radius 4 + mean 8 per Gaussian (16 N), one id per intersection out (4 I), the backward's class "
+            "lists (4 Nv), tile offsets / order (8 T)"),
         dict(_kernel_row("raycast_kernel", 1.0, fus["raycast_s"], 24.0 * P * s_bar + 20.0 * P, hbm_peak_gbs, N,
                          "latency (dependent gathers along the ray)",
                          "algorithmic_bytes = P x S-bar x 24 (one hash entry + one voxel per castRay step, an upper bound: neighbouring "
@@ -299,6 +327,10 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
             "measured_copy_GBs": copy_gbs,
             "measured_copy_note": "device-to-device copy of 1 GiB on this box, read + write bytes / best of 10 (SURVEY 8(d)); fractions use the nominal peak",
             "frac": top["frac"], "traffic": top.get("traffic"), "avg_launch_us": top["avg_us"],
+            "traffic_source": "profiles/pmc_*.json: separate rocprofv3 --pmc passes over this program's micro-loops on a scene of the same "
+                              "size (N within 2 %), committed -- not measured in this run; 2 x FETCH_SIZE + WRITE_SIZE, factor calibrated "
+                              "for streams and gathers (profiles/r05_fetch_calibration.md)",
+            "traffic_calibrated": bool(top.get("traffic_calibrated", False)),
             "algorithmic_bytes": top["algorithmic_bytes"],
             "dominant_by": "calls per frame x live average launch time (kernels[] is sorted by it)",
             "kernels": rows,
@@ -491,13 +523,17 @@ def cpu_baseline(seq, W, H, max_seconds=15.0):
         per = 1.0 / max(1e-3, sweep[best])
         n = int(max(6, min(seq["rgb"].shape[0], 1 + max_seconds / per)))
         res = R.time_reference(seq, n, 0.005, 0.02, 0.2, 10.0, threads=best)
-        return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": best, "kind": "reference",
+        # the same loop with the reference's depth tracker estimating every pose (what the headline's frames do): a shorter sample
+        nt = int(max(6, min(n, 1 + 0.4 * max_seconds / per)))
+        trk = R.time_reference(seq, nt, 0.005, 0.02, 0.2, 10.0, threads=best, track=True)
+        return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": cores, "threads": best, "kind": "reference",
+                "tracked_value": trk["frames"] / trk["seconds"] if trk else None, "tracked_sample_frames": trk["frames"] if trk else 0,
                 "thread_sweep_frames_per_s": {str(t): round(v, 3) for t, v in sweep.items()},
                 "sample": "%d ProcessFrame calls (TSDF fuse + live raycast + ICP maps, tracking off, no Gaussians) of the same "
                           "%dx%d synthetic sequence by the reference's ITMLib CPU engine (oracle/_ref/itm_ref_omp: g++ -O3 "
-                          "-fopenmp as upstream), OMP_NUM_THREADS=%d = the fastest of a sweep over %s threads (6 frames each; %d "
-                          "physical cores), first frame excluded; host CPU: %s"
-                          % (res["frames"], W, H, best, "/".join(str(t) for t in sweep), cores, _cpu_name())}
+                          "-fopenmp as upstream), OMP_NUM_THREADS=%d = the fastest of a sweep over %s threads (6 frames each) on %d "
+                          "physical cores, first frame excluded; tracked_value = the same loop with the engine's depth tracker on; "
+                          "host CPU: %s" % (res["frames"], W, H, best, "/".join(str(t) for t in sweep), cores, _cpu_name())}
     return cpu_baseline_port(seq, W, H, max_seconds)
 
 
@@ -538,7 +574,7 @@ def cpu_baseline_port(seq, W, H, max_seconds=20.0):
         n += 1
     o.close()
     timed = max(1, n - 1)
-    return {"value": timed / t_used if t_used > 0 else 0.0, "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": timed / t_used if t_used > 0 else 0.0, "unit": "frames/s", "cores": 1, "threads": 1, "kind": "port",
             "sample": "%d ProcessFrame calls (TSDF fuse + live raycast + ICP maps, no Gaussians) of the same %dx%d "
                       "synthetic sequence, first frame excluded; host CPU: %s" % (timed, W, H, _cpu_name())}
 

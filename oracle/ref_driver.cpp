@@ -11,6 +11,7 @@
 // usage: itm_ref <input.bin> <output.bin>          dump mode (parity fixtures)
 //        itm_ref <input.bin> <output.bin> track    same dump with the default tracker ON (poses estimated, not given)
 //        itm_ref <input.bin> - time              timing mode: ProcessFrame loop only, prints one JSON line
+//        itm_ref <input.bin> - timetrack         timing mode with the default tracker ON
 //                                                (frames after the first; the CPU baseline of bench.py)
 //        itm_ref <input.bin> <output.bin> mesh   dump + the CPU meshing engine's triangles of the final scene ("mesh"
 //                                                chunk: 9 floats per triangle) and, if GPS_REF_SAVE_DIR is set, the
@@ -219,7 +220,8 @@ int main(int argc, char **argv) {
     Engine *eng = new Engine(settings, calib, dims, dims);
     // "track" mode keeps the default tracker of ITMLibSettings (depth-only extended tracker) active; otherwise poses come
     // from gtC2wPoses exactly as slam/InfiniTAM_tools.cpp:59-62 sets the engine up for use_gt_pose: true
-    const bool track_mode = argc >= 4 && std::string(argv[3]) == "track";
+    const std::string mode = argc >= 4 ? std::string(argv[3]) : std::string();
+    const bool track_mode = mode == "track" || mode == "timetrack";
     if (!track_mode) eng->turnOffTracking();
 
     std::vector<ITMUChar4Image *> rgbs(h.nframes);
@@ -247,7 +249,7 @@ int main(int argc, char **argv) {
     fclose(in);
     eng->gtC2wPoses = poses;
 
-    if (argc >= 4 && std::string(argv[3]) == "time") {
+    if (mode == "time" || mode == "timetrack") {   // timetrack: the same loop with the depth tracker estimating every pose
         // CLIEngine::ProcessFrame loop of the TSDF-only `recon` mode (slam/TsdfFusion/CLIEngine.cpp:34-58); the first
         // frame (bulk allocation) is excluded, as BASELINE.md prescribes
         struct timespec t0, t1;
@@ -260,7 +262,7 @@ int main(int argc, char **argv) {
 #ifdef _OPENMP
         threads = omp_get_max_threads();
 #endif
-        printf("{\"frames\": %d, \"seconds\": %.6f, \"threads\": %d}\n", h.nframes - 1, sec, threads);
+        printf("{\"frames\": %d, \"seconds\": %.6f, \"threads\": %d, \"tracking\": %d}\n", h.nframes - 1, sec, threads, track_mode ? 1 : 0);
         return 0;
     }
 

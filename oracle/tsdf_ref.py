@@ -33,7 +33,7 @@ def _write_input(f, seq, n, voxel, mu, vfmin, vfmax, free_views=(), dump_vba_eve
         f.write(np.ascontiguousarray(c2w, dtype=np.float32).tobytes())
 
 
-def time_reference(seq, n_frames, voxel, mu, vfmin, vfmax, threads=None, openmp=True):
+def time_reference(seq, n_frames, voxel, mu, vfmin, vfmax, threads=None, openmp=True, track=False):
     """Time the reference's own ProcessFrame loop (TSDF-only `recon` mode) on the first n_frames of seq with the timing
     mode of ref_driver.  openmp=True uses itm_ref_omp (built like upstream: -O3 + OpenMP) with `threads` OpenMP threads.
     -> dict(frames, seconds, threads) or None if the binary is not there."""
@@ -48,7 +48,7 @@ def time_reference(seq, n_frames, voxel, mu, vfmin, vfmax, threads=None, openmp=
         fin = os.path.join(td, "in.bin")
         with open(fin, "wb") as f:
             _write_input(f, seq, n_frames, voxel, mu, vfmin, vfmax)
-        out = subprocess.check_output([binary, fin, "-", "time"], env=env, timeout=600).decode()
+        out = subprocess.check_output([binary, fin, "-", "timetrack" if track else "time"], env=env, timeout=600).decode()
     return json.loads(out.strip().splitlines()[-1])
 
 
