@@ -123,7 +123,7 @@ def seed_gaussians(seq, n_gauss, seed, device):
     return [new[k].contiguous() for k in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities")]
 
 
-ENV_SWITCHES = ("GPS_BENCH_PINNED_LINE", "GPS_BENCH_RIDING_ALONG", "GPS_BENCH_OPT_ITERS", "GPS_BENCH_PREFETCH", "GPS_BENCH_ASYNC_RAYCASTS",
+ENV_SWITCHES = ("GPS_BENCH_PINNED_LINE", "GPS_BENCH_RIDING_ALONG", "GPS_BENCH_DEVICE_SUMMER", "GPS_BENCH_OPT_ITERS", "GPS_BENCH_PREFETCH", "GPS_BENCH_ASYNC_RAYCASTS",
                 "GPS_BENCH_STREAMS", "GPS_BENCH_MERGE", "GPS_BENCH_FRAME_TIMES", "GPS_BENCH_PIPE_TIMES", "GPS_BENCH_SHARE_GPU")
 
 
@@ -162,6 +162,8 @@ class Scene:
         self.engine = self.cli.getMainEngine()
         if os.environ.get("GPS_BENCH_PINNED_LINE"):  # A/B aid: the tracker's argument line in the pinned mailbox (relay path)
             self.engine.setBarArgLine(False)
+        if os.environ.get("GPS_BENCH_DEVICE_SUMMER"):  # A/B aid: the evaluation's rows added by a workgroup on the device (round 4) instead of by the tracking thread
+            self.engine.setHostSummedRows(False)
         if os.environ.get("GPS_BENCH_RIDING_ALONG"):  # A/B aid: poses of the LM loop's reject branch evaluated with every evaluation (0..2, default 1)
             self.engine.setPosesRidingAlong(int(os.environ["GPS_BENCH_RIDING_ALONG"]))
         self.model = H_.SLAMGaussianModel()

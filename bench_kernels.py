@@ -303,7 +303,7 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
                                      "evaluating; bytes assume the evaluations spread evenly over the 4 pyramid levels and count ONE evaluation per "
                                      "launch (the pose that rides along, config.tracker, reads as much again when it runs: not counted, the "
                                      "counters see it)"),
-                         spin_us=fus["poll_spin_s"] * 1e6, eval_us=fus["poll_eval_s"] * 1e6,
+                         spin_us=fus["poll_spin_s"] * 1e6, eval_us=fus["poll_eval_s"] * 1e6, phases=fus.get("poll_phases"),
                          gpu_held_idle_us_per_frame=ev * fus["poll_spin_s"] * 1e6,
                          tracking_ms_per_frame=fus["tracking_ms_per_frame"]))
     if fus.get("freeview"):
@@ -315,9 +315,9 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
         rows.append(_kernel_row("colour_kernel", 0.9, fv["colour_s"], 56.0 * P, hbm_peak_gbs, N, "latency (corner gathers)",
                                 "16 P of rays in, 4 P of colour + 36 P of view maps out (the batched launch writes the maps; timed "
                                 "here without them); the eight corner voxels are cache-served gathers, not counted"))
-        rows.append(_kernel_row("expected_depths_partial_kernel", 1.9, fv["ed_s"], 16.0 * fv["visible_blocks"] + 64.0 * fv["cells"] * 8,
+        rows.append(_kernel_row("expected_depths_partial_kernel", 1.9, fv["ed_s"], 16.0 * fv["visible_blocks"] + 128.0 * fv["cells"] * 8,
                                 hbm_peak_gbs, N, "latency (one entry per thread, LDS atomics)",
-                                "16 B per visible entry in, 64 partial min/max images out; timed with its reduce pass (two launches)"))
+                                "16 B per visible entry in, 128 partial min/max images out (one visible block per thread); timed with its reduce pass (two launches)"))
     rows.sort(key=lambda x: -x["us_per_frame"])
     top = rows[0]
     t_frame = result["ms_per_step"] * 1e-3
@@ -426,11 +426,13 @@ def _fusion_timings(seq, gt_pose, device, n_sub=12):
                        "s_bar": fs1["steps"] / max(1, fs1["rays"])}
     if not gt_pose:
         trk = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], 0.005, 0.02, 0.2, 10.0, device=device)
-        trk.turnOnTracking()
+        trk.turnOnTracking(host_summed_rows=not os.environ.get("GPS_BENCH_DEVICE_SUMMER"),
+                           poses_riding_along=int(os.environ.get("GPS_BENCH_RIDING_ALONG", 1)))
         trk.ProcessFrameTracked(rgba[0], dmm[0])
         trk.ProcessFrameTracked(rgba[1], dmm[1])
         torch.cuda.synchronize()
         prof0 = trk.track_poll_profile()
+        ph0 = trk.track_poll_phases()
         torch.cuda._sleep(1)   # marker: "tracked"
         t0 = time.perf_counter()
         for k in range(2, len(c2w)):
@@ -439,6 +441,14 @@ def _fusion_timings(seq, gt_pose, device, n_sub=12):
         dt = (time.perf_counter() - t0) / max(1, len(c2w) - 2)
         prof1 = trk.track_poll_profile()
         d = [(b - a) & 0xFFFFFFFF for a, b in zip(prof0, prof1)]
+        ph1 = trk.track_poll_phases()
+        phases = {}
+        for key in ("level0", "coarse"):   # per evaluation, microseconds (100 MHz ticks)
+            dd = [(b - a) & 0xFFFFFFFF for a, b in zip(ph0[key], ph1[key])]
+            cnt = max(1, dd[0])
+            phases[key] = {"evaluations_per_frame": dd[0] / max(1, len(c2w) - 2), "own_pixel_loop_us": dd[1] * 0.01 / cnt,
+                           "until_all_rows_us": dd[2] * 0.01 / cnt, "sum_and_mailbox_us": dd[3] * 0.01 / cnt}
+        out["poll_phases"] = phases
         evals = max(1, d[2])
         out.update(tracked_ms_per_frame=dt * 1e3, tracking_ms_per_frame=max(0.0, dt - t_frame) * 1e3,
                    evals_per_frame=d[2] / max(1, len(c2w) - 2), poll_spin_s=d[0] * 1e-8 / (evals + d[3]),

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "gps_track_arg_line_free": (i32, [vp]),
     "gps_track_scratch_bytes": (i64, [i32, i32]),
     "gps_track_poll_profile": (i32, [vp, i32, i32, vp, vp]),
+    "gps_track_poll_phases": (i32, [vp, i32, i32, vp, vp]),
     "gps_tsdf_track_camera": (i32, [C.POINTER(TsdfState), C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64, vp]),
     "gps_tsdf_process_frame_tracked": (i32, [C.POINTER(TsdfState), vp, C.POINTER(TrackConfig), C.POINTER(TrackState), vp, i64,
                                              vp]),

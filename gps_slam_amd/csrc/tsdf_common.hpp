@@ -26,7 +26,7 @@ constexpr float FAR_AWAY = 999999.9f;
 constexpr float VERY_CLOSE = 0.05f;
 constexpr int MINMAX_SUB = 8;
 constexpr int MAX_RENDERING_BLOCKS = 65536 * 4;
-constexpr int ED_GROUPS = 64;  // per-workgroup partial min/max images of CreateExpectedDepths
+constexpr int ED_GROUPS = 128;  // per-workgroup partial min/max images of CreateExpectedDepths (x 512 threads: one visible block per thread up to 65,536)
 
 // Layout of gps_tsdf_state.scan_scratch (int32 words; sized by gps_tsdf_scratch_bytes):
 //   [3 * nblk + 16]             per-1024-slot counts of the ordered sweeps + totals
@@ -56,7 +56,7 @@ __host__ __device__ inline int64_t ray_stats_offset_words(const gps_tsdf_state& 
     const int64_t n_total = (int64_t)s.n_buckets + s.n_excess;
     const int64_t nblk = (n_total + 1023) / 1024;
     const int64_t sw = s.width / 8 + 2, sh = s.height / 8 + 2;
-    return 3 * nblk + 16 + (n_total + 3) / 4 + 2 + (int64_t)64 * sw * sh * 2 + 16 + ((int64_t)s.n_buckets + 31) / 32 + 16;
+    return 3 * nblk + 16 + (n_total + 3) / 4 + 2 + (int64_t)ED_GROUPS * sw * sh * 2 + 16 + ((int64_t)s.n_buckets + 31) / 32 + 16;
 }
 __host__ __device__ inline float4* ray_stats_rows(const gps_tsdf_state& s) {
     return reinterpret_cast<float4*>(s.scan_scratch + ((ray_stats_offset_words(s) + 3) & ~(int64_t)3));   // (16-byte aligned rows)

@@ -23,10 +23,10 @@ using namespace gpst;
 namespace {
 
 // CreateExpectedDepths in two passes without global atomics:
-//  A) each workgroup keeps a private copy of the 1/8-resolution min/max image in LDS (<= 160 KB: 640x480 -> 81x61x8 B
-//     = 39 KB), strides over the visible list, projects the 8 block corners (ProjectSingleBlock, Shared.h:36-91) and
-//     min/max-es the bounding box with LDS integer atomics (positive floats order like their bit patterns), then
-//     writes its image to a partial buffer with plain coalesced stores;
+//  A) each workgroup keeps a private copy of the 1/8-resolution min/max image in LDS (<= 160 KB: 640x480 -> 82x62x8 B
+//     = 40 KB, a plane of mins and a plane of maxes), takes its share of the visible list, projects the 8 block corners
+//     (ProjectSingleBlock, Shared.h:36-91) and min/max-es the bounding box with LDS integer atomics (positive floats order like
+//     their bit patterns), then writes its image to a partial buffer with plain coalesced stores;
 //  B) one thread per cell of that window reduces the partials into the full-resolution-stride image the raycaster indexes
 //     (x/8 + (y/8)*W).  Every other pixel of that image holds (FAR_AWAY, VERY_CLOSE) -- the reference's memset kernel
 //     rewrites them every call; here gps_tsdf_reset writes them once and nothing ever touches them again.
@@ -36,62 +36,87 @@ namespace {
 #define GPS_ED_THREADS 512
 #endif
 GPS_TUNABLE_REPORT(GPS_ED_THREADS, 512);
-constexpr int ED_THREADS = GPS_ED_THREADS;  // ~45k visible blocks over 64 x 1024 threads: one block per thread, no dependent second trip
+constexpr int ED_THREADS = GPS_ED_THREADS;
 
+// One visible block: ProjectSingleBlock (Shared.h:36-91) + the min / max of its bounding box into the workgroup's LDS image
+// (two planes -- every bank serves the mins and every bank serves the maxes; interleaved, each plane sat on half the banks).
+// -> rendering blocks the reference would have created for it (CreateRenderingBlocks counts 16 x 16 pixel pieces)
+__device__ __forceinline__ int ed_one_block(const TsdfState& s, const Mat4& M, const HashEntry& he, int sw, int sh,
+                                            uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
+    const int W = s.width, H = s.height;
+    if (he.ptr < 0) return 0;
+    int ulx = W / MINMAX_SUB, uly = H / MINMAX_SUB, lrx = -1, lry = -1;
+    float zmin = FAR_AWAY, zmax = VERY_CLOSE;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        short tx = (short)he.x, ty = (short)he.y, tz = (short)he.z;
+        tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
+        float px, py, pz;
+        mul_point(M, (float)tx * (float)BLK * s.voxel_size, (float)ty * (float)BLK * s.voxel_size,
+                  (float)tz * (float)BLK * s.voxel_size, 1.0f, px, py, pz);
+        if (pz < 1e-6) continue;
+        const float u = (s.fx * px / pz + s.cx) / MINMAX_SUB;
+        const float v = (s.fy * py / pz + s.cy) / MINMAX_SUB;
+        if (ulx > floorf(u)) ulx = (int)floorf(u);
+        if (lrx < ceilf(u)) lrx = (int)ceilf(u);
+        if (uly > floorf(v)) uly = (int)floorf(v);
+        if (lry < ceilf(v)) lry = (int)ceilf(v);
+        if (zmin > pz) zmin = pz;
+        if (zmax < pz) zmax = pz;
+    }
+    if (ulx < 0) ulx = 0;
+    if (uly < 0) uly = 0;
+    if (lrx >= W) lrx = W - 1;
+    if (lry >= H) lry = H - 1;
+    if (ulx > lrx) return 0;
+    if (uly > lry) return 0;
+    if (zmin < VERY_CLOSE) zmin = VERY_CLOSE;
+    if (zmax < VERY_CLOSE) return 0;
+    const int blocks = (int)ceilf((float)(lrx - ulx + 1) / 16.0f) * (int)ceilf((float)(lry - uly + 1) / 16.0f);
+    // the bounding box can only leave the sw x sh window in degenerate projections (the reference clamps to the
+    // FULL image size, Shared.h:77-80); those pixels are never read by the raycaster -> clip to the window
+    lrx = min(lrx, sw - 1); lry = min(lry, sh - 1);
+    for (int y = uly; y <= lry; ++y)
+        for (int x = ulx; x <= lrx; ++x) {
+            atomicMin(&lo[x + y * sw], __float_as_uint(zmin));
+            atomicMax(&hi[x + y * sw], __float_as_uint(zmax));
+        }
+    return blocks;
+}
+
+// ED_GROUPS x ED_THREADS threads = one visible block per thread up to 65,536 blocks (a 640x480 frame of 5 mm voxels sees 40-60 k):
+// ONE dependent chain per thread -- list entry, hash entry, 8 projections, a handful of LDS atomics -- instead of two back to
+// back (round 4: 64 x 512 threads, two trips; 19 us).  The chain's head does not wait for the list LENGTH either: the first
+// trip's list entry and hash entry are requested before the counter has arrived (the list buffer is n_blocks long and holds
+// slot numbers of earlier frames behind its end: the speculative reads stay inside the table, their result is dropped).
 __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(TsdfState s, Mat4 M,
                                                                      const int32_t* __restrict__ vis_ids, int count_slot,
                                                                      int sw, int sh, uint2* __restrict__ partial,
                                                                      const ViewRec* __restrict__ views) {
     GPS_FRAME_PRIO();
-    extern __shared__ uint2 img[];  // [sw*sh] {min bits, max bits}
+    extern __shared__ uint32_t ed_img[];  // [sw*sh] min bits | [sw*sh] max bits
     int32_t* const overflow_word = s.counters + GPS_TSDF_OVERFLOW;  // (of the scene, also for a view of a batch)
     if (views) { apply_view(s, views[blockIdx.z]); M = views[blockIdx.z].M; vis_ids = s.fv_visible_ids; partial = minmax_partials(s); }
+    const int cells = sw * sh;
+    uint32_t* const lo = ed_img;
+    uint32_t* const hi = ed_img + cells;
+    const int stride = gridDim.x * blockDim.x, k0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_total = s.n_buckets + s.n_excess;
+    // first trip, speculatively (k0 < n_blocks: the grid is smaller than the list buffer)
+    const bool spec = k0 < s.n_blocks;
+    const int id0 = spec ? vis_ids[k0] : -1;
+    const bool id_ok = id0 >= 0 && id0 < n_total;
+    uint4 raw0 = make_uint4(0, 0, 0, 0);
+    if (id_ok) raw0 = load_raw(s.hash, id0);
     const int n = s.counters[count_slot];
-    const int W = s.width, H = s.height;
-    const uint2 init = make_uint2(__float_as_uint(FAR_AWAY), __float_as_uint(VERY_CLOSE));
-    for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) img[i] = init;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) { lo[i] = __float_as_uint(FAR_AWAY); hi[i] = __float_as_uint(VERY_CLOSE); }
     __syncthreads();
     int my_blocks = 0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const HashEntry he = load_entry(s.hash, vis_ids[k]);
-        if (he.ptr < 0) continue;
-        int ulx = W / MINMAX_SUB, uly = H / MINMAX_SUB, lrx = -1, lry = -1;
-        float zmin = FAR_AWAY, zmax = VERY_CLOSE;
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            short tx = (short)he.x, ty = (short)he.y, tz = (short)he.z;
-            tx += (corner & 1) ? 1 : 0; ty += (corner & 2) ? 1 : 0; tz += (corner & 4) ? 1 : 0;
-            float px, py, pz;
-            mul_point(M, (float)tx * (float)BLK * s.voxel_size, (float)ty * (float)BLK * s.voxel_size,
-                      (float)tz * (float)BLK * s.voxel_size, 1.0f, px, py, pz);
-            if (pz < 1e-6) continue;
-            const float u = (s.fx * px / pz + s.cx) / MINMAX_SUB;
-            const float v = (s.fy * py / pz + s.cy) / MINMAX_SUB;
-            if (ulx > floorf(u)) ulx = (int)floorf(u);
-            if (lrx < ceilf(u)) lrx = (int)ceilf(u);
-            if (uly > floorf(v)) uly = (int)floorf(v);
-            if (lry < ceilf(v)) lry = (int)ceilf(v);
-            if (zmin > pz) zmin = pz;
-            if (zmax < pz) zmax = pz;
-        }
-        if (ulx < 0) ulx = 0;
-        if (uly < 0) uly = 0;
-        if (lrx >= W) lrx = W - 1;
-        if (lry >= H) lry = H - 1;
-        if (ulx > lrx) continue;
-        if (uly > lry) continue;
-        if (zmin < VERY_CLOSE) zmin = VERY_CLOSE;
-        if (zmax < VERY_CLOSE) continue;
-        my_blocks += (int)ceilf((float)(lrx - ulx + 1) / 16.0f) * (int)ceilf((float)(lry - uly + 1) / 16.0f);
-        // the bounding box can only leave the sw x sh window in degenerate projections (the reference clamps to the
-        // FULL image size, Shared.h:77-80); those pixels are never read by the raycaster -> clip to the window
-        lrx = min(lrx, sw - 1); lry = min(lry, sh - 1);
-        for (int y = uly; y <= lry; ++y)
-            for (int x = ulx; x <= lrx; ++x) {
-                atomicMin(&img[x + y * sw].x, __float_as_uint(zmin));
-                atomicMax(&img[x + y * sw].y, __float_as_uint(zmax));
-            }
+    if (k0 < n && id_ok) {
+        pin(raw0);
+        my_blocks += ed_one_block(s, M, decode_entry(raw0), sw, sh, lo, hi);
     }
+    for (int k = k0 + stride; k < n; k += stride) my_blocks += ed_one_block(s, M, load_entry(s.hash, vis_ids[k]), sw, sh, lo, hi);
     // one atomic per WORKGROUP on the rendering-block counter (same-address atomics serialise at the memory side: the tracker's
     // prepare kernel spent 10 of its 16 us on 1,200 of them)
     __shared__ int wave_tot[ED_THREADS / 64];
@@ -107,8 +132,8 @@ __global__ __launch_bounds__(ED_THREADS) void expected_depths_partial_kernel(Tsd
             if (before + tot >= MAX_RENDERING_BLOCKS) *overflow_word = 1;
         }
     }
-    uint2* out = partial + (size_t)blockIdx.x * sw * sh;
-    for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) out[i] = img[i];
+    uint2* out = partial + (size_t)blockIdx.x * cells;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) out[i] = make_uint2(lo[i], hi[i]);
 }
 
 __global__ __launch_bounds__(256) void expected_depths_reduce_kernel(TsdfState s, int sw, int sh, int groups,

@@ -94,18 +94,6 @@ __device__ __forceinline__ float4 bilerp4(const float4 a, const float4 b, const 
     return r;
 }
 
-// interpolateBilinear_withHoles (Utils/ITMPixelUtils.h:78-106) of the point map and of the normal map at the same position
-// (each with its own hole rule)
-__device__ __forceinline__ void bilinear_pair_with_holes(const float4* __restrict__ pn, float px, float py, int W, float4& cp, float4& n) {
-    const short ix = (short)floorf(px), iy = (short)floorf(py);
-    const float dx = px - (float)ix, dy = py - (float)iy;
-    const float4* r0 = pn + 2 * (ix + iy * W);
-    const float4* r1 = pn + 2 * (ix + (iy + 1) * W);
-    const float4 pa = r0[0], na = r0[1], pb = r0[2], nb = r0[3], pc = r1[0], nc = r1[1], pd = r1[2], nd = r1[3];
-    cp = bilerp4(pa, pb, pc, pd, dx, dy);
-    n = bilerp4(na, nb, nc, nd, dx, dy);
-}
-
 struct GhArgs {
     const float* depth;
     int vw, vh;
@@ -119,23 +107,51 @@ struct GhArgs {
 };
 
 // computePerPointGH_exDepth for one pixel, accumulated into the caller's registers.  ITER: 0 rotation, 1 translation, 2 both.
-template <int ITER>
-__device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float depth, float& cnt, float& f, float* nabla, float* hess) {
-    constexpr int NP = ITER == TRK_BOTH ? 6 : 3;
-    if (depth <= 1e-8f) return;
-    float px = depth * (((float)x - a.view_intr.z) / a.view_intr.x);
-    float py = depth * (((float)y - a.view_intr.w) / a.view_intr.y);
-    float tx, ty, tz;
-    mul_point(a.approxInvPose, px, py, depth, 1.0f, tx, ty, tz);
+// Split in two around the bilinear footprint's eight 16-byte loads so that a thread can have the footprints of ALL its pixels (and of
+// all the poses of a fused evaluation) in flight at once: gh_project decides where the footprint lies (no memory access, no
+// branch), the caller issues the loads, gh_accumulate does everything behind them.  The arithmetic and its order per pixel and
+// pose are those of the one-piece version (-ffp-contract=off: no re-association across the split).
+struct GhProj {
+    float tx, ty, tz;   // the view point in the scene's frame of the last raycast
+    float dx, dy;       // bilinear weights
+    int idx;            // pixel index of the footprint's upper-left corner in the scene maps (0 when !ok)
+    bool ok;            // the point projects inside the scene image
+};
+
+__device__ __forceinline__ GhProj gh_project(const GhArgs& a, const Mat4& approxInvPose, float px, float py, float depth, bool live) {
+    GhProj r;
+    mul_point(approxInvPose, px, py, depth, 1.0f, r.tx, r.ty, r.tz);
     float qx, qy, qz;
-    mul_point(a.scenePose, tx, ty, tz, 1.0f, qx, qy, qz);
-    if (qz <= 0.0f) return;
+    mul_point(a.scenePose, r.tx, r.ty, r.tz, 1.0f, qx, qy, qz);
     const float u = a.scene_intr.x * qx / qz + a.scene_intr.z;
     const float v = a.scene_intr.y * qy / qz + a.scene_intr.w;
-    if (!((u >= 0.0f) && (u <= a.sw - 2) && (v >= 0.0f) && (v <= a.sh - 2))) return;
-    float4 cp, n;
-    bilinear_pair_with_holes(a.pn, u, v, a.sw, cp, n);
+    r.ok = live && !(qz <= 0.0f) && ((u >= 0.0f) && (u <= a.sw - 2) && (v >= 0.0f) && (v <= a.sh - 2));
+    // interpolateBilinear_withHoles (Utils/ITMPixelUtils.h:78-106): corner and weights
+    const short ix = (short)floorf(r.ok ? u : 0.0f), iy = (short)floorf(r.ok ? v : 0.0f);
+    r.dx = u - (float)ix; r.dy = v - (float)iy;
+    r.idx = r.ok ? ix + iy * a.sw : 0;
+    return r;
+}
+
+// the footprint: point | normal records of the four corners (pn[2i], pn[2i+1]), two rows of 64 contiguous bytes
+struct GhFoot { float4 pa, na, pb, nb, pc, nc, pd, nd; };
+__device__ __forceinline__ GhFoot gh_fetch(const GhArgs& a, const GhProj& r) {
+    const float4* r0 = a.pn + 2 * r.idx;
+    const float4* r1 = a.pn + 2 * (r.idx + a.sw);
+    GhFoot f;
+    f.pa = r0[0]; f.na = r0[1]; f.pb = r0[2]; f.nb = r0[3]; f.pc = r1[0]; f.nc = r1[1]; f.pd = r1[2]; f.nd = r1[3];
+    return f;
+}
+
+template <int ITER>
+__device__ __forceinline__ void gh_accumulate(const GhArgs& a, const GhProj& r, const GhFoot& ft, float depth, float& cnt, float& f,
+                                              float* nabla, float* hess) {
+    constexpr int NP = ITER == TRK_BOTH ? 6 : 3;
+    if (!r.ok) return;
+    const float4 cp = bilerp4(ft.pa, ft.pb, ft.pc, ft.pd, r.dx, r.dy);
+    const float4 n = bilerp4(ft.na, ft.nb, ft.nc, ft.nd, r.dx, r.dy);
     if (cp.w < 0.0f) return;
+    const float tx = r.tx, ty = r.ty, tz = r.tz;
     const float dx = cp.x - tx, dy = cp.y - ty, dz = cp.z - tz;
     const float dist = dx * dx + dy * dy + dz * dz;
     if (dist > a.tukey_cutoff * a.space_thresh) return;
@@ -164,10 +180,10 @@ __device__ __forceinline__ void gh_point(const GhArgs& a, int x, int y, float de
     cnt += 1.0f;
     f += rho * w;
 #pragma unroll
-    for (int r = 0, counter = 0; r < NP; r++) {
-        nabla[r] += rho1 * w * A[r];
+    for (int rr = 0, counter = 0; rr < NP; rr++) {
+        nabla[rr] += rho1 * w * A[rr];
 #pragma unroll
-        for (int c = 0; c <= r; c++, counter++) hess[counter] += rho2 * w * A[r] * A[c];
+        for (int c = 0; c <= rr; c++, counter++) hess[counter] += rho2 * w * A[rr] * A[c];
     }
 }
 
@@ -191,9 +207,9 @@ constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 // track_camera_impl).  Each pose is evaluated by its own group of EV_MAX_WGS workgroups with its own argument line, row table
 // and result block.
 #ifndef GPS_TRACK_EV_GROUPS
-#define GPS_TRACK_EV_GROUPS 3
+#define GPS_TRACK_EV_GROUPS 4
 #endif
-GPS_TUNABLE_REPORT(GPS_TRACK_EV_GROUPS, 3);
+GPS_TUNABLE_REPORT(GPS_TRACK_EV_GROUPS, 4);
 constexpr int EV_GROUPS = GPS_TRACK_EV_GROUPS;
 constexpr int MAILBOX_GROUP_WORDS = 64;   // a group's block of the host mailbox (words 0..31: its result row)
 
@@ -345,53 +361,28 @@ __global__ __launch_bounds__(256) void track_prepare_tile_kernel(PrepArgs a) {
 __device__ __forceinline__ int chunk_word(int d) { return d + d / 15; }
 // words of the 16-word `sync` block besides [0] ticket ([1], [2]: unused since the valid-pixel counts moved behind the block): the pre-launched evaluation's profile
 constexpr int SYNC_SPIN_TICKS = 8, SYNC_EVAL_TICKS = 9, SYNC_EVALS = 10, SYNC_SKIPPED = 11;
+// where an evaluation's time goes, as workgroup 0 (the summer) sees it, for the finest level and for the coarser ones: number of
+// evaluations, ticks from the argument line's arrival to the end of its own pixel loop, from there until every row of the table
+// carries this launch's tag (the slowest workgroup + the hand-over through memory), from there to the mailbox store
+constexpr int SYNC_PHASE_L0 = 1, SYNC_PHASE_COARSE = 5;   // words [1..4] and [5..7] + [12]
+__host__ __device__ __forceinline__ int phase_word(int base, int k) { return base == SYNC_PHASE_COARSE && k == 3 ? 12 : base + k; }
 constexpr long long ROW_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
 
-template <int ITER>
-__device__ __forceinline__ void eval_body(const GhArgs& a, int bid /* workgroup of this evaluation */, int n_rows,
-                                          uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
-                                          float* __restrict__ result, volatile float* mailbox, int seq, int parity,
-                                          long long t_arrived = -1) {
-    constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ, NQ = (NV + 3) / 4;
-    static_assert(NV <= 29, "29 sums + the valid-pixel count fill the two 15-word chunks");
-    __shared__ float red[EV_THREADS / 64][GH_SLOTS];
-    __shared__ float group[EV_ROW_GROUPS][GH_SLOTS];
-    __shared__ int all_ok;
-    float acc[4 * NQ];
-#pragma unroll
-    for (int k = 0; k < 4 * NQ; k++) acc[k] = 0.0f;
-    const int n = a.vw * a.vh;
-    // (prefetching the next pixel's depth ahead of this pixel's bilinear gather -- one dependent round trip per trip instead of
-    // two -- and two pixels in flight were both measured: no change; launch-to-launch overhead and the hand-over chain set
-    // an iteration's length, not this loop)
-    for (int i = bid * blockDim.x + threadIdx.x; i < n; i += n_rows * blockDim.x) {
-        const int y = i / a.vw, x = i - y * a.vw;
-        gh_point<ITER>(a, x, y, a.depth[i], acc[0], acc[1], acc + 2, acc + 2 + NP);
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // wave totals, four values per register (wave_reduce.hpp): 10 VALU ops per quad instead of 24 ds_bpermute round trips
-    const int row_slot = ((lane >> 4) & 1) * 2 + (lane >> 5);  // reduce4 leaves (a, c, b, d) in rows 0..3
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const float z = gps::reduce4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        if ((lane & 15) == 15) red[wave][4 * q + row_slot] = z;
-    }
-    __syncthreads();
-    if (tid < GH_SLOTS) {  // word tid of this workgroup's row: sums in words d + d / 15, the sequence number in words 15 and 31
-        const int d = tid - (tid >> 4);  // inverse of chunk_word for non-tag words
-        uint32_t wv = (uint32_t)seq;
-        if ((tid & 15) != 15) {
-            float t = 0.0f;
-            if (d < NV) {
-#pragma unroll
-                for (int w2 = 0; w2 < EV_THREADS / 64; w2 += 2) t += red[w2][d] + red[w2 + 1][d];  // fixed order
-            }
-            wv = __float_as_uint(t);
-        }
-        __hip_atomic_store(partial + (size_t)bid * GH_SLOTS + tid, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (bid != 0) return;
-    // ---- workgroup 0, the summer: word k of rows r, r + 8, ... by thread (r, k); a round is ONE batch of loads
+// LDS of an evaluation workgroup (declared once per kernel: the fused body below is instantiated per kind and pose count)
+struct EvLds {
+    float red[EV_GROUPS][EV_THREADS / 64][GH_SLOTS];   // per pose: the waves' totals
+    float group[EV_ROW_GROUPS][GH_SLOTS];              // the summer's row groups
+    int all_ok;
+};
+
+// The summer of ONE pose's row table (every thread of its workgroup): re-reads the rows until all n_rows carry this launch's tag,
+// adds them in fixed order, writes the totals + the frame's valid-pixel count to `result` and the host mailbox block `mailbox`.
+// -> wall-clock stamp of "all rows seen" (0 when it gave up)
+__device__ __forceinline__ long long sum_rows_and_answer(EvLds& lds, int n_rows, const uint32_t* __restrict__ partial,
+                                                         uint32_t* __restrict__ sync, float* __restrict__ result,
+                                                         volatile float* mailbox, int seq, int parity) {
+    const int tid = threadIdx.x;
+    // word k of rows r, r + 8, ... by thread (r, k); a round is ONE batch of loads
     const int k = tid & (GH_SLOTS - 1), r = tid >> 5;
     const int rows = n_rows;
     float s = 0.0f;
@@ -414,17 +405,18 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int bid /* workgroup 
                 else s += __uint_as_float(v[u]);                       // rows added in row order
             }
         }
-        if (tid == 0) all_ok = 1;
+        if (tid == 0) lds.all_ok = 1;
         __syncthreads();
-        if (!ok) all_ok = 0;
+        if (!ok) lds.all_ok = 0;
         __syncthreads();
-        const int done = all_ok;
+        const int done = lds.all_ok;
         __syncthreads();
         if (done) break;
-        if (wall_clock64() - t0 > ROW_TIMEOUT) return;  // a row never arrived: no result (the host's bounded wait reports it)
+        if (wall_clock64() - t0 > ROW_TIMEOUT) return 0;  // a row never arrived: no result (the host's bounded wait reports it)
         __builtin_amdgcn_s_sleep(1);
     }
-    group[r][k] = s;
+    const long long t_rows = wall_clock64();
+    lds.group[r][k] = s;
     __syncthreads();
     if (tid < GH_SLOTS) {  // word tid of the result, chunked like a row: sums, then the valid-pixel count as payload 29
         const int d = tid - (tid >> 4);
@@ -438,7 +430,7 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int bid /* workgroup 
         if ((tid & 15) != 15) {
             if (d < 29) {
 #pragma unroll
-                for (int g2 = 0; g2 < EV_ROW_GROUPS; g2++) t += group[g2][tid];
+                for (int g2 = 0; g2 < EV_ROW_GROUPS; g2++) t += lds.group[g2][tid];
                 wv = __float_as_uint(t);
             } else {  // d == 29: the frame's valid-pixel count
                 wv = vc;
@@ -446,9 +438,132 @@ __device__ __forceinline__ void eval_body(const GhArgs& a, int bid /* workgroup 
         }
         result[tid] = __uint_as_float(wv);  // (device copy, same layout: the host_mailbox == NULL path reads it back)
         if (mailbox) reinterpret_cast<volatile uint32_t*>(mailbox)[tid] = wv;  // one store instruction: two 64-byte chunks
-        // profile words (gps_track_poll_profile): wall-clock ticks between the arrival of this launch's argument line and its
-        // result leaving, and the number of evaluations.  Launches of a stream run one after the other: plain read-modify-write
-        if (tid == 0 && t_arrived >= 0) { sync[SYNC_EVAL_TICKS] += (uint32_t)(wall_clock64() - t_arrived); sync[SYNC_EVALS] += 1u; }
+    }
+    __syncthreads();   // (lds.group is reused by a later pass of the same workgroup)
+    return t_rows;
+}
+
+// K poses of ONE level and kind evaluated by the workgroups [0, n_rows) of a launch: a pixel's depth and back-projection are shared,
+// every pose keeps its own sums (accumulated in the order a single-pose evaluation accumulates them: bit-equal), its own row
+// table (`partial` + k tables), result block and mailbox block; pose k's table is summed by workgroup k.
+template <int ITER, int K>
+__device__ __forceinline__ void eval_fused(EvLds& lds, const GhArgs& a, const Mat4* poses, int bid, int n_rows,
+                                           uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
+                                           float* __restrict__ result, volatile float* mailbox, int seq, int parity,
+                                           long long t_arrived = -1, int phase_base = 0, volatile uint32_t* host_rows = nullptr) {
+    constexpr int NP = ITER == TRK_BOTH ? 6 : 3, NSQ = ITER == TRK_BOTH ? 21 : 6, NV = 2 + NP + NSQ, NQ = (NV + 3) / 4;
+    // HOST-SUMMED ROWS (host_rows != NULL, round 5): every workgroup stores its row straight into the pinned host table and is done
+    // -- no summer, no second hop through the memory-side coherence point; the host, which spins for the answer anyway, adds the
+    // rows in the summer's order.  Workgroup 0's row carries the frame's valid-pixel count (payload 29): requested HERE, before
+    // the pixel loop, so that its round trip is not in front of the row store.
+    uint32_t vc = 0;
+    if (host_rows && bid == 0 && threadIdx.x < GH_SLOTS) {
+        vc = __hip_atomic_load(&sync[VC_BASE + parity * VC_SLOTS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[VC_BASE + (1 - parity) * VC_SLOTS + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static_assert(NV <= 29, "29 sums + the valid-pixel count fill the two 15-word chunks");
+    static_assert(K >= 1 && K <= EV_GROUPS && K * GH_SLOTS <= EV_THREADS, "one thread per row word of every pose");
+    float acc[K][4 * NQ];
+#pragma unroll
+    for (int p = 0; p < K; p++)
+#pragma unroll
+        for (int k = 0; k < 4 * NQ; k++) acc[p][k] = 0.0f;
+    const int n = a.vw * a.vh;
+    // A thread's pixels in batches of B with every memory round trip of a batch taken ONCE: B depth loads, then the B x K bilinear
+    // footprints (8 loads of 16 bytes each; a footprint that does not exist reads pixel 0 and is dropped), then the sums in pixel
+    // order.  The finest level of a 640x480 frame is 4.7 pixels per thread: one batch, two round trips -- the pixel-at-a-time
+    // loop took two per pixel (10 us of the evaluation's 18).  One wave per SIMD runs here (256 workgroups of 4 waves on 256
+    // compute units), so the ~200 registers of a batch cost no occupancy.
+#ifndef GPS_TRACK_EV_BATCH
+#define GPS_TRACK_EV_BATCH 1
+#endif
+    constexpr int B = K == 1 ? GPS_TRACK_EV_BATCH : K == 2 ? 3 : 2;
+    const int stride = n_rows * blockDim.x;
+    for (int i0 = bid * blockDim.x + threadIdx.x; i0 < n; i0 += B * stride) {
+        float depth[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) { const int i = i0 + b * stride; depth[b] = i < n ? a.depth[i] : 0.0f; }
+        GhProj pr[B][K];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int i = i0 + b * stride;
+            const int y = i / a.vw, x = i - y * a.vw;
+            const bool live = !(depth[b] <= 1e-8f);
+            const float px = depth[b] * (((float)x - a.view_intr.z) / a.view_intr.x);
+            const float py = depth[b] * (((float)y - a.view_intr.w) / a.view_intr.y);
+#pragma unroll
+            for (int p = 0; p < K; p++) pr[b][p] = gh_project(a, poses[p], px, py, depth[b], live);
+        }
+        GhFoot ft[B][K];
+#pragma unroll
+        for (int b = 0; b < B; b++)
+#pragma unroll
+            for (int p = 0; p < K; p++) ft[b][p] = gh_fetch(a, pr[b][p]);
+#pragma unroll
+        for (int b = 0; b < B; b++)
+#pragma unroll
+            for (int p = 0; p < K; p++) gh_accumulate<ITER>(a, pr[b][p], ft[b][p], depth[b], acc[p][0], acc[p][1], acc[p] + 2, acc[p] + 2 + NP);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool prof = bid == 0 && t_arrived >= 0 && phase_base != 0;
+    const long long t_loop = prof ? wall_clock64() : 0;
+    // wave totals, four values per register (wave_reduce.hpp): 10 VALU ops per quad instead of 24 ds_bpermute round trips
+    const int row_slot = ((lane >> 4) & 1) * 2 + (lane >> 5);  // reduce4 leaves (a, c, b, d) in rows 0..3
+#pragma unroll
+    for (int p = 0; p < K; p++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const float z = gps::reduce4(acc[p][4 * q], acc[p][4 * q + 1], acc[p][4 * q + 2], acc[p][4 * q + 3]);
+            if ((lane & 15) == 15) lds.red[p][wave][4 * q + row_slot] = z;
+        }
+    __syncthreads();
+    if (tid < K * GH_SLOTS) {  // word w of this workgroup's row of pose p: sums in words d + d / 15, the sequence number in words 15 and 31
+        const int p = tid >> 5, w = tid & (GH_SLOTS - 1);
+        const int d = w - (w >> 4);  // inverse of chunk_word for non-tag words
+        uint32_t wv = (uint32_t)seq;
+        if ((w & 15) != 15) {
+            float t = 0.0f;
+            if (d < NV) {
+#pragma unroll
+                for (int w2 = 0; w2 < EV_THREADS / 64; w2 += 2) t += lds.red[p][w2][d] + lds.red[p][w2 + 1][d];  // fixed order
+            }
+            wv = __float_as_uint(t);
+        }
+        if (host_rows) {
+            if (bid == 0) {   // payload 29 (word 30) of row 0: the frame's valid-pixel count
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) vc += (uint32_t)__shfl_xor((int)vc, o, 32);
+                if (w == 30) wv = vc;
+            }
+            host_rows[((size_t)p * EV_MAX_WGS + bid) * GH_SLOTS + w] = wv;   // one store instruction: two 64-byte chunks across PCIe
+        } else {
+            __hip_atomic_store(partial + ((size_t)p * EV_MAX_WGS + bid) * GH_SLOTS + w, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (host_rows) {
+        if (tid == 0 && bid == 0 && t_arrived >= 0) {   // (profile: this workgroup's share; "until all rows" is the host's now)
+            const long long t_end = wall_clock64();
+            sync[SYNC_EVAL_TICKS] += (uint32_t)(t_end - t_arrived); sync[SYNC_EVALS] += 1u;
+            if (prof) { sync[phase_word(phase_base, 0)] += 1u; sync[phase_word(phase_base, 1)] += (uint32_t)(t_loop - t_arrived);
+                        sync[phase_word(phase_base, 3)] += (uint32_t)(t_end - t_loop); }
+        }
+        return;
+    }
+    if (bid >= K) return;
+    // ---- workgroup p < K is the summer of pose p
+    const long long t_rows = sum_rows_and_answer(lds, n_rows, partial + (size_t)bid * EV_MAX_WGS * GH_SLOTS, sync, result + bid * MAILBOX_GROUP_WORDS,
+                                                 mailbox ? mailbox + bid * MAILBOX_GROUP_WORDS : nullptr, seq, parity);
+    // profile words (gps_track_poll_profile / _phases): wall-clock ticks between the arrival of this launch's argument line and its
+    // result leaving, and the number of evaluations.  Launches of a stream run one after the other: plain read-modify-write
+    if (tid == 0 && bid == 0 && t_arrived >= 0 && t_rows) {
+        const long long t_end = wall_clock64();
+        sync[SYNC_EVAL_TICKS] += (uint32_t)(t_end - t_arrived); sync[SYNC_EVALS] += 1u;
+        if (prof) {
+            sync[phase_word(phase_base, 0)] += 1u;
+            sync[phase_word(phase_base, 1)] += (uint32_t)(t_loop - t_arrived);
+            sync[phase_word(phase_base, 2)] += (uint32_t)(t_rows - t_loop);
+            sync[phase_word(phase_base, 3)] += (uint32_t)(t_end - t_rows);
+        }
     }
 }
 
@@ -457,7 +572,8 @@ template <int ITER>
 __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32_t* __restrict__ partial, uint32_t* __restrict__ sync,
                                                               float* __restrict__ result, volatile float* mailbox, int seq, int parity) {
     GPS_FRAME_PRIO();
-    eval_body<ITER>(a, (int)blockIdx.x, (int)gridDim.x, partial, sync, result, mailbox, seq, parity);
+    __shared__ EvLds lds;
+    eval_fused<ITER, 1>(lds, a, &a.approxInvPose, (int)blockIdx.x, (int)gridDim.x, partial, sync, result, mailbox, seq, parity);
 }
 
 // (2) PRE-LAUNCHED evaluation (mailbox path).  What an LM iteration evaluates -- level, kind, pose -- is decided by the host
@@ -474,6 +590,14 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_kernel(GhArgs a, uint32
 // of exiting; late workgroups join at the current evaluation) -- no faster (0.571 vs 0.560 ms per tracked frame, overlap
 // schedule 934 vs 960 frames/s): with the next launch already queued, launch-to-launch overhead is off the critical path;
 // an iteration is the host <-> device loop itself (sums -> PCIe -> solve -> line -> PCIe -> relay -> rows -> sums).
+//
+// Round 5, measured and dropped: THE REJECTION CHAIN IN THE SAME WORKGROUPS -- consecutive argument lines of one level and kind
+// evaluated by the same 256 workgroups in one pass over the pixels (depth load and back-projection shared, every pose its own sums,
+// row table and mailbox block; bit-equal poses with 0..3 poses riding along).  The evaluation is latency-bound, not bandwidth-
+// bound: a second pose in the same thread adds its own dependent footprint round trip (own pixel loop of the finest level 10.0 ->
+// 14.1 us, of the coarser levels 4.7 -> 7.5 us; with all footprints of a batch of pixels and poses in flight at once 13.3 / 9.3 us
+// at 256 registers), whereas a second GROUP of workgroups runs beside the first on otherwise idle compute units for free.  The
+// groups stay (tools/probe/track_phases.py prints the phases these numbers are).
 struct PollArgs {
     const float4* pn; int sw, sh;
     float4 scene_intr;
@@ -483,8 +607,9 @@ struct PollArgs {
     LevelTab tab[GPS_TRACK_MAX_LEVELS];  // per-level constants (kernel arguments: selected with static indices, no memory round trip)
     const uint32_t* arg_line;  // pinned host memory, 64-byte aligned
     uint32_t* dev_line;        // device copy of the line (relayed by workgroup 0)
-    const uint32_t* bar_line;  // != NULL: the host writes the line into THIS block of fine-grained device memory through the
-                               // BAR (gps_track_state.dev_arg_line) and every workgroup polls it here: no PCIe read, no relay
+    const uint32_t* bar_line;  // != NULL: the host writes the lines into THIS block of fine-grained device memory through the
+                               // BAR (gps_track_state.dev_arg_line) and every workgroup polls them here: no PCIe read, no relay
+    volatile uint32_t* host_rows;  // != NULL: the row tables live in the pinned host mailbox and the HOST adds the rows (eval_fused)
 };
 constexpr uint32_t ARG_RUN = 1, ARG_SKIP = 2;
 constexpr long long ARG_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
@@ -494,6 +619,7 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
                                                                    volatile float* mailbox, int seq, int parity) {
     __shared__ uint32_t line[16];
     __shared__ long long t_arrived;
+    __shared__ EvLds lds;
     // group 0 = the LM loop's evaluation; groups 1 .. EV_GROUPS - 1 (BAR line only: the grid has them only then) = the poses the
     // loop would evaluate next if that one is rejected.  A group has its own argument line (64 bytes apart), rows and result.
     const int grp = (int)blockIdx.x / EV_MAX_WGS, bid = (int)blockIdx.x - grp * EV_MAX_WGS;
@@ -584,9 +710,11 @@ __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa
     uint32_t* const rows = partial + (size_t)grp * EV_MAX_WGS * GH_SLOTS;
     float* const res = result + grp * MAILBOX_GROUP_WORDS;
     volatile float* const mb = mailbox ? mailbox + grp * MAILBOX_GROUP_WORDS : nullptr;
-    if (kind == TRK_ROTATION) eval_body<TRK_ROTATION>(a, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta);
-    else if (kind == TRK_TRANSLATION) eval_body<TRK_TRANSLATION>(a, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta);
-    else eval_body<TRK_BOTH>(a, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta);
+    const int pb = level == 0 ? SYNC_PHASE_L0 : SYNC_PHASE_COARSE;   // (group 0's workgroup 0 keeps the profile: ta >= 0 only there)
+    volatile uint32_t* const hr = pa.host_rows ? pa.host_rows + (size_t)grp * EV_MAX_WGS * GH_SLOTS : nullptr;
+    if (kind == TRK_ROTATION) eval_fused<TRK_ROTATION, 1>(lds, a, &a.approxInvPose, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta, pb, hr);
+    else if (kind == TRK_TRANSLATION) eval_fused<TRK_TRANSLATION, 1>(lds, a, &a.approxInvPose, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta, pb, hr);
+    else eval_fused<TRK_BOTH, 1>(lds, a, &a.approxInvPose, bid, lt.n_wgs, rows, sync, res, mb, seq, parity, ta, pb, hr);
 }
 
 // ---------------------------------------------------------------- host side: ORUtils::Cholesky, TrackCamera bookkeeping
@@ -913,6 +1041,18 @@ int gps_track_poll_profile(const void* scratch, int width, int height, uint32_t 
     return hipStreamSynchronize(st) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
+int gps_track_poll_phases(const void* scratch, int width, int height, uint32_t out[8], gps_stream stream) {
+    if (!scratch || !out || width <= 0 || height <= 0) return GPS_ERR_ARG;
+    Scratch w;
+    carve(&w, (char*)const_cast<void*>(scratch), width, height);
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t words[16];
+    if (hipMemcpyAsync(words, w.sync, sizeof(words), hipMemcpyDeviceToHost, st) != hipSuccess) GPS_FAIL_LAUNCH();
+    if (hipStreamSynchronize(st) != hipSuccess) return GPS_ERR_LAUNCH;
+    for (int k = 0; k < 4; k++) { out[k] = words[phase_word(SYNC_PHASE_L0, k)]; out[4 + k] = words[phase_word(SYNC_PHASE_COARSE, k)]; }
+    return GPS_OK;
+}
+
 int64_t gps_track_scratch_bytes(int width, int height) {
     if (width <= 0 || height <= 0) return GPS_ERR_ARG;
     return (int64_t)carve(nullptr, nullptr, width, height);
@@ -1021,8 +1161,56 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         return (int)(++ts->mail_seq);
     };
     // groups of an evaluation launch: the loop's pose + the poses that ride along (BAR lines and a mailbox block per group)
-    const int mailbox_groups = ts->mailbox_bytes >= 2 * MAILBOX_GROUP_WORDS * 4 ? ts->mailbox_bytes / (MAILBOX_GROUP_WORDS * 4) : 1;
+    // mailbox layout (gps_track_state.mailbox_bytes): G answer blocks of 256 bytes -- and, when there is room for them, G row tables of
+    // EV_MAX_WGS x 128 bytes behind the blocks: the workgroups then store their rows THERE and this thread adds them (host_rows)
+    constexpr int BLOCK_BYTES = MAILBOX_GROUP_WORDS * 4, ROWS_BYTES = EV_MAX_WGS * GH_SLOTS * 4;
+    static_assert(BLOCK_BYTES == GPS_TRACK_MAILBOX_BLOCK_BYTES && ROWS_BYTES == GPS_TRACK_MAILBOX_ROWS_BYTES, "include/gps_slam_hip.h");
+    const int groups_with_rows = ts->mailbox_bytes / (BLOCK_BYTES + ROWS_BYTES);
+    const bool host_sums = mailbox && groups_with_rows >= 1;
+    const int mailbox_groups = host_sums ? groups_with_rows : ts->mailbox_bytes >= 2 * BLOCK_BYTES ? ts->mailbox_bytes / BLOCK_BYTES : 1;
     const int n_groups = (mailbox && bar_line) ? max(1, min(EV_GROUPS, mailbox_groups)) : 1;
+    volatile uint32_t* const host_rows = host_sums ? reinterpret_cast<volatile uint32_t*>(ts->host_mailbox) + (size_t)min(EV_GROUPS, mailbox_groups) * MAILBOX_GROUP_WORDS : nullptr;
+    pl.host_rows = host_rows;
+    // The answer of group g to launch `seq`: the summer's block, or -- host_rows -- the rows of its table added in the summer's order
+    // (thread (r, k) of the summer adds word k of rows r, r + 8, ... in increasing order, then the eight partial sums in order:
+    // eval_fused / sum_rows_and_answer; IEEE additions only, so the bits are the device's).  `next` remembers the first row not yet
+    // seen: rows are stable once tagged (nothing rewrites them before the next launch's lines are published).
+    int rows_next[EV_GROUPS] = {0};
+    auto answered = [&](int g, int seq, int n_rows) -> bool {
+        if (!host_rows) {
+            volatile float* const mb = mailbox + g * MAILBOX_GROUP_WORDS;
+            return float_bits(mb[15]) == seq && float_bits(mb[31]) == seq;
+        }
+        volatile uint32_t* const T = host_rows + (size_t)g * EV_MAX_WGS * GH_SLOTS;
+        int& r = rows_next[g];
+        while (r < n_rows && (int)T[r * GH_SLOTS + 15] == seq && (int)T[r * GH_SLOTS + 31] == seq) r++;
+        return r >= n_rows;
+    };
+    auto collect = [&](int g, int n_rows, float* raw /* GH_SLOTS words, chunked like a row */) {
+        if (!host_rows) {
+            volatile float* const mb = mailbox + g * MAILBOX_GROUP_WORDS;
+            for (int k = 0; k < GH_SLOTS; k++) raw[k] = mb[k];
+            return;
+        }
+        volatile uint32_t* const T = host_rows + (size_t)g * EV_MAX_WGS * GH_SLOTS;
+        float part[EV_ROW_GROUPS][GH_SLOTS];
+        for (int q = 0; q < EV_ROW_GROUPS; q++)
+            for (int k = 0; k < GH_SLOTS; k++) part[q][k] = 0.0f;
+        for (int r = 0; r < n_rows; r++) {
+            float* dst = part[r % EV_ROW_GROUPS];
+            for (int k = 0; k < GH_SLOTS; k++) {
+                if ((k & 15) == 15) continue;   // the row's tags
+                const uint32_t v = T[r * GH_SLOTS + k]; float f; memcpy(&f, &v, 4); dst[k] += f;
+            }
+        }
+        for (int k = 0; k < GH_SLOTS; k++) {
+            float t = 0.0f;
+            for (int q = 0; q < EV_ROW_GROUPS; q++) t += part[q][k];
+            raw[k] = t;
+        }
+        const uint32_t vcount = T[30];   // payload 29 of row 0: the frame's valid-pixel count (bits)
+        memcpy(&raw[30], &vcount, 4);
+    };
     // One argument line: payload first, sequence number last (x86 stores are not reordered with each other; the compiler barrier
     // keeps the order).  Group g's line sits 64 bytes behind group g - 1's in the BAR block; the pinned line has group 0 only.
     auto write_line = [&](int grp, int seq, uint32_t cmd, int kind, int level, const float* pose) {
@@ -1116,6 +1304,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         const int n_wgs = min(EV_MAX_WGS, gps_div_up(a.vw * a.vh, EV_THREADS));
         float raw[EV_GROUPS][GH_SLOTS];  // per group two 64-byte chunks: 15 payload words + the sequence number each (eval_body)
         int answers = 1;                 // raw[0 .. answers) hold results: the evaluation itself, then the poses that rode along
+        int ride_seq = 0;                // host-summed rows: the launch whose riding-along groups may still be collected (0: none)
         if (mailbox) {
             // this evaluation is the pre-launched kernel (or the frame's first launch): hand it its arguments, then put
             // the NEXT evaluation on the stream before waiting -- its launch cost overlaps this evaluation
@@ -1124,6 +1313,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             pending.seq = 0;
             for (int g = 0; g < n_groups; g++) {   // per-state sequence numbers (>= 1): nothing stale can match
                 mailbox[g * MAILBOX_GROUP_WORDS + 15] = 0.0f; mailbox[g * MAILBOX_GROUP_WORDS + 31] = 0.0f;
+                rows_next[g] = 0;
             }
             for (int g = 1; g < n_groups; g++) {
                 if (g <= nc) write_line(g, seq, ARG_RUN, cand[g - 1].kind, cand[g - 1].level, cand[g - 1].pose);
@@ -1141,7 +1331,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             const unsigned long long tsc0 = host_cycles();
             unsigned long long tsc_prev = tsc0, tsc_gap = 0;
             for (long spin = 0; spin < 200000000L; spin++) {
-                if (float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq) { got = true; break; }
+                if (answered(0, seq, n_wgs)) { got = true; break; }
                 const unsigned long long now = host_cycles();
                 if (now - tsc_prev > tsc_gap) tsc_gap = now - tsc_prev;
                 tsc_prev = now;
@@ -1165,7 +1355,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                 // after all (tags) or has retired itself (acknowledgement word).
                 bool late = false, gone = false;
                 for (long spin = 0; spin < 400000000L && !late && !gone; spin++) {
-                    late = float_bits(mailbox[15]) == seq && float_bits(mailbox[31]) == seq;
+                    late = answered(0, seq, n_wgs);
                     gone = float_bits(mailbox[32]) == seq;
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                 }
@@ -1200,16 +1390,20 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                     GPS_FAIL_LAUNCH();
                 by_mailbox = false;   // (whatever rode along with launch seq is not waited for)
             }
-            for (int k = 0; k < GH_SLOTS; k++) raw[0][k] = mailbox[k];
-            // The poses that rode along: their groups started with group 0's and end within a few microseconds of it.  ALWAYS waited
-            // for, needed or not: the next launch's lines may only be written once every workgroup of this one that has pixels has
-            // delivered its row (a workgroup that finds a later line takes itself out -- its group's summer would then wait
-            // for that row until ROW_TIMEOUT, with the frame stream behind it).
-            for (int g = 1; by_mailbox && g <= nc; g++) {
-                volatile float* const mb = mailbox + g * MAILBOX_GROUP_WORDS;
+            if (by_mailbox) collect(0, n_wgs, raw[0]);
+            else for (int k = 0; k < GH_SLOTS; k++) raw[0][k] = mailbox[k];   // (the plain launch's summer wrote the block)
+            // The poses that rode along: their groups started with group 0's and end within a few microseconds of it.
+            // Device summer: ALWAYS waited for, needed or not -- the next launch's lines may only be written once every workgroup of
+            // this one that has pixels has delivered its row (a workgroup that finds a later line takes itself out; its group's
+            // summer would then wait for that row until ROW_TIMEOUT, with the frame stream behind it).
+            // Host-summed rows: nobody on the device waits for a row, so a pose that rode along costs the host nothing unless the
+            // loop gets to it -- its rows are waited for and added only then (ride_seq below).
+            for (int g = 1; by_mailbox && !host_rows && g <= nc; g++) {
+                const int lg = cand[g - 1].level;
+                const int n_wgs_g = min(EV_MAX_WGS, gps_div_up(lw[lg] * lh[lg], EV_THREADS));
                 bool have = false;
                 for (long spin = 0; spin < 200000000L; spin++) {
-                    if (float_bits(mb[15]) == seq && float_bits(mb[31]) == seq) { have = true; break; }
+                    if (answered(g, seq, n_wgs_g)) { have = true; break; }
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                 }
                 if (!have) {
@@ -1218,9 +1412,10 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                         fprintf(stderr, "[gps_slam_hip] tracker: the pose riding along with evaluation %d (group %d) never answered\n", seq, g);
                     break;
                 }
-                for (int k = 0; k < GH_SLOTS; k++) raw[g][k] = mb[k];
+                collect(g, n_wgs_g, raw[g]);
                 answers = g + 1;
             }
+            if (by_mailbox && host_rows) ride_seq = seq;
         } else {
             const int seq = next_seq();
             if (it == TRK_ROTATION) track_eval_kernel<TRK_ROTATION><<<n_wgs, EV_THREADS, 0, st>>>(a, w.partial, w.sync, w.result, nullptr, seq, parity);
@@ -1235,9 +1430,20 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         }
         // the loop's decision on the evaluation -- and, while it keeps rejecting, on the poses that rode along with it
         bool rejected = true;
-        for (int g = 0; g < answers && rejected && lm.active; g++) {
+        for (int g = 0; g < (ride_seq ? nc + 1 : answers) && rejected && lm.active; g++) {
             if (g > 0) {
                 if (!lm.request().same(cand[g - 1])) break;   // (cannot happen: the same arithmetic on the same state)
+                if (ride_seq) {   // the rows of this pose's group: waited for and added only now that the loop has got to it
+                    const int lg = cand[g - 1].level;
+                    const int n_wgs_g = min(EV_MAX_WGS, gps_div_up(lw[lg] * lh[lg], EV_THREADS));
+                    bool have = false;
+                    for (long spin = 0; spin < 200000000L; spin++) {
+                        if (answered(g, ride_seq, n_wgs_g)) { have = true; break; }
+                        if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
+                    }
+                    if (!have) break;   // (its group never delivered: the loop evaluates the pose itself, as if nothing had ridden along)
+                    collect(g, n_wgs_g, raw[g]);
+                }
                 spec_used++;
             }
             float host[GH_SLOTS];

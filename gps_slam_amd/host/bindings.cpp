@@ -159,6 +159,8 @@ PYBIND11_MODULE(_host, m) {
         .def("usesBarArgLine", &TsdfEngine::usesBarArgLine)
         .def("setPosesRidingAlong", &TsdfEngine::setPosesRidingAlong)
         .def("posesRidingAlong", &TsdfEngine::posesRidingAlong)
+        .def("setHostSummedRows", &TsdfEngine::setHostSummedRows)
+        .def("hostSummedRows", &TsdfEngine::hostSummedRows)
         .def("ridingAlongStats", &TsdfEngine::ridingAlongStats)
         .def("trackerTotals", &TsdfEngine::trackerTotals)
         .def("lastPose", [](TsdfEngine& e) {

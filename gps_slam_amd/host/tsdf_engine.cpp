@@ -77,7 +77,7 @@ void TsdfEngine::resetAll() {
     camIntrincs.clear();
     check(gps_track_state_reset(&track_state_), "gps_track_state_reset");
     if (track_mailbox_.defined()) track_state_.host_mailbox = track_mailbox_.data_ptr();
-    track_state_.mailbox_bytes = 256 * (1 + poses_riding_along);
+    track_state_.mailbox_bytes = mailboxBytes();
     track_state_.dev_arg_line = bar_arg_line ? track_arg_line_.get() : nullptr;
 }
 
@@ -87,13 +87,15 @@ void TsdfEngine::turnOnTracking(const char* levels, int numIterC, int numIterF, 
                                 framesToSkip, framesToWeight), "gps_track_config_init");
     if (!track_scratch_.defined()) {
         track_scratch_ = torch::empty({gps_track_scratch_bytes(state_.width, state_.height)}, u8(device_));
-        track_mailbox_ = torch::zeros({64 * (1 + kMaxRidingAlong)}, torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
+        // (room for the answer blocks and the host-summed row tables of every group: gps_track_state.mailbox_bytes)
+        track_mailbox_ = torch::zeros({(GPS_TRACK_MAILBOX_BLOCK_BYTES + GPS_TRACK_MAILBOX_ROWS_BYTES) / 4 * (1 + kMaxRidingAlong)},
+                                      torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
         void* line = nullptr;
         check(gps_track_arg_line_alloc(&line), "gps_track_arg_line_alloc");
         if (line) track_arg_line_ = std::shared_ptr<void>(line, [](void* p) { (void)gps_track_arg_line_free(p); });
     }
     track_state_.host_mailbox = track_mailbox_.data_ptr();
-    track_state_.mailbox_bytes = 256 * (1 + poses_riding_along);
+    track_state_.mailbox_bytes = mailboxBytes();
     track_state_.dev_arg_line = bar_arg_line ? track_arg_line_.get() : nullptr;
     trackingActive = true;
 }

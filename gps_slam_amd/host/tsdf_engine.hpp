@@ -200,7 +200,14 @@ public:
     // gps_track_state.mailbox_bytes).  Same poses, fewer round trips; the switch exists for A/B measurements and the equality test.
     void setPosesRidingAlong(int n) {
         poses_riding_along = n < 0 ? 0 : n > kMaxRidingAlong ? kMaxRidingAlong : n;
-        track_state_.mailbox_bytes = 256 * (1 + poses_riding_along);
+        track_state_.mailbox_bytes = mailboxBytes();
+    }
+    // the evaluation's workgroups store their rows of partial sums straight into the pinned mailbox and the tracking thread adds
+    // them (default), or a summing workgroup on the device does and only the totals travel (round 4); same poses, bit for bit
+    void setHostSummedRows(bool on) { host_summed_rows = on; track_state_.mailbox_bytes = mailboxBytes(); }
+    bool hostSummedRows() const { return host_summed_rows; }
+    int32_t mailboxBytes() const {
+        return (1 + poses_riding_along) * (GPS_TRACK_MAILBOX_BLOCK_BYTES + (host_summed_rows ? GPS_TRACK_MAILBOX_ROWS_BYTES : 0));
     }
     int posesRidingAlong() const { return poses_riding_along; }
     // of the last tracked frame: {poses that rode along with evaluations, poses the loop consumed}
@@ -259,8 +266,8 @@ private:
     // the tracker's argument line in host-writable device memory (gps_track_arg_line_alloc; null without a large BAR).  The
     // switch exists for A/B measurements and for the tests that cover both hand-over paths.
     std::shared_ptr<void> track_arg_line_;
-    bool bar_arg_line = true;
-    static constexpr int kMaxRidingAlong = 2;
+    bool bar_arg_line = true, host_summed_rows = true;
+    static constexpr int kMaxRidingAlong = 3;
     int64_t tracked_frames_ = 0, evals_total_ = 0, rode_total_ = 0, used_total_ = 0;
     int poses_riding_along = 1;   // (0 / 1 / 2 measured on the 640x480 loop: 973 / 993 / 980 frames/s sequential, 1,316 / 1,324 / 1,306 overlap)
     ORUtils::SE3Pose pose_d_;

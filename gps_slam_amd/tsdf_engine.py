@@ -120,11 +120,13 @@ class TsdfEngine:
     # ---- ITMBasicEngine::ProcessFrame with the tracker ON (use_gt_pose: false)
     def turnOnTracking(self, levels="rrbb", num_iter_coarse=20, num_iter_fine=50, thresh_coarse=0.1, thresh_fine=0.004,
                        term_thresh=1e-4, tukey_cutoff=8.0, frames_to_skip=20, frames_to_weight=50, bar_arg_line=True,
-                       poses_riding_along=1):
+                       poses_riding_along=1, host_summed_rows=True):
         """Depth-only ExtendedTracker with the parameters of ITMLibSettings.cpp:54-57 (defaults).
         poses_riding_along: how many of the poses the LM loop would evaluate next after a REJECTION are evaluated together with
-        every evaluation (gps_track_state.mailbox_bytes; BAR argument line only; 0 = one pose per evaluation; 0..2).  Same poses
-        whatever the number; 1 measured best on the 640x480 loop (0 / 1 / 2: 973 / 993 / 980 frames/s sequential)."""
+        every evaluation (gps_track_state.mailbox_bytes; BAR argument line only; 0 = one pose per evaluation; 0..3).  Same poses
+        whatever the number; 1 measured best on the 640x480 loop (0 / 1 / 2: 973 / 993 / 980 frames/s sequential).
+        host_summed_rows: the evaluation's workgroups store their rows of partial sums into the pinned mailbox and the tracking call
+        adds them (same order, same bits) instead of a summing workgroup on the device."""
         self.track_cfg = TrackConfig()
         check(lib.gps_track_config_init(C.byref(self.track_cfg), levels.encode(), num_iter_coarse, num_iter_fine, thresh_coarse,
                                         thresh_fine, term_thresh, tukey_cutoff, frames_to_skip, frames_to_weight),
@@ -133,10 +135,13 @@ class TsdfEngine:
         check(lib.gps_track_state_reset(C.byref(self.track_state)), "gps_track_state_reset")
         nbytes = int(lib.gps_track_scratch_bytes(self.W, self.H))
         self.track_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        groups = 1 + max(0, min(2, int(poses_riding_along)))
-        self._mailbox = torch.zeros(64 * groups, dtype=torch.float32).pin_memory()  # kernel -> host accumulators, no memcpy
+        groups = 1 + max(0, min(3, int(poses_riding_along)))
+        # kernel -> host, no memcpy: an answer block per group and (host_summed_rows) a table of the workgroups' rows per group, which
+        # the tracking call adds up itself instead of a summing workgroup on the device (gps_track_state.mailbox_bytes)
+        per_group = 256 + (32768 if host_summed_rows else 0)
+        self._mailbox = torch.zeros(per_group // 4 * groups, dtype=torch.float32).pin_memory()
         self.track_state.host_mailbox = self._mailbox.data_ptr()
-        self.track_state.mailbox_bytes = 256 * groups
+        self.track_state.mailbox_bytes = per_group * groups
         # the argument line in host-writable device memory (written through the BAR; None without a large BAR)
         if not hasattr(self, "_arg_line"):
             self._arg_line = None
@@ -172,6 +177,13 @@ class TsdfEngine:
         out = (C.c_uint32 * 4)()
         check(lib.gps_track_poll_profile(self.track_scratch.data_ptr(), self.W, self.H, out, self._stream()), "gps_track_poll_profile")
         return [int(v) for v in out]
+
+    def track_poll_phases(self):
+        """gps_track_poll_phases -> {"level0": [evaluations, loop ticks, rows-wait ticks, tail ticks], "coarse": [...]} (cumulative)"""
+        out = (C.c_uint32 * 8)()
+        check(lib.gps_track_poll_phases(self.track_scratch.data_ptr(), self.W, self.H, out, self._stream()), "gps_track_poll_phases")
+        v = [int(x) for x in out]
+        return {"level0": v[:4], "coarse": v[4:]}
 
     def track_diag(self):
         return np.array(self.track_state.diag, dtype=np.float32)

@@ -719,6 +719,8 @@ typedef struct {
  * evaluations, [13] those the loop consumed, [14] host ms in the tracker, [15] host ms enqueueing the fusion kernels
  * (gps_tsdf_process_frame_tracked)} of the last call.
  * Matrices in ORUtils layout m[col*4 + row]. */
+#define GPS_TRACK_MAILBOX_BLOCK_BYTES 256    /* one answer block of gps_track_state.host_mailbox */
+#define GPS_TRACK_MAILBOX_ROWS_BYTES 32768   /* one row table (256 workgroups x 128 bytes) behind the blocks: host-summed rows */
 typedef struct {
     float pose_M[16], pose_invM[16], pose_pc_M[16];
     int32_t age_point_cloud, frames_processed;
@@ -771,6 +773,10 @@ GPS_API int64_t gps_track_scratch_bytes(int width, int height);
  * (blocking read-back): out = { wall-clock ticks (100 MHz) launches spent on the GPU WAITING for the host's argument line,
  * ticks between the line's arrival and the result leaving (the evaluation proper), evaluations run, launches retired unused }. */
 GPS_API int gps_track_poll_profile(const void *scratch, int width, int height, uint32_t out[4], gps_stream stream);
+/* The same clock split into phases, as workgroup 0 (the summer) of an evaluation sees them, for the finest level (out[0..3]) and
+ * for the coarser levels (out[4..7]): { evaluations, ticks from the argument line's arrival to the end of its own pixel loop,
+ * ticks from there until every row of the table carries the launch's tag, ticks from there to the mailbox store }. */
+GPS_API int gps_track_poll_phases(const void *scratch, int width, int height, uint32_t out[8], gps_stream stream);
 
 /* ITMExtendedTracker::TrackCamera (useDepth, !useColour): refines ts->pose_M / pose_invM against the ICP maps of the last
  * raycast (s->icp_points / s->icp_normals, rendered from ts->pose_pc_M) using s->depth.

@@ -487,7 +487,7 @@ def test_cpp_engine_tracks_like_the_reference():
     seq = synth.make_sequence(W, Hh, n, step_deg=float(G["step_deg"]))
     rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
     runs = []
-    for riders in (1, 0, 2):   # poses of the LM loop's reject branch riding along with every evaluation (setPosesRidingAlong)
+    for riders in (1, 0, 2, 3):   # poses of the LM loop's reject branch riding along with every evaluation (setPosesRidingAlong)
         eng = h.ITMBasicEngine(W, Hh, seq["fx"], seq["fy"], seq["cx"], seq["cy"], float(G["voxel"]), float(G["mu"]),
                                float(G["vf_min"]), float(G["vf_max"]))
         assert eng.posesRidingAlong() == 1   # the default
@@ -504,7 +504,7 @@ def test_cpp_engine_tracks_like_the_reference():
         assert eng.trackDiag()[8] > 10000  # inliers of the last accepted evaluation
         assert riders == 0 or not eng.usesBarArgLine() or consumed > 0
         runs.append(np.stack(poses))
-    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])   # the same poses, bit for bit
+    assert all(np.array_equal(runs[0], r) for r in runs[1:])   # the same poses, bit for bit
 
 
 def test_cpp_engine_mesh_and_state_files_equal_python_host(tmp_path):

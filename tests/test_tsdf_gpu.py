@@ -335,12 +335,13 @@ def test_tracker_without_mailbox_gives_the_same_poses():
     seq = synth.make_sequence(W, H, n, step_deg=0.4)
     rgba = np.concatenate([seq["rgb"], np.full(seq["rgb"].shape[:-1] + (1,), 255, np.uint8)], -1)
     runs, counts, along = [], [], {}
-    for mode in ("mailbox", "memcpy", "new-scratch", "pinned-line", "alone", "two-along"):
+    for mode in ("mailbox", "memcpy", "new-scratch", "pinned-line", "alone", "two-along", "three-along", "device-summer", "device-summer-pinned-line"):
         eng = TsdfEngine(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], voxel_size=0.01, mu=0.04, device="cuda:0")
         # "mailbox": the default hand-over -- pre-launched evaluations, argument line written through the BAR into device memory
         # (gps_track_state.dev_arg_line) when the device has a large BAR; "pinned-line": the line in the pinned mailbox, relayed
-        eng.turnOnTracking(bar_arg_line=mode != "pinned-line", poses_riding_along={"alone": 0, "two-along": 2}.get(mode, 1))
-        assert (eng.track_state.dev_arg_line is None) == (mode == "pinned-line" or eng._arg_line is None)
+        eng.turnOnTracking(bar_arg_line="pinned-line" not in mode, poses_riding_along={"alone": 0, "two-along": 2, "three-along": 3}.get(mode, 1),
+                           host_summed_rows="device-summer" not in mode)   # (host-summed rows are the default hand-over)
+        assert (eng.track_state.dev_arg_line is None) == ("pinned-line" in mode or eng._arg_line is None)
         if mode == "memcpy":
             eng.track_state.host_mailbox = None
         poses, levels, rode, used = [], [], 0, 0
@@ -359,11 +360,12 @@ def test_tracker_without_mailbox_gives_the_same_poses():
     assert all(np.array_equal(runs[0], r) for r in runs[1:])
     assert all(np.array_equal(counts[0], c) for c in counts[1:])   # evaluations per level, valid points, f, score, det(H)
     assert np.abs(runs[0][-1] - runs[0][0]).max() > 1e-3  # the camera actually moved
-    assert along["memcpy"] == (0, 0) and along["pinned-line"] == (0, 0) and along["alone"] == (0, 0)
+    assert along["memcpy"] == (0, 0) and along["pinned-line"] == (0, 0) and along["alone"] == (0, 0) and along["device-summer-pinned-line"] == (0, 0)
     if eng._arg_line is not None:   # (a device whose memory the host can write: the BAR line)
         rode, used = along["mailbox"]
         assert rode > 0 and 0 < used <= rode, along
         assert along["two-along"][0] > rode and along["two-along"][1] >= used, along
+        assert along["three-along"][0] > along["two-along"][0] and along["three-along"][1] >= along["two-along"][1], along
 
 
 # ----------------------------------------------------------------------------- meshing + persistence

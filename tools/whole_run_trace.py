@@ -20,7 +20,8 @@ def main():
     bench.prime(device)
     seq = bench.synthetic_sequence_device(W, H, n, 1234, device)
     out = {}
-    for sched in ("sequential", "overlap"):
+    for sched in (os.environ.get("TRACE_SCHEDULES", "sequential,overlap").split(",")):
+        torch.cuda._sleep(1)   # phase marker for tools/prof_summary.py
         sc = bench.Scene(seq, None, 1234, False, overlap=sched == "overlap", n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02)
         sc.pipe.keep_frame_ms = True
         if os.environ.get("TRACE_REPORT_MS"):
@@ -36,6 +37,7 @@ def main():
                           mallocs=int(torch.cuda.memory_stats().get("num_device_alloc", 0) - m0),
                           kf_mean=float(ms[10::10].mean()), nonkf_mean=float(np.delete(ms, np.arange(0, n, 10)).mean()))
         print(sched, json.dumps(out[sched]), flush=True)
+        torch.cuda._sleep(1)
         sc.close()
         del sc
         torch.cuda.empty_cache()
