@@ -1175,7 +1175,15 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     // (thread (r, k) of the summer adds word k of rows r, r + 8, ... in increasing order, then the eight partial sums in order:
     // eval_fused / sum_rows_and_answer; IEEE additions only, so the bits are the device's).  `next` remembers the first row not yet
     // seen: rows are stable once tagged (nothing rewrites them before the next launch's lines are published).
+    // Rows are added AS THEY ARRIVE (in row order: the scan below only ever moves forward), so that the last row to land costs one
+    // row's additions, not a pass over the table.
     int rows_next[EV_GROUPS] = {0};
+    float rows_part[EV_GROUPS][EV_ROW_GROUPS][GH_SLOTS];
+    auto rows_reset = [&](int g) {
+        rows_next[g] = 0;
+        for (int q = 0; q < EV_ROW_GROUPS; q++)
+            for (int k = 0; k < GH_SLOTS; k++) rows_part[g][q][k] = 0.0f;
+    };
     auto answered = [&](int g, int seq, int n_rows) -> bool {
         if (!host_rows) {
             volatile float* const mb = mailbox + g * MAILBOX_GROUP_WORDS;
@@ -1183,7 +1191,14 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
         }
         volatile uint32_t* const T = host_rows + (size_t)g * EV_MAX_WGS * GH_SLOTS;
         int& r = rows_next[g];
-        while (r < n_rows && (int)T[r * GH_SLOTS + 15] == seq && (int)T[r * GH_SLOTS + 31] == seq) r++;
+        while (r < n_rows && (int)T[r * GH_SLOTS + 15] == seq && (int)T[r * GH_SLOTS + 31] == seq) {
+            float* dst = rows_part[g][r % EV_ROW_GROUPS];
+            for (int k = 0; k < GH_SLOTS; k++) {
+                if ((k & 15) == 15) continue;   // the row's tags
+                const uint32_t v = T[r * GH_SLOTS + k]; float f; memcpy(&f, &v, 4); dst[k] += f;
+            }
+            r++;
+        }
         return r >= n_rows;
     };
     auto collect = [&](int g, int n_rows, float* raw /* GH_SLOTS words, chunked like a row */) {
@@ -1192,20 +1207,11 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             for (int k = 0; k < GH_SLOTS; k++) raw[k] = mb[k];
             return;
         }
+        (void)n_rows;   // (answered(g) has added every row)
         volatile uint32_t* const T = host_rows + (size_t)g * EV_MAX_WGS * GH_SLOTS;
-        float part[EV_ROW_GROUPS][GH_SLOTS];
-        for (int q = 0; q < EV_ROW_GROUPS; q++)
-            for (int k = 0; k < GH_SLOTS; k++) part[q][k] = 0.0f;
-        for (int r = 0; r < n_rows; r++) {
-            float* dst = part[r % EV_ROW_GROUPS];
-            for (int k = 0; k < GH_SLOTS; k++) {
-                if ((k & 15) == 15) continue;   // the row's tags
-                const uint32_t v = T[r * GH_SLOTS + k]; float f; memcpy(&f, &v, 4); dst[k] += f;
-            }
-        }
         for (int k = 0; k < GH_SLOTS; k++) {
             float t = 0.0f;
-            for (int q = 0; q < EV_ROW_GROUPS; q++) t += part[q][k];
+            for (int q = 0; q < EV_ROW_GROUPS; q++) t += rows_part[g][q][k];
             raw[k] = t;
         }
         const uint32_t vcount = T[30];   // payload 29 of row 0: the frame's valid-pixel count (bits)
@@ -1313,7 +1319,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             pending.seq = 0;
             for (int g = 0; g < n_groups; g++) {   // per-state sequence numbers (>= 1): nothing stale can match
                 mailbox[g * MAILBOX_GROUP_WORDS + 15] = 0.0f; mailbox[g * MAILBOX_GROUP_WORDS + 31] = 0.0f;
-                rows_next[g] = 0;
+                rows_reset(g);
             }
             for (int g = 1; g < n_groups; g++) {
                 if (g <= nc) write_line(g, seq, ARG_RUN, cand[g - 1].kind, cand[g - 1].level, cand[g - 1].pose);
