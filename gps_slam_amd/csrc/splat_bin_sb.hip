@@ -330,16 +330,21 @@ bool sb_supported(int N, int tile_width, int tile_height) {
     if (((nblk + ((int64_t)1 << shift) - 1) >> shift) > SB_MAX) return false;
     const size_t lds = sb_scatter_lds_bytes(N, (int)n_tiles);
     if (lds > 160 * 1024) return false;
-    // the opt-in for more than 64 KB of dynamic LDS, granted once per size class (monotonic; two host threads may ask)
+    if (lds <= 64 * 1024) return true;   // (no opt-in needed: the common sizes never take the lock below)
+    // the opt-in for more than 64 KB of dynamic LDS is a per-DEVICE function attribute: granted once per device and size class
+    // (monotonic; several host threads may ask)
+    constexpr int MAX_DEVICES = 64;
     static std::mutex mu;
-    static size_t granted = 64 * 1024;
+    static size_t granted[MAX_DEVICES] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return false; }
     std::lock_guard<std::mutex> lock(mu);
-    if (lds <= granted) return true;
+    if (lds <= granted[dev]) return true;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    granted = lds;
+    granted[dev] = lds;
     return true;
 }
 

@@ -258,7 +258,13 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnGrid* __
     };
     // a point's computed cell can differ from its exact one by rounding at a face: the faces of the searched cube are trusted only
     // up to a margin of 1 % of a cell (the coordinate error is < 1e-4 cells at <= 1024 cells per axis)
-    const float margin = 0.01f * g.h;
+    // -- plus, for point sets far from the origin relative to their extent, the rounding of the coordinates themselves: the face
+    // distances are taken in the grid's own frame (q - min, one rounding of |q|'s magnitude) and the margin grows by a few ulps of
+    // the largest coordinate magnitude in the box
+    const float reach = fmaxf(fmaxf(fmaxf(fabsf(g.minx), fabsf(g.minx + (float)g.gx * g.h)), fmaxf(fabsf(g.miny), fabsf(g.miny + (float)g.gy * g.h))),
+                              fmaxf(fabsf(g.minz), fabsf(g.minz + (float)g.gz * g.h)));
+    const float margin = 0.01f * g.h + 4.0f * 1.1920929e-7f * reach;
+    const float sx = q.x - g.minx, sy = q.y - g.miny, sz = q.z - g.minz;
     for (int r = 0;; r++) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, g.gx - 1), y0 = max(cy - r, 0), y1 = min(cy + r, g.gy - 1),
                   z0 = max(cz - r, 0), z1 = min(cz + r, g.gz - 1);
@@ -279,12 +285,12 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnGrid* __
         // distance from the query to the nearest face of the searched cube that has grid behind it
         float dmin = FLT_MAX;
         bool open = false;
-        if (cx - r > 0) { open = true; dmin = fminf(dmin, q.x - (g.minx + (float)(cx - r) * g.h)); }
-        if (cx + r < g.gx - 1) { open = true; dmin = fminf(dmin, (g.minx + (float)(cx + r + 1) * g.h) - q.x); }
-        if (cy - r > 0) { open = true; dmin = fminf(dmin, q.y - (g.miny + (float)(cy - r) * g.h)); }
-        if (cy + r < g.gy - 1) { open = true; dmin = fminf(dmin, (g.miny + (float)(cy + r + 1) * g.h) - q.y); }
-        if (cz - r > 0) { open = true; dmin = fminf(dmin, q.z - (g.minz + (float)(cz - r) * g.h)); }
-        if (cz + r < g.gz - 1) { open = true; dmin = fminf(dmin, (g.minz + (float)(cz + r + 1) * g.h) - q.z); }
+        if (cx - r > 0) { open = true; dmin = fminf(dmin, sx - (float)(cx - r) * g.h); }
+        if (cx + r < g.gx - 1) { open = true; dmin = fminf(dmin, (float)(cx + r + 1) * g.h - sx); }
+        if (cy - r > 0) { open = true; dmin = fminf(dmin, sy - (float)(cy - r) * g.h); }
+        if (cy + r < g.gy - 1) { open = true; dmin = fminf(dmin, (float)(cy + r + 1) * g.h - sy); }
+        if (cz - r > 0) { open = true; dmin = fminf(dmin, sz - (float)(cz - r) * g.h); }
+        if (cz + r < g.gz - 1) { open = true; dmin = fminf(dmin, (float)(cz + r + 1) * g.h - sz); }
         if (!open) break;                       // the cube covers the grid
         dmin -= margin;
         if (dmin > 0.f && m2 <= dmin * dmin) break;   // nothing outside the cube can be closer than the third best

@@ -486,11 +486,16 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     // one per lookup; the free-space look-ahead above folds up to 1 + SKIP of them into one trip), the trips of THIS loop (= voxel
     // reads) and the rays cast, summed over the wave (swap / DPP adds of small exact floats, no LDS) and stored as this wave's
     // row: plain stores, no atomics, no zero-fill (an atomic per workgroup on shared counters cost 8 us of the kernel's 115).
-    const float f_reads = (float)(n_log & 0xFFFFu), f_steps = f_reads + (float)(n_log >> 16);
-    const float tot = gps::reduce4(f_steps, f_reads, inside ? 1.0f : 0.0f, 0.0f);   // rows 0..3, lane 15: sums of (steps, rays, reads, 0)
-    if ((lane_ & 15) == 15 && lane_ < 48) {
-        float* row = reinterpret_cast<float*>(ray_stats_rows(s) + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_in_wg));
-        row[lane_ == 15 ? 0 : lane_ == 31 ? 2 : 1] = tot;   // {steps, reads, rays}
+    // Valid for the LAST live or single-free-view launch on the SCENE's scratch (gps_tsdf_ray_stats reads those rows; a launch on
+    // another stream that shares the scratch overwrites them).  The views of a batch are not logged (kernel-argument-uniform branch):
+    // nobody reads their rows.
+    if (views == nullptr) {
+        const float f_reads = (float)(n_log & 0xFFFFu), f_steps = f_reads + (float)(n_log >> 16);
+        const float tot = gps::reduce4(f_steps, f_reads, inside ? 1.0f : 0.0f, 0.0f);   // rows 0..3, lane 15: sums of (steps, rays, reads, 0)
+        if ((lane_ & 15) == 15 && lane_ < 48) {
+            float* row = reinterpret_cast<float*>(ray_stats_rows(s) + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_in_wg));
+            row[lane_ == 15 ? 0 : lane_ == 31 ? 2 : 1] = tot;   // {steps, reads, rays}
+        }
     }
 }
 

@@ -161,10 +161,14 @@ def pin_to_gpu_numa(local_rank, world=1, device_of_rank=None):
     except AttributeError:
         return "affinity: unsupported"
     dev = device_of_rank or (lambda r: r)
-    gpu_nodes = [gpu_numa_node(dev(r)) for r in range(world)]
+    # `world` is the number of ranks on THIS host (LOCAL_WORLD_SIZE); a caller that only knows its local rank (world left at 1) is
+    # planned as the last of local_rank + 1 ranks.  One index, r, everywhere below.
+    world = max(1, int(world), int(local_rank) + 1)
+    r = int(local_rank) % world
+    gpu_nodes = [gpu_numa_node(dev(k)) for k in range(world)]
     plans, how = plan_affinity(world, gpu_nodes, _node_cpus(), allowed, core_of=_core_of())
-    mine = plans[local_rank % max(1, world)]
-    where = "numa node %d" % gpu_nodes[local_rank] if how == "numa" else "no numa info"
+    mine = plans[r]
+    where = "numa node %d" % gpu_nodes[r] if how == "numa" else "no numa info"
     try:
         os.sched_setaffinity(0, mine)
     except OSError as e:

@@ -237,3 +237,23 @@ def test_timed_window_is_whole_keyframe_periods():
     for w in (0, 5, 10, 20, 25, 31, 40):
         first, prologue = bench.timed_window(w)
         assert first % bench.PERIOD == 0 and first >= 30 and first - prologue == w and prologue >= 0
+
+
+def test_pin_to_gpu_numa_with_only_a_local_rank():
+    """pin_to_gpu_numa(local_rank) with the world left at its default (a caller that only knows LOCAL_RANK): planned as the last
+    of local_rank + 1 ranks, no IndexError, a non-empty core set inside what the process may use (round-4 advisor finding)."""
+    from gps_slam_amd.dist_util import pin_to_gpu_numa
+    before = os.sched_getaffinity(0)
+    try:
+        for lr in (0, 3):
+            os.sched_setaffinity(0, before)
+            desc = pin_to_gpu_numa(lr)
+            assert desc.startswith("affinity:") and "cpus" in desc, desc
+            now = os.sched_getaffinity(0)
+            assert now and now <= before
+        os.sched_setaffinity(0, before)
+        desc = pin_to_gpu_numa(1, 2, device_of_rank=lambda r: 0)   # two ranks sharing GPU 0 (the rehearsal's map)
+        assert "cpus" in desc
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(max(1, min(8, len(before))))

@@ -3,7 +3,7 @@
 # the iterations, the update is critical; if it follows the tracker, the frame chain is.
 # run ON the GPU box:  bash tools/probe/critical_path.sh  -> gpurun_out/critical_path.txt
 mkdir -p gpurun_out
-CMD="python bench.py --steps 20 --warmup 5 --windows 3 --no-cpu-baseline --no-oracle-psnr --no-other-configs"
+CMD="python bench.py --steps 20 --warmup 5 --windows 3 --no-cpu-baseline --no-oracle-psnr --no-other-configs --whole-run-frames 0"
 show() { python -c "
 import json,sys
 for l in sys.stdin:

@@ -4,7 +4,7 @@ VAR=$1; VALS=$2
 mkdir -p gpurun_out
 for v in $VALS; do
   for i in 1 2; do
-  env $VAR=$v GPS_BENCH_FRAME_TIMES=1 python bench.py --steps 20 --warmup 5 --windows 5 --schedule ${SCHEDULE:-overlap} --no-cpu-baseline --no-oracle-psnr --no-other-configs 2> gpurun_out/ft_${v}_$i.err | grep '^{' | python -c "
+  env $VAR=$v GPS_BENCH_FRAME_TIMES=1 python bench.py --steps 20 --warmup 5 --windows 5 --schedule ${SCHEDULE:-overlap} --no-cpu-baseline --no-oracle-psnr --no-other-configs --whole-run-frames 0 2> gpurun_out/ft_${v}_$i.err | grep '^{' | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$VAR=$v run $i: value %.1f' % d['value'])"
   done
