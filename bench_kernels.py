@@ -297,13 +297,29 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     ]
     if fus.get("evals_per_frame"):
         ev = fus["evals_per_frame"]
-        rows.append(dict(_kernel_row("track_eval_poll_kernel", ev, fus["poll_eval_s"] + fus["poll_spin_s"],
+        trk_row = _kernel_row("track_eval_poll_kernel", ev, fus["poll_eval_s"] + fus["poll_spin_s"],
                                      36.0 * P * 0.332, hbm_peak_gbs, N, "host <-> device loop",
                                      "avg_us = GPU residency of one pre-launched evaluation = waiting for the host's argument line + "
                                      "evaluating; bytes assume the evaluations spread evenly over the 4 pyramid levels and count ONE evaluation per "
                                      "launch (the pose that rides along, config.tracker, reads as much again when it runs: not counted, the "
-                                     "counters see it)"),
+                                     "counters see it)")
+        # What an evaluation HAS to move, in the 128-byte lines the memory side deals in (profiles/r05_fetch_calibration.md): the
+        # level's depth image (4 P_l) + the lines of the FULL-resolution point | normal map (32 B per pixel; the reference keeps the
+        # scene side at full resolution at every level, ITMExtendedTracker.cpp:294-298) its bilinear footprints touch -- two 64-byte
+        # runs per view pixel, a run starting at byte 96 of a line straddles two: levels 0 and 1 touch every line of the map
+        # (32 P), level 2 every line of every second row pair (16 P), level 3 a quarter of the rows and 5 of 8 lines there (5 P)
+        lv = fus.get("evals_per_level_per_frame") or [0, 0, 0, 0]
+        per_level_bytes = [4.0 * P + 32.0 * P, 4.0 * P / 4 + 32.0 * P, 4.0 * P / 16 + 16.0 * P, 4.0 * P / 64 + 5.0 * P]
+        own = sum(n_ * b_ for n_, b_ in zip(lv, per_level_bytes)) / max(1e-9, sum(lv))
+        trk_row = _with_own_bytes(trk_row, own, fus["poll_eval_s"] + fus["poll_spin_s"], hbm_peak_gbs,
+                                  "per evaluation, averaged over the levels with this run's evaluations per level %s: the level's depth "
+                                  "image + the 128-byte lines of the full-resolution point | normal map its bilinear footprints touch (a "
+                                  "4-byte gather moves a 128-byte line on this device: profiles/r05_fetch_calibration.md).  SURVEY's 36 P_L "
+                                  "counts 36 bytes per VIEW pixel, which is right at the finest level only; the counters' traffic is per "
+                                  "LAUNCH = this evaluation + the pose riding along, each line fetched by ~2 of the 8 XCDs' L2s" % [round(v, 2) for v in lv])
+        rows.append(dict(trk_row,
                          spin_us=fus["poll_spin_s"] * 1e6, eval_us=fus["poll_eval_s"] * 1e6, phases=fus.get("poll_phases"),
+                         evals_per_level_per_frame=lv,
                          gpu_held_idle_us_per_frame=ev * fus["poll_spin_s"] * 1e6,
                          tracking_ms_per_frame=fus["tracking_ms_per_frame"]))
     if fus.get("freeview"):
@@ -435,8 +451,10 @@ def _fusion_timings(seq, gt_pose, device, n_sub=12):
         ph0 = trk.track_poll_phases()
         torch.cuda._sleep(1)   # marker: "tracked"
         t0 = time.perf_counter()
+        per_level = np.zeros(8)
         for k in range(2, len(c2w)):
             trk.ProcessFrameTracked(rgba[k], dmm[k])
+            per_level += np.asarray(trk.track_state.diag[:8], np.float64)   # evaluations the LM loop consumed per pyramid level
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / max(1, len(c2w) - 2)
         prof1 = trk.track_poll_profile()
@@ -449,6 +467,7 @@ def _fusion_timings(seq, gt_pose, device, n_sub=12):
             phases[key] = {"evaluations_per_frame": dd[0] / max(1, len(c2w) - 2), "own_pixel_loop_us": dd[1] * 0.01 / cnt,
                            "until_all_rows_us": dd[2] * 0.01 / cnt, "sum_and_mailbox_us": dd[3] * 0.01 / cnt}
         out["poll_phases"] = phases
+        out["evals_per_level_per_frame"] = [float(v) / max(1, len(c2w) - 2) for v in per_level[:4]]
         evals = max(1, d[2])
         out.update(tracked_ms_per_frame=dt * 1e3, tracking_ms_per_frame=max(0.0, dt - t_frame) * 1e3,
                    evals_per_frame=d[2] / max(1, len(c2w) - 2), poll_spin_s=d[0] * 1e-8 / (evals + d[3]),

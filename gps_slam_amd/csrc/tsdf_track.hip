@@ -211,6 +211,12 @@ constexpr int EV_ROW_GROUPS = EV_THREADS / 32;
 #endif
 GPS_TUNABLE_REPORT(GPS_TRACK_EV_GROUPS, 4);
 constexpr int EV_GROUPS = GPS_TRACK_EV_GROUPS;
+// pixels of a thread whose memory round trips are taken together (eval_fused): 5 = a whole finest-level share per batch -- own pixel
+// loop 6.1 vs 6.3 us there, but 5.7 vs 3.5 us at the coarse levels (one pixel per thread, four empty slots of unrolled code)
+#ifndef GPS_TRACK_EV_BATCH
+#define GPS_TRACK_EV_BATCH 1
+#endif
+GPS_TUNABLE_REPORT(GPS_TRACK_EV_BATCH, 1);
 constexpr int MAILBOX_GROUP_WORDS = 64;   // a group's block of the host mailbox (words 0..31: its result row)
 
 // The frame's valid-pixel count lives behind the 16-word block, spread over VC_SLOTS words per frame parity: the prepare
@@ -474,9 +480,6 @@ __device__ __forceinline__ void eval_fused(EvLds& lds, const GhArgs& a, const Ma
     // order.  The finest level of a 640x480 frame is 4.7 pixels per thread: one batch, two round trips -- the pixel-at-a-time
     // loop took two per pixel (10 us of the evaluation's 18).  One wave per SIMD runs here (256 workgroups of 4 waves on 256
     // compute units), so the ~200 registers of a batch cost no occupancy.
-#ifndef GPS_TRACK_EV_BATCH
-#define GPS_TRACK_EV_BATCH 1
-#endif
     constexpr int B = K == 1 ? GPS_TRACK_EV_BATCH : K == 2 ? 3 : 2;
     const int stride = n_rows * blockDim.x;
     for (int i0 = bid * blockDim.x + threadIdx.x; i0 < n; i0 += B * stride) {
@@ -611,6 +614,11 @@ struct PollArgs {
                                // BAR (gps_track_state.dev_arg_line) and every workgroup polls them here: no PCIe read, no relay
     volatile uint32_t* host_rows;  // != NULL: the row tables live in the pinned host mailbox and the HOST adds the rows (eval_fused)
 };
+// Round 5, measured and dropped: WARMING UP WHILE THE LAUNCH WAITS FOR ITS LINE.  The host knows, when it enqueues launch n + 1, the
+// level and pose of evaluation n; while the workgroups waited (~3 us) every thread fetched its first pixel's depth at that level and
+// waves 1..3 gathered the first pixels' footprints under that pose and dropped them.  Own pixel loop 7.3 -> 6.2 us (finest level),
+// 4.0 -> 3.6 us (coarser levels) -- and nothing end to end (tracked frame 0.454 vs 0.457 ms, sequential 1,038 vs 1,032 frames/s in
+// a 3 + 3 A/B): the loop is not two bare memory latencies, and the host's share of an iteration (rows, solve, line) hides the rest.
 constexpr uint32_t ARG_RUN = 1, ARG_SKIP = 2;
 constexpr long long ARG_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
 
