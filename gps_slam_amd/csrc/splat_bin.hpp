@@ -61,6 +61,7 @@ struct SbTables {
 };
 // splat_raster_bwd.hip: gps_set_frame_chain_reserve(on) -- the host runs tracking / fusion on another stream beside the map update
 bool map_runs_beside_frame_chain();
+int frame_chain_reserve_bits();   // the value last given to gps_set_frame_chain_reserve (bit 1: experiment, see splat_raster_bwd.hip)
 // splat_bin_sb.hip: can the superblock binning take N Gaussians on a tile_width x tile_height grid on THIS device (tile count,
 // packed box fields, superblock count, the scatter kernel's dynamic LDS incl. its > 64 KB opt-in)?  False -> sorted-key binning.
 bool sb_supported(int N, int tile_width, int tile_height);

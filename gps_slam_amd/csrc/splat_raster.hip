@@ -577,7 +577,10 @@ int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_dept
         GPS_REQUIRE(fc.base_color && fc.gt_rgb && fc.rgb && fc.loss && fc.v_render_colors && fc.v_render_alphas);
     }
     const int tw = gps_div_up(width, 16), th = gps_div_up(height, 16);
-    raster_ges_fwd_pk_kernel<<<tw * th, FWD_THREADS, 0, (hipStream_t)stream>>>(
+    // (experiment, gps_set_frame_chain_reserve bit 1: 14 KB of unused dynamic LDS on top of the 26.7 KB the kernel declares -> 3
+    // workgroups of 8 waves per compute unit instead of the 4 that fill every wave slot)
+    const size_t pad = (gps::frame_chain_reserve_bits() & 2) ? 14 * 1024 : 0;
+    raster_ges_fwd_pk_kernel<<<tw * th, FWD_THREADS, pad, (hipStream_t)stream>>>(
         (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
         (float4*)render_colors, render_alphas, fc, tile_order);
     GPS_LAUNCH_CHECK();

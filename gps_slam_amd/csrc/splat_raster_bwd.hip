@@ -39,9 +39,11 @@
 // Measured (tools/probe/ab_envval.sh, 3 + 3 runs): overlap schedule 1,290 -> 1,315 frames/s; the strip kernel alone is slower
 // with 5 waves (sequential schedule 963 -> 951), so the pipeline switches the reserve on only while tracking and mapping overlap.
 // The forward rasterizer (a retiring workgroup frees 2 x 64), the batched free-view raycaster and colour kernels: no gain, left alone.
+// (bit 0: the strip kernel's reserve + the forward's row-major launch order; bit 1, an experiment switch: the forward rasterizer
+// held to 3 workgroups per compute unit -- splat_raster.hip)
 static int g_frame_chain_reserve = 0;
 static inline int frame_chain_reserve_lds() {
-    return __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED) ? 28 * 1024 : 0;
+    return (__atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED) & 1) ? 28 * 1024 : 0;
 }
 
 
@@ -335,13 +337,14 @@ int raster_ges_bwd_strips_launch(int N, const float* records, const int32_t* rad
 }
 
 // (splat_step.hip: the forward's launch order by list length only pays when the map kernels have the chip to themselves)
-bool map_runs_beside_frame_chain() { return __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED) != 0; }
+bool map_runs_beside_frame_chain() { return (__atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED) & 1) != 0; }
+int frame_chain_reserve_bits() { return __atomic_load_n(&g_frame_chain_reserve, __ATOMIC_RELAXED); }
 
 }  // namespace gps
 
 extern "C" {
 
-void gps_set_frame_chain_reserve(int on) { __atomic_store_n(&g_frame_chain_reserve, on ? 1 : 0, __ATOMIC_RELAXED); }
+void gps_set_frame_chain_reserve(int on) { __atomic_store_n(&g_frame_chain_reserve, on < 0 ? 0 : on, __ATOMIC_RELAXED); }
 
 
 int gps_raster_ges_bwd_strips(int N, const float* records, const int32_t* radii, const int32_t* cls_ids,

@@ -614,7 +614,7 @@ void SLAMPipeline::processFrameImpl(int i, Camera& cam, const torch::Tensor& rgb
 void SLAMPipeline::processFrame(int i, Camera& cam, const torch::Tensor& rgb_u8, const torch::Tensor& depth_mm_i16) {
     // room for the tracker's evaluations beside the strip backward only while the two chains really run side by side (the strip
     // kernel alone is faster without the reserve: include/gps_slam_hip.h)
-    gps_set_frame_chain_reserve(overlap_mapping ? 1 : 0);
+    gps_set_frame_chain_reserve(overlap_mapping ? frame_chain_reserve : 0);
     if (!overlap_mapping) { processFrameImpl(i, cam, rgb_u8, depth_mm_i16); return; }
     // overlap: frames run on a HIGH-priority stream of their own, so that the short, latency-bound tracker kernels are
     // dispatched ahead of the map stream's long rasterizer kernels; ordered after the caller's stream (inputs), and the

@@ -175,6 +175,9 @@ public:
     // an optimise iteration's backward + Adam kernel also runs the NEXT iteration's preprocessing forward (the next camera is drawn
     // one iteration early: same draws, same order): one launch and one pass over the parameters less per iteration, same results
     bool prefetch_next_preprocess = true;
+    // what gps_set_frame_chain_reserve gets while the schedules overlap (1: the strip backward leaves register room for a tracker wave
+    // and the forward launches row-major; 0: off; other bits: experiment switches of the kernel library)
+    int frame_chain_reserve = 1;
     // with overlap_mapping: run the map update on a worker thread of its own (tracking thread + mapping thread) instead of
     // interleaving its host work with the frames on the caller's thread
     bool mapping_thread = false;

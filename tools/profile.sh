@@ -14,7 +14,7 @@ WARMUP=${WARMUP:-5}
 WINDOWS=${WINDOWS:-5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-CMD="python bench.py --steps $STEPS --warmup $WARMUP --windows $WINDOWS --no-cpu-baseline --no-oracle-psnr"
+CMD="python bench.py --steps $STEPS --warmup $WARMUP --windows $WINDOWS --no-cpu-baseline --no-oracle-psnr --no-other-configs --whole-run-frames 0"
 rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o bench -- $CMD > gpurun_out/bench_prof.log 2>&1
 {
   echo "# $TAG -- rocprofv3 --kernel-trace --stats summary (MI355X, gfx950)"
