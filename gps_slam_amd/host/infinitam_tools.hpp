@@ -107,6 +107,7 @@ public:
     // enqueued on the frame's own stream right before its kernels.
     bool prefetch = true;
     int64_t uploadedBytes = 0;
+    bool ownsInputs = false;   // Shutdown() deletes the images and the engine (set by createTsdfEngine, which allocated them)
 
 private:
     void upload(int frame);  // pinned host images of `frame` -> staging slot frame % 3, on the copy stream

@@ -14,7 +14,11 @@ using namespace gpsh;
 
 namespace {
 inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
-struct MapStream { c10::hip::HIPStream s; };
+struct MapStream {
+    c10::hip::HIPStream s;
+    // a stream this pipeline created itself (make_stream kinds 2..4) is destroyed with it; torch's pool streams are not ours
+    void release(bool owned) { if (owned) { (void)hipStreamSynchronize(s.stream()); (void)hipStreamDestroy(s.stream()); } }
+};
 // kind 0 / 1: torch's high- / normal-priority pool; 2 / 3 / 4: a stream of this pipeline's own (hipStreamCreateWithPriority,
 // non-blocking) at the lowest / highest / default priority, wrapped for the stream guards
 c10::hip::HIPStream make_stream(int kind) {
@@ -832,8 +836,19 @@ SLAMPipeline::~SLAMPipeline() {
         (void)hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream());
         (void)hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream());
         for (void* e : {ev_frame_, ev_raycasts_, ev_map_, ev_caller_}) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        static_cast<MapStream*>(map_stream_)->release(map_stream_kind >= 2);
+        static_cast<MapStream*>(frame_stream_)->release(frame_stream_kind >= 2);
         delete static_cast<MapStream*>(map_stream_);
         delete static_cast<MapStream*>(frame_stream_);
+    }
+    // the free views' stream and its events (round 5: they used to outlive the pipeline -- one stream of the lowest-priority pool and
+    // a dozen events leaked per scene of a process that builds many)
+    if (rc_stream_) {
+        (void)hipStreamSynchronize(static_cast<MapStream*>(rc_stream_)->s.stream());
+        for (void* e : rc_events_) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        if (ev_rc_begin_) (void)hipEventDestroy((hipEvent_t)ev_rc_begin_);
+        static_cast<MapStream*>(rc_stream_)->release(raycast_stream_kind >= 2);
+        delete static_cast<MapStream*>(rc_stream_);
     }
 }
 

@@ -171,7 +171,14 @@ public:
     bool async_raycasts = true;   // the update's free-view raycasts run beside its optimise iterations (same results)
     // which stream each chain gets (slam_pipeline.cpp: make_stream): 0 / 1 = torch's high- / normal-priority pool, 2 / 3 / 4 = a
     // stream of the pipeline's own at the lowest / highest / default priority
-    int frame_stream_kind = 0, map_stream_kind = 1, raycast_stream_kind = 2;
+    // Round 5: ALL THREE are streams of the pipeline's own now, created at the first frame and destroyed with the pipeline.  torch hands
+    // its pool streams out round-robin and never destroys them, ROCm spreads the streams of one priority level over <= 4 hardware
+    // queues by reference count -- so which chains ended up sharing a queue depended on how many scenes the PROCESS had built
+    // before: the same 1,000-frame run gave 1,120 frames/s in a fresh process and 900 after six other scenes, a test process's
+    // tenth scene ran its frames and its map update on ONE queue (540 instead of 850 frames/s, every period's fifth frame 6 ms
+    // late); with own streams every measurement is history-free (bench.py: cfg1 1,070 -> 1,640 and cfgR 710 -> 820 frames/s when
+    // they run after the whole-sequence leg).
+    int frame_stream_kind = 3, map_stream_kind = 4, raycast_stream_kind = 2;
     // an optimise iteration's backward + Adam kernel also runs the NEXT iteration's preprocessing forward (the next camera is drawn
     // one iteration early: same draws, same order): one launch and one pass over the parameters less per iteration, same results
     bool prefetch_next_preprocess = true;
