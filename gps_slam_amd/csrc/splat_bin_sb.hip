@@ -310,6 +310,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
 
 namespace gps {
 
+// Round 5, measured and dropped: WINDOWED per-tile tables (a window of R tile rows of the superblock's band in LDS, one pass over the
+// superblock's pairs per window; bit-equal).  At Replica's 75 x 43 tiles the whole-grid tables are 79 KB (one workgroup per compute
+// unit) -- but a superblock's band is most of the image in the SLAM loop (radii up to 100 px, Gaussians of several keyframes'
+// views): R = 8 / 16 / 24 rows: 143 / 84 / 65 us per launch against 62 for the whole grid (640x480: 44 us at R = 8 against 22).
 // Dynamic LDS of sb_scatter_kernel: per-tile histogram + per-wave cursors (n_tiles words + (SCAT_WAVES + 1) n_tiles halves) + two
 // words per Gaussian of a superblock.  It grows with the tile count (79 KB at 1200x680, up to 160 KB): above the default 64 KB a
 // workgroup needs the opt-in attribute, which a device with less LDS per workgroup refuses.
