@@ -122,6 +122,7 @@ PROTOTYPES = {
     "gps_tsdf_allocate": (i32, [C.POINTER(TsdfState), vp, vp, vp]),
     "gps_tsdf_integrate": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_expected_depths": (i32, [C.POINTER(TsdfState), vp, i32, vp]),
+    "gps_tsdf_expected_depths_partial": (i32, [C.POINTER(TsdfState), vp, i32, vp]),
     "gps_tsdf_raycast": (i32, [C.POINTER(TsdfState), vp, i32, i32, vp]),
     "gps_tsdf_expected_depths_and_raycast": (i32, [C.POINTER(TsdfState), vp, vp, i32, i32, vp]),
     "gps_tsdf_icp_maps": (i32, [C.POINTER(TsdfState), vp, vp]),

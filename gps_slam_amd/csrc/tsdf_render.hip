@@ -766,6 +766,11 @@ int gps_tsdf_expected_depths(const gps_tsdf_state* sp, const float* M, int free_
     return expected_depths_impl(sp, M, free_view, true, stream);
 }
 
+int gps_tsdf_expected_depths_partial(const gps_tsdf_state* sp, const float* M, int free_view, gps_stream stream) {
+    GPS_ENTER();
+    return expected_depths_impl(sp, M, free_view, false, stream);
+}
+
 int64_t gps_tsdf_scratch_bytes(int width, int height, int n_buckets, int n_excess) {
     if (width <= 0 || height <= 0 || n_buckets <= 0 || n_excess <= 0) return GPS_ERR_ARG;
     const int64_t n_total = (int64_t)n_buckets + n_excess;

@@ -599,6 +599,10 @@ GPS_API int gps_tsdf_integrate(const gps_tsdf_state *s, const float *M, gps_stre
 /* ITMVisualisationEngine::CreateExpectedDepths (Visualisation/CUDA/…_CUDA.tcu:137-184); free_view selects the
  * render state (0 = live, 1 = free view). */
 GPS_API int gps_tsdf_expected_depths(const gps_tsdf_state *s, const float *M, int free_view, gps_stream stream);
+/* Pass A of the above alone (the per-workgroup partial min/max images; the rendering-block count stays in its scratch counter): what
+ * gps_tsdf_expected_depths_and_raycast launches in front of its raycaster, which does pass B.  A measurement hook -- a caller that
+ * wants the min/max image calls gps_tsdf_expected_depths or gps_tsdf_expected_depths_and_raycast NEXT on the same render state. */
+GPS_API int gps_tsdf_expected_depths_partial(const gps_tsdf_state *s, const float *M, int free_view, gps_stream stream);
 
 /* GenericRaycast / castRay (…_CUDA.tcu:186-225, Shared:122-221).  update_visible = 1 reproduces
  * CreateICPMaps' modifyVisibleEntries = true (only meaningful for the live state). */
