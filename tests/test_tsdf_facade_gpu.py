@@ -33,6 +33,47 @@ def _reader(h, seq, n):
     return r, cams
 
 
+def _reader_bytes(h, seq, n):
+    """the same sequence handed over as the dataset's files hold it: uint8 colour, uint16 millimetres (bench.Scene's route)"""
+    W, H = seq["rgb"].shape[2], seq["rgb"].shape[1]
+    r = h.DatasetReader(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"])
+    for i in range(n):
+        c = h.Camera(W, H, seq["fx"], seq["fy"], seq["cx"], seq["cy"], True, torch.as_tensor(seq["c2w"][i].astype(np.float32)))
+        c.id = i
+        c.image = torch.as_tensor(seq["rgb"][i])
+        c.depth = torch.as_tensor(seq["depth"][i].view(np.int16))
+        r.addTrainCamera(c)
+    return r
+
+
+def test_create_tsdf_engine_takes_the_files_bytes_and_gives_the_same_frames():
+    """createTsdfEngine with uint8 / int16 inputs == with the reader's float tensors (the reference's k / 255.f * 255 truncation and
+    mm / 1000.f * 1000 rounding applied to every byte / short value), frame for frame: same uploaded bytes, same volume, same raycast."""
+    h = _host()
+    W, H, n = 160, 120, 5
+    seq = synth.make_sequence(W, H, n, step_deg=0.5)
+    # every byte value and a spread of depth values occur in frame 0
+    seq["rgb"][0].reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    seq["depth"][0].reshape(-1)[:4096] = np.linspace(1, 65535, 4096).astype(np.uint16)
+    cfg = dict(voxel_size=0.01, trunc_dist=0.04, viewFrustum_min=0.2, viewFrustum_max=10.0, use_gt_pose=1)
+    outs = []
+    for make in (lambda: _reader(h, seq, n)[0], lambda: _reader_bytes(h, seq, n)):
+        cli = h.createTsdfEngine(make(), cfg)
+        eng = cli.getMainEngine()
+        for i in range(n):
+            assert cli.ProcessFrame()
+        torch.cuda.synchronize()
+        outs.append((eng.counters().cpu()[:3].clone(), eng.GetLiveVertex().clone(), cli.uploadedBytes))
+        if len(outs) == 1:
+            rgba0, mm0 = _converted(seq, 0)
+        cli.Shutdown()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    # the table createTsdfEngine applies to a byte == the float round trip of _converted
+    lut = (torch.arange(256, dtype=torch.float32) / 255.0 * 255.0).to(torch.uint8)
+    assert torch.equal(lut[torch.as_tensor(seq["rgb"][0]).long()].to(DEV), rgba0[..., :3])
+    assert torch.equal(torch.as_tensor(seq["depth"][0].view(np.int16)).to(DEV), mm0)
+
+
 def _converted(seq, i):
     """what createTsdfEngine turns camera i into (cv_utils.cpp:57-101): truncating *255, rounding *1000"""
     img = torch.as_tensor(seq["rgb"][i].astype(np.float32) / 255.0)
