@@ -124,7 +124,7 @@ def seed_gaussians(seq, n_gauss, seed, device):
 
 
 ENV_SWITCHES = ("GPS_BENCH_PINNED_LINE", "GPS_BENCH_RIDING_ALONG", "GPS_BENCH_DEVICE_SUMMER", "GPS_BENCH_OPT_ITERS", "GPS_BENCH_PREFETCH", "GPS_BENCH_ASYNC_RAYCASTS",
-                "GPS_BENCH_STREAMS", "GPS_BENCH_MERGE", "GPS_BENCH_RESERVE", "GPS_BENCH_FRAME_TIMES", "GPS_BENCH_PIPE_TIMES", "GPS_BENCH_SHARE_GPU")
+                "GPS_BENCH_STREAMS", "GPS_BENCH_MERGE", "GPS_BENCH_RESERVE", "GPS_BENCH_PIPELINE_RAYCASTS", "GPS_BENCH_FRAME_TIMES", "GPS_BENCH_PIPE_TIMES", "GPS_BENCH_SHARE_GPU")
 
 
 def env_overrides():
@@ -185,6 +185,8 @@ class Scene:
         if os.environ.get("GPS_BENCH_STREAMS"):  # A/B aid: stream kinds "frame,map,raycast" (SLAMPipeline::frame_stream_kind ...; default 3,4,2 = own streams at the highest / default / lowest priority; 0 / 1 = torch's high- / normal-priority pool)
             f_, m_, r_ = (int(x) for x in os.environ["GPS_BENCH_STREAMS"].split(","))
             self.pipe.frame_stream_kind, self.pipe.map_stream_kind, self.pipe.raycast_stream_kind = f_, m_, r_
+        if os.environ.get("GPS_BENCH_PIPELINE_RAYCASTS"):  # A/B aid: an update's free views enqueued by the frame thread at the keyframe (1, default) or by the map worker at the start of its job (0)
+            self.pipe.pipeline_raycasts = os.environ["GPS_BENCH_PIPELINE_RAYCASTS"] != "0"
         if os.environ.get("GPS_BENCH_RESERVE"):  # A/B aid: what gps_set_frame_chain_reserve gets in the overlap schedule (default 1; 0 = off; 3 = + forward rasterizer at 3 workgroups per unit)
             self.pipe.frame_chain_reserve = int(os.environ["GPS_BENCH_RESERVE"])
         if os.environ.get("GPS_BENCH_MERGE"):  # A/B aid: window and keyframe views raycast as one batch (default 0)

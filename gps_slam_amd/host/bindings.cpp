@@ -292,6 +292,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("raycast_stream_kind", &SLAMPipeline::raycast_stream_kind)
         .def_readwrite("prefetch_next_preprocess", &SLAMPipeline::prefetch_next_preprocess)
         .def_readwrite("frame_chain_reserve", &SLAMPipeline::frame_chain_reserve)
+        .def_readwrite("pipeline_raycasts", &SLAMPipeline::pipeline_raycasts)
         .def_readwrite("merge_keyframe_raycasts", &SLAMPipeline::merge_keyframe_raycasts)
         .def_readwrite("pump_iters_first", &SLAMPipeline::pump_iters_first)
         .def_readwrite("pump_iters_per_frame", &SLAMPipeline::pump_iters_per_frame)

@@ -44,13 +44,13 @@ torch::Tensor computeNormalMap(const torch::Tensor& vertex_map_in) {
 }
 
 SLAMPipeline::SLAMPipeline(TsdfEngine* tsdf_engine, SLAMGaussianModel* model_, uint64_t seed, bool use_gt_pose)
-    : main_engine(tsdf_engine), model(model_), rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {
+    : main_engine(tsdf_engine), model(model_), rng_kf_(seed ^ 0x9E3779B97F4A7C15ull), rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {
     if (use_gt_pose) main_engine->turnOffTracking();
     device = model->device;
     voxel_size = main_engine->getVoxelSize();
 }
 
-SLAMPipeline::SLAMPipeline(uint64_t seed) : rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {}
+SLAMPipeline::SLAMPipeline(uint64_t seed) : rng_kf_(seed ^ 0x9E3779B97F4A7C15ull), rng_(seed), gen_(at::detail::createCPUGenerator(seed)) {}
 
 void SLAMPipeline::setTsdfEngine(InfiniTAM::Engine::CLIEngine* engine) {
     tsdf_engine = engine;
@@ -207,7 +207,38 @@ void SLAMPipeline::waitRaycast(void* ev) {
 }
 
 void SLAMPipeline::waitAllRaycasts() {
+    if (last_raycast_event_) { waitRaycast(last_raycast_event_); return; }   // (an adopted job's views: its last batch)
     if (rc_event_next_ > 0) waitRaycast(rc_events_[rc_event_next_ - 1]);  // one stream: the last event covers all
+}
+
+// localFrameRaycast + keyFrameRaycast of the keyframe just fused, by the frame thread, into a job the map worker adopts later
+// (pipeline_raycasts): the same two batches, the same draws, the same tensors as raycastWindow + raycastKeyframes.
+void SLAMPipeline::buildUpdateViews(MapJob& out) {
+    const std::vector<ORUtils::SE3Pose>& poses = main_engine->camPoses;
+    void** evs = job_events_[job_parity_];
+    job_parity_ ^= 1;
+    std::vector<const Camera*> cams;
+    for (const Camera& cam : localframe_cam_window) cams.push_back(&cam);
+    void* ev = nullptr;
+    for (TensorDict& m : raycastCams(cams, poses, &ev, evs[0])) { out.window_raycasts.push_back(m); out.window_events.push_back(evs[0]); }
+    out.opt_cams.assign(localframe_cam_window.begin(), localframe_cam_window.end());
+    out.window_len = localframe_cam_window.size();
+    out.opt_raycasts.assign(out.window_raycasts.begin(), out.window_raycasts.end());
+    out.opt_events = out.window_events;
+    out.last_event = cams.empty() ? nullptr : evs[0];
+    const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframe_cam_list.size()) : 0;   // :538
+    if (n > 0) {
+        RandomSelector<Camera> sel(keyframe_cam_list, rng_kf_);
+        std::vector<const Camera*> kcams;
+        for (int k = 0; k < n; k++) {
+            const Camera* cam = sel.getNext().second;
+            out.opt_cams.push_back(*cam);
+            kcams.push_back(cam);
+        }
+        for (TensorDict& m : raycastCams(kcams, poses, &ev, evs[1])) { out.opt_raycasts.push_back(m); out.opt_events.push_back(evs[1]); }
+        out.last_event = evs[1];
+    }
+    out.views_ready = true;
 }
 
 // ------------------------------------------------------------------ frame bookkeeping (updateFrameList :319-360)
@@ -249,7 +280,7 @@ void SLAMPipeline::initNewGaussians(TensorDict& rm) { initNewGaussiansFor(rm, cu
 // runRaycastByCam for several cameras of ONE volume state: one batched free-view chain (TsdfEngine::runRaycastBatch) instead
 // of one chain per camera, then each view's tensor glue.  Same tensors as raycastCam per camera; one event covers them all.
 std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera*>& cams,
-                                                  const std::vector<ORUtils::SE3Pose>& poses, void** ev_out) {
+                                                  const std::vector<ORUtils::SE3Pose>& poses, void** ev_out, void* use_event) {
     std::vector<TensorDict> out;
     if (cams.empty()) return out;
     TsdfEngine* eng = main_engine;
@@ -269,7 +300,7 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
         }
         raycast_pool_warm_ = true;
     }
-    if (ev_out && !rc_stream_) beginAsyncRaycasts();  // (keyFrameRaycast() without a preceding localFrameRaycast())
+    if (ev_out && !rc_stream_ && !use_event) beginAsyncRaycasts();  // (keyFrameRaycast() without a preceding localFrameRaycast())
     std::vector<ORUtils::SE3Pose> view_poses(cams.size());
     std::vector<ITMLib::ITMIntrinsics> view_intr(cams.size());
     std::vector<torch::Tensor> w2c(cams.size());
@@ -309,12 +340,16 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
         eng->runRaycastBatch(std::vector<ORUtils::SE3Pose>(view_poses.begin() + base, view_poses.begin() + base + cnt), nullptr, &maps, &intr);
     }
     if (ev_out) {
-        if (rc_event_next_ == rc_events_.size()) {
-            hipEvent_t ev;
-            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
-            rc_events_.push_back(ev);
+        if (use_event) {
+            *ev_out = use_event;
+        } else {
+            if (rc_event_next_ == rc_events_.size()) {
+                hipEvent_t ev;
+                hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+                rc_events_.push_back(ev);
+            }
+            *ev_out = rc_events_[rc_event_next_++];
         }
-        *ev_out = rc_events_[rc_event_next_++];
         hip_ok(hipEventRecord((hipEvent_t)*ev_out, c10::hip::getCurrentHIPStream().stream()), "hipEventRecord");
     }
     stats.raycasts += (int64_t)cams.size();
@@ -341,7 +376,7 @@ void SLAMPipeline::raycastKeyframes(const std::deque<Camera>& window, const std:
     opt_raycast_events_ = window_raycast_events_;
     const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframes.size()) : 0;   // :538
     if (n == 0) return;
-    RandomSelector<Camera> sel(keyframes, rng_);
+    RandomSelector<Camera> sel(keyframes, rng_kf_);
     std::vector<const Camera*> cams;
     for (int k = 0; k < n; k++) {
         const Camera* cam = sel.getNext().second;
@@ -366,7 +401,7 @@ void SLAMPipeline::raycastWindowAndKeyframes(const std::deque<Camera>& window, c
     opt_cam_list.assign(window.begin(), window.end());
     opt_window_len_ = window.size(); opt_frame_id_ = update_frame_id_;   // (what checkKeyFrameError indexes / stamps with)
     const int n = sample_method == "random" ? std::min<int>(keyframe_select_max, (int)keyframes.size()) : 0;   // :538
-    RandomSelector<Camera> sel(keyframes, rng_);
+    RandomSelector<Camera> sel(keyframes, rng_kf_);
     for (int k = 0; k < n; k++) {
         const Camera* cam = sel.getNext().second;
         opt_cam_list.push_back(*cam);
@@ -640,7 +675,7 @@ void SLAMPipeline::ensureStreams() {
     if (map_stream_) return;
     map_stream_ = new MapStream{make_stream(map_stream_kind)};
     frame_stream_ = new MapStream{make_stream(frame_stream_kind)};
-    for (void** e : {&ev_frame_, &ev_raycasts_, &ev_map_, &ev_caller_}) {
+    for (void** e : {&ev_frame_, &ev_raycasts_, &ev_map_, &ev_caller_, &job_events_[0][0], &job_events_[0][1], &job_events_[1][0], &job_events_[1][1]}) {
         hipEvent_t ev;
         hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
         *e = ev;
@@ -711,6 +746,43 @@ void SLAMPipeline::keyframeStepOverlapped() {
 void SLAMPipeline::keyframeStepThreaded() {
     ensureStreams();
     const hipStream_t frames = c10::hip::getCurrentHIPStream().stream();
+    if (pipeline_raycasts && async_raycasts) {
+        // (1) this keyframe's free views, now: the raycast stream starts behind frame i's fusion; the result tensors are allocated
+        // with the CONSUMER's stream current (the caching allocator ties a block to the stream it was allocated under)
+        if (!rc_stream_) {
+            rc_stream_ = new MapStream{make_stream(raycast_stream_kind)};
+            hipEvent_t ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            ev_rc_begin_ = ev;
+        }
+        hip_ok(hipEventRecord((hipEvent_t)ev_frame_, frames), "hipEventRecord");
+        const hipStream_t rcs = static_cast<MapStream*>(rc_stream_)->s.stream();
+        hip_ok(hipStreamWaitEvent(rcs, (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");
+        MapJob next;
+        next.curr_cam = curr_cam;
+        next.frame_id = curr_frame_id;
+        {
+            c10::hip::HIPStreamGuard as_consumer(static_cast<MapStream*>(map_stream_)->s);
+            buildUpdateViews(next);
+        }
+        hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, rcs), "hipEventRecord");
+        // (2) the next frame's fusion must not modify the volume before these raycasts have read it: a stream-side wait, no host wait
+        main_engine->beforeNextFusion = [this] {
+            hip_ok(hipStreamWaitEvent(c10::hip::getCurrentHIPStream().stream(), (hipEvent_t)ev_raycasts_, 0), "hipStreamWaitEvent");
+        };
+        // (3) hand the job over once the worker has finished the previous update
+        std::unique_lock<std::mutex> lk(mu_);
+        if (!worker_.joinable()) worker_ = std::thread([this, dev = (int)c10::hip::current_device()] { mapWorker(dev); });
+        const double tw0 = now_ms();
+        cv_.wait(lk, [&] { return done_seq_ == job_seq_ || worker_error_; });
+        g_handover_wait_ms = now_ms() - tw0;
+        if (worker_error_) { lk.unlock(); rethrowWorkerError(); }
+        job_ = std::move(next);
+        job_seq_++;
+        g_job_post_ms = now_ms();
+        cv_.notify_all();
+        return;
+    }
     std::unique_lock<std::mutex> lk(mu_);
     if (!worker_.joinable()) worker_ = std::thread([this, dev = (int)c10::hip::current_device()] { mapWorker(dev); });
     const double tw0 = now_ms();
@@ -760,12 +832,24 @@ void SLAMPipeline::mapWorker(int device_index) {
             // job_ is stable until done_seq_ catches up (the frame thread waits for that before it writes the next one)
             hip_ok(hipStreamWaitEvent(ms.stream(), (hipEvent_t)ev_frame_, 0), "hipStreamWaitEvent");  // raycasts see frame i's volume
             update_frame_id_ = job_.frame_id;
-            if (merge_keyframe_raycasts) raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
-            else { raycastWindow(job_.window, job_.poses); raycastKeyframes(job_.window, job_.keyframes, job_.poses); }
-            // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)
-            hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, async_raycasts && rc_stream_ ? static_cast<MapStream*>(rc_stream_)->s.stream()
-                                                                                         : ms.stream()), "hipEventRecord");
-            { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
+            if (job_.views_ready) {   // the frame thread has enqueued this update's views (and the gate event) already: adopt them
+                localframe_raycast_window = std::move(job_.window_raycasts);
+                window_raycast_events_ = std::move(job_.window_events);
+                opt_cam_list = std::move(job_.opt_cams);
+                opt_raycast_list = std::move(job_.opt_raycasts);
+                opt_raycast_events_ = std::move(job_.opt_events);
+                opt_window_len_ = job_.window_len; opt_frame_id_ = update_frame_id_;
+                last_raycast_event_ = job_.last_event;
+                { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
+            } else {
+                last_raycast_event_ = nullptr;
+                if (merge_keyframe_raycasts) raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
+                else { raycastWindow(job_.window, job_.poses); raycastKeyframes(job_.window, job_.keyframes, job_.poses); }
+                // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)
+                hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, async_raycasts && rc_stream_ ? static_cast<MapStream*>(rc_stream_)->s.stream()
+                                                                                             : ms.stream()), "hipEventRecord");
+                { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
+            }
             cv_.notify_all();
             if (frame_report_ms >= 0.0 && now_ms() - g_job_post_ms > 1.0)
                 fprintf(stderr, "[pipe] update %lld: raycasts enqueued %.3f ms after the hand-over (woke after %.3f)\n", (long long)seen,
@@ -835,7 +919,7 @@ SLAMPipeline::~SLAMPipeline() {
     if (map_stream_) {
         (void)hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream());
         (void)hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream());
-        for (void* e : {ev_frame_, ev_raycasts_, ev_map_, ev_caller_}) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        for (void* e : {ev_frame_, ev_raycasts_, ev_map_, ev_caller_, job_events_[0][0], job_events_[0][1], job_events_[1][0], job_events_[1][1]}) if (e) (void)hipEventDestroy((hipEvent_t)e);
         static_cast<MapStream*>(map_stream_)->release(map_stream_kind >= 2);
         static_cast<MapStream*>(frame_stream_)->release(frame_stream_kind >= 2);
         delete static_cast<MapStream*>(map_stream_);

@@ -185,6 +185,11 @@ public:
     // what gps_set_frame_chain_reserve gets while the schedules overlap (1: the strip backward leaves register room for a tracker wave
     // and the forward launches row-major; 0: off; other bits: experiment switches of the kernel library)
     int frame_chain_reserve = 1;
+    // with mapping_thread + async_raycasts: the free views of update k + 1 are enqueued by the FRAME thread the moment keyframe k + 1 is
+    // fused, whether or not the worker has finished update k (they read the volume, not the model; their results go into the job the
+    // worker adopts when it gets there).  Before, the worker raycast at the start of its job: 0.6-0.8 ms at the head of a chain that
+    // carries the period once the update is longer than its ten frames, and the next frame's fusion waited for the worker to get that far.
+    bool pipeline_raycasts = true;
     // with overlap_mapping: run the map update on a worker thread of its own (tracking thread + mapping thread) instead of
     // interleaving its host work with the frames on the caller's thread
     bool mapping_thread = false;
@@ -203,8 +208,9 @@ private:
     // `ev_out` != nullptr: run on the raycast stream and hand back the event that marks the result complete
     TensorDict raycastCam(const Camera& cam, const std::vector<ORUtils::SE3Pose>& poses, void** ev_out = nullptr);
     // the same for several cameras of one volume state in ONE batched free-view chain; one event for all results
+    // (use_event: record THIS event behind the batch instead of one of the update's pooled events)
     std::vector<TensorDict> raycastCams(const std::vector<const Camera*>& cams, const std::vector<ORUtils::SE3Pose>& poses,
-                                        void** ev_out = nullptr);
+                                        void** ev_out = nullptr, void* use_event = nullptr);
     void raycastWindowAndKeyframes(const std::deque<Camera>& window, const std::vector<Camera>& keyframes,
                                    const std::vector<ORUtils::SE3Pose>& poses);
     void raycastWindow(const std::deque<Camera>& window, const std::vector<ORUtils::SE3Pose>& poses);
@@ -216,8 +222,20 @@ private:
     void keyframeStepThreaded();
     void mapWorker(int device_index);
     void rethrowWorkerError();
-    struct MapJob { Camera curr_cam; int frame_id = 0; std::deque<Camera> window; std::vector<Camera> keyframes; std::vector<ORUtils::SE3Pose> poses; };
+    struct MapJob {
+        Camera curr_cam; int frame_id = 0; std::deque<Camera> window; std::vector<Camera> keyframes; std::vector<ORUtils::SE3Pose> poses;
+        // pipeline_raycasts: the update's views, already enqueued by the frame thread (the worker adopts them instead of raycasting)
+        bool views_ready = false;
+        std::vector<Camera> opt_cams; std::vector<TensorDict> opt_raycasts; std::vector<void*> opt_events;
+        std::deque<TensorDict> window_raycasts; std::vector<void*> window_events;
+        size_t window_len = 0; void* last_event = nullptr;
+    };
     MapJob job_;
+    void buildUpdateViews(MapJob& out);           // localFrameRaycast + keyFrameRaycast of the keyframe at hand into `out` (frame thread)
+    void* job_events_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // {window batch, keyframe batch} per update parity
+    int job_parity_ = 0;
+    void* last_raycast_event_ = nullptr;          // the adopted job's last batch (waitAllRaycasts)
+    std::mt19937_64 rng_kf_;                      // the history keyframes' draw (its own generator: the frame thread draws while the worker's update draws cameras)
     size_t opt_window_len_ = 0;                  // length of the local window at the front of opt_cam_list (the rest: history keyframes)
     int opt_frame_id_ = 0, update_frame_id_ = 0; // frame number of the update opt_cam_list belongs to / of the update being built
     std::mutex loss_mu_;                         // keyframe_loss_dict: written by updateFrameList (frame thread) and checkKeyFrameError (map thread)
