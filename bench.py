@@ -212,7 +212,13 @@ class Scene:
 
 
 def prime(device):
-    """Run the whole per-frame loop once on a tiny throwaway scene (loads every kernel, warms the allocator)."""
+    """Run the whole per-frame loop once on a tiny throwaway scene (loads every kernel, warms the allocator).  Also bounds
+    libtorch's intra-op pool by the container's CPU quota for callers that did not go through main()'s pin_to_gpu_numa (the
+    tools, the soak test; GPS_BENCH_NO_THREAD_CAP=1 leaves it alone: tools/probe/early_stall.py reproduces the frozen-process
+    stalls with it)."""
+    if not os.environ.get("GPS_BENCH_NO_THREAD_CAP"):
+        from gps_slam_amd.dist_util import cap_host_threads
+        cap_host_threads()
     seq = synthetic_sequence(64, 48, 21, 1)
     seeds = seed_gaussians(seq, 500, 1, device)
     for use_gt in (True, False):
@@ -423,7 +429,7 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                             whole_run_fusion_fps=wr["overlap"]["fusion_fps"], whole_run_gaussian_fps=wr["overlap"]["gaussian_fps"],
                             whole_run_fusion_fps_sequential=wr["sequential"]["fusion_fps"],
                             whole_run_gaussian_fps_sequential=wr["sequential"]["gaussian_fps"],
-                            whole_run_slowest_frame_ms=wr["overlap"]["slowest_frame_ms_after_30"],
+                            whole_run_slowest_frame_ms=wr["overlap"]["slowest_frame_ms_after_30"], whole_run_gpu_memory_mb=wr["overlap"]["gpu_memory_mb"],
                             whole_run_seconds_total=wr["seconds_total"])
             if world == 1 and not args.no_other_configs:
                 oc = other_configs(args, seq, seed, device, first)
@@ -510,7 +516,7 @@ def whole_run(args, seed, device, n_frames):
                       "per_frame_fusion_ms": tm.per_frame / max(1, tm.frames), "keyframe_step_host_ms_per_frame": tm.keyframe_step / max(1, tm.frames),
                       "stage_ms_per_frame": {k: getattr(tm, k) / max(1, tm.frames) for k in
                                              ("localFrameRaycast", "keyFrameRaycast", "initNewGaussians", "localOptimize", "removeGaussian")},
-                      "slowest_frame_ms_after_30": tm.max_frame_after_30, "slowest_frame_id": tm.max_frame_id,
+                      "slowest_frame_ms_after_30": tm.max_frame_after_30, "slowest_frame_id": tm.max_frame_id, "gpu_memory_mb": int(tm.gpu_memory_mb),
                       "gaussians_end": int(sc.model.getGaussianNum()), "pipeline_stats": st, "device_mallocs": _device_mallocs(True) - mallocs0,
                       "visible_blocks_end": int(sc.engine.counters().cpu()[2]), "allocated_blocks_end": int((1 << 18) - 1 - int(sc.engine.counters().cpu()[0])),
                       "scene_build_seconds": t_build}

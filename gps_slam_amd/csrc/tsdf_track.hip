@@ -372,7 +372,9 @@ constexpr int SYNC_SPIN_TICKS = 8, SYNC_EVAL_TICKS = 9, SYNC_EVALS = 10, SYNC_SK
 // carries this launch's tag (the slowest workgroup + the hand-over through memory), from there to the mailbox store
 constexpr int SYNC_PHASE_L0 = 1, SYNC_PHASE_COARSE = 5;   // words [1..4] and [5..7] + [12]
 __host__ __device__ __forceinline__ int phase_word(int base, int k) { return base == SYNC_PHASE_COARSE && k == 3 ? 12 : base + k; }
-constexpr long long ROW_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
+// (2 s, not the 50 ms of rounds 3-4: a host thread that is frozen for one CPU-accounting period -- 100 ms, a container over its
+// quota -- must find its launch still waiting when it comes back; the timeouts are for a host that never comes back)
+constexpr long long ROW_TIMEOUT = 2000LL * 1000 * 100;  // wall_clock64 ticks (100 MHz): 2 s
 
 // LDS of an evaluation workgroup (declared once per kernel: the fused body below is instantiated per kind and pose count)
 struct EvLds {
@@ -620,7 +622,7 @@ struct PollArgs {
 // 4.0 -> 3.6 us (coarser levels) -- and nothing end to end (tracked frame 0.454 vs 0.457 ms, sequential 1,038 vs 1,032 frames/s in
 // a 3 + 3 A/B): the loop is not two bare memory latencies, and the host's share of an iteration (rows, solve, line) hides the rest.
 constexpr uint32_t ARG_RUN = 1, ARG_SKIP = 2;
-constexpr long long ARG_TIMEOUT = 50 * 1000 * 100;  // wall_clock64 ticks (100 MHz): 50 ms
+constexpr long long ARG_TIMEOUT = 2000LL * 1000 * 100;  // wall_clock64 ticks (100 MHz): 2 s (see ROW_TIMEOUT)
 
 __global__ __launch_bounds__(EV_THREADS) void track_eval_poll_kernel(PollArgs pa, uint32_t* __restrict__ partial,
                                                                    uint32_t* __restrict__ sync, float* __restrict__ result,
@@ -1161,6 +1163,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     auto next_seq = [&]() {
         if (ts->mail_seq >= 0x3FFFFFFF) {
             ts->mail_seq = 0;
+            if (mailbox) mailbox[32] = 0.0f;   // (the retirement word compares like the line: `retired` below)
             if (bar_line) {
                 for (int k = 0; k < 8 * EV_GROUPS; k++) reinterpret_cast<volatile uint64_t*>(bar_line)[k] = 0;
                 host_store_fence();
@@ -1258,11 +1261,14 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
     // 32 := its sequence number).  Usually that launch is already polling and answers within a PCIe round trip; when it is
     // still queued behind other streams' kernels the wait is what keeps the next frame's first arguments from overwriting the
     // line it has yet to read (measured without it: 1 overlap run in ~10 lost 50 ms -- one ARG_TIMEOUT -- in a single frame).
+    // launch `seq` -- or a later one, which cannot have started before `seq` had drained -- has taken itself out (ARG_SKIP or its
+    // own ARG_TIMEOUT) and said so in mailbox word 32
+    auto retired = [&](int seq) -> bool { return (int32_t)((uint32_t)float_bits(mailbox[32]) - (uint32_t)seq) >= 0; };
     auto retire = [&](int seq) {
         for (int g = 1; g < n_groups; g++) write_line(g, seq, ARG_SKIP, 0, 0, nullptr);
         publish(seq, ARG_SKIP, 0, 0, nullptr);
         for (long spin = 0; spin < 400000000L; spin++) {  // (bounded; the launch gives up by itself after ARG_TIMEOUT)
-            if (float_bits(mailbox[32]) == seq) break;
+            if (retired(seq)) break;
             if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
         }
     };
@@ -1346,6 +1352,9 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
             unsigned long long tsc_prev = tsc0, tsc_gap = 0;
             for (long spin = 0; spin < 200000000L; spin++) {
                 if (answered(0, seq, n_wgs)) { got = true; break; }
+                // the launch gave up before its line arrived (this thread did not run for longer than ARG_TIMEOUT): no answer will
+                // come -- straight to the plain launch below instead of spinning out the budget (rounds 3-4 did: 2 s per event)
+                if ((spin & 0xFF) == 0xFF && retired(seq)) { got = answered(0, seq, n_wgs); break; }
                 const unsigned long long now = host_cycles();
                 if (now - tsc_prev > tsc_gap) tsc_gap = now - tsc_prev;
                 tsc_prev = now;
@@ -1370,7 +1379,7 @@ static int track_camera_impl(const gps_tsdf_state* sp, const gps_track_config* c
                 bool late = false, gone = false;
                 for (long spin = 0; spin < 400000000L && !late && !gone; spin++) {
                     late = answered(0, seq, n_wgs);
-                    gone = float_bits(mailbox[32]) == seq;
+                    gone = retired(seq);
                     if ((spin & 0xFFFF) == 0xFFFF) sched_yield();
                 }
                 if (!late && !gone) {

@@ -149,6 +149,44 @@ def _node_cpus():
     return out
 
 
+def cpu_quota():
+    """CPUs this process's container may use per accounting period (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None without a
+    quota.  os.cpu_count() and sched_getaffinity() know nothing of it: the MI355X boxes show 256 logical CPUs to a container that
+    may use 16."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def cap_host_threads(limit=8, cpus=None):
+    """Bound libtorch's intra-op pool by what this process may actually run on: `limit`, the CPUs of its affinity mask (or `cpus`)
+    and HALF the container's CPU quota (the frame thread, the map worker and the runtime's own threads need the other half).
+    libtorch sizes the pool by the machine's cores; after every parallel CPU op -- a fill of a megabyte is one -- each of those
+    threads spins for a while, and a container over its quota is frozen WHOLE until the accounting period (100 ms) ends: measured
+    on the MI355X box (256 CPUs shown, quota 16, pool of 128): a 90 ms hole in the first frames of 6 runs out of 10 that started
+    right after a scene had been built with torch::zeros images (tools/probe/early_stall.py; LABBOOK section 14).  The host side
+    of this path is bookkeeping: a handful of threads is plenty.  -> the number of threads set."""
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0)) if cpus is None else int(cpus)
+    except AttributeError:
+        n = os.cpu_count() or 1
+    q = cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q // 2)))
+    n = max(1, min(int(limit), n, torch.get_num_threads()))
+    torch.set_num_threads(n)
+    return n
+
+
 def pin_to_gpu_numa(local_rank, world=1, device_of_rank=None):
     """Pin this process (and the threads it starts later: the tracker's frame thread, the mapping worker) to its share of the
     cores of its GPU's NUMA node (plan_affinity: the ranks of a node split it evenly; without NUMA information every rank takes
@@ -174,8 +212,8 @@ def pin_to_gpu_numa(local_rank, world=1, device_of_rank=None):
     except OSError as e:
         return "affinity: %s" % e
     # libtorch's intra-op pool defaults to one thread per LOGICAL cpu of the machine: more threads than this rank may run on
-    # turns the first parallel CPU op (randperm / sort of the new-Gaussian subset) into a 50 ms barrier storm.  The host side
-    # of this path is bookkeeping: a handful of threads is plenty.
+    # turns the first parallel CPU op into a 50 ms barrier storm -- or, in a container with a CPU quota, into a frozen process
+    # (cap_host_threads)
     import torch
-    torch.set_num_threads(max(1, min(8, len(mine))))
+    cap_host_threads(8, cpus=len(mine))
     return "affinity: %s, %d cpus (%d..%d), %d intra-op threads" % (where, len(mine), min(mine), max(mine), torch.get_num_threads())

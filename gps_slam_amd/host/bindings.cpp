@@ -72,6 +72,7 @@ PYBIND11_MODULE(_host, m) {
     m.def("RawGaussianParamsMake", &RawGaussianParams::make, py::arg("xyz"), py::arg("rgb"), py::arg("normals"),
           py::arg("max_sh_degree") = 3, py::arg("init_opacs") = 0.5f, py::arg("max_scale") = 0.01f, py::arg("min_scale") = -1.0f);
     m.def("computeNormalMap", &computeNormalMap);
+    m.def("getGPUMemoryUsage", &getGPUMemoryUsage, py::arg("gpu_id") = 0);
 
     // ---- Camera
     py::class_<Camera>(m, "Camera")
@@ -250,6 +251,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readonly("checkError", &SLAMPipeline::PipelineTimes::checkError)
         .def_readonly("max_frame_after_30", &SLAMPipeline::PipelineTimes::max_frame_after_30)
         .def_readonly("max_frame_id", &SLAMPipeline::PipelineTimes::max_frame_id)
+        .def_readonly("gpu_memory_mb", &SLAMPipeline::PipelineTimes::gpu_memory_mb)
         .def("fps", &SLAMPipeline::PipelineTimes::fps)
         .def("fusion_fps", &SLAMPipeline::PipelineTimes::fusion_fps)
         .def("gaussian_fps", &SLAMPipeline::PipelineTimes::gaussian_fps);

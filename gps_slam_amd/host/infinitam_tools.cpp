@@ -4,6 +4,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 using namespace gpsh;
 using namespace InfiniTAM::Engine;
@@ -25,13 +27,37 @@ struct CLIEngine::Staging {
     int frame_in_slot[3] = {-1, -1, -1};
     bool used[3] = {false, false, false};
     ~Staging() {
-        if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+        if (copy) (void)hipStreamSynchronize(copy);   // (the stream itself lives as long as the process: copy_stream())
         for (int k = 0; k < 3; k++) {
             if (uploaded[k]) (void)hipEventDestroy(uploaded[k]);
             if (consumed[k]) (void)hipEventDestroy(consumed[k]);
         }
     }
 };
+
+// The upload stream: one per device for the life of the process.  A stream's hardware queue is created when it is first used
+// (80-100 ms: it showed up as the first frame of every scene), so it is created -- and used once -- the first time any sequence is
+// initialised, and every later CLIEngine of the process finds it ready.
+static hipStream_t copy_stream() {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    int dev = 0;
+    hip_ok(hipGetDevice(&dev), "hipGetDevice");
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(dev);
+    if (it == streams.end()) {
+        hipStream_t st = nullptr;
+        hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        void *d = nullptr, *h = nullptr;
+        hip_ok(hipMalloc(&d, 4096), "hipMalloc");
+        hip_ok(hipHostMalloc(&h, 4096, hipHostMallocDefault), "hipHostMalloc");
+        hip_ok(hipMemcpyAsync(d, h, 4096, hipMemcpyHostToDevice, st), "hipMemcpyAsync");   // (the copy engine's queue too)
+        hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+        (void)hipFree(d); (void)hipHostFree(h);
+        it = streams.emplace(dev, st).first;
+    }
+    return it->second;
+}
 
 void CLIEngine::Initialise(std::vector<ITMUChar4Image*> rgb_images_, std::vector<ITMShortImage*> depth_images_,
                            ITMMainEngine* mainEngine_) {
@@ -42,13 +68,18 @@ void CLIEngine::Initialise(std::vector<ITMUChar4Image*> rgb_images_, std::vector
     currentFrameNo = 0;
     uploadedBytes = 0;
     staging_.reset(new Staging());
-    hip_ok(hipStreamCreateWithFlags(&staging_->copy, hipStreamNonBlocking), "hipStreamCreate");
+    staging_->copy = copy_stream();
     for (int k = 0; k < 3; k++) {
         staging_->rgb[k].reset(new ITMUChar4Image(GetRGBSize(), false, true));
         staging_->depth[k].reset(new ITMShortImage(GetDepthSize(), false, true));
         hip_ok(hipEventCreateWithFlags(&staging_->uploaded[k], hipEventDisableTiming), "hipEventCreate");
         hip_ok(hipEventCreateWithFlags(&staging_->consumed[k], hipEventDisableTiming), "hipEventCreate");
     }
+    // The staging images were zero-filled on the CURRENT stream just now (ORUtils::Image clears what it allocates); the first
+    // uploads run on the copy stream: it waits for those fills, or a fill lands on top of frame 0 (seen once the copy stream
+    // stopped being created -- a device-wide stall -- per engine: tests/test_tsdf_facade_gpu.py, counters of the two routes apart)
+    hip_ok(hipEventRecord(staging_->consumed[0], (hipStream_t)current_stream()), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(staging_->copy, staging_->consumed[0], 0), "hipStreamWaitEvent");
 }
 
 void CLIEngine::upload(int frame) {

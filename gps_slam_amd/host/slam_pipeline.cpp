@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdlib>
 
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPGuard.h>
 #include <hip/hip_runtime_api.h>
 
@@ -14,25 +15,48 @@ using namespace gpsh;
 
 namespace {
 inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess, what, ": ", hipGetErrorString(e)); }
-struct MapStream {
-    c10::hip::HIPStream s;
-    // a stream this pipeline created itself (make_stream kinds 2..4) is destroyed with it; torch's pool streams are not ours
-    void release(bool owned) { if (owned) { (void)hipStreamSynchronize(s.stream()); (void)hipStreamDestroy(s.stream()); } }
-};
-// kind 0 / 1: torch's high- / normal-priority pool; 2 / 3 / 4: a stream of this pipeline's own (hipStreamCreateWithPriority,
-// non-blocking) at the lowest / highest / default priority, wrapped for the stream guards
+struct MapStream { c10::hip::HIPStream s; };
+// kind 0 / 1: torch's high- / normal-priority pool; 2 / 3 / 4: a stream of this library's own (hipStreamCreateWithPriority,
+// non-blocking) at the lowest / highest / default priority, wrapped for the stream guards.  ONE stream per (device, kind) for the
+// life of the process, shared by every pipeline: a hardware queue is created when a stream is first used (80-100 ms, measured as a
+// stall of the frame that did it) and ROCm places a new stream on a queue by what exists at that moment -- creating the three
+// streams once keeps both out of every scene but the process's first, and the placement the same for all of them.  (Round 5 first
+// created and destroyed them per pipeline: 3 x ~90 ms inside every whole-sequence run, and one run in five lost 2.1 s in its first
+// dozen frames.)  Two pipelines alive at once share the streams: ordered, just not concurrent with each other.
 c10::hip::HIPStream make_stream(int kind) {
     const auto dev = c10::hip::current_device();
     if (kind == 0) return c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev);
     if (kind == 1) return c10::hip::getStreamFromPool(/*isHighPriority=*/false, dev);
-    int least = 0, greatest = 0;
-    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    hipStream_t st = nullptr;
-    hip_ok(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, kind == 2 ? least : kind == 3 ? greatest : 0), "hipStreamCreateWithPriority");
-    return c10::hip::getStreamFromExternal(st, dev);
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> own;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = own.find({(int)dev, kind});
+    if (it == own.end()) {
+        int least = 0, greatest = 0;
+        hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        hipStream_t st = nullptr;
+        hip_ok(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, kind == 2 ? least : kind == 3 ? greatest : 0), "hipStreamCreateWithPriority");
+        // first use now, not in somebody's frame: the queue behind the stream exists when this returns
+        void* word = nullptr;
+        hip_ok(hipMalloc(&word, 256), "hipMalloc");
+        hip_ok(hipMemsetAsync(word, 0, 256, st), "hipMemsetAsync");
+        hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+        (void)hipFree(word);
+        it = own.emplace(std::make_pair((int)dev, kind), st).first;
+    }
+    return c10::hip::getStreamFromExternal(it->second, dev);
 }
 }  // namespace
 using torch::indexing::Slice;
+
+unsigned long long getGPUMemoryUsage(int gpu_id) {
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) return ~0ull;
+    size_t free_b = 0, total_b = 0;
+    const bool ok = hipSetDevice(gpu_id) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    (void)hipSetDevice(prev);
+    return ok ? (unsigned long long)((total_b - free_b) / (1024 * 1024)) : ~0ull;
+}
 
 torch::Tensor computeNormalMap(const torch::Tensor& vertex_map_in) {
     auto vertex_map = vertex_map_in.contiguous();
@@ -85,6 +109,20 @@ void SLAMPipeline::SLAMTrainCams(SLAMGaussianModel& model_, std::vector<Camera>&
     hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
     times.slam_total = now_ms() - t0;
     times.frames = (int)cams.size();
+    // slam_pipeline.cpp:168-171: emptyCache(), then the device memory in use (what run/read_results.py reads as "GPU memory usage")
+    c10::hip::HIPCachingAllocator::emptyCache();
+    times.gpu_memory_mb = (long long)getGPUMemoryUsage((int)c10::hip::current_device());
+    if (log_pipeline_time) {
+        if (FILE* f = fopen((workspace_dir + "/time_log.txt").c_str(), "w")) {   // (the file run/read_results.py parses)
+            fprintf(f, "[PIPELINE AVG TIME] GS num: %d, per frame fusion time: %f, localFrameRaycast time: %f, keyFrameRaycast time: %f, "
+                       "initNewGaussians time: %f, localOptimize time: %f, FPS: %f\n", model->getGaussianNum(), times.per_frame / times.frames,
+                    times.localFrameRaycast / times.frames, times.keyFrameRaycast / times.frames, times.initNewGaussians / times.frames,
+                    times.localOptimize / times.frames, times.fps());
+            fprintf(f, "GPU memory usage: %d MB\n", (int)times.gpu_memory_mb);
+            fclose(f);
+        }
+        printf("GPU memory usage: %d MB\n", (int)times.gpu_memory_mb);
+    }
     if (log_pipeline_time)
         printf("[PIPELINE AVG TIME] GS num: %d, per frame fusion time: %f, localFrameRaycast time: %f, keyFrameRaycast time: %f, "
                "initNewGaussians time: %f, localOptimize time: %f, FPS: %f\n", model->getGaussianNum(), times.per_frame / times.frames,
@@ -920,8 +958,6 @@ SLAMPipeline::~SLAMPipeline() {
         (void)hipStreamSynchronize(static_cast<MapStream*>(map_stream_)->s.stream());
         (void)hipStreamSynchronize(static_cast<MapStream*>(frame_stream_)->s.stream());
         for (void* e : {ev_frame_, ev_raycasts_, ev_map_, ev_caller_, job_events_[0][0], job_events_[0][1], job_events_[1][0], job_events_[1][1]}) if (e) (void)hipEventDestroy((hipEvent_t)e);
-        static_cast<MapStream*>(map_stream_)->release(map_stream_kind >= 2);
-        static_cast<MapStream*>(frame_stream_)->release(frame_stream_kind >= 2);
         delete static_cast<MapStream*>(map_stream_);
         delete static_cast<MapStream*>(frame_stream_);
     }
@@ -931,7 +967,6 @@ SLAMPipeline::~SLAMPipeline() {
         (void)hipStreamSynchronize(static_cast<MapStream*>(rc_stream_)->s.stream());
         for (void* e : rc_events_) if (e) (void)hipEventDestroy((hipEvent_t)e);
         if (ev_rc_begin_) (void)hipEventDestroy((hipEvent_t)ev_rc_begin_);
-        static_cast<MapStream*>(rc_stream_)->release(raycast_stream_kind >= 2);
         delete static_cast<MapStream*>(rc_stream_);
     }
 }

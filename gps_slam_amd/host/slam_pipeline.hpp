@@ -47,6 +47,9 @@ private:
     std::mt19937_64& rng_;
 };
 
+// include/file_utils.h:35, src/file_utils.cpp:172-210: device memory in use, MiB (the reference asks NVML for `memory.used`; here
+// hipMemGetInfo of the device: total - free, the same quantity -- every process's allocations on that GPU)
+unsigned long long getGPUMemoryUsage(int gpu_id = 0);
 torch::Tensor computeNormalMap(const torch::Tensor& vertex_map);  // src/tensor_math.cpp:278-300 -> gps_normal_map
 
 class SLAMPipeline {
@@ -133,6 +136,7 @@ public:
         int frames = 0;
         double slam_total = 0, per_frame = 0, keyframe_step = 0, localFrameRaycast = 0, keyFrameRaycast = 0, initNewGaussians = 0,
                localOptimize = 0, removeGaussian = 0, checkError = 0;
+        long long gpu_memory_mb = -1;    // getGPUMemoryUsage after emptyCache() at the end of the run (slam_pipeline.cpp:168-171)
         double max_frame_after_30 = 0;   // slowest processFrame call (host wall) from frame 30 on
         int max_frame_id = -1;
         double fps() const { return slam_total > 0 ? frames / (slam_total / 1000.0) : 0.0; }
@@ -171,7 +175,7 @@ public:
     bool async_raycasts = true;   // the update's free-view raycasts run beside its optimise iterations (same results)
     // which stream each chain gets (slam_pipeline.cpp: make_stream): 0 / 1 = torch's high- / normal-priority pool, 2 / 3 / 4 = a
     // stream of the pipeline's own at the lowest / highest / default priority
-    // Round 5: ALL THREE are streams of the pipeline's own now, created at the first frame and destroyed with the pipeline.  torch hands
+    // Round 5: ALL THREE are streams of the library's own now (one per priority for the life of the process: make_stream).  torch hands
     // its pool streams out round-robin and never destroys them, ROCm spreads the streams of one priority level over <= 4 hardware
     // queues by reference count -- so which chains ended up sharing a queue depended on how many scenes the PROCESS had built
     // before: the same 1,000-frame run gave 1,120 frames/s in a fresh process and 900 after six other scenes, a test process's

@@ -1,3 +1,4 @@
+#include <cstring>
 #include "tsdf_engine.hpp"
 
 #include <hip/hip_runtime_api.h>
@@ -88,8 +89,9 @@ void TsdfEngine::turnOnTracking(const char* levels, int numIterC, int numIterF, 
     if (!track_scratch_.defined()) {
         track_scratch_ = torch::empty({gps_track_scratch_bytes(state_.width, state_.height)}, u8(device_));
         // (room for the answer blocks and the host-summed row tables of every group: gps_track_state.mailbox_bytes)
-        track_mailbox_ = torch::zeros({(GPS_TRACK_MAILBOX_BLOCK_BYTES + GPS_TRACK_MAILBOX_ROWS_BYTES) / 4 * (1 + kMaxRidingAlong)},
+        track_mailbox_ = torch::empty({(GPS_TRACK_MAILBOX_BLOCK_BYTES + GPS_TRACK_MAILBOX_ROWS_BYTES) / 4 * (1 + kMaxRidingAlong)},
                                       torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
+        std::memset(track_mailbox_.data_ptr(), 0, (size_t)track_mailbox_.nbytes());   // (not torch::zeros: tsdf_engine.hpp, Image)
         void* line = nullptr;
         check(gps_track_arg_line_alloc(&line), "gps_track_arg_line_alloc");
         if (line) track_arg_line_ = std::shared_ptr<void>(line, [](void* p) { (void)gps_track_arg_line_free(p); });

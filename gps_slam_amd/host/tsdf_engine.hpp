@@ -14,6 +14,7 @@
 // GetTrackingState()->pose_d->GetInvM(), camPoses, camIntrincs, gtC2wPoses, turnOffTracking, SaveToFile, LoadFromFile,
 // SaveSceneToMesh.
 #pragma once
+#include <cstring>
 #include <memory>
 #include <functional>
 #include <mutex>
@@ -57,7 +58,14 @@ public:
     // ORUtils::Image(noDims, allocate_CPU, allocate_CUDA) (Image.h:27-33)
     Image(Vector2<int> dims, bool allocate_CPU, bool allocate_CUDA, torch::Device device = torch::kCUDA) : noDims(dims) {
         const int64_t bytes = (int64_t)dims.x * dims.y * (int64_t)sizeof(T);
-        if (allocate_CPU) host_ = torch::zeros({bytes}, torch::TensorOptions().dtype(torch::kUInt8).pinned_memory(true));
+        // (empty + memset, not torch::zeros: the fill of a megabyte is a parallel region of torch's intra-op pool -- one thread per
+        // core the machine SHOWS, each spinning for a while afterwards; two such regions per frame of a sequence exhaust a
+        // container's CPU quota and the kernel then freezes every thread of the process, the tracking thread included, until the
+        // end of the 100 ms accounting period: LABBOOK section 14, tools/probe/early_stall.py)
+        if (allocate_CPU) {
+            host_ = torch::empty({bytes}, torch::TensorOptions().dtype(torch::kUInt8).pinned_memory(true));
+            std::memset(host_.data_ptr(), 0, (size_t)bytes);
+        }
         if (allocate_CUDA) dev_ = torch::zeros({bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(device));
     }
     T* GetData(MemoryDeviceType t) const {

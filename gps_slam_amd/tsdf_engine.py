@@ -139,7 +139,9 @@ class TsdfEngine:
         # kernel -> host, no memcpy: an answer block per group and (host_summed_rows) a table of the workgroups' rows per group, which
         # the tracking call adds up itself instead of a summing workgroup on the device (gps_track_state.mailbox_bytes)
         per_group = 256 + (32768 if host_summed_rows else 0)
-        self._mailbox = torch.zeros(per_group // 4 * groups, dtype=torch.float32).pin_memory()
+        # (empty + a numpy fill, not torch.zeros: the fill would be a parallel region of torch's intra-op pool -- dist_util.cap_host_threads)
+        self._mailbox = torch.empty(per_group // 4 * groups, dtype=torch.float32, pin_memory=True)
+        self._mailbox.numpy().fill(0.0)
         self.track_state.host_mailbox = self._mailbox.data_ptr()
         self.track_state.mailbox_bytes = per_group * groups
         # the argument line in host-writable device memory (written through the BAR; None without a large BAR)

@@ -23,8 +23,9 @@ def _pose_err(est, gt):
     return float(np.linalg.norm(est[:3, 3] - gt[:3, 3])), float(np.degrees(np.arccos(np.clip(cos, -1, 1))))
 
 
-def test_soak_1000_frames_overlap_schedule_capacity_growth_under_the_worker():
+def test_soak_1000_frames_overlap_schedule_capacity_growth_under_the_worker(tmp_path):
     import bench
+    import re
     n, seed, W, H = 1000, 1234, 640, 480
     seq = bench.synthetic_sequence_device(W, H, n, seed, DEV)
     # ~150 k seeds + what the run adds itself (this orbit saturates near 400 k Gaussians at the configs' new_gs_sample_ratio of 0.25;
@@ -38,9 +39,16 @@ def test_soak_1000_frames_overlap_schedule_capacity_growth_under_the_worker():
     sc.pipe.loadConfig(dict(new_gs_sample_ratio=0.5))
     assert sc.model.capacity() == 1 << 18
     sc.pipe.keep_frame_ms = True
+    sc.pipe.log_pipeline_time = True            # the reference's LOG_PIPELINE_TIME output: stdout + <workspace>/time_log.txt
+    sc.pipe.workspace_dir = str(tmp_path)
     torch.cuda.synchronize()
     cams = sc.pipe.SLAMTrainCamsModel(sc.model, sc.cams)   # (returns the cameras with c2w_slam filled in)
     tm = sc.pipe.times
+    # time_log.txt as run/read_results.py:14-31 parses it
+    log = open(tmp_path / "time_log.txt").read()
+    m_t, m_f, m_g = re.search(r"per frame fusion time: (\d+\.\d+)", log), re.search(r"FPS: (\d+\.\d+)", log), re.search(r"GPU memory usage: (\d+) MB", log)
+    assert m_t and m_f and m_g, log
+    assert abs(float(m_f.group(1)) - tm.fps()) < 0.01 and int(m_g.group(1)) == tm.gpu_memory_mb > 1000
     st = dict(sc.pipe.stats())
     N = sc.model.getGaussianNum()
     print("soak: %.0f frames/s over %d frames, N = %d (capacity %d), stats %s" % (tm.fps(), tm.frames, N, sc.model.capacity(), st))
