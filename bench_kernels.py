@@ -558,14 +558,19 @@ def cpu_baseline(seq, W, H, max_seconds=15.0):
         # the same loop with the reference's depth tracker estimating every pose (what the headline's frames do): a shorter sample
         nt = int(max(6, min(n, 1 + 0.4 * max_seconds / per)))
         trk = R.time_reference(seq, nt, 0.005, 0.02, 0.2, 10.0, threads=best, track=True)
+        from gps_slam_amd.dist_util import cpu_quota
+        quota = cpu_quota()
         return {"value": res["frames"] / res["seconds"], "unit": "frames/s", "cores": cores, "threads": best, "kind": "reference",
+                "cpu_quota": quota,
                 "tracked_value": trk["frames"] / trk["seconds"] if trk else None, "tracked_sample_frames": trk["frames"] if trk else 0,
                 "thread_sweep_frames_per_s": {str(t): round(v, 3) for t, v in sweep.items()},
                 "sample": "%d ProcessFrame calls (TSDF fuse + live raycast + ICP maps, tracking off, no Gaussians) of the same "
                           "%dx%d synthetic sequence by the reference's ITMLib CPU engine (oracle/_ref/itm_ref_omp: g++ -O3 "
                           "-fopenmp as upstream), OMP_NUM_THREADS=%d = the fastest of a sweep over %s threads (6 frames each) on %d "
-                          "physical cores, first frame excluded; tracked_value = the same loop with the engine's depth tracker on; "
-                          "host CPU: %s" % (res["frames"], W, H, best, "/".join(str(t) for t in sweep), cores, _cpu_name())}
+                          "physical cores%s, first frame excluded; tracked_value = the same loop with the engine's depth tracker on; "
+                          "host CPU: %s" % (res["frames"], W, H, best, "/".join(str(t) for t in sweep), cores,
+                                            "" if quota is None else " of which this container may use %.3g at a time (cgroup cpu.max: "
+                                            "thread counts above that are throttled, as the sweep shows)" % quota, _cpu_name())}
     return cpu_baseline_port(seq, W, H, max_seconds)
 
 

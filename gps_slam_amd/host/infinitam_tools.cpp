@@ -35,9 +35,8 @@ struct CLIEngine::Staging {
     }
 };
 
-// The upload stream: one per device for the life of the process.  A stream's hardware queue is created when it is first used
-// (80-100 ms: it showed up as the first frame of every scene), so it is created -- and used once -- the first time any sequence is
-// initialised, and every later CLIEngine of the process finds it ready.
+// The upload stream: one per device for the life of the process (creating a stream blocks the runtime for ~10 ms; the copy
+// engine's queue behind it is created at its first copy): made, and used once, the first time any sequence is initialised.
 static hipStream_t copy_stream() {
     static std::mutex mu;
     static std::map<int, hipStream_t> streams;

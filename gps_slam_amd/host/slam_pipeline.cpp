@@ -18,11 +18,11 @@ inline void hip_ok(hipError_t e, const char* what) { TORCH_CHECK(e == hipSuccess
 struct MapStream { c10::hip::HIPStream s; };
 // kind 0 / 1: torch's high- / normal-priority pool; 2 / 3 / 4: a stream of this library's own (hipStreamCreateWithPriority,
 // non-blocking) at the lowest / highest / default priority, wrapped for the stream guards.  ONE stream per (device, kind) for the
-// life of the process, shared by every pipeline: a hardware queue is created when a stream is first used (80-100 ms, measured as a
-// stall of the frame that did it) and ROCm places a new stream on a queue by what exists at that moment -- creating the three
-// streams once keeps both out of every scene but the process's first, and the placement the same for all of them.  (Round 5 first
-// created and destroyed them per pipeline: 3 x ~90 ms inside every whole-sequence run, and one run in five lost 2.1 s in its first
-// dozen frames.)  Two pipelines alive at once share the streams: ordered, just not concurrent with each other.
+// life of the process, shared by every pipeline: ROCm places a new stream on a hardware queue by what exists at that moment, and
+// creating a stream costs ~10 ms of a blocked runtime -- creating the three once keeps the placement the same for every scene of
+// a process and the cost out of all but the first.  Two pipelines alive at once share the streams: ordered, just not concurrent
+// with each other.  (The 90 ms / 2.1 s holes in the first frames of round 5's early whole-sequence runs, first blamed on queue
+// creation, were the container's CPU quota: LABBOOK section 14, dist_util.cap_host_threads.)
 c10::hip::HIPStream make_stream(int kind) {
     const auto dev = c10::hip::current_device();
     if (kind == 0) return c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev);
