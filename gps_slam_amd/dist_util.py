@@ -216,4 +216,8 @@ def pin_to_gpu_numa(local_rank, world=1, device_of_rank=None):
     # (cap_host_threads)
     import torch
     cap_host_threads(8, cpus=len(mine))
-    return "affinity: %s, %d cpus (%d..%d), %d intra-op threads" % (where, len(mine), min(mine), max(mine), torch.get_num_threads())
+    q = cpu_quota()
+    # (every rank keeps ~2 threads busy -- the tracking thread polls its mailbox, the map worker enqueues and waits: a quota below
+    # ~2.5 CPUs per rank means frozen accounting periods, and the line says so instead of leaving a slow number unexplained)
+    quota = "" if q is None else ", container quota %.3g cpus%s" % (q, " (< 2.5 per rank: expect throttling)" if q < 2.5 * world else "")
+    return "affinity: %s, %d cpus (%d..%d), %d intra-op threads%s" % (where, len(mine), min(mine), max(mine), torch.get_num_threads(), quota)

@@ -258,7 +258,10 @@ void SLAMPipeline::buildUpdateViews(MapJob& out) {
     std::vector<const Camera*> cams;
     for (const Camera& cam : localframe_cam_window) cams.push_back(&cam);
     void* ev = nullptr;
+    const double t0 = now_ms();
     for (TensorDict& m : raycastCams(cams, poses, &ev, evs[0])) { out.window_raycasts.push_back(m); out.window_events.push_back(evs[0]); }
+    const double t1 = now_ms();
+    times.localFrameRaycast += t1 - t0;
     out.opt_cams.assign(localframe_cam_window.begin(), localframe_cam_window.end());
     out.window_len = localframe_cam_window.size();
     out.opt_raycasts.assign(out.window_raycasts.begin(), out.window_raycasts.end());
@@ -276,6 +279,7 @@ void SLAMPipeline::buildUpdateViews(MapJob& out) {
         for (TensorDict& m : raycastCams(kcams, poses, &ev, evs[1])) { out.opt_raycasts.push_back(m); out.opt_events.push_back(evs[1]); }
         out.last_event = evs[1];
     }
+    times.keyFrameRaycast += now_ms() - t1;
     out.views_ready = true;
 }
 
@@ -881,8 +885,16 @@ void SLAMPipeline::mapWorker(int device_index) {
                 { std::lock_guard<std::mutex> lk(mu_); raycasts_seq_ = seen; }
             } else {
                 last_raycast_event_ = nullptr;
-                if (merge_keyframe_raycasts) raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
-                else { raycastWindow(job_.window, job_.poses); raycastKeyframes(job_.window, job_.keyframes, job_.poses); }
+                const double r0 = now_ms();
+                if (merge_keyframe_raycasts) {
+                    raycastWindowAndKeyframes(job_.window, job_.keyframes, job_.poses);
+                    times.localFrameRaycast += now_ms() - r0;
+                } else {
+                    raycastWindow(job_.window, job_.poses);
+                    const double r1 = now_ms();
+                    raycastKeyframes(job_.window, job_.keyframes, job_.poses);
+                    times.localFrameRaycast += r1 - r0; times.keyFrameRaycast += now_ms() - r1;
+                }
                 // the gate of the next frame's fusion: the last raycast (on the raycast stream when they run beside the iterations)
                 hip_ok(hipEventRecord((hipEvent_t)ev_raycasts_, async_raycasts && rc_stream_ ? static_cast<MapStream*>(rc_stream_)->s.stream()
                                                                                              : ms.stream()), "hipEventRecord");
@@ -892,12 +904,22 @@ void SLAMPipeline::mapWorker(int device_index) {
             if (frame_report_ms >= 0.0 && now_ms() - g_job_post_ms > 1.0)
                 fprintf(stderr, "[pipe] update %lld: raycasts enqueued %.3f ms after the hand-over (woke after %.3f)\n", (long long)seen,
                         now_ms() - g_job_post_ms, t_woke - g_job_post_ms);
+            // the stages' host time on THIS thread (the reference's stage timers, slam_pipeline.cpp:116-135, with the update moved
+            // here; read by the frame thread only after flush()); the wait for the map stream at the end is the iterations' GPU time
+            // the enqueues ran ahead of: booked under localOptimize, which it mostly is
+            const double s0 = now_ms();
             initNewGaussiansFor(localframe_raycast_window.back(), job_.curr_cam);
+            const double s1 = now_ms();
             localOptimize();
+            const double s2 = now_ms();
             removeRedundantGs();
+            const double s3 = now_ms();
             if (sample_method == "ours") checkKeyFrameError();
+            const double s4 = now_ms();
             waitAllRaycasts();
             hip_ok(hipStreamSynchronize(ms.stream()), "hipStreamSynchronize");
+            times.initNewGaussians += s1 - s0; times.localOptimize += (s2 - s1) + (now_ms() - s4); times.removeGaussian += s3 - s2;
+            times.checkError += s4 - s3;
             { std::lock_guard<std::mutex> lk(mu_); done_seq_ = seen; }
             cv_.notify_all();
         }

@@ -257,3 +257,35 @@ def test_pin_to_gpu_numa_with_only_a_local_rank():
     finally:
         os.sched_setaffinity(0, before)
         torch.set_num_threads(max(1, min(8, len(before))))
+
+
+def test_cap_host_threads_respects_the_container_quota(monkeypatch):
+    """cap_host_threads: the intra-op pool never exceeds the limit, the affinity mask or HALF the cgroup's CPU quota (the box shows
+    256 CPUs to a container that may use 16; a pool sized by the former froze the whole process for the rest of a 100 ms
+    accounting period after every parallel CPU op: LABBOOK section 14)."""
+    import builtins
+    from gps_slam_amd import dist_util
+    before = torch.get_num_threads()
+    real_open = builtins.open
+
+    def fake(quota_line):
+        def _open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                import io
+                return io.StringIO(quota_line)
+            return real_open(path, *a, **k)
+        return _open
+    try:
+        monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+        assert dist_util.cpu_quota() == 16.0
+        torch.set_num_threads(before)
+        assert dist_util.cap_host_threads(limit=64, cpus=256) == min(8, before) and torch.get_num_threads() == min(8, before)
+        monkeypatch.setattr(builtins, "open", fake("300000 100000\n"))
+        assert dist_util.cpu_quota() == 3.0 and dist_util.cap_host_threads(limit=8, cpus=256) == 1
+        monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+        assert dist_util.cpu_quota() is None
+        torch.set_num_threads(before)
+        assert dist_util.cap_host_threads(limit=4, cpus=256) == min(4, before)
+    finally:
+        monkeypatch.undo()
+        torch.set_num_threads(before)
