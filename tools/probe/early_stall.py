@@ -1,6 +1,8 @@
 """The early-run stall (one ~90 ms or ~2.08 s gap within the first ~20 frames of some whole runs): does it follow the START OF THE
 RUN or the CREATION OF THE SCENE?  Scenes are created, then the run starts after SLEEP seconds (alternating 0 / SLEEP).
-MODE = seq | ovl; REPS scenes each."""
+MODE = seq | ovl; REPS scenes each; TRIGGER = an allocation burst right before the run; the container's throttled CPU periods
+(cgroup cpu.stat) are printed per run.  GPS_BENCH_NO_THREAD_CAP=1 keeps libtorch's default intra-op pool (the stalls' cause:
+LABBOOK section 14); the stalls only reproduce with a build whose createTsdfEngine zero-fills its images with torch::zeros."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -16,12 +18,12 @@ keep = os.environ.get("KEEP", "0") == "1"       # keep every scene alive (no clo
 seq = bench.synthetic_sequence_device(640, 480, n, 1234, dev)
 kept = []
 import glob
-def kfd_stats():   # the container's CPU accounting: throttled periods so far
+def cpu_stat():   # the container's CPU accounting: throttled periods so far
     try:
         return {l.split()[0]: l.split()[1] for l in open("/sys/fs/cgroup/cpu.stat") if l.startswith(("nr_throttled", "throttled_usec"))}
     except OSError:
         return {}
-print("intra-op threads %d; cpu.stat at start: %s" % (torch.get_num_threads(), kfd_stats()), flush=True)
+print("intra-op threads %d; cpu.stat at start: %s" % (torch.get_num_threads(), cpu_stat()), flush=True)
 for rep in range(reps):
     ov = os.environ.get("MODE", "ovl") == "ovl"
     t_c = time.time()
@@ -44,9 +46,9 @@ for rep in range(reps):
     elif trig == "memset":    # first touch of a fresh 1 GB device allocation
         junk = torch.zeros(1 << 28, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    k0 = kfd_stats()
+    k0 = cpu_stat()
     tm = sc.pipe.SLAMTrainCamsTimed(sc.model, sc.cams)
-    k1 = kfd_stats()
+    k1 = cpu_stat()
     print("   throttled during the run:", {k: int(v) - int(k0.get(k, 0)) for k, v in k1.items()}, flush=True)
     ms = np.asarray(sc.pipe.frame_ms)
     w = int(ms.argmax())
