@@ -9,6 +9,11 @@ namespace gps {
 // scalars of one Adam step for one parameter tensor (host side computes them in double like libtorch)
 struct AdamScalars {
     float beta1, beta2, one_minus_b1, one_minus_b2, inv_bc2_sqrt, eps, step_size;  // step_size = lr / (1 - beta1^t)
+    // step 1: torch::optim::Adam creates exp_avg / exp_avg_sq as zeros at a parameter's first step, so the kernels take m = v = 0
+    // WITHOUT reading the buffers (same operations on the same values as with zeroed buffers) -- a host that re-creates its
+    // optimizers (raw_gs_model.cpp:654-659, every localOptimize) need not zero 2 x 59 floats per Gaussian first, and the first
+    // step reads a third less
+    int fresh;
 };
 
 static inline AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, int step) {
@@ -19,6 +24,7 @@ static inline AdamScalars adam_scalars(double lr, double beta1, double beta2, do
     a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     a.eps = (float)eps;
     a.step_size = (float)(lr / bc1);
+    a.fresh = step == 1 ? 1 : 0;
     return a;
 }
 

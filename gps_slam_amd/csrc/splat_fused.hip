@@ -222,10 +222,18 @@ __device__ __forceinline__ void adam_small_rows(const FusedAdam& ad, int i, cons
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const float* p = ad.sp[k] + (size_t)i * L[k];
-        const float* m = ad.sm[k] + (size_t)i * L[k];
-        const float* v = ad.sv[k] + (size_t)i * L[k];
 #pragma unroll
-        for (int c = 0; c < L[k]; c++, o++) { P[o] = p[c]; M[o] = m[c]; V[o] = v[c]; }
+        for (int c = 0; c < L[k]; c++, o++) { P[o] = p[c]; M[o] = 0.f; V[o] = 0.f; }
+    }
+    if (!ad.sc.fresh) {   // (uniform; step 1: the moments are zero by definition, AdamScalars::fresh)
+        o = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float* m = ad.sm[k] + (size_t)i * L[k];
+            const float* v = ad.sv[k] + (size_t)i * L[k];
+#pragma unroll
+            for (int c = 0; c < L[k]; c++, o++) { M[o] = m[c]; V[o] = v[c]; }
+        }
     }
     o = 0;
 #pragma unroll
@@ -368,7 +376,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
 #pragma unroll
                 for (int u = 0; u < ADAM_BATCH; u++) {
                     const int e = min(e0 + u * T, n4 - 1);  // unconditional loads: one clause
-                    m[u] = gm[e]; v[u] = gv[e];
+                    m[u] = make_float4(0.f, 0.f, 0.f, 0.f); v[u] = m[u];
+                    if (!ad.sc.fresh) { m[u] = gm[e]; v[u] = gv[e]; }   // (uniform: step 1 starts from zero moments, AdamScalars::fresh)
                 }
 #pragma unroll
                 for (int u = 0; u < ADAM_BATCH; u++) {
@@ -384,7 +393,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
                 }
             }
             for (int e = (n4 << 2) + threadIdx.x; e < n; e += blockDim.x) {
-                float p = sh_tile[e], m = ad.exp_avg[tile_first + e], v = ad.exp_avg_sq[tile_first + e];
+                float p = sh_tile[e], m = 0.f, v = 0.f;
+                if (!ad.sc.fresh) { m = ad.exp_avg[tile_first + e]; v = ad.exp_avg_sq[tile_first + e]; }
                 adam_update(ad.sc, g_tile[e], m, v, p);
                 ad.exp_avg[tile_first + e] = m; ad.exp_avg_sq[tile_first + e] = v; ad.param[tile_first + e] = p;
                 if (nf.viewmat) sh_tile[e] = p;

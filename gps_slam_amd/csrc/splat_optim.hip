@@ -78,10 +78,11 @@ struct AdamArgs {
     int64_t seg_end[GPS_ADAM_MAX_SEGMENTS];  // exclusive prefix end in the flattened index space
     int n_segments;
     float beta1, beta2, one_minus_b1, one_minus_b2, inv_bc2_sqrt, eps;
+    int fresh;   // step 1: the moments are zero by definition and not read (AdamScalars::fresh)
 };
 
 __device__ __forceinline__ void adam_update(const AdamArgs& a, int s, float g, float& m, float& v, float& p) {
-    gps::AdamScalars sc = {a.beta1, a.beta2, a.one_minus_b1, a.one_minus_b2, a.inv_bc2_sqrt, a.eps, a.step_size[s]};
+    gps::AdamScalars sc = {a.beta1, a.beta2, a.one_minus_b1, a.one_minus_b2, a.inv_bc2_sqrt, a.eps, a.step_size[s], a.fresh};
     gps::adam_update(sc, g, m, v, p);
 }
 
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         const int64_t i = i4 * 4;
         if (i + 4 <= sg.numel) {
             const float4 g = *reinterpret_cast<const float4*>(sg.grad + i);
-            float4 m = *reinterpret_cast<float4*>(sg.exp_avg + i);
-            float4 v = *reinterpret_cast<float4*>(sg.exp_avg_sq + i);
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
+            if (!a.fresh) { m = *reinterpret_cast<float4*>(sg.exp_avg + i); v = *reinterpret_cast<float4*>(sg.exp_avg_sq + i); }
             float4 p = *reinterpret_cast<float4*>(sg.param + i);
             adam_update(a, s, g.x, m.x, v.x, p.x); adam_update(a, s, g.y, m.y, v.y, p.y);
             adam_update(a, s, g.z, m.z, v.z, p.z); adam_update(a, s, g.w, m.w, v.w, p.w);
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
             *reinterpret_cast<float4*>(sg.param + i) = p;
         } else {
             for (int64_t j = i; j < sg.numel; j++) {
-                float m = sg.exp_avg[j], v = sg.exp_avg_sq[j], p = sg.param[j];
+                float m = 0.f, v = 0.f, p = sg.param[j];
+                if (!a.fresh) { m = sg.exp_avg[j]; v = sg.exp_avg_sq[j]; }
                 adam_update(a, s, sg.grad[j], m, v, p);
                 sg.exp_avg[j] = m; sg.exp_avg_sq[j] = v; sg.param[j] = p;
             }
@@ -188,6 +190,7 @@ int gps_adam_step(const gps_adam_segment* segments, int n_segments, double beta1
     a.one_minus_b2 = (float)(1.0 - beta2);
     a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     a.eps = (float)eps;
+    a.fresh = step == 1 ? 1 : 0;
     adam_kernel<<<min((int64_t)4096, (int64_t)gps_div_up(run, 256)), 256, 0, (hipStream_t)stream>>>(a);
     GPS_LAUNCH_CHECK();
     return GPS_OK;

@@ -369,10 +369,8 @@ class RawGaussianModel:
         if self._opt is None or self._opt["cap"] != p.cap:
             mk = lambda: [torch.zeros_like(p._buf[n]) for n in p.NAMES]
             self._opt = dict(m=mk(), v=mk(), g=mk(), cap=p.cap)
-        else:
-            for k in ("m", "v"):
-                for t in self._opt[k]:
-                    t[:p.N].zero_()
+        # (an existing state is NOT zeroed: step 1 of gps_splat_train_step / gps_adam_step takes the moments as zero without reading
+        # them and writes every live row -- include/gps_slam_hip.h, gps_adam_step)
         self._opt.update(lrs=lrs, step=0)
 
     def grads(self):

@@ -374,20 +374,10 @@ void RawGaussianModel::initOptimizers(int max_iterations, float scene_scale) {
             adam_g_.push_back(torch::zeros_like(p.buffer(k)));
         }
         adam_cap_ = cap;
-    } else {
-        // fresh state for the live rows: one launch for the 12 tensors (lengths rounded up to whole float4s inside the
-        // capacity-sized buffers)
-        const int64_t N = getGaussianNum();
-        float* ptrs[12];
-        int64_t numels[12];
-        for (int k = 0; k < 6; k++) {
-            const int64_t row = adam_m_[k].numel() / std::max<int64_t>(1, adam_m_[k].size(0));
-            const int64_t n = std::min<int64_t>(adam_m_[k].numel(), (N * row + 3) / 4 * 4);
-            ptrs[2 * k] = fptr(adam_m_[k]); ptrs[2 * k + 1] = fptr(adam_v_[k]);
-            numels[2 * k] = numels[2 * k + 1] = n;
-        }
-        if (N > 0) check(gps_zero_floats(12, ptrs, numels, current_stream()), "gps_zero_floats");
     }
+    // (fresh state for the live rows: nothing to do -- step 1 of every route (gps_splat_train_step, gps_adam_step) takes the
+    // moments as zero without reading them and writes them for every live row; rounds 1-4 zeroed 2 x 59 floats per Gaussian here,
+    // 50 us per keyframe at 245 k)
     pending_prunes_.clear();  // the state those would have compacted has just been replaced
     lrs_[0] = means_lr * scene_scale; lrs_[1] = scales_lr; lrs_[2] = quats_lr; lrs_[3] = featuresDc_lr;
     lrs_[4] = featuresRest_lr; lrs_[5] = opacities_lr;

@@ -289,7 +289,10 @@ GPS_API int gps_zero_floats(int n, float *const *ptrs, const int64_t *numels, gp
  * torch::optim::Adam (raw_gs_model.cpp:654-705; eps 1e-15, betas (0.9,0.999), no weight decay):
  *   m = m*b1 + g*(1-b1); v = v*b2 + g*g*(1-b2);
  *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
- * step is the 1-based step count t. */
+ * step is the 1-based step count t.  step == 1 is the first step of a freshly created optimizer: libtorch creates exp_avg /
+ * exp_avg_sq as zeros then, and so do these kernels -- the two buffers are WRITTEN but NOT READ at step 1 (here, in
+ * gps_gauss_preprocess_bwd_adam and in gps_splat_train_step), whatever they hold: a host that re-creates its optimizers need not
+ * zero them (gps_zero_floats) first. */
 GPS_API int gps_adam_step(const gps_adam_segment *segments, int n_segments, double beta1, double beta2, double eps, int step,
                   gps_stream stream);
 
@@ -490,7 +493,8 @@ GPS_API int gps_splat_discard_prefetch(const gps_splat_step *a, gps_stream strea
 /* gesForward up to the rasterizer (preprocess -> binning -> ges forward): fills render_colors / weight_sum. */
 GPS_API int gps_splat_render(const gps_splat_step *a, gps_stream stream);
 
-/* forward + L1 loss + backward + fused Adam step number `adam_step` (1-based); `loss` must be zeroed by the caller. */
+/* forward + L1 loss + backward + fused Adam step number `adam_step` (1-based; 1 = fresh optimizers: the moment buffers are
+ * written, not read -- see gps_adam_step); `loss` must be zeroed by the caller. */
 GPS_API int gps_splat_train_step(const gps_splat_step *a, int adam_step, gps_stream stream);
 
 /* ------------------------------------------------------------------ */

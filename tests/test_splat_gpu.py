@@ -508,6 +508,26 @@ def test_record_streaming_forward_equals_lds_forward(N, W, H):
         assert d.max().item() < 0.05
 
 
+def test_adam_step_one_writes_the_moments_without_reading_them():
+    """Step 1 is the first step of a fresh torch::optim::Adam (state created as zeros): gps_adam_step takes m = v = 0 without
+    reading exp_avg / exp_avg_sq, so buffers full of NaN give the result of zeroed ones, and step 2 carries on from what step 1
+    wrote (sizes with a scalar tail included)."""
+    from gps_slam_amd import gsplat_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    shapes = [(40001, 3), (40001, 15, 3), (7,), (40001, 1)]
+    lrs = [1e-3, 1.25e-4, 5e-2, 5e-3]
+    P = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+    Pz = [p.clone() for p in P]
+    M, V = [torch.full_like(p, float("nan")) for p in P], [torch.full_like(p, float("nan")) for p in P]
+    Mz, Vz = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
+    for step in (1, 2):
+        G = [torch.randn(s, generator=gen).to(_dev()) * 1e-3 for s in shapes]
+        ops.adam_step(P, G, M, V, lrs, step)
+        ops.adam_step(Pz, G, Mz, Vz, lrs, step)
+        for x, y in zip(P + M + V, Pz + Mz + Vz):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
 def test_fused_adam_is_bit_identical_to_separate_step():
     """gps_gauss_preprocess_bwd_adam (Adam step inside the backward kernel: sh_rest on the LDS tiles, optionally the five
     small tensors per thread) must leave exactly the parameters / exp_avg / exp_avg_sq that gps_gauss_preprocess_bwd +

@@ -371,3 +371,40 @@ def test_sh_degree_4_preprocess_and_train_step(fuse):
     torch.cuda.synchronize()
     after = model.opt_gs_params.featuresRest
     assert torch.isfinite(after).all() and (after != before).any()
+
+
+@pytest.mark.parametrize("fuse", [0, 1, 2])
+def test_first_step_after_init_optimizers_does_not_read_the_moments(fuse):
+    """initOptimizers re-creates the Adam state (raw_gs_model.cpp:654-659, every localOptimize); step 1 of every route takes
+    exp_avg / exp_avg_sq as zero WITHOUT reading the buffers (include/gps_slam_hip.h, gps_adam_step), so the hosts do not zero
+    them: a model whose moment buffers hold NaN after initOptimizers must end three train steps with exactly the parameters and
+    moments of one whose buffers hold zeros -- in all three Adam modes, and again after a second initOptimizers."""
+    from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
+    N, W, H = 30011, 320, 240
+    g = scenes.random_gaussians(N, seed=7, scale_range=(0.004, 0.03))
+    c2w, K = scenes.default_camera(W, H, seed=7)
+    gen = torch.Generator().manual_seed(3)
+    gt, base = torch.rand((H, W, 3), generator=gen).to(DEV), torch.rand((H, W, 3), generator=gen).to(DEV)
+    ref = (torch.rand((H, W, 1), generator=gen) * 4).to(DEV)
+    cam = Camera(0, W, H, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), c2w, image=gt, device=DEV)
+    models = []
+    for poison in (False, True):
+        m = SLAMGaussianModel(dict(capacity=1 << 15, sh_degree=3, fuse_sh_rest_adam=fuse), device=DEV)
+        m.add_params(dict(means=T(g["means"]), scales=T(g["log_scales"]), quats=T(g["quats"]), featuresDc=T(g["sh"][:, 0].copy()),
+                          featuresRest=T(g["sh"][:, 1:].copy()), opacities=T(g["opac_logit"])))
+        for rnd in range(2):
+            m.initOptimizers(-1, 1.0)
+            if poison:
+                for t in m._opt["m"] + m._opt["v"]:
+                    t.fill_(float("nan"))
+            for _ in range(3):
+                m.train_step(cam, ref, base, gt)
+        torch.cuda.synchronize()
+        models.append(m)
+    a, b = models
+    for x, y in zip(a.opt_gs_params._buf.values() if isinstance(a.opt_gs_params._buf, dict) else a.opt_gs_params._buf,
+                    b.opt_gs_params._buf.values() if isinstance(b.opt_gs_params._buf, dict) else b.opt_gs_params._buf):
+        assert torch.equal(x[:N], y[:N])
+    for k in ("m", "v"):
+        for x, y in zip(a._opt[k], b._opt[k]):
+            assert torch.isfinite(y[:N]).all() and torch.equal(x[:N], y[:N])
