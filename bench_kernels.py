@@ -240,7 +240,7 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
                                           ptr(cg["viewmat"]), ptr(cg["K"]), ptr(cg["cam_pos"]), W, H, model.eps2d, ptr(B["radii"]),
                                           ptr(B["conics"]), ptr(B["v_means2d"]), ptr(B["v_conics"]), ptr(B["v_colors"]),
                                           ptr(B["v_opacities"]), null, null, null, null, null, null, ptr(o["m"][4]), ptr(o["v"][4]), 0.0,
-                                          seg, 0.9, 0.999, 1e-15, 1, sp)
+                                          seg, 0.9, 0.999, 1e-15, 2, sp)   # (step 2: the steady iteration -- step 1 does not read the moments)
 
     marker = lambda: torch.cuda._sleep(1)   # (tools/profile.sh finds each loop's launches behind its marker)
     t = {}
