@@ -105,6 +105,10 @@ struct StripPix {
 #define GPS_STRIP_PIPE 0
 #endif
 GPS_TUNABLE_REPORT(GPS_STRIP_PIPE, 0);
+#ifndef GPS_STRIP_COOP4
+#define GPS_STRIP_COOP4 1
+#endif
+GPS_TUNABLE_REPORT(GPS_STRIP_COOP4, 1);
 #ifndef GPS_STRIP_WAVES
 #define GPS_STRIP_WAVES 6
 #endif
@@ -116,9 +120,16 @@ constexpr uint32_t STRIP_OOB = 0x7FFFFFF0u;  // a byte offset past every buffer:
 // The 64-lane class covers every radius above 32: a half box wider than 64 columns takes several passes over the same task
 // (pass p: columns 64 p + l of each half); pass 0 stores the Gaussian's row, a later pass adds to it.  Returns whether the
 // task needs another pass.
+// `share` != nullptr (the 64-lane class only): the FOUR waves of the workgroup run the same task, wave w on rows Q_lo + w, + 4,
+// ...; each leaves its ten totals in share[w][] and wave 0 adds them in wave order and stores the row (a workgroup barrier on
+// both sides: every wave of the workgroup makes the same calls).  A radius-100 Gaussian is 2 passes x 200 rows = 400 dependent
+// row trips -- as long as everything else a wave does in a launch at 1200x680 (tools/probe/radius_hist.py): dealt to ONE wave it
+// set the kernel's length; shared by four it is 100.
 __device__ __forceinline__ bool strip_task(const float4* __restrict__ recs, const int32_t* __restrict__ radii,
                                            const int32_t* __restrict__ ids, int n_ids, int task, int cls, int pass,
-                                           const StripPix& px, float* __restrict__ v_rows, int lane) {
+                                           const StripPix& px, float* __restrict__ v_rows, int lane,
+                                           float (*share)[12] = nullptr, int wave_in_wg = 0) {
+    const int row_step = share ? 4 : 1, row_phase = share ? wave_in_wg : 0;
     const int gw_log2 = cls + 2;
     const int l = lane & ((1 << gw_log2) - 1);
     const int slot = (task << (6 - gw_log2)) + (lane >> gw_log2);
@@ -151,15 +162,16 @@ __device__ __forceinline__ bool strip_task(const float4* __restrict__ recs, cons
         const v2f dx = {mx - ((float)jA + 0.5f), mx - ((float)jB + 0.5f)};
         const v2f A2 = hA * dx * dx, Bd = bL * dx;
         v2f S0 = {0.f, 0.f}, S1 = S0, S2 = S0;
-        float pyf = (float)(y0 + Q_lo) + 0.5f;
-        uint32_t offA = (uint32_t)((y0 + Q_lo) * px.W + jA) * 16u, offB = offA + (uint32_t)r * 16u;
-        const uint32_t row_bytes = (uint32_t)px.W * 16u;
+        float pyf = (float)(y0 + Q_lo + row_phase) + 0.5f;
+        uint32_t offA = (uint32_t)((y0 + Q_lo + row_phase) * px.W + jA) * 16u, offB = offA + (uint32_t)r * 16u;
+        const uint32_t row_bytes = (uint32_t)px.W * 16u * (uint32_t)row_step;
+        const float row_stepf = (float)row_step;
         // One row of the lane's two columns in two halves: eval() needs the record only and ends by ISSUING the row's four
         // gathers; accum() consumes them.  GPS_STRIP_PIPE = 1: the next row is evaluated (and its gathers issued) before the
         // current one is accumulated, so a wave always has two rows' gathers in flight (two Row sets, trip unrolled by two:
         // no register moves); an odd row count is padded with a row no lane is on (it reads nothing).
         struct Row { float dy, alA, alB; v2f ov; bool onA, onB; float4 vcA, vcB; float2 pA, pB; };
-        int q = Q_lo;
+        int q = Q_lo + row_phase;
         auto eval = [&](Row& R) {
             R.dy = my - pyf;
             const bool rowok = (uint32_t)(q - q_lo) < (uint32_t)span;
@@ -175,9 +187,9 @@ __device__ __forceinline__ bool strip_task(const float4* __restrict__ recs, cons
             R.vcB = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(px.rc, fB, 0, 0));
             R.pA = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(px.p2, fA >> 1, 0, 0));
             R.pB = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(px.p2, fB >> 1, 0, 0));
-            pyf += 1.0f;
+            pyf += row_stepf;
             offA += row_bytes; offB += row_bytes;
-            ++q;
+            q += row_step;
         };
         auto accum = [&](const Row& R) {
             // (a lane that failed the test read zeros: cut = 0 < depth, so it fails here as well)
@@ -195,8 +207,8 @@ __device__ __forceinline__ bool strip_task(const float4* __restrict__ recs, cons
             S2 += vsy * R.dy;
         };
 #if GPS_STRIP_PIPE
-        if (Q_lo < Q_hi) {
-            const int n2 = (Q_hi - Q_lo + 1) & ~1;
+        if (Q_lo + row_phase < Q_hi) {
+            const int n2 = ((Q_hi - Q_lo - row_phase + row_step - 1) / row_step + 1) & ~1;
             Row R0, R1;
             eval(R0);
 #pragma unroll 1
@@ -226,6 +238,19 @@ __device__ __forceinline__ bool strip_task(const float4* __restrict__ recs, cons
     }
     Totals t = {{c0, c1, c2, c3, ka, kb, kc, gx, gy, gop}};
     group_sums(t, cls);
+    if (share) {   // (wave-uniform)
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) share[wave_in_wg][k] = t.v[k];
+        }
+        __syncthreads();
+        if (wave_in_wg == 0) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) t.v[k] = ((share[0][k] + share[1][k]) + share[2][k]) + share[3][k];
+        }
+        __syncthreads();   // (the next pass / task overwrites the slots)
+        if (wave_in_wg != 0) return cls == 4 && __builtin_amdgcn_readfirstlane(wave_max_i(r)) > 64 * (pass + 1);
+    }
     if (have && l == 0) {
         float4* row = reinterpret_cast<float4*>(v_rows + 12 * (size_t)id);
         float4 o0 = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]), o1 = make_float4(t.v[4], t.v[5], t.v[6], t.v[7]),
@@ -275,8 +300,22 @@ __global__ __launch_bounds__(256, GPS_STRIP_WAVES) void raster_ges_bwd_strip_ker
         t_cnt[k] = min(tasks, t_lo[k] + per_xcd) - t_lo[k];
         total += t_cnt[k];
     }
+#if GPS_STRIP_COOP4
+    // the 64-lane class: one task per WORKGROUP at a time, its rows shared by the four waves (strip_task, `share`)
+    __shared__ float share[4][12];
+    for (int t4 = slot; t4 < t_cnt[NCLS - 1]; t4 += wgs_per_xcd) {
+        int pass = 0;
+        while (strip_task(a.recs, a.radii, a.cls_ids + (NCLS - 1) * (size_t)a.cls_stride, n_ids[NCLS - 1], t_lo[NCLS - 1] + t4, NCLS - 1, pass,
+                          px, a.v_rows, lane, share, wave_in_wg))
+            ++pass;
+    }
+    total -= t_cnt[NCLS - 1];
+    constexpr int TOP = NCLS - 2;
+#else
+    constexpr int TOP = NCLS - 1;
+#endif
     for (int f = wave_in_xcd; f < total; f += waves_per_xcd) {
-        int rest = f, cls = NCLS - 1;   // widest class first
+        int rest = f, cls = TOP;   // widest class first
         while (cls > 0 && rest >= t_cnt[cls]) { rest -= t_cnt[cls]; --cls; }
         cls = __builtin_amdgcn_readfirstlane(cls);
         int pass = 0;
