@@ -314,6 +314,9 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     ap.add_argument("--whole-run-frames", type=int, default=1000,
                     help="frames of the whole-sequence run from frame 0 (the reference's own FPS definition; N = 1 only, after the "
                          "headline windows; 0 = skip): config.whole_run_fps / whole_run_fps_sequential")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL record (tens of kilobytes) as the stdout line, as rounds 1-5 did, instead of the compact one; "
+                         "the full record is written to bench_full.json either way")
     ap.add_argument("--gt-pose", action="store_true",
                     help="use_gt_pose: true (what every shipped config sets: the tracker is off, poses are given).  Default: the "
                          "depth-only ExtendedTracker estimates the pose of every frame, as BASELINE configs[2] "
@@ -452,13 +455,91 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
         # (the reference's own whole-run FPS, the sequential schedule, the other single-GPU configurations, the keyframe
         # thresholds, the frame / iteration HBM fractions, which A/B switches were set) is one of them
         out["config"] = dict(flat, **out["config"])
-        print(json.dumps(out), flush=True)
+        emit(out, full_line=args.full_line, side_dir=os.environ.get("GPS_BENCH_SIDE_DIR"))
     # ranks != 0 wait here while rank 0 runs its post-window measurements and prints: no rank tears the process group down
     # (or exits, which torch.distributed.run treats as the job ending) under another rank's feet
     grp.barrier()
     if scene is not None:
         scene.close()
     grp.close()
+
+
+LINE_LIMIT = 4096   # bytes of the stdout line: the driver's record of round 5 (23 KB line) came back unparsed, round 4's 16 KB parsed
+
+
+def _finite(o, path="line"):
+    """every float of the record is finite: json.dumps would print NaN / Infinity, which are not JSON and which a strict parser
+    (the driver's) rejects together with the whole line"""
+    if isinstance(o, float):
+        assert o == o and abs(o) != float("inf"), "%s is %r: not representable in JSON" % (path, o)
+    elif isinstance(o, dict):
+        for k, v in o.items():
+            _finite(v, "%s.%s" % (path, k))
+    elif isinstance(o, (list, tuple)):
+        for i, v in enumerate(o):
+            _finite(v, "%s[%d]" % (path, i))
+
+
+def _sig(v, digits=6):
+    """floats to 6 significant digits (the line is for reading and for the driver's record; bench_full.json keeps every bit)"""
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v))
+    return v
+
+
+def compact_line(out):
+    """The stdout line of the contract, <= LINE_LIMIT bytes: the headline fields, `config` = workload + the flat scalars (the
+    reference's own whole-run FPS, both schedules, the other single-GPU configurations, thresholds, A/B switches), `roofline` =
+    the dominant kernel's in-loop figures + the frame / iteration fractions, `cpu_baseline` = the reference CPU engine's rate.
+    Everything nested (per-kernel tables, per-window lists, notes) stays in bench_full.json."""
+    line = {k: _sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data")}
+    cfg = out.get("config", {})
+    c = {"workload": cfg.get("workload", "synthetic RGB-D SLAM frames, independent scene per GPU")}
+    for k, v in cfg.items():
+        if k != "workload" and isinstance(v, (int, float, bool)) or (isinstance(v, str) and k in ("schedule", "host", "env_overrides", "placement")):
+            c[k] = _sig(v)
+    q = cfg.get("quality") or {}
+    for k in ("render_psnr_db_vs_input", "tsdf_colour_psnr_db_vs_input", "render_psnr_db_vs_oracle"):
+        if isinstance(q.get(k), (int, float)):
+            c[k] = _sig(float(q[k]), 5)
+    c["full_record"] = "bench_full.json"
+    line["config"] = c
+    r = out.get("roofline")
+    if r:
+        keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us", "timed_in",
+                "launches_timed", "frac_alone", "avg_launch_us_alone", "measured_copy_GBs", "traffic_calibrated")
+        rr = {k: _sig(r[k]) for k in keep if k in r}
+        rr["frame_frac"], rr["iteration_frac"] = _sig(r["frame"]["frac"]), _sig(r["iteration"]["frac"])
+        rr["frame_ms"], rr["iteration_us"] = _sig(r["frame"]["ms"]), _sig(r["iteration"]["avg_us"])
+        line["roofline"] = rr
+    b = out.get("cpu_baseline")
+    if b:
+        bb = {k: _sig(b[k]) for k in ("value", "unit", "cores", "threads", "kind", "tracked_value", "cpu_quota") if k in b}
+        bb["sample"] = str(b.get("sample", ""))[:300]
+        line["cpu_baseline"] = bb
+    return line
+
+
+def emit(out, full_line=False, side_dir=None):
+    """rank 0: the full record to bench_full.json (beside this file; also under gpurun_out/ when that exists, so that a gpurun
+    call brings it back), ONE compact JSON line to stdout as the last thing printed there"""
+    _finite(out)
+    full = json.dumps(out, allow_nan=False)
+    for d in ([side_dir] if side_dir else [ROOT, os.path.join(ROOT, "gpurun_out")]):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError as e:   # (a read-only checkout must not cost the line)
+                print("bench_full.json not written in %s: %s" % (d, e), file=sys.stderr)
+    # (the full record is NOT echoed to stderr: a driver that captures stdout and stderr into one buffer would then see a 20+ KB
+    # line next to -- possibly after -- the compact one)
+    print("bench: full record (%d bytes) in bench_full.json" % len(full), file=sys.stderr, flush=True)
+    text = full if full_line else json.dumps(compact_line(out), allow_nan=False, separators=(",", ":"))
+    assert full_line or len(text.encode()) <= LINE_LIMIT, "compact line is %d bytes (> %d)" % (len(text.encode()), LINE_LIMIT)
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def _time_scene(factory, first, K, NW):

@@ -182,7 +182,8 @@ def _main_worker(rank, world, port, out_dir):
     import io
     import json
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), GPS_BENCH_SIDE_DIR=os.path.join(out_dir, "side%d" % rank))
+    os.makedirs(os.environ["GPS_BENCH_SIDE_DIR"])
     import bench
     scenes = []
 
@@ -195,6 +196,37 @@ def _main_worker(rank, world, port, out_dir):
                    need_gpu=False, extras=False)
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
         json.dump({"stdout": buf.getvalue(), "log": [s.log for s in scenes], "overlap": [s.overlap for s in scenes]}, f)
+
+
+def _reject_constant(name):
+    raise ValueError("%s is not JSON" % name)
+
+
+def test_compact_line_of_a_full_record_fits_and_is_strict_json():
+    """bench.compact_line on a real full record (round 5's 23 KB line, profiles/r05_bench_line.json): under 4 KB, parses with
+    NaN / Infinity rejected, carries the headline, the flat scalars, `roofline` with bound / achieved / peak / unit / frac /
+    traffic and `cpu_baseline` with value / unit / cores / kind / sample; emit() refuses a record holding a NaN."""
+    import io
+    import json
+    import contextlib
+    import bench
+    full = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r05_bench_line.json")))
+    text = json.dumps(bench.compact_line(full), allow_nan=False, separators=(",", ":"))
+    assert len(text.encode()) < 4096
+    line = json.loads(text, parse_constant=_reject_constant)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line, k
+    assert abs(line["value"] - full["value"]) < 1e-4 * full["value"] and line["dtype"] == "f32"
+    assert all(not isinstance(v, (dict, list)) for v in line["config"].values())
+    for k in ("workload", "sequential_fps", "overlap_fps", "whole_run_fps", "cfg1_fps", "cfg3_fps", "cfgR_fps", "keyframe_theta_deg", "gaussians"):
+        assert k in line["config"], k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us", "frame_frac", "iteration_frac"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample", "threads", "tracked_value"):
+        assert k in line["cpu_baseline"], k
+    bad = dict(full, value=float("nan"))
+    with pytest.raises(AssertionError), contextlib.redirect_stdout(io.StringIO()):
+        bench.emit(bad, side_dir="/nonexistent")
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -215,15 +247,22 @@ def test_bench_main_end_to_end_on_gloo(tmp_path, world):
         assert p.exitcode == 0
     res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
     assert all(res[r]["stdout"].strip() == "" for r in range(1, world))     # only rank 0 prints
-    lines = [l for l in res[0]["stdout"].splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == world and out["steps"] == 10 and out["warmup"] == 5 and out["scaling"] == "weak"
-    assert "cpu_baseline" not in out and out["higher_is_better"] is True and out["unit"] == "frames/s"
-    assert out["config"]["windows"] == 3 and len(out["config"]["windows_ms_per_step"]) == 3
+    lines = [l for l in res[0]["stdout"].splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")                      # ONE line, the last (and only) thing on stdout
+    assert len(lines[0].encode()) < 4096                                     # (round 5's 23 KB line came back from the driver unparsed)
+    line = json.loads(lines[0], parse_constant=_reject_constant)
+    assert line["n_gpus"] == world and line["steps"] == 10 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert "cpu_baseline" not in line and line["higher_is_better"] is True and line["unit"] == "frames/s"
+    assert line["config"]["windows"] == 3 and line["config"]["schedule"] == "overlap" and "workload" in line["config"]
+    assert all(not isinstance(v, (dict, list)) for v in line["config"].values())   # flat scalars only
     # the slowest rank sets the time: ~2 ms x world per frame (rank 0 alone needs ~2 ms) -> world x 10 frames / that for the job
-    assert 1.95 * world < out["ms_per_step"] < 4.0 * world, out["ms_per_step"]
-    assert abs(out["value"] - world * 10 / (out["ms_per_step"] * 1e-3 * 10)) < 1e-6 * out["value"]
+    assert 1.95 * world < line["ms_per_step"] < 4.0 * world, line["ms_per_step"]
+    assert abs(line["value"] - world * 10 / (line["ms_per_step"] * 1e-3 * 10)) < 1e-4 * line["value"]
+    # the full record: ONE side file per job, written by rank 0 only
+    assert [os.path.exists(tmp_path / ("side%d" % r) / "bench_full.json") for r in range(world)] == [True] + [False] * (world - 1)
+    out = json.loads(open(tmp_path / "side0" / "bench_full.json").read(), parse_constant=_reject_constant)
+    assert out["n_gpus"] == world and abs(out["value"] - line["value"]) < 1e-4 * out["value"]
+    assert len(out["config"]["windows_ms_per_step"]) == 3
     assert sorted(out["config"]["schedules"]) == ["overlap", "sequential"]
     assert out["config"]["stats"]["frames"] == 10                           # stats of ONE window
     # every rank ran the same frame ranges: prologue + warm-up to frame 30, then three 10-frame windows, per schedule

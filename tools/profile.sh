@@ -6,7 +6,8 @@
 #      counter groups in SEPARATE --pmc passes (one counter group each, MI355X guide "rocprofv3 PMC slots"; never combined with
 #      trace domains other than --kernel-trace) over the same bench command; the counters of bench_kernels.roofline_section's
 #      micro-benchmark loops (each behind its own marker kernel) -> gpurun_out/pmc_<kernel>.json (tools/pmc_extract.py)
-#   3. the bench line itself (which then picks the PMC files up) -> gpurun_out/<tag>_bench_line.json
+#   3. the bench line itself (which then picks the PMC files up) -> gpurun_out/<tag>_bench_line.json (compact, as printed) and
+#      gpurun_out/<tag>_bench_full.json (the full record)
 # Copy the files into profiles/ and commit them.
 TAG=${1:-rXX}
 STEPS=${STEPS:-20}
@@ -14,7 +15,7 @@ WARMUP=${WARMUP:-5}
 WINDOWS=${WINDOWS:-5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-CMD="python bench.py --steps $STEPS --warmup $WARMUP --windows $WINDOWS --no-cpu-baseline --no-oracle-psnr --no-other-configs --whole-run-frames 0"
+CMD="python bench.py --steps $STEPS --warmup $WARMUP --windows $WINDOWS --no-cpu-baseline --no-oracle-psnr --no-other-configs --whole-run-frames 0 --full-line"
 rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o bench -- $CMD > gpurun_out/bench_prof.log 2>&1
 {
   echo "# $TAG -- rocprofv3 --kernel-trace --stats summary (MI355X, gfx950)"
@@ -36,6 +37,9 @@ python tools/pmc_extract.py gpurun_out/pmc_FETCH_SIZE.log /tmp/prof_FETCH_SIZE /
 cat gpurun_out/pmc_extract.log
 # the bench line with the fresh PMC files in place (bench_kernels reads profiles/pmc_*.json)
 mkdir -p profiles && cp gpurun_out/pmc/pmc_*.json profiles/ 2>/dev/null
-python bench.py --steps $STEPS --warmup $WARMUP --windows $WINDOWS > gpurun_out/bench_full.log 2>&1
-grep '^{"metric"' gpurun_out/bench_full.log | tail -1 > gpurun_out/${TAG}_bench_line.json
-cut -c1-400 gpurun_out/${TAG}_bench_line.json
+# (the driver's command; stdout = ONE compact line, the full record goes to gpurun_out/bench_full.json)
+python bench.py --steps $STEPS --warmup $WARMUP --windows $WINDOWS > gpurun_out/bench_stdout.log 2> gpurun_out/bench_stderr.log
+tail -1 gpurun_out/bench_stdout.log > gpurun_out/${TAG}_bench_line.json
+cp gpurun_out/bench_full.json gpurun_out/${TAG}_bench_full.json
+wc -c gpurun_out/${TAG}_bench_line.json gpurun_out/${TAG}_bench_full.json
+cat gpurun_out/${TAG}_bench_line.json
