@@ -330,7 +330,8 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     marker = (lambda: torch.cuda._sleep(1)) if need_gpu else _no_gpu_sync  # spin_kernel: phase marker for tools/prof_summary.py
     W, H, K, Wm, NW = args.width, args.height, args.steps, args.warmup, max(1, args.windows)
     first, prologue = timed_window(Wm)
-    n_frames = first + NW * K
+    in_loop = extras and need_gpu   # one more K-frame window per schedule with every launch of the frame's kernels event-timed (roofline)
+    n_frames = first + (NW + (1 if in_loop else 0)) * K
     seed = scene_seed(rank)
     seq = None
     if scene_factory is None:
@@ -380,6 +381,13 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
         order = sorted(range(NW), key=lambda i: windows[i]["seconds"])
         med = windows[order[NW // 2]]  # the median window (upper median for an even count): every reported number is of ONE window
         ms = [w["ms_per_step"] for w in windows]
+        if in_loop and rank == 0:
+            from bench_kernels import in_loop_kernel_times
+            lo = first + NW * K
+            marker()   # (the in-loop window between its own pair of phase markers: tools/prof_summary.py tabulates it separately)
+            med = dict(med, schedule=sched, in_loop=in_loop_kernel_times(lambda: scene.run(lo, lo + K), K))
+            marker()
+            dev_sync()
         results[sched] = dict(med, windows_ms_per_step=ms, window_spread=(max(ms) - min(ms)) / med["ms_per_step"],
                               window_spread_detrended=_detrended_spread(ms), windows_gaussians=[w["gaussians"] for w in windows],
                               windows_device_mallocs=[w["device_mallocs"] for w in windows])
@@ -394,7 +402,7 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
             "dtype": "f32", "data": "synthetic",
             "config": {"keyframe_thresholds": {"theta_deg": args.keyframe_theta, "trans_m": args.keyframe_trans,
                                                "reference": {"theta_deg": 30.0, "trans_m": 0.3}},
-                       "schedule": main_sched, "windows": NW, "windows_ms_per_step": results[main_sched]["windows_ms_per_step"],
+                       "schedule": main_sched, "windows": NW, "marker_windows_per_schedule": NW + (1 if in_loop else 0), "windows_ms_per_step": results[main_sched]["windows_ms_per_step"],
                        "window_spread": results[main_sched]["window_spread"],
                        "window_spread_detrended": results[main_sched]["window_spread_detrended"],
                        "windows_gaussians": results[main_sched]["windows_gaussians"],

@@ -21,6 +21,40 @@ def _time_launches(fn, n, stream):
     return start.elapsed_time(end) * 1e-3 / n
 
 
+TIMED_KINDS = ("preprocess_bwd_kernel", "preprocess_fwd_kernel", "raster_ges_fwd_pk_kernel", "raster_ges_bwd_strip_kernel",
+               "sb_scan_kernel", "sb_scatter_kernel", "integrate_kernel", "raycast_kernel")   # == GPS_TIMED_* (include/gps_slam_hip.h)
+
+
+def in_loop_kernel_times(run, frames):
+    """Per-kernel launch durations INSIDE the running schedule: gps_launch_timing_start, `run()` (K SLAM frames of the scene the
+    timed windows just measured, same schedule, same streams and host threads), gps_launch_timing_stop.  Every launch of the
+    instrumented kernels carries a start and a stop event bound to its own dispatch (hipExtLaunchKernelGGL,
+    csrc/launch_timing.hpp: the kernel's begin / end timestamps, as a rocprofv3 kernel trace reports them); this is what the
+    `roofline` of the line is priced with -- the kernels-alone micro-loops of roofline_section run with nothing beside them and warm
+    inputs.  The window is an extra one after the timed windows."""
+    from gps_slam_amd._lib import lib
+    assert lib.gps_launch_timing_start(1 << 16) == 0
+    t0 = time.perf_counter()
+    try:
+        run()
+        torch.cuda.synchronize()
+    finally:
+        rc = lib.gps_launch_timing_stop()
+    wall = time.perf_counter() - t0
+    assert rc == 0, "gps_launch_timing_stop: %d" % rc
+    out = {"frames": frames, "window_ms_per_step": 1e3 * wall / frames, "kernels": {}}
+    for kind, name in enumerate(TIMED_KINDS):
+        tot, totf, mx = C.c_double(), C.c_double(), C.c_double()
+        n, nf, dropped = C.c_int64(), C.c_int64(), C.c_int64()
+        assert lib.gps_launch_timing_read(kind, C.byref(tot), C.byref(n), C.byref(totf), C.byref(nf), C.byref(mx), C.byref(dropped)) == 0
+        assert dropped.value == 0, "launch timing ring overflowed"
+        if n.value:
+            out["kernels"][name] = {"launches": n.value, "avg_us": tot.value / n.value, "us_per_frame": tot.value / frames, "max_us": mx.value,
+                                    "launches_flagged": nf.value, "avg_us_flagged": totf.value / nf.value if nf.value else None,
+                                    "avg_us_unflagged": (tot.value - totf.value) / (n.value - nf.value) if n.value > nf.value else None}
+    return out
+
+
 def iteration_bytes(N, Nv, I, G, P, T):
     """Algorithmic (compulsory) HBM bytes of one optimise iteration, SURVEY.md 8(d), term by term."""
     terms = {
@@ -334,21 +368,56 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
         rows.append(_kernel_row("expected_depths_partial_kernel", 1.9, fv["ed_s"], 16.0 * fv["visible_blocks"] + 128.0 * fv["cells"] * 8,
                                 hbm_peak_gbs, N, "latency (one entry per thread, LDS atomics)",
                                 "16 B per visible entry in, 128 partial min/max images out (one visible block per thread); pass B rides in the raycaster"))
-    rows.sort(key=lambda x: -x["us_per_frame"])
-    top = rows[0]
+    # In-loop figures of the schedule `value` reports (result["in_loop"], in_loop_kernel_times): per instrumented kernel the
+    # average of ALL its launches in K frames of the running loop.  The fused backward's launches that carry the next
+    # iteration's preprocessing forward (flagged) move that kernel's bytes as well: counted by their share.
+    il = dict((result.get("in_loop") or {}).get("kernels") or {})
+    if "sb_scan_kernel" in il and "sb_scatter_kernel" in il:   # the binning row = one scan + one scatter launch
+        a_, b_ = il["sb_scan_kernel"], il["sb_scatter_kernel"]
+        il["binning (sb_scan_kernel + sb_scatter_kernel)"] = {
+            "launches": b_["launches"], "avg_us": a_["avg_us"] + b_["avg_us"], "us_per_frame": a_["us_per_frame"] + b_["us_per_frame"],
+            "max_us": a_["max_us"] + b_["max_us"], "launches_flagged": 0}
+    pre_bytes = 68.0 * N + 217.0 * nvis
+    for row in rows:
+        k = il.get(row["kernel"])
+        if not k:
+            continue
+        b = row["algorithmic_bytes"]
+        own = row.get("own_bytes")
+        if row["kernel"] == "preprocess_bwd_kernel":
+            share = k["launches_flagged"] / k["launches"]
+            b, row["in_loop_tail_forward_share"], row["in_loop_tail_forward_bytes"] = b + share * pre_bytes, share, pre_bytes
+        row.update(in_loop_avg_us=k["avg_us"], in_loop_launches=k["launches"], in_loop_us_per_frame=k["us_per_frame"], in_loop_max_us=k["max_us"],
+                   in_loop_bytes=b, in_loop_achieved_GBs=b / k["avg_us"] / 1e3, in_loop_frac=b / k["avg_us"] / 1e3 / hbm_peak_gbs)
+        if own:
+            row["in_loop_own_frac"] = own / k["avg_us"] / 1e3 / hbm_peak_gbs
+    rows.sort(key=lambda x: -x.get("in_loop_us_per_frame", x["us_per_frame"]))
+    timed = [r_ for r_ in rows if "in_loop_avg_us" in r_]
+    top = timed[0] if timed else rows[0]
+    in_loop = bool(timed)
     t_frame = result["ms_per_step"] * 1e-3
     b_frame = 2.0 * b_iter + b_fuse
     copy_gbs = measured_copy_bandwidth(device)
-    return {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_GBs"], "peak": hbm_peak_gbs, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": top["kernel"],
+            "achieved": top["in_loop_achieved_GBs"] if in_loop else top["achieved_GBs"], "peak": hbm_peak_gbs, "unit": "GB/s",
+            "timed_in": ("the running %s schedule: start / stop events bound to every dispatch of the kernel (hipExtLaunchKernelGGL) in %d "
+                         "extra frames after the timed windows (gps_launch_timing_*)" % (result.get("schedule", "?"), (result.get("in_loop") or {}).get("frames", 0)))
+                        if in_loop else "kernels-alone micro-loop (no in-loop window in this run)",
+            "launches_timed": top.get("in_loop_launches"),
+            "frac_alone": top["frac"], "avg_launch_us_alone": top["avg_us"],
+            "in_loop_window_ms_per_step": (result.get("in_loop") or {}).get("window_ms_per_step"),
             "measured_copy_GBs": copy_gbs,
             "measured_copy_note": "device-to-device copy of 1 GiB on this box, read + write bytes / best of 10 (SURVEY 8(d)); fractions use the nominal peak",
-            "frac": top["frac"], "traffic": top.get("traffic"), "avg_launch_us": top["avg_us"],
+            "frac": top["in_loop_frac"] if in_loop else top["frac"], "traffic": top.get("traffic"),
+            "avg_launch_us": top["in_loop_avg_us"] if in_loop else top["avg_us"],
             "traffic_source": "profiles/pmc_*.json: separate rocprofv3 --pmc passes over this program's micro-loops on a scene of the same "
                               "size (N within 2 %), committed -- not measured in this run; 2 x FETCH_SIZE + WRITE_SIZE, factor calibrated "
                               "for streams and gathers (profiles/r05_fetch_calibration.md)",
             "traffic_calibrated": bool(top.get("traffic_calibrated", False)),
-            "algorithmic_bytes": top["algorithmic_bytes"],
-            "dominant_by": "calls per frame x live average launch time (kernels[] is sorted by it)",
+            "algorithmic_bytes": top["in_loop_bytes"] if in_loop else top["algorithmic_bytes"],
+            "dominant_by": "largest in-loop time per frame (launches x average duration inside the running schedule) among the kernels "
+                           "that move data; kernels[] is sorted by it.  track_eval_poll_kernel's residency is mostly its wait for the "
+                           "host's argument line and is not instrumented: its row carries the micro-loop figures",
             "kernels": rows,
             "units": {"gaussians": N, "n_visible": nvis, "n_isects": ni, "n_groups": ng, "pixels": P, "tiles": T, "visible_blocks": V},
             "iteration": {"algorithmic_bytes": b_iter, "terms": terms, "avg_us": t["step"] * 1e6,

@@ -68,6 +68,9 @@ class AdamSegment(C.Structure):
 PROTOTYPES = {
     "gps_version": (C.c_char_p, []),
     "gps_build_flags": (C.c_char_p, []),
+    "gps_launch_timing_start": (i32, [i32]),
+    "gps_launch_timing_stop": (i32, []),
+    "gps_launch_timing_read": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "gps_proj_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
     "gps_proj_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gps_sh_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -9,6 +9,7 @@
 // scatter re-derives a superblock's pairs from the same boxes.
 #include <mutex>
 
+#include "launch_timing.hpp"
 #include "splat_bin.hpp"
 
 namespace {
@@ -394,10 +395,10 @@ int isect_tiles_superblock(int N, const float* means2d, const int32_t* radii, co
     }
     const int nblk = gps_div_up(N, BIN_BLOCK);
     const int n_sb = (nblk + (1 << cnt.sb.sb_shift) - 1) >> cnt.sb.sb_shift;
-    sb_scan_kernel<<<gps_div_up(n_tiles + BWD_KEYS, 4), 256, 0, s>>>(n_tiles, cnt.sb);
+    launch_kernel(TK_SB_SCAN, 0, sb_scan_kernel, dim3(gps_div_up(n_tiles + BWD_KEYS, 4)), dim3(256), 0, s, n_tiles, cnt.sb);
     const size_t lds = sb_scatter_lds_bytes(N, n_tiles);
-    sb_scatter_kernel<<<n_sb + 1, SCAT_THREADS, lds, s>>>(N, means2d, radii, tiles_per_gauss, cnt.tile_size, cnt.tw, cnt.th, cnt.sb,
-                                                     isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_counts, cls_stride);
+    launch_kernel(TK_SB_SCATTER, 0, sb_scatter_kernel, dim3(n_sb + 1), dim3(SCAT_THREADS), lds, s, N, means2d, radii, tiles_per_gauss,
+                  cnt.tile_size, cnt.tw, cnt.th, cnt.sb, isect_capacity, flatten_ids, tile_offsets, counts, cls_ids, cls_counts, cls_stride);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

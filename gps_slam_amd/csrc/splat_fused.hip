@@ -11,6 +11,7 @@
 // forward reads 59 floats/Gaussian and writes 15, backward reads the same + 10 gradient floats and writes
 // the 59 parameter gradients (plain stores, no memsets, no atomics).
 // The per-Gaussian math is splat_math.hpp, shared with the op-level kernels the parity tests pin.
+#include "launch_timing.hpp"
 #include "splat_adam.hpp"
 #include "splat_bin.hpp"
 #include "splat_math.hpp"
@@ -498,9 +499,9 @@ int preprocess_bwd_launch(int N, int K, int sh_degree, const float* means, const
     }
     hipStream_t s = (hipStream_t)stream;
 #define GPS_BWD(D)                                                                                                 \
-    preprocess_bwd_kernel<D><<<g, b, lds, s>>>(in, ad, radii, conics, v_means2d, v_conics, v_colors, v_opacities,         \
-                                               reinterpret_cast<const float4*>(v_rows), v_means,                         \
-                                               v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest, nf)
+    launch_kernel(TK_PREPROCESS_BWD, next ? 1 : 0, preprocess_bwd_kernel<D>, g, b, lds, s, in, ad, radii, conics,         \
+                  v_means2d, v_conics, v_colors, v_opacities, reinterpret_cast<const float4*>(v_rows), v_means,           \
+                  v_log_scales, v_quats, v_opac_logit, v_sh_dc, v_sh_rest, nf)
     switch (sh_degree) {
         case 0: GPS_BWD(0); break;
         case 1: GPS_BWD(1); break;
@@ -536,11 +537,11 @@ int preprocess_fwd_launch(int N, int K, int sh_degree, const float* means, const
     hipStream_t s = (hipStream_t)stream;
     const FwdOut w = {radii, means2d, depths, conics, colors, opacities, recs};
     switch (sh_degree) {
-        case 0: preprocess_fwd_kernel<0><<<g, b, 0, s>>>(in, w, cnt, zg); break;
-        case 1: preprocess_fwd_kernel<1><<<g, b, 0, s>>>(in, w, cnt, zg); break;
-        case 2: preprocess_fwd_kernel<2><<<g, b, 0, s>>>(in, w, cnt, zg); break;
-        case 3: preprocess_fwd_kernel<3><<<g, b, 0, s>>>(in, w, cnt, zg); break;
-        default: preprocess_fwd_kernel<4><<<g, b, 0, s>>>(in, w, cnt, zg); break;
+        case 0: launch_kernel(TK_PREPROCESS_FWD, 0, preprocess_fwd_kernel<0>, g, b, 0, s, in, w, cnt, zg); break;
+        case 1: launch_kernel(TK_PREPROCESS_FWD, 0, preprocess_fwd_kernel<1>, g, b, 0, s, in, w, cnt, zg); break;
+        case 2: launch_kernel(TK_PREPROCESS_FWD, 0, preprocess_fwd_kernel<2>, g, b, 0, s, in, w, cnt, zg); break;
+        case 3: launch_kernel(TK_PREPROCESS_FWD, 0, preprocess_fwd_kernel<3>, g, b, 0, s, in, w, cnt, zg); break;
+        default: launch_kernel(TK_PREPROCESS_FWD, 0, preprocess_fwd_kernel<4>, g, b, 0, s, in, w, cnt, zg); break;
     }
     GPS_LAUNCH_CHECK();
     return GPS_OK;

@@ -21,6 +21,7 @@
 // ~N_visible x 10 atomics instead of n_groups x 10.  Pixel/box semantics
 // (int() truncation, +1 offsets, i > y_max guard) are the reference's.
 #include "common.hpp"
+#include "launch_timing.hpp"
 #include "splat_bin.hpp"
 
 namespace {
@@ -580,9 +581,9 @@ int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_dept
     // (experiment, gps_set_frame_chain_reserve bit 1: 14 KB of unused dynamic LDS on top of the 26.7 KB the kernel declares -> 3
     // workgroups of 8 waves per compute unit instead of the 4 that fill every wave slot)
     const size_t pad = (gps::frame_chain_reserve_bits() & 2) ? 14 * 1024 : 0;
-    raster_ges_fwd_pk_kernel<<<tw * th, FWD_THREADS, pad, (hipStream_t)stream>>>(
-        (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
-        (float4*)render_colors, render_alphas, fc, tile_order);
+    launch_kernel(TK_RASTER_FWD, compose ? 1 : 0, raster_ges_fwd_pk_kernel, dim3(tw * th), dim3(FWD_THREADS), pad, (hipStream_t)stream,
+                  (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
+                  (float4*)render_colors, render_alphas, fc, tile_order);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

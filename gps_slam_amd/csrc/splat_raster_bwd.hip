@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "launch_timing.hpp"
 #include "splat_bin.hpp"
 #include "splat_math.hpp"
 
@@ -370,7 +371,7 @@ int raster_ges_bwd_strips_launch(int N, const float* records, const int32_t* rad
     // 4 + 4 and 6 + 6 bench runs on two boxes: overlap 1,328 -> 1,337 and 1,306 -> 1,318 frames/s)
     const int lds_reserve = frame_chain_reserve_lds();
     const int blocks = lds_reserve ? GPS_BWD_STRIP_BLOCKS / GPS_STRIP_WAVES * (GPS_STRIP_WAVES - 1) : GPS_BWD_STRIP_BLOCKS;
-    raster_ges_bwd_strip_kernel<<<blocks, 256, lds_reserve, (hipStream_t)stream>>>(a);
+    launch_kernel(TK_RASTER_BWD_STRIPS, 0, raster_ges_bwd_strip_kernel, dim3(blocks), dim3(256), (size_t)lds_reserve, (hipStream_t)stream, a);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

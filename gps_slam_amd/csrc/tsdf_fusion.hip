@@ -20,6 +20,7 @@
 //    over counters[GPS_TSDF_N_VISIBLE].
 //  * Integration: one wave64 per visible block walking its 8 z-slices (coalesced 512-byte slice
 //    accesses, 8-byte voxel per lane), ~8k blocks in flight to hide the per-block header latency.
+#include "launch_timing.hpp"
 #include "tsdf_common.hpp"
 
 using namespace gpst;
@@ -682,8 +683,8 @@ int gps_tsdf_integrate(const gps_tsdf_state* sp, const float* M, gps_stream stre
 #ifndef GPS_INTEGRATE_WGS
 #define GPS_INTEGRATE_WGS 4096
 #endif
-    if (div_known_safe(s.mu)) integrate_kernel<true><<<GPS_INTEGRATE_WGS, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
-    else integrate_kernel<false><<<GPS_INTEGRATE_WGS, 256, 0, (hipStream_t)stream>>>(s, load_mat(M));
+    if (div_known_safe(s.mu)) gps::launch_kernel(gps::TK_INTEGRATE, 0, integrate_kernel<true>, dim3(GPS_INTEGRATE_WGS), dim3(256), 0, (hipStream_t)stream, s, load_mat(M));
+    else gps::launch_kernel(gps::TK_INTEGRATE, 0, integrate_kernel<false>, dim3(GPS_INTEGRATE_WGS), dim3(256), 0, (hipStream_t)stream, s, load_mat(M));
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -14,6 +14,7 @@
 //  * All kernels read their sizes from the device counters: no blocking readback anywhere.
 #include <math.h>
 
+#include "launch_timing.hpp"
 #include "tsdf_common.hpp"
 #include "tsdf_pose.hpp"
 #include "wave_reduce.hpp"
@@ -797,10 +798,13 @@ static int raycast_impl(const gps_tsdf_state* sp, const float* invM, int free_vi
     const int n_total = s.n_buckets + s.n_excess, nblk = gps_div_up(n_total, 1024);
     // (where expected_depths_impl put the partial images)
     const uint2* partial = reduce_here ? reinterpret_cast<const uint2*>(s.scan_scratch + 3 * nblk + 16 + (n_total + 3) / 4 + 2) : nullptr;
+    const ViewRec* no_table = nullptr;
     if (update_visible)
-        raycast_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr, partial, sw, sh, mm);
+        gps::launch_kernel(gps::TK_RAYCAST, 0, raycast_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, s, load_mat(invM), (const float2*)mm, rays,
+                           bucket_bits(s), no_table, partial, sw, sh, mm);
     else
-        raycast_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(s, load_mat(invM), mm, rays, bucket_bits(s), nullptr, partial, sw, sh, mm);
+        gps::launch_kernel(gps::TK_RAYCAST, 1, raycast_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, s, load_mat(invM), (const float2*)mm, rays,
+                           bucket_bits(s), no_table, partial, sw, sh, mm);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }

@@ -14,6 +14,7 @@ import math
 import os
 import sys
 
+import numpy as np
 import torch
 
 import ctypes as C
@@ -47,6 +48,10 @@ def pose_inv(c2w):
 
 
 _PACK_SERIAL = itertools.count(1)
+
+# RawGaussianModel::initOptimizers computes eps and the betas in FLOAT variables (raw_gs_model.cpp:661-664) which AdamOptions
+# widens: beta1 = 0.8999999761581421, beta2 = 0.9990000128746033, eps = 1.0000000036274937e-15 (tests/test_adam_libtorch_gpu.py)
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = float(np.float32(0.9)), float(np.float32(0.999)), float(np.float32(1e-15))
 
 
 class Camera:
@@ -303,7 +308,7 @@ class RawGaussianModel:
                     setattr(st, name, t.data_ptr())
             st.isect_capacity, st.group_capacity, st.workspace_bytes = icap, gcap, B["workspace"].numel()
             st.cls_stride = cap
-            st.beta1, st.beta2, st.adam_eps = 0.9, 0.999, 1e-15
+            st.beta1, st.beta2, st.adam_eps = ADAM_BETA1, ADAM_BETA2, ADAM_EPS
             st.fuse_sh_rest_adam = self.fuse_adam
             self._step, self._step_key, self._B = st, key, B
         st = self._step
@@ -364,8 +369,9 @@ class RawGaussianModel:
     def initOptimizers(self, max_iterations=-1, scene_scale=1.0):
         """raw_gs_model.cpp:654-675: all Adam state is re-created (step counts restart at 1)."""
         p = self.opt_gs_params
-        lrs = [self.lrs["means"] * scene_scale, self.lrs["scales"], self.lrs["quats"], self.lrs["featuresDc"],
-               self.lrs["featuresRest"], self.lrs["opacities"]]
+        # (float members, float product, widened for AdamOptions: raw_gs_model.cpp:26-32, :666-671)
+        f32 = np.float32
+        lrs = [float(f32(self.lrs["means"]) * f32(scene_scale))] + [float(f32(self.lrs[k])) for k in ("scales", "quats", "featuresDc", "featuresRest", "opacities")]
         if self._opt is None or self._opt["cap"] != p.cap:
             mk = lambda: [torch.zeros_like(p._buf[n]) for n in p.NAMES]
             self._opt = dict(m=mk(), v=mk(), g=mk(), cap=p.cap)

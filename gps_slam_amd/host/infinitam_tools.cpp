@@ -137,6 +137,7 @@ void CLIEngine::Run() {
 }
 
 void CLIEngine::Shutdown() {
+    if (beforeShutdown) { auto detach = std::move(beforeShutdown); beforeShutdown = nullptr; detach(); }
     staging_.reset();
     // createTsdfEngine handed this object the sequence's images and the engine it built for it (ownsInputs): a process that builds
     // scene after scene -- bench.py, the tests -- gets the pinned images (1.8 MB per 640x480 frame) and the engine's 1.5 GB back

@@ -11,6 +11,7 @@
 // reference's UpdateView is a blocking cudaMemcpy per frame, ITMViewBuilder_CUDA.cu:61-62) -- every frame's 6 bytes per
 // pixel still cross PCIe inside the frame loop.
 #pragma once
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -107,6 +108,10 @@ public:
     // enqueued on the frame's own stream right before its kernels.
     bool prefetch = true;
     int64_t uploadedBytes = 0;
+    // called first thing by Shutdown(): a SLAMPipeline attached with setTsdfEngine() flushes its map worker and drops its raw
+    // pointers into this engine (and the engine's beforeNextFusion hook that captures the pipeline) before the engine is freed
+    // (round-5 advisor finding: bench.Scene.close() shuts the engine down while the pipeline is still alive)
+    std::function<void()> beforeShutdown;
     bool ownsInputs = false;   // Shutdown() deletes the images and the engine (set by createTsdfEngine, which allocated them)
 
 private:

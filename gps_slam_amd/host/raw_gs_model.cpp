@@ -1,6 +1,12 @@
 #include "raw_gs_model.hpp"
 
 using namespace gpsh;
+
+// RawGaussianModel::initOptimizers computes eps and the betas in FLOAT variables (raw_gs_model.cpp:661-664: float eps = 1e-15 /
+// sqrt(BS), float B1 = 1 - BS * (1 - 0.9), float B2 = 1 - BS * (1 - 0.999), BS = 1) and AdamOptions widens them: the optimiser
+// runs with beta1 = 0.8999999761581421, beta2 = 0.9990000128746033 (1 - beta2 is 1.3e-5 smaller than 0.001), eps =
+// 1.0000000036274937e-15.  Pinned by tests/test_adam_libtorch_gpu.py against torch::optim::Adam built the reference's way.
+static const double kAdamBeta1 = (double)0.9f, kAdamBeta2 = (double)0.999f, kAdamEps = (double)1e-15f;
 using torch::autograd::AutogradContext;
 using torch::autograd::tensor_list;
 using torch::indexing::Slice;
@@ -86,7 +92,7 @@ gps_splat_step& RawGaussianModel::stepStruct(int W, int H) {
             s.v_rows = fptr(B_.v_rows); s.pix2 = fptr(B_.pix2);
             s.cls_ids = iptr(B_.cls_ids); s.cls_counts = iptr(B_.cls_counts); s.cls_stride = cap;
         }
-        s.beta1 = 0.9; s.beta2 = 0.999; s.adam_eps = 1e-15;
+        s.beta1 = kAdamBeta1; s.beta2 = kAdamBeta2; s.adam_eps = kAdamEps;
         step_cap_ = cap; step_w_ = W; step_h_ = H;
         // fresh intermediates: a forward the last trainStep() ran ahead lived in the buffers just replaced (checkBinningCapacity()
         // growing the tables, a parameter-capacity change, another image size) -- the next step preprocesses itself
@@ -379,8 +385,11 @@ void RawGaussianModel::initOptimizers(int max_iterations, float scene_scale) {
     // moments as zero without reading them and writes them for every live row; rounds 1-4 zeroed 2 x 59 floats per Gaussian here,
     // 50 us per keyframe at 245 k)
     pending_prunes_.clear();  // the state those would have compacted has just been replaced
-    lrs_[0] = means_lr * scene_scale; lrs_[1] = scales_lr; lrs_[2] = quats_lr; lrs_[3] = featuresDc_lr;
-    lrs_[4] = featuresRest_lr; lrs_[5] = opacities_lr;
+    // the reference holds its rates in float members (config[...].as<float>(), raw_gs_model.cpp:26-32), multiplies meansLr by the
+    // float scene_scale and widens the float result for AdamOptions (:666-671): the doubles the optimiser divides by 1 - beta1^t
+    // are those floats' values
+    lrs_[0] = (double)((float)means_lr * scene_scale); lrs_[1] = (double)(float)scales_lr; lrs_[2] = (double)(float)quats_lr;
+    lrs_[3] = (double)(float)featuresDc_lr; lrs_[4] = (double)(float)featuresRest_lr; lrs_[5] = (double)(float)opacities_lr;
     adam_step_ = 0;
     have_opt_ = true;
     setParamsRequireGrad();
@@ -416,7 +425,7 @@ void RawGaussianModel::optimizersStep() {
         seg[k].lr = lrs_[k];
     }
     adam_step_ += 1;
-    check(gps_adam_step(seg, 6, 0.9, 0.999, 1e-15, adam_step_, current_stream()), "gps_adam_step");
+    check(gps_adam_step(seg, 6, kAdamBeta1, kAdamBeta2, kAdamEps, adam_step_, current_stream()), "gps_adam_step");
 }
 
 void RawGaussianModel::trainStep(const Camera& cam, const torch::Tensor& ref_depth, const torch::Tensor& base_color,

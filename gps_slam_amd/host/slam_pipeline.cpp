@@ -82,6 +82,18 @@ void SLAMPipeline::setTsdfEngine(InfiniTAM::Engine::CLIEngine* engine) {
     TORCH_CHECK(be != nullptr, "setTsdfEngine: the main engine must be an ITMBasicEngine<ITMVoxel, ITMVoxelIndex>");
     main_engine = be;
     voxel_size = be->getVoxelSize();
+    // CLIEngine::Shutdown() frees the engine (ownsInputs): finish what is in flight and let go of it first
+    engine->beforeShutdown = [this] { detachTsdfEngine(); };
+}
+
+void SLAMPipeline::detachTsdfEngine() {
+    if (!tsdf_engine) return;
+    try { flush(); } catch (...) {}   // (a worker error has been, or will be, reported by the call that hit it)
+    (void)hipDeviceSynchronize();
+    if (main_engine) main_engine->beforeNextFusion = nullptr;
+    if (tsdf_engine->beforeShutdown) tsdf_engine->beforeShutdown = nullptr;
+    main_engine = nullptr;
+    tsdf_engine = nullptr;
 }
 
 static inline double now_ms() {
@@ -109,6 +121,7 @@ void SLAMPipeline::SLAMTrainCams(SLAMGaussianModel& model_, std::vector<Camera>&
     hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
     times.slam_total = now_ms() - t0;
     times.frames = (int)cams.size();
+    if (times.frames == 0) return;   // (nothing to average: the reference would print NaN into time_log.txt)
     // slam_pipeline.cpp:168-171: emptyCache(), then the device memory in use (what run/read_results.py reads as "GPU memory usage")
     c10::hip::HIPCachingAllocator::emptyCache();
     times.gpu_memory_mb = (long long)getGPUMemoryUsage((int)c10::hip::current_device());
@@ -327,22 +340,43 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
     if (cams.empty()) return out;
     TsdfEngine* eng = main_engine;
     const auto F = f32(device);
+    if (ev_out && !rc_stream_ && !use_event) beginAsyncRaycasts();  // (keyFrameRaycast() without a preceding localFrameRaycast())
+    // Whose pool the result tensors come from.  They are WRITTEN on the raycast stream and READ on the consumer's (the stream
+    // current here: the map stream, or the frames stream in the sequential schedule).  Rounds 4-5 allocated them with the
+    // consumer's stream current -- fine while the worker enqueued the raycasts itself (the raycast stream was ordered behind
+    // the map stream), a write-after-read hazard once the FRAME thread enqueues update k+1's views while the worker is still
+    // running update k on the map stream: the caching allocator may hand out a block the worker freed a moment ago that queued
+    // map-stream kernels still read, and the raycast stream only waits for the frame's fusion (round-5 advisor finding).  Now:
+    // allocated with the RAYCAST stream current (a block of that pool is only reused in that stream's order) and the consumer
+    // registered with recordStream, so that a freed block waits for the consumer's queued work before the raycast stream gets
+    // it again; the consumer itself waits on the batch events as before.  (Only the allocations run under the raycast stream's
+    // guard: the pose glue below must not inherit it.)
+    const c10::hip::HIPStream consumer = c10::hip::getCurrentHIPStream();
+    auto result = [&](int64_t h, int64_t w, int64_t c) {
+        c10::optional<c10::hip::HIPStreamGuard> alloc_on_rc;
+        if (ev_out) alloc_on_rc.emplace(static_cast<MapStream*>(rc_stream_)->s);
+        torch::Tensor t = torch::empty({h, w, c}, F);
+        // (the allocator's own entry point: Tensor::record_stream wants a c10::Stream of the masquerading "cuda" device type)
+        if (ev_out) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), consumer);
+        return t;
+    };
     if (!raycast_pool_warm_) {
         // The result tensors of an update (5 per view, ~11 MB per 640x480 view) are allocated on the consumer's stream and freed
         // when the next update replaces them, so in steady state the caching allocator hands the same blocks out again -- but
         // while the keyframe list is still filling every update has one view more than the last, i.e. a fresh hipMalloc under
         // the allocator's lock in the middle of an update (measured: the frame thread's own 3.7 MB image allocation then waited
         // 3-6 ms for that lock in about one run in six).  Take the full set once, up front, and give it back to the cache.
+        // (two sets where the frame thread enqueues update k+1's views while update k's are still being read)
         std::vector<torch::Tensor> warm;
         const int64_t H = cams[0]->height, W = cams[0]->width;
-        for (int k = 0; k < localframe_cam_window_length + keyframe_select_max; k++) {
-            warm.push_back(torch::empty({H, W, 3}, F)); warm.push_back(torch::empty({H, W, 3}, F));
-            warm.push_back(torch::empty({H, W, 1}, F)); warm.push_back(torch::empty({H, W, 1}, F));
-            warm.push_back(torch::empty({H, W, 1}, F));
+        const int sets = mapping_thread && pipeline_raycasts && async_raycasts ? 2 : 1;
+        for (int k = 0; k < sets * (localframe_cam_window_length + keyframe_select_max); k++) {
+            warm.push_back(result(H, W, 3)); warm.push_back(result(H, W, 3));
+            warm.push_back(result(H, W, 1)); warm.push_back(result(H, W, 1));
+            warm.push_back(result(H, W, 1));
         }
         raycast_pool_warm_ = true;
     }
-    if (ev_out && !rc_stream_ && !use_event) beginAsyncRaycasts();  // (keyFrameRaycast() without a preceding localFrameRaycast())
     std::vector<ORUtils::SE3Pose> view_poses(cams.size());
     std::vector<ITMLib::ITMIntrinsics> view_intr(cams.size());
     std::vector<torch::Tensor> w2c(cams.size());
@@ -356,13 +390,12 @@ std::vector<TensorDict> SLAMPipeline::raycastCams(const std::vector<const Camera
             view_poses[k].Coerce();
         }
         view_intr[k] = intrinsicsOf(cam, eng);
-        // (result tensors on the CONSUMER's stream, before the guard below, as in raycastCam)
         TensorDict m;
-        m["color_map"] = torch::empty({cam.height, cam.width, 3}, F);
-        m["vertex_map"] = torch::empty({cam.height, cam.width, 3}, F);
-        m["confidence_map"] = torch::empty({cam.height, cam.width, 1}, F);
-        m["depth_map"] = torch::empty({cam.height, cam.width, 1}, F);
-        m["depth_map_clamped"] = torch::empty({cam.height, cam.width, 1}, F);
+        m["color_map"] = result(cam.height, cam.width, 3);
+        m["vertex_map"] = result(cam.height, cam.width, 3);
+        m["confidence_map"] = result(cam.height, cam.width, 1);
+        m["depth_map"] = result(cam.height, cam.width, 1);
+        m["depth_map_clamped"] = result(cam.height, cam.width, 1);
         out.push_back(m);
         w2c[k] = poseInv(cam.c2w.to(torch::kCPU, torch::kFloat32)).contiguous();  // poseInv(cam.c2w): dataset pose (:398)
     }
@@ -971,6 +1004,10 @@ void SLAMPipeline::flush() {
 }
 
 SLAMPipeline::~SLAMPipeline() {
+    if (tsdf_engine) {   // the engine outlives this pipeline: its hooks must not call into a dead object
+        if (main_engine) main_engine->beforeNextFusion = nullptr;
+        tsdf_engine->beforeShutdown = nullptr;
+    }
     if (worker_.joinable()) {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();

@@ -62,6 +62,7 @@ public:
     // (per-frame upload inside the loop) instead of device tensors handed to processFrame.
     explicit SLAMPipeline(uint64_t seed = 1234);
     void setTsdfEngine(InfiniTAM::Engine::CLIEngine* tsdf_engine);  // slam_pipeline.h:22-29
+    void detachTsdfEngine();   // flush + drop the pointers into the engine (CLIEngine::Shutdown calls it through beforeShutdown)
     void SLAMTrainCams(SLAMGaussianModel& model, std::vector<Camera>& cams);  // slam_pipeline.cpp:52-173
     void processFrame(int i, Camera& cam);  // one iteration of that loop: tsdf_engine->ProcessFrame() + the Gaussian block
 
@@ -132,6 +133,9 @@ public:
     // 1000 / (1000 / FPS - per_frame) from them.  The five per-stage totals are taken in the sequential keyframe step only (the
     // overlapped schedules run the stages on another stream / thread; their host share of the frame thread is `keyframe_step`).
     // slam_total here ends AFTER flush() and a device synchronise (the reference stops its clock with kernels still in flight).
+    // Under overlap_mapping / mapping_thread only per_frame (-> fusion_fps), slam_total (-> fps) and gpu_memory_mb mean what the
+    // reference's timers mean: localFrameRaycast / keyFrameRaycast are then the frame thread's ENQUEUE time, localOptimize includes
+    // the map stream's synchronisation wait -- not comparable with the reference's per-stage numbers (sequential schedule: they are).
     struct PipelineTimes {
         int frames = 0;
         double slam_total = 0, per_frame = 0, keyframe_step = 0, localFrameRaycast = 0, keyFrameRaycast = 0, initNewGaussians = 0,

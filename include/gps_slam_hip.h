@@ -43,6 +43,29 @@ GPS_API const char *gps_version(void);
  * builds made with tools/probe/variant.py identify themselves. */
 GPS_API const char *gps_build_flags(void);
 
+/* In-loop launch timing -- measurement support for bench.py's `roofline` ("achieved = algorithmic bytes / that
+ * kernel's average launch duration, measured live with HIP events on the stream the kernel is launched on").  Between _start and
+ * _stop every launch of the kernels below, from whichever entry point, host thread and stream, is dispatched with a start and a
+ * stop event bound to the kernel's own dispatch (hipExtLaunchKernelGGL: the begin / end timestamps of that kernel, what a
+ * rocprofv3 kernel trace reports); _stop waits for them and sums the elapsed times per kind.  `flagged` = the subset with the
+ * kind's flag set (PREPROCESS_BWD: the next iteration's preprocessing forward rode in the launch; RASTER_FWD: with the compose +
+ * L1 epilogue; RAYCAST: a free view).  Results never depend on it; off by default and after _stop.  capacity = launches
+ * recorded at most (further ones are counted in *dropped).  No reference counterpart (the reference times stages on the host,
+ * slam_pipeline.cpp:135-167). */
+#define GPS_TIMED_PREPROCESS_BWD 0
+#define GPS_TIMED_PREPROCESS_FWD 1
+#define GPS_TIMED_RASTER_FWD 2
+#define GPS_TIMED_RASTER_BWD_STRIPS 3
+#define GPS_TIMED_SB_SCAN 4
+#define GPS_TIMED_SB_SCATTER 5
+#define GPS_TIMED_INTEGRATE 6
+#define GPS_TIMED_RAYCAST 7
+#define GPS_TIMED_KINDS 8
+GPS_API int gps_launch_timing_start(int capacity);
+GPS_API int gps_launch_timing_stop(void);
+GPS_API int gps_launch_timing_read(int kind, double *total_us, int64_t *launches, double *total_us_flagged,
+                                   int64_t *launches_flagged, double *max_us, int64_t *dropped);
+
 /* ------------------------------------------------------------------ */
 /* Splat: projection                                                   */
 /* ------------------------------------------------------------------ */

@@ -119,3 +119,31 @@ def test_gaussian_ply_format_is_the_reference_layout(tmp_path):
     back = read_gaussian_ply(path)
     for k in t:
         assert np.array_equal(back[k], t[k]), k
+
+
+def test_gaussian_ply_of_both_hosts_is_the_golden_file_byte_for_byte(tmp_path):
+    """RawGaussianParams::savePly (src/raw_gs_param.cpp:159-217) against tests/golden/gaussian_ply_n2_k16.ply -- a file written
+    by tests/golden/make_gaussian_ply_golden.py from the reference writer's property list and row order with nothing of this
+    package imported (data, not a self-comparison): the C++ host's savePly and the Python mirror's must both produce exactly
+    those 2,022 bytes from the same tensors, and the reader must give the tensors back."""
+    import numpy as np
+    import torch
+    from gps_slam_amd import _build, _build_host, _lib
+    from gps_slam_amd.gs_model import read_gaussian_ply, write_gaussian_ply
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = open(os.path.join(gdir, "gaussian_ply_n2_k16.ply"), "rb").read()
+    t = dict(np.load(os.path.join(gdir, "gaussian_ply_n2_k16.npz")))
+    assert len(want) == 2022 and want.count(b"\n", 0, want.index(b"end_header")) == 3 + 62
+    write_gaussian_ply(str(tmp_path / "p.ply"), t["means"], t["scales"], t["quats"], t["featuresDc"], t["featuresRest"], t["opacities"])
+    assert open(tmp_path / "p.ply", "rb").read() == want
+    _build.build()
+    _lib.load_library()
+    _build_host.build()
+    import gps_slam_amd._host as h
+    p = h.SLAMGaussianModel().getGaussianParms()   # (host tensors: savePly is host code, raw_gs_param.cpp copies to the CPU first)
+    p.add([torch.as_tensor(t[k]) for k in ("means", "scales", "quats", "featuresDc", "featuresRest", "opacities")])
+    p.savePly(str(tmp_path / "c.ply"))
+    assert open(tmp_path / "c.ply", "rb").read() == want
+    back = read_gaussian_ply(str(tmp_path / "c.ply"))
+    for k in t:
+        assert np.array_equal(back[k].reshape(t[k].shape), t[k]), k

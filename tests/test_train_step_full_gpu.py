@@ -137,12 +137,13 @@ def test_timed_train_step_chain_matches_oracle_at_baseline_sizes(N, W, H, scale_
     cam_pos = c2w[:3, 3].astype(np.float32)
     ref_c = mA.clamp_ref_depth(ref)
     ref_np = N_(ref_c)[..., 0]
-    lrs = [1.6e-4 * 3.3, 5e-3, 1e-3, 2.5e-3, 5e-4, 5e-2]  # NAMES order; initOptimizers(-1, 3.3) scales the means lr
+    lrs = list(mA._opt["lrs"])  # NAMES order; initOptimizers(-1, 3.3) scales the means lr (float product, as the reference's)
+    assert lrs == [float(np.float32(x)) for x in (np.float32(1.6e-4) * np.float32(3.3), 5e-3, 1e-3, 2.5e-3, 5e-4, 5e-2)]
     # ATen reference Adam state (GPU tensors, stepped with the op sequence of torch::optim::Adam::step)
     Pe = [t.clone() for t in mA.opt_gs_params.tensors()]
     Me = [torch.zeros_like(t) for t in Pe]
     Ve = [torch.zeros_like(t) for t in Pe]
-    b1, b2, eps = 0.9, 0.999, 1e-15
+    from gps_slam_amd.gs_model import ADAM_BETA1 as b1, ADAM_BETA2 as b2, ADAM_EPS as eps   # the reference's float-derived scalars
 
     for step in range(1, 4):
         P = [N_(t).copy() for t in mA.opt_gs_params.tensors()]          # parameters_k (NAMES order)

@@ -83,7 +83,7 @@ def main():
     roof = line["roofline"]
     order = roof["micro_order"]
     cfg = line["config"]
-    n_window_markers = 2 * cfg["windows"] * len(cfg["schedules"])
+    n_window_markers = 2 * cfg.get("marker_windows_per_schedule", cfg["windows"]) * len(cfg["schedules"])   # (+ the in-loop window's pair)
     live = {r["kernel"]: r for r in roof["kernels"]}
     sets = {"FETCH_SIZE": d_fetch, "WRITE_SIZE": d_write}
     sq1 = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")

@@ -55,21 +55,31 @@ def main():
         print("(no phase markers in this trace: whole run)")
         table([(n, e - s) for n, s, e in body], top)
         return
-    # markers come in (start, end) pairs per timed window: nw windows per schedule, 1 or 2 schedules; then one scaffolding marker
-    # followed by one marker in front of every micro-benchmark loop
-    n_sched = 2 if len(marks) >= 4 * nw + 1 else 1
-    n_timed = nw * n_sched
+    # markers come in (start, end) pairs per timed window: nw windows per schedule, 1 or 2 schedules (round 6: + one pair per
+    # schedule around the in-loop launch-timing window, --in-loop); then one scaffolding marker followed by one marker in front of
+    # every micro-benchmark loop
+    il = 1 if "--in-loop" in sys.argv else 0
+    per = nw + il
+    n_sched = 2 if len(marks) >= 4 * per + 1 else 1
+    n_timed = per * n_sched
     if len(marks) < 2 * n_timed:
-        n_timed, n_sched, nw = len(marks) // 2, 1, len(marks) // 2
+        n_timed, n_sched, nw, per, il = len(marks) // 2, 1, len(marks) // 2, len(marks) // 2, 0
     names = ("sequential", "overlap") if n_sched == 2 else ("timed",)
     for sidx in range(n_sched):
         sel, span = [], 0
-        for k in range(sidx * nw, (sidx + 1) * nw):
+        for k in range(sidx * per, sidx * per + nw):
             lo, hi = marks[2 * k], marks[2 * k + 1]
             sel += [(n, e - s) for n, s, e in body if lo <= s < hi]
             span += hi - lo
         print("\n### schedule %s: %d timed window(s), %.3f ms between their markers\n" % (names[sidx], nw, span / 1e6))
         table(sel, top, frames * nw if frames else None)
+        if il:
+            k = sidx * per + nw
+            lo, hi = marks[2 * k], marks[2 * k + 1]
+            print("\n### schedule %s: the in-loop launch-timing window (%d extra frames after the timed windows, every launch of the instrumented "
+                  "kernels dispatched with start / stop events; %.3f ms between its markers) -- the bench line's roofline.avg_launch_us is the "
+                  "event-measured average of THESE launches\n" % (names[sidx], frames or 0, (hi - lo) / 1e6))
+            table([(n, e - s) for n, s, e in body if lo <= s < hi], 12, frames)
     scaffold_from = marks[2 * n_timed] if len(marks) > 2 * n_timed else None
     if scaffold_from is not None:
         sel = [(n, e - s) for n, s, e in body if s >= scaffold_from]

@@ -23,7 +23,7 @@ rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o
   echo "Command: \`rocprofv3 --kernel-trace --stats -- $CMD\`.  Summarised from the rocpd database with tools/prof_summary.py:"
   echo "one table per schedule over its $WINDOWS timed windows of $STEPS frames (phase markers: bench.py's spin_kernel launches);"
   echo "\`sequential\` = the reference's schedule, \`overlap\` = the one \`value\` reports; us/frame = total / ($WINDOWS x $STEPS) frames."
-  python tools/prof_summary.py "$(find /tmp/prof_stats -name '*.db' | head -1)" 40 --frames $STEPS --windows $WINDOWS
+  python tools/prof_summary.py "$(find /tmp/prof_stats -name '*.db' | head -1)" 40 --frames $STEPS --windows $WINDOWS --in-loop
   echo
   echo "bench line of the profiled run:"
   grep '^{"metric"' gpurun_out/bench_prof.log | tail -1 | cut -c1-600
