@@ -28,12 +28,13 @@ TIMED_KINDS = ("preprocess_bwd_kernel", "preprocess_fwd_kernel", "raster_ges_fwd
 def in_loop_kernel_times(run, frames):
     """Per-kernel launch durations INSIDE the running schedule: gps_launch_timing_start, `run()` (K SLAM frames of the scene the
     timed windows just measured, same schedule, same streams and host threads), gps_launch_timing_stop.  Every launch of the
-    instrumented kernels carries a start and a stop event bound to its own dispatch (hipExtLaunchKernelGGL,
-    csrc/launch_timing.hpp: the kernel's begin / end timestamps, as a rocprofv3 kernel trace reports them); this is what the
-    `roofline` of the line is priced with -- the kernels-alone micro-loops of roofline_section run with nothing beside them and warm
+    instrumented kernels stamps the device's 100 MHz wall clock at the start and end of each of its waves into its workgroup's
+    {first start, last end} slot (csrc/launch_timing.hpp: the kernel's own execution interval -- a rocprofv3 kernel trace reports the
+    same launches 1-3 us longer, the dispatch's ramp-up and the end-of-kernel release); this is what the `roofline` of the
+    line is priced with -- the kernels-alone micro-loops of roofline_section run with nothing beside them and warm
     inputs.  The window is an extra one after the timed windows."""
     from gps_slam_amd._lib import lib
-    assert lib.gps_launch_timing_start(1 << 16) == 0
+    assert lib.gps_launch_timing_start(1 << 21) == 0   # workgroup slots (32 MB): ~0.4 M workgroups in 20 frames
     t0 = time.perf_counter()
     try:
         run()
@@ -400,8 +401,8 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
     copy_gbs = measured_copy_bandwidth(device)
     return {"bound": "hbm", "kernel": top["kernel"],
             "achieved": top["in_loop_achieved_GBs"] if in_loop else top["achieved_GBs"], "peak": hbm_peak_gbs, "unit": "GB/s",
-            "timed_in": ("the running %s schedule: start / stop events bound to every dispatch of the kernel (hipExtLaunchKernelGGL) in %d "
-                         "extra frames after the timed windows (gps_launch_timing_*)" % (result.get("schedule", "?"), (result.get("in_loop") or {}).get("frames", 0)))
+            "timed_in": ("the running %s schedule: every launch of the kernel stamps the device clock at its first wave's start and last wave's "
+                         "end (gps_launch_timing_*), averaged over all its launches in %d extra frames after the timed windows" % (result.get("schedule", "?"), (result.get("in_loop") or {}).get("frames", 0)))
                         if in_loop else "kernels-alone micro-loop (no in-loop window in this run)",
             "launches_timed": top.get("in_loop_launches"),
             "frac_alone": top["frac"], "avg_launch_us_alone": top["avg_us"],

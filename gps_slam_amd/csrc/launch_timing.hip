@@ -1,5 +1,4 @@
 // gps_launch_timing_start / _stop / _read: see launch_timing.hpp and include/gps_slam_hip.h.
-// (events are handed out here and bound to the kernel dispatch by hipExtLaunchKernelGGL at the launch site)
 #include "common.hpp"
 #include "launch_timing.hpp"
 
@@ -9,42 +8,35 @@
 namespace gps {
 namespace {
 
-struct Pair { hipEvent_t a, b; int kind, flag; bool closed; };
+struct Rec { int kind, flag; size_t first, count; };   // slots [first, first + count) = the launch's workgroups
 
 std::mutex g_mu;
-int g_on = 0;                 // (read without the lock on the launch path)
-size_t g_capacity = 0;
-std::vector<Pair> g_pairs;    // launches of the current session, in record order over all streams and host threads
-std::vector<hipEvent_t> g_pool;
+int g_on = 0;                        // (read without the lock on the launch path)
+unsigned long long* g_slots = nullptr;   // device: {first start, last end} per workgroup, initialised to {~0, 0}
+size_t g_capacity = 0, g_used = 0;       // in slots
+std::vector<Rec> g_recs;             // launches of the current window, in slot order over all streams and host threads
 double g_total_us[TK_COUNT][2];
 long long g_launches[TK_COUNT][2];
 double g_max_us[TK_COUNT];
 long long g_dropped = 0;
+constexpr double TICK_US = 0.01;     // wall_clock64(): the 100 MHz constant clock
 
-hipEvent_t take_event() {
-    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    return e;
+__global__ void stamp_init_kernel(unsigned long long* s, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) { s[2 * i] = ~0ull; s[2 * i + 1] = 0ull; }
 }
 
 }  // namespace
 
 bool launch_timing_on() { return __atomic_load_n(&g_on, __ATOMIC_RELAXED) != 0; }
 
-bool launch_timing_events(int kind, int flag, hipEvent_t* start, hipEvent_t* stop) {
+LaunchStamp launch_timing_slots(int kind, int flag, size_t n_workgroups) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on || kind < 0 || kind >= TK_COUNT) return false;
-    if (g_pairs.size() >= g_capacity) { g_dropped++; return false; }
-    Pair p = {take_event(), take_event(), kind, flag ? 1 : 0, true};
-    if (!p.a || !p.b) {
-        if (p.a) g_pool.push_back(p.a);
-        g_dropped++;
-        return false;
-    }
-    g_pairs.push_back(p);
-    *start = p.a; *stop = p.b;
-    return true;
+    if (!g_on || !g_slots || kind < 0 || kind >= TK_COUNT || n_workgroups == 0) return LaunchStamp{nullptr};
+    if (g_used + n_workgroups > g_capacity) { g_dropped++; return LaunchStamp{nullptr}; }
+    g_recs.push_back(Rec{kind, flag ? 1 : 0, g_used, n_workgroups});
+    g_used += n_workgroups;
+    return LaunchStamp{g_slots + 2 * g_recs.back().first};
 }
 
 }  // namespace gps
@@ -52,12 +44,17 @@ bool launch_timing_events(int kind, int flag, hipEvent_t* start, hipEvent_t* sto
 extern "C" {
 
 int gps_launch_timing_start(int capacity) {
-    GPS_REQUIRE(capacity > 0 && capacity <= (1 << 20));
+    GPS_ENTER();
+    GPS_REQUIRE(capacity > 0 && capacity <= (1 << 24));   // workgroup slots (16 bytes each)
     std::lock_guard<std::mutex> lk(gps::g_mu);
-    for (auto& p : gps::g_pairs) { gps::g_pool.push_back(p.a); gps::g_pool.push_back(p.b); }
-    gps::g_pairs.clear();
-    gps::g_pairs.reserve((size_t)capacity);
+    if (gps::g_on) return GPS_ERR_ARG;   // (one window at a time)
+    if (gps::g_slots && gps::g_capacity != (size_t)capacity) { (void)hipFree(gps::g_slots); gps::g_slots = nullptr; }
+    if (!gps::g_slots && hipMalloc(&gps::g_slots, (size_t)capacity * 16) != hipSuccess) { gps::g_slots = nullptr; return GPS_ERR_LAUNCH; }
     gps::g_capacity = (size_t)capacity;
+    gps::stamp_init_kernel<<<gps_div_up(capacity, 256), 256, 0, nullptr>>>(gps::g_slots, (size_t)capacity);
+    if (hipDeviceSynchronize() != hipSuccess) return GPS_ERR_LAUNCH;
+    gps::g_recs.clear();
+    gps::g_used = 0;
     gps::g_dropped = 0;
     for (int k = 0; k < gps::TK_COUNT; k++) {
         gps::g_total_us[k][0] = gps::g_total_us[k][1] = 0.0;
@@ -69,24 +66,28 @@ int gps_launch_timing_start(int capacity) {
 }
 
 int gps_launch_timing_stop(void) {
+    GPS_ENTER();
     __atomic_store_n(&gps::g_on, 0, __ATOMIC_RELAXED);
+    if (hipDeviceSynchronize() != hipSuccess) return GPS_ERR_LAUNCH;   // every stamped launch has ended
     std::lock_guard<std::mutex> lk(gps::g_mu);
-    int rc = GPS_OK;
-    for (auto& p : gps::g_pairs) {
-        float ms = 0.f;
-        if (p.closed && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            gps::g_total_us[p.kind][p.flag] += 1e3 * (double)ms;
-            gps::g_launches[p.kind][p.flag]++;
-            if (1e3 * (double)ms > gps::g_max_us[p.kind]) gps::g_max_us[p.kind] = 1e3 * (double)ms;
-        } else {
-            rc = GPS_ERR_LAUNCH;
+    const size_t n = gps::g_used;
+    if (n == 0) return GPS_OK;
+    std::vector<unsigned long long> h(2 * n);
+    if (hipMemcpy(h.data(), gps::g_slots, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return GPS_ERR_LAUNCH;
+    for (const gps::Rec& r : gps::g_recs) {
+        unsigned long long a = ~0ull, b = 0ull;
+        for (size_t i = r.first; i < r.first + r.count; i++) {
+            if (h[2 * i] < a) a = h[2 * i];
+            if (h[2 * i + 1] > b) b = h[2 * i + 1];
         }
-        gps::g_pool.push_back(p.a);
-        gps::g_pool.push_back(p.b);
+        if (a == ~0ull || b < a) continue;   // (a launch that was refused)
+        const double us = (double)(b - a) * gps::TICK_US;
+        gps::g_total_us[r.kind][r.flag] += us;
+        gps::g_launches[r.kind][r.flag]++;
+        if (us > gps::g_max_us[r.kind]) gps::g_max_us[r.kind] = us;
     }
-    gps::g_pairs.clear();
-    (void)hipGetLastError();
-    return rc;
+    gps::g_recs.clear();
+    return GPS_OK;
 }
 
 int gps_launch_timing_read(int kind, double* total_us, int64_t* launches, double* total_us_flagged, int64_t* launches_flagged,

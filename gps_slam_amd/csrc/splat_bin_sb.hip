@@ -43,7 +43,8 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
 }
 
 // ---- one wave per tile: exclusive prefix of the tile's row of C over the superblocks; C is left zero ----
-__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t) {
+__global__ __launch_bounds__(256) void sb_scan_kernel(int n_tiles, SbTables t, gps::LaunchStamp stamp) {
+    gps::StampScope timed(stamp);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
     static_assert(SB_MAX == 512, "a lane owns 8 consecutive superblocks");
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void sb_scatter_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const int32_t* __restrict__ tiles_per_gauss,
     int tile_size, int tw, int th, SbTables t, int64_t isect_cap, int32_t* __restrict__ flatten_ids,
     int32_t* __restrict__ tile_offsets, int64_t* __restrict__ counts, int32_t* __restrict__ cls_ids,
-    int32_t* __restrict__ cls_counts, int64_t cls_stride) {
+    int32_t* __restrict__ cls_counts, int64_t cls_stride, gps::LaunchStamp stamp) {
+    gps::StampScope timed(stamp);
     extern __shared__ uint32_t lds[];
     const int n_tiles = tw * th;
     if (blockIdx.x == gridDim.x - 1) {

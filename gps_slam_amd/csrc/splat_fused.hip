@@ -163,7 +163,8 @@ __device__ __forceinline__ void sb_histogram_block(const BinCountOut& cnt, uint3
 }
 
 template <int DEG>
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, FwdOut w, BinCountOut cnt, ZeroGrads zg) {
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(FusedIn in, FwdOut w, BinCountOut cnt, ZeroGrads zg, LaunchStamp stamp) {
+    StampScope timed(stamp);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     FwdBox bx = {0, 0, 0, 0.f, 0.f, 0};
     if (i < in.N) {
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(FusedIn in, FusedAd
                                                              float* __restrict__ v_quats,
                                                              float* __restrict__ v_opac_logit,
                                                              float* __restrict__ v_sh_dc,
-                                                             float* __restrict__ v_sh_rest, NextFwd nf) {
+                                                             float* __restrict__ v_sh_rest, NextFwd nf, LaunchStamp stamp) {
+    StampScope timed(stamp);
     // sh_tile: this workgroup's sh_rest rows.  Without FUSE_ADAM their gradients overwrite them in place; with it the
     // gradients go to a second tile so that parameter and gradient are both at hand for the update.
     extern __shared__ float sh_tile[];

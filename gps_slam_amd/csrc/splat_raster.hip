@@ -171,7 +171,8 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
     const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
-    float* __restrict__ render_alphas, gps::FwdCompose fc, const int32_t* __restrict__ tile_order) {
+    float* __restrict__ render_alphas, gps::FwdCompose fc, const int32_t* __restrict__ tile_order, gps::LaunchStamp stamp) {
+    gps::StampScope timed(stamp);
     // 48-byte records {mx, my, 0.5*ca*log2e, cb*log2e | 0.5*cc*log2e, -log2(opac), depth, r | g, b, -, -}; after the last batch the
     // same memory carries the parts' partial sums
     constexpr int PART_FLOATS = (FWD_SPLIT - 1) * 128 * 10;

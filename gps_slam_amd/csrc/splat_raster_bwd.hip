@@ -281,7 +281,8 @@ struct StripArgs {
 
 constexpr int NCLS = GPS_BWD_CLASSES;
 
-__global__ __launch_bounds__(256, GPS_STRIP_WAVES) void raster_ges_bwd_strip_kernel(StripArgs a) {
+__global__ __launch_bounds__(256, GPS_STRIP_WAVES) void raster_ges_bwd_strip_kernel(StripArgs a, gps::LaunchStamp stamp) {
+    gps::StampScope timed(stamp);
     const uint32_t n_px = (uint32_t)(a.W * a.H);
     const StripPix px = {buf_rsrc(a.v_render_colors, n_px * 16u), buf_rsrc(a.pix2, n_px * 8u), a.W, a.H};
     const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;

@@ -419,7 +419,8 @@ __device__ __forceinline__ bool project_voxel(const TsdfState& s, const Mat4& M,
 }
 
 template <bool FAST_DIV>
-__global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M) {
+__global__ __launch_bounds__(256) void integrate_kernel(TsdfState s, Mat4 M, gps::LaunchStamp stamp) {
+    gps::StampScope timed(stamp);
     GPS_FRAME_PRIO();
     __shared__ uint16_t queue[4][BLK3];  // per wave: (slice << 6 | lane) of the voxels that take the colour update
     const int n_visible = s.counters[GPS_TSDF_N_VISIBLE];

@@ -313,7 +313,8 @@ template <bool MODIFY_VISIBLE>
 __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
                                                      float4* __restrict__ rays, const uint32_t* __restrict__ bits,
                                                      const ViewRec* __restrict__ views, const uint2* __restrict__ partial, int sw,
-                                                     int sh, float2* __restrict__ mm_out) {
+                                                     int sh, float2* __restrict__ mm_out, gps::LaunchStamp stamp) {
+    gps::StampScope timed(stamp);
     GPS_FRAME_PRIO();
     if (views) {
         apply_view(s, views[blockIdx.z]); invM = views[blockIdx.z].invM;
@@ -730,10 +731,10 @@ int gps_tsdf_free_raycast_batch(const gps_tsdf_state* sp, int n_views, const gps
     const dim3 grid(gps_div_up(s.width, 2 * RC_PW), gps_div_up(s.height, 2 * RC_PH), n_views);   // (the raycaster's)
 #ifdef GPS_ED_REDUCE_LAUNCH
     expected_depths_reduce_kernel<<<dim3(gps_div_up(sw * sh, 256), 1, n_views), 256, 0, st>>>(s, sw, sh, ED_GROUPS, nullptr, nullptr, tab);
-    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, 0, 0, nullptr);
+    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, 0, 0, nullptr, gps::LaunchStamp{nullptr});
 #else
     // (pass B of the expected depths rides in the raycaster)
-    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, sw, sh, nullptr);
+    raycast_kernel<false><<<grid, 256, 0, st>>>(s, none, nullptr, nullptr, bucket_bits(s), tab, nullptr, sw, sh, nullptr, gps::LaunchStamp{nullptr});
 #endif
     colour_kernel<<<dim3(gps_div_up(s.width, 16), gps_div_up(s.height, 16), n_views), 256, 0, st>>>(s, nullptr, nullptr, tab);
     GPS_LAUNCH_CHECK();

@@ -45,12 +45,14 @@ GPS_API const char *gps_build_flags(void);
 
 /* In-loop launch timing -- measurement support for bench.py's `roofline` ("achieved = algorithmic bytes / that
  * kernel's average launch duration, measured live with HIP events on the stream the kernel is launched on").  Between _start and
- * _stop every launch of the kernels below, from whichever entry point, host thread and stream, is dispatched with a start and a
- * stop event bound to the kernel's own dispatch (hipExtLaunchKernelGGL: the begin / end timestamps of that kernel, what a
- * rocprofv3 kernel trace reports); _stop waits for them and sums the elapsed times per kind.  `flagged` = the subset with the
- * kind's flag set (PREPROCESS_BWD: the next iteration's preprocessing forward rode in the launch; RASTER_FWD: with the compose +
- * L1 epilogue; RAYCAST: a free view).  Results never depend on it; off by default and after _stop.  capacity = launches
- * recorded at most (further ones are counted in *dropped).  No reference counterpart (the reference times stages on the host,
+ * _stop every launch of the kernels below, from whichever entry point, host thread and stream, stamps the device's 100 MHz
+ * wall clock at the start and at the end of each of its waves into its workgroup's {first start, last end} slot
+ * (csrc/launch_timing.hpp; a launch's interval = last end - first start over its workgroups):
+ * the kernel's own execution interval, as a rocprofv3 kernel trace reports it minus the dispatch's ramp-up and the end-of-kernel
+ * release; _stop synchronises the device, reads the slots and sums per kind.  `flagged` = the subset with the kind's flag set
+ * (PREPROCESS_BWD: the next iteration's preprocessing forward rode in the launch; RASTER_FWD: with the compose + L1 epilogue;
+ * RAYCAST: a free view).  Results never depend on it; off by default and after _stop.  capacity = workgroup slots (16 bytes
+ * each) a window can hold; launches that no longer fit run unstamped and are counted in *dropped.  No reference counterpart (the reference times stages on the host,
  * slam_pipeline.cpp:135-167). */
 #define GPS_TIMED_PREPROCESS_BWD 0
 #define GPS_TIMED_PREPROCESS_FWD 1

@@ -12,7 +12,7 @@ rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o
   echo "Command: \`rocprofv3 --kernel-trace --stats -- $CMD\`; tools/prof_summary.py, one table per schedule over 5 windows of 20 frames."
   python tools/prof_summary.py "$(find /tmp/prof_stats -name '*.db' | head -1)" 40 --frames 20 --windows 5 --in-loop
   echo
-  echo "### the same run's in-loop launch timings (start / stop events bound to each dispatch, one extra 20-frame window per schedule)"
+  echo "### the same run's in-loop launch timings (device-clock stamps of each launch's first wave start / last wave end, one extra 20-frame window per schedule)"
   echo
   grep '^{"metric"' gpurun_out/bench_prof.log | tail -1 | python -c "
 import json, sys

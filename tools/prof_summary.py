@@ -77,8 +77,8 @@ def main():
             k = sidx * per + nw
             lo, hi = marks[2 * k], marks[2 * k + 1]
             print("\n### schedule %s: the in-loop launch-timing window (%d extra frames after the timed windows, every launch of the instrumented "
-                  "kernels dispatched with start / stop events; %.3f ms between its markers) -- the bench line's roofline.avg_launch_us is the "
-                  "event-measured average of THESE launches\n" % (names[sidx], frames or 0, (hi - lo) / 1e6))
+                  "kernels stamps the device clock; %.3f ms between its markers) -- the bench line's roofline.avg_launch_us is the "
+                  "stamp-measured average of THESE launches\n" % (names[sidx], frames or 0, (hi - lo) / 1e6))
             table([(n, e - s) for n, s, e in body if lo <= s < hi], 12, frames)
     scaffold_from = marks[2 * n_timed] if len(marks) > 2 * n_timed else None
     if scaffold_from is not None:
