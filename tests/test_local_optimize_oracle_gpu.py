@@ -11,11 +11,11 @@ kernels it calls): projection + SH + clamp -> isect_tiles -> raster_ges_fwd -> (
 image gradients -> raster_ges_bwd_gs -> SH / projection adjoints -> exp / sigmoid chain rule -> Adam in float32 with the
 reference's float-derived scalars (tests/test_adam_libtorch_gpu.py pins the HIP Adam to libtorch's own).
 
-Stated tolerances.  Loss: |hip - oracle| <= 1e-3 * oracle at every one of the 20 iterations (measured: see the printed
-trajectory).  Final parameters: Adam normalises the gradient, so an element whose gradient cancels to ~0 can take a step of
-the opposite sign on the two sides (+-lr per step, whatever the size of the rounding difference that flipped it); the bound
-per element is therefore the hard one, |diff| <= 2 lr x 20 steps, and the distribution is what is asserted: >= 99 % of the
-elements of every tensor within 2 % of that travel (0.8 lr), and the mean |diff| below 0.05 lr.
+Stated tolerances (about ten times what the committed scene measures: loss 1.7e-7 relative, parameters <= 0.0023 lr).  Loss:
+|hip - oracle| <= 2e-6 * oracle at every one of the 20 iterations.  Final parameters: Adam normalises the gradient, so an
+element whose gradient cancels to ~0 could take a step of the opposite sign on the two sides (+-lr per step, whatever the size of
+the rounding difference that flipped it) -- the hard bound per element is 2 lr x 20 steps, and none does on this scene: asserted
+are max |diff| <= 0.02 lr and mean |diff| <= 1e-4 lr for every tensor.
 """
 import numpy as np
 import pytest
@@ -66,6 +66,7 @@ def test_free_running_local_optimize_matches_the_oracle():
 
     # ---- HIP: the product's train step, 20 times
     loss_hip = []
+    m._step_struct(W, H)   # (allocates the persistent buffers on first use)
     for it in range(ITERS):
         v = views[draws[it]]
         m.loss_sum().zero_()
@@ -101,7 +102,7 @@ def test_free_running_local_optimize_matches_the_oracle():
     print("loss hip   :", " ".join("%.6f" % x for x in loss_hip))
     print("loss oracle:", " ".join("%.6f" % x for x in loss_orc))
     print("max relative loss difference over %d iterations: %.3g" % (ITERS, max(rel)))
-    assert max(rel) <= 1e-3, rel
+    assert max(rel) <= 2e-6, rel
     assert loss_orc[-1] < loss_orc[0] or len(set(draws)) > 1   # (different views: not a monotone sequence by construction)
     for name, a, b, lr in zip(("means", "scales", "quats", "featuresDc", "featuresRest", "opacities"), P_hip, P, lrs):
         d = np.abs(a.astype(np.float64) - b)
@@ -109,6 +110,5 @@ def test_free_running_local_optimize_matches_the_oracle():
         frac_small = float((d <= 0.02 * travel).mean())
         print("%-13s max |diff| %.3g (%.3f of the 2 lr x %d bound), mean %.3g (%.4f lr), within 0.8 lr: %.5f"
               % (name, d.max(), d.max() / travel, ITERS, d.mean(), d.mean() / lr, frac_small))
-        assert d.max() <= travel * 1.001, name
-        assert frac_small >= 0.99, (name, frac_small)
-        assert d.mean() <= 0.05 * lr, (name, d.mean() / lr)
+        assert d.max() <= 0.02 * lr, (name, d.max() / lr)
+        assert d.mean() <= 1e-4 * lr, (name, d.mean() / lr)
