@@ -90,6 +90,7 @@ PROTOTYPES = {
                                     i32, vp]),
     "gps_raster_ges_bwd_strips": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]),
     "gps_set_frame_chain_reserve": (None, [i32]),
+    "gps_set_raster_fwd_persistent": (None, [i32]),
     "gps_raster_pack_records": (i32, [i32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_raster_pair_image": (i32, [i32, i32, vp, vp, f32, vp, vp]),
     "gps_raster_ges_bwd_exact": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),

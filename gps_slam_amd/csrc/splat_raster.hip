@@ -318,6 +318,247 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_ges_fwd_pk_kernel(
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// The same forward as a PERSISTENT launch (round 6; the round-5 review's item 3).  BUILT, BIT-IDENTICAL, MEASURED SLOWER -- kept behind
+// gps_set_raster_fwd_persistent(1) with its equality test, off by default.  The idea: raster_ges_fwd_pk_kernel's workgroups pay three
+// dependent loads (tile offsets -> list -> records) + barriers before they evaluate, all workgroups of a compute unit go through
+// those phases in lock-step, and 1,200 tiles on 1,024 workgroup slots leave a nearly empty second round; so let PP_WGS_PER_CU
+// workgroups per compute unit stay resident and walk a STATIC share of the tiles:
+//   * dealing: the binning's tile_order (tiles by descending list length) is dealt in a snake -- pass p gives workgroup w the
+//     tile at position p G + w (p even) or (p + 1) G - 1 - w (p odd): the longest list of one pass meets the shortest of the
+//     next, no tickets, no atomics;
+//   * cross-tile staging: the work is a stream of (tile, 512-entry batch) items.  While item s is evaluated out of LDS the
+//     records of item s + 1 are on their way into registers (their list entries were fetched one item earlier still) and the
+//     list entries of item s + 2 are being fetched (unconditional loads from clamped indices: a load under a lane mask, or a
+//     select on its value, makes the compiler wait on the spot); the next tile's reference depths come in the same way;
+//   * everything per (pixel, entry) -- staging arithmetic, culling, survivor partition, blend, the order partial sums are added
+//     in -- is the per-tile kernel's, so the images are BIT-IDENTICAL to it (tests/test_splat_gpu.py).
+// Measured (tools/probe/fwd_pp_ab.py, fwd_pp_stamps.py; 640x480 / 499 k list entries and 1200x680 / 951 k): 51.5 us against 42.7
+// (per-tile, ordered) and 91.4 against 72.8.  The stamps say why: the look-ahead works (a further tile costs 11.6 / 12.7 us
+// against 19-28 of residency in the per-tile launch), but (i) the FIRST tile of every workgroup -- the 768 longest lists --
+// starts at t = 0 everywhere: 7 us of dependent loads during which no wave of the chip evaluates, then 16.5 us (median, 26 max)
+// in which every wave evaluates at once and the compute units are VALU-bound (13.7 M of the launch's 18.3 M wave instructions
+// = 11 us at full issue rate), then a 4 us tail per tile waiting for its slowest wave; (ii) 80 VGPRs (look-ahead registers) allow 6
+// waves per SIMD, not 8.  What bounds the forward is its VALU work (15-18 us at these sizes) plus one synchronised start-up
+// and per-tile tails, not the load chain of the later tiles; the per-tile launch already hides that chain behind the other
+// three workgroups of its compute unit.
+constexpr int PP_MAX_PASSES = 32;   // tiles one persistent workgroup can be dealt (more: the per-tile kernel)
+constexpr int PP_WGS_PER_CU = 3;    // 8 waves each at <= 80 VGPRs and 27 KB of LDS
+
+__global__ __launch_bounds__(FWD_THREADS, 2 * PP_WGS_PER_CU) void raster_ges_fwd_pp_kernel(
+    const float4* __restrict__ recs, const float* __restrict__ ref_depth, int W, int H, int tw, int th,
+    const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    const int64_t* __restrict__ counts, float delta_depth, float4* __restrict__ render_colors,
+    float* __restrict__ render_alphas, gps::FwdCompose fc, const int32_t* __restrict__ tile_order, gps::LaunchStamp stamp) {
+    static_assert(FWD_TRIPS == 1, "one list entry per thread and batch");
+    gps::StampScope timed(stamp);
+    constexpr int PART_FLOATS = (FWD_SPLIT - 1) * 128 * 10;
+    constexpr int REC_FLOATS = FWD_BATCH * 12;
+    __shared__ float4 lds_rec[(REC_FLOATS > PART_FLOATS ? REC_FLOATS : PART_FLOATS) / 4];
+    __shared__ uint16_t sidx[2][FWD_BATCH];
+    __shared__ int scnt[2][FWD_SEGS];
+    __shared__ int t_tile[PP_MAX_PASSES], t_lo[PP_MAX_PASSES], t_hi[PP_MAX_PASSES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int list_part = wave >> 1, pix_half = wave & 1;
+    const int T = tw * th, G = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int n_pass = (T + G - 1) / G;
+    const int n_isects = (int)counts[0];
+    if (tid < n_pass) {
+        const int pos = (tid & 1) ? (tid + 1) * G - 1 - wg : tid * G + wg;
+        int tile = -1, lo = 0, hi = 0;
+        if (pos < T) {
+            tile = tile_order ? tile_order[pos] : pos;
+            lo = tile_offsets[tile];
+            hi = (tile == T - 1) ? n_isects : tile_offsets[tile + 1];
+        }
+        t_tile[tid] = tile; t_lo[tid] = lo; t_hi[tid] = hi;
+    }
+    FWD_STAMP(0);
+    __syncthreads();
+    FWD_STAMP(1);
+    // (positions past the last tile only occur in the last pass)
+    const int n_mine = __builtin_amdgcn_readfirstlane(n_pass > 0 && t_tile[n_pass - 1] < 0 ? n_pass - 1 : n_pass);
+    if (n_mine <= 0) return;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const unsigned long long lt = lanemask_lt();
+
+    // the item stream: (index into my tiles, batch start); uniform over the workgroup
+    struct Item { int ti, bs; };
+    auto item_next = [&](Item it) {
+        if (it.ti >= n_mine) return it;
+        if (it.bs + FWD_BATCH < t_hi[it.ti]) { it.bs += FWD_BATCH; return it; }
+        it.ti++;
+        it.bs = it.ti < n_mine ? t_lo[it.ti] : 0;
+        return it;
+    };
+    // Every load of the look-ahead is UNCONDITIONAL, from a clamped index, and nothing is computed from its result before the item
+    // that consumes it: a load under a lane mask (or a select on its value) makes the compiler wait for it on the spot -- the
+    // first build of this kernel did, and ran behind its own "prefetches".  Validity travels separately, from the indices alone.
+    auto has_entry = [&](Item it) -> bool { return it.ti < n_mine && it.bs + tid < t_hi[it.ti]; };
+    auto load_id = [&](Item it) -> int {   // this thread's list entry of the item (some valid entry's id when it has none)
+        const int idx = it.ti < n_mine ? it.bs + tid : 0;
+        return flatten_ids[max(0, min(idx, n_isects - 1))];   // (no list at all: word 0 of the buffer, never used as an id -- has_entry)
+    };
+    auto pixel_of = [&](int tile, int& row, int& col) {
+        const int ty = tile / tw, tx = tile - ty * tw;
+        row = ty * 16 + pix_half * 8 + (lane >> 3); col = tx * 16 + 2 * (lane & 7);
+    };
+    auto load_depths = [&](int tile, float& d0, float& d1) {   // raw reference depths of the thread's two pixels (clamped into the image)
+        int row, col;
+        pixel_of(tile, row, col);
+        const int r = min(row, H - 1);
+        d0 = ref_depth[r * W + min(col, W - 1)];
+        d1 = ref_depth[r * W + min(col + 1, W - 1)];
+    };
+    auto cuts_of = [&](int row, int col, float d0, float d1, float& c0, float& c1) {   // pixels outside the image never pass the depth test
+        c0 = (row < H && col < W) ? d0 + delta_depth : -3.0e38f;
+        c1 = (row < H && col + 1 < W) ? d1 + delta_depth : -3.0e38f;
+    };
+
+    Item A = {0, t_lo[0]}, B = item_next(A), C = item_next(B);
+    const int idA = load_id(A);
+    int idB = load_id(B);
+    bool haveA = has_entry(A), haveB = has_entry(B);
+    const size_t gA = haveA ? (size_t)idA : 0;   // (record 0 stands in where the thread has no entry: N > 0)
+    float4 Ra = recs[3 * gA], Rb = recs[3 * gA + 1], Rc = recs[3 * gA + 2];
+    int row, col;
+    pixel_of(t_tile[0], row, col);
+    float cut0, cut1, dn0, dn1;
+    load_depths(t_tile[0], dn0, dn1);
+    cuts_of(row, col, dn0, dn1, cut0, cut1);
+    v2f o0 = {0.f, 0.f}, o1 = o0, o2 = o0, o3 = o0, ws = o0;
+    const char* rec_bytes = reinterpret_cast<const char*>(lds_rec);
+
+    while (A.ti < n_mine) {
+        const int tile = t_tile[A.ti], hiA = t_hi[A.ti];
+        const int ty = tile / tw, tx = tile - ty * tw;
+        const bool empty = A.bs >= hiA;               // a tile without a list: straight to its epilogue
+        const bool last_batch = empty || A.bs + FWD_BATCH >= hiA;
+        const v2f px = {(float)col + 0.5f, (float)col + 1.5f};
+        const float py = (float)row + 0.5f;
+        __syncthreads();   // the previous item's records, lists and partial sums are consumed
+        bool h0 = false, h1 = false;
+        if (!empty) {
+            // ---- stage item A (its records are in registers) + cull per 16 x 8 half, exactly as the per-tile kernel does
+            if (haveA) {
+                const int k = tid;
+                lds_rec[3 * k] = make_float4(Ra.x, Ra.y, 0.5f * LOG2E * Ra.z, LOG2E * Ra.w);
+                lds_rec[3 * k + 1] = make_float4(0.5f * LOG2E * Rb.x, -__log2f(Rb.y), Rb.z, Rb.w);
+                lds_rec[3 * k + 2] = make_float4(Rc.x, Rc.y, 0.f, 0.f);
+                const int xb = __float_as_int(Rc.z), yb = __float_as_int(Rc.w);
+                const int x_lo = (int)(short)(xb & 0xffff), x_hi = xb >> 16, y_lo = (int)(short)(yb & 0xffff), y_hi = yb >> 16;
+                const bool in_x = x_lo <= x_hi && y_lo <= y_hi && x_lo <= tx * 16 + 15 && x_hi >= tx * 16;
+                h0 = in_x && y_lo <= ty * 16 + 7 && y_hi >= ty * 16;
+                h1 = in_x && y_lo <= ty * 16 + 15 && y_hi >= ty * 16 + 8;
+            }
+        }
+        // ---- the loads of the items behind: records of B (its entries arrived an item ago), entries of C, the next tile's depths
+        const size_t gB = haveB ? (size_t)idB : 0;
+        Ra = recs[3 * gB]; Rb = recs[3 * gB + 1]; Rc = recs[3 * gB + 2];
+        const int idC = load_id(C);
+        const bool haveC = has_entry(C);
+        load_depths(t_tile[min(A.ti + 1, n_mine - 1)], dn0, dn1);
+        if (!empty) {
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            const int r0 = __popcll(m0 & lt), r1 = __popcll(m1 & lt);
+            if (lane == 0) { scnt[0][wave] = __popcll(m0); scnt[1][wave] = __popcll(m1); }
+            __syncthreads();
+            int pre0[FWD_SEGS + 1], pre1[FWD_SEGS + 1];
+            pre0[0] = 0; pre1[0] = 0;
+#pragma unroll
+            for (int w = 0; w < FWD_SEGS; w++) { pre0[w + 1] = pre0[w] + scnt[0][w]; pre1[w + 1] = pre1[w] + scnt[1][w]; }
+            int S = pix_half ? pre1[FWD_SEGS] : pre0[FWD_SEGS];
+            int b0 = 0, b1 = 0;
+#pragma unroll
+            for (int w = 0; w < FWD_SEGS; w++)
+                if (w == wave) { b0 = pre0[w]; b1 = pre1[w]; }
+            if (h0) sidx[0][b0 + r0] = (uint16_t)(3 * tid);
+            if (h1) sidx[1][b1 + r1] = (uint16_t)(3 * tid);
+            __syncthreads();
+            if (A.ti == 0 && A.bs == t_lo[0]) FWD_STAMP(2);
+            S = __builtin_amdgcn_readfirstlane(S);
+            const int lo = list_part * S / FWD_SPLIT, cnt = (list_part + 1) * S / FWD_SPLIT - lo;
+            int addr[FWD_VECS];
+#pragma unroll
+            for (int k = 0; k < FWD_VECS; k++) addr[k] = (64 * k + lane < cnt) ? 16 * (int)sidx[pix_half][lo + 64 * k + lane] : 0;
+            auto blend = [&](int byte_off) {
+                const float4 a = *reinterpret_cast<const float4*>(rec_bytes + byte_off);
+                const float4 b = *reinterpret_cast<const float4*>(rec_bytes + byte_off + 16);
+                const float2 c = *reinterpret_cast<const float2*>(rec_bytes + byte_off + 32);
+                const float dy = a.y - py;
+                const v2f dx = a.x - px;
+                const float cdy2 = b.x * dy * dy, bdy = a.w * dy;
+                const v2f w = a.z * dx + bdy;
+                const v2f sig = w * dx + cdy2;
+                const v2f e = sig + b.y;
+                float al0 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.x));
+                float al1 = fminf(0.999f, __builtin_amdgcn_exp2f(-e.y));
+                const bool hit0 = !(b.z > cut0) && !(sig.x < 0.f) && !(al0 < 1.f / 255.f);
+                const bool hit1 = !(b.z > cut1) && !(sig.y < 0.f) && !(al1 < 1.f / 255.f);
+                const v2f al = {hit0 ? al0 : 0.f, hit1 ? al1 : 0.f};
+                o0 += b.w * al; o1 += c.x * al; o2 += c.y * al; o3 += b.z * al; ws += al;
+            };
+#pragma unroll
+            for (int k = 0; k < FWD_VECS; k++) {
+                const int n_k = min(cnt - 64 * k, 64);
+                for (int j = 0; j + 1 < n_k; j += 2) {
+                    const int t0 = __builtin_amdgcn_readlane(addr[k], j), t1 = __builtin_amdgcn_readlane(addr[k], j + 1);
+                    blend(t0);
+                    blend(t1);
+                }
+                if (n_k > 0 && (n_k & 1)) blend(__builtin_amdgcn_readlane(addr[k], n_k - 1));
+            }
+        }
+        if (A.ti == 0 && last_batch) FWD_STAMP(3);
+        if (last_batch) {
+            // ---- the tile's epilogue: list parts 1.. -> LDS (over the records) -> part 0 adds them in order and stores
+            __syncthreads();
+            if (A.ti == 0) FWD_STAMP(4);
+            float* part = reinterpret_cast<float*>(lds_rec);
+            const int slot = (pix_half * 64 + lane) * 10;
+            if (list_part) {
+                float* q = part + (list_part - 1) * 1280 + slot;
+                q[0] = o0.x; q[1] = o1.x; q[2] = o2.x; q[3] = o3.x; q[4] = ws.x;
+                q[5] = o0.y; q[6] = o1.y; q[7] = o2.y; q[8] = o3.y; q[9] = ws.y;
+            }
+            __syncthreads();
+            if (!list_part) {
+                const bool in0 = (row < H) && (col < W), in1 = (row < H) && (col + 1 < W);
+                const int pix = row * W + col;
+#pragma unroll
+                for (int k = 0; k < FWD_SPLIT - 1; k++) {
+                    const float* q = part + k * 1280 + slot;
+                    o0.x += q[0]; o1.x += q[1]; o2.x += q[2]; o3.x += q[3]; ws.x += q[4];
+                    o0.y += q[5]; o1.y += q[6]; o2.y += q[7]; o3.y += q[8]; ws.y += q[9];
+                }
+                const float4 c0 = make_float4(o0.x, o1.x, o2.x, o3.x);
+                const float4 c1 = make_float4(o0.y, o1.y, o2.y, o3.y);
+                const float w0 = ws.x, w1 = ws.y;
+                if (in0) { render_colors[pix] = c0; render_alphas[pix] = w0; }
+                if (in1) { render_colors[pix + 1] = c1; render_alphas[pix + 1] = w1; }
+                if (fc.base_color) {
+                    float lsum = 0.f;
+                    if (in0) lsum += compose_l1_pixel(fc, pix, c0, w0, cut0);
+                    if (in1) lsum += compose_l1_pixel(fc, pix + 1, c1, w1, cut1);
+                    lsum = wave_sum(lsum);
+                    if (lane == 0) atomicAdd(fc.loss, lsum * fc.inv_count);
+                }
+            }
+            if (A.ti == 0) FWD_STAMP(5);
+            o0 = {0.f, 0.f}; o1 = o0; o2 = o0; o3 = o0; ws = o0;
+            if (A.ti + 1 < n_mine) { pixel_of(t_tile[A.ti + 1], row, col); cuts_of(row, col, dn0, dn1, cut0, cut1); }
+        }
+        haveA = haveB; haveB = haveC;
+        idB = idC;
+        A = B; B = C; C = item_next(C);
+    }
+    FWD_STAMP(6);
+#ifdef GPS_FWD_STAMPS
+    if (threadIdx.x == 0) gps_fwd_stamps_buf[blockIdx.x * 8 + 7] = (unsigned long long)n_mine;
+#endif
+}
+
+
 __global__ __launch_bounds__(256) void zero_grads_kernel(int N, float* __restrict__ v_means2d,
                                                         float* __restrict__ v_conics, float* __restrict__ v_colors,
                                                         float* __restrict__ v_opacities) {
@@ -563,6 +804,20 @@ __global__ __launch_bounds__(256) void raster_ges_bwd_gs_kernel(
 
 }  // namespace
 
+// persistent forward: OFF by default (measured slower, see the kernel's header); workgroups = PP_WGS_PER_CU per compute unit of the
+// current device (asked once)
+static int g_fwd_persistent = 0;
+static int fwd_persistent_workgroups() {
+    if (!__atomic_load_n(&g_fwd_persistent, __ATOMIC_RELAXED)) return 0;
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        (void)hipGetLastError();
+        return n;
+    }();
+    return cus * PP_WGS_PER_CU;
+}
+
 namespace gps {
 
 int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_depth_map, int width, int height,
@@ -582,9 +837,16 @@ int raster_ges_fwd_rec_launch(int N, const float* records, const float* ref_dept
     // (experiment, gps_set_frame_chain_reserve bit 1: 14 KB of unused dynamic LDS on top of the 26.7 KB the kernel declares -> 3
     // workgroups of 8 waves per compute unit instead of the 4 that fill every wave slot)
     const size_t pad = (gps::frame_chain_reserve_bits() & 2) ? 14 * 1024 : 0;
-    launch_kernel(TK_RASTER_FWD, compose ? 1 : 0, raster_ges_fwd_pk_kernel, dim3(tw * th), dim3(FWD_THREADS), pad, (hipStream_t)stream,
-                  (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
-                  (float4*)render_colors, render_alphas, fc, tile_order);
+    // the persistent launch (round 6) wherever its static dealing applies; gps_set_raster_fwd_persistent(0): the per-tile kernel
+    const int n_wg = fwd_persistent_workgroups();
+    if (FWD_TRIPS == 1 && N > 0 && n_wg > 0 && tw * th > n_wg / 2 && gps_div_up(tw * th, n_wg) <= PP_MAX_PASSES && pad == 0)
+        launch_kernel(TK_RASTER_FWD, compose ? 1 : 0, raster_ges_fwd_pp_kernel, dim3(n_wg), dim3(FWD_THREADS), 0, (hipStream_t)stream,
+                      (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
+                      (float4*)render_colors, render_alphas, fc, tile_order);
+    else
+        launch_kernel(TK_RASTER_FWD, compose ? 1 : 0, raster_ges_fwd_pk_kernel, dim3(tw * th), dim3(FWD_THREADS), pad, (hipStream_t)stream,
+                      (const float4*)records, ref_depth_map, width, height, tw, th, tile_offsets, flatten_ids, counts, delta_depth,
+                      (float4*)render_colors, render_alphas, fc, tile_order);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
@@ -636,6 +898,8 @@ int gps_raster_ges_fwd(int N, const float* means2d, const float* conics, const f
     GPS_LAUNCH_CHECK();
     return GPS_OK;
 }
+
+void gps_set_raster_fwd_persistent(int on) { __atomic_store_n(&g_fwd_persistent, on ? 1 : 0, __ATOMIC_RELAXED); }
 
 int gps_raster_ges_fwd_rec(int N, const float* records, const float* ref_depth_map, int width, int height,
                            const int32_t* tile_offsets, const int32_t* flatten_ids, const int64_t* counts,

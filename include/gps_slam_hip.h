@@ -205,6 +205,12 @@ GPS_API int gps_raster_ges_bwd_strips(int N, const float *records, const int32_t
  * part-filled second round is then the short lists; iteration 257 -> 248 us), on -> row-major (beside a frame chain the ordered
  * launch is 0.7 % slower).  Results do not depend on it. */
 GPS_API void gps_set_frame_chain_reserve(int on);
+/* Experiment switch (round 6): the record forward (gps_raster_ges_fwd_rec*, gps_splat_render, gps_splat_train_step) as a persistent
+ * launch -- 3 workgroups per compute unit walk a static, cost-balanced share of the tiles and stage the next batch's records
+ * while the current one is evaluated (csrc/splat_raster.hip: raster_ges_fwd_pp_kernel).  OFF by default: bit-identical images
+ * (tests/test_splat_gpu.py) but 51 against 43 us at 640x480 -- the forward is bound by its VALU work and one synchronised
+ * start-up, not by the later tiles' load chain (LABBOOK.md).  1 = on, for that test and for A/B timing. */
+GPS_API void gps_set_raster_fwd_persistent(int on);
 /* records[N,12] (the 48-byte records gps_gauss_preprocess_fwd writes, incl. the ellipse bounds) from the operator-level arrays
  * means2d[N,2] conics[N,3] colors[N,4] (rgb + depth) opacities[N] radii[N]: lets a caller that holds those run the strip backward */
 GPS_API int gps_raster_pack_records(int N, const float *means2d, const float *conics, const float *colors,

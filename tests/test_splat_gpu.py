@@ -508,6 +508,53 @@ def test_record_streaming_forward_equals_lds_forward(N, W, H):
         assert d.max().item() < 0.05
 
 
+@pytest.mark.parametrize("N,W,H", [(150000, 640, 480), (300000, 1200, 680), (4000, 50, 37), (1, 33, 17), (30000, 1600, 720), (600, 2560, 1440)])
+def test_persistent_forward_is_bit_identical_to_the_per_tile_forward(N, W, H):
+    """raster_ges_fwd_pp_kernel (persistent workgroups, snake-dealt tiles, records staged one item ahead) against
+    raster_ges_fwd_pk_kernel (one workgroup per tile): the same staging arithmetic, culling, survivor partition and summation order,
+    so the render and the weight sum must be IDENTICAL bit for bit -- row-major tile order and a permuted tile_order (the dealing
+    changes which workgroup renders a tile, never what it computes).  Sizes: BASELINE's 640x480, Replica's 1200x680 (ragged last
+    tile row), tiny images (fewer tiles than workgroups: the launcher keeps the per-tile kernel), 1600x720 and a 1440p image whose
+    14,400 tiles are 19 passes per workgroup, many of them with an empty list."""
+    from gps_slam_amd import gsplat_ops as ops
+    from gps_slam_amd._lib import check, lib
+    import ctypes as C
+    TS, delta = 16, 0.1
+    tw, th = (W + TS - 1) // TS, (H + TS - 1) // TS
+    g, vm, K, c2w = _setup(N, W, H, seed=N + 3)
+    rng = np.random.default_rng(N)
+    ref_depth = rng.uniform(1.5, 4.5, (H, W)).astype(np.float32)
+    ref_depth[rng.uniform(size=(H, W)) < 0.1] = 1000.0
+    rec = torch.empty((N, 12), device=_dev())
+    sh = T(g["sh"])
+    radii, m2, depths, conics, colors, opac = ops.gauss_preprocess_fwd(
+        T(g["means"]), T(g["log_scales"]), T(g["quats"]), T(g["opac_logit"]).view(-1), sh[:, 0].contiguous(),
+        sh[:, 1:].contiguous(), 3, T(vm), T(K), T(c2w[:3, 3].copy()), W, H, records=rec)
+    isect = ops.isect_tiles_no_depth(m2.view(1, N, 2), radii.view(1, N), TS, tw, th)
+    tref = T(ref_depth)[None, ..., None].contiguous()
+    order = torch.as_tensor(rng.permutation(tw * th).astype(np.int32)).to(_dev())
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def render(persistent, tile_order):
+        lib.gps_set_raster_fwd_persistent(1 if persistent else 0)
+        rc = torch.full((1, H, W, 4), float("nan"), device=_dev())
+        ra = torch.full((1, H, W, 1), float("nan"), device=_dev())
+        check(lib.gps_raster_ges_fwd_rec_ordered(N, ptr(rec), ptr(tref), W, H, ptr(isect.isect_offsets), ptr(isect.flatten_ids), ptr(isect.counts),
+                                                 delta, ptr(rc), ptr(ra), ptr(tile_order) if tile_order is not None else C.c_void_p(0), sp),
+              "gps_raster_ges_fwd_rec_ordered")
+        torch.cuda.synchronize()
+        return rc, ra
+    try:
+        rc0, ra0 = render(False, None)
+        assert torch.isfinite(rc0).all() and torch.isfinite(ra0).all()
+        for tile_order in (None, order):
+            rc1, ra1 = render(True, tile_order)
+            assert torch.equal(rc1, rc0) and torch.equal(ra1, ra0), "persistent forward differs (tile_order %s)" % ("given" if tile_order is not None else "row-major")
+    finally:
+        lib.gps_set_raster_fwd_persistent(0)   # (the shipped default)
+
+
 def test_adam_step_one_writes_the_moments_without_reading_them():
     """Step 1 is the first step of a fresh torch::optim::Adam (state created as zeros): gps_adam_step takes m = v = 0 without
     reading exp_avg / exp_avg_sq, so buffers full of NaN give the result of zeroed ones, and step 2 carries on from what step 1
