@@ -47,18 +47,26 @@ def synthetic_sequence(W, H, n_frames, seed):
     return seq
 
 
-def synthetic_sequence_device(W, H, n_frames, seed, device, intrinsics=None):
+def synthetic_sequence_device(W, H, n_frames, seed, device, intrinsics=None, step_deg=None, texture="room", world_scale=1.0):
     """tests/synth.py's room rendered with torch on the GPU (float64, the same formulas): the numpy renderer needs 0.2-0.6 s per
     frame, too slow for the extra configurations measured after the main windows (config.other_configs).  Same dictionary as
-    synthetic_sequence (arrays on the host).  intrinsics = (fx, fy, cx, cy) or None for the 90-degree pinhole."""
+    synthetic_sequence (arrays on the host).  intrinsics = (fx, fy, cx, cy) or None for the 90-degree pinhole.
+    step_deg: the orbit's angle per frame (default 0.25-0.31 by seed).  world_scale: the whole scene -- room, spheres, orbit --
+    scaled about the origin (0.4: the camera is 0.4-1.5 m from the surfaces, a pixel's footprint 1.3-4.7 mm, below the 5 mm voxel).
+    texture "fine": no checker; the low-frequency colour at 0.55 contrast + three sine gratings of 12 / 15 / 19 mm period (amplitude 0.15
+    each) in different directions: detail of 2-4 voxels per period that the image resolves (4-12 pixels per period at 0.5-1.5 m)
+    and a 5 mm colour volume attenuates -- a workload where the Gaussians have something to add (round-5 review, item 8a)."""
     from tests import synth
     fx, fy, cx, cy = intrinsics if intrinsics else (0.5 * W, 0.5 * W, (W - 1) / 2.0, (H - 1) / 2.0)
-    poses = synth.orbit_poses(n_frames, step_deg=0.25 + 0.01 * (seed % 7))
+    poses = synth.orbit_poses(n_frames, step_deg=step_deg if step_deg is not None else 0.25 + 0.01 * (seed % 7))
+    ws = float(world_scale)
+    if ws != 1.0:
+        poses = [np.concatenate([np.concatenate([p[:3, :3], p[:3, 3:4] * ws], 1), p[3:4]], 0) for p in poses]
     dd = dict(dtype=torch.float64, device=device)
     ys, xs = torch.meshgrid(torch.arange(H, **dd), torch.arange(W, **dd), indexing="ij")
     d_cam = torch.stack([(xs - cx) / fx, (ys - cy) / fy, torch.ones_like(xs)], -1)
-    half = torch.tensor((3.0, 1.5, 2.5), **dd)
-    spheres = ((0.4, 0.2, 0.3, 0.45), (-0.8, 0.5, -0.4, 0.35))
+    half = torch.tensor((3.0 * ws, 1.5 * ws, 2.5 * ws), **dd)
+    spheres = tuple(tuple(v * ws for v in sp) for sp in ((0.4, 0.2, 0.3, 0.45), (-0.8, 0.5, -0.4, 0.35)))
     rgbs, depths = [], []
     for c2w in poses:
         R, o = torch.as_tensor(c2w[:3, :3], **dd), torch.as_tensor(c2w[:3, 3], **dd)
@@ -82,12 +90,21 @@ def synthetic_sequence_device(W, H, n_frames, seed, device, intrinsics=None):
             t_best = torch.where(ok & (t < t_best), t, t_best)
         hit = torch.isfinite(t_best)
         tb = torch.where(hit, t_best, torch.zeros_like(t_best))
-        p = o + tb[..., None] * d
+        p = (o + tb[..., None] * d) / ws   # (texture coordinates of the unscaled room)
         r = 0.5 + 0.5 * torch.sin(3.1 * p[..., 0] + 1.7 * p[..., 1])
         g = 0.5 + 0.5 * torch.sin(2.3 * p[..., 1] - 2.9 * p[..., 2] + 1.0)
         b_ = 0.5 + 0.5 * torch.sin(4.1 * p[..., 2] + 0.7 * p[..., 0] - 0.5)
-        checker = ((torch.floor(p[..., 0] * 2) + torch.floor(p[..., 1] * 2) + torch.floor(p[..., 2] * 2)) % 2) * 0.25
-        tex = (torch.stack([r, g, b_], -1) * 0.75 + checker[..., None]).clamp(0, 1)
+        if texture == "fine":
+            q = p * ws   # (metres of the scene as rendered: the gratings' periods are physical)
+            tau = 2.0 * np.pi
+            g1 = torch.sin(tau * (q[..., 0] + 0.5 * q[..., 1] + 0.3 * q[..., 2]) / 0.012)
+            g2 = torch.sin(tau * (0.4 * q[..., 0] - q[..., 1] + 0.6 * q[..., 2]) / 0.015)
+            g3 = torch.sin(tau * (0.3 * q[..., 0] + 0.5 * q[..., 1] - q[..., 2]) / 0.019)
+            base = 0.225 + 0.55 * torch.stack([r, g, b_], -1)
+            tex = (base + 0.15 * torch.stack([g1, g2, g3], -1)).clamp(0, 1)
+        else:
+            checker = ((torch.floor(p[..., 0] * 2) + torch.floor(p[..., 1] * 2) + torch.floor(p[..., 2] * 2)) % 2) * 0.25
+            tex = (torch.stack([r, g, b_], -1) * 0.75 + checker[..., None]).clamp(0, 1)
         rgbs.append((torch.where(hit[..., None], tex, torch.zeros_like(tex)) * 255.0 + 0.5).to(torch.uint8).cpu())
         depths.append(torch.where(hit, torch.round(tb * 1000.0).clamp(0, 65535), torch.zeros_like(tb)).to(torch.int32).cpu())
     c2w = np.stack(poses).astype(np.float64)
@@ -314,6 +331,9 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
     ap.add_argument("--whole-run-frames", type=int, default=1000,
                     help="frames of the whole-sequence run from frame 0 (the reference's own FPS definition; N = 1 only, after the "
                          "headline windows; 0 = skip): config.whole_run_fps / whole_run_fps_sequential")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the two extra whole-sequence workloads (fine-texture detail run -> whole_run_gain_db; the reference's 30 deg / "
+                         "0.3 m keyframe thresholds on a 3 deg/frame orbit -> whole_run_fps_ref_thresholds)")
     ap.add_argument("--full-line", action="store_true",
                     help="print the FULL record (tens of kilobytes) as the stdout line, as rounds 1-5 did, instead of the compact one; "
                          "the full record is written to bench_full.json either way")
@@ -442,6 +462,18 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                             whole_run_gaussian_fps_sequential=wr["sequential"]["gaussian_fps"],
                             whole_run_slowest_frame_ms=wr["overlap"]["slowest_frame_ms_after_30"], whole_run_gpu_memory_mb=wr["overlap"]["gpu_memory_mb"],
                             whole_run_seconds_total=wr["seconds_total"])
+            if world == 1 and args.whole_run_frames > 0 and not args.no_workloads:
+                t_w = time.perf_counter()
+                dr = detail_run(args, seed, device)
+                # (every shipped config sets use_gt_pose: true; the headline run tracks -- both pose sources on the same sequence)
+                dg = detail_run(args, seed, device, gt_pose=not args.gt_pose)
+                rr = ref_threshold_run(args, seed, device)
+                out["config"]["detail_run"], out["config"]["detail_run_other_pose_source"], out["config"]["ref_threshold_run"] = dr, dg, rr
+                flat.update(whole_run_gain_db=dr["gain_db"], whole_run_detail_render_psnr_db=dr["render_psnr_db"],
+                            whole_run_detail_tsdf_psnr_db=dr["tsdf_colour_psnr_db"], whole_run_detail_gaussians_end=dr["gaussians_end"],
+                            **{"whole_run_gain_db_%s" % ("gt_pose" if dg["use_gt_pose"] else "tracked"): dg["gain_db"]},
+                            whole_run_fps_ref_thresholds=rr["overlap"]["fps"], whole_run_fps_ref_thresholds_sequential=rr["sequential"]["fps"],
+                            workloads_seconds=time.perf_counter() - t_w)
             if world == 1 and not args.no_other_configs:
                 oc = other_configs(args, seq, seed, device, first)
                 out["config"]["other_configs"] = oc
@@ -516,7 +548,7 @@ def compact_line(out):
     r = out.get("roofline")
     if r:
         keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us", "timed_in",
-                "launches_timed", "frac_alone", "avg_launch_us_alone", "measured_copy_GBs", "traffic_calibrated")
+                "launches_timed", "frac_alone", "avg_launch_us_alone", "measured_copy_GBs", "traffic_calibrated", "traffic_library_commit")
         rr = {k: _sig(r[k]) for k in keep if k in r}
         rr["frame_frac"], rr["iteration_frac"] = _sig(r["frame"]["frac"]), _sig(r["iteration"]["frac"])
         rr["frame_ms"], rr["iteration_us"] = _sig(r["frame"]["ms"]), _sig(r["iteration"]["avg_us"])
@@ -620,6 +652,74 @@ def whole_run(args, seed, device, n_frames):
         del sc
         torch.cuda.empty_cache()
     return res
+
+
+def _held_out_psnr(sc, seq, device, frames):
+    """render and TSDF-colour PSNR against the input image on `frames` (never optimise cameras), from their tracked poses, on the
+    scene's final state (tools/convergence.py does the same per keyframe update): -> (render dB, TSDF colour dB), means"""
+    def _psnr(a, b):
+        return float(-10.0 * torch.log10(((a.clamp(0, 1) - b) ** 2).mean()))
+    r, t = [], []
+    with torch.no_grad():
+        for j in frames:
+            cam = sc.cams[j]
+            rc = sc.pipe.runRaycastByCam(cam, False)
+            img = torch.as_tensor(seq["rgb"][j]).to(device).float() / 255.0
+            cam.image = img
+            cam.toGPU()
+            r.append(_psnr(sc.model.forward(cam, rc["depth_map"], rc["color_map"])["rgb"], img))
+            t.append(_psnr(rc["color_map"], img))
+    return sum(r) / len(r), sum(t) / len(t)
+
+
+def detail_run(args, seed, device, n_frames=300, gt_pose=None):
+    """A workload where the Gaussians have something to add (round-5 review, item 8a): the room scaled to 0.4 (the camera 0.4-1.5 m
+    from the surfaces: a pixel's footprint is below the 5 mm voxel) with the `fine` texture (12 / 15 / 19 mm gratings, no hard
+    steps), SLAMTrainCams from an empty model with the bench's keyframe thresholds, sequential schedule.  Afterwards the held-out
+    frames of the last ten keyframe periods (two per period; the local window takes every 5th frame and keyframes are picked
+    from those) are rendered from their tracked poses: gain = render PSNR - TSDF-colour PSNR against the input images."""
+    W, H = args.width, args.height
+    gt_pose = args.gt_pose if gt_pose is None else gt_pose
+    seq = synthetic_sequence_device(W, H, n_frames, seed, device, texture="fine", world_scale=0.4)
+    sc = Scene(seq, None, seed, gt_pose, overlap=False, n_frames=n_frames, keyframe_theta=args.keyframe_theta, keyframe_trans=args.keyframe_trans)
+    torch.cuda.synchronize()
+    tm = sc.pipe.SLAMTrainCamsTimed(sc.model, sc.cams)
+    last_kf = (n_frames - 1) // PERIOD * PERIOD
+    held = [k for p0 in range(max(PERIOD, last_kf - 10 * PERIOD), last_kf, PERIOD) for k in (p0 + 3, p0 + 7) if k < n_frames]
+    r_db, t_db = _held_out_psnr(sc, seq, device, held)
+    out = {"frames": n_frames, "size": "%dx%d" % (W, H), "use_gt_pose": bool(gt_pose), "fps_sequential": tm.fps(), "gaussians_end": int(sc.model.getGaussianNum()),
+           "held_out_frames": len(held), "render_psnr_db": r_db, "tsdf_colour_psnr_db": t_db, "gain_db": r_db - t_db,
+           "what": "room x 0.4, `fine` texture (12 / 15 / 19 mm sine gratings), empty model, sequential schedule; PSNR of the render and of the "
+                   "TSDF colour against the input on %d held-out frames of the last ten keyframe periods, %s poses"
+                   % (len(held), "given" if gt_pose else "tracked")}
+    sc.close()
+    del sc
+    torch.cuda.empty_cache()
+    return out
+
+
+def ref_threshold_run(args, seed, device, n_frames=300, step_deg=3.0):
+    """The reference's OWN keyframe thresholds (keyframe_theta_thres 30 deg, keyframe_trans_thres 0.3 m: configs/release/replica/
+    office0.yaml:54-55) on an orbit fast enough for them to trigger (3 deg per frame: a keyframe every ~10 frames), SLAMTrainCams
+    from an empty model, both schedules (round-5 review, item 8b)."""
+    W, H = args.width, args.height
+    seq = synthetic_sequence_device(W, H, n_frames, seed, device, step_deg=step_deg)
+    out = {"frames": n_frames, "size": "%dx%d" % (W, H), "orbit_deg_per_frame": step_deg, "keyframe_theta_deg": 30.0, "keyframe_trans_m": 0.3}
+    for sched in ("sequential", "overlap"):
+        sc = Scene(seq, None, seed, args.gt_pose, overlap=sched == "overlap", n_frames=n_frames, keyframe_theta=30.0, keyframe_trans=0.3)
+        torch.cuda.synchronize()
+        tm = sc.pipe.SLAMTrainCamsTimed(sc.model, sc.cams)
+        st = {k: int(v) for k, v in dict(sc.pipe.stats()).items()}
+        out[sched] = {"fps": tm.fps(), "gaussians_end": int(sc.model.getGaussianNum()), "keyframes": int(sc.pipe.keyframeCount()) if hasattr(sc.pipe, "keyframeCount") else None,
+                      "pipeline_stats": st}
+        if sched == "overlap" and not args.gt_pose:
+            # the tracked trajectory against the given one at the last frame (the fast orbit is a harder tracking problem)
+            fr, ev, rode, used = sc.engine.trackerTotals()
+            out["tracker_evaluations_per_frame"] = ev / max(1, fr)
+        sc.close()
+        del sc
+        torch.cuda.empty_cache()
+    return out
 
 
 def other_configs(args, seq, seed, device, first):

@@ -125,6 +125,7 @@ def _kernel_row(name, calls_per_frame, t, alg_bytes, hbm_peak_gbs, N, bound, not
     if rec:
         if rec.get("hbm_bytes_per_launch"):
             row["traffic"] = rec["hbm_bytes_per_launch"]
+            row["traffic_library_commit"] = rec.get("library_commit", "unknown (collected before round 6)")
             row["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / max(1.0, alg_bytes)
             # 2 x FETCH_SIZE + WRITE_SIZE.  The factor 2 is measured for streams AND for narrow gathers on this gfx950: every L2 miss
             # -- a 4-byte gather of an otherwise untouched line included -- is ONE 128-byte memory-side request that FETCH_SIZE
@@ -415,6 +416,7 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
                               "size (N within 2 %), committed -- not measured in this run; 2 x FETCH_SIZE + WRITE_SIZE, factor calibrated "
                               "for streams and gathers (profiles/r05_fetch_calibration.md)",
             "traffic_calibrated": bool(top.get("traffic_calibrated", False)),
+            "traffic_library_commit": top.get("traffic_library_commit"),
             "algorithmic_bytes": top["in_loop_bytes"] if in_loop else top["algorithmic_bytes"],
             "dominant_by": "largest in-loop time per frame (launches x average duration inside the running schedule) among the kernels "
                            "that move data; kernels[] is sorted by it.  track_eval_poll_kernel's residency is mostly its wait for the "

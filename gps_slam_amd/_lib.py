@@ -91,6 +91,7 @@ PROTOTYPES = {
     "gps_raster_ges_bwd_strips": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]),
     "gps_set_frame_chain_reserve": (None, [i32]),
     "gps_set_raster_fwd_persistent": (None, [i32]),
+
     "gps_raster_pack_records": (i32, [i32, vp, vp, vp, vp, vp, vp, vp]),
     "gps_raster_pair_image": (i32, [i32, i32, vp, vp, f32, vp, vp]),
     "gps_raster_ges_bwd_exact": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
@@ -131,6 +132,7 @@ PROTOTYPES = {
     "gps_tsdf_expected_depths_and_raycast": (i32, [C.POINTER(TsdfState), vp, vp, i32, i32, vp]),
     "gps_tsdf_icp_maps": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_ray_stats": (i32, [C.POINTER(TsdfState), vp]),
+    "gps_tsdf_ray_wave_rows": (i32, [C.POINTER(TsdfState), vp, i32, vp]),
     "gps_tsdf_find_visible": (i32, [C.POINTER(TsdfState), vp, vp]),
     "gps_tsdf_render_colour": (i32, [C.POINTER(TsdfState), vp]),
     "gps_tsdf_process_frame": (i32, [C.POINTER(TsdfState), vp, vp, vp, vp]),

@@ -497,10 +497,14 @@ __global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, co
     if (views == nullptr) {
         const float f_reads = (float)(n_log & 0xFFFFu), f_steps = f_reads + (float)(n_log >> 16);
         const float tot = gps::reduce4(f_steps, f_reads, inside ? 1.0f : 0.0f, 0.0f);   // rows 0..3, lane 15: sums of (steps, rays, reads, 0)
-        if ((lane_ & 15) == 15 && lane_ < 48) {
-            float* row = reinterpret_cast<float*>(ray_stats_rows(s) + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_in_wg));
-            row[lane_ == 15 ? 0 : lane_ == 31 ? 2 : 1] = tot;   // {steps, reads, rays}
-        }
+        // (round 6) the wave's LONGEST ray in trips of this loop: the wave is resident until that lane leaves the loop -- is the launch as
+        // long as its longest rays?  (tools/raycast_wave_hist.py; six shuffles per wave)
+        int wmax = (int)(n_log & 0xFFFFu);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+        float* row = reinterpret_cast<float*>(ray_stats_rows(s) + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave_in_wg));
+        if ((lane_ & 15) == 15 && lane_ < 48) row[lane_ == 15 ? 0 : lane_ == 31 ? 2 : 1] = tot;   // {steps, reads, rays}
+        if (lane_ == 63) row[3] = (float)wmax;
     }
 }
 
@@ -836,6 +840,17 @@ int gps_tsdf_ray_stats(const gps_tsdf_state* sp, gps_stream stream) {
     ray_stats_sum_kernel<<<1, 256, 0, (hipStream_t)stream>>>(*sp);
     GPS_LAUNCH_CHECK();
     return GPS_OK;
+}
+
+int gps_tsdf_ray_wave_rows(const gps_tsdf_state* sp, float* rows_out, int capacity_rows, gps_stream stream) {
+    GPS_ENTER();
+    GPS_REQUIRE(sp != nullptr && rows_out != nullptr && capacity_rows >= 0);
+    GPS_REQUIRE(state_valid(*sp));
+    const TsdfState& s = *sp;
+    const int n_rows = ((s.width + 2 * RC_PW - 1) / (2 * RC_PW)) * ((s.height + 2 * RC_PH - 1) / (2 * RC_PH)) * 4;   // waves of one raycast launch
+    const int n = n_rows < capacity_rows ? n_rows : capacity_rows;
+    if (n > 0 && hipMemcpyAsync(rows_out, ray_stats_rows(s), (size_t)n * 16, hipMemcpyDefault, (hipStream_t)stream) != hipSuccess) return GPS_ERR_LAUNCH;
+    return n;
 }
 
 int gps_tsdf_icp_maps(const gps_tsdf_state* sp, const float* invM, gps_stream stream) {

@@ -322,6 +322,7 @@ PYBIND11_MODULE(_host, m) {
             d["added"] = p.stats.added.load(); d["pruned"] = p.stats.pruned.load();
             return d;
         })
+        .def("keyframeCount", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return (int)p.keyframe_cam_list.size(); })
         .def("optCams", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return p.opt_cam_list; })
         .def("optRaycasts", [](SLAMPipeline& p) { { py::gil_scoped_release nogil; p.flush(); } return p.opt_raycast_list; })
         .def_readwrite("workspace_dir", &SLAMPipeline::workspace_dir)

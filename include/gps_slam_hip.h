@@ -655,6 +655,11 @@ GPS_API int gps_tsdf_icp_maps(const gps_tsdf_state *s, const float *invM, gps_st
 /* counters[GPS_TSDF_RAY_STEPS / _READS / _RAYS] := the ray statistics of the last raycast launch on this scene's scratch
  * (one short launch; measurement only -- bench.py prices the raycaster's ray term with them) */
 GPS_API int gps_tsdf_ray_stats(const gps_tsdf_state *s, gps_stream stream);
+/* The per-wave rows behind those sums, copied to rows_out[capacity_rows][4] (host or device memory, stream-ordered): {castRay steps,
+ * loop trips (voxel reads), rays, the LONGEST ray of the wave in loop trips}, one row per wave (8 x 8 pixels) of the last raycast
+ * launch on the scene's scratch, workgroup-major (16 x 16 pixel patches row by row, 4 waves each).  Returns the rows copied (>= 0) or
+ * a negative error.  Measurement only (tools/raycast_wave_hist.py: is the launch as long as its longest rays?). */
+GPS_API int gps_tsdf_ray_wave_rows(const gps_tsdf_state *s, float *rows_out, int capacity_rows, gps_stream stream);
 
 /* ITMVisualisationEngine::FindVisibleBlocks for a free view (…_CUDA.tcu:77-92, buildCompleteVisibleList_device) */
 GPS_API int gps_tsdf_find_visible(const gps_tsdf_state *s, const float *M, gps_stream stream);

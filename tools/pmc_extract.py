@@ -36,6 +36,15 @@ def pmc_file_name(kernel):
     return "pmc_%s.json" % re.sub(r"[^A-Za-z0-9_]+", "_", kernel.split(" (")[0]).strip("_")
 
 
+def build_commit():
+    """the commit the profiled library was built from: `git rev-parse HEAD > .build_commit` before the gpurun call (the GPU box's
+    snapshot has no .git); "unknown" when the file is missing"""
+    try:
+        return open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")).read().strip()
+    except OSError:
+        return "unknown"
+
+
 def bench_line(log):
     for l in reversed(open(log).read().splitlines()):
         if l.startswith('{"metric"'):
@@ -101,7 +110,7 @@ def main():
                 continue
             w, _ = per_launch(seg["WRITE_SIZE"].get(loop, []), parts)
             fb, wb = f * 1024.0, (w or 0.0) * 1024.0   # rocprofv3 reports both in KiB
-            rec = {"kernel": kname, "loop": loop, "launches": n,
+            rec = {"kernel": kname, "loop": loop, "launches": n, "library_commit": build_commit(),
                    "command": "bench.py as tools/profile.sh runs it; counters of the roofline micro-benchmark loop `%s`" % loop,
                    # FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B on gfx950 (MI355X guide, HBM section): doubled
                    "fetch_bytes_raw": fb, "fetch_bytes_x2": 2 * fb, "write_bytes": wb, "hbm_bytes_per_launch": 2 * fb + wb,
