@@ -440,7 +440,8 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
         if "overlap" in results:
             flat["overlap_fps"] = world * K / results["overlap"]["seconds"]
         if extras:
-            out["config"].update(_describe_and_measure(args, scene, seq, results[main_sched], first, K, dt, marker))
+            out["config"].update(_describe_and_measure(args, scene, seq, dict(results[main_sched], in_loop_sequential=(results.get("sequential") or {}).get("in_loop")),
+                                                        first, K, dt, marker))
             out["roofline"] = out["config"].pop("roofline")
             flat["frame_frac"] = out["roofline"]["frame"]["frac"]
             flat["iteration_frac"] = out["roofline"]["iteration"]["frac"]
@@ -548,7 +549,7 @@ def compact_line(out):
     r = out.get("roofline")
     if r:
         keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us", "timed_in",
-                "launches_timed", "frac_alone", "avg_launch_us_alone", "measured_copy_GBs", "traffic_calibrated", "traffic_library_commit")
+                "launches_timed", "frac_alone", "avg_launch_us_alone", "frac_sequential", "avg_launch_us_sequential", "measured_copy_GBs", "traffic_calibrated", "traffic_library_commit")
         rr = {k: _sig(r[k]) for k in keep if k in r}
         rr["frame_frac"], rr["iteration_frac"] = _sig(r["frame"]["frac"]), _sig(r["iteration"]["frac"])
         rr["frame_ms"], rr["iteration_us"] = _sig(r["frame"]["ms"]), _sig(r["iteration"]["avg_us"])

@@ -169,6 +169,14 @@ def _with_survey_formula(row, survey_bytes, t, hbm_peak_gbs, note):
     return row
 
 
+def _sequential_in_loop(result, top, pre_bytes, hbm_peak_gbs):
+    k = (((result.get("in_loop_sequential") or {}).get("kernels")) or {}).get(top["kernel"])
+    if not k:
+        return {}
+    b = top["algorithmic_bytes"] + (k["launches_flagged"] / k["launches"] * pre_bytes if top["kernel"] == "preprocess_bwd_kernel" else 0.0)
+    return {"avg_launch_us_sequential": k["avg_us"], "frac_sequential": b / k["avg_us"] / 1e3 / hbm_peak_gbs}
+
+
 def measured_copy_bandwidth(device, nbytes=1 << 30, reps=10):
     """"record the measured copy bandwidth of the box" -- a device-to-device copy of 1 GiB (read + write counted),
     best of `reps`, HIP events on the current stream.  `roofline.peak` stays the nominal 8 TB/s; this is the box's own ceiling."""
@@ -408,6 +416,9 @@ def roofline_section(scene, seq, result, hbm_peak_gbs, K, gt_pose=False):
             "launches_timed": top.get("in_loop_launches"),
             "frac_alone": top["frac"], "avg_launch_us_alone": top["avg_us"],
             "in_loop_window_ms_per_step": (result.get("in_loop") or {}).get("window_ms_per_step"),
+            # the same kernel inside the SEQUENTIAL schedule (nothing runs beside it: the figure a rocprofv3 table of either schedule's
+            # in-loop window reproduces to a few percent; the overlap figure moves with how much of the other chain it meets)
+            **_sequential_in_loop(result, top, pre_bytes, hbm_peak_gbs),
             "measured_copy_GBs": copy_gbs,
             "measured_copy_note": "device-to-device copy of 1 GiB on this box, read + write bytes / best of 10 (SURVEY 8(d)); fractions use the nominal peak",
             "frac": top["in_loop_frac"] if in_loop else top["frac"], "traffic": top.get("traffic"),

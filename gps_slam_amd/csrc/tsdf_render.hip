@@ -309,8 +309,21 @@ __device__ __forceinline__ float read_sdf_interp(const TsdfState& s, float px, f
 // cell of the min/max image, so its 64 lanes fetch the cell's ED_GROUPS partial values (one each), reduce them with six
 // shuffles, lane 0 writes the cell where pass B would have (the image other readers and the tests see), and the first wave
 // publishes + clears the rendering-block counter: one launch and its ~8-10 us leave the frame chain.
+// Waves per SIMD the register allocation must leave room for.  Left alone the kernel takes 98 VGPRs = 4 waves per SIMD = 4,096 waves
+// on the chip, fewer than the 4,800 waves of a 640x480 launch: a second round for the last rows of the image.  5 -> 95 VGPRs, no
+// spill, the whole launch resident at once (6 spills 18 registers).  Measured (round 6): a batch of 7 free views 516 -> 489 us,
+// bench windows 1,042 / 1,369 -> 1,052 / 1,381 frames/s (2 + 2 runs: inside the noise, never below).  0 = no constraint.
+#ifndef GPS_RAYCAST_WAVES_PER_EU
+#define GPS_RAYCAST_WAVES_PER_EU 5
+#endif
+GPS_TUNABLE_REPORT(GPS_RAYCAST_WAVES_PER_EU, 5);
+#if GPS_RAYCAST_WAVES_PER_EU > 0
+#define GPS_RAYCAST_BOUNDS __launch_bounds__(256, GPS_RAYCAST_WAVES_PER_EU)
+#else
+#define GPS_RAYCAST_BOUNDS __launch_bounds__(256)
+#endif
 template <bool MODIFY_VISIBLE>
-__global__ __launch_bounds__(256) void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
+__global__ GPS_RAYCAST_BOUNDS void raycast_kernel(TsdfState s, Mat4 invM, const float2* __restrict__ minmax,
                                                      float4* __restrict__ rays, const uint32_t* __restrict__ bits,
                                                      const ViewRec* __restrict__ views, const uint2* __restrict__ partial, int sw,
                                                      int sh, float2* __restrict__ mm_out, gps::LaunchStamp stamp) {
