@@ -391,6 +391,7 @@ __global__ GPS_RAYCAST_BOUNDS void raycast_kernel(TsdfState s, Mat4 invM, const 
     BlockCache cache = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1};
     float sdfValue = 1.0f, confidence = 0.f, stepLength;
     int vmIndex = 0;
+    bool look = true;    // fetch the free-space candidates with the next uncached lookup (the last lookup failed / none yet)
     uint32_t n_log = 0;  // S-bar log, packed: trips of this loop (= voxel reads) in the low half, skipped candidates in the high half
     const uint64_t* vox = reinterpret_cast<const uint64_t*>(s.vba);
     while (totalLength < totalLengthMax) {
@@ -417,20 +418,28 @@ __global__ GPS_RAYCAST_BOUNDS void raycast_kernel(TsdfState s, Mat4 invM, const 
             // 122.2 / 141.1 us -- past ~7 the per-candidate index arithmetic (round, shift, hash: ~25 VALU ops) outweighs
             // the saved round trips (on a scene of 10 m free-space runs: 926 -> 673 us with ONE candidate, slower again
             // with more).
-            uint32_t word[SKIP], shift[SKIP];
-            float cx_ = px, cy_ = py, cz_ = pz;
+            // (round 6) ... and only for a lane whose LAST lookup failed (or that has not looked anything up yet): a ray marching
+            // through the truncation band enters its next block every few trips, finds it allocated nearly always, and has no use
+            // for the candidates -- but one such lane per trip made the whole wave issue their ~125 instructions.  The longest
+            // rays of a launch are such rays (tools/raycast_wave_hist.py), and a lone wave issues an instruction every ~5 cycles.
+            // Without the candidates a failed lookup advances by its own block edge only and the next trip looks ahead: the same
+            // positions, the same additions, one more trip at a band -> free-space transition.
+            if (look) {
+                uint32_t word[SKIP], shift[SKIP];
+                float cx_ = px, cy_ = py, cz_ = pz;
 #pragma unroll
-            for (int j = 0; j < SKIP; j++) {
-                cx_ += (float)BLK * rx; cy_ += (float)BLK * ry; cz_ += (float)BLK * rz;
-                const int h = hash_index(floor_div_blk((int)roundf_ref(cx_)), floor_div_blk((int)roundf_ref(cy_)),
-                                         floor_div_blk((int)roundf_ref(cz_)), s.n_buckets - 1);
-                word[j] = bits[h >> 5];
-                shift[j] = (uint32_t)h & 31u;
+                for (int j = 0; j < SKIP; j++) {
+                    cx_ += (float)BLK * rx; cy_ += (float)BLK * ry; cz_ += (float)BLK * rz;
+                    const int h = hash_index(floor_div_blk((int)roundf_ref(cx_)), floor_div_blk((int)roundf_ref(cy_)),
+                                             floor_div_blk((int)roundf_ref(cz_)), s.n_buckets - 1);
+                    word[j] = bits[h >> 5];
+                    shift[j] = (uint32_t)h & 31u;
+                }
+                pin(hraw0);
+                occupied = 1u;
+#pragma unroll
+                for (int j = 0; j < SKIP; j++) occupied |= ((word[j] >> shift[j]) & 1u) << (j + 1);
             }
-            pin(hraw0);
-            occupied = 1u;
-#pragma unroll
-            for (int j = 0; j < SKIP; j++) occupied |= ((word[j] >> shift[j]) & 1u) << (j + 1);
         }
         const HashEntry head0 = decode_entry(hraw0);
         int base;
@@ -457,6 +466,7 @@ __global__ GPS_RAYCAST_BOUNDS void raycast_kernel(TsdfState s, Mat4 invM, const 
         sdfValue = vox_sdf(raw) / 32767.0f;
         if (MODIFY_VISIBLE) { if (vmIndex) s.visible_type[vmIndex - 1] = 1; }  // incl. the vmIndex==1 cache-hit quirk
         n_log++;
+        look = !vmIndex;
         if (!vmIndex) {
             stepLength = BLK;
             // advance over the candidates that are certainly unallocated steps inside the range (empty bucket head); the
