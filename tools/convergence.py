@@ -41,13 +41,15 @@ def main():
                     "pipeline's own addGaussians, as in a run of the reference")
     ap.add_argument("--gt-pose", action="store_true")
     ap.add_argument("--oracle-every", type=int, default=5)
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_convergence"))
+    ap.add_argument("--detail", action="store_true", help="the detail workload of bench.detail_run: the room scaled to 0.4 (a pixel's footprint "
+                    "below the 5 mm voxel) with the `fine` texture (12 / 15 / 19 mm sine gratings, no hard steps)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_convergence"))
     args = ap.parse_args()
     dev = "cuda:0"
     torch.cuda.set_device(0)
     W, H, n = 640, 480, args.frames
     seed = 1234
-    seq = bench.synthetic_sequence_device(W, H, n, seed, dev)
+    seq = bench.synthetic_sequence_device(W, H, n, seed, dev, **(dict(texture="fine", world_scale=0.4) if args.detail else {}))
     seeds = bench.seed_gaussians(seq, 2000 if args.empty else args.gaussians, seed, dev)
     bench.prime(dev)
     scene = bench.Scene(seq, seeds, seed, args.gt_pose, overlap=False, n_frames=n, keyframe_theta=1.0, keyframe_trans=0.02)
@@ -136,6 +138,8 @@ def main():
     lo, hi = min(r + t), max(r + t)
     with open(args.out + ".md", "w") as f:
         f.write("# Render PSNR per keyframe update on held-out frames (tools/convergence.py, MI355X)\n\n")
+        if args.detail:
+            f.write("DETAIL WORKLOAD: the room scaled to 0.4 with the `fine` texture (bench.detail_run).\n\n")
         f.write("%d frames of the synthetic orbit (640x480), %s, tracking %s, sequential schedule; after every update the two frames of\n"
                 "the last period that are never optimise cameras are rendered from their tracked pose.\n\n"
                 % (n, "start from ~%d k seeded Gaussians" % (args.gaussians // 1000) if not args.empty else "start from 2,000 seeds "
