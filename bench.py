@@ -689,7 +689,7 @@ def detail_run(args, seed, device, n_frames=300, gt_pose=None):
     torch.cuda.synchronize()
     tm = sc.pipe.SLAMTrainCamsTimed(sc.model, sc.cams)
     last_kf = (n_frames - 1) // PERIOD * PERIOD
-    held = [k for p0 in range(max(PERIOD, last_kf - 3 * PERIOD), last_kf, PERIOD) for k in (p0 + 3, p0 + 7) if k < n_frames]
+    held = [k for p0 in range(max(PERIOD, last_kf - 2 * PERIOD), last_kf + 1, PERIOD) for k in (p0 + 3, p0 + 7) if k < n_frames]
     r_db, t_db = _held_out_psnr(sc, seq, device, held)
     out = {"frames": n_frames, "size": "%dx%d" % (W, H), "use_gt_pose": bool(gt_pose), "fps_sequential": tm.fps(), "gaussians_end": int(sc.model.getGaussianNum()),
            "held_out_frames": len(held), "render_psnr_db": r_db, "tsdf_colour_psnr_db": t_db, "gain_db": r_db - t_db,
