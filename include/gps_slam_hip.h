@@ -52,7 +52,9 @@ GPS_API const char *gps_build_flags(void);
  * release; _stop synchronises the device, reads the slots and sums per kind.  `flagged` = the subset with the kind's flag set
  * (PREPROCESS_BWD: the next iteration's preprocessing forward rode in the launch; RASTER_FWD: with the compose + L1 epilogue;
  * RAYCAST: a free view).  Results never depend on it; off by default and after _stop.  capacity = workgroup slots (16 bytes
- * each) a window can hold; launches that no longer fit run unstamped and are counted in *dropped.  No reference counterpart (the reference times stages on the host,
+ * each) a window can hold; launches that no longer fit run unstamped and are counted in *dropped.  _start is the one entry point
+ * of this library that allocates (the slot buffer, hipMalloc, kept for the next window) and, with _stop, that synchronises the
+ * device: measurement calls, outside any timed region.  No reference counterpart (the reference times stages on the host,
  * slam_pipeline.cpp:135-167). */
 #define GPS_TIMED_PREPROCESS_BWD 0
 #define GPS_TIMED_PREPROCESS_FWD 1
