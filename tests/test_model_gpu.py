@@ -396,3 +396,47 @@ def test_fused_binning_and_class_lists_survive_add_and_prune(W, H):
         else:                 # ... and put them back behind the rest
             model.add_params(removed)
             assert model.getGaussianNum() == N + removed["means"].shape[0]
+
+
+@pytest.mark.parametrize("case", ["no gaussians", "all behind the camera", "all outside the image"])
+def test_a_model_nothing_of_which_reaches_the_image_renders_the_base_colour(case):
+    """Edge cases of gesForward (raw_gs_model.cpp:188-367): with no Gaussian at all (the pipeline's state before the first
+    keyframe), with every Gaussian behind the camera (culled by the near plane: radius 0, no tile) or projected outside the
+    image (no tile), the tile lists are empty, the render is (0 + base) / (0 + 1) = the base colour EXACTLY, the weight sum 0,
+    the loss mean |gt - base|; a train step runs to the end, leaves every parameter finite and -- no gradient reaches anything --
+    only moves parameters by Adam's zero-gradient step (exactly nothing: m = v = 0)."""
+    from gps_slam_amd.gs_model import Camera, SLAMGaussianModel
+    W, H = 130, 70   # (ragged: 8.1 x 4.4 tiles)
+    c2w, K = scenes.default_camera(W, H, seed=9)
+    model = SLAMGaussianModel(dict(capacity=1 << 12), device=DEV)
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    if case != "no gaussians":
+        g = scenes.random_gaussians(500, seed=9, scale_range=(0.004, 0.03))
+        means = g["means"].copy()
+        if case == "all behind the camera":
+            means[:, 2] = -np.abs(means[:, 2]) - 1.0      # the camera sits near the origin and looks down +z
+        else:
+            means[:, 0] += 1.0e3                          # far off to the side: projected centre thousands of pixels outside
+        model.add_params(dict(means=T(means), scales=T(g["log_scales"]), quats=T(g["quats"]), featuresDc=T(g["sh"][:, 0].copy()),
+                              featuresRest=T(g["sh"][:, 1:].copy()), opacities=T(g["opac_logit"])))
+    gen = torch.Generator().manual_seed(9)
+    gt = torch.rand((H, W, 3), generator=gen).to(DEV)
+    base = torch.rand((H, W, 3), generator=gen).to(DEV)
+    ref = (torch.rand((H, W, 1), generator=gen) * 4).to(DEV)
+    cam = Camera(0, W, H, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), c2w, image=gt, device=DEV)
+    res = model.forward(cam, ref, base)
+    torch.cuda.synchronize()
+    assert torch.equal(res["rgb"], base), case
+    assert float(res["alpha"].abs().max()) == 0.0
+    if model.getGaussianNum() > 0:
+        assert int((res["radiis"] > 0).sum()) == 0
+        before = [t.clone() for t in model.opt_gs_params.tensors()]
+        model.initOptimizers(-1, 1.0)
+        model._step_struct(W, H)
+        model.loss_sum().zero_()
+        model.train_step(cam, ref, base, gt)
+        torch.cuda.synchronize()
+        want = float((gt - base).abs().double().mean())
+        assert abs(float(model.loss_sum()[0]) - want) <= 1e-5 * want
+        for a, b in zip(model.opt_gs_params.tensors(), before):
+            assert torch.isfinite(a).all() and torch.equal(a, b), case
