@@ -439,19 +439,32 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
             flat["sequential_fps"] = world * K / results["sequential"]["seconds"]
         if "overlap" in results:
             flat["overlap_fps"] = world * K / results["overlap"]["seconds"]
-        if extras:
+        def leg(name, fn):
+            """one measurement leg behind the timed windows: a failure there is reported in the line (`<name>_error`, traceback on
+            stderr) instead of costing the line -- and the other ranks their barrier"""
+            try:
+                fn()
+            except Exception as e:   # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                flat["%s_error" % name] = ("%s: %s" % (type(e).__name__, e))[:200]
+
+        def leg_roofline():
             out["config"].update(_describe_and_measure(args, scene, seq, dict(results[main_sched], in_loop_sequential=(results.get("sequential") or {}).get("in_loop")),
                                                         first, K, dt, marker))
             out["roofline"] = out["config"].pop("roofline")
             flat["frame_frac"] = out["roofline"]["frame"]["frac"]
             flat["iteration_frac"] = out["roofline"]["iteration"]["frac"]
             flat["iteration_us"] = out["roofline"]["iteration"]["avg_us"]
+
+        if extras:
+            leg("roofline", leg_roofline)
             if world == 1 and (not args.no_other_configs or args.whole_run_frames > 0):
                 scene.close()
                 scene = None
                 torch.cuda.empty_cache()
             # (the whole-sequence run first: it is the metric as the reference defines it)
-            if world == 1 and args.whole_run_frames > 0:
+            def leg_whole_run():
                 t_w = time.perf_counter()
                 wr = whole_run(args, seed, device, args.whole_run_frames)
                 wr["seconds_total"] = time.perf_counter() - t_w
@@ -463,7 +476,8 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                             whole_run_gaussian_fps_sequential=wr["sequential"]["gaussian_fps"],
                             whole_run_slowest_frame_ms=wr["overlap"]["slowest_frame_ms_after_30"], whole_run_gpu_memory_mb=wr["overlap"]["gpu_memory_mb"],
                             whole_run_seconds_total=wr["seconds_total"])
-            if world == 1 and args.whole_run_frames > 0 and not args.no_workloads:
+
+            def leg_workloads():
                 t_w = time.perf_counter()
                 dr = detail_run(args, seed, device)
                 # (every shipped config sets use_gt_pose: true; the headline run tracks -- both pose sources on the same sequence)
@@ -475,7 +489,8 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                             **{"whole_run_gain_db_%s" % ("gt_pose" if dg["use_gt_pose"] else "tracked"): dg["gain_db"]},
                             whole_run_fps_ref_thresholds=rr["overlap"]["fps"], whole_run_fps_ref_thresholds_sequential=rr["sequential"]["fps"],
                             workloads_seconds=time.perf_counter() - t_w)
-            if world == 1 and not args.no_other_configs:
+
+            def leg_other_configs():
                 oc = other_configs(args, seq, seed, device, first)
                 out["config"]["other_configs"] = oc
                 flat.update(cfg0_fps=oc["configs0_tsdf_only_gt_pose"]["frames_per_s"],
@@ -489,9 +504,19 @@ def main(argv=None, scene_factory=None, backend="nccl", need_gpu=True, extras=Tr
                             cfgR_fps_sequential=oc["configsR_replica_1200x680_300k"]["schedules"]["sequential"]["frames_per_s"],
                             cfgR_gaussians=oc["configsR_replica_1200x680_300k"]["schedules"]["overlap"]["gaussians"],
                             other_configs_seconds=oc["seconds"])
-            if not args.no_cpu_baseline and world == 1:
+
+            def leg_cpu_baseline():
                 from bench_kernels import cpu_baseline
                 out["cpu_baseline"] = cpu_baseline(seq, W, H)
+
+            if world == 1 and args.whole_run_frames > 0:
+                leg("whole_run", leg_whole_run)
+            if world == 1 and args.whole_run_frames > 0 and not args.no_workloads:
+                leg("workloads", leg_workloads)
+            if world == 1 and not args.no_other_configs:
+                leg("other_configs", leg_other_configs)
+            if not args.no_cpu_baseline and world == 1:
+                leg("cpu_baseline", leg_cpu_baseline)
         # flat scalars FIRST in `config`: the driver's record keeps scalar fields only -- every number that matters beside `value`
         # (the reference's own whole-run FPS, the sequential schedule, the other single-GPU configurations, the keyframe
         # thresholds, the frame / iteration HBM fractions, which A/B switches were set) is one of them
@@ -538,7 +563,7 @@ def compact_line(out):
     cfg = out.get("config", {})
     c = {"workload": cfg.get("workload", "synthetic RGB-D SLAM frames, independent scene per GPU")}
     for k, v in cfg.items():
-        if k != "workload" and isinstance(v, (int, float, bool)) or (isinstance(v, str) and k in ("schedule", "host", "env_overrides", "placement")):
+        if k != "workload" and isinstance(v, (int, float, bool)) or (isinstance(v, str) and (k in ("schedule", "host", "env_overrides", "placement") or k.endswith("_error"))):
             c[k] = _sig(v)
     q = cfg.get("quality") or {}
     for k in ("render_psnr_db_vs_input", "tsdf_colour_psnr_db_vs_input", "render_psnr_db_vs_oracle"):
