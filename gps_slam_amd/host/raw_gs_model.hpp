@@ -66,7 +66,12 @@ public:
     int getGaussianNum() { return opt_gs_params.getGaussianNum(); }
     std::string getRenderMethod() const { return render_method; }
     std::vector<torch::Tensor> grads();  // gradients of the last iteration, reference parameter order
-    // Adam state as [:N] views: {exp_avg x 6, exp_avg_sq x 6} in reference parameter order (empty before initOptimizers)
+    // Adam state as [:N] views: {exp_avg x 6, exp_avg_sq x 6} in reference parameter order (empty before initOptimizers).
+    // UNDEFINED between initOptimizers() and the first step: initOptimizers does not zero the buffers -- step 1 of every route
+    // (gps_splat_train_step in all three fuse modes, gps_adam_step) takes m = v = 0 without reading them and writes every live row
+    // (tests: test_first_step_after_init_optimizers_does_not_read_the_moments, test_adam_step_one_writes_the_moments_without_
+    // reading_them, tests/test_adam_libtorch_gpu.py with NaN-filled buffers).  A caller that steps only SOME tensors at step 1, or
+    // starts an optimiser at adam_step != 1, must zero them itself.
     std::vector<torch::Tensor> adamState() {
         std::vector<torch::Tensor> out;
         if (!have_opt_) return out;
