@@ -147,3 +147,47 @@ def test_gaussian_ply_of_both_hosts_is_the_golden_file_byte_for_byte(tmp_path):
     back = read_gaussian_ply(str(tmp_path / "c.ply"))
     for k in t:
         assert np.array_equal(back[k].reshape(t[k].shape), t[k]), k
+
+
+def test_adam_scalars_of_both_hosts_are_the_reference_optimisers():
+    """The doubles libtorch's torch::optim::Adam runs with when it is constructed the way RawGaussianModel::initOptimizers
+    constructs it (src/raw_gs_model.cpp:661-671: eps, betas and rates pass through float variables) -- read back from the
+    library itself (oracle/libtorch_adam.cpp) -- are what the Python host hands to the kernels, and the C++ host's source carries
+    the same literals; three steps of the library on the CPU agree with a float32 restatement that uses them (and NOT with one
+    that uses 0.9 / 0.999 / 1e-15, which rounds 1-5 passed: the second moment differs by 1.3e-5 relative)."""
+    import numpy as np
+    import torch
+    from gps_slam_amd import gs_model
+    from oracle import libtorch_adam_build
+    mod = libtorch_adam_build.load()
+    eps, b1, b2 = mod.RefAdam.scalars()
+    assert (b1, b2, eps) == (0.8999999761581421, 0.9990000128746033, 1.0000000036274937e-15)
+    assert (gs_model.ADAM_BETA1, gs_model.ADAM_BETA2, gs_model.ADAM_EPS) == (b1, b2, eps)
+    src = open(os.path.join(ROOT, "gps_slam_amd", "host", "raw_gs_model.cpp")).read()
+    assert "kAdamBeta1 = (double)0.9f" in src and "kAdamBeta2 = (double)0.999f" in src and "kAdamEps = (double)1e-15f" in src
+    gen = torch.Generator().manual_seed(0)
+    p0 = torch.randn((4096, 3), generator=gen)
+    lr = float(np.float32(5e-3))
+    ref = mod.RefAdam([p0], [lr])
+    f = np.float32
+
+    def restated(beta1, beta2, eps_):
+        p, m, v = p0.numpy().copy(), np.zeros((4096, 3), f), np.zeros((4096, 3), f)
+        g_ = torch.Generator().manual_seed(1)
+        for step in (1, 2, 3):
+            g = (torch.randn((4096, 3), generator=g_) * 1e-3).numpy()
+            m = (m * f(beta1) + g * f(1.0 - beta1)).astype(f)
+            v = (v * f(beta2) + (g * g).astype(f) * f(1.0 - beta2)).astype(f)
+            denom = (np.sqrt(v) / f(np.sqrt(1.0 - beta2 ** step)) + f(eps_)).astype(f)
+            p = (p - f(lr / (1.0 - beta1 ** step)) * (m / denom).astype(f)).astype(f)
+        return p, v
+    g_ = torch.Generator().manual_seed(1)
+    for step in (1, 2, 3):
+        ref.step([torch.randn((4096, 3), generator=g_) * 1e-3])
+    v_lib = ref.exp_avg_sq()[0].numpy()
+    p_new, v_new = restated(b1, b2, eps)
+    p_old, v_old = restated(0.9, 0.999, 1e-15)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(v_new, v_lib) < 5e-7, rel(v_new, v_lib)            # a few float32 ulps (CPU ATen fuses differently)
+    assert rel(v_old, v_lib) > 5e-6, rel(v_old, v_lib)            # the 1.3e-5 of (1 - 0.999) vs (1 - 0.999f)
+    assert float(np.abs(p_new - ref.parameters()[0].numpy()).max()) < 1e-6
